@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI in include/tfc_hip.h (libtfc_hip.so).
+
+There is no CPU fallback: if the library is missing this module raises on
+import of the symbol table, and every op raises if no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtfc_hip.so")
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+
+# name -> (restype, argtypes); must list every symbol include/tfc_hip.h declares.
+SIGNATURES = {
+    "tfc_abi_version": (_int, []),
+    "tfc_last_error": (C.c_char_p, []),
+    "tfc_tables_create": (_int, [_vp, _int, _i64, _i64, _vp, C.POINTER(_vp)]),
+    "tfc_tables_count": (_i64, [_vp]),
+    "tfc_tables_destroy": (None, [_vp]),
+    "tfc_encoder_create": (_int, [_vp, _i64, _vp, C.POINTER(_vp)]),
+    "tfc_encoder_encode": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "tfc_encoder_encode_quantized": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
+    "tfc_encoder_encode_quantized_indexed": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _vp]),
+    "tfc_encoder_finalize": (_int, [_vp, _vp, C.POINTER(_i64)]),
+    "tfc_encoder_result": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "tfc_encoder_read": (_int, [_vp, _vp, _vp, _int, _vp]),
+    "tfc_encoder_destroy": (None, [_vp]),
+    "tfc_decoder_create": (_int, [_vp, _vp, _vp, _i64, _int, _vp, C.POINTER(_vp)]),
+    "tfc_decoder_decode": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "tfc_decoder_decode_dequantized": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
+    "tfc_decoder_finalize": (_int, [_vp, _vp, _vp]),
+    "tfc_decoder_destroy": (None, [_vp]),
+    "tfc_range_encode": (_int, [_vp, _vp, _int, _vp, _vp, _int, _int, _int, _vp,
+                                C.POINTER(_vp), C.POINTER(_i64)]),
+    "tfc_range_decode": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    "tfc_free": (None, [_vp]),
+    "tfc_pmf_to_quantized_cdf": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
+    "tfc_gdn_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "tfc_gdn_backward": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _int, _int, _int,
+                                _int, _vp, _vp, _vp]),
+    "tfc_conv2d_down": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int,
+                               _int, _int, _vp]),
+    "tfc_conv2d_up": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int,
+                             _int, _int, _vp]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libtfc_hip.so once; raises HipLibraryMissing if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return lib().tfc_last_error().decode()
+
+
+def check(rc: int) -> None:
+    """Maps a non-zero status to the exception type the reference ops raise
+    (tf.errors.InvalidArgumentError is a ValueError-like; we use ValueError)."""
+    if rc:
+        raise ValueError(last_error())
+
+
+def require_device():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "compression_amd needs a HIP device (MI355X): torch.cuda.is_available() is False "
+            "and there is no CPU fallback for the HIP kernels.")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,54 @@
+// Shared host-side helpers for the gfx950 C-ABI library (libtfc_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace tfc {
+
+std::string& last_error();
+int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define TFC_HIP(expr)                                                              \
+  do {                                                                             \
+    hipError_t e__ = (expr);                                                       \
+    if (e__ != hipSuccess)                                                         \
+      return ::tfc::fail("HIP error %s at %s:%d (%s)", hipGetErrorString(e__),     \
+                         __FILE__, __LINE__, #expr);                               \
+  } while (0)
+
+// Stream-ordered device buffer.  Freed on the stream it was allocated on.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipStream_t st = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), st(o.st) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; st = o.st; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  hipError_t alloc(size_t n, hipStream_t s) {
+    release();
+    st = s;
+    bytes = n;
+    if (n == 0) n = 16;
+    return hipMallocAsync(&p, n, s);
+  }
+  void release() {
+    if (p) (void)hipFreeAsync(p, st);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace tfc

@@ -1,0 +1,1481 @@
+// Multi-stream range coder for gfx950 (MI355X): one 64-lane wavefront per code
+// stream.
+//
+// What runs where
+//   * The arithmetic of one stream is a strict chain (every interval update
+//     needs the previous span), so parallelism = number of streams.  Each
+//     stream gets a whole wave; the wave's 64 lanes do everything that is NOT
+//     on the chain in parallel — coalesced symbol loads, CDF gathers from the
+//     LDS-resident table, escape detection, the decoder's CDF search
+//     (64 candidate symbols per compare + ballot), byte-window refills and
+//     coalesced output stores — while the chain itself runs on wave-uniform
+//     values that hipcc keeps in scalar registers.
+//   * Output is append-only 16-bit digits (the delayed-carry scheme never
+//     rewrites emitted bytes), collected 64 at a time in one VGPR via
+//     v_writelane and flushed as one coalesced 128-byte store.
+//
+// Behaviour follows (bit-exact, checked by tests/ against oracle/):
+//   cc/lib/range_coder.cc:37-307, cc/lib/range_coder.h:79-282,
+//   cc/kernels/range_coder_kernels.cc:101-471.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tfc_hip.h"
+#include "common.h"
+#include "range_coder_device.h"
+
+namespace tfc {
+
+std::string& last_error() {
+  static thread_local std::string e;
+  return e;
+}
+
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return 1;
+}
+
+}  // namespace tfc
+
+using namespace tfc;
+
+// ===========================================================================
+// Tables
+// ===========================================================================
+
+struct tfc_tables {
+  std::vector<int32_t> host;       // raw lookup
+  std::vector<int2> rows;          // (start of header, ints incl. header)
+  DevBuf d_data, d_rows;
+  int max_abs_prec = 0;
+  bool any_escape = false;
+  int64_t max_row = 0;
+};
+
+namespace {
+
+int scan_row(const std::vector<int32_t>& v, int64_t end, int64_t* cur, std::vector<int2>* rows) {
+  int64_t p = *cur;
+  if (end < p + 3) return fail("CDF ended prematurely.");
+  const int64_t head = p;
+  const int64_t ap = std::llabs(static_cast<long long>(v[head]));
+  if (ap < 1 || ap >= 17)
+    return fail("precision=%lld not in range [1, 17)", static_cast<long long>(ap));
+  const int32_t last = 1 << ap;
+  ++p;
+  if (v[p] != 0) return fail("CDF must start with 0.");
+  do {
+    ++p;
+    if (p == end) return fail("CDF must end with 1 << precision.");
+    if (v[p] < v[p - 1]) return fail("CDF must be monotonically increasing.");
+  } while (v[p] != last);
+  ++p;
+  rows->push_back(make_int2(static_cast<int>(head), static_cast<int>(p - head)));
+  while (p != end && v[p] == last) ++p;
+  *cur = p;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tfc_abi_version(void) { return 1; }
+extern "C" const char* tfc_last_error(void) { return last_error().c_str(); }
+extern "C" void tfc_free(void* p) { std::free(p); }
+
+extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, int64_t cols,
+                                 void* stream, tfc_tables** out) {
+  *out = nullptr;
+  if (rank != 1 && rank != 2) return fail("`lookup` must be rank 1 or 2: rank=%d", rank);
+  const int64_t total = rank == 1 ? cols : rows * cols;
+  if (total >= (int64_t{1} << 31)) return fail("`lookup` too large");
+  std::unique_ptr<tfc_tables> t(new tfc_tables);
+  t->host.assign(lookup, lookup + total);
+  if (rank == 1) {
+    for (int64_t cur = 0; cur != total;)
+      if (scan_row(t->host, total, &cur, &t->rows)) return 1;
+  } else {
+    for (int64_t cur = 0; cur != total;) {
+      const int64_t row_end = cur + cols;
+      if (scan_row(t->host, row_end, &cur, &t->rows)) return 1;
+      if (cur != row_end) return fail("CDF must end with 1 << precision.");
+    }
+  }
+  for (const int2& r : t->rows) {
+    const int32_t sp = t->host[r.x];
+    t->max_abs_prec = std::max(t->max_abs_prec, std::abs(sp));
+    t->any_escape |= sp < 0;
+    t->max_row = std::max<int64_t>(t->max_row, r.y);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TFC_HIP(t->d_data.alloc(sizeof(int32_t) * std::max<int64_t>(total, 1), st));
+  TFC_HIP(t->d_rows.alloc(sizeof(int2) * std::max<size_t>(t->rows.size(), 1), st));
+  if (total)
+    TFC_HIP(hipMemcpyAsync(t->d_data.p, t->host.data(), sizeof(int32_t) * total,
+                           hipMemcpyHostToDevice, st));
+  if (!t->rows.empty())
+    TFC_HIP(hipMemcpyAsync(t->d_rows.p, t->rows.data(), sizeof(int2) * t->rows.size(),
+                           hipMemcpyHostToDevice, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  *out = t.release();
+  return 0;
+}
+
+extern "C" int64_t tfc_tables_count(const tfc_tables* t) { return static_cast<int64_t>(t->rows.size()); }
+extern "C" void tfc_tables_destroy(tfc_tables* t) { delete t; }
+
+// ===========================================================================
+// Kernels
+// ===========================================================================
+
+namespace tfc {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWavesPerBlock * 64;
+// Tables up to this many bytes are staged in LDS (160 KiB per CU on gfx950).
+constexpr size_t kLdsTableBytes = 144 * 1024;
+
+struct TableView {
+  const int32_t* data;
+  const int2* rows;
+  int ntab;
+  int total;
+};
+
+// Where symbols come from (encode) / go to (decode).
+struct SymInt32 {          // plain int32 symbols
+  const int32_t* value;
+  __device__ int32_t load(int64_t pos, int /*table*/) const { return value[pos]; }
+};
+
+template <typename T>
+__device__ inline float to_float(T v);
+template <> __device__ inline float to_float<float>(float v) { return v; }
+template <> __device__ inline float to_float<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <> __device__ inline float to_float<__half>(__half v) { return __half2float(v); }
+template <typename T>
+__device__ inline T from_float(float v);
+template <> __device__ inline float from_float<float>(float v) { return v; }
+template <> __device__ inline __hip_bfloat16 from_float<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+template <> __device__ inline __half from_float<__half>(float v) { return __float2half(v); }
+
+// Fused quantisation: sym = int32(rint(y - qoff[t])) - cdf_offset[t].  The
+// subtraction happens in the bottleneck dtype like the reference's
+// `bottleneck -= offset` (continuous_batched.py:375-378); rintf is
+// round-half-to-even like tf.round.
+template <typename T>
+struct SymQuant {
+  const T* y;
+  const float* qoffset;        // may be null
+  const int32_t* cdf_offset;
+  __device__ int32_t load(int64_t pos, int table) const {
+    float f = to_float<T>(y[pos]);
+    if (qoffset) f = to_float<T>(from_float<T>(f - to_float<T>(from_float<T>(qoffset[table]))));
+    return static_cast<int32_t>(rintf(f)) - cdf_offset[table];
+  }
+};
+
+struct EncParams {
+  TableView tab;
+  const int32_t* index;     // null => channel mode
+  int64_t streams;
+  int64_t elems;
+  // outputs of the counting pass / inputs of the coding pass
+  unsigned long long* calls;        // [streams]
+  unsigned long long* first_error;  // [1], linear position of the first range error
+  // coding pass
+  uint4* state;                     // [streams] base, span_m1, pend_digit, pend_bytes
+  uint8_t* chunk;
+  const long long* chunk_off;       // [streams + 1]
+  unsigned int* chunk_len;          // [streams]
+  unsigned int* overflow_flag;      // [1]
+};
+
+// Per-element classification shared by the counting and the coding pass.
+struct Call {
+  int32_t lo16, hi16;   // interval scaled to 16-bit precision
+  int32_t gamma;        // > 0 => escape follows
+  int32_t neg;
+  int32_t bad;          // 1: index out of range, 2: value out of range
+};
+
+template <typename TabFn>
+__device__ inline Call classify(const TabFn& T, const int2 row, int32_t v) {
+  Call c;
+  c.gamma = 0;
+  c.neg = 0;
+  c.bad = 0;
+  const int32_t sp = T(row.x);
+  const int32_t prec = sp < 0 ? -sp : sp;
+  int32_t sym = v;
+  if (sp > 0) {
+    if (v < 0 || v >= row.y - 2) {
+      c.bad = 2;
+      sym = 0;
+    }
+  } else {
+    const int32_t vmax = row.y - 3;
+    if (v < 0) {
+      c.neg = 1;
+      c.gamma = -v;
+      sym = vmax;
+    } else if (v >= vmax) {
+      c.gamma = v - vmax + 1;
+      sym = vmax;
+    }
+  }
+  const int sh = 16 - prec;
+  c.lo16 = T(row.x + 1 + sym) << sh;
+  c.hi16 = T(row.x + 2 + sym) << sh;
+  return c;
+}
+
+__device__ inline int escape_calls(int32_t gamma) {
+  // 1 + 2*floor(log2 gamma) bits for the Elias-gamma code, plus one sign bit
+  // (range_coder_kernels.cc:304-321).
+  const int nb = 31 - __clz(gamma);
+  return 2 * nb + 2;
+}
+
+// Counting + validation pass: fully parallel, one thread per element.
+template <typename Src>
+__global__ void __launch_bounds__(256) enc_count_kernel(EncParams p, Src src) {
+  const int64_t tiles = (p.elems + 255) / 256;
+  const int64_t s = blockIdx.x / tiles;
+  const int64_t j = (blockIdx.x % tiles) * 256 + threadIdx.x;
+  unsigned int calls = 0;
+  if (j < p.elems) {
+    const int64_t pos = s * p.elems + j;
+    int t;
+    bool bad_index = false;
+    if (p.index) {
+      t = p.index[pos];
+      if (t < 0 || t >= p.tab.ntab) { bad_index = true; t = 0; }
+    } else {
+      t = static_cast<int>(j % p.tab.ntab);
+    }
+    const int2 row = p.tab.rows[t];
+    auto T = [&](int i) { return p.tab.data[i]; };
+    const Call c = classify(T, row, src.load(pos, t));
+    if (bad_index || c.bad) atomicMin(p.first_error, static_cast<unsigned long long>(pos));
+    calls = 1 + (c.gamma > 0 ? escape_calls(c.gamma) : 0);
+  }
+  // block reduce (4 waves)
+  for (int off = 32; off > 0; off >>= 1) calls += __shfl_down(calls, off, 64);
+  __shared__ unsigned int part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = calls;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int tot = part[0] + part[1] + part[2] + part[3];
+    atomicAdd(&p.calls[s], static_cast<unsigned long long>(tot));
+  }
+}
+
+// calls[s] -> byte capacity 2*calls + 4 rounded to 16, exclusive scan -> off.
+__global__ void enc_offsets_kernel(const unsigned long long* calls, int64_t streams,
+                                   long long* off, unsigned long long* total) {
+  // single block; streams is usually 1e2..1e5
+  __shared__ long long carry;
+  __shared__ long long tmp[1024];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < streams; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    long long cap = 0;
+    if (i < streams) cap = ((2 * static_cast<long long>(calls[i]) + 4 + 15) / 16) * 16;
+    tmp[threadIdx.x] = cap;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      long long v = threadIdx.x >= d ? tmp[threadIdx.x - d] : 0;
+      __syncthreads();
+      tmp[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (i < streams) off[i] = carry + tmp[threadIdx.x] - cap;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += tmp[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    off[streams] = carry;
+    *total = static_cast<unsigned long long>(carry);
+  }
+}
+
+// 16-bit digit collector: 64 digits per VGPR, one coalesced store per flush.
+struct DigitSink {
+  uint8_t* dst;        // 2-byte aligned
+  unsigned int nbytes; // bytes already stored
+  unsigned int cap;
+  int n;               // digits waiting in reg
+  int reg;
+  unsigned int overflow;
+};
+
+__device__ inline void sink_flush(DigitSink& o, int lane) {
+  if (o.nbytes + 2u * o.n > o.cap) {
+    o.overflow = 1;
+  } else if (lane < o.n) {
+    const unsigned int d = static_cast<unsigned int>(o.reg);
+    const unsigned short be = static_cast<unsigned short>(((d & 0xFF) << 8) | ((d >> 8) & 0xFF));
+    reinterpret_cast<unsigned short*>(o.dst + o.nbytes)[lane] = be;
+  }
+  o.nbytes += 2u * o.n;
+  o.n = 0;
+}
+
+__device__ inline void sink_put(DigitSink& o, unsigned int digit, int lane) {
+  o.reg = tfc_writelane(static_cast<int>(digit), o.n, o.reg);
+  ++o.n;
+  if (o.n == 64) sink_flush(o, lane);
+}
+
+// One interval update on wave-uniform state; [lo16, hi16) / 2^16.
+__device__ inline void enc_update(EncoderState& st, unsigned int lo16, unsigned int hi16,
+                                  DigitSink& o, int lane) {
+  const unsigned long long span = static_cast<unsigned long long>(st.span_m1) + 1;
+  const unsigned int a = static_cast<unsigned int>((span * lo16) >> 16);
+  const unsigned int b = static_cast<unsigned int>(((span * hi16) >> 16) - 1);
+  st.base += a;
+  st.span_m1 = b - a;
+  const bool wrapped = st.base < a;
+  if (static_cast<unsigned int>(st.base + st.span_m1) < st.base) {
+    if ((st.span_m1 >> 16) == 0) {
+      st.base <<= 16;
+      st.span_m1 = (st.span_m1 << 16) | 0xFFFFu;
+      st.pend_bytes += 2;
+    }
+    return;
+  }
+  if (st.pend_digit != 0) {
+    unsigned int d = st.pend_digit;
+    unsigned int fill = 0;
+    if (!wrapped) {
+      d -= 1;
+      fill = 0xFFFFu;
+    }
+    sink_put(o, d, lane);
+    for (unsigned int k = 0; k < st.pend_bytes; k += 2) sink_put(o, fill, lane);
+    st.pend_digit = 0;
+    st.pend_bytes = 0;
+  }
+  if ((st.span_m1 >> 16) == 0) {
+    const unsigned int top = st.base >> 16;
+    st.base <<= 16;
+    st.span_m1 = (st.span_m1 << 16) | 0xFFFFu;
+    if (st.base <= static_cast<unsigned int>(st.base + st.span_m1)) {
+      sink_put(o, top, lane);
+    } else {
+      st.pend_digit = top + 1;
+    }
+  }
+}
+
+template <bool LDS_TAB, typename Src>
+__global__ void __launch_bounds__(kBlock) enc_kernel(EncParams p, Src src) {
+  extern __shared__ int32_t lds_tab[];
+  if (LDS_TAB) {
+    for (int i = threadIdx.x; i < p.tab.total; i += kBlock) lds_tab[i] = p.tab.data[i];
+    __syncthreads();
+  }
+  auto T = [&](int i) -> int32_t { return LDS_TAB ? lds_tab[i] : p.tab.data[i]; };
+
+  const int lane = threadIdx.x & 63;
+  const int64_t s = __builtin_amdgcn_readfirstlane(
+      static_cast<int>(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
+  if (s >= p.streams) return;
+
+  const uint4 st0 = p.state[s];
+  EncoderState st;
+  st.base = __builtin_amdgcn_readfirstlane(st0.x);
+  st.span_m1 = __builtin_amdgcn_readfirstlane(st0.y);
+  st.pend_digit = __builtin_amdgcn_readfirstlane(st0.z);
+  st.pend_bytes = __builtin_amdgcn_readfirstlane(st0.w);
+
+  DigitSink o;
+  const long long off0 = p.chunk_off[s];
+  o.dst = p.chunk + off0;
+  o.cap = static_cast<unsigned int>(p.chunk_off[s + 1] - off0);
+  o.nbytes = 0;
+  o.n = 0;
+  o.reg = 0;
+  o.overflow = 0;
+
+  for (int64_t j0 = 0; j0 < p.elems; j0 += 64) {
+    // ---- vector phase: 64 symbols at once --------------------------------
+    const int64_t j = j0 + lane;
+    Call c;
+    c.lo16 = 0; c.hi16 = 0; c.gamma = 0; c.neg = 0; c.bad = 0;
+    if (j < p.elems) {
+      const int64_t pos = s * p.elems + j;
+      int t = p.index ? p.index[pos] : static_cast<int>(j % p.tab.ntab);
+      t = min(max(t, 0), p.tab.ntab - 1);  // range errors were reported by the counting pass
+      const int2 row = p.tab.rows[t];
+      c = classify(T, row, src.load(pos, t));
+    }
+    const unsigned long long esc_mask = __ballot(c.gamma > 0);
+    const int cnt = static_cast<int>(min<int64_t>(64, p.elems - j0));
+    // ---- serial phase: the chain -----------------------------------------
+    for (int n = 0; n < cnt; ++n) {
+      const unsigned int lo = __builtin_amdgcn_readlane(c.lo16, n);
+      const unsigned int hi = __builtin_amdgcn_readlane(c.hi16, n);
+      enc_update(st, lo, hi, o, lane);
+      if ((esc_mask >> n) & 1) {
+        const int g = __builtin_amdgcn_readlane(c.gamma, n);
+        const int neg = __builtin_amdgcn_readlane(c.neg, n);
+        int nb = 31 - __clz(g);             // floor(log2 g)
+        for (int k = 0; k < nb; ++k) enc_update(st, 0, 0x8000u, o, lane);   // zeros
+        for (int k = nb; k >= 0; --k) {
+          const unsigned int bit = (g >> k) & 1;
+          enc_update(st, bit << 15, (bit + 1) << 15, o, lane);
+        }
+        enc_update(st, static_cast<unsigned int>(neg) << 15,
+                   static_cast<unsigned int>(neg + 1) << 15, o, lane);
+      }
+    }
+  }
+  sink_flush(o, lane);
+  if (lane == 0) {
+    p.state[s] = make_uint4(st.base, st.span_m1, st.pend_digit, st.pend_bytes);
+    p.chunk_len[s] = o.nbytes;
+    if (o.overflow) atomicOr(p.overflow_flag, 1u);
+  }
+}
+
+// ---- finalize -------------------------------------------------------------
+
+struct ChunkRef {
+  const uint8_t* data;
+  const long long* off;
+  const unsigned int* len;
+};
+
+// tail bytes per RangeEncoder::Finalize (range_coder.cc:266-307); one thread
+// per stream.  Also sums the stream's total length.
+__global__ void enc_tail_kernel(const uint4* state, int64_t streams, const ChunkRef* chunks,
+                                int nchunks, uint8_t* tail, long long* length) {
+  const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (s >= streams) return;
+  const uint4 st = state[s];
+  uint8_t t0 = 0, t1 = 0;
+  int nt = 0;
+  if (st.z != 0) {
+    t0 = (st.z >> 8) & 0xFF;
+    nt = 1;
+    if ((st.z & 0xFF) != 0) { t1 = st.z & 0xFF; nt = 2; }
+  } else if (st.x != 0) {
+    const unsigned int top = st.x + st.y;
+    const unsigned int r24 = ((st.x - 1) >> 24) + 1;
+    if (r24 <= (top >> 24)) {
+      t0 = r24 & 0xFF;
+      nt = 1;
+    } else {
+      const unsigned int r16 = ((st.x - 1) >> 16) + 1;
+      t0 = (r16 >> 8) & 0xFF;
+      nt = 1;
+      if ((r16 & 0xFF) != 0) { t1 = r16 & 0xFF; nt = 2; }
+    }
+  }
+  tail[2 * s] = t0;
+  tail[2 * s + 1] = t1;
+  long long len = nt;
+  for (int c = 0; c < nchunks; ++c) len += chunks[c].len[s];
+  length[s] = len;
+}
+
+__global__ void scan_lengths_kernel(const long long* length, int64_t streams, long long* off) {
+  __shared__ long long carry;
+  __shared__ long long tmp[1024];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < streams; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const long long v0 = i < streams ? length[i] : 0;
+    tmp[threadIdx.x] = v0;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      long long v = threadIdx.x >= d ? tmp[threadIdx.x - d] : 0;
+      __syncthreads();
+      tmp[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (i < streams) off[i] = carry + tmp[threadIdx.x] - v0;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += tmp[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[streams] = carry;
+}
+
+// One wave per stream: copy the stream's chunk pieces then its tail.
+__global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const ChunkRef* chunks,
+                                                         int nchunks, const uint8_t* tail,
+                                                         const long long* off, uint8_t* blob) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (s >= streams) return;
+  uint8_t* dst = blob + off[s];
+  const long long total = off[s + 1] - off[s];
+  long long done = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const uint8_t* src = chunks[c].data + chunks[c].off[s];
+    const unsigned int n = chunks[c].len[s];
+    for (unsigned int i = lane; i < n; i += 64) dst[done + i] = src[i];
+    done += n;
+  }
+  const long long nt = total - done;
+  if (lane < nt) dst[done + lane] = tail[2 * s + lane];
+}
+
+// ---- decoder --------------------------------------------------------------
+
+struct DecParams {
+  TableView tab;
+  const int32_t* index;
+  int64_t streams;
+  int64_t elems;
+  const uint8_t* blob;
+  const long long* off;            // [streams + 1]
+  uint4* state;                    // base, span_m1, window, pulls
+  unsigned long long* first_error; // index range error
+};
+
+// 64 upcoming big-endian digits of the stream, one per lane.
+struct DigitWindow {
+  const uint8_t* src;
+  long long len;        // stream length in bytes
+  unsigned int pulls;   // digits consumed so far (including the two of the ctor)
+  unsigned int base;    // digit index held by lane 0
+  int reg;
+};
+
+__device__ inline void window_load(DigitWindow& w, int lane) {
+  const long long b = 2ll * (static_cast<long long>(w.base) + lane);
+  unsigned int hi = b < w.len ? w.src[b] : 0u;
+  unsigned int lo = b + 1 < w.len ? w.src[b + 1] : 0u;
+  w.reg = static_cast<int>((hi << 8) | lo);
+}
+
+__device__ inline unsigned int window_pull(DigitWindow& w, int lane) {
+  if (w.pulls - w.base >= 64u) {
+    w.base = w.pulls;
+    window_load(w, lane);
+  }
+  const unsigned int d = __builtin_amdgcn_readlane(w.reg, static_cast<int>(w.pulls - w.base));
+  ++w.pulls;
+  return d;
+}
+
+struct DecoderState {
+  unsigned int base, span_m1, window;
+};
+
+__device__ inline void dec_narrow(DecoderState& st, unsigned int lo, unsigned int hi, int prec,
+                                  DigitWindow& w, int lane) {
+  const unsigned long long span = static_cast<unsigned long long>(st.span_m1) + 1;
+  const unsigned int a = static_cast<unsigned int>((span * lo) >> prec);
+  const unsigned int b = static_cast<unsigned int>(((span * hi) >> prec) - 1);
+  st.base += a;
+  st.span_m1 = b - a;
+  if ((st.span_m1 >> 16) == 0) {
+    st.base <<= 16;
+    st.span_m1 = (st.span_m1 << 16) | 0xFFFFu;
+    st.window = (st.window << 16) | window_pull(w, lane);
+  }
+}
+
+// Decode one binary digit with the uniform cdf {0,1,2}, precision 1
+// (DecodeLinearly, range_coder.h:193-202 with the call at
+// range_coder_kernels.cc:449-471).
+__device__ inline int dec_bit(DecoderState& st, DigitWindow& w, int lane) {
+  const unsigned long long span = static_cast<unsigned long long>(st.span_m1) + 1;
+  const unsigned long long target =
+      (static_cast<unsigned long long>(static_cast<unsigned int>(st.window - st.base)) + 1) << 1;
+  const int bit = (target <= span) ? 0 : 1;
+  dec_narrow(st, bit, bit + 1, 1, w, lane);
+  return bit;
+}
+
+// Finds the first symbol k with target <= span * cdf[k + 1]; all 64 lanes test
+// one candidate each.  `cdf0` = position of cdf[0], `ncdf` = number of cdf
+// entries.  On damaged input (no candidate matches) the last symbol is taken.
+template <typename TabFn>
+__device__ inline int dec_symbol(const TabFn& T, DecoderState& st, int cdf0, int ncdf, int prec,
+                                 DigitWindow& w, int lane) {
+  const unsigned long long span = static_cast<unsigned long long>(st.span_m1) + 1;
+  const unsigned long long target =
+      (static_cast<unsigned long long>(static_cast<unsigned int>(st.window - st.base)) + 1) << prec;
+  const int nsym = ncdf - 1;
+  int sym = nsym - 1;
+  unsigned int lo = 0, hi = 0;
+  bool found = false;
+  for (int c0 = 0; c0 < nsym; c0 += 64) {
+    const int k = c0 + lane;
+    unsigned int lo_k = 0, hi_k = 0;
+    if (k < nsym) {
+      lo_k = static_cast<unsigned int>(T(cdf0 + k));
+      hi_k = static_cast<unsigned int>(T(cdf0 + k + 1));
+    }
+    const bool pred = (k < nsym) && (target <= span * hi_k);
+    const unsigned long long m = __ballot(pred);
+    if (m != 0) {
+      const int kk = __builtin_ctzll(m);
+      lo = __builtin_amdgcn_readlane(static_cast<int>(lo_k), kk);
+      hi = __builtin_amdgcn_readlane(static_cast<int>(hi_k), kk);
+      sym = c0 + kk;
+      found = true;
+      break;
+    }
+  }
+  if (!found) {
+    lo = static_cast<unsigned int>(T(cdf0 + nsym - 1));
+    hi = static_cast<unsigned int>(T(cdf0 + nsym));
+  }
+  dec_narrow(st, lo, hi, prec, w, lane);
+  return sym;
+}
+
+struct OutInt32 {
+  int32_t* out;
+  __device__ void store(int64_t pos, int /*table*/, int32_t sym) const { out[pos] = sym; }
+};
+
+template <typename T>
+struct OutDequant {
+  T* y;
+  const float* qoffset;
+  const int32_t* cdf_offset;
+  __device__ void store(int64_t pos, int table, int32_t sym) const {
+    // outputs = cast(symbols + cdf_offset, dtype) (+ quantization_offset)
+    T v = from_float<T>(static_cast<float>(sym + cdf_offset[table]));
+    if (qoffset) v = from_float<T>(to_float<T>(v) + to_float<T>(from_float<T>(qoffset[table])));
+    y[pos] = v;
+  }
+};
+
+template <bool LDS_TAB, typename Dst>
+__global__ void __launch_bounds__(kBlock) dec_kernel(DecParams p, Dst dst) {
+  extern __shared__ int32_t lds_tab[];
+  if (LDS_TAB) {
+    for (int i = threadIdx.x; i < p.tab.total; i += kBlock) lds_tab[i] = p.tab.data[i];
+    __syncthreads();
+  }
+  auto T = [&](int i) -> int32_t { return LDS_TAB ? lds_tab[i] : p.tab.data[i]; };
+
+  const int lane = threadIdx.x & 63;
+  const int64_t s = __builtin_amdgcn_readfirstlane(
+      static_cast<int>(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
+  if (s >= p.streams) return;
+
+  const uint4 st0 = p.state[s];
+  DecoderState st;
+  st.base = __builtin_amdgcn_readfirstlane(st0.x);
+  st.span_m1 = __builtin_amdgcn_readfirstlane(st0.y);
+  st.window = __builtin_amdgcn_readfirstlane(st0.z);
+  DigitWindow w;
+  const long long o0 = p.off[s];
+  w.src = p.blob + o0;
+  w.len = p.off[s + 1] - o0;
+  w.pulls = __builtin_amdgcn_readfirstlane(st0.w);
+  w.base = w.pulls;
+  window_load(w, lane);
+
+  for (int64_t j0 = 0; j0 < p.elems; j0 += 64) {
+    const int64_t j = j0 + lane;
+    int t = 0;
+    if (j < p.elems) {
+      const int64_t pos = s * p.elems + j;
+      if (p.index) {
+        t = p.index[pos];
+        if (t < 0 || t >= p.tab.ntab) {
+          atomicMin(p.first_error, static_cast<unsigned long long>(pos));
+          t = 0;
+        }
+      } else {
+        t = static_cast<int>(j % p.tab.ntab);
+      }
+    }
+    const int cnt = static_cast<int>(min<int64_t>(64, p.elems - j0));
+    int outv = 0;
+    for (int n = 0; n < cnt; ++n) {
+      const int tn = __builtin_amdgcn_readlane(t, n);
+      const int2 row = p.tab.rows[tn];
+      const int start = __builtin_amdgcn_readfirstlane(row.x);
+      const int nints = __builtin_amdgcn_readfirstlane(row.y);
+      const int sp = __builtin_amdgcn_readfirstlane(T(start));
+      const int prec = sp < 0 ? -sp : sp;
+      int sym = dec_symbol(T, st, start + 1, nints - 1, prec, w, lane);
+      if (sp < 0 && sym == nints - 3) {
+        int nb = 0;
+        // bound the unary prefix so damaged input cannot spin forever
+        while (nb < 31 && dec_bit(st, w, lane) == 0) ++nb;
+        int v = 1 << nb;
+        while (--nb >= 0) v |= dec_bit(st, w, lane) << nb;
+        const int neg = dec_bit(st, w, lane);
+        sym = neg ? -v : v + (nints - 3) - 1;
+      }
+      outv = tfc_writelane(sym, n, outv);
+    }
+    if (j < p.elems) dst.store(s * p.elems + j, t, outv);
+  }
+  if (lane == 0) p.state[s] = make_uint4(st.base, st.span_m1, st.window, w.pulls);
+}
+
+// Reads the first four bytes of every stream (RangeDecoder ctor,
+// range_coder.h:79-83).
+__global__ void dec_open_kernel(const uint8_t* blob, const long long* off, int64_t streams,
+                                uint4* state) {
+  const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (s >= streams) return;
+  const uint8_t* src = blob + off[s];
+  const long long len = off[s + 1] - off[s];
+  unsigned int w = 0;
+  for (int i = 0; i < 4; ++i) w = (w << 8) | (i < len ? src[i] : 0u);
+  state[s] = make_uint4(0u, 0xFFFFFFFFu, w, 2u);
+}
+
+// RangeDecoder::Finalize (range_coder.h:144-169).
+__global__ void dec_close_kernel(const uint4* state, const long long* off, int64_t streams,
+                                 uint8_t* ok) {
+  const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (s >= streams) return;
+  const uint4 st = state[s];
+  const long long len = off[s + 1] - off[s];
+  bool good;
+  if (2ll * st.w < len) {
+    good = false;
+  } else {
+    const unsigned int top = st.x + st.y;
+    if (st.x == 0 || top < st.x) {
+      good = st.z == 0;
+    } else {
+      const int sh = (((st.x - 1) >> 24) < (top >> 24)) ? 24 : 16;
+      const unsigned int r = ((st.x - 1) >> sh) + 1;
+      good = (r << sh) == st.z;
+    }
+  }
+  ok[s] = good ? 1 : 0;
+}
+
+__global__ void fill_state_kernel(uint4* state, int64_t n, uint4 v) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) state[i] = v;
+}
+
+}  // namespace tfc
+
+// ===========================================================================
+// Host side: encoder
+// ===========================================================================
+
+struct EncChunk {
+  DevBuf data, off, len;
+};
+
+struct tfc_encoder {
+  const tfc_tables* tables = nullptr;
+  int64_t streams = 0;
+  DevBuf state;                 // uint4 [streams]
+  std::vector<EncChunk> chunks;
+  // results
+  bool finalized = false;
+  DevBuf blob, offsets;
+  int64_t total = 0;
+};
+
+namespace {
+
+size_t table_lds_bytes(const tfc_tables* t) {
+  const size_t b = t->host.size() * sizeof(int32_t);
+  return b <= kLdsTableBytes ? b : 0;
+}
+
+TableView view_of(const tfc_tables* t) {
+  TableView v;
+  v.data = t->d_data.as<int32_t>();
+  v.rows = t->d_rows.as<int2>();
+  v.ntab = static_cast<int>(t->rows.size());
+  v.total = static_cast<int>(t->host.size());
+  return v;
+}
+
+template <typename Src>
+int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& src,
+               hipStream_t st, const std::function<int(uint64_t)>& on_error) {
+  if (e->finalized) return fail("encoder handle was already finalized");
+  if (elems < 0) return fail("negative element count");
+  if (e->streams == 0 || elems == 0) return 0;
+  const tfc_tables* t = e->tables;
+  if (t->rows.empty()) return fail("index=0 not in range [0, 0)");
+
+  EncChunk ch;
+  DevBuf calls, status;
+  TFC_HIP(calls.alloc(sizeof(unsigned long long) * e->streams, st));
+  TFC_HIP(status.alloc(sizeof(unsigned long long) * 3, st));
+  TFC_HIP(hipMemsetAsync(calls.p, 0, sizeof(unsigned long long) * e->streams, st));
+  // status[0] = first error position, [1] = total capacity, [2] = overflow flag
+  const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+  TFC_HIP(hipMemcpyAsync(status.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  TFC_HIP(ch.off.alloc(sizeof(long long) * (e->streams + 1), st));
+  TFC_HIP(ch.len.alloc(sizeof(unsigned int) * e->streams, st));
+
+  EncParams p;
+  p.tab = view_of(t);
+  p.index = index;
+  p.streams = e->streams;
+  p.elems = elems;
+  p.calls = calls.as<unsigned long long>();
+  p.first_error = status.as<unsigned long long>();
+  p.state = e->state.as<uint4>();
+  p.chunk = nullptr;
+  p.chunk_off = ch.off.as<long long>();
+  p.chunk_len = ch.len.as<unsigned int>();
+  p.overflow_flag = reinterpret_cast<unsigned int*>(status.as<unsigned long long>() + 2);
+
+  const int64_t tiles = ceil_div(elems, 256);
+  if (e->streams * tiles >= (int64_t{1} << 31)) return fail("encode call too large for one launch");
+  hipLaunchKernelGGL((enc_count_kernel<Src>), dim3(static_cast<unsigned>(e->streams * tiles)),
+                     dim3(256), 0, st, p, src);
+  hipLaunchKernelGGL(enc_offsets_kernel, dim3(1), dim3(1024), 0, st, p.calls, e->streams,
+                     ch.off.as<long long>(), status.as<unsigned long long>() + 1);
+  unsigned long long host_status[3];
+  TFC_HIP(hipMemcpyAsync(host_status, status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  if (host_status[0] != ~0ull) return on_error(host_status[0]);
+
+  TFC_HIP(ch.data.alloc(host_status[1], st));
+  p.chunk = ch.data.as<uint8_t>();
+  const size_t lds = table_lds_bytes(t);
+  const unsigned blocks = static_cast<unsigned>(ceil_div(e->streams, kWavesPerBlock));
+  if (lds) {
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_kernel<true, Src>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((enc_kernel<true, Src>), dim3(blocks), dim3(kBlock), lds, st, p, src);
+  } else {
+    hipLaunchKernelGGL((enc_kernel<false, Src>), dim3(blocks), dim3(kBlock), 0, st, p, src);
+  }
+  TFC_HIP(hipGetLastError());
+  e->chunks.push_back(std::move(ch));
+  return 0;
+}
+
+// Builds the reference's range-error text for the element at `pos`.
+int range_error_text(const tfc_tables* t, bool has_index, int32_t idx, int64_t channel,
+                     int32_t value) {
+  const int64_t ntab = static_cast<int64_t>(t->rows.size());
+  if (has_index && (idx < 0 || idx >= ntab))
+    return fail("index=%d not in range [0, %lld)", idx, static_cast<long long>(ntab));
+  const int2 row = t->rows[has_index ? idx : channel];
+  return fail("value=%d not in range [0, %d)", value, row.y - 2);
+}
+
+}  // namespace
+
+extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, void* stream,
+                                  tfc_encoder** out) {
+  *out = nullptr;
+  if (!tables) return fail("tables is null");
+  if (streams < 0) return fail("negative stream count");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::unique_ptr<tfc_encoder> e(new tfc_encoder);
+  e->tables = tables;
+  e->streams = streams;
+  TFC_HIP(e->state.alloc(sizeof(uint4) * std::max<int64_t>(streams, 1), st));
+  if (streams)
+    hipLaunchKernelGGL(fill_state_kernel, dim3(static_cast<unsigned>(ceil_div(streams, 256))),
+                       dim3(256), 0, st, e->state.as<uint4>(), streams,
+                       make_uint4(0u, 0xFFFFFFFFu, 0u, 0u));
+  *out = e.release();
+  return 0;
+}
+
+extern "C" int tfc_encoder_encode(tfc_encoder* e, const int32_t* value, const int32_t* index,
+                                  int64_t elems, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SymInt32 src{value};
+  auto on_error = [&](uint64_t pos) -> int {
+    int32_t v = 0, ix = 0;
+    if (hipMemcpy(&v, value + pos, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("value out of range");
+    if (index && hipMemcpy(&ix, index + pos, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("index out of range");
+    const int64_t ch = static_cast<int64_t>((pos % elems) % e->tables->rows.size());
+    return range_error_text(e->tables, index != nullptr, ix, ch, v);
+  };
+  return run_encode(e, index, elems, src, st, on_error);
+}
+
+namespace {
+
+template <typename T>
+int encode_quantized_t(tfc_encoder* e, const void* y, const float* qoffset, const int32_t* index,
+                       const int32_t* cdf_offset, int64_t elems, hipStream_t st) {
+  SymQuant<T> src{static_cast<const T*>(y), qoffset, cdf_offset};
+  auto on_error = [&](uint64_t pos) -> int {
+    int32_t ix = 0;
+    if (index && hipMemcpy(&ix, index + pos, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("index out of range");
+    const int64_t ntab = static_cast<int64_t>(e->tables->rows.size());
+    if (index && (ix < 0 || ix >= ntab))
+      return fail("index=%d not in range [0, %lld)", ix, static_cast<long long>(ntab));
+    return fail("value=<quantized element %llu> not in range [0, %d)",
+                static_cast<unsigned long long>(pos),
+                e->tables->rows[index ? ix : (pos % elems) % ntab].y - 2);
+  };
+  return run_encode(e, index, elems, src, st, on_error);
+}
+
+int dispatch_quantized(tfc_encoder* e, const void* y, int dtype, const float* qoffset,
+                       const int32_t* index, const int32_t* cdf_offset, int64_t elems,
+                       hipStream_t st) {
+  switch (dtype) {
+    case 0: return encode_quantized_t<float>(e, y, qoffset, index, cdf_offset, elems, st);
+    case 1: return encode_quantized_t<__hip_bfloat16>(e, y, qoffset, index, cdf_offset, elems, st);
+    case 2: return encode_quantized_t<__half>(e, y, qoffset, index, cdf_offset, elems, st);
+    default: return fail("unsupported dtype code %d", dtype);
+  }
+}
+
+}  // namespace
+
+extern "C" int tfc_encoder_encode_quantized(tfc_encoder* e, const void* y, int dtype,
+                                            const float* qoffset, const int32_t* cdf_offset,
+                                            int64_t channels, int64_t elems, void* stream) {
+  if (channels != static_cast<int64_t>(e->tables->rows.size()))
+    return fail("channel count %lld does not match table count %lld",
+                static_cast<long long>(channels), static_cast<long long>(e->tables->rows.size()));
+  return dispatch_quantized(e, y, dtype, qoffset, nullptr, cdf_offset, elems,
+                            static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tfc_encoder_encode_quantized_indexed(tfc_encoder* e, const void* y, int dtype,
+                                                    const int32_t* index,
+                                                    const int32_t* cdf_offset, int64_t elems,
+                                                    void* stream) {
+  if (!index) return fail("index is null");
+  return dispatch_quantized(e, y, dtype, nullptr, index, cdf_offset, elems,
+                            static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total_bytes) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (e->finalized) {
+    *total_bytes = e->total;
+    return 0;
+  }
+  const int64_t n = e->streams;
+  TFC_HIP(e->offsets.alloc(sizeof(long long) * (n + 1), st));
+  if (n == 0) {
+    TFC_HIP(hipMemsetAsync(e->offsets.p, 0, sizeof(long long), st));
+    TFC_HIP(e->blob.alloc(0, st));
+    e->total = 0;
+    e->finalized = true;
+    *total_bytes = 0;
+    return 0;
+  }
+  std::vector<ChunkRef> refs;
+  for (auto& c : e->chunks)
+    refs.push_back(ChunkRef{c.data.as<uint8_t>(), c.off.as<long long>(), c.len.as<unsigned int>()});
+  DevBuf d_refs, tail, length;
+  TFC_HIP(d_refs.alloc(sizeof(ChunkRef) * std::max<size_t>(refs.size(), 1), st));
+  if (!refs.empty())
+    TFC_HIP(hipMemcpyAsync(d_refs.p, refs.data(), sizeof(ChunkRef) * refs.size(),
+                           hipMemcpyHostToDevice, st));
+  TFC_HIP(tail.alloc(2 * n, st));
+  TFC_HIP(length.alloc(sizeof(long long) * n, st));
+  const unsigned tb = static_cast<unsigned>(ceil_div(n, 256));
+  hipLaunchKernelGGL(enc_tail_kernel, dim3(tb), dim3(256), 0, st, e->state.as<uint4>(), n,
+                     d_refs.as<ChunkRef>(), static_cast<int>(refs.size()), tail.as<uint8_t>(),
+                     length.as<long long>());
+  hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, length.as<long long>(), n,
+                     e->offsets.as<long long>());
+  long long total = 0;
+  TFC_HIP(hipMemcpyAsync(&total, e->offsets.as<long long>() + n, sizeof(long long),
+                         hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  TFC_HIP(e->blob.alloc(static_cast<size_t>(total), st));
+  hipLaunchKernelGGL(enc_pack_kernel, dim3(static_cast<unsigned>(ceil_div(n, kWavesPerBlock))),
+                     dim3(kBlock), 0, st, n, d_refs.as<ChunkRef>(), static_cast<int>(refs.size()),
+                     tail.as<uint8_t>(), e->offsets.as<long long>(), e->blob.as<uint8_t>());
+  TFC_HIP(hipGetLastError());
+  TFC_HIP(hipStreamSynchronize(st));
+  e->chunks.clear();
+  e->total = total;
+  e->finalized = true;
+  *total_bytes = total;
+  return 0;
+}
+
+extern "C" int tfc_encoder_result(const tfc_encoder* e, const uint8_t** blob, const int64_t** offsets) {
+  if (!e->finalized) return fail("encoder handle is not finalized");
+  *blob = e->blob.as<uint8_t>();
+  *offsets = e->offsets.as<int64_t>();
+  return 0;
+}
+
+extern "C" int tfc_encoder_read(const tfc_encoder* e, uint8_t* blob_dst, int64_t* offsets_dst,
+                                int dst_on_device, void* stream) {
+  if (!e->finalized) return fail("encoder handle is not finalized");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const hipMemcpyKind k = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (offsets_dst)
+    TFC_HIP(hipMemcpyAsync(offsets_dst, e->offsets.p, sizeof(int64_t) * (e->streams + 1), k, st));
+  if (blob_dst && e->total)
+    TFC_HIP(hipMemcpyAsync(blob_dst, e->blob.p, static_cast<size_t>(e->total), k, st));
+  if (!dst_on_device) TFC_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" void tfc_encoder_destroy(tfc_encoder* e) { delete e; }
+
+// ===========================================================================
+// Host side: decoder
+// ===========================================================================
+
+struct tfc_decoder {
+  const tfc_tables* tables = nullptr;
+  int64_t streams = 0;
+  DevBuf blob, offsets, state, status;
+};
+
+extern "C" int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob,
+                                  const int64_t* offsets, int64_t streams, int src_on_device,
+                                  void* stream, tfc_decoder** out) {
+  *out = nullptr;
+  if (!tables) return fail("tables is null");
+  if (streams < 0) return fail("negative stream count");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::unique_ptr<tfc_decoder> d(new tfc_decoder);
+  d->tables = tables;
+  d->streams = streams;
+  const hipMemcpyKind k = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  int64_t total = 0;
+  if (src_on_device) {
+    TFC_HIP(hipMemcpyAsync(&total, offsets + streams, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    TFC_HIP(hipStreamSynchronize(st));
+  } else {
+    total = offsets[streams];
+  }
+  TFC_HIP(d->offsets.alloc(sizeof(int64_t) * (streams + 1), st));
+  TFC_HIP(hipMemcpyAsync(d->offsets.p, offsets, sizeof(int64_t) * (streams + 1), k, st));
+  TFC_HIP(d->blob.alloc(static_cast<size_t>(total), st));
+  if (total) TFC_HIP(hipMemcpyAsync(d->blob.p, blob, static_cast<size_t>(total), k, st));
+  TFC_HIP(d->state.alloc(sizeof(uint4) * std::max<int64_t>(streams, 1), st));
+  TFC_HIP(d->status.alloc(sizeof(unsigned long long), st));
+  TFC_HIP(hipMemsetAsync(d->status.p, 0xFF, sizeof(unsigned long long), st));
+  if (streams)
+    hipLaunchKernelGGL(dec_open_kernel, dim3(static_cast<unsigned>(ceil_div(streams, 256))),
+                       dim3(256), 0, st, d->blob.as<uint8_t>(), d->offsets.as<long long>(),
+                       streams, d->state.as<uint4>());
+  if (!src_on_device) TFC_HIP(hipStreamSynchronize(st));  // host buffers may go away
+  *out = d.release();
+  return 0;
+}
+
+namespace {
+
+template <typename Dst>
+int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& dst,
+               hipStream_t st) {
+  if (elems < 0) return fail("negative element count");
+  if (d->streams == 0 || elems == 0) return 0;
+  const tfc_tables* t = d->tables;
+  if (t->rows.empty()) return fail("index=0 not in range [0, 0)");
+  DecParams p;
+  p.tab = view_of(t);
+  p.index = index;
+  p.streams = d->streams;
+  p.elems = elems;
+  p.blob = d->blob.as<uint8_t>();
+  p.off = d->offsets.as<long long>();
+  p.state = d->state.as<uint4>();
+  p.first_error = d->status.as<unsigned long long>();
+  const size_t lds = table_lds_bytes(t);
+  const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
+  if (lds) {
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_kernel<true, Dst>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((dec_kernel<true, Dst>), dim3(blocks), dim3(kBlock), lds, st, p, dst);
+  } else {
+    hipLaunchKernelGGL((dec_kernel<false, Dst>), dim3(blocks), dim3(kBlock), 0, st, p, dst);
+  }
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tfc_decoder_decode(tfc_decoder* d, const int32_t* index, int32_t* out,
+                                  int64_t elems, void* stream) {
+  return run_decode(d, index, elems, OutInt32{out}, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tfc_decoder_decode_dequantized(tfc_decoder* d, const int32_t* index, void* y,
+                                              int dtype, const float* qoffset,
+                                              const int32_t* cdf_offset, int64_t channels,
+                                              int64_t elems, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!index && channels != static_cast<int64_t>(d->tables->rows.size()))
+    return fail("channel count %lld does not match table count %lld",
+                static_cast<long long>(channels), static_cast<long long>(d->tables->rows.size()));
+  if (index && qoffset) return fail("qoffset is not supported in index mode");
+  switch (dtype) {
+    case 0: return run_decode(d, index, elems, OutDequant<float>{static_cast<float*>(y), qoffset, cdf_offset}, st);
+    case 1: return run_decode(d, index, elems, OutDequant<__hip_bfloat16>{static_cast<__hip_bfloat16*>(y), qoffset, cdf_offset}, st);
+    case 2: return run_decode(d, index, elems, OutDequant<__half>{static_cast<__half*>(y), qoffset, cdf_offset}, st);
+    default: return fail("unsupported dtype code %d", dtype);
+  }
+}
+
+extern "C" int tfc_decoder_finalize(tfc_decoder* d, uint8_t* ok, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = d->streams;
+  unsigned long long first_error = ~0ull;
+  DevBuf d_ok;
+  TFC_HIP(d_ok.alloc(std::max<int64_t>(n, 1), st));
+  if (n)
+    hipLaunchKernelGGL(dec_close_kernel, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256),
+                       0, st, d->state.as<uint4>(), d->offsets.as<long long>(), n,
+                       d_ok.as<uint8_t>());
+  TFC_HIP(hipMemcpyAsync(&first_error, d->status.p, sizeof(first_error), hipMemcpyDeviceToHost, st));
+  if (n) TFC_HIP(hipMemcpyAsync(ok, d_ok.p, n, hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  if (first_error != ~0ull)
+    return fail("index=<element %llu> not in range [0, %lld)", first_error,
+                static_cast<long long>(d->tables->rows.size()));
+  return 0;
+}
+
+extern "C" void tfc_decoder_destroy(tfc_decoder* d) { delete d; }
+
+// ===========================================================================
+// Deprecated single-stream ops: RangeEncode / RangeDecode
+// (cc/kernels/range_coding_kernels.cc:60-379, range_coding_kernels_util.cc:34-91)
+// ===========================================================================
+
+namespace tfc {
+
+// Merged broadcast geometry: data index -> cdf row offset.
+struct Broadcast {
+  int nd;
+  long long shape[6];       // merged data shape
+  long long cdf_stride[6];  // cdf elements per step along the axis (0 when broadcast)
+  long long width;          // cdf entries per row
+};
+
+__device__ inline long long cdf_row_of(const Broadcast& b, long long k) {
+  long long off = 0;
+  for (int i = b.nd - 1; i >= 0; --i) {
+    const long long q = k / b.shape[i];
+    off += (k - q * b.shape[i]) * b.cdf_stride[i];
+    k = q;
+  }
+  return off;
+}
+
+struct LegacyEncParams {
+  const int16_t* data;
+  const int32_t* cdf;
+  Broadcast geo;
+  long long total;
+  int precision;
+  int check;                         // debug_level > 0
+  uint8_t* out;
+  unsigned int cap;
+  unsigned int* out_len;
+  unsigned long long* first_error;
+};
+
+__global__ void __launch_bounds__(64) legacy_enc_kernel(LegacyEncParams p) {
+  const int lane = threadIdx.x;
+  EncoderState st{0u, 0xFFFFFFFFu, 0u, 0u};
+  DigitSink o;
+  o.dst = p.out;
+  o.cap = p.cap;
+  o.nbytes = 0;
+  o.n = 0;
+  o.reg = 0;
+  o.overflow = 0;
+  const int sh = 16 - p.precision;
+  bool failed = false;
+  for (long long k0 = 0; k0 < p.total && !failed; k0 += 64) {
+    const long long k = k0 + lane;
+    int lo = 0, hi = 0;
+    bool bad = false;
+    if (k < p.total) {
+      const long long row = cdf_row_of(p.geo, k);
+      long long v = p.data[k];
+      if (v < 0 || p.geo.width <= v + 1) {
+        bad = true;
+        v = 0;
+      }
+      lo = p.cdf[row + v] << sh;
+      hi = p.cdf[row + v + 1] << sh;
+    }
+    const unsigned long long badmask = __ballot(bad);
+    int cnt = static_cast<int>(min<long long>(64, p.total - k0));
+    if (badmask != 0) {
+      // debug_level 1 reports the first offender; debug_level 0 leaves it
+      // undefined in the reference (DCHECK only) — we stop there too.
+      const int first = __builtin_ctzll(badmask);
+      if (lane == 0) atomicMin(p.first_error, static_cast<unsigned long long>(k0 + first));
+      cnt = first;
+      failed = true;
+    }
+    for (int n = 0; n < cnt; ++n) {
+      const unsigned int l = __builtin_amdgcn_readlane(lo, n);
+      const unsigned int h = __builtin_amdgcn_readlane(hi, n);
+      enc_update(st, l, h, o, lane);
+    }
+  }
+  sink_flush(o, lane);
+  if (lane == 0) {
+    // RangeEncoder::Finalize
+    unsigned int n = o.nbytes;
+    uint8_t* dst = p.out + n;
+    if (st.pend_digit != 0) {
+      dst[0] = (st.pend_digit >> 8) & 0xFF; ++n;
+      if ((st.pend_digit & 0xFF) != 0) { dst[1] = st.pend_digit & 0xFF; ++n; }
+    } else if (st.base != 0) {
+      const unsigned int top = st.base + st.span_m1;
+      const unsigned int r24 = ((st.base - 1) >> 24) + 1;
+      if (r24 <= (top >> 24)) {
+        dst[0] = r24 & 0xFF; ++n;
+      } else {
+        const unsigned int r16 = ((st.base - 1) >> 16) + 1;
+        dst[0] = (r16 >> 8) & 0xFF; ++n;
+        if ((r16 & 0xFF) != 0) { dst[1] = r16 & 0xFF; ++n; }
+      }
+    }
+    *p.out_len = n;
+  }
+}
+
+struct LegacyDecParams {
+  const uint8_t* bytes;
+  long long nbytes;
+  const int32_t* cdf;
+  Broadcast geo;
+  long long total;
+  int precision;
+  int16_t* out;
+};
+
+__global__ void __launch_bounds__(64) legacy_dec_kernel(LegacyDecParams p) {
+  const int lane = threadIdx.x;
+  DecoderState st{0u, 0xFFFFFFFFu, 0u};
+  DigitWindow w;
+  w.src = p.bytes;
+  w.len = p.nbytes;
+  w.pulls = 0;
+  w.base = 0;
+  window_load(w, lane);
+  st.window = window_pull(w, lane) << 16;
+  st.window |= window_pull(w, lane);
+  for (long long k0 = 0; k0 < p.total; k0 += 64) {
+    const long long k = k0 + lane;
+    long long row = 0;
+    if (k < p.total) row = cdf_row_of(p.geo, k);
+    const int cnt = static_cast<int>(min<long long>(64, p.total - k0));
+    int outv = 0;
+    for (int n = 0; n < cnt; ++n) {
+      const unsigned int rlo = __builtin_amdgcn_readlane(static_cast<int>(row & 0xFFFFFFFFll), n);
+      const unsigned int rhi = __builtin_amdgcn_readlane(static_cast<int>(row >> 32), n);
+      const long long r = (static_cast<long long>(rhi) << 32) | rlo;
+      const int32_t* base = p.cdf + r;
+      auto T = [&](int i) -> int32_t { return base[i]; };
+      const int sym = dec_symbol(T, st, 0, static_cast<int>(p.geo.width), p.precision, w, lane);
+      outv = tfc_writelane(sym, n, outv);
+    }
+    if (k < p.total) p.out[k] = static_cast<int16_t>(outv);
+  }
+}
+
+// cdf[..., 0] == 0, cdf[..., -1] == 1 << precision, strictly increasing
+// (CheckCdfValues, range_coding_kernels.cc:149-173).  flag: bit0 ends wrong,
+// bit1 not monotonic; bad_row = first offending row (min).
+__global__ void check_cdf_kernel(const int32_t* cdf, long long rows, long long width,
+                                 int precision, unsigned int* flag, unsigned long long* bad_row) {
+  const long long r = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  if (r >= rows) return;
+  const int32_t* s = cdf + r * width;
+  if (s[0] != 0 || s[width - 1] != (1 << precision)) {
+    atomicOr(flag, 1u);
+    atomicMin(bad_row, static_cast<unsigned long long>(r));
+  }
+  for (long long j = 0; j + 1 < width; ++j)
+    if (s[j + 1] <= s[j]) { atomicOr(flag, 2u); break; }
+}
+
+}  // namespace tfc
+
+namespace {
+
+std::string shape_str(const int64_t* s, int n) {
+  std::string r = "[";
+  for (int i = 0; i < n; ++i) r += (i ? "," : "") + std::to_string(s[i]);
+  return r + "]";
+}
+
+// MergeAxes (range_coding_kernels_util.cc:34-91) + the stride table the
+// kernels use instead of BroadcastRange's incremental displacement.
+int make_broadcast(const int64_t* data_shape, int nd, const int64_t* cdf_shape, int nc,
+                   Broadcast* out) {
+  if (nc != nd + 1)
+    return fail("`cdf` should have one more axis than `data`: data shape=%s, cdf shape=%s",
+                shape_str(data_shape, nd).c_str(), shape_str(cdf_shape, nc).c_str());
+  if (cdf_shape[nc - 1] <= 1)
+    return fail("The last dimension of `cdf` should be > 1: %s", shape_str(cdf_shape, nc).c_str());
+  std::vector<int64_t> md(1, 1), mc(1, 1);
+  for (int j = 0; j < nd; ++j) {
+    if (data_shape[j] != cdf_shape[j] && cdf_shape[j] != 1)
+      return fail("Cannot broadcast shape %s to %s", shape_str(cdf_shape, nc).c_str(),
+                  shape_str(data_shape, nd).c_str());
+    const bool was_b = mc.back() == 1;
+    const bool is_b = cdf_shape[j] == 1;
+    if (was_b == is_b || data_shape[j] <= 1 || md.back() <= 1) {
+      md.back() *= data_shape[j];
+      mc.back() *= cdf_shape[j];
+    } else {
+      md.push_back(data_shape[j]);
+      mc.push_back(cdf_shape[j]);
+    }
+  }
+  if (md.size() > 6)
+    return fail("Irregular broadcast pattern: %s, %s", shape_str(data_shape, nd).c_str(),
+                shape_str(cdf_shape, nc).c_str());
+  out->nd = static_cast<int>(md.size());
+  out->width = cdf_shape[nc - 1];
+  long long stride = out->width;
+  for (int i = out->nd - 1; i >= 0; --i) {
+    out->shape[i] = md[i];
+    out->cdf_stride[i] = mc[i] <= 1 ? 0 : stride;
+    stride *= mc[i];
+  }
+  return 0;
+}
+
+int check_cdf_values(const int32_t* cdf, const int64_t* cdf_shape, int nc, int precision,
+                     hipStream_t st) {
+  const long long width = cdf_shape[nc - 1];
+  if (width <= 2) return fail("CDF size should be > 2: %lld", width);
+  long long rows = 1;
+  for (int i = 0; i + 1 < nc; ++i) rows *= cdf_shape[i];
+  if (rows == 0) return 0;
+  DevBuf flag;
+  TFC_HIP(flag.alloc(16, st));
+  const unsigned long long init[2] = {0ull, ~0ull};
+  TFC_HIP(hipMemcpyAsync(flag.p, init, 16, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(check_cdf_kernel, dim3(static_cast<unsigned>(ceil_div(rows, 256))), dim3(256),
+                     0, st, cdf, rows, width, precision, flag.as<unsigned int>(),
+                     flag.as<unsigned long long>() + 1);
+  unsigned long long h[2];
+  TFC_HIP(hipMemcpyAsync(h, flag.p, 16, hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  const unsigned int f = static_cast<unsigned int>(h[0] & 0xFFFFFFFFu);
+  if (f & 1u) {
+    int32_t ends[2] = {0, 0};
+    (void)hipMemcpy(&ends[0], cdf + h[1] * width, 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&ends[1], cdf + h[1] * width + width - 1, 4, hipMemcpyDeviceToHost);
+    return fail("CDF should start from 0 and end at %d: cdf[0]=%d, cdf[^1]=%d", 1 << precision,
+                ends[0], ends[1]);
+  }
+  if (f & 2u) return fail("CDF is not monotonic");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tfc_range_encode(const int16_t* data, const int64_t* data_shape, int nd,
+                                const int32_t* cdf, const int64_t* cdf_shape, int nc,
+                                int precision, int debug_level, void* stream, uint8_t** out,
+                                int64_t* out_len) {
+  *out = nullptr;
+  *out_len = 0;
+  if (!(0 < precision && precision <= 16)) return fail("`precision` must be in [1, 16]: %d", precision);
+  if (debug_level != 0 && debug_level != 1) return fail("`debug_level` must be 0 or 1: %d", debug_level);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Broadcast geo;
+  if (nc != nd + 1 || cdf_shape[nc - 1] <= 1) return make_broadcast(data_shape, nd, cdf_shape, nc, &geo);
+  if (debug_level > 0 && check_cdf_values(cdf, cdf_shape, nc, precision, st)) return 1;
+  if (make_broadcast(data_shape, nd, cdf_shape, nc, &geo)) return 1;
+  long long total = 1;
+  for (int i = 0; i < nd; ++i) total *= data_shape[i];
+  if (2 * total + 16 >= (1ll << 32)) return fail("`data` too large for a single code stream");
+  DevBuf buf, meta;
+  const unsigned int cap = static_cast<unsigned int>(2 * total + 16);
+  TFC_HIP(buf.alloc(cap, st));
+  TFC_HIP(meta.alloc(16, st));
+  const unsigned long long init[2] = {~0ull, 0ull};
+  TFC_HIP(hipMemcpyAsync(meta.p, init, 16, hipMemcpyHostToDevice, st));
+  LegacyEncParams p;
+  p.data = data;
+  p.cdf = cdf;
+  p.geo = geo;
+  p.total = total;
+  p.precision = precision;
+  p.check = debug_level;
+  p.out = buf.as<uint8_t>();
+  p.cap = cap - 4;
+  p.first_error = meta.as<unsigned long long>();
+  p.out_len = reinterpret_cast<unsigned int*>(meta.as<unsigned long long>() + 1);
+  hipLaunchKernelGGL(legacy_enc_kernel, dim3(1), dim3(64), 0, st, p);
+  TFC_HIP(hipGetLastError());
+  unsigned long long h[2];
+  TFC_HIP(hipMemcpyAsync(h, meta.p, 16, hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  if (h[0] != ~0ull) {
+    int16_t v = 0;
+    (void)hipMemcpy(&v, data + h[0], 2, hipMemcpyDeviceToHost);
+    return fail("'data' value not in [0, %lld): value=%d", static_cast<long long>(geo.width - 1), v);
+  }
+  const unsigned int n = static_cast<unsigned int>(h[1] & 0xFFFFFFFFu);
+  uint8_t* host = static_cast<uint8_t*>(std::malloc(n ? n : 1));
+  if (n) TFC_HIP(hipMemcpy(host, buf.p, n, hipMemcpyDeviceToHost));
+  *out = host;
+  *out_len = n;
+  return 0;
+}
+
+extern "C" int tfc_range_decode(const uint8_t* encoded, int64_t encoded_len,
+                                const int64_t* out_shape, int nd, const int32_t* cdf,
+                                const int64_t* cdf_shape, int nc, int precision, int debug_level,
+                                void* stream, int16_t* out) {
+  if (!(0 < precision && precision <= 16)) return fail("`precision` must be in [1, 16]: %d", precision);
+  if (debug_level != 0 && debug_level != 1) return fail("`debug_level` must be 0 or 1: %d", debug_level);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Broadcast geo;
+  if (nc != nd + 1 || cdf_shape[nc - 1] <= 1) return make_broadcast(out_shape, nd, cdf_shape, nc, &geo);
+  if (debug_level > 0 && check_cdf_values(cdf, cdf_shape, nc, precision, st)) return 1;
+  if (make_broadcast(out_shape, nd, cdf_shape, nc, &geo)) return 1;
+  long long total = 1;
+  for (int i = 0; i < nd; ++i) total *= out_shape[i];
+  if (total == 0) return 0;
+  DevBuf bytes;
+  TFC_HIP(bytes.alloc(static_cast<size_t>(encoded_len), st));
+  if (encoded_len)
+    TFC_HIP(hipMemcpyAsync(bytes.p, encoded, static_cast<size_t>(encoded_len), hipMemcpyHostToDevice, st));
+  LegacyDecParams p;
+  p.bytes = bytes.as<uint8_t>();
+  p.nbytes = encoded_len;
+  p.cdf = cdf;
+  p.geo = geo;
+  p.total = total;
+  p.precision = precision;
+  p.out = out;
+  hipLaunchKernelGGL(legacy_dec_kernel, dim3(1), dim3(64), 0, st, p);
+  TFC_HIP(hipGetLastError());
+  TFC_HIP(hipStreamSynchronize(st));  // `encoded` is a host buffer the caller may free
+  return 0;
+}

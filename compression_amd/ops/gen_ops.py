@@ -1,0 +1,376 @@
+"""Op-level API: the callables the reference injects from its C++ plugin
+(`python/ops/gen_ops.py:20-41` loading `cc/libtensorflow_compression.so`),
+re-implemented on the C ABI of libtfc_hip.so (include/tfc_hip.h).
+
+Same names, argument order and error substrings as the reference ops
+(`cc/ops/range_coder_ops.cc`, `cc/ops/range_coding_ops.cc`,
+`cc/ops/pmf_to_cdf_ops.cc`).  Tensors are torch tensors living in HBM;
+"string tensors" are returned as numpy object arrays of `bytes` shaped like the
+handle (plus a zero-copy device view on the handle).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+__all__ = [
+    "create_range_encoder", "create_range_decoder",
+    "entropy_decode_channel", "entropy_decode_finalize", "entropy_decode_index",
+    "entropy_encode_channel", "entropy_encode_finalize", "entropy_encode_index",
+    "pmf_to_quantized_cdf", "range_encode", "range_decode",
+]
+
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def _dev_i32(t, device):
+    t = torch.as_tensor(t)
+    if t.dtype != torch.int32:
+        raise TypeError(f"expected int32 tensor, got {t.dtype}")
+    return t.to(device).contiguous()
+
+
+class _Tables:
+    """Owns a tfc_tables*; cached per lookup tensor version."""
+
+    def __init__(self, lookup: torch.Tensor):
+        host = lookup.detach().to("cpu", torch.int32).contiguous().numpy()
+        if host.ndim not in (1, 2):
+            raise ValueError(f"`lookup` must be rank 1 or 2: {tuple(host.shape)}")
+        rows, cols = (1, host.shape[0]) if host.ndim == 1 else host.shape
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tfc_tables_create(
+            host.ctypes.data, host.ndim, rows, cols, _lib.stream_ptr(), C.byref(out)))
+        self.ptr = out
+        self.count = int(_lib.lib().tfc_tables_count(out))
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                _lib.lib().tfc_tables_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+_TABLE_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
+_TABLE_CACHE_SIZE = 32
+
+
+def _tables_for(lookup) -> _Tables:
+    lookup = torch.as_tensor(lookup)
+    if lookup.dtype != torch.int32:
+        raise TypeError(f"`lookup` must be int32, got {lookup.dtype}")
+    key = (lookup.data_ptr(), lookup._version, tuple(lookup.shape), str(lookup.device))
+    hit = _TABLE_CACHE.get(key)
+    if hit is not None and hit[0] is lookup:
+        _TABLE_CACHE.move_to_end(key)
+        return hit[1]
+    tables = _Tables(lookup)
+    _TABLE_CACHE[key] = (lookup, tables)   # holding `lookup` pins data_ptr
+    while len(_TABLE_CACHE) > _TABLE_CACHE_SIZE:
+        _TABLE_CACHE.popitem(last=False)
+    return tables
+
+
+class EncoderHandle:
+    """Stands in for the DT_VARIANT handle tensor of CreateRangeEncoder
+    (cc/kernels/range_coder_kernels.cc:62-78, 484-507)."""
+
+    def __init__(self, shape, tables: _Tables, device):
+        self.shape = tuple(int(s) for s in shape)
+        self.tables = tables
+        self.device = device
+        self.streams = int(np.prod(self.shape, dtype=np.int64))
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tfc_encoder_create(tables.ptr, self.streams, _lib.stream_ptr(),
+                                                C.byref(out)))
+        self.ptr = out
+        self._keep = []       # inputs of in-flight kernels
+        self.blob = None      # after finalize: device uint8 [total]
+        self.offsets = None   # after finalize: device int64 [streams + 1]
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                _lib.lib().tfc_encoder_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class DecoderHandle:
+    """Stands in for the handle of CreateRangeDecoder
+    (cc/kernels/range_coder_kernels.cc:80-96, 597-619)."""
+
+    def __init__(self, shape, tables: _Tables, device, ptr):
+        self.shape = tuple(int(s) for s in shape)
+        self.tables = tables
+        self.device = device
+        self.streams = int(np.prod(self.shape, dtype=np.int64))
+        self.ptr = ptr
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                _lib.lib().tfc_decoder_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+def _shape_list(shape):
+    if isinstance(shape, torch.Tensor):
+        shape = shape.detach().cpu().tolist()
+    shape = [int(s) for s in np.asarray(shape).reshape(-1)]
+    if any(s < 0 for s in shape):
+        raise ValueError(f"invalid shape {shape}")
+    return shape
+
+
+def create_range_encoder(shape, lookup) -> EncoderHandle:
+    """CreateRangeEncoder(shape, lookup) -> handle."""
+    device = _lib.require_device()
+    return EncoderHandle(_shape_list(shape), _tables_for(lookup), device)
+
+
+def _check_prefix(handle_shape, value_shape, what="value"):
+    if tuple(value_shape[:len(handle_shape)]) != tuple(handle_shape):
+        raise ValueError(
+            f"'{what}' shape should start with 'handle' shape: {what}.shape={list(value_shape)} "
+            f"does not start with handle.shape={list(handle_shape)}")
+
+
+def entropy_encode_channel(handle: EncoderHandle, value) -> EncoderHandle:
+    """EntropyEncodeChannel(handle, value) -> aliased handle."""
+    if handle.streams == 0:
+        raise ValueError(f"`handle` is empty: handle.shape={list(handle.shape)}")
+    value = _dev_i32(value, handle.device)
+    _check_prefix(handle.shape, value.shape)
+    elems = value.numel() // handle.streams
+    handle._keep.append(value)
+    _lib.check(_lib.lib().tfc_encoder_encode(handle.ptr, value.data_ptr(), None, elems,
+                                             _lib.stream_ptr()))
+    return handle
+
+
+def entropy_encode_index(handle: EncoderHandle, index, value) -> EncoderHandle:
+    """EntropyEncodeIndex(handle, index, value) -> aliased handle."""
+    if handle.streams == 0:
+        raise ValueError(f"`handle` is empty: handle.shape={list(handle.shape)}")
+    value = _dev_i32(value, handle.device)
+    index = _dev_i32(index, handle.device)
+    _check_prefix(handle.shape, value.shape)
+    if index.shape != value.shape:
+        raise ValueError(
+            f"'index' shape should match 'value' shape: index.shape={list(index.shape)} "
+            f"!= value.shape={list(value.shape)}")
+    elems = value.numel() // handle.streams
+    handle._keep += [value, index]
+    _lib.check(_lib.lib().tfc_encoder_encode(handle.ptr, value.data_ptr(), index.data_ptr(),
+                                             elems, _lib.stream_ptr()))
+    return handle
+
+
+def _finalize_device(handle: EncoderHandle):
+    total = C.c_int64()
+    _lib.check(_lib.lib().tfc_encoder_finalize(handle.ptr, _lib.stream_ptr(), C.byref(total)))
+    handle._keep.clear()
+    blob = torch.empty(max(total.value, 1), dtype=torch.uint8, device=handle.device)
+    offsets = torch.empty(handle.streams + 1, dtype=torch.int64, device=handle.device)
+    _lib.check(_lib.lib().tfc_encoder_read(handle.ptr, blob.data_ptr(), offsets.data_ptr(), 1,
+                                           _lib.stream_ptr()))
+    handle.blob = blob[:total.value]
+    handle.offsets = offsets
+    return handle.blob, handle.offsets
+
+
+def strings_from_blob(blob, offsets, shape):
+    """(uint8 blob, int64 offsets) -> numpy object array of bytes with `shape`."""
+    blob_h = blob.detach().cpu().numpy().tobytes()
+    off = offsets.detach().cpu().numpy()
+    out = np.empty(len(off) - 1, dtype=object)
+    for i in range(len(off) - 1):
+        out[i] = blob_h[off[i]:off[i + 1]]
+    return out.reshape(shape)
+
+
+def entropy_encode_finalize(handle: EncoderHandle):
+    """EntropyEncodeFinalize(handle) -> encoded strings shaped like handle."""
+    if handle.streams == 0:
+        raise ValueError(f"`handle` is empty: {list(handle.shape)}")
+    blob, offsets = _finalize_device(handle)
+    return strings_from_blob(blob, offsets, handle.shape)
+
+
+def blob_from_strings(strings):
+    """numpy/bytes container -> (uint8 ndarray blob, int64 ndarray offsets, shape)."""
+    if isinstance(strings, (bytes, bytearray)):
+        arr = np.empty((), dtype=object)
+        arr[()] = bytes(strings)
+    else:
+        arr = np.asarray(strings, dtype=object)
+    flat = [bytes(s) for s in arr.reshape(-1)]
+    off = np.zeros(len(flat) + 1, np.int64)
+    if flat:
+        off[1:] = np.cumsum([len(s) for s in flat])
+    blob = np.frombuffer(b"".join(flat), np.uint8).copy() if off[-1] else np.zeros(1, np.uint8)
+    return blob, off, arr.shape
+
+
+def create_range_decoder(encoded, lookup) -> DecoderHandle:
+    """CreateRangeDecoder(encoded, lookup) -> handle.  `encoded` is a container
+    of bytes (any shape) or a (device blob, device offsets, shape) triple."""
+    device = _lib.require_device()
+    tables = _tables_for(lookup)
+    out = C.c_void_p()
+    if isinstance(encoded, tuple) and len(encoded) == 3 and isinstance(encoded[0], torch.Tensor):
+        blob, offsets, shape = encoded
+        shape = tuple(int(s) for s in shape)
+        streams = int(np.prod(shape, dtype=np.int64))
+        if streams == 0:
+            raise ValueError(f"`encoded` is empty: {list(shape)}")
+        blob = blob.to(device).contiguous()
+        offsets = offsets.to(device, torch.int64).contiguous()
+        _lib.check(_lib.lib().tfc_decoder_create(tables.ptr, blob.data_ptr(), offsets.data_ptr(),
+                                                streams, 1, _lib.stream_ptr(), C.byref(out)))
+    else:
+        blob, off, shape = blob_from_strings(encoded)
+        streams = len(off) - 1
+        if streams == 0:
+            raise ValueError(f"`encoded` is empty: {list(shape)}")
+        _lib.check(_lib.lib().tfc_decoder_create(tables.ptr, blob.ctypes.data, off.ctypes.data,
+                                                streams, 0, _lib.stream_ptr(), C.byref(out)))
+    return DecoderHandle(shape, tables, device, out)
+
+
+def _decode(handle: DecoderHandle, index, shape, Tdecoded):
+    if Tdecoded not in (torch.int32, None):
+        raise TypeError("Tdecoded must be int32")
+    if handle.streams == 0:
+        raise ValueError(f"`handle` is empty: {list(handle.shape)}")
+    suffix = _shape_list(shape)
+    out_shape = tuple(handle.shape) + tuple(suffix)
+    elems = int(np.prod(suffix, dtype=np.int64))
+    out = torch.empty(out_shape, dtype=torch.int32, device=handle.device)
+    iptr = None
+    if index is not None:
+        index = _dev_i32(index, handle.device)
+        if tuple(index.shape) != out_shape:
+            raise ValueError(
+                "'index' shape should match 'handle' shape + 'shape': "
+                f"index.shape={list(index.shape)}, handle.shape={list(handle.shape)}, "
+                f"shape={suffix}")
+        handle._keep.append(index)
+        iptr = index.data_ptr()
+    _lib.check(_lib.lib().tfc_decoder_decode(handle.ptr, iptr, out.data_ptr(), elems,
+                                             _lib.stream_ptr()))
+    return handle, out
+
+
+def entropy_decode_channel(handle: DecoderHandle, shape, Tdecoded=torch.int32):
+    """EntropyDecodeChannel(handle, shape, Tdecoded) -> (aliased handle, decoded)."""
+    return _decode(handle, None, shape, Tdecoded)
+
+
+def entropy_decode_index(handle: DecoderHandle, index, shape, Tdecoded=torch.int32):
+    """EntropyDecodeIndex(handle, index, shape, Tdecoded) -> (aliased handle, decoded)."""
+    return _decode(handle, index, shape, Tdecoded)
+
+
+def entropy_decode_finalize(handle: DecoderHandle) -> torch.Tensor:
+    """EntropyDecodeFinalize(handle) -> bool tensor shaped like handle."""
+    if handle.streams == 0:
+        raise ValueError(f"`handle` is empty: {list(handle.shape)}")
+    ok = np.zeros(handle.streams, np.uint8)
+    _lib.check(_lib.lib().tfc_decoder_finalize(handle.ptr, ok.ctypes.data, _lib.stream_ptr()))
+    handle._keep.clear()
+    return torch.from_numpy(ok.astype(bool)).reshape(handle.shape)
+
+
+def pmf_to_quantized_cdf(pmf, precision: int) -> torch.Tensor:
+    """PmfToQuantizedCdf(pmf; precision) -> cdf with last dim + 1."""
+    precision = int(precision)
+    if not 0 < precision <= 16:
+        raise ValueError(f"`precision` must be in [1, 16]: {precision}")
+    device = _lib.require_device()
+    pmf = torch.as_tensor(pmf)
+    if pmf.dtype != torch.float32:
+        raise TypeError(f"`pmf` must be float32, got {pmf.dtype}")
+    if pmf.dim() < 1:
+        raise ValueError("`pmf` should be at least 1-D.")
+    n = pmf.shape[-1]
+    if n <= 1:
+        raise ValueError("`pmf` size should be at least 2 in the last axis.")
+    pmf = pmf.to(device).contiguous()
+    if not bool((torch.isfinite(pmf) & (pmf >= 0)).all()):
+        bad = pmf[~(torch.isfinite(pmf) & (pmf >= 0))][0].item()
+        raise ValueError(
+            f"`pmf` has non-finite or negative element: {bad}. Please check for numerical "
+            "problems in the probability computation.")
+    rows = pmf.numel() // n
+    cdf = torch.empty(pmf.shape[:-1] + (n + 1,), dtype=torch.int32, device=device)
+    _lib.check(_lib.lib().tfc_pmf_to_quantized_cdf(pmf.data_ptr(), rows, n, precision,
+                                                   cdf.data_ptr(), _lib.stream_ptr()))
+    return cdf
+
+
+def _check_precision_debug(precision, debug_level):
+    if not 0 < int(precision) <= 16:
+        raise ValueError(f"`precision` must be in [1, 16]: {precision}")
+    if int(debug_level) not in (0, 1):
+        raise ValueError(f"`debug_level` must be 0 or 1: {debug_level}")
+
+
+def range_encode(data, cdf, precision: int, debug_level: int = 1) -> bytes:
+    """RangeEncode(data:int16, cdf:int32; precision, debug_level) -> bytes."""
+    _check_precision_debug(precision, debug_level)
+    device = _lib.require_device()
+    data = torch.as_tensor(data)
+    cdf = torch.as_tensor(cdf)
+    if data.dtype != torch.int16 or cdf.dtype != torch.int32:
+        raise TypeError("range_encode expects int16 data and int32 cdf")
+    data = data.to(device).contiguous()
+    cdf = cdf.to(device).contiguous()
+    ds = np.array(data.shape, np.int64)
+    cs = np.array(cdf.shape, np.int64)
+    out = C.c_void_p()
+    n = C.c_int64()
+    _lib.check(_lib.lib().tfc_range_encode(
+        data.data_ptr(), ds.ctypes.data, data.dim(), cdf.data_ptr(), cs.ctypes.data, cdf.dim(),
+        int(precision), int(debug_level), _lib.stream_ptr(), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        _lib.lib().tfc_free(out)
+
+
+def range_decode(encoded, shape, cdf, precision: int, debug_level: int = 1) -> torch.Tensor:
+    """RangeDecode(encoded, shape, cdf; precision, debug_level) -> int16 tensor."""
+    _check_precision_debug(precision, debug_level)
+    device = _lib.require_device()
+    if isinstance(encoded, np.ndarray):
+        if encoded.shape != ():
+            raise ValueError(f"Invalid `encoded` shape: {list(encoded.shape)}")
+        encoded = encoded[()]
+    if not isinstance(encoded, (bytes, bytearray)):
+        raise ValueError("Invalid `encoded` shape: expected a scalar byte string")
+    if isinstance(shape, torch.Tensor) and shape.dim() != 1:
+        raise ValueError(f"Invalid `shape` shape: {list(shape.shape)}")
+    shape = _shape_list(shape)
+    cdf = torch.as_tensor(cdf)
+    if cdf.dtype != torch.int32:
+        raise TypeError("range_decode expects int32 cdf")
+    cdf = cdf.to(device).contiguous()
+    out = torch.empty(shape, dtype=torch.int16, device=device)
+    os_ = np.array(shape, np.int64)
+    cs = np.array(cdf.shape, np.int64)
+    buf = np.frombuffer(bytes(encoded), np.uint8).copy() if len(encoded) else np.zeros(1, np.uint8)
+    _lib.check(_lib.lib().tfc_range_decode(
+        buf.ctypes.data, len(encoded), os_.ctypes.data, len(shape), cdf.data_ptr(),
+        cs.ctypes.data, cdf.dim(), int(precision), int(debug_level), _lib.stream_ptr(),
+        out.data_ptr()))
+    return out

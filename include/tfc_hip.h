@@ -1,0 +1,225 @@
+/*
+ * tfc_hip.h — C ABI of the MI355X (gfx950) entropy-coding + transform hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one CPU op kernel
+ * (or one stock-TF composition) of tensorflow/compression; the reference
+ * interface it stands in for is cited as file:line under /root/reference/
+ * tensorflow_compression/.  Plain pointers and sizes only — no torch / TF types.
+ *
+ * Conventions
+ *   - Pointers marked DEV are HIP device pointers, HOST are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *     are asynchronous on that stream unless the comment says "synchronises".
+ *   - Return value 0 = OK; non-zero = InvalidArgument-class failure whose text
+ *     (same substrings the reference's OP_REQUIRES messages carry) is returned
+ *     by tfc_last_error() on the calling thread.
+ *   - A handle must not be used from two host threads at once (the reference
+ *     handles are single-consumer too, cc/ops/range_coder_ops.cc:94-95).
+ */
+#ifndef TFC_HIP_H_
+#define TFC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfc_tables tfc_tables;
+typedef struct tfc_encoder tfc_encoder;
+typedef struct tfc_decoder tfc_decoder;
+
+/* Library identity; bumps when the ABI changes. */
+int tfc_abi_version(void);
+/* Text of the last failure on this thread ("" if none). */
+const char* tfc_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* CDF tables                                                               */
+/* ------------------------------------------------------------------------ */
+
+/* Validates `lookup` and uploads it in the device layout the coders use.
+ * Replaces ScanCDF / IndexCDFVector / IndexCDFMatrix
+ * (cc/kernels/range_coder_kernels.cc:101-164): rank 1 = ragged concatenation
+ * of rows [+-precision, 0, ..., 1<<precision]; rank 2 = [rows, cols], rows
+ * padded with 1<<precision.  Negative precision enables the Elias-gamma
+ * escape for that row.  `lookup` is HOST (rank 1: cols ints; rank 2:
+ * rows*cols ints).  Synchronises on `stream` for the upload. */
+int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, int64_t cols,
+                      void* stream, tfc_tables** out);
+int64_t tfc_tables_count(const tfc_tables* t);
+void tfc_tables_destroy(tfc_tables* t);
+
+/* ------------------------------------------------------------------------ */
+/* Multi-stream range encoder (one independent code stream per handle       */
+/* element)                                                                 */
+/* ------------------------------------------------------------------------ */
+
+/* CreateRangeEncoder — cc/ops/range_coder_ops.cc:28-67,
+ * cc/kernels/range_coder_kernels.cc:484-507.  `streams` = number of elements
+ * of the handle shape. */
+int tfc_encoder_create(const tfc_tables* tables, int64_t streams, void* stream,
+                       tfc_encoder** out);
+
+/* EntropyEncodeChannel (index == NULL) / EntropyEncodeIndex —
+ * cc/ops/range_coder_ops.cc:69-127, cc/kernels/range_coder_kernels.cc:191-272,
+ * 290-322.  value/index: DEV int32 [streams, elems] row-major.  Appends to
+ * every stream; may be called repeatedly on one handle.  Range errors
+ * ("index=… not in range", "value=… not in range") are detected by a
+ * validation pass before anything is appended; this call synchronises once to
+ * read the pass result (and the exact output bound). */
+int tfc_encoder_encode(tfc_encoder* e, const int32_t* value, const int32_t* index,
+                       int64_t elems, void* stream);
+
+/* Fused quantise + encode, channel mode:
+ *   sym = int32(rint(y - qoffset[c])) - cdf_offset[c],  c = j mod channels
+ * i.e. ContinuousBatchedEntropyModel.compress's prologue
+ * (python/entropy_models/continuous_batched.py:370-380) folded into the
+ * coder's load.  y: DEV [streams, elems], dtype 0 = float32, 1 = bfloat16,
+ * 2 = float16.  qoffset: DEV float32 [channels] or NULL; cdf_offset: DEV int32
+ * [channels]. */
+int tfc_encoder_encode_quantized(tfc_encoder* e, const void* y, int dtype,
+                                 const float* qoffset, const int32_t* cdf_offset,
+                                 int64_t channels, int64_t elems, void* stream);
+
+/* Fused quantise + encode, index mode
+ * (python/entropy_models/continuous_indexed.py:355-386):
+ *   sym = int32(rint(y)) - cdf_offset[index]. */
+int tfc_encoder_encode_quantized_indexed(tfc_encoder* e, const void* y, int dtype,
+                                         const int32_t* index, const int32_t* cdf_offset,
+                                         int64_t elems, void* stream);
+
+/* EntropyEncodeFinalize — cc/ops/range_coder_ops.cc:129-135,
+ * cc/kernels/range_coder_kernels.cc:274-287 + cc/lib/range_coder.cc:266-307.
+ * Flushes every stream, packs the streams back to back and returns the total
+ * byte count.  Synchronises. */
+int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total_bytes);
+
+/* After finalize: device views of the packed result (owned by the handle):
+ * blob DEV uint8 [total_bytes], offsets DEV int64 [streams + 1]. */
+int tfc_encoder_result(const tfc_encoder* e, const uint8_t** blob, const int64_t** offsets);
+/* After finalize: copies the result out.  dst_on_device selects hipMemcpy
+ * direction.  Synchronises when copying to the host. */
+int tfc_encoder_read(const tfc_encoder* e, uint8_t* blob_dst, int64_t* offsets_dst,
+                     int dst_on_device, void* stream);
+void tfc_encoder_destroy(tfc_encoder* e);
+
+/* ------------------------------------------------------------------------ */
+/* Multi-stream range decoder                                               */
+/* ------------------------------------------------------------------------ */
+
+/* CreateRangeDecoder — cc/ops/range_coder_ops.cc:137-153,
+ * cc/kernels/range_coder_kernels.cc:597-619.  blob/offsets describe `streams`
+ * byte strings (offsets int64 [streams+1]); src_on_device says where they
+ * live.  The decoder keeps its own device copy (the reference ref-holds the
+ * tensor instead, range_coder_kernels.cc:475-478). */
+int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob, const int64_t* offsets,
+                       int64_t streams, int src_on_device, void* stream, tfc_decoder** out);
+
+/* EntropyDecodeChannel (index == NULL) / EntropyDecodeIndex —
+ * cc/ops/range_coder_ops.cc:155-237, cc/kernels/range_coder_kernels.cc:360-429,
+ * 449-471.  index DEV int32 [streams, elems] or NULL; out DEV int32
+ * [streams, elems].  Continues where the previous decode call stopped. */
+int tfc_decoder_decode(tfc_decoder* d, const int32_t* index, int32_t* out, int64_t elems,
+                       void* stream);
+
+/* Fused decode + dequantise (continuous_batched.py:416-422 /
+ * continuous_indexed.py:411-417):
+ *   y = float(sym + cdf_offset[c or index]) + (qoffset ? qoffset[c] : 0)
+ * written as `dtype`.  Channel mode when index == NULL (then `channels` is the
+ * table count), else index mode (qoffset must be NULL). */
+int tfc_decoder_decode_dequantized(tfc_decoder* d, const int32_t* index, void* y, int dtype,
+                                   const float* qoffset, const int32_t* cdf_offset,
+                                   int64_t channels, int64_t elems, void* stream);
+
+/* EntropyDecodeFinalize — cc/ops/range_coder_ops.cc:239-246,
+ * cc/lib/range_coder.h:144-169.  ok: HOST uint8 [streams] (1 = the weak
+ * end-of-stream check passed).  Also reports a deferred "index=… not in
+ * range" failure of a previous decode call.  Synchronises. */
+int tfc_decoder_finalize(tfc_decoder* d, uint8_t* ok, void* stream);
+void tfc_decoder_destroy(tfc_decoder* d);
+
+/* ------------------------------------------------------------------------ */
+/* Deprecated single-stream ops                                             */
+/* ------------------------------------------------------------------------ */
+
+/* RangeEncode — cc/ops/range_coding_ops.cc:30-90,
+ * cc/kernels/range_coding_kernels.cc:175-275 (+ MergeAxes,
+ * range_coding_kernels_util.cc:34-91).  data DEV int16 with shape
+ * data_shape[nd]; cdf DEV int32 with shape cdf_shape[nd+1], broadcastable to
+ * data_shape + [width].  Returns the encoded string in a malloc'ed HOST buffer
+ * (*out, *out_len) which the caller frees with tfc_free().  Synchronises. */
+int tfc_range_encode(const int16_t* data, const int64_t* data_shape, int nd,
+                     const int32_t* cdf, const int64_t* cdf_shape, int nc,
+                     int precision, int debug_level, void* stream,
+                     uint8_t** out, int64_t* out_len);
+
+/* RangeDecode — cc/ops/range_coding_ops.cc:92-124,
+ * cc/kernels/range_coding_kernels.cc:277-379.  encoded HOST bytes; out DEV
+ * int16 of shape out_shape[nd]. */
+int tfc_range_decode(const uint8_t* encoded, int64_t encoded_len, const int64_t* out_shape,
+                     int nd, const int32_t* cdf, const int64_t* cdf_shape, int nc,
+                     int precision, int debug_level, void* stream, int16_t* out);
+
+void tfc_free(void* p);
+
+/* ------------------------------------------------------------------------ */
+/* PmfToQuantizedCdf                                                        */
+/* ------------------------------------------------------------------------ */
+
+/* cc/ops/pmf_to_cdf_ops.cc:28-57, cc/kernels/pmf_to_cdf_kernels.cc:58-208.
+ * pmf DEV float32 [rows, n] -> cdf DEV int32 [rows, n+1]; every symbol >= 1,
+ * cdf[:,0] = 0, cdf[:,n] = 1 << precision.  Ties between equal penalties are
+ * broken towards the lower symbol index (the reference's own tie order is
+ * libstdc++-specific and disclaimed, pmf_to_cdf_ops.cc:45-49). */
+int tfc_pmf_to_quantized_cdf(const float* pmf, int64_t rows, int64_t n, int precision,
+                             int32_t* cdf, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* GDN / IGDN                                                               */
+/* ------------------------------------------------------------------------ */
+
+/* GDN.call — python/layers/gdn.py:371-421 with channels_last layout:
+ *   u = |x|^alpha (alpha_mode 1) or x^2 (alpha_mode 2); rectify => x = max(x,0) first
+ *   n_i = beta_i + sum_j gamma[j,i] u_j
+ *   y_i = x_i / n_i^eps  (inverse=0)   or   x_i * n_i^eps (inverse=1)
+ * eps_mode 0: eps = 1; 1: eps = 0.5.  x,y DEV [pixels, channels] dtype (0 f32,
+ * 1 bf16); beta DEV f32 [channels]; gamma DEV f32 [channels(in j), channels(out i)]. */
+int tfc_gdn_forward(const void* x, void* y, int dtype, int64_t pixels, int64_t channels,
+                    const float* beta, const float* gamma, int inverse, int rectify,
+                    int alpha_mode, int eps_mode, void* stream);
+
+/* Backward of the above (the reference relies on TF autodiff).  g = dL/dy.
+ * Outputs: dx (dtype) and float32 accumulators dbeta [channels], dgamma
+ * [channels, channels] which are ADDED to (caller zeroes them). */
+int tfc_gdn_backward(const void* x, const void* g, void* dx, int dtype, int64_t pixels,
+                     int64_t channels, const float* beta, const float* gamma, int inverse,
+                     int rectify, int alpha_mode, int eps_mode, float* dbeta, float* dgamma,
+                     void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* SignalConv2D (same_zeros, explicit padding, NHWC, non-separable)         */
+/* ------------------------------------------------------------------------ */
+
+/* _correlate_down_explicit — python/layers/signal_conv.py:663-690:
+ * cross-correlation with zero padding (k/2, (k-1)/2) and stride `stride`;
+ * out = ceil(in / stride).  x DEV [N,H,W,Cin], w DEV [kh,kw,Cin,Cout] (HWIO),
+ * bias DEV f32 [Cout] or NULL, y DEV [N,ceil(H/s),ceil(W/s),Cout]; dtype 0 f32,
+ * 1 bf16 (weights in the same dtype). */
+int tfc_conv2d_down(const void* x, const void* w, const float* bias, void* y, int dtype,
+                    int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout,
+                    int kh, int kw, int stride, void* stream);
+
+/* _up_convolve_transpose_explicit — python/layers/signal_conv.py:778-847:
+ * zero-insertion upsampling by `stride` followed by a true convolution centred
+ * at k/2; out = in * stride.  w DEV [kh,kw,Cout,Cin] as the reference stores
+ * it for transposed use is NOT assumed: pass HWIO [kh,kw,Cin,Cout] of the
+ * equivalent forward kernel; the library does the flip/phase split. */
+int tfc_conv2d_up(const void* x, const void* w, const float* bias, void* y, int dtype,
+                  int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout,
+                  int kh, int kw, int stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFC_HIP_H_ */

@@ -1,0 +1,163 @@
+"""TEST INFRASTRUCTURE — regenerates tests/golden/*.npz from the reference's own
+range coder core (oracle/_ref/libtfc_ref.so, compiled verbatim from
+/root/reference/tensorflow_compression/cc/lib/range_coder.cc).
+
+Run in the build container (needs /root/reference):  python oracle/make_golden.py
+The vectors are committed so that the GPU box (no /root/reference) and the
+CPU test tier can pin both the restated oracle and the HIP kernels to bytes the
+reference itself produced.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle  # noqa: E402
+from compression_amd import synthetic  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def mt19937_mod5(n):
+    """std::mt19937(0)() % 5 sequence (numpy's MT19937 with seed 0 via init_genrand matches)."""
+    # numpy's legacy seeding uses init_genrand(seed) == std::mt19937(seed).
+    rs = np.random.RandomState(0)
+    # RandomState.randint consumes differently; draw raw 32-bit outputs instead.
+    raw = rs.bytes(4 * n)
+    vals = np.frombuffer(raw, dtype="<u4")
+    return (vals % 5).astype(np.int32)
+
+
+def main():
+    ref = oracle.reference()
+    assert ref is not None, "oracle/_ref not built (needs /root/reference)"
+    os.makedirs(GOLD, exist_ok=True)
+
+    # ---- K1..K7: raw-call known answers --------------------
+    kats = {}
+
+    def add(name, lower, upper, precision):
+        lower = np.asarray(lower, np.int32)
+        upper = np.asarray(upper, np.int32)
+        precision = np.broadcast_to(np.asarray(precision, np.int32), lower.shape).copy()
+        data = ref.raw_encode(lower, upper, precision)
+        kats[name + "_lower"] = lower
+        kats[name + "_upper"] = upper
+        kats[name + "_precision"] = precision
+        kats[name + "_bytes"] = np.frombuffer(data, np.uint8).copy()
+        return data
+
+    def add_syms(name, cdf, precision, syms):
+        cdf = np.asarray(cdf, np.int32)
+        syms = np.asarray(syms, np.int32)
+        kats[name + "_cdf"] = cdf
+        kats[name + "_syms"] = syms
+        return add(name, cdf[syms], cdf[syms + 1], precision)
+
+    k1 = add("K1", [16], [18], 5)
+    k2 = add("K2", [], [], 1)
+    k3 = add_syms("K3", [0, 1, 2], 1, [int(c) for c in "10110010111000011010"])
+    k4 = add_syms("K4", [0, 4000, 4050, 4090, 4096], 12, [int(c) for c in "0001002030000100"])
+    k5 = add_syms("K5", [0, 1, 65535, 65536], 16, [int(c) for c in "111101121100221"])
+    k6 = add_syms("K6", [0, 1, 2, 4096], 12, [0 if i % 7 == 3 else 2 for i in range(40)])
+    k7 = add_syms("K7", [0, 100, 1000, 3000, 4000, 4096], 12, mt19937_mod5(100000))
+    print("K1", k1.hex(), "K2", k2.hex(), "K3", k3.hex(), "K4", k4.hex())
+    print("K5", k5.hex(), "K6", k6.hex(), "K7", len(k7), "bytes crc32=%08x" % zlib.crc32(k7))
+    # The survey recorded these from the same compiled reference:
+    assert k1.hex() == "80" and k2.hex() == "" and k3.hex() == "b2e1a0"
+    assert k4.hex() == "eb99fb9f" and k5.hex() == "0004ffe9001dffe8fff0ffff01"
+    assert k6.hex() == "005ffff6be4fdc0533"
+    np.savez_compressed(os.path.join(GOLD, "kat_raw.npz"), **kats)
+
+    # ---- multi-stream channel / index cases with escapes ------------------
+    port = oracle.port()
+    pmfs, minima = synthetic.gaussian_pmfs(num_tables=24, octave=3.0)   # sigma .25 .. 51
+    cdfs = [port.pmf_to_quantized_cdf(p, 12) for p in pmfs]
+    lookup = synthetic.assemble_lookup(cdfs, 12, overflow=True)
+    val = synthetic.sample_symbols(lookup, streams=6, elems=1000, seed=11, escape_fraction=0.02)
+    strings, blob, offs = ref.encode(lookup, val, threads=1)
+    dec, ok = ref.decode(lookup, strings, 1000)
+    assert (dec == val).all() and ok.all()
+    rng = np.random.Generator(np.random.PCG64(5))
+    idx = rng.integers(0, 24, size=val.shape).astype(np.int32)
+    val_i = np.zeros_like(val)
+    rows = synthetic.lookup_rows(lookup)
+    for t, (sp, cdf) in enumerate(rows):
+        m = idx == t
+        u = rng.integers(0, 1 << 12, size=int(m.sum()))
+        s = np.minimum(np.searchsorted(cdf, u, side="right") - 1, len(cdf) - 3)
+        val_i[m] = np.maximum(s, 0)
+    esc = rng.random(val.shape) < 0.02
+    val_i = np.where(esc, rng.integers(-3000, 3000, size=val.shape), val_i).astype(np.int32)
+    strings_i, blob_i, offs_i = ref.encode(lookup, val_i, index=idx, threads=1)
+    dec_i, ok_i = ref.decode(lookup, strings_i, 1000, index=idx)
+    assert (dec_i == val_i).all() and ok_i.all()
+    np.savez_compressed(
+        os.path.join(GOLD, "streams_escape.npz"), lookup=lookup, value=val, blob=blob, offsets=offs,
+        index=idx, value_indexed=val_i, blob_indexed=blob_i, offsets_indexed=offs_i)
+
+    # ---- precision sweep, 2-D (matrix) lookup, no escapes -----------------
+    sweep = {}
+    for prec in (1, 2, 5, 8, 12, 16):
+        rng = np.random.Generator(np.random.PCG64(100 + prec))
+        nsym = min(1 << prec, 40)
+        rowsM = []
+        for _ in range(5):
+            w = rng.random(nsym) ** 3 + 1e-3
+            pmf = (w / w.sum()).astype(np.float32)
+            rowsM.append(port.pmf_to_quantized_cdf(pmf, prec))
+        width = nsym + 2
+        mat = np.full((5, width), 1 << prec, np.int32)
+        for r, c in enumerate(rowsM):
+            mat[r, 0] = prec
+            mat[r, 1:1 + len(c)] = c
+        v = np.empty((3, 777), np.int32)
+        for j in range(777):
+            c = rowsM[j % 5]
+            u = rng.integers(0, 1 << prec, size=3)
+            v[:, j] = np.searchsorted(c, u, side="right") - 1
+        strs, b, o = ref.encode(mat, v)
+        d, okk = ref.decode(mat, strs, 777)
+        assert (d == v).all() and okk.all()
+        sweep[f"p{prec}_lookup"] = mat
+        sweep[f"p{prec}_value"] = v
+        sweep[f"p{prec}_blob"] = b
+        sweep[f"p{prec}_offsets"] = o
+    np.savez_compressed(os.path.join(GOLD, "precision_sweep.npz"), **sweep)
+
+    # ---- legacy RangeEncode with broadcasting -----------------------------
+    leg = {}
+    rng = np.random.Generator(np.random.PCG64(77))
+
+    def hist_cdf(shape, m, prec):
+        w = rng.random(shape + (m,)) + 0.05
+        pmf = (w / w.sum(-1, keepdims=True)).astype(np.float32)
+        return port.pmf_to_quantized_cdf(pmf, prec)
+
+    cases = {
+        "nobroadcast": ((4, 5, 6), (4, 5, 6)),
+        "bcast1": ((4, 5, 6), (4, 1, 6)),
+        "bcast2": ((3, 4, 5, 2), (1, 4, 1, 2)),
+        "bcastall": ((7, 9), (1, 1)),
+    }
+    for name, (dshape, cshape) in cases.items():
+        m, prec = 9, 10
+        cdf = hist_cdf(cshape, m, prec)
+        full = np.broadcast_to(cdf, dshape + (m + 1,))
+        u = rng.integers(0, 1 << prec, size=dshape)
+        data = (np.sum(full[..., 1:] <= u[..., None], axis=-1)).astype(np.int16)
+        enc = ref.range_encode(data, cdf, prec)
+        back = ref.range_decode(enc, dshape, cdf, prec)
+        assert (back == data).all()
+        leg[name + "_data"] = data
+        leg[name + "_cdf"] = cdf
+        leg[name + "_precision"] = np.int32(prec)
+        leg[name + "_bytes"] = np.frombuffer(enc, np.uint8).copy()
+    np.savez_compressed(os.path.join(GOLD, "legacy_broadcast.npz"), **leg)
+    print("golden vectors written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

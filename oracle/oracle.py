@@ -1,0 +1,228 @@
+"""TEST INFRASTRUCTURE — ctypes front-end for the CPU oracle libraries.
+
+Not product code: only tests/, bench.py's ``cpu_baseline`` leg and
+``__graft_entry__.smoke()`` may import this module.
+
+Two libraries share one C surface (see oracle/tfc_oracle.cc):
+
+* ``libtfc_oracle.so``   — the restated algorithm (symbols ``tfco_*``)
+* ``_ref/libtfc_ref.so`` — the reference's own ``cc/lib/range_coder.cc`` compiled
+  verbatim behind the restated op drivers (symbols ``tfcr_*``); only present
+  where it was built from ``/root/reference``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_i16p = C.POINTER(C.c_int16)
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+
+
+def build(force: bool = False) -> None:
+    """Builds the oracle (and oracle/_ref when /root/reference is present)."""
+    target = os.path.join(_HERE, "libtfc_oracle.so")
+    if force or not os.path.exists(target) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(target)
+        for f in ("tfc_oracle.cc", "coder_core.h", "drivers.h", "pmf_to_cdf.h")
+    ):
+        subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
+    elif os.path.isdir("/root/reference") and not os.path.exists(
+        os.path.join(_HERE, "_ref", "libtfc_ref.so")
+    ):
+        subprocess.run(["make", "-C", _HERE, "ref"], check=True, capture_output=True)
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ) if a is not None else None
+
+
+class CoderLib:
+    """One of the two oracle libraries, addressed by symbol prefix."""
+
+    def __init__(self, path: str, prefix: str):
+        self.path = path
+        self.kind = "reference" if prefix == "tfcr_" else "port"
+        self._l = C.CDLL(path)
+        self._p = prefix
+        f = self._f
+        f("last_error", C.c_char_p)
+        f("raw_encode", C.c_int64, C.c_int64, _i32p, _i32p, _i32p, _u8p, C.c_int64)
+        f("raw_decode", C.c_int, _u8p, C.c_int64, _i32p, C.c_int64, C.c_int, C.c_int64, _i32p)
+        f("encoder_create", C.c_void_p, _i32p, C.c_int, C.c_int64, C.c_int64, C.c_int64)
+        f("encoder_encode", C.c_int, C.c_void_p, _i32p, _i32p, C.c_int64, C.c_int)
+        f("encoder_finalize", C.c_int64, C.c_void_p)
+        f("encoder_output", None, C.c_void_p, _u8p, _i64p)
+        f("encoder_free", None, C.c_void_p)
+        f("decoder_create", C.c_void_p, _u8p, _i64p, C.c_int64, _i32p, C.c_int, C.c_int64, C.c_int64)
+        f("decoder_decode", C.c_int, C.c_void_p, _i32p, _i32p, C.c_int64, C.c_int)
+        f("decoder_finalize", None, C.c_void_p, _u8p)
+        f("decoder_free", None, C.c_void_p)
+        f("range_encode", C.c_int64, _i16p, _i64p, C.c_int, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int64)
+        f("range_decode", C.c_int, _u8p, C.c_int64, _i64p, C.c_int, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _i16p)
+        f("pmf_to_quantized_cdf", C.c_int, _f32p, C.c_int64, C.c_int64, C.c_int, _i32p)
+
+    def _f(self, name, restype, *argtypes):
+        fn = getattr(self._l, self._p + name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+        setattr(self, "_" + name, fn)
+
+    def _err(self) -> str:
+        return self._last_error().decode()
+
+    # -- raw calls ---------------------------------------------------------
+    def raw_encode(self, lower, upper, precision) -> bytes:
+        lower = np.ascontiguousarray(lower, np.int32)
+        upper = np.ascontiguousarray(upper, np.int32)
+        precision = np.ascontiguousarray(np.broadcast_to(precision, lower.shape), np.int32)
+        cap = 2 * lower.size + 16
+        out = np.zeros(cap, np.uint8)
+        n = self._raw_encode(lower.size, _ptr(lower, _i32p), _ptr(upper, _i32p),
+                             _ptr(precision, _i32p), _ptr(out, _u8p), cap)
+        assert n <= cap
+        return out[:n].tobytes()
+
+    def raw_decode(self, data: bytes, cdf, precision: int, n: int):
+        cdf = np.ascontiguousarray(cdf, np.int32)
+        buf = np.frombuffer(data, np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+        out = np.zeros(n, np.int32)
+        ok = self._raw_decode(_ptr(buf, _u8p), len(data), _ptr(cdf, _i32p), cdf.size,
+                              precision, n, _ptr(out, _i32p))
+        return out, bool(ok)
+
+    # -- multi-stream ops --------------------------------------------------
+    @staticmethod
+    def _lookup_args(lookup):
+        lookup = np.ascontiguousarray(lookup, np.int32)
+        if lookup.ndim == 1:
+            return lookup, 1, 1, lookup.shape[0]
+        if lookup.ndim == 2:
+            return lookup, 2, lookup.shape[0], lookup.shape[1]
+        return lookup, lookup.ndim, 0, 0
+
+    def encode(self, lookup, value, index=None, threads: int = 1, calls: int = 1):
+        """value/index: [streams, elems] int32. Returns (list[bytes], blob, offsets).
+
+        ``calls`` > 1 splits elems into that many consecutive encode calls on
+        the same handle (the append semantics of the reference handles)."""
+        lookup, rank, rows, cols = self._lookup_args(lookup)
+        value = np.ascontiguousarray(value, np.int32)
+        streams, elems = value.shape
+        if index is not None:
+            index = np.ascontiguousarray(index, np.int32)
+            assert index.shape == value.shape
+        h = self._encoder_create(_ptr(lookup, _i32p), rank, rows, cols, streams)
+        if not h:
+            raise ValueError(self._err())
+        try:
+            bounds = [elems * k // calls for k in range(calls + 1)]
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                v = np.ascontiguousarray(value[:, a:b])
+                ix = np.ascontiguousarray(index[:, a:b]) if index is not None else None
+                if self._encoder_encode(h, _ptr(v, _i32p), _ptr(ix, _i32p), b - a, threads):
+                    raise ValueError(self._err())
+            total = self._encoder_finalize(h)
+            blob = np.zeros(max(total, 1), np.uint8)
+            offs = np.zeros(streams + 1, np.int64)
+            self._encoder_output(h, _ptr(blob, _u8p), _ptr(offs, _i64p))
+        finally:
+            self._encoder_free(h)
+        blob = blob[:total]
+        strings = [blob[offs[i]:offs[i + 1]].tobytes() for i in range(streams)]
+        return strings, blob, offs
+
+    def decode(self, lookup, strings, elems: int, index=None, threads: int = 1):
+        """Returns (decoded [streams, elems] int32, ok [streams] bool)."""
+        lookup, rank, rows, cols = self._lookup_args(lookup)
+        streams = len(strings)
+        offs = np.zeros(streams + 1, np.int64)
+        offs[1:] = np.cumsum([len(s) for s in strings])
+        blob = np.frombuffer(b"".join(strings), np.uint8).copy() if offs[-1] else np.zeros(1, np.uint8)
+        if index is not None:
+            index = np.ascontiguousarray(index, np.int32)
+        h = self._decoder_create(_ptr(blob, _u8p), _ptr(offs, _i64p), streams,
+                                 _ptr(lookup, _i32p), rank, rows, cols)
+        if not h:
+            raise ValueError(self._err())
+        try:
+            out = np.zeros((streams, elems), np.int32)
+            if self._decoder_decode(h, _ptr(index, _i32p), _ptr(out, _i32p), elems, threads):
+                raise ValueError(self._err())
+            ok = np.zeros(streams, np.uint8)
+            self._decoder_finalize(h, _ptr(ok, _u8p))
+        finally:
+            self._decoder_free(h)
+        return out, ok.astype(bool)
+
+    # -- legacy ops --------------------------------------------------------
+    def range_encode(self, data, cdf, precision: int, debug_level: int = 1) -> bytes:
+        data = np.ascontiguousarray(data, np.int16)
+        cdf = np.ascontiguousarray(cdf, np.int32)
+        ds = np.array(data.shape, np.int64)
+        cs = np.array(cdf.shape, np.int64)
+        cap = 2 * data.size + 16
+        out = np.zeros(cap, np.uint8)
+        n = self._range_encode(_ptr(data, _i16p), _ptr(ds, _i64p), data.ndim, _ptr(cdf, _i32p),
+                               _ptr(cs, _i64p), cdf.ndim, precision, debug_level,
+                               _ptr(out, _u8p), cap)
+        if n < 0:
+            raise ValueError(self._err())
+        return out[:n].tobytes()
+
+    def range_decode(self, data: bytes, shape, cdf, precision: int, debug_level: int = 1):
+        cdf = np.ascontiguousarray(cdf, np.int32)
+        shape = tuple(int(s) for s in shape)
+        os_ = np.array(shape, np.int64)
+        cs = np.array(cdf.shape, np.int64)
+        buf = np.frombuffer(data, np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+        out = np.zeros(shape, np.int16)
+        rc = self._range_decode(_ptr(buf, _u8p), len(data), _ptr(os_, _i64p), len(shape),
+                                _ptr(cdf, _i32p), _ptr(cs, _i64p), cdf.ndim, precision,
+                                debug_level, _ptr(out, _i16p))
+        if rc:
+            raise ValueError(self._err())
+        return out
+
+    # -- tables ------------------------------------------------------------
+    def pmf_to_quantized_cdf(self, pmf, precision: int):
+        pmf = np.ascontiguousarray(pmf, np.float32)
+        n = pmf.shape[-1]
+        rows = int(np.prod(pmf.shape[:-1])) if pmf.ndim > 1 else 1
+        out = np.zeros((rows, n + 1), np.int32)
+        if self._pmf_to_quantized_cdf(_ptr(pmf, _f32p), rows, n, precision, _ptr(out, _i32p)):
+            raise ValueError(self._err())
+        return out.reshape(pmf.shape[:-1] + (n + 1,))
+
+
+_cache = {}
+
+
+def port() -> CoderLib:
+    """The restated-algorithm oracle."""
+    if "port" not in _cache:
+        build()
+        _cache["port"] = CoderLib(os.path.join(_HERE, "libtfc_oracle.so"), "tfco_")
+    return _cache["port"]
+
+
+def reference():
+    """The compiled reference core, or None when it was never built here."""
+    if "ref" not in _cache:
+        build()
+        p = os.path.join(_HERE, "_ref", "libtfc_ref.so")
+        _cache["ref"] = CoderLib(p, "tfcr_") if os.path.exists(p) else None
+    return _cache["ref"]
+
+
+def best() -> CoderLib:
+    """Reference build if available, else the restatement."""
+    return reference() or port()

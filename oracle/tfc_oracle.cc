@@ -1,0 +1,174 @@
+// TEST INFRASTRUCTURE — CPU oracle, not product code.
+//
+// extern "C" surface over drivers.h.  Built twice by oracle/Makefile:
+//   libtfc_oracle.so        restated core (coder_core.h), symbols tfco_*
+//   _ref/libtfc_ref.so      reference core compiled verbatim from
+//                           /root/reference (ref_core.h), symbols tfcr_*
+// Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() use it.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#ifdef TFC_USE_REF
+#include "ref_core.h"
+#define SYM(name) tfcr_##name
+using Core = tfc_oracle::RefCore;
+#else
+#include "coder_core.h"
+#define SYM(name) tfco_##name
+using Core = tfc_oracle::OracleCore;
+#endif
+#include "drivers.h"
+#include "pmf_to_cdf.h"
+
+using tfc_oracle::StreamDecoder;
+using tfc_oracle::StreamEncoder;
+
+static thread_local std::string g_err;
+
+struct EncHandle {
+  StreamEncoder<Core> impl;
+  std::vector<int64_t> offs;
+};
+struct DecHandle {
+  StreamDecoder<Core> impl;
+};
+
+extern "C" {
+
+const char* SYM(last_error)() { return g_err.c_str(); }
+
+// ---- raw coder calls (known-answer vectors) --------------------------------
+// Encodes n intervals [lower[i], upper[i]) / 2^precision[i]; returns the byte
+// count (bytes copied into out if it fits in cap).
+int64_t SYM(raw_encode)(int64_t n, const int32_t* lower, const int32_t* upper,
+                        const int32_t* precision, uint8_t* out, int64_t cap) {
+  typename Core::Enc e{};
+  std::string s;
+  for (int64_t i = 0; i < n; ++i) Core::encode(e, lower[i], upper[i], precision[i], &s);
+  Core::flush(e, &s);
+  if (static_cast<int64_t>(s.size()) <= cap && !s.empty()) std::memcpy(out, s.data(), s.size());
+  return static_cast<int64_t>(s.size());
+}
+
+// Decodes n symbols against one cdf (binary search); returns Finalize().
+int SYM(raw_decode)(const uint8_t* bytes, int64_t nbytes, const int32_t* cdf, int64_t cdf_n,
+                    int precision, int64_t n, int32_t* out) {
+  std::vector<uint8_t> copy(bytes, bytes + nbytes);
+  copy.push_back(0);
+  typename Core::Dec d;
+  Core::open(d, copy.data(), static_cast<size_t>(nbytes));
+  for (int64_t i = 0; i < n; ++i) out[i] = Core::decode(d, cdf, cdf_n, precision);
+  return Core::close(d) ? 1 : 0;
+}
+
+// ---- multi-stream encoder handle -------------------------------------------
+void* SYM(encoder_create)(const int32_t* lookup, int rank, int64_t rows, int64_t cols,
+                          int64_t streams) {
+  auto* h = new EncHandle;
+  if (!h->impl.init(lookup, rank, rows, cols, streams)) {
+    g_err = h->impl.err;
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+int SYM(encoder_encode)(void* handle, const int32_t* value, const int32_t* index,
+                        int64_t elems, int threads) {
+  auto* h = static_cast<EncHandle*>(handle);
+  if (!h->impl.encode(value, index, elems, threads)) { g_err = h->impl.err; return 1; }
+  return 0;
+}
+
+// Flushes every stream; returns total byte count.
+int64_t SYM(encoder_finalize)(void* handle) {
+  auto* h = static_cast<EncHandle*>(handle);
+  h->impl.finalize();
+  h->offs.assign(1, 0);
+  for (auto& s : h->impl.sink) h->offs.push_back(h->offs.back() + static_cast<int64_t>(s.size()));
+  return h->offs.back();
+}
+
+void SYM(encoder_output)(void* handle, uint8_t* blob, int64_t* offsets) {
+  auto* h = static_cast<EncHandle*>(handle);
+  std::memcpy(offsets, h->offs.data(), h->offs.size() * sizeof(int64_t));
+  for (size_t s = 0; s < h->impl.sink.size(); ++s)
+    if (!h->impl.sink[s].empty())
+      std::memcpy(blob + h->offs[s], h->impl.sink[s].data(), h->impl.sink[s].size());
+}
+
+void SYM(encoder_free)(void* handle) { delete static_cast<EncHandle*>(handle); }
+
+// ---- multi-stream decoder handle -------------------------------------------
+void* SYM(decoder_create)(const uint8_t* blob, const int64_t* offsets, int64_t streams,
+                          const int32_t* lookup, int rank, int64_t rows, int64_t cols) {
+  auto* h = new DecHandle;
+  if (!h->impl.init(blob, offsets, streams, lookup, rank, rows, cols)) {
+    g_err = h->impl.err;
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+int SYM(decoder_decode)(void* handle, const int32_t* index, int32_t* output, int64_t elems,
+                        int threads) {
+  auto* h = static_cast<DecHandle*>(handle);
+  if (!h->impl.decode(index, output, elems, threads)) { g_err = h->impl.err; return 1; }
+  return 0;
+}
+
+void SYM(decoder_finalize)(void* handle, uint8_t* ok) {
+  auto* h = static_cast<DecHandle*>(handle);
+  for (size_t s = 0; s < h->impl.dec.size(); ++s) ok[s] = Core::close(h->impl.dec[s]) ? 1 : 0;
+}
+
+void SYM(decoder_free)(void* handle) { delete static_cast<DecHandle*>(handle); }
+
+// ---- legacy single-stream ops ----------------------------------------------
+// Returns byte count (>= 0) or -1 on error.
+int64_t SYM(range_encode)(const int16_t* data, const int64_t* data_shape, int nd,
+                          const int32_t* cdf, const int64_t* cdf_shape, int nc, int precision,
+                          int debug_level, uint8_t* out, int64_t cap) {
+  std::string s, err;
+  if (!tfc_oracle::legacy_encode<Core>(data, data_shape, nd, cdf, cdf_shape, nc, precision,
+                                       debug_level, &s, &err)) {
+    g_err = err;
+    return -1;
+  }
+  if (static_cast<int64_t>(s.size()) <= cap && !s.empty()) std::memcpy(out, s.data(), s.size());
+  return static_cast<int64_t>(s.size());
+}
+
+int SYM(range_decode)(const uint8_t* bytes, int64_t nbytes, const int64_t* out_shape, int nd,
+                      const int32_t* cdf, const int64_t* cdf_shape, int nc, int precision,
+                      int debug_level, int16_t* out) {
+  std::string err;
+  if (!tfc_oracle::legacy_decode<Core>(bytes, nbytes, out_shape, nd, cdf, cdf_shape, nc,
+                                       precision, debug_level, out, &err)) {
+    g_err = err;
+    return 1;
+  }
+  return 0;
+}
+
+// ---- PmfToQuantizedCdf -----------------------------------------------------
+// pmf [rows, n] float32 -> cdf [rows, n + 1] int32.  Validation as in
+// pmf_to_cdf_kernels.cc:58-86.
+int SYM(pmf_to_quantized_cdf)(const float* pmf, int64_t rows, int64_t n, int precision,
+                              int32_t* cdf) {
+  if (!(0 < precision && precision <= 16)) { g_err = "`precision` must be in [1, 16]"; return 1; }
+  if (n <= 1) { g_err = "`pmf` size should be at least 2 in the last axis."; return 1; }
+  for (int64_t i = 0; i < rows * n; ++i)
+    if (!(std::isfinite(pmf[i]) && pmf[i] >= 0)) {
+      g_err = "`pmf` has non-finite or negative element";
+      return 1;
+    }
+  for (int64_t r = 0; r < rows; ++r)
+    tfc_oracle::pmf_row_to_cdf(pmf + r * n, n, precision, cdf + r * (n + 1));
+  return 0;
+}
+
+}  // extern "C"
