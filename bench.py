@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): Mpixels/s of the entropy-coding round trip
+(range encode + range decode, bit-exact) on MI355X, at BASELINE config 2:
+512 code streams x (16*16*192 = 49152) int32 latents = 512 images of 256x256,
+192 discretised-Gaussian tables of precision 12 (escape coding enabled).
+
+One "step" = one full pass of the hot path over the batch, inputs resident in
+HBM: CreateRangeEncoder -> EntropyEncodeChannel -> EntropyEncodeFinalize ->
+CreateRangeDecoder -> EntropyDecodeChannel -> EntropyDecodeFinalize, all through
+the C ABI (libtfc_hip.so).  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: the batch dimension shards (independent code streams), so every rank
+codes its own 512-stream shard (weak scaling); no data-path collective, only the
+barrier + max-reduce of the timing.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import compression_amd as tfc  # noqa: E402
+from compression_amd import _lib, synthetic  # noqa: E402
+
+STREAMS = 512
+CHANNELS = 192
+ELEMS = 16 * 16 * CHANNELS           # latents of one 256x256 image (bls2017 geometry)
+PIXELS_PER_STREAM = 256 * 256
+PRECISION = 12
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_tables(device):
+    """192 Gaussian tables through the PRODUCT table builder (HIP pmf_to_quantized_cdf)."""
+    pmfs, _ = synthetic.gaussian_pmfs(num_tables=CHANNELS)
+    cdfs = []
+    for p in pmfs:
+        c = tfc.pmf_to_quantized_cdf(torch.from_numpy(p).to(device), PRECISION)
+        cdfs.append(c.cpu().numpy())
+    return synthetic.assemble_lookup(cdfs, PRECISION, overflow=True)
+
+
+def profile_query(name):
+    ms = C.c_double()
+    n = C.c_int64()
+    _lib.lib().tfc_profile_query(name.encode(), C.byref(ms), C.byref(n))
+    return ms.value, n.value
+
+
+def one_step(lookup_t, value_t):
+    h = tfc.create_range_encoder([STREAMS], lookup_t)
+    h = tfc.entropy_encode_channel(h, value_t)
+    blob, offsets = tfc.gen_ops._finalize_device(h)
+    d = tfc.create_range_decoder((blob, offsets, (STREAMS,)), lookup_t)
+    d, decoded = tfc.entropy_decode_channel(d, [ELEMS], torch.int32)
+    ok = tfc.entropy_decode_finalize(d)
+    return blob, offsets, decoded, ok
+
+
+def cpu_baseline(lookup, value, blob_ref):
+    """Reference coder core (oracle/_ref) or its restatement on the host cores.
+    This is the ONLY place bench.py touches oracle/."""
+    from oracle import oracle
+    lib = oracle.best()
+    cores = os.cpu_count() or 1
+    # bounded sample: the full 512-stream batch, all host cores, median of 5 after a warm-up
+    times = []
+    strings = None
+    for rep in range(6):
+        t0 = time.perf_counter()
+        strings, blob, offs = lib.encode(lookup, value, threads=cores)
+        t1 = time.perf_counter()
+        dec, ok = lib.decode(lookup, strings, value.shape[1], threads=cores)
+        t2 = time.perf_counter()
+        if rep:
+            times.append((t2 - t0, t1 - t0, t2 - t1))
+    assert (dec == value).all() and ok.all()
+    identical = bool(blob.tobytes() == blob_ref)
+    rt = float(np.median([t[0] for t in times]))
+    pixels = value.shape[0] * PIXELS_PER_STREAM
+    t1c = time.perf_counter()
+    s1, _, _ = lib.encode(lookup, value[:8], threads=1)
+    lib.decode(lookup, s1, value.shape[1], threads=1)
+    one_thread = (8 * PIXELS_PER_STREAM / 1e6) / (time.perf_counter() - t1c)
+    return {
+        "value": round(pixels / 1e6 / rt, 2), "unit": "Mpixels/s", "cores": cores,
+        "kind": lib.kind,
+        "sample": f"full batch ({value.shape[0]} streams x {value.shape[1]} symbols), "
+                  f"encode+decode sharded over {cores} host threads, median of 5",
+        "encode_ms": round(1e3 * float(np.median([t[1] for t in times])), 2),
+        "decode_ms": round(1e3 * float(np.median([t[2] for t in times])), 2),
+        "one_thread_mpixels_s": round(one_thread, 2),
+        "bytes_identical_to_gpu": identical,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--escape-fraction", type=float, default=0.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    lookup = build_tables(device)
+    value = synthetic.sample_symbols(lookup, STREAMS, ELEMS, seed=rank,
+                                     escape_fraction=args.escape_fraction, escape_seed=1000 + rank)
+    lookup_t = torch.from_numpy(lookup)            # tables are uploaded once (cached per tensor)
+    value_t = torch.from_numpy(value).to(device)   # inputs resident in HBM
+
+    for _ in range(args.warmup):
+        one_step(lookup_t, value_t)
+
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    _lib.lib().tfc_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        blob, offsets, decoded, ok = one_step(lookup_t, value_t)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    enc_ms, enc_n = profile_query("enc_kernel")
+    dec_ms, dec_n = profile_query("dec_kernel")
+    _lib.lib().tfc_profile_enable(0)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity gate (outside the timed region): round trip is exact, sanity flags true
+    assert bool(ok.all()), "EntropyDecodeFinalize reported a failed stream"
+    assert torch.equal(decoded.reshape(STREAMS, ELEMS), value_t), "decode(encode(x)) != x"
+    total_bytes = int(offsets[-1].item())
+    blob_host = blob.cpu().numpy().tobytes()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        pixels_all = world * STREAMS * PIXELS_PER_STREAM
+        value_mpix = pixels_all / 1e6 / (elapsed / args.steps)
+        symbols = STREAMS * ELEMS
+        enc_avg = enc_ms / max(enc_n, 1)
+        dec_avg = dec_ms / max(dec_n, 1)
+        # algorithmic bytes per launch: encode reads 4 B/symbol and
+        # writes the code bytes; decode reads the code bytes and writes 4 B/symbol.
+        alg_dec = 4 * symbols + total_bytes
+        alg_enc = 4 * symbols + total_bytes
+        dom, dom_ms, dom_bytes = ("dec_kernel", dec_avg, alg_dec) if dec_avg >= enc_avg else (
+            "enc_kernel", enc_avg, alg_enc)
+        achieved = dom_bytes / 1e9 / (dom_ms / 1e3) if dom_ms > 0 else 0.0
+        out = {
+            "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
+            "value": round(value_mpix, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": "range_encode+range_decode, 512 streams x 49152 int32 latents "
+                            "(192ch x 16 x 16 = one 256x256 image each), 192 Gaussian tables, "
+                            "precision 12, escape coding enabled, per GPU",
+                "streams_per_gpu": STREAMS, "symbols_per_stream": ELEMS,
+                "escape_fraction": args.escape_fraction,
+                "parallelism": f"batch-sharded x{world}",
+            },
+            "bits_per_pixel": round(8.0 * total_bytes / (STREAMS * PIXELS_PER_STREAM), 5),
+            "bits_per_symbol": round(8.0 * total_bytes / symbols, 4),
+            "gsymbols_per_s_roundtrip": round(world * symbols / 1e9 / (elapsed / args.steps), 3),
+            "kernels_ms": {"enc_kernel": round(enc_avg, 4), "dec_kernel": round(dec_avg, 4)},
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "note": "latency-bound serial chain per stream (512 chains); see DESIGN.md",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(lookup, value, blob_host)
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,18 @@ struct DevBuf {
   template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Optional per-kernel timing (tfc_profile_enable): HIP events recorded on the
+// launch stream around the named kernel; read back by tfc_profile_query.
+struct KernelTimer {
+  const char* name;
+  hipStream_t st;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  KernelTimer(const char* name, hipStream_t st);
+  ~KernelTimer();
+};
+bool profiling_enabled();
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace tfc

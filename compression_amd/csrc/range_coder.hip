@@ -50,9 +50,74 @@ int fail(const char* fmt, ...) {
   return 1;
 }
 
+// ---- optional kernel timing --------------------------------------------------
+namespace {
+struct ProfileEntry {
+  std::string name;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+bool g_profile_on = false;
+std::vector<ProfileEntry>& profile_table() {
+  static std::vector<ProfileEntry> t;
+  return t;
+}
+ProfileEntry& profile_entry(const char* name) {
+  for (auto& e : profile_table())
+    if (e.name == name) return e;
+  profile_table().push_back(ProfileEntry{name, {}, 0, 0});
+  return profile_table().back();
+}
+}  // namespace
+
+bool profiling_enabled() { return g_profile_on; }
+
+KernelTimer::KernelTimer(const char* n, hipStream_t s) : name(n), st(s), on(g_profile_on) {
+  if (!on) return;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  (void)hipEventRecord(a, st);
+}
+
+KernelTimer::~KernelTimer() {
+  if (!on) return;
+  (void)hipEventRecord(b, st);
+  profile_entry(name).pending.emplace_back(a, b);
+}
+
 }  // namespace tfc
 
 using namespace tfc;
+
+extern "C" void tfc_profile_enable(int on) {
+  g_profile_on = on != 0;
+  if (on) {
+    for (auto& e : profile_table()) {
+      for (auto& p : e.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+      e.pending.clear();
+      e.total_ms = 0;
+      e.launches = 0;
+    }
+  }
+}
+
+extern "C" int tfc_profile_query(const char* kernel, double* total_ms, int64_t* launches) {
+  ProfileEntry& e = profile_entry(kernel);
+  for (auto& p : e.pending) {
+    float ms = 0;
+    if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+      e.total_ms += ms;
+      e.launches += 1;
+    }
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  e.pending.clear();
+  *total_ms = e.total_ms;
+  *launches = e.launches;
+  return 0;
+}
 
 // ===========================================================================
 // Tables
@@ -861,12 +926,15 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   p.chunk = ch.data.as<uint8_t>();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(e->streams, kWavesPerBlock));
-  if (lds) {
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_kernel<true, Src>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((enc_kernel<true, Src>), dim3(blocks), dim3(kBlock), lds, st, p, src);
-  } else {
-    hipLaunchKernelGGL((enc_kernel<false, Src>), dim3(blocks), dim3(kBlock), 0, st, p, src);
+  {
+    KernelTimer timer("enc_kernel", st);
+    if (lds) {
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_kernel<true, Src>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL((enc_kernel<true, Src>), dim3(blocks), dim3(kBlock), lds, st, p, src);
+    } else {
+      hipLaunchKernelGGL((enc_kernel<false, Src>), dim3(blocks), dim3(kBlock), 0, st, p, src);
+    }
   }
   TFC_HIP(hipGetLastError());
   e->chunks.push_back(std::move(ch));
@@ -1103,12 +1171,15 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   p.first_error = d->status.as<unsigned long long>();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
-  if (lds) {
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_kernel<true, Dst>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((dec_kernel<true, Dst>), dim3(blocks), dim3(kBlock), lds, st, p, dst);
-  } else {
-    hipLaunchKernelGGL((dec_kernel<false, Dst>), dim3(blocks), dim3(kBlock), 0, st, p, dst);
+  {
+    KernelTimer timer("dec_kernel", st);
+    if (lds) {
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_kernel<true, Dst>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL((dec_kernel<true, Dst>), dim3(blocks), dim3(kBlock), lds, st, p, dst);
+    } else {
+      hipLaunchKernelGGL((dec_kernel<false, Dst>), dim3(blocks), dim3(kBlock), 0, st, p, dst);
+    }
   }
   TFC_HIP(hipGetLastError());
   return 0;

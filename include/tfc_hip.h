@@ -34,6 +34,14 @@ int tfc_abi_version(void);
 /* Text of the last failure on this thread ("" if none). */
 const char* tfc_last_error(void);
 
+/* Diagnostics for bench.py: when enabled, the library brackets its main kernels
+ * ("enc_kernel", "dec_kernel", "gdn_forward", ...) with HIP events on the
+ * launch stream; tfc_profile_query returns the accumulated time and launch
+ * count of one kernel name (synchronises on the recorded events).  Enabling
+ * resets the counters. */
+void tfc_profile_enable(int on);
+int tfc_profile_query(const char* kernel, double* total_ms, int64_t* launches);
+
 /* ------------------------------------------------------------------------ */
 /* CDF tables                                                               */
 /* ------------------------------------------------------------------------ */
