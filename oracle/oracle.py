@@ -69,6 +69,9 @@ class CoderLib:
         f("range_encode", C.c_int64, _i16p, _i64p, C.c_int, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int64)
         f("range_decode", C.c_int, _u8p, C.c_int64, _i64p, C.c_int, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _i16p)
         f("pmf_to_quantized_cdf", C.c_int, _f32p, C.c_int64, C.c_int64, C.c_int, _i32p)
+        f("bench_roundtrip", C.c_int, _i32p, C.c_int, C.c_int64, C.c_int64, _i32p, C.c_int64,
+          C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+          _i64p, C.POINTER(C.c_int))
 
     def _f(self, name, restype, *argtypes):
         fn = getattr(self._l, self._p + name)
@@ -162,6 +165,23 @@ class CoderLib:
         finally:
             self._decoder_free(h)
         return out, ok.astype(bool)
+
+    def bench_roundtrip(self, lookup, value, threads: int, reps: int):
+        """Channel-mode encode+decode of value [streams, elems] on a persistent
+        pool of `threads` workers; returns (enc_seconds[reps], dec_seconds[reps],
+        total_bytes, all_ok)."""
+        lookup, rank, rows, cols = self._lookup_args(lookup)
+        value = np.ascontiguousarray(value, np.int32)
+        enc = (C.c_double * reps)()
+        dec = (C.c_double * reps)()
+        total = C.c_int64()
+        ok = C.c_int()
+        rc = self._bench_roundtrip(_ptr(lookup, _i32p), rank, rows, cols, _ptr(value, _i32p),
+                                   value.shape[0], value.shape[1], threads, reps, enc, dec,
+                                   C.byref(total), C.byref(ok))
+        if rc:
+            raise ValueError(self._err())
+        return np.array(enc[:]), np.array(dec[:]), int(total.value), bool(ok.value)
 
     # -- legacy ops --------------------------------------------------------
     def range_encode(self, data, cdf, precision: int, debug_level: int = 1) -> bytes:

@@ -172,3 +172,110 @@ int SYM(pmf_to_quantized_cdf)(const float* pmf, int64_t rows, int64_t n, int pre
 }
 
 }  // extern "C"
+
+// ---- timed round trip for bench.py's cpu_baseline ---------------------------
+// Mirrors how the reference ops run: streams sharded over a persistent pool of
+// `threads` workers (ThreadPool::ParallelFor over streams,
+// range_coder_kernels.cc:212-267,377-424), output buffers reused between
+// repetitions.  Times only the coding loops (encode: Encode+Finalize per
+// stream; decode: ctor+Decode+Finalize per stream), per repetition.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <thread>
+
+namespace {
+struct Gate {
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0, generation = 0, parties;
+  explicit Gate(int n) : parties(n) {}
+  void arrive() {
+    std::unique_lock<std::mutex> lk(m);
+    const int gen = generation;
+    if (++waiting == parties) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return gen != generation; });
+    }
+  }
+};
+}  // namespace
+
+extern "C" int SYM(bench_roundtrip)(const int32_t* lookup, int rank, int64_t rows, int64_t cols,
+                                    const int32_t* value, int64_t streams, int64_t elems,
+                                    int threads, int reps, double* enc_seconds,
+                                    double* dec_seconds, int64_t* total_bytes, int* all_ok) {
+  std::vector<tfc_oracle::TableRef> tables;
+  std::string err;
+  if (!tfc_oracle::scan_tables(lookup, rank, rows, cols, &tables, &err)) { g_err = err; return 1; }
+  threads = std::max(1, std::min<int>(threads, static_cast<int>(streams)));
+  std::vector<std::string> sink(streams);
+  std::vector<int32_t> decoded(static_cast<size_t>(streams) * elems);
+  std::vector<uint8_t> okv(streams, 0);
+  for (auto& s : sink) s.reserve(static_cast<size_t>(elems));
+  Gate gate(threads + 1);
+  const int64_t ntab = static_cast<int64_t>(tables.size());
+  auto worker = [&](int64_t lo, int64_t hi) {
+    for (int r = 0; r < reps; ++r) {
+      gate.arrive();  // start encode
+      for (int64_t s = lo; s < hi; ++s) {
+        typename Core::Enc e{};
+        std::string* out = &sink[s];
+        out->clear();
+        const int32_t* pv = value + s * elems;
+        int64_t ch = 0;
+        for (int64_t j = 0; j < elems; ++j, ++ch) {
+          if (ch >= ntab) ch = 0;
+          const tfc_oracle::TableRef& row = tables[ch];
+          if (row.p[0] > 0) Core::encode(e, row.p[pv[j] + 1], row.p[pv[j] + 2], row.p[0], out);
+          else StreamEncoder<Core>::escape_encode(e, out, row, pv[j]);
+        }
+        Core::flush(e, out);
+      }
+      gate.arrive();  // end encode
+      gate.arrive();  // start decode
+      for (int64_t s = lo; s < hi; ++s) {
+        typename Core::Dec d;
+        Core::open(d, reinterpret_cast<const uint8_t*>(sink[s].data()), sink[s].size());
+        int32_t* po = decoded.data() + s * elems;
+        int64_t ch = 0;
+        for (int64_t j = 0; j < elems; ++j, ++ch) {
+          if (ch >= ntab) ch = 0;
+          const tfc_oracle::TableRef& row = tables[ch];
+          po[j] = (row.p[0] > 0) ? Core::decode(d, row.p + 1, row.n - 1, row.p[0])
+                                 : StreamDecoder<Core>::escape_decode(d, row);
+        }
+        okv[s] = Core::close(d) ? 1 : 0;
+      }
+      gate.arrive();  // end decode
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int k = 0; k < threads; ++k)
+    pool.emplace_back(worker, streams * k / threads, streams * (k + 1) / threads);
+  using clk = std::chrono::steady_clock;
+  for (int r = 0; r < reps; ++r) {
+    auto t0 = clk::now();
+    gate.arrive();
+    gate.arrive();
+    auto t1 = clk::now();
+    gate.arrive();
+    gate.arrive();
+    auto t2 = clk::now();
+    (void)t0;
+    enc_seconds[r] = std::chrono::duration<double>(t1 - t0).count();
+    dec_seconds[r] = std::chrono::duration<double>(t2 - t1).count();
+  }
+  for (auto& th : pool) th.join();
+  int64_t total = 0;
+  for (auto& s : sink) total += static_cast<int64_t>(s.size());
+  *total_bytes = total;
+  int ok = 1;
+  for (int64_t s = 0; s < streams; ++s) ok &= okv[s];
+  ok &= std::memcmp(decoded.data(), value, sizeof(int32_t) * static_cast<size_t>(streams) * elems) == 0;
+  *all_ok = ok;
+  return 0;
+}
