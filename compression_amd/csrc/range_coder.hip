@@ -127,6 +127,7 @@ struct tfc_tables {
   std::vector<int32_t> host;       // raw lookup
   std::vector<int2> rows;          // (start of header, ints incl. header)
   DevBuf d_data, d_rows;
+  DevBuf d_fast;                   // same layout, cdf entries scaled to 16-bit precision
   int max_abs_prec = 0;
   bool any_escape = false;
   int64_t max_row = 0;
@@ -195,6 +196,18 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
   if (!t->rows.empty())
     TFC_HIP(hipMemcpyAsync(t->d_rows.p, t->rows.data(), sizeof(int2) * t->rows.size(),
                            hipMemcpyHostToDevice, st));
+  {
+    std::vector<int32_t> fast(t->host);
+    for (const int2& r : t->rows) {
+      const int sh = 16 - std::abs(t->host[r.x]);
+      for (int i = 1; i < r.y; ++i) fast[r.x + i] = t->host[r.x + i] << sh;
+    }
+    TFC_HIP(t->d_fast.alloc(sizeof(int32_t) * std::max<int64_t>(total, 1), st));
+    if (total)
+      TFC_HIP(hipMemcpyAsync(t->d_fast.p, fast.data(), sizeof(int32_t) * total,
+                             hipMemcpyHostToDevice, st));
+    TFC_HIP(hipStreamSynchronize(st));
+  }
   TFC_HIP(hipStreamSynchronize(st));
   *out = t.release();
   return 0;
@@ -216,6 +229,7 @@ constexpr size_t kLdsTableBytes = 144 * 1024;
 
 struct TableView {
   const int32_t* data;
+  const int32_t* fast;   // cdf entries pre-scaled to 16-bit precision (headers unchanged)
   const int2* rows;
   int ntab;
   int total;
@@ -278,8 +292,8 @@ struct Call {
   int32_t bad;          // 1: index out of range, 2: value out of range
 };
 
-template <typename TabFn>
-__device__ inline Call classify(const TabFn& T, const int2 row, int32_t v) {
+template <bool NORMALISED, typename TabFn>
+__device__ inline Call classify_impl(const TabFn& T, const int2 row, int32_t v) {
   Call c;
   c.gamma = 0;
   c.neg = 0;
@@ -303,10 +317,19 @@ __device__ inline Call classify(const TabFn& T, const int2 row, int32_t v) {
       sym = vmax;
     }
   }
-  const int sh = 16 - prec;
+  const int sh = NORMALISED ? 0 : 16 - prec;
   c.lo16 = T(row.x + 1 + sym) << sh;
   c.hi16 = T(row.x + 2 + sym) << sh;
   return c;
+}
+
+template <typename TabFn>
+__device__ inline Call classify(const TabFn& T, const int2 row, int32_t v) {
+  return classify_impl<false>(T, row, v);
+}
+template <typename TabFn>
+__device__ inline Call classify_normalised(const TabFn& T, const int2 row, int32_t v) {
+  return classify_impl<true>(T, row, v);
 }
 
 __device__ inline int escape_calls(int32_t gamma) {
@@ -351,7 +374,8 @@ __global__ void __launch_bounds__(256) enc_count_kernel(EncParams p, Src src) {
 }
 
 // calls[s] -> byte capacity 2*calls + 4 rounded to 16, exclusive scan -> off.
-__global__ void enc_offsets_kernel(const unsigned long long* calls, int64_t streams,
+__global__ void enc_offsets_kernel(const unsigned long long* calls, const uint4* state,
+                                   int held_digits, int64_t streams,
                                    long long* off, unsigned long long* total) {
   // single block; streams is usually 1e2..1e5
   __shared__ long long carry;
@@ -361,7 +385,12 @@ __global__ void enc_offsets_kernel(const unsigned long long* calls, int64_t stre
   for (int64_t base = 0; base < streams; base += 1024) {
     const int64_t i = base + threadIdx.x;
     long long cap = 0;
-    if (i < streams) cap = ((2 * static_cast<long long>(calls[i]) + 4 + 15) / 16) * 16;
+    if (i < streams) {
+      // 2 bytes per coder call, plus (fast kernels) the digits the previous calls held back
+      long long digits = static_cast<long long>(calls[i]);
+      if (held_digits) digits += 1 + static_cast<long long>(state[i].w);
+      cap = ((2 * digits + 4 + 15) / 16) * 16;
+    }
     tmp[threadIdx.x] = cap;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -521,6 +550,10 @@ __global__ void __launch_bounds__(kBlock) enc_kernel(EncParams p, Src src) {
   }
 }
 
+}  // namespace tfc
+#include "range_encoder_fast.h"
+namespace tfc {
+
 // ---- finalize -------------------------------------------------------------
 
 struct ChunkRef {
@@ -529,35 +562,58 @@ struct ChunkRef {
   const unsigned int* len;
 };
 
-// tail bytes per RangeEncoder::Finalize (range_coder.cc:266-307); one thread
-// per stream.  Also sums the stream's total length.
+// Tail of every stream per RangeEncoder::Finalize (range_coder.cc:266-307); one
+// thread per stream.  tail[s] = {head bytes (<= 2), 0xFFFF digits to insert,
+// end bytes (<= 2)}; also sums the stream's total length.
+//   generic kernels: state = (base, span-1, delay digit + 1, delayed bytes)
+//   fast kernels:    state = (base, span-1, valid<<31 | held digit, held 0xFFFF run)
+struct Tail {
+  unsigned char head[2];
+  unsigned char end[2];
+  unsigned int nhead, nend, run;
+};
+
 __global__ void enc_tail_kernel(const uint4* state, int64_t streams, const ChunkRef* chunks,
-                                int nchunks, uint8_t* tail, long long* length) {
+                                int nchunks, int fast_state, Tail* tail, long long* length) {
   const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (s >= streams) return;
   const uint4 st = state[s];
-  uint8_t t0 = 0, t1 = 0;
-  int nt = 0;
-  if (st.z != 0) {
-    t0 = (st.z >> 8) & 0xFF;
-    nt = 1;
-    if ((st.z & 0xFF) != 0) { t1 = st.z & 0xFF; nt = 2; }
+  Tail t;
+  t.nhead = t.nend = t.run = 0;
+  t.head[0] = t.head[1] = t.end[0] = t.end[1] = 0;
+  const bool state1 = static_cast<unsigned int>(st.x + st.y) < st.x;   // carry still undecided
+  unsigned int delay = 0;                                              // reference's delay_ & 0xFFFF
+  if (fast_state) {
+    if (state1) {
+      delay = (st.z & 0xFFFFu) + 1u;
+    } else if (st.z >> 31) {
+      t.head[0] = (st.z >> 8) & 0xFF;
+      t.head[1] = st.z & 0xFF;
+      t.nhead = 2;
+      t.run = st.w;
+    }
+  } else {
+    delay = st.z;
+  }
+  if (delay != 0) {
+    t.end[0] = (delay >> 8) & 0xFF;
+    t.nend = 1;
+    if ((delay & 0xFF) != 0) { t.end[1] = delay & 0xFF; t.nend = 2; }
   } else if (st.x != 0) {
     const unsigned int top = st.x + st.y;
     const unsigned int r24 = ((st.x - 1) >> 24) + 1;
     if (r24 <= (top >> 24)) {
-      t0 = r24 & 0xFF;
-      nt = 1;
+      t.end[0] = r24 & 0xFF;
+      t.nend = 1;
     } else {
       const unsigned int r16 = ((st.x - 1) >> 16) + 1;
-      t0 = (r16 >> 8) & 0xFF;
-      nt = 1;
-      if ((r16 & 0xFF) != 0) { t1 = r16 & 0xFF; nt = 2; }
+      t.end[0] = (r16 >> 8) & 0xFF;
+      t.nend = 1;
+      if ((r16 & 0xFF) != 0) { t.end[1] = r16 & 0xFF; t.nend = 2; }
     }
   }
-  tail[2 * s] = t0;
-  tail[2 * s + 1] = t1;
-  long long len = nt;
+  tail[s] = t;
+  long long len = static_cast<long long>(t.nhead) + 2ll * t.run + t.nend;
   for (int c = 0; c < nchunks; ++c) len += chunks[c].len[s];
   length[s] = len;
 }
@@ -588,13 +644,12 @@ __global__ void scan_lengths_kernel(const long long* length, int64_t streams, lo
 
 // One wave per stream: copy the stream's chunk pieces then its tail.
 __global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const ChunkRef* chunks,
-                                                         int nchunks, const uint8_t* tail,
+                                                         int nchunks, const Tail* tail,
                                                          const long long* off, uint8_t* blob) {
   const int lane = threadIdx.x & 63;
   const int64_t s = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (s >= streams) return;
   uint8_t* dst = blob + off[s];
-  const long long total = off[s + 1] - off[s];
   long long done = 0;
   for (int c = 0; c < nchunks; ++c) {
     const uint8_t* src = chunks[c].data + chunks[c].off[s];
@@ -602,8 +657,12 @@ __global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const
     for (unsigned int i = lane; i < n; i += 64) dst[done + i] = src[i];
     done += n;
   }
-  const long long nt = total - done;
-  if (lane < nt) dst[done + lane] = tail[2 * s + lane];
+  const Tail t = tail[s];
+  if (lane < static_cast<int>(t.nhead)) dst[done + lane] = t.head[lane];
+  done += t.nhead;
+  for (unsigned long long i = lane; i < 2ull * t.run; i += 64) dst[done + i] = 0xFF;
+  done += 2ll * t.run;
+  if (lane < static_cast<int>(t.nend)) dst[done + lane] = t.end[lane];
 }
 
 // ---- decoder --------------------------------------------------------------
@@ -854,7 +913,11 @@ struct EncChunk {
 struct tfc_encoder {
   const tfc_tables* tables = nullptr;
   int64_t streams = 0;
+  bool fast = false;            // fast kernels (and their state encoding) are in use
+  int fast_waves = 0;           // waves per workgroup for the fast kernels
+  size_t fast_lds = 0;
   DevBuf state;                 // uint4 [streams]
+  DevBuf oflag;                 // unsigned int: a kernel ran out of slab space (internal error)
   std::vector<EncChunk> chunks;
   // results
   bool finalized = false;
@@ -872,6 +935,7 @@ size_t table_lds_bytes(const tfc_tables* t) {
 TableView view_of(const tfc_tables* t) {
   TableView v;
   v.data = t->d_data.as<int32_t>();
+  v.fast = t->d_fast.as<int32_t>();
   v.rows = t->d_rows.as<int2>();
   v.ntab = static_cast<int>(t->rows.size());
   v.total = static_cast<int>(t->host.size());
@@ -909,14 +973,15 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   p.chunk = nullptr;
   p.chunk_off = ch.off.as<long long>();
   p.chunk_len = ch.len.as<unsigned int>();
-  p.overflow_flag = reinterpret_cast<unsigned int*>(status.as<unsigned long long>() + 2);
+  p.overflow_flag = e->oflag.as<unsigned int>();
 
   const int64_t tiles = ceil_div(elems, 256);
   if (e->streams * tiles >= (int64_t{1} << 31)) return fail("encode call too large for one launch");
   hipLaunchKernelGGL((enc_count_kernel<Src>), dim3(static_cast<unsigned>(e->streams * tiles)),
                      dim3(256), 0, st, p, src);
-  hipLaunchKernelGGL(enc_offsets_kernel, dim3(1), dim3(1024), 0, st, p.calls, e->streams,
-                     ch.off.as<long long>(), status.as<unsigned long long>() + 1);
+  hipLaunchKernelGGL(enc_offsets_kernel, dim3(1), dim3(1024), 0, st, p.calls, p.state,
+                     e->fast ? 1 : 0, e->streams, ch.off.as<long long>(),
+                     status.as<unsigned long long>() + 1);
   unsigned long long host_status[3];
   TFC_HIP(hipMemcpyAsync(host_status, status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
   TFC_HIP(hipStreamSynchronize(st));
@@ -926,7 +991,15 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   p.chunk = ch.data.as<uint8_t>();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(e->streams, kWavesPerBlock));
-  {
+  if (e->fast) {
+    KernelTimer timer("enc_kernel", st);
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_fast_kernel<Src>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(e->fast_lds)));
+    hipLaunchKernelGGL((enc_fast_kernel<Src>),
+                       dim3(static_cast<unsigned>(ceil_div(e->streams, e->fast_waves))),
+                       dim3(64 * e->fast_waves), e->fast_lds, st, p, src);
+  } else {
     KernelTimer timer("enc_kernel", st);
     if (lds) {
       TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_kernel<true, Src>),
@@ -962,7 +1035,21 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
   std::unique_ptr<tfc_encoder> e(new tfc_encoder);
   e->tables = tables;
   e->streams = streams;
+  {
+    // LDS plan of enc_fast_kernel: tables + row directory + one call ring per wave.
+    const size_t fixed = sizeof(int32_t) * ((tables->host.size() + 1) & ~size_t{1}) +
+                         sizeof(int2) * tables->rows.size();
+    const size_t ring = sizeof(unsigned int) * kRingWords;
+    const char* force = std::getenv("TFC_FORCE_GENERIC");
+    if (!(force && force[0] == '1') && !tables->rows.empty() && fixed + ring <= 160 * 1024) {
+      e->fast = true;
+      e->fast_waves = static_cast<int>(std::min<size_t>(4, (160 * 1024 - fixed) / ring));
+      e->fast_lds = fixed + ring * e->fast_waves;
+    }
+  }
   TFC_HIP(e->state.alloc(sizeof(uint4) * std::max<int64_t>(streams, 1), st));
+  TFC_HIP(e->oflag.alloc(sizeof(unsigned int), st));
+  TFC_HIP(hipMemsetAsync(e->oflag.p, 0, sizeof(unsigned int), st));
   if (streams)
     hipLaunchKernelGGL(fill_state_kernel, dim3(static_cast<unsigned>(ceil_div(streams, 256))),
                        dim3(256), 0, st, e->state.as<uint4>(), streams,
@@ -1060,22 +1147,25 @@ extern "C" int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total
   if (!refs.empty())
     TFC_HIP(hipMemcpyAsync(d_refs.p, refs.data(), sizeof(ChunkRef) * refs.size(),
                            hipMemcpyHostToDevice, st));
-  TFC_HIP(tail.alloc(2 * n, st));
+  TFC_HIP(tail.alloc(sizeof(Tail) * n, st));
   TFC_HIP(length.alloc(sizeof(long long) * n, st));
   const unsigned tb = static_cast<unsigned>(ceil_div(n, 256));
   hipLaunchKernelGGL(enc_tail_kernel, dim3(tb), dim3(256), 0, st, e->state.as<uint4>(), n,
-                     d_refs.as<ChunkRef>(), static_cast<int>(refs.size()), tail.as<uint8_t>(),
-                     length.as<long long>());
+                     d_refs.as<ChunkRef>(), static_cast<int>(refs.size()), e->fast ? 1 : 0,
+                     tail.as<Tail>(), length.as<long long>());
   hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, length.as<long long>(), n,
                      e->offsets.as<long long>());
   long long total = 0;
+  unsigned int oflag = 0;
   TFC_HIP(hipMemcpyAsync(&total, e->offsets.as<long long>() + n, sizeof(long long),
                          hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipMemcpyAsync(&oflag, e->oflag.p, sizeof(oflag), hipMemcpyDeviceToHost, st));
   TFC_HIP(hipStreamSynchronize(st));
+  if (oflag) return fail("internal error: an encoder kernel ran out of output slab space");
   TFC_HIP(e->blob.alloc(static_cast<size_t>(total), st));
   hipLaunchKernelGGL(enc_pack_kernel, dim3(static_cast<unsigned>(ceil_div(n, kWavesPerBlock))),
                      dim3(kBlock), 0, st, n, d_refs.as<ChunkRef>(), static_cast<int>(refs.size()),
-                     tail.as<uint8_t>(), e->offsets.as<long long>(), e->blob.as<uint8_t>());
+                     tail.as<Tail>(), e->offsets.as<long long>(), e->blob.as<uint8_t>());
   TFC_HIP(hipGetLastError());
   TFC_HIP(hipStreamSynchronize(st));
   e->chunks.clear();
