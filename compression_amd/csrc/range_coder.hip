@@ -128,6 +128,9 @@ struct tfc_tables {
   std::vector<int2> rows;          // (start of header, ints incl. header)
   DevBuf d_data, d_rows;
   DevBuf d_fast;                   // same layout, cdf entries scaled to 16-bit precision
+  DevBuf d_dec_image, d_dec_dir;   // decoder LDS image: d_fast + pad + pivot arrays; row directory
+  int dec_words = 0;
+  bool dec_fast_ok = false;
   int max_abs_prec = 0;
   bool any_escape = false;
   int64_t max_row = 0;
@@ -206,6 +209,40 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
     if (total)
       TFC_HIP(hipMemcpyAsync(t->d_fast.p, fast.data(), sizeof(int32_t) * total,
                              hipMemcpyHostToDevice, st));
+    // Decoder image: the scaled table, 64 words of padding (lanes past a row's end
+    // read harmless data), then 64 pivots per wide row (> 64 symbols).
+    std::vector<int32_t> image(fast);
+    image.resize(image.size() + 64, 65536);
+    std::vector<int4> dir;
+    bool ok = true;
+    for (const int2& r : t->rows) {
+      const int nsym = r.y - 2;
+      const int cdf0 = r.x + 1;
+      const int chunk = (nsym + 63) / 64;
+      if (chunk > 64) ok = false;
+      int4 d;
+      d.y = cdf0;
+      d.z = nsym | (std::max(chunk, 1) << 16);
+      d.w = t->host[r.x] < 0 ? nsym - 1 : -1;
+      if (chunk <= 1) {
+        d.x = cdf0 + 1;
+      } else {
+        d.x = static_cast<int>(image.size());
+        for (int j = 0; j < 64; ++j)
+          image.push_back(fast[cdf0 + std::min((j + 1) * chunk, nsym)]);
+      }
+      dir.push_back(d);
+    }
+    image.resize(image.size() + 64, 65536);
+    t->dec_words = static_cast<int>(image.size());
+    t->dec_fast_ok = ok && !t->rows.empty();
+    TFC_HIP(t->d_dec_image.alloc(sizeof(int32_t) * image.size(), st));
+    TFC_HIP(t->d_dec_dir.alloc(sizeof(int4) * std::max<size_t>(dir.size(), 1), st));
+    TFC_HIP(hipMemcpyAsync(t->d_dec_image.p, image.data(), sizeof(int32_t) * image.size(),
+                           hipMemcpyHostToDevice, st));
+    if (!dir.empty())
+      TFC_HIP(hipMemcpyAsync(t->d_dec_dir.p, dir.data(), sizeof(int4) * dir.size(),
+                             hipMemcpyHostToDevice, st));
     TFC_HIP(hipStreamSynchronize(st));
   }
   TFC_HIP(hipStreamSynchronize(st));
@@ -227,9 +264,13 @@ constexpr int kBlock = kWavesPerBlock * 64;
 // Tables up to this many bytes are staged in LDS (160 KiB per CU on gfx950).
 constexpr size_t kLdsTableBytes = 144 * 1024;
 
+struct DecRow;
 struct TableView {
   const int32_t* data;
   const int32_t* fast;   // cdf entries pre-scaled to 16-bit precision (headers unchanged)
+  const int32_t* dec_image;   // decoder LDS image (see tfc_tables_create)
+  const struct DecRow* dec_dir;
+  int dec_words;
   const int2* rows;
   int ntab;
   int total;
@@ -859,6 +900,10 @@ __global__ void __launch_bounds__(kBlock) dec_kernel(DecParams p, Dst dst) {
   if (lane == 0) p.state[s] = make_uint4(st.base, st.span_m1, st.window, w.pulls);
 }
 
+}  // namespace tfc
+#include "range_decoder_fast.h"
+namespace tfc {
+
 // Reads the first four bytes of every stream (RangeDecoder ctor,
 // range_coder.h:79-83).
 __global__ void dec_open_kernel(const uint8_t* blob, const long long* off, int64_t streams,
@@ -936,6 +981,9 @@ TableView view_of(const tfc_tables* t) {
   TableView v;
   v.data = t->d_data.as<int32_t>();
   v.fast = t->d_fast.as<int32_t>();
+  v.dec_image = t->d_dec_image.as<int32_t>();
+  v.dec_dir = t->d_dec_dir.as<DecRow>();
+  v.dec_words = t->dec_words;
   v.rows = t->d_rows.as<int2>();
   v.ntab = static_cast<int>(t->rows.size());
   v.total = static_cast<int>(t->host.size());
@@ -1043,7 +1091,9 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
     const char* force = std::getenv("TFC_FORCE_GENERIC");
     if (!(force && force[0] == '1') && !tables->rows.empty() && fixed + ring <= 160 * 1024) {
       e->fast = true;
-      e->fast_waves = static_cast<int>(std::min<size_t>(4, (160 * 1024 - fixed) / ring));
+      const size_t fit = (160 * 1024 - fixed) / ring;
+      const size_t want = static_cast<size_t>(std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(streams, 256))));
+      e->fast_waves = static_cast<int>(std::min(fit, want));
       e->fast_lds = fixed + ring * e->fast_waves;
     }
   }
@@ -1261,7 +1311,18 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   p.first_error = d->status.as<unsigned long long>();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
-  {
+  const size_t fast_lds = sizeof(int32_t) * ((t->dec_words + 3) & ~3) + sizeof(int4) * t->rows.size();
+  const char* force = std::getenv("TFC_FORCE_GENERIC");
+  if (t->dec_fast_ok && fast_lds <= 160 * 1024 && !(force && force[0] == '1')) {
+    KernelTimer timer("dec_kernel", st);
+    const int waves = static_cast<int>(std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(d->streams, 256))));
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(fast_lds)));
+    hipLaunchKernelGGL((dec_fast_kernel<Dst>),
+                       dim3(static_cast<unsigned>(ceil_div(d->streams, waves))), dim3(64 * waves),
+                       fast_lds, st, p, dst);
+  } else {
     KernelTimer timer("dec_kernel", st);
     if (lds) {
       TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_kernel<true, Dst>),
