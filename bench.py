@@ -69,6 +69,33 @@ def one_step(lookup_t, value_t):
     return blob, offsets, decoded, ok
 
 
+def gdn_forward_bandwidth(device, steps=20):
+    """BASELINE config 3 (second half of the metric): GDN forward on
+    256 x 192 x 32 x 32 bf16 (NHWC [262144, 192]); algorithmic bytes = read x + write y."""
+    from compression_amd.layers import gdn_forward
+    torch.manual_seed(3)
+    C, M = 192, 256 * 32 * 32
+    x = torch.randn(M, C, device=device).bfloat16()
+    beta = 1 + 0.1 * torch.rand(C)
+    gamma = 0.1 * torch.eye(C) + 0.01 * torch.rand(C, C)
+    for _ in range(3):
+        y = gdn_forward(x, beta, gamma)
+    torch.cuda.synchronize()
+    _lib.lib().tfc_profile_enable(1)
+    for _ in range(steps):
+        y = gdn_forward(x, beta, gamma)
+    torch.cuda.synchronize()
+    ms, n = profile_query("gdn_forward")
+    _lib.lib().tfc_profile_enable(0)
+    avg_ms = ms / max(n, 1)
+    nbytes = 2 * x.numel() * x.element_size()
+    gbs = nbytes / 1e9 / (avg_ms / 1e3)
+    return {"workload": "GDN fwd, [262144, 192] bf16 (= 256x192x32x32), alpha=1, eps=1",
+            "kernel_ms": round(avg_ms, 4), "algorithmic_bytes": nbytes,
+            "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm"}
+
+
 def cpu_baseline(lookup, value, total_bytes_gpu):
     """Reference coder core (oracle/_ref) or its restatement on the host cores,
     sharded over streams like the reference's ThreadPool::ParallelFor.
@@ -201,6 +228,8 @@ def main():
                 "note": "latency-bound serial chain per stream (512 chains); see DESIGN.md",
             },
         }
+        if world == 1:
+            out["gdn_fwd"] = gdn_forward_bandwidth(device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(lookup, value, total_bytes)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)

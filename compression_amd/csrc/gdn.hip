@@ -1,0 +1,312 @@
+// GDN / IGDN forward for gfx950 (channels-last, [pixels, C]).
+//
+//   u = |x|^alpha,  n_i = beta_i + sum_j gamma[j][i] u_j,  y_i = x_i / n_i^eps  (GDN)
+//                                                      or  x_i * n_i^eps  (IGDN)
+// python/layers/gdn.py:371-421 runs this as 4-5 separate TF kernels (abs, 1x1
+// conv, bias_add, div), each streaming the whole tensor.  Here it is one kernel
+// whose HBM traffic is the algorithmic minimum (read x once, write y once):
+//
+//   * The contraction runs TRANSPOSED on the matrix cores: N^T = Gamma^T * U^T,
+//     A operand = Gamma^T (out-channel rows) from LDS, B operand = U^T whose
+//     fragment for lane l is 8 (bf16) / 1 (f32) channels of ONE pixel (l & 31) —
+//     i.e. plain contiguous loads from the NHWC tensor, no LDS staging.
+//   * The K (input-channel) order fed to the MFMA is permuted so that the
+//     channels a lane loads as B fragments are exactly the channels whose
+//     outputs land in that lane's accumulator registers
+//     (C/D map: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).
+//     The epilogue (add beta, reciprocal, multiply by x) therefore needs no
+//     transpose, no shuffle and no second read of x; y leaves with the same
+//     access pattern x came in with.
+//   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate), gamma rounded to bf16
+//     like a Keras mixed_bfloat16 policy would.  f32: v_mfma_f32_32x32x2_f32,
+//     bit-exact fp32 FMA chains (the <=1e-5 parity path).
+//
+// Roofline: HBM-bound, 2*sizeof(dtype) bytes per element.
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/tfc_hip.h"
+#include "common.h"
+
+namespace tfc {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct GdnParams {
+  const void* x;
+  void* y;
+  const float* beta;
+  const float* gamma;   // [C in j][C out i]
+  long long pixels;
+  int C;
+  int inverse, rectify, alpha2, eps_half;
+  long long tiles;      // ceil(pixels / 32)
+};
+
+__device__ inline float gdn_apply(float x, float n, int inverse, int eps_half) {
+  if (eps_half) n = __builtin_sqrtf(n);
+  return inverse ? x * n : x * __builtin_amdgcn_rcpf(n);
+}
+
+__device__ inline float bf16_bits_to_float(unsigned int bits16) { return __uint_as_float(bits16 << 16); }
+
+__device__ inline unsigned int float_to_bf16_bits(float f) {
+  // round to nearest even, NaN preserved (matches __float2bfloat16)
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// ---------------------------------------------------------------------------
+// bf16 I/O.  KT = C / 32 output tiles, KS = C / 16 K-steps.
+// LDS: A fragments of Gamma^T, fragment-ordered: [(t * KS + s) * 64 + lane][8].
+//   element e of lane (i = lane & 31, h = lane >> 5) at (t, s) is
+//   gamma[ch(s, h, e)][32 t + i],  ch(s, h, e) = 16 s + 4 h + (e & 3) + 8 (e >> 2).
+// ---------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
+  constexpr int C = KT * 32;
+  constexpr int KS = KT * 2;
+  extern __shared__ unsigned char smem[];
+  bf16x8* afrag = reinterpret_cast<bf16x8*>(smem);
+  float* beta_s = reinterpret_cast<float*>(smem + sizeof(bf16x8) * KT * KS * 64);
+
+  for (int idx = threadIdx.x; idx < KT * KS * 64; idx += blockDim.x) {
+    const int l = idx & 63, ts = idx >> 6;
+    const int t = ts / KS, s = ts % KS;
+    const int i = l & 31, h = l >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = 16 * s + 4 * h + (e & 3) + 8 * (e >> 2);
+      v[e] = static_cast<__bf16>(p.gamma[ch * C + 32 * t + i]);
+    }
+    afrag[idx] = v;
+  }
+  for (int i = threadIdx.x; i < C; i += blockDim.x) beta_s[i] = p.beta[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5;
+  const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = static_cast<long long>(gridDim.x) * (blockDim.x >> 6);
+  const unsigned short* x = static_cast<const unsigned short*>(p.x);
+  unsigned short* y = static_cast<unsigned short*>(p.y);
+
+  for (long long tile = wave; tile < p.tiles; tile += nwaves) {
+    const long long pix = tile * 32 + (lane & 31);
+    const bool live = pix < p.pixels;
+    const long long row = (live ? pix : p.pixels - 1) * C;
+    // ---- loads: for every K-step, channels 16s+4h+{0..3} and 16s+4h+8+{0..3} ----
+    u32x4 xr[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x2 a = *reinterpret_cast<const u32x2*>(x + row + 16 * s + 4 * h);
+      const u32x2 b = *reinterpret_cast<const u32x2*>(x + row + 16 * s + 4 * h + 8);
+      xr[s] = u32x4{a.x, a.y, b.x, b.y};
+    }
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      // u = |x| (clear sign bits), relu first if rectify, x*x if alpha == 2
+      u32x4 u = xr[s];
+      if (p.rectify || p.alpha2) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float lo = bf16_bits_to_float(u[w] & 0xFFFFu), hi = bf16_bits_to_float(u[w] >> 16);
+          if (p.rectify) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+          if (p.alpha2) { lo = lo * lo; hi = hi * hi; } else { lo = fabsf(lo); hi = fabsf(hi); }
+          u[w] = float_to_bf16_bits(lo) | (float_to_bf16_bits(hi) << 16);
+        }
+      } else {
+        u &= 0x7FFF7FFFu;
+      }
+      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[(t * KS + s) * 64 + lane], bfrag,
+                                                          acc[t], 0, 0, 0);
+      // keep the scheduler from hoisting every K-step's LDS fragment loads to the top
+      // (72 fragments = 288 VGPRs): one K-step's fragments at a time.
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: acc[t][4q + r] is channel 32t + 8q + 4h + r of this lane's pixel ----
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int t = s >> 1;
+      u32x4 out;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int q = 2 * (s & 1) + half;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+        float yv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned int word = xr[s][2 * half + (r >> 1)];
+          float xv = bf16_bits_to_float((r & 1) ? (word >> 16) : (word & 0xFFFFu));
+          if (p.rectify) xv = fmaxf(xv, 0.f);
+          yv[r] = gdn_apply(xv, acc[t][4 * q + r] + b4[r], p.inverse, p.eps_half);
+        }
+        out[2 * half] = float_to_bf16_bits(yv[0]) | (float_to_bf16_bits(yv[1]) << 16);
+        out[2 * half + 1] = float_to_bf16_bits(yv[2]) | (float_to_bf16_bits(yv[3]) << 16);
+      }
+      if (live) {
+        *reinterpret_cast<u32x2*>(y + row + 16 * s + 4 * h) = u32x2{out.x, out.y};
+        *reinterpret_cast<u32x2*>(y + row + 16 * s + 4 * h + 8) = u32x2{out.z, out.w};
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// f32 I/O, exact fp32 MFMA (v_mfma_f32_32x32x2_f32: K = 2 per instruction).
+// K index inside K-tile kt at step u (0..15), half h:  ch = 32 kt + 4 h + (u & 3) + 8 (u >> 2).
+// LDS: Gamma^T fragments [((t * KT + kt) * 4 + u4) * 64 + lane][4]  (4 consecutive steps u).
+// ---------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(512) gdn_fwd_f32_kernel(GdnParams p) {
+  constexpr int C = KT * 32;
+  extern __shared__ unsigned char smem[];
+  f32x4* afrag = reinterpret_cast<f32x4*>(smem);
+  float* beta_s = reinterpret_cast<float*>(smem + sizeof(f32x4) * KT * KT * 4 * 64);
+
+  for (int idx = threadIdx.x; idx < KT * KT * 4 * 64; idx += blockDim.x) {
+    const int l = idx & 63, rest = idx >> 6;
+    const int u4 = rest & 3, tk = rest >> 2;
+    const int t = tk / KT, kt = tk % KT;
+    const int i = l & 31, h = l >> 5;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = 32 * kt + 4 * h + e + 8 * u4;
+      v[e] = p.gamma[ch * C + 32 * t + i];
+    }
+    afrag[idx] = v;
+  }
+  for (int i = threadIdx.x; i < C; i += blockDim.x) beta_s[i] = p.beta[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5;
+  const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = static_cast<long long>(gridDim.x) * (blockDim.x >> 6);
+  const float* x = static_cast<const float*>(p.x);
+  float* y = static_cast<float*>(p.y);
+
+  for (long long tile = wave; tile < p.tiles; tile += nwaves) {
+    const long long pix = tile * 32 + (lane & 31);
+    const bool live = pix < p.pixels;
+    const long long row = (live ? pix : p.pixels - 1) * C;
+    f32x4 xr[KT][4];   // [K-tile][q]: channels 32kt + 8q + 4h + {0..3}
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + row + 32 * kt + 8 * q + 4 * h);
+        if (p.rectify) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        xr[kt][q] = v;
+      }
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 u = xr[kt][q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = p.alpha2 ? u[e] * u[e] : fabsf(u[e]);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const f32x4 a4 = afrag[((t * KT + kt) * 4 + q) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], u[e], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+        f32x4 out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[r] = gdn_apply(xr[t][q][r], acc[t][4 * q + r] + b4[r], p.inverse, p.eps_half);
+        if (live) *reinterpret_cast<f32x4*>(y + row + 32 * t + 8 * q + 4 * h) = out;
+      }
+  }
+}
+
+template <int KT>
+int launch_gdn(const GdnParams& p, int dtype, hipStream_t st) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int waves_per_block = 8;
+  const long long want = ceil_div(p.tiles, waves_per_block);
+  const unsigned blocks = static_cast<unsigned>(std::max<long long>(1, std::min<long long>(want, cus)));
+  KernelTimer timer("gdn_forward", st);
+  if (dtype == 1) {
+    const size_t lds = sizeof(bf16x8) * KT * (KT * 2) * 64 + sizeof(float) * KT * 32;
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT>), dim3(blocks), dim3(64 * waves_per_block), lds, st, p);
+  } else {
+    const size_t lds = sizeof(f32x4) * KT * KT * 4 * 64 + sizeof(float) * KT * 32;
+    if (lds > 160 * 1024)
+      return fail("tfc_gdn_forward: float32 path supports up to 192 channels (Gamma must fit in LDS)");
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_f32_kernel<KT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((gdn_fwd_f32_kernel<KT>), dim3(blocks), dim3(64 * waves_per_block), lds, st, p);
+  }
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace tfc
+
+extern "C" int tfc_gdn_forward(const void* x, void* y, int dtype, int64_t pixels, int64_t channels,
+                               const float* beta, const float* gamma, int inverse, int rectify,
+                               int alpha_mode, int eps_mode, void* stream) {
+  using namespace tfc;
+  if (dtype != 0 && dtype != 1) return fail("tfc_gdn_forward: dtype must be 0 (float32) or 1 (bfloat16)");
+  if (alpha_mode != 1 && alpha_mode != 2) return fail("tfc_gdn_forward: alpha must be 1 or 2");
+  if (eps_mode != 0 && eps_mode != 1) return fail("tfc_gdn_forward: epsilon must be 1 or 0.5");
+  if (channels <= 0 || channels % 32 != 0 || channels > 256)
+    return fail("tfc_gdn_forward: channels must be a multiple of 32, at most 256 (got %lld)",
+                static_cast<long long>(channels));
+  if (pixels == 0) return 0;
+  GdnParams p;
+  p.x = x; p.y = y; p.beta = beta; p.gamma = gamma;
+  p.pixels = pixels; p.C = static_cast<int>(channels);
+  p.inverse = inverse; p.rectify = rectify; p.alpha2 = alpha_mode == 2; p.eps_half = eps_mode == 1;
+  p.tiles = ceil_div(pixels, 32);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (channels / 32) {
+    case 1: return launch_gdn<1>(p, dtype, st);
+    case 2: return launch_gdn<2>(p, dtype, st);
+    case 3: return launch_gdn<3>(p, dtype, st);
+    case 4: return launch_gdn<4>(p, dtype, st);
+    case 5: return launch_gdn<5>(p, dtype, st);
+    case 6: return launch_gdn<6>(p, dtype, st);
+    case 7: return launch_gdn<7>(p, dtype, st);
+    default: return launch_gdn<8>(p, dtype, st);
+  }
+}
