@@ -25,6 +25,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/tfc_hip.h"
 #include "common.h"
 
@@ -46,14 +48,26 @@ struct GdnParams {
   int C;
   int inverse, rectify, alpha2, eps_half;
   long long tiles;      // ceil(pixels / 32)
+  const void* image;    // fragment-ordered Gamma^T (+ beta) built by gdn_prep_*_kernel
 };
 
-__device__ inline float gdn_apply(float x, float n, int inverse, int eps_half) {
-  if (eps_half) n = __builtin_sqrtf(n);
-  return inverse ? x * n : x * __builtin_amdgcn_rcpf(n);
+// y = x / n^eps (GDN) or x * n^eps (IGDN); hardware rcp / rsq / sqrt are 1-ulp approximations,
+// far inside the 1e-5 tolerance.  Flags are template parameters so that the epilogue carries
+// only the instructions of the variant in use (the kernel switches once, wave-uniformly).
+template <bool INVERSE, bool EPS_HALF>
+__device__ inline float gdn_apply(float x, float n) {
+  if (INVERSE) return x * (EPS_HALF ? __builtin_amdgcn_sqrtf(n) : n);
+  return x * (EPS_HALF ? __builtin_amdgcn_rsqf(n) : __builtin_amdgcn_rcpf(n));
 }
 
 __device__ inline float bf16_bits_to_float(unsigned int bits16) { return __uint_as_float(bits16 << 16); }
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// v_cvt_pk_bf16_f32: two floats -> packed bf16 pair, round-to-nearest-even.
+__device__ inline unsigned int pack_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
 
 __device__ inline unsigned int float_to_bf16_bits(float f) {
   // round to nearest even, NaN preserved (matches __float2bfloat16)
@@ -77,19 +91,13 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
   bf16x8* afrag = reinterpret_cast<bf16x8*>(smem);
   float* beta_s = reinterpret_cast<float*>(smem + sizeof(bf16x8) * KT * KS * 64);
 
-  for (int idx = threadIdx.x; idx < KT * KS * 64; idx += blockDim.x) {
-    const int l = idx & 63, ts = idx >> 6;
-    const int t = ts / KS, s = ts % KS;
-    const int i = l & 31, h = l >> 5;
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ch = 16 * s + 4 * h + (e & 3) + 8 * (e >> 2);
-      v[e] = static_cast<__bf16>(p.gamma[ch * C + 32 * t + i]);
-    }
-    afrag[idx] = v;
+  {
+    // fragment image (built once per call by gdn_prep_bf16_kernel): linear 16-byte copy
+    const u32x4* src = static_cast<const u32x4*>(p.image);
+    u32x4* dstv = reinterpret_cast<u32x4*>(smem);
+    constexpr int n16 = KT * KS * 64 + (C * 4) / 16;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dstv[i] = src[i];
   }
-  for (int i = threadIdx.x; i < C; i += blockDim.x) beta_s[i] = p.beta[i];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -103,13 +111,18 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
     const long long pix = tile * 32 + (lane & 31);
     const bool live = pix < p.pixels;
     const long long row = (live ? pix : p.pixels - 1) * C;
-    // ---- loads: for every K-step, channels 16s+4h+{0..3} and 16s+4h+8+{0..3} ----
+    // ---- loads: after the swap, K-step s holds channels 16s+4h+{0..3} and 16s+4h+8+{0..3} ----
     u32x4 xr[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const u32x2 a = *reinterpret_cast<const u32x2*>(x + row + 16 * s + 4 * h);
-      const u32x2 b = *reinterpret_cast<const u32x2*>(x + row + 16 * s + 4 * h + 8);
-      xr[s] = u32x4{a.x, a.y, b.x, b.y};
+      // One 16-byte load per lane (channels 16s + 8h + 0..7), then v_permlane32_swap trades
+      // the inner halves between lanes l and l+32 so that the lane ends up with channels
+      // 16s + 4h + {0..3} and 16s + 4h + 8 + {0..3} — twice the bytes per cache line touched
+      // by one load instruction compared with two 8-byte loads.
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
+      const auto s0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+      xr[s] = u32x4{s0[0], s1[0], s0[1], s1[1]};
     }
     f32x16 acc[KT];
 #pragma unroll
@@ -126,7 +139,7 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
           float lo = bf16_bits_to_float(u[w] & 0xFFFFu), hi = bf16_bits_to_float(u[w] >> 16);
           if (p.rectify) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
           if (p.alpha2) { lo = lo * lo; hi = hi * hi; } else { lo = fabsf(lo); hi = fabsf(hi); }
-          u[w] = float_to_bf16_bits(lo) | (float_to_bf16_bits(hi) << 16);
+          u[w] = pack_bf16(lo, hi);
         }
       } else {
         u &= 0x7FFF7FFFu;
@@ -141,29 +154,38 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: acc[t][4q + r] is channel 32t + 8q + 4h + r of this lane's pixel ----
+    auto epilogue = [&](auto inv, auto epsh) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int t = s >> 1;
-      u32x4 out;
+      for (int s = 0; s < KS; ++s) {
+        const int t = s >> 1;
+        u32x4 out;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int q = 2 * (s & 1) + half;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
-        float yv[4];
+        for (int half = 0; half < 2; ++half) {
+          const int q = 2 * (s & 1) + half;
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+          float yv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned int word = xr[s][2 * half + (r >> 1)];
-          float xv = bf16_bits_to_float((r & 1) ? (word >> 16) : (word & 0xFFFFu));
-          if (p.rectify) xv = fmaxf(xv, 0.f);
-          yv[r] = gdn_apply(xv, acc[t][4 * q + r] + b4[r], p.inverse, p.eps_half);
+          for (int r = 0; r < 4; ++r) {
+            const unsigned int word = xr[s][2 * half + (r >> 1)];
+            float xv = __uint_as_float((r & 1) ? (word & 0xFFFF0000u) : (word << 16));
+            if (p.rectify) xv = fmaxf(xv, 0.f);
+            yv[r] = gdn_apply<decltype(inv)::value, decltype(epsh)::value>(xv, acc[t][4 * q + r] + b4[r]);
+          }
+          out[2 * half] = pack_bf16(yv[0], yv[1]);
+          out[2 * half + 1] = pack_bf16(yv[2], yv[3]);
         }
-        out[2 * half] = float_to_bf16_bits(yv[0]) | (float_to_bf16_bits(yv[1]) << 16);
-        out[2 * half + 1] = float_to_bf16_bits(yv[2]) | (float_to_bf16_bits(yv[3]) << 16);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(out.x, out.z, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(out.y, out.w, false, false);
+        if (live)
+          *reinterpret_cast<u32x4*>(y + row + 16 * s + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
-      if (live) {
-        *reinterpret_cast<u32x2*>(y + row + 16 * s + 4 * h) = u32x2{out.x, out.y};
-        *reinterpret_cast<u32x2*>(y + row + 16 * s + 4 * h + 8) = u32x2{out.z, out.w};
-      }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (p.inverse) {
+      if (p.eps_half) epilogue(T{}, T{}); else epilogue(T{}, F{});
+    } else {
+      if (p.eps_half) epilogue(F{}, T{}); else epilogue(F{}, F{});
     }
   }
 }
@@ -174,26 +196,18 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
 // LDS: Gamma^T fragments [((t * KT + kt) * 4 + u4) * 64 + lane][4]  (4 consecutive steps u).
 // ---------------------------------------------------------------------------
 template <int KT>
-__global__ void __launch_bounds__(512) gdn_fwd_f32_kernel(GdnParams p) {
+__global__ void __launch_bounds__(256) gdn_fwd_f32_kernel(GdnParams p) {
   constexpr int C = KT * 32;
   extern __shared__ unsigned char smem[];
   f32x4* afrag = reinterpret_cast<f32x4*>(smem);
   float* beta_s = reinterpret_cast<float*>(smem + sizeof(f32x4) * KT * KT * 4 * 64);
 
-  for (int idx = threadIdx.x; idx < KT * KT * 4 * 64; idx += blockDim.x) {
-    const int l = idx & 63, rest = idx >> 6;
-    const int u4 = rest & 3, tk = rest >> 2;
-    const int t = tk / KT, kt = tk % KT;
-    const int i = l & 31, h = l >> 5;
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int ch = 32 * kt + 4 * h + e + 8 * u4;
-      v[e] = p.gamma[ch * C + 32 * t + i];
-    }
-    afrag[idx] = v;
+  {
+    const u32x4* src = static_cast<const u32x4*>(p.image);
+    u32x4* dstv = reinterpret_cast<u32x4*>(smem);
+    constexpr int n16 = KT * KT * 4 * 64 + (C * 4) / 16;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dstv[i] = src[i];
   }
-  for (int i = threadIdx.x; i < C; i += blockDim.x) beta_s[i] = p.beta[i];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -240,31 +254,89 @@ __global__ void __launch_bounds__(512) gdn_fwd_f32_kernel(GdnParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+    auto epilogue = [&](auto inv, auto epsh) {
 #pragma unroll
-    for (int t = 0; t < KT; ++t)
+      for (int t = 0; t < KT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
-        f32x4 out;
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+          f32x4 out;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          out[r] = gdn_apply(xr[t][q][r], acc[t][4 * q + r] + b4[r], p.inverse, p.eps_half);
-        if (live) *reinterpret_cast<f32x4*>(y + row + 32 * t + 8 * q + 4 * h) = out;
-      }
+          for (int r = 0; r < 4; ++r)
+            out[r] = gdn_apply<decltype(inv)::value, decltype(epsh)::value>(
+                xr[t][q][r], acc[t][4 * q + r] + b4[r]);
+          if (live) *reinterpret_cast<f32x4*>(y + row + 32 * t + 8 * q + 4 * h) = out;
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (p.inverse) {
+      if (p.eps_half) epilogue(T{}, T{}); else epilogue(T{}, F{});
+    } else {
+      if (p.eps_half) epilogue(F{}, T{}); else epilogue(F{}, F{});
+    }
   }
 }
 
+// Builds the fragment-ordered Gamma^T image (+ beta behind it) the main kernels copy to LDS.
+__global__ void gdn_prep_bf16_kernel(const float* gamma, const float* beta, int C, bf16x8* image) {
+  const int KT = C / 32, KS = C / 16;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < KT * KS * 64) {
+    const int l = idx & 63, ts = idx >> 6;
+    const int t = ts / KS, s = ts % KS;
+    const int i = l & 31, h = l >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = 16 * s + 4 * h + (e & 3) + 8 * (e >> 2);
+      v[e] = static_cast<__bf16>(gamma[ch * C + 32 * t + i]);
+    }
+    image[idx] = v;
+  }
+  float* b = reinterpret_cast<float*>(image + KT * KS * 64);
+  if (idx < C) b[idx] = beta[idx];
+}
+
+__global__ void gdn_prep_f32_kernel(const float* gamma, const float* beta, int C, f32x4* image) {
+  const int KT = C / 32;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < KT * KT * 4 * 64) {
+    const int l = idx & 63, rest = idx >> 6;
+    const int u4 = rest & 3, tk = rest >> 2;
+    const int t = tk / KT, kt = tk % KT;
+    const int i = l & 31, h = l >> 5;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = 32 * kt + 4 * h + e + 8 * u4;
+      v[e] = gamma[ch * C + 32 * t + i];
+    }
+    image[idx] = v;
+  }
+  float* b = reinterpret_cast<float*>(image + KT * KT * 4 * 64);
+  if (idx < C) b[idx] = beta[idx];
+}
+
 template <int KT>
-int launch_gdn(const GdnParams& p, int dtype, hipStream_t st) {
+int launch_gdn(GdnParams p, int dtype, hipStream_t st) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int waves_per_block = 8;
+  // bf16: 8 waves (2 per SIMD, <= 256 VGPRs each); f32: 4 waves so that the 96 x + 96
+  // accumulator registers fit the 512-entry unified file without spilling.
+  const int waves_per_block = dtype == 1 ? 8 : 4;
   const long long want = ceil_div(p.tiles, waves_per_block);
   const unsigned blocks = static_cast<unsigned>(std::max<long long>(1, std::min<long long>(want, cus)));
-  KernelTimer timer("gdn_forward", st);
+  DevBuf image;
   if (dtype == 1) {
     const size_t lds = sizeof(bf16x8) * KT * (KT * 2) * 64 + sizeof(float) * KT * 32;
+    TFC_HIP(image.alloc(lds, st));
+    const int n = KT * KT * 2 * 64;
+    hipLaunchKernelGGL(gdn_prep_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.gamma, p.beta,
+                       KT * 32, image.as<bf16x8>());
+    p.image = image.p;
+    KernelTimer timer("gdn_forward", st);
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT>), dim3(blocks), dim3(64 * waves_per_block), lds, st, p);
@@ -272,6 +344,12 @@ int launch_gdn(const GdnParams& p, int dtype, hipStream_t st) {
     const size_t lds = sizeof(f32x4) * KT * KT * 4 * 64 + sizeof(float) * KT * 32;
     if (lds > 160 * 1024)
       return fail("tfc_gdn_forward: float32 path supports up to 192 channels (Gamma must fit in LDS)");
+    TFC_HIP(image.alloc(lds, st));
+    const int n = KT * KT * 4 * 64;
+    hipLaunchKernelGGL(gdn_prep_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.gamma, p.beta,
+                       KT * 32, image.as<f32x4>());
+    p.image = image.p;
+    KernelTimer timer("gdn_forward", st);
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_f32_kernel<KT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((gdn_fwd_f32_kernel<KT>), dim3(blocks), dim3(64 * waves_per_block), lds, st, p);
