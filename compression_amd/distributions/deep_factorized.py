@@ -1,0 +1,106 @@
+"""Deep factorized density model (python/distributions/deep_factorized.py:50-267):
+per-channel monotone MLP for the logits of the cumulative, K = len(num_filters)+1
+layers with softplus-reparameterised matrices and tanh gates."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import helpers
+from .base import Distribution
+from .uniform_noise import UniformNoiseAdapter
+
+__all__ = ["DeepFactorized", "NoisyDeepFactorized"]
+
+
+def _log_expm1(x: float) -> float:
+    return math.log(math.expm1(x))
+
+
+class DeepFactorized(Distribution):
+    def __init__(self, batch_shape=(), num_filters=(3, 3), init_scale=10, dtype=torch.float32):
+        super().__init__(dtype)
+        self._batch_shape = torch.Size(int(s) for s in batch_shape)
+        self.num_filters = tuple(int(f) for f in num_filters)
+        self.init_scale = float(init_scale)
+        channels = self._batch_shape.numel()
+        filters = (1,) + self.num_filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.num_filters) + 1))
+        self.matrices = torch.nn.ParameterList()
+        self.biases = torch.nn.ParameterList()
+        self.factors = torch.nn.ParameterList()
+        for i in range(len(self.num_filters) + 1):
+            init = _log_expm1(1 / scale / filters[i + 1])
+            self.matrices.append(torch.nn.Parameter(
+                torch.full((channels, filters[i + 1], filters[i]), init, dtype=dtype)))
+            self.biases.append(torch.nn.Parameter(
+                torch.rand((channels, filters[i + 1], 1), dtype=dtype) - 0.5))
+            if i < len(self.num_filters):
+                self.factors.append(torch.nn.Parameter(
+                    torch.zeros((channels, filters[i + 1], 1), dtype=dtype)))
+
+    @property
+    def batch_shape(self):
+        return self._batch_shape
+
+    def _broadcast(self, x):
+        x = x.to(self.matrices[0].device)
+        return x.expand(torch.broadcast_shapes(x.shape, self._batch_shape))
+
+    def _logits_cumulative(self, inputs):
+        """deep_factorized.py:166-194: (channels, 1, batch) layout, matmul chain."""
+        shape = inputs.shape
+        channels = self._batch_shape.numel()
+        logits = inputs.reshape(-1, 1, channels).permute(2, 1, 0)
+        for i in range(len(self.num_filters) + 1):
+            logits = torch.matmul(torch.nn.functional.softplus(self.matrices[i]), logits)
+            logits = logits + self.biases[i]
+            if i < len(self.num_filters):
+                logits = logits + torch.tanh(self.factors[i]) * torch.tanh(logits)
+        return logits.permute(2, 1, 0).reshape(shape)
+
+    def _cdf(self, x): return torch.sigmoid(self._logits_cumulative(self._broadcast(x)))
+    def _survival_function(self, x): return torch.sigmoid(-self._logits_cumulative(self._broadcast(x)))
+    def _log_cdf(self, x): return torch.nn.functional.logsigmoid(self._logits_cumulative(self._broadcast(x)))
+    def _log_survival_function(self, x):
+        return torch.nn.functional.logsigmoid(-self._logits_cumulative(self._broadcast(x)))
+
+    def _dlogits(self, x):
+        x = self._broadcast(x).detach().requires_grad_(True) if not x.requires_grad else self._broadcast(x)
+        with torch.enable_grad():
+            logits = self._logits_cumulative(x)
+            d, = torch.autograd.grad(logits.sum(), x, create_graph=torch.is_grad_enabled())
+        return logits, d
+
+    def _log_prob(self, x):
+        logits, d = self._dlogits(x)
+        return (torch.nn.functional.logsigmoid(logits) + torch.nn.functional.logsigmoid(-logits)
+                + torch.log(d))
+
+    def _prob(self, x):
+        logits, d = self._dlogits(x)
+        s = torch.sigmoid(logits)
+        return s * (1 - s) * d
+
+    def _quantization_offset(self):
+        with torch.no_grad():
+            dev = self.matrices[0].device
+        return helpers.estimate_tails(self._logits_cumulative, 0.0, self._batch_shape, self.dtype, dev)
+
+    def _tail(self, logits):
+        dev = self.matrices[0].device
+        return helpers.estimate_tails(self._logits_cumulative, logits, self._batch_shape, self.dtype, dev)
+
+    def _lower_tail(self, tail_mass):
+        return self._tail(math.log(tail_mass / 2 / (1.0 - tail_mass / 2)))
+
+    def _upper_tail(self, tail_mass):
+        return self._tail(-math.log(tail_mass / 2 / (1.0 - tail_mass / 2)))
+
+
+class NoisyDeepFactorized(UniformNoiseAdapter):
+    """`DeepFactorized` convolved with uniform noise (deep_factorized.py:262-267)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(DeepFactorized(**kwargs))

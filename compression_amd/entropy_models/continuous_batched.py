@@ -1,0 +1,203 @@
+"""`ContinuousBatchedEntropyModel` (python/entropy_models/continuous_batched.py:33-436),
+the TFC-2.x successor of `EntropyBottleneck`: quantisation, rate estimate, and range
+coding with per-channel tables.  compress()/decompress() run on the HIP coder; the
+quantise prologue / dequantise epilogue are fused into the coder's load/store."""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..distributions import helpers
+from ..ops import gen_ops, math_ops, round_ops
+from . import continuous_base
+
+__all__ = ["ContinuousBatchedEntropyModel", "EntropyBottleneck"]
+
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
+    def __init__(self, prior=None, coding_rank=None, compression=False, stateless=False,
+                 expected_grads=False, tail_mass=2 ** -8, range_coder_precision=12,
+                 bottleneck_dtype=None, prior_shape=None, cdf=None, cdf_offset=None,
+                 cdf_shapes=None, offset_heuristic=True, quantization_offset=None,
+                 decode_sanity_check=True, laplace_tail_mass=0):
+        if (prior is None) == (prior_shape is None):
+            raise ValueError("Either `prior` or `prior_shape` must be provided.")
+        if (prior is None) + (cdf_shapes is None) + (cdf is None) != 2:
+            raise ValueError("Must provide exactly one of `prior`, `cdf`, or `cdf_shapes`.")
+        if not compression and not (cdf is None and cdf_offset is None and cdf_shapes is None):
+            raise ValueError("CDFs can't be provided with `compression=False`")
+        if prior is not None and len(prior.event_shape):
+            raise ValueError("`prior` must be a (batch of) scalar distribution(s).")
+        super().__init__(coding_rank=coding_rank, compression=compression, stateless=stateless,
+                         expected_grads=expected_grads, tail_mass=tail_mass,
+                         bottleneck_dtype=bottleneck_dtype, laplace_tail_mass=laplace_tail_mass)
+        self._prior = prior
+        self._offset_heuristic = bool(offset_heuristic)
+        self._prior_shape = torch.Size(prior_shape if prior is None else prior.batch_shape)
+        if self.coding_rank < len(self.prior_shape):
+            raise ValueError("`coding_rank` can't be smaller than `prior_shape`.")
+        self.decode_sanity_check = decode_sanity_check
+        self.fused = True   # quantise/dequantise inside the coder kernels
+
+        if cdf_shapes is not None:
+            assert isinstance(quantization_offset, bool) and self.compression
+            quantization_offset = torch.zeros(tuple(self.prior_shape)) if quantization_offset else None
+        elif quantization_offset is not None:
+            quantization_offset = torch.as_tensor(quantization_offset)
+        elif self.offset_heuristic and self.compression:
+            if self._prior is None:
+                raise ValueError("To use the offset heuristic, a `prior` needs to be provided.")
+            quantization_offset = helpers.quantization_offset(self.prior)
+            if bool(torch.all(quantization_offset == 0.0)):
+                quantization_offset = None
+            else:
+                quantization_offset = quantization_offset.expand(tuple(self.prior_shape)).clone()
+        if quantization_offset is None:
+            self._quantization_offset = None
+        else:
+            q = quantization_offset.detach().to(self.bottleneck_dtype)
+            if self.compression and not self.stateless:
+                self.register_buffer("_quantization_offset", q)
+            else:
+                self._quantization_offset = q
+        if self.compression:
+            if cdf is None and cdf_shapes is None:
+                cdf, cdf_offset = self._build_tables(self.prior, range_coder_precision,
+                                                     offset=quantization_offset)
+            self._init_compression(cdf, cdf_offset, cdf_shapes)
+
+    prior_shape = property(lambda self: self._prior_shape)
+    offset_heuristic = property(lambda self: self._offset_heuristic)
+
+    @property
+    def quantization_offset(self):
+        if self._quantization_offset is not None:
+            return self._quantization_offset
+        if self.offset_heuristic and not self.compression:
+            if self._prior is None:
+                raise RuntimeError("To use the offset heuristic, a `prior` needs to be provided.")
+            return helpers.quantization_offset(self.prior).to(self.bottleneck_dtype)
+        return None
+
+    def forward(self, bottleneck, training=True):
+        """(bottleneck_perturbed, bits) — continuous_batched.py:291-322."""
+        bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
+        log_prob_fn = functools.partial(self._log_prob, self.prior)
+        if training:
+            log_probs, perturbed = math_ops.perturb_and_apply(
+                log_prob_fn, bottleneck, expected_grads=self.expected_grads)
+        else:
+            perturbed = self.quantize(bottleneck)
+            log_probs = log_prob_fn(perturbed)
+        axes = tuple(range(-self.coding_rank, 0))
+        bits = log_probs.sum(dim=axes) / (-float(np.log(2.0))) if axes else log_probs / (-float(np.log(2.0)))
+        return perturbed, bits
+
+    def quantize(self, bottleneck):
+        bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
+        offset = self.quantization_offset
+        if offset is not None:
+            offset = offset.to(bottleneck.device)
+        return round_ops.round_st(bottleneck, offset)
+
+    # ------------------------------------------------------------------ coding
+    def _device_tables(self, device):
+        cache = getattr(self, "_dev_cache", None)
+        key = (self.cdf.data_ptr(), self.cdf._version, str(device))
+        if cache is None or cache[0] != key:
+            off = self.cdf_offset.to(device).contiguous()
+            q = self._quantization_offset
+            qf = None if q is None else q.to(device, torch.float32).reshape(-1).contiguous()
+            object.__setattr__(self, "_dev_cache", (key, off, qf))
+            cache = self._dev_cache
+        return cache[1], cache[2]
+
+    def compress(self, bottleneck):
+        """continuous_batched.py:347-383.  Returns a numpy object array of `bytes`
+        shaped like `bottleneck` minus the `coding_rank` innermost dimensions."""
+        self._check_compression()
+        device = _lib.require_device()
+        bottleneck = torch.as_tensor(bottleneck).to(device, self.bottleneck_dtype).contiguous()
+        shape = tuple(bottleneck.shape)
+        batch_shape = shape[:len(shape) - self.coding_rank] if self.coding_rank else shape
+        handle = gen_ops.create_range_encoder(batch_shape, self.cdf)
+        if handle.streams == 0:
+            raise ValueError(f"`handle` is empty: handle.shape={list(batch_shape)}")
+        channels = int(self.prior_shape.numel())
+        elems = bottleneck.numel() // handle.streams
+        cdf_offset, qoff = self._device_tables(device)
+        if self.fused and bottleneck.dtype in _DTYPE_CODE:
+            handle._keep += [bottleneck, cdf_offset, qoff]
+            _lib.check(_lib.lib().tfc_encoder_encode_quantized(
+                handle.ptr, bottleneck.data_ptr(), _DTYPE_CODE[bottleneck.dtype],
+                None if qoff is None else qoff.data_ptr(), cdf_offset.data_ptr(), channels, elems,
+                _lib.stream_ptr()))
+        else:
+            offset = self.quantization_offset
+            if offset is not None:
+                bottleneck = bottleneck - offset.to(device)
+            symbols = torch.round(bottleneck).to(torch.int32)
+            iid = shape[:len(shape) - len(self.prior_shape)] if len(self.prior_shape) else shape
+            symbols = symbols.reshape(tuple(iid) + (-1,)) - cdf_offset
+            handle = gen_ops.entropy_encode_channel(handle, symbols.contiguous())
+        return gen_ops.entropy_encode_finalize(handle)
+
+    def decompress(self, strings, broadcast_shape):
+        """continuous_batched.py:385-422: output shape = strings.shape + broadcast_shape +
+        prior_shape."""
+        self._check_compression()
+        device = _lib.require_device()
+        broadcast_shape = tuple(int(s) for s in broadcast_shape)
+        handle = gen_ops.create_range_decoder(strings, self.cdf)
+        channels = int(self.prior_shape.numel())
+        out_shape = tuple(handle.shape) + broadcast_shape + tuple(self.prior_shape)
+        elems = int(np.prod(broadcast_shape, dtype=np.int64)) * channels
+        cdf_offset, qoff = self._device_tables(device)
+        if self.fused and self.bottleneck_dtype in _DTYPE_CODE:
+            out = torch.empty(out_shape, dtype=self.bottleneck_dtype, device=device)
+            _lib.check(_lib.lib().tfc_decoder_decode_dequantized(
+                handle.ptr, None, out.data_ptr(), _DTYPE_CODE[self.bottleneck_dtype],
+                None if qoff is None else qoff.data_ptr(), cdf_offset.data_ptr(), channels, elems,
+                _lib.stream_ptr()))
+            sanity = gen_ops.entropy_decode_finalize(handle)
+        else:
+            handle, symbols = gen_ops.entropy_decode_channel(
+                handle, broadcast_shape + (channels,), torch.int32)
+            sanity = gen_ops.entropy_decode_finalize(handle)
+            out = (symbols + cdf_offset).reshape(out_shape).to(self.bottleneck_dtype)
+            offset = self.quantization_offset
+            if offset is not None:
+                out = out + offset.to(device)
+        if self.decode_sanity_check and not bool(sanity.all()):
+            raise RuntimeError("Sanity check failed.")
+        return out
+
+    def get_config(self):
+        config = super().get_config()
+        config.update(prior_shape=tuple(map(int, self.prior_shape)),
+                      offset_heuristic=self.offset_heuristic,
+                      quantization_offset=self.quantization_offset is not None)
+        return config
+
+    @classmethod
+    def from_config(cls, config):
+        config = dict(config)
+        config["bottleneck_dtype"] = getattr(torch, config["bottleneck_dtype"])
+        return cls(**config)
+
+
+class EntropyBottleneck(ContinuousBatchedEntropyModel):
+    """TFC-1.x name kept by the north star: a `ContinuousBatchedEntropyModel` over a
+    `NoisyDeepFactorized(batch_shape=(filters,))` prior with coding_rank 3, which is what
+    `models/bls2017.py:108,160` instantiates in the 2.x API."""
+
+    def __init__(self, filters, coding_rank=3, **kwargs):
+        from ..distributions import NoisyDeepFactorized
+        super().__init__(prior=NoisyDeepFactorized(batch_shape=(int(filters),)),
+                         coding_rank=coding_rank, **kwargs)

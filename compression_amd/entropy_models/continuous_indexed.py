@@ -1,0 +1,199 @@
+"""Indexed (conditional) entropy models
+(python/entropy_models/continuous_indexed.py:30-633)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..ops import gen_ops, math_ops, round_ops
+from . import continuous_base
+
+__all__ = ["ContinuousIndexedEntropyModel", "LocationScaleIndexedEntropyModel"]
+
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
+    def __init__(self, prior_fn, index_ranges, parameter_fns, coding_rank, channel_axis=-1,
+                 compression=False, stateless=False, expected_grads=False, tail_mass=2 ** -8,
+                 range_coder_precision=12, bottleneck_dtype=None, prior_dtype=torch.float32,
+                 decode_sanity_check=True, laplace_tail_mass=0):
+        if not callable(prior_fn):
+            raise TypeError("`prior_fn` must be a class or factory function.")
+        for name, fn in parameter_fns.items():
+            if not isinstance(name, str):
+                raise TypeError("`parameter_fns` must have string keys.")
+            if not callable(fn):
+                raise TypeError(f"`parameter_fns['{name}']` must be callable.")
+        super().__init__(coding_rank=coding_rank, compression=compression, stateless=stateless,
+                         expected_grads=expected_grads, tail_mass=tail_mass,
+                         bottleneck_dtype=bottleneck_dtype, laplace_tail_mass=laplace_tail_mass)
+        self._index_ranges = tuple(int(r) for r in index_ranges)
+        if not self.index_ranges:
+            raise ValueError("`index_ranges` must have at least one element.")
+        self._channel_axis = None if channel_axis is None else int(channel_axis)
+        if self.channel_axis is None and len(self.index_ranges) > 1:
+            raise ValueError("`channel_axis` can't be `None` for `len(index_ranges) > 1`.")
+        self._prior_fn = prior_fn
+        self._parameter_fns = dict(parameter_fns)
+        self._prior_dtype = prior_dtype
+        self.decode_sanity_check = decode_sanity_check
+        self.fused = True
+        if self.compression:
+            if self.channel_axis is None:
+                indexes = torch.arange(self.index_ranges[0], dtype=torch.int32)
+            else:
+                grids = torch.meshgrid(*[torch.arange(r, dtype=torch.int32) for r in self.index_ranges],
+                                       indexing="ij")
+                indexes = torch.stack(grids, dim=self.channel_axis)
+            self._prior = self._make_prior(indexes)
+            cdf, cdf_offset = self._build_tables(self.prior, range_coder_precision)
+            self._init_compression(cdf, cdf_offset, None)
+
+    index_ranges = property(lambda self: self._index_ranges)
+    parameter_fns = property(lambda self: self._parameter_fns)
+    prior_dtype = property(lambda self: self._prior_dtype)
+    prior_fn = property(lambda self: self._prior_fn)
+    channel_axis = property(lambda self: self._channel_axis)
+
+    def _make_prior(self, indexes):
+        indexes = indexes.to(self.prior_dtype)
+        parameters = {k: f(indexes) for k, f in self.parameter_fns.items()}
+        prior = self.prior_fn(**parameters)
+        assert prior.dtype == self.prior_dtype
+        if len(prior.event_shape):
+            raise ValueError("`prior` must be a (batch of) scalar distribution(s).")
+        return prior
+
+    def _normalize_indexes(self, indexes):
+        indexes = math_ops.lower_bound(indexes, 0)
+        if self.channel_axis is None:
+            bounds = torch.tensor(self.index_ranges[0] - 1, dtype=indexes.dtype, device=indexes.device)
+        else:
+            axes = [1] * indexes.dim()
+            axes[self.channel_axis] = len(self.index_ranges)
+            bounds = torch.tensor([s - 1 for s in self.index_ranges], dtype=indexes.dtype,
+                                  device=indexes.device).reshape(axes)
+        return math_ops.upper_bound(indexes, bounds)
+
+    def _flatten_indexes(self, indexes):
+        indexes = indexes.to(torch.int32)
+        if self.channel_axis is None:
+            return indexes
+        strides = np.cumprod((self.index_ranges + (1,))[::-1])[::-1][1:]
+        strides = torch.tensor(strides.copy(), dtype=torch.int32, device=indexes.device)
+        return torch.tensordot(indexes.movedim(self.channel_axis, -1), strides, dims=([-1], [0]))
+
+    def forward(self, bottleneck, indexes, training=True):
+        bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
+        indexes = self._normalize_indexes(torch.as_tensor(indexes))
+        if training:
+            def log_prob_fn(perturbed, idx):
+                return self._log_prob(self._make_prior(idx), perturbed)
+            log_probs, perturbed = math_ops.perturb_and_apply(
+                log_prob_fn, bottleneck, indexes, expected_grads=self.expected_grads)
+        else:
+            prior = self._make_prior(indexes)
+            perturbed = self.quantize(bottleneck)
+            log_probs = self._log_prob(prior, perturbed)
+        axes = tuple(range(-self.coding_rank, 0))
+        bits = log_probs.sum(dim=axes) / (-float(np.log(2.0)))
+        return perturbed, bits
+
+    def quantize(self, bottleneck):
+        return round_ops.round_st(torch.as_tensor(bottleneck).to(self.bottleneck_dtype))
+
+    def compress(self, bottleneck, indexes):
+        """continuous_indexed.py:355-386."""
+        self._check_compression()
+        device = _lib.require_device()
+        bottleneck = torch.as_tensor(bottleneck).to(device, self.bottleneck_dtype).contiguous()
+        indexes = self._normalize_indexes(torch.as_tensor(indexes).to(device))
+        flat = self._flatten_indexes(indexes).contiguous()
+        shape = tuple(flat.shape)
+        batch_shape = shape[:len(shape) - self.coding_rank] if self.coding_rank else shape
+        cdf_offset = self.cdf_offset.to(device)
+        handle = gen_ops.create_range_encoder(batch_shape, self.cdf)
+        if handle.streams == 0:
+            raise ValueError(f"`handle` is empty: handle.shape={list(batch_shape)}")
+        if self.fused and bottleneck.dtype in _DTYPE_CODE:
+            elems = flat.numel() // handle.streams
+            handle._keep += [bottleneck, flat, cdf_offset]
+            _lib.check(_lib.lib().tfc_encoder_encode_quantized_indexed(
+                handle.ptr, bottleneck.data_ptr(), _DTYPE_CODE[bottleneck.dtype], flat.data_ptr(),
+                cdf_offset.data_ptr(), elems, _lib.stream_ptr()))
+        else:
+            symbols = torch.round(bottleneck).to(torch.int32) - cdf_offset[flat.long()]
+            handle = gen_ops.entropy_encode_index(handle, flat, symbols.contiguous())
+        return gen_ops.entropy_encode_finalize(handle)
+
+    def decompress(self, strings, indexes):
+        """continuous_indexed.py:388-417."""
+        self._check_compression()
+        device = _lib.require_device()
+        indexes = self._normalize_indexes(torch.as_tensor(indexes).to(device))
+        flat = self._flatten_indexes(indexes).contiguous()
+        shape = tuple(flat.shape)
+        decode_shape = shape[len(shape) - self.coding_rank:] if self.coding_rank else ()
+        cdf_offset = self.cdf_offset.to(device)
+        handle = gen_ops.create_range_decoder(strings, self.cdf)
+        if tuple(handle.shape) + tuple(decode_shape) != shape:
+            raise ValueError(
+                "'index' shape should match 'handle' shape + 'shape': "
+                f"index.shape={list(shape)}, handle.shape={list(handle.shape)}, shape={list(decode_shape)}")
+        if self.fused and self.bottleneck_dtype in _DTYPE_CODE:
+            out = torch.empty(shape, dtype=self.bottleneck_dtype, device=device)
+            elems = flat.numel() // handle.streams
+            handle._keep.append(flat)
+            _lib.check(_lib.lib().tfc_decoder_decode_dequantized(
+                handle.ptr, flat.data_ptr(), out.data_ptr(), _DTYPE_CODE[self.bottleneck_dtype],
+                None, cdf_offset.data_ptr(), 0, elems, _lib.stream_ptr()))
+            sanity = gen_ops.entropy_decode_finalize(handle)
+        else:
+            handle, symbols = gen_ops.entropy_decode_index(handle, flat, decode_shape, torch.int32)
+            sanity = gen_ops.entropy_decode_finalize(handle)
+            out = (symbols + cdf_offset[flat.long()]).to(self.bottleneck_dtype)
+        if self.decode_sanity_check and not bool(sanity.all()):
+            raise RuntimeError("Sanity check failed.")
+        return out
+
+    def get_config(self):
+        raise NotImplementedError("Serializing indexed entropy models is not yet implemented.")
+
+
+class LocationScaleIndexedEntropyModel(ContinuousIndexedEntropyModel):
+    """continuous_indexed.py:431-633: `num_scales` scale tables, location handled by
+    shifting the bottleneck."""
+
+    def __init__(self, prior_fn, num_scales, scale_fn, coding_rank, compression=False,
+                 stateless=False, expected_grads=False, tail_mass=2 ** -8, range_coder_precision=12,
+                 bottleneck_dtype=None, prior_dtype=torch.float32, laplace_tail_mass=0):
+        num_scales = int(num_scales)
+        super().__init__(
+            prior_fn=prior_fn, index_ranges=(num_scales,),
+            parameter_fns=dict(loc=lambda _: 0.0, scale=scale_fn),
+            coding_rank=coding_rank, channel_axis=None, compression=compression,
+            stateless=stateless, expected_grads=expected_grads, tail_mass=tail_mass,
+            range_coder_precision=range_coder_precision, bottleneck_dtype=bottleneck_dtype,
+            prior_dtype=prior_dtype, laplace_tail_mass=laplace_tail_mass)
+
+    def forward(self, bottleneck, scale_indexes, loc=None, training=True):
+        if loc is None:
+            return super().forward(bottleneck, scale_indexes, training=training)
+        perturbed, bits = super().forward(bottleneck - loc, scale_indexes, training=training)
+        return perturbed + loc, bits
+
+    def quantize(self, bottleneck, loc=None):
+        return round_ops.round_st(torch.as_tensor(bottleneck).to(self.bottleneck_dtype), loc)
+
+    def compress(self, bottleneck, scale_indexes, loc=None):
+        if loc is not None:
+            bottleneck = bottleneck - loc
+        return super().compress(bottleneck, scale_indexes)
+
+    def decompress(self, strings, scale_indexes, loc=None):
+        values = super().decompress(strings, scale_indexes)
+        if loc is not None:
+            values = values + loc
+        return values

@@ -1,0 +1,61 @@
+"""Bound ops with the reference's gradient rules and the noise perturbation helper
+(python/ops/math_ops.py:27-216)."""
+import torch
+
+__all__ = ["upper_bound", "lower_bound", "perturb_and_apply"]
+
+_MODES = ("identity_if_towards", "identity", "disconnected")
+
+
+class _Bound(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, bound, upper, mode):
+        ctx.save_for_backward(inputs, bound)
+        ctx.upper, ctx.mode = upper, mode
+        return torch.minimum(inputs, bound) if upper else torch.maximum(inputs, bound)
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, bound = ctx.saved_tensors
+        inside = inputs <= bound if ctx.upper else inputs >= bound
+        if ctx.mode == "identity":
+            return grad, None, None, None
+        if ctx.mode == "disconnected":
+            return inside.to(grad.dtype) * grad, None, None, None
+        towards = grad > 0 if ctx.upper else grad < 0      # descent would push towards the bound
+        return (inside | towards).to(grad.dtype) * grad, None, None, None
+
+
+def _bound(inputs, bound, upper, gradient):
+    if gradient not in _MODES:
+        raise ValueError(f"Invalid value for `gradient`: '{gradient}'.")
+    inputs = torch.as_tensor(inputs)
+    bound = torch.as_tensor(bound, dtype=inputs.dtype, device=inputs.device)
+    return _Bound.apply(inputs, bound, upper, gradient)
+
+
+def upper_bound(inputs, bound, gradient="identity_if_towards"):
+    """`minimum(inputs, bound)` with the gradient rules of math_ops.py:27-90."""
+    return _bound(inputs, bound, True, gradient)
+
+
+def lower_bound(inputs, bound, gradient="identity_if_towards"):
+    """`maximum(inputs, bound)` with the gradient rules of math_ops.py:92-152."""
+    return _bound(inputs, bound, False, gradient)
+
+
+def perturb_and_apply(f, x, *args, u=None, x_plus_u=None, expected_grads=True):
+    """y = f(x + u, *args) with u ~ U(-.5, .5); with expected_grads the derivative
+    w.r.t. x is replaced by E_u[df/dx] = f(x+.5) - f(x-.5) (math_ops.py:157-216)."""
+    if x_plus_u is None:
+        if u is None:
+            u = torch.rand_like(x) - 0.5
+        x_plus_u = x + u
+    elif u is not None:
+        raise ValueError("Cannot provide both `u` and `x_plus_u`.")
+    if not expected_grads:
+        return f(x_plus_u, *args), x_plus_u
+    y = f(x_plus_u.detach(), *args)
+    with torch.no_grad():
+        dydx = f(x + 0.5, *args) - f(x - 0.5, *args)
+    return y + dydx * (x - x.detach()), x_plus_u

@@ -1,0 +1,171 @@
+"""GPU tier: compress/decompress of the entropy models (ports of
+continuous_batched_test.py:103-242 and continuous_indexed_test.py) plus pipeline
+parity: the byte strings equal the CPU oracle's for the same tables and symbols."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import compression_amd as tfc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_instantiate_statelessly_and_tables():
+    noisy = tfc.NoisyNormal(loc=0.25, scale=1.0)
+    em = tfc.ContinuousBatchedEntropyModel(noisy, coding_rank=1, compression=True)
+    assert em.compression and not em.stateless
+    assert float(em.quantization_offset) == 0.25
+    em2 = tfc.ContinuousBatchedEntropyModel(
+        compression=True, stateless=True, coding_rank=1, prior_shape=noisy.batch_shape,
+        cdf=em.cdf, cdf_offset=em.cdf_offset, quantization_offset=em.quantization_offset)
+    assert em2.stateless and float(em2.quantization_offset) == 0.25
+    with pytest.raises(RuntimeError):
+        em2.prior
+    assert em2.range_coder_precision == 12
+
+
+def test_compression_consistent_with_quantization():
+    torch.manual_seed(0)
+    noisy = tfc.NoisyNormal(loc=0.25, scale=10.0)
+    em = tfc.ContinuousBatchedEntropyModel(noisy, 1, compression=True)
+    x = 0.25 + 10 * torch.randn(100)
+    xq = em.quantize(x)
+    for fused in (True, False):
+        em.fused = fused
+        xd = em.decompress(em.compress(x), [100])
+        assert torch.equal(xd.cpu(), xq), fused
+
+
+def test_pipeline_parity_with_oracle(port):
+    """compress() == oracle(range coder) on the model's own tables and symbols."""
+    torch.manual_seed(1)
+    prior = tfc.NoisyNormal(loc=torch.linspace(-0.4, 0.4, 24), scale=torch.logspace(-1, 1.3, 24))
+    em = tfc.ContinuousBatchedEntropyModel(prior, coding_rank=3, compression=True)
+    y = torch.randn(5, 6, 7, 24) * torch.logspace(-1, 1.3, 24) * 1.5   # wider than the prior: escapes
+    strings = em.compress(y)
+    assert strings.shape == (5,)
+    off = em.quantization_offset
+    sym = torch.round(y - off).to(torch.int32).reshape(5, -1) - em.cdf_offset.repeat(42)
+    want, _, _ = port.encode(em.cdf.numpy(), sym.numpy())
+    assert [bytes(s) for s in strings] == want
+    back = em.decompress(strings, [6, 7])
+    assert torch.equal(back.cpu(), em.quantize(y))
+
+
+@pytest.mark.parametrize("scale", [2.0 ** i for i in (-2, 0, 3, 7)])
+def test_information_bounds(scale):
+    torch.manual_seed(2)
+    prior = tfc.NoisyNormal(loc=0.5, scale=scale)
+    em = tfc.ContinuousBatchedEntropyModel(prior, coding_rank=1, compression=True)
+    x = 0.5 + scale * torch.randn(1000000)
+    _, bits_eval = em(x, training=False)
+    _, bits_training = em(x, training=True)
+    s = em.compress(x)
+    bits_compressed = 8 * len(bytes(s[()]))
+    assert float(bits_training) > 0.999999 * float(bits_eval)
+    assert bits_compressed > float(bits_eval)
+    if scale >= 64:
+        assert abs(float(bits_training) - float(bits_eval)) <= 1e-4 * float(bits_eval)
+    assert abs(bits_compressed - float(bits_eval)) <= 5e-3 * float(bits_eval)
+
+
+def test_compression_works_after_serialization():
+    torch.manual_seed(3)
+    for loc, scale in ((0.5, 8.0), (0.0, 5.0)):
+        noisy = tfc.NoisyNormal(loc=loc, scale=scale)
+        em = tfc.ContinuousBatchedEntropyModel(noisy, 1, compression=True)
+        assert (em._quantization_offset is None) == (loc == 0.0)
+        config, weights, state = em.get_config(), em.get_weights(), em.state_dict()
+        x = loc + scale * torch.randn(100)
+        xq, xc = em.quantize(x), em.compress(x)
+        em2 = tfc.ContinuousBatchedEntropyModel.from_config(config)
+        em2.set_weights(weights)
+        assert bytes(em2.compress(x)[()]) == bytes(xc[()])
+        assert torch.equal(em2.decompress(xc, [100]).cpu(), xq)
+        em3 = tfc.ContinuousBatchedEntropyModel.from_config(config)
+        em3.load_state_dict(state)
+        assert bytes(em3.compress(x)[()]) == bytes(xc[()])
+
+
+def test_mixed_precision_bottleneck():
+    noisy = tfc.NoisyNormal(loc=torch.tensor(0.5, dtype=torch.float64),
+                            scale=torch.tensor(1.0, dtype=torch.float64), dtype=torch.float64)
+    for dt in (torch.float16, torch.bfloat16):
+        em = tfc.ContinuousBatchedEntropyModel(noisy, 1, compression=True, bottleneck_dtype=dt)
+        assert em.prior.dtype == torch.float64
+        x = torch.randn(2, 5).to(dt)
+        xt, bits = em(x)
+        s = em.compress(x)
+        xh = em.decompress(s, (5,))
+        assert xh.dtype == dt and xt.dtype == dt and bits.dtype == torch.float64 and bits.shape == (2,)
+        assert (xh.cpu().float() - x.float()).abs().max() <= 0.5 + 2 ** -6
+        assert torch.equal(xh.cpu(), em.quantize(x))
+        assert (bits >= 0).all()
+
+
+def test_dirac_priors():
+    prior = tfc.NoisyNormal(loc=100.0 * torch.arange(16.0), scale=1e-10)
+    em = tfc.ContinuousBatchedEntropyModel(prior, coding_rank=2, offset_heuristic=False, compression=True)
+    assert em.cdf_offset.shape[0] == 16 and em.cdf.shape[0] <= 16 * 6
+    em = tfc.ContinuousBatchedEntropyModel(prior, coding_rank=2, compression=True)
+    x = (100.0 * torch.arange(16.0)).expand(3, 1000, 16).contiguous()
+    _, bits_estimate = em(x, training=True)
+    strings = em.compress(x)
+    xd = em.decompress(strings, (1000,))
+    assert (bits_estimate <= 16).all()
+    assert all(8 * len(bytes(b)) <= 16 for b in strings.reshape(-1))
+    assert (xd.cpu() - x).abs().max() <= 0.5
+
+
+def test_noisy_deep_factorized_bottleneck(port):
+    torch.manual_seed(5)
+    em = tfc.EntropyBottleneck(8, compression=True)          # bls2017's entropy model, 8 filters
+    y = torch.randn(2, 4, 4, 8) * 6
+    s = em.compress(y)
+    assert s.shape == (2,)
+    yh = em.decompress(s, (4, 4))
+    assert torch.equal(yh.cpu(), em.quantize(y))
+    # byte parity with the oracle on the same tables
+    off = em.quantization_offset
+    sym = (torch.round(y - off) if off is not None else torch.round(y)).to(torch.int32)
+    sym = sym.reshape(2, -1) - em.cdf_offset.repeat(16)
+    want, _, _ = port.encode(em.cdf.numpy(), sym.numpy())
+    assert [bytes(b) for b in s] == want
+
+
+def _scale_fn(i):
+    return torch.exp(math.log(0.11) + (math.log(256.0) - math.log(0.11)) / 63 * i)
+
+
+def test_location_scale_indexed_roundtrip_and_parity(port):
+    torch.manual_seed(6)
+    em = tfc.LocationScaleIndexedEntropyModel(tfc.NoisyNormal, num_scales=64, scale_fn=_scale_fn,
+                                              coding_rank=3, compression=True)
+    idx = torch.randint(0, 64, (3, 8, 12, 16)).float()
+    y = torch.randn(3, 8, 12, 16) * _scale_fn(idx) * 1.2
+    for fused in (True, False):
+        em.fused = fused
+        s = em.compress(y, idx)
+        assert s.shape == (3,)
+        yh = em.decompress(s, idx)
+        assert torch.equal(yh.cpu(), torch.round(y)), fused
+    flat = idx.to(torch.int32)
+    sym = torch.round(y).to(torch.int32) - em.cdf_offset[flat.long()]
+    want, _, _ = port.encode(em.cdf.numpy(), sym.reshape(3, -1).numpy(), index=flat.reshape(3, -1).numpy())
+    assert [bytes(b) for b in s] == want
+    loc = torch.randn_like(y)
+    s2 = em.compress(y, idx, loc=loc)
+    assert torch.allclose(em.decompress(s2, idx, loc=loc.cuda()).cpu(), torch.round(y - loc) + loc)
+
+
+def test_indexed_bits_close_to_rate():
+    torch.manual_seed(7)
+    em = tfc.LocationScaleIndexedEntropyModel(tfc.NoisyNormal, num_scales=64, scale_fn=_scale_fn,
+                                              coding_rank=1, compression=True)
+    idx = torch.randint(8, 56, (200000,)).float()
+    y = torch.randn(200000) * _scale_fn(idx)
+    _, bits = em(y, idx, training=False)
+    n = 8 * len(bytes(em.compress(y, idx)[()]))
+    assert float(bits) < n <= 1.01 * float(bits)
