@@ -46,9 +46,9 @@ SIGNATURES = {
     "tfc_gdn_backward": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _int, _int, _int,
                                 _int, _vp, _vp, _vp]),
     "tfc_conv2d_down": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int,
-                               _int, _int, _vp]),
+                               _int, _int, _int, _vp]),
     "tfc_conv2d_up": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int,
-                             _int, _int, _vp]),
+                             _int, _int, _int, _vp]),
 }
 
 _lib = None

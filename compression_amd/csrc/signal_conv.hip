@@ -1,0 +1,415 @@
+// SignalConv2D for gfx950: 2-D, non-separable, `same_zeros`, NHWC
+// (python/layers/signal_conv.py:663-690 `_correlate_down_explicit` and
+//  :778-847 `_up_convolve_transpose_explicit`, extra_pad_end=True).
+//
+// ONE implicit-GEMM kernel serves both directions:
+//   down (analysis):  y[q] = sum_u x[q*sd + u - k/2] * w[u]            (cross-correlation)
+//   up (synthesis):   y[q*s + phi] = sum_i x[i] * w[phi + (q-i)*s + k/2]  (transposed conv)
+// The upsampled convolution is decomposed into its s*s output phases; each phase
+// is a small stride-1 correlation over the LOW-resolution input, and the phases
+// become extra output columns (N' = s*s*Cout) that the epilogue scatters back
+// (depth-to-space).  No zero-insertion, no wasted multiplies on inserted zeros.
+//
+// GEMM orientation is the same as in gdn.hip: D^T = W'^T * patches^T, i.e. the
+// MFMA A operand is the packed weight tile (rows = output columns) staged in
+// LDS, the B operand is 8 consecutive input channels of ONE pixel per lane —
+// a plain 16-byte load from the NHWC tensor, zero-filled outside the image.
+// A lane therefore ends up with groups of 4 consecutive output channels of one
+// pixel, which leave as 8/16-byte stores after bias (+ ReLU).
+//
+// bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate.  f32: v_mfma_f32_32x32x2_f32
+// (exact fp32 FMA chains; 1/16 of the bf16 rate) for the parity path.
+// Cin must be a multiple of 16, or <= 4 (image input: the host packs it to a
+// zero-bordered 4-channel buffer and whole kernel rows become contiguous K runs).
+// Roofline: MFMA-bound, 2*M*K*N FLOP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/tfc_hip.h"
+#include "common.h"
+
+namespace tfc {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kConvWaves = 4;          // pixel tiles (32 px) per workgroup
+constexpr int kMaxTiles = 6;           // 32-column tiles per column group (192 columns)
+
+struct ConvGeom {
+  // input
+  long long N;
+  int H, W, Cin;          // Cin as seen by the kernel (4 for packed image input)
+  int Hp, Wp;             // packed image input: padded extents (else H, W)
+  // low-resolution output grid the GEMM rows run over
+  int OHq, OWq;
+  int sd;                 // input step per output row/col
+  int Uy, Ux;             // taps of the equivalent correlation
+  int py0, px0;           // zero padding before
+  // columns
+  int Cout, su;           // real output channels, depth-to-space factor
+  int cols;               // su*su*Cout
+  int groups;             // column groups of `tiles` 32-wide tiles
+  int tiles;
+  // K
+  int ksteps;             // K steps of 16
+  int kchunk;             // K steps staged in LDS at a time
+  int small_cin;          // 1: packed-image mode (K runs along kernel rows)
+  int kw4;                // small_cin: K steps per kernel row
+  int activation;         // 0 none, 1 relu
+  // output
+  int OH, OW;
+};
+
+template <typename T> struct ConvTraits;
+template <> struct ConvTraits<__bf16> {
+  static constexpr int kFragBytes = 16;        // A fragment bytes per lane per K step per tile
+};
+template <> struct ConvTraits<float> {
+  static constexpr int kFragBytes = 32;
+};
+
+// ---------------------------------------------------------------------------
+// Weight packing: A fragments in the order the main kernel reads them:
+//   packed[((group * ksteps + ks) * tiles + t) * 64 + lane]  (16 B bf16 / 32 B f32)
+// lane (i = lane & 31, h = lane >> 5), element e (0..7): K offset 8h + e of step ks,
+// output column group*tiles*32 + 32 t + i.
+// ---------------------------------------------------------------------------
+struct PackGeom {
+  int kh, kw, Cin_real, Cout, su, up;
+  int Uy, Ux, dmax_y, dmax_x;
+};
+
+__device__ inline float packed_weight(const float* w, const PackGeom& g, const ConvGeom& c, int ks,
+                                      int koff, int col) {
+  if (col >= c.cols) return 0.f;
+  int uy, ux, ci;
+  if (c.small_cin) {
+    uy = ks / c.kw4;
+    const int o = (ks % c.kw4) * 16 + koff;
+    ux = o >> 2;
+    ci = o & 3;
+    if (ux >= c.Ux || ci >= g.Cin_real) return 0.f;
+  } else {
+    const int cb = c.Cin / 16;
+    const int tap = ks / cb;
+    uy = tap / c.Ux;
+    ux = tap % c.Ux;
+    ci = (ks % cb) * 16 + koff;
+  }
+  const int co = col % g.Cout;
+  int ty, tx;
+  if (g.up) {
+    const int phase = col / g.Cout;
+    const int phy = phase / g.su, phx = phase % g.su;
+    // tap u reads input i = q + u - dmax, i.e. d = q - i = dmax - u; kernel index t = phi + d*s + k/2
+    ty = phy + (g.dmax_y - uy) * g.su + g.kh / 2;
+    tx = phx + (g.dmax_x - ux) * g.su + g.kw / 2;
+    if (ty < 0 || ty >= g.kh || tx < 0 || tx >= g.kw) return 0.f;
+  } else {
+    ty = uy;
+    tx = ux;
+  }
+  return w[((static_cast<long long>(ty) * g.kw + tx) * g.Cin_real + ci) * g.Cout + co];
+}
+
+template <typename T>
+__global__ void conv_pack_kernel(const float* w, PackGeom g, ConvGeom c, void* packed) {
+  const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  const long long total = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  long long rest = idx >> 6;
+  const int t = rest % c.tiles; rest /= c.tiles;
+  const int ks = rest % c.ksteps;
+  const int group = static_cast<int>(rest / c.ksteps);
+  const int i = lane & 31, h = lane >> 5;
+  const int col = (group * c.tiles + t) * 32 + i;
+  if constexpr (std::is_same<T, __bf16>::value) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = static_cast<__bf16>(packed_weight(w, g, c, ks, 8 * h + e, col));
+    static_cast<bf16x8*>(packed)[idx] = v;
+  } else {
+    // f32: K offset of MFMA step u (0..7), half h is 8h + u -> store u-major
+    float* dst = static_cast<float*>(packed) + idx * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = packed_weight(w, g, c, ks, 8 * h + e, col);
+  }
+}
+
+// Image input (Cin <= 4): zero-bordered 4-channel copy so that a kernel row is one
+// contiguous K run.  xp[n][y + py0][x + px0][c] = x[n][y][x][c].
+template <typename T>
+__global__ void conv_pad_image_kernel(const T* x, ConvGeom c, int cin_real, T* xp) {
+  const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  const long long total = c.N * c.Hp * c.Wp;
+  if (idx >= total) return;
+  const int xw = idx % c.Wp;
+  const int yh = (idx / c.Wp) % c.Hp;
+  const long long n = idx / (static_cast<long long>(c.Wp) * c.Hp);
+  const int sy = yh - c.py0, sx = xw - c.px0;
+  T v[4] = {T(0.f), T(0.f), T(0.f), T(0.f)};
+  if (sy >= 0 && sy < c.H && sx >= 0 && sx < c.W)
+    for (int ch = 0; ch < cin_real; ++ch) v[ch] = x[((n * c.H + sy) * c.W + sx) * cin_real + ch];
+  for (int ch = 0; ch < 4; ++ch) xp[idx * 4 + ch] = v[ch];
+}
+
+// ---------------------------------------------------------------------------
+// Main kernel
+// ---------------------------------------------------------------------------
+template <typename T, int TILES>
+__global__ void __launch_bounds__(64 * kConvWaves) conv_kernel(const T* x, const void* packed,
+                                                               const float* bias, T* y, ConvGeom c) {
+  constexpr bool BF = std::is_same<T, __bf16>::value;
+  constexpr int FB = ConvTraits<T>::kFragBytes;
+  extern __shared__ unsigned char smem[];          // kchunk * TILES * 64 fragments
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int h = lane >> 5;
+  const int group = blockIdx.x % c.groups;         // column groups innermost: neighbours share inputs
+  const long long pblock = blockIdx.x / c.groups;
+  const long long M = c.N * c.OHq * c.OWq;
+  const long long m = (pblock * kConvWaves + wid) * 32 + (lane & 31);
+  const bool live = m < M;
+  const long long mm = live ? m : M - 1;
+  const int qx = mm % c.OWq;
+  const int qy = (mm / c.OWq) % c.OHq;
+  const long long n = mm / (static_cast<long long>(c.OWq) * c.OHq);
+
+  f32x16 acc[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const unsigned char* wsrc = static_cast<const unsigned char*>(packed) +
+                              static_cast<size_t>(group) * c.ksteps * TILES * 64 * FB;
+  const int cb = c.small_cin ? 1 : c.Cin / 16;
+
+  for (int k0 = 0; k0 < c.ksteps; k0 += c.kchunk) {
+    const int kn = min(c.kchunk, c.ksteps - k0);
+    __syncthreads();
+    {  // stage the chunk's weight fragments: contiguous 16-byte copies
+      const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + static_cast<size_t>(k0) * TILES * 64 * FB);
+      u32x4* dst = reinterpret_cast<u32x4*>(smem);
+      const int n16 = kn * TILES * 64 * FB / 16;
+      for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int kk = 0; kk < kn; ++kk) {
+      const int ks = k0 + kk;
+      // ---- B fragment: 8 input values of this lane's pixel at K offset 8h ----
+      const T* src;
+      bool ok = live;
+      if (c.small_cin) {
+        const int uy = ks / c.kw4;
+        const int seg = ks % c.kw4;
+        // zero-bordered image: always in bounds (the buffer carries a right margin)
+        src = x + ((n * c.Hp + (qy * c.sd + uy)) * c.Wp + qx * c.sd) * 4 + seg * 16 + 8 * h;
+      } else {
+        const int tap = ks / cb;
+        const int uy = tap / c.Ux, ux = tap % c.Ux;
+        const int iy = qy * c.sd + uy - c.py0, ix = qx * c.sd + ux - c.px0;
+        ok = ok && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W;
+        src = x + ((n * c.H + (ok ? iy : 0)) * c.W + (ok ? ix : 0)) * c.Cin + (ks % cb) * 16 + 8 * h;
+      }
+      if constexpr (BF) {
+        u32x4 v = ok ? *reinterpret_cast<const u32x4*>(src) : u32x4{0u, 0u, 0u, 0u};
+        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
+        const bf16x8* a = reinterpret_cast<const bf16x8*>(smem) + (kk * TILES) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t * 64], bfrag, acc[t], 0, 0, 0);
+      } else {
+        f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 v1 = ok ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4* a = reinterpret_cast<const f32x4*>(smem) + ((kk * TILES) * 64 + lane) * 2;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          const f32x4 a0 = a[t * 128], a1 = a[t * 128 + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], v0[e], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], v1[e], acc[t], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: acc[t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel m ----
+  if (!live) return;
+  const int colbase = group * TILES * 32;
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col0 = colbase + 32 * t + 8 * q + 4 * h;
+      if (col0 >= c.cols) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = col0 + r;
+        float b = 0.f;
+        if (bias && col < c.cols) b = bias[col % c.Cout];
+        v[r] = acc[t][4 * q + r] + b;
+        if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (c.su == 1 && (c.Cout & 3) == 0) {
+        T* dst = y + mm * c.Cout + col0;
+        if constexpr (BF) {
+          u32x2 o;
+          o.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          o.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          *reinterpret_cast<u32x2*>(dst) = o;
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = col0 + r;
+          if (col >= c.cols) continue;
+          const int co = col % c.Cout, phase = col / c.Cout;
+          const int oy = qy * c.su + phase / c.su, ox = qx * c.su + phase % c.su;
+          y[((n * c.OH + oy) * c.OW + ox) * c.Cout + co] = static_cast<T>(v[r]);
+        }
+      }
+    }
+}
+
+template <typename T>
+int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom c, PackGeom g,
+             hipStream_t st) {
+  constexpr int FB = ConvTraits<T>::kFragBytes;
+  const int tiles_total = (c.cols + 31) / 32;
+  c.tiles = std::min(tiles_total, kMaxTiles);
+  c.groups = (tiles_total + c.tiles - 1) / c.tiles;
+  // 64 KiB of LDS per workgroup (two workgroups per CU)
+  c.kchunk = std::max(1, std::min(c.ksteps, (64 * 1024) / (c.tiles * 64 * FB)));
+  const size_t lds = static_cast<size_t>(c.kchunk) * c.tiles * 64 * FB;
+
+  DevBuf packed, padded;
+  const long long frags = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
+  TFC_HIP(packed.alloc(static_cast<size_t>(frags) * FB, st));
+  hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(static_cast<unsigned>(ceil_div(frags, 256))),
+                     dim3(256), 0, st, w, g, c, packed.p);
+  const T* xin = static_cast<const T*>(x);
+  if (c.small_cin) {
+    // right margin: a K run may read up to kw4*16 values past the last window start
+    const size_t elems = (static_cast<size_t>(c.N) * c.Hp * c.Wp + c.kw4 * 16 + 16) * 4;
+    TFC_HIP(padded.alloc(elems * sizeof(T), st));
+    TFC_HIP(hipMemsetAsync(padded.p, 0, elems * sizeof(T), st));
+    const long long total = c.N * c.Hp * c.Wp;
+    hipLaunchKernelGGL((conv_pad_image_kernel<T>), dim3(static_cast<unsigned>(ceil_div(total, 256))),
+                       dim3(256), 0, st, xin, c, g.Cin_real, padded.as<T>());
+    xin = padded.as<T>();
+  }
+  const long long M = c.N * c.OHq * c.OWq;
+  const long long pblocks = ceil_div(M, 32 * kConvWaves);
+  if (pblocks * c.groups >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
+  const dim3 grid(static_cast<unsigned>(pblocks * c.groups));
+  KernelTimer timer("conv2d", st);
+#define TFC_CONV_CASE(NT)                                                                        \
+  case NT:                                                                                       \
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, NT>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+    hipLaunchKernelGGL((conv_kernel<T, NT>), grid, dim3(64 * kConvWaves), lds, st, xin, packed.p, \
+                       bias, static_cast<T*>(y), c);                                             \
+    break
+  switch (c.tiles) {
+    TFC_CONV_CASE(1);
+    TFC_CONV_CASE(2);
+    TFC_CONV_CASE(3);
+    TFC_CONV_CASE(4);
+    TFC_CONV_CASE(5);
+    default:
+      TFC_CONV_CASE(6);
+  }
+#undef TFC_CONV_CASE
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
+               int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
+               int activation, int up, void* stream) {
+  if (dtype != 0 && dtype != 1) return fail("tfc_conv2d: dtype must be 0 (float32) or 1 (bfloat16)");
+  if (kh < 1 || kw < 1 || stride < 1 || cin < 1 || cout < 1) return fail("tfc_conv2d: bad geometry");
+  if (!(cin % 16 == 0 || cin <= 4))
+    return fail("tfc_conv2d: input channels must be a multiple of 16 or <= 4 (got %lld)",
+                static_cast<long long>(cin));
+  if (activation != 0 && activation != 1) return fail("tfc_conv2d: activation must be 0 (none) or 1 (relu)");
+  if (n == 0 || h == 0 || wd == 0) return 0;
+  ConvGeom c{};
+  PackGeom g{};
+  g.kh = kh; g.kw = kw; g.Cin_real = static_cast<int>(cin); g.Cout = static_cast<int>(cout);
+  g.up = up; g.su = up ? stride : 1;
+  c.N = n; c.H = static_cast<int>(h); c.W = static_cast<int>(wd);
+  c.Cout = static_cast<int>(cout);
+  c.activation = activation;
+  if (!up) {
+    c.sd = stride; c.su = 1;
+    c.Uy = kh; c.Ux = kw;
+    c.py0 = kh / 2; c.px0 = kw / 2;
+    c.OHq = static_cast<int>((h + stride - 1) / stride);
+    c.OWq = static_cast<int>((wd + stride - 1) / stride);
+  } else {
+    // y[q*s + phi] = sum_d x[q - d] w[phi + d*s + k/2]; d in [dmin, dmax] over all phases
+    auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    const int s = stride;
+    g.dmax_y = fdiv(kh - 1 - kh / 2, s);
+    g.dmax_x = fdiv(kw - 1 - kw / 2, s);
+    const int dmin_y = -fdiv((s - 1) + kh / 2, s), dmin_x = -fdiv((s - 1) + kw / 2, s);
+    c.sd = 1; c.su = s;
+    c.Uy = g.dmax_y - dmin_y + 1; c.Ux = g.dmax_x - dmin_x + 1;
+    c.py0 = g.dmax_y; c.px0 = g.dmax_x;
+    c.OHq = c.H; c.OWq = c.W;
+  }
+  g.Uy = c.Uy; g.Ux = c.Ux;
+  c.cols = c.su * c.su * c.Cout;
+  c.OH = c.OHq * c.su; c.OW = c.OWq * c.su;
+  if (cin <= 4) {
+    c.small_cin = 1;
+    c.Cin = 4;
+    c.kw4 = (c.Ux * 4 + 15) / 16;
+    c.ksteps = c.Uy * c.kw4;
+    c.Hp = (c.OHq - 1) * c.sd + c.Uy;
+    c.Wp = std::max((c.OWq - 1) * c.sd + c.Ux, c.px0 + c.W);
+    c.Hp = std::max(c.Hp, c.py0 + c.H);
+  } else {
+    c.small_cin = 0;
+    c.Cin = static_cast<int>(cin);
+    c.Hp = c.H; c.Wp = c.W;
+    c.ksteps = c.Uy * c.Ux * (c.Cin / 16);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float* wf = static_cast<const float*>(w);
+  return dtype == 1 ? run_conv<__bf16>(x, wf, bias, y, c, g, st) : run_conv<float>(x, wf, bias, y, c, g, st);
+}
+
+}  // namespace tfc
+
+extern "C" int tfc_conv2d_down(const void* x, const void* w, const float* bias, void* y, int dtype,
+                               int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh,
+                               int kw, int stride, int activation, void* stream) {
+  return tfc::conv_entry(x, w, bias, y, dtype, n, h, wd, cin, cout, kh, kw, stride, activation, 0, stream);
+}
+
+extern "C" int tfc_conv2d_up(const void* x, const void* w, const float* bias, void* y, int dtype,
+                             int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh,
+                             int kw, int stride, int activation, void* stream) {
+  return tfc::conv_entry(x, w, bias, y, dtype, n, h, wd, cin, cout, kh, kw, stride, activation, 1, stream);
+}

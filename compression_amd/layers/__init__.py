@@ -1,1 +1,1 @@
-from .functional import gdn_forward  # noqa: F401
+from .functional import conv2d_down, conv2d_up, gdn_forward  # noqa: F401

@@ -29,3 +29,39 @@ def gdn_forward(x: torch.Tensor, beta: torch.Tensor, gamma: torch.Tensor, invers
         gamma.data_ptr(), int(bool(inverse)), int(bool(rectify)), int(alpha),
         1 if epsilon == 0.5 else 0, _lib.stream_ptr()))
     return y
+
+
+def _conv(fn_name, x, kernel, bias, stride, activation, up):
+    _lib.require_device()
+    if x.dtype not in _DTYPE_CODE:
+        raise TypeError(f"conv kernel supports float32 and bfloat16, got {x.dtype}")
+    if x.dim() != 4:
+        raise ValueError(f"Input tensor must have rank 4, received shape {tuple(x.shape)}.")
+    x = x.contiguous()
+    n, h, w, cin = x.shape
+    kh, kw, kcin, cout = kernel.shape
+    if kcin != cin:
+        raise ValueError(f"kernel expects {kcin} input channels, input has {cin}")
+    kernel = kernel.detach().to(x.device, torch.float32).contiguous()
+    if bias is not None:
+        bias = bias.detach().to(x.device, torch.float32).contiguous()
+    if up:
+        oh, ow = h * stride, w * stride
+    else:
+        oh, ow = -(-h // stride), -(-w // stride)
+    y = torch.empty((n, oh, ow, cout), dtype=x.dtype, device=x.device)
+    act = {None: 0, "relu": 1}[activation]
+    _lib.check(getattr(_lib.lib(), fn_name)(
+        x.data_ptr(), kernel.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+        _DTYPE_CODE[x.dtype], n, h, w, cin, cout, kh, kw, int(stride), act, _lib.stream_ptr()))
+    return y
+
+
+def conv2d_down(x, kernel, bias=None, stride=1, activation=None):
+    """Analysis correlation (signal_conv.py:663-690): NHWC x, HWIO kernel, `same_zeros`."""
+    return _conv("tfc_conv2d_down", x, kernel, bias, stride, activation, False)
+
+
+def conv2d_up(x, kernel, bias=None, stride=1, activation=None):
+    """Synthesis transposed convolution (signal_conv.py:778-847, extra_pad_end=True)."""
+    return _conv("tfc_conv2d_up", x, kernel, bias, stride, activation, True)

@@ -211,21 +211,24 @@ int tfc_gdn_backward(const void* x, const void* g, void* dx, int dtype, int64_t 
 
 /* _correlate_down_explicit — python/layers/signal_conv.py:663-690:
  * cross-correlation with zero padding (k/2, (k-1)/2) and stride `stride`;
- * out = ceil(in / stride).  x DEV [N,H,W,Cin], w DEV [kh,kw,Cin,Cout] (HWIO),
- * bias DEV f32 [Cout] or NULL, y DEV [N,ceil(H/s),ceil(W/s),Cout]; dtype 0 f32,
- * 1 bf16 (weights in the same dtype). */
+ * out = ceil(in / stride), first output aligned with the first input.
+ * x DEV [N,H,W,Cin] (dtype: 0 f32, 1 bf16), w DEV float32 [kh,kw,Cin,Cout] (HWIO, the
+ * layer's `kernel`), bias DEV f32 [Cout] or NULL, y DEV [N,ceil(H/s),ceil(W/s),Cout]
+ * (same dtype as x).  activation: 0 none, 1 ReLU (fused).  Cin must be a
+ * multiple of 16 or <= 4. */
 int tfc_conv2d_down(const void* x, const void* w, const float* bias, void* y, int dtype,
                     int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout,
-                    int kh, int kw, int stride, void* stream);
+                    int kh, int kw, int stride, int activation, void* stream);
 
-/* _up_convolve_transpose_explicit — python/layers/signal_conv.py:778-847:
- * zero-insertion upsampling by `stride` followed by a true convolution centred
- * at k/2; out = in * stride.  w DEV [kh,kw,Cout,Cin] as the reference stores
- * it for transposed use is NOT assumed: pass HWIO [kh,kw,Cin,Cout] of the
- * equivalent forward kernel; the library does the flip/phase split. */
+/* _up_convolve_transpose_explicit — python/layers/signal_conv.py:778-847 with
+ * extra_pad_end=True: zero-insertion upsampling by `stride` followed by a true
+ * convolution centred at k/2, i.e. y[q*s + phi] = sum_i x[i] * w[phi + (q-i)*s + k/2];
+ * out = in * stride.  w is the layer's own HWIO kernel [kh,kw,Cin,Cout]; the
+ * library does the phase split.  stride 1 gives the flipped-kernel correlation
+ * the reference uses for `corr=False` without upsampling (signal_conv.py:865-870). */
 int tfc_conv2d_up(const void* x, const void* w, const float* bias, void* y, int dtype,
                   int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout,
-                  int kh, int kw, int stride, void* stream);
+                  int kh, int kw, int stride, int activation, void* stream);
 
 #ifdef __cplusplus
 }

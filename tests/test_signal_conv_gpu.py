@@ -1,0 +1,127 @@
+"""GPU tier: SignalConv2D kernels (2-D, same_zeros, explicit-padding paths,
+python/layers/signal_conv.py:663-690, 778-847) against a torch fp32 evaluation of
+the same definition (conv2d with explicit padding / conv_transpose2d), which plays
+the role of the reference test's NumPy/SciPy oracle (signal_conv_test.py:171-264),
+plus the identity-kernel alignment checks of signal_conv_test.py:266-314."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_down(x, k, bias, stride, relu):
+    kh, kw = k.shape[:2]
+    xp = F.pad(x.permute(0, 3, 1, 2), (kw // 2, (kw - 1) // 2, kh // 2, (kh - 1) // 2))
+    y = F.conv2d(xp, k.permute(3, 2, 0, 1), bias, stride=stride)
+    y = y.permute(0, 2, 3, 1)
+    return F.relu(y) if relu else y
+
+
+def ref_up(x, k, bias, stride, relu):
+    # y[j] = sum_i x[i] w[j - i*s + k//2], length in*s (extra_pad_end=True)
+    kh, kw = k.shape[:2]
+    n, h, w, _ = x.shape
+    full = F.conv_transpose2d(x.permute(0, 3, 1, 2), k.permute(2, 3, 0, 1), bias, stride=stride)
+    full = F.pad(full, (0, kw, 0, kh))       # room for the crop below
+    y = full[:, :, kh // 2:kh // 2 + h * stride, kw // 2:kw // 2 + w * stride]
+    y = y.permute(0, 2, 3, 1)
+    return F.relu(y) if relu else y
+
+
+CASES = [
+    # (N, H, W, Cin, Cout, k, stride)
+    (2, 19, 23, 3, 32, 9, 4),      # bls2017 analysis layer 0 shape class (image input)
+    (1, 16, 18, 3, 192, 5, 2),     # bmshj2018 analysis layer 0
+    (2, 17, 13, 32, 64, 5, 2),
+    (1, 9, 11, 192, 192, 5, 2),    # the C -> C layers
+    (1, 8, 8, 48, 32, 3, 1),       # hyper-analysis 3x3 s1
+    (1, 10, 7, 16, 40, 4, 2),      # even kernel, asymmetric padding
+    (1, 6, 5, 64, 320, 5, 2),      # more than one column group
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_down_f32(case, relu):
+    from compression_amd.layers import conv2d_down
+    n, h, w, cin, cout, k, s = case
+    torch.manual_seed(0)
+    x = torch.randn(n, h, w, cin)
+    ker = torch.randn(k, k, cin, cout) / np.sqrt(k * k * cin)
+    bias = torch.randn(cout)
+    y = conv2d_down(x.cuda(), ker, bias, s, "relu" if relu else None).cpu()
+    want = ref_down(x, ker, bias, s, relu)
+    assert y.shape == want.shape == (n, -(-h // s), -(-w // s), cout)
+    assert (y - want).abs().max() <= 2e-5 * max(1.0, want.abs().max())
+
+
+UP_CASES = [
+    (2, 7, 9, 32, 32, 5, 2),
+    (1, 6, 5, 192, 192, 5, 2),     # synthesis C -> C
+    (1, 5, 6, 192, 3, 9, 4),       # bls2017 synthesis last layer (C -> 3, x4)
+    (1, 8, 7, 64, 3, 5, 2),        # bmshj2018 synthesis last layer
+    (1, 9, 8, 48, 48, 3, 1),       # corr=False without upsampling (flipped kernel)
+    (1, 5, 5, 16, 24, 4, 2),       # even kernel
+    (1, 4, 6, 32, 96, 5, 3),
+]
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+def test_up_f32(case):
+    from compression_amd.layers import conv2d_up
+    n, h, w, cin, cout, k, s = case
+    torch.manual_seed(1)
+    x = torch.randn(n, h, w, cin)
+    ker = torch.randn(k, k, cin, cout) / np.sqrt(k * k * cin)
+    bias = torch.randn(cout)
+    y = conv2d_up(x.cuda(), ker, bias, s).cpu()
+    want = ref_up(x, ker, bias, s, False)
+    assert y.shape == want.shape == (n, h * s, w * s, cout)
+    assert (y - want).abs().max() <= 2e-5 * max(1.0, want.abs().max())
+
+
+def test_bf16_paths():
+    from compression_amd.layers import conv2d_down, conv2d_up
+    torch.manual_seed(2)
+    x = torch.randn(2, 12, 10, 64).bfloat16()
+    ker = (torch.randn(5, 5, 64, 96) / 40).bfloat16().float()     # weights exactly representable
+    bias = torch.randn(96)
+    want = ref_down(x.float(), ker, bias, 2, True)
+    y = conv2d_down(x.cuda(), ker, bias, 2, "relu").float().cpu()
+    assert (y - want).abs().max() <= 2 ** -7 * max(1.0, want.abs().max())
+    want = ref_up(x.float(), ker, bias, 2, False)
+    y = conv2d_up(x.cuda(), ker, bias, 2).float().cpu()
+    assert (y - want).abs().max() <= 2 ** -7 * max(1.0, want.abs().max())
+    xi = torch.rand(1, 20, 20, 3).bfloat16()
+    k0 = (torch.randn(9, 9, 3, 32) / 16).bfloat16().float()
+    y = conv2d_down(xi.cuda(), k0, None, 4).float().cpu()
+    want = ref_down(xi.float(), k0, None, 4, False)
+    assert (y - want).abs().max() <= 2 ** -7 * max(1.0, want.abs().max())
+
+
+def test_identity_kernel_alignment():
+    """signal_conv_test.py:266-314: with a centred delta kernel, `same_zeros` output
+    sample 0 is aligned with input sample 0 (down: subsampling; up: zero-stuffing)."""
+    from compression_amd.layers import conv2d_down, conv2d_up
+    C = 16
+    x = torch.arange(1.0, 1 + 2 * 9 * 11 * C).reshape(2, 9, 11, C) / 100
+    for k in (3, 4, 5):
+        ker = torch.zeros(k, k, C, C)
+        ker[k // 2, k // 2] = torch.eye(C)
+        for s in (1, 2, 3):
+            y = conv2d_down(x.cuda(), ker, None, s).cpu()
+            assert torch.equal(y, x[:, ::s, ::s])
+            yu = conv2d_up(x.cuda(), ker, None, s).cpu()
+            want = torch.zeros(2, 9 * s, 11 * s, C)
+            want[:, ::s, ::s] = x
+            assert torch.equal(yu, want), (k, s)
+
+
+def test_argument_errors():
+    from compression_amd.layers import conv2d_down
+    with pytest.raises(ValueError, match="multiple of 16"):
+        conv2d_down(torch.zeros(1, 4, 4, 10).cuda(), torch.zeros(3, 3, 10, 8))
+    with pytest.raises(ValueError, match="rank 4"):
+        conv2d_down(torch.zeros(4, 4, 16).cuda(), torch.zeros(3, 3, 16, 8))
