@@ -15,3 +15,4 @@ from .entropy_models import *  # noqa: F401,F403
 from .layers import *  # noqa: F401,F403
 
 __version__ = "0.1.0"
+from . import models  # noqa: F401,E402

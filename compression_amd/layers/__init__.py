@@ -1,1 +1,3 @@
-from .functional import conv2d_down, conv2d_up, gdn_forward  # noqa: F401
+from .functional import conv2d_down, conv2d_up, gdn_backward, gdn_forward  # noqa: F401
+from .gdn import GDN  # noqa: F401
+from .signal_conv import SignalConv2D  # noqa: F401

@@ -65,3 +65,21 @@ def conv2d_down(x, kernel, bias=None, stride=1, activation=None):
 def conv2d_up(x, kernel, bias=None, stride=1, activation=None):
     """Synthesis transposed convolution (signal_conv.py:778-847, extra_pad_end=True)."""
     return _conv("tfc_conv2d_up", x, kernel, bias, stride, activation, True)
+
+
+def gdn_backward(x, grad, beta, gamma, inverse=False, rectify=False, alpha=1, epsilon=1):
+    """Gradients of gdn_forward w.r.t. (x, beta, gamma) on the HIP kernel."""
+    _lib.require_device()
+    x = x.contiguous()
+    grad = grad.contiguous()
+    C = x.shape[-1]
+    beta = beta.detach().to(x.device, torch.float32).contiguous()
+    gamma = gamma.detach().to(x.device, torch.float32).contiguous()
+    dx = torch.empty_like(x)
+    dbeta = torch.zeros(C, dtype=torch.float32, device=x.device)
+    dgamma = torch.zeros(C, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tfc_gdn_backward(
+        x.data_ptr(), grad.data_ptr(), dx.data_ptr(), _DTYPE_CODE[x.dtype], x.numel() // C, C,
+        beta.data_ptr(), gamma.data_ptr(), int(bool(inverse)), int(bool(rectify)), int(alpha),
+        1 if epsilon == 0.5 else 0, dbeta.data_ptr(), dgamma.data_ptr(), _lib.stream_ptr()))
+    return dx, dbeta, dgamma

@@ -1,0 +1,87 @@
+"""`GDN` layer (python/layers/gdn.py:41-470) on the fused HIP kernel."""
+from __future__ import annotations
+
+import torch
+
+from . import functional, parameters
+
+__all__ = ["GDN"]
+
+
+class _GDNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, beta, gamma, inverse, rectify, alpha, epsilon):
+        ctx.save_for_backward(x, beta, gamma)
+        ctx.cfg = (inverse, rectify, alpha, epsilon)
+        return functional.gdn_forward(x, beta, gamma, inverse, rectify, alpha, epsilon)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, beta, gamma = ctx.saved_tensors
+        inverse, rectify, alpha, epsilon = ctx.cfg
+        dx, dbeta, dgamma = functional.gdn_backward(x, grad.contiguous(), beta, gamma, inverse,
+                                                    rectify, alpha, epsilon)
+        return dx, dbeta, dgamma, None, None, None, None
+
+
+class GDN(torch.nn.Module):
+    """y_i = x_i / (beta_i + sum_j gamma[j, i] |x_j|^alpha)^epsilon  (inverse: multiply).
+
+    Same constructor arguments as the reference layer (gdn.py:127-139); alpha and
+    epsilon are fixed scalars in {1, 2} / {1, .5} (the fast paths of gdn.py:377-416).
+    Weights: `reparam_beta` [C], `reparam_gamma` [C, C] (gdn_test.py:97-100), created
+    on first call like a Keras `build`."""
+
+    def __init__(self, inverse=False, rectify=False, data_format="channels_last",
+                 alpha_parameter=1, beta_parameter=None, gamma_parameter=None,
+                 epsilon_parameter=1, beta_initializer=None, gamma_initializer=None,
+                 num_channels=None):
+        super().__init__()
+        if data_format not in ("channels_first", "channels_last"):
+            raise ValueError(f"Unknown data format: '{data_format}'.")
+        if alpha_parameter not in (1, 2) or epsilon_parameter not in (1, 0.5):
+            raise NotImplementedError(
+                "The HIP GDN kernel implements alpha in {1, 2} and epsilon in {1, .5}.")
+        self.inverse, self.rectify = bool(inverse), bool(rectify)
+        self.data_format = data_format
+        self.alpha, self.epsilon = alpha_parameter, epsilon_parameter
+        self._beta_fixed, self._gamma_fixed = beta_parameter, gamma_parameter
+        self._beta_init = beta_initializer or (lambda c: torch.ones(c))
+        self._gamma_init = gamma_initializer or (lambda c: 0.1 * torch.eye(c))
+        self.reparam_beta = self.reparam_gamma = None
+        if num_channels is not None:
+            self.build(int(num_channels))
+
+    def build(self, c, device=None):
+        if self._beta_fixed is None and self.reparam_beta is None:
+            self.reparam_beta = torch.nn.Parameter(
+                parameters.gdn_reparam_init(self._beta_init(c).float()).to(device))
+        if self._gamma_fixed is None and self.reparam_gamma is None:
+            self.reparam_gamma = torch.nn.Parameter(
+                parameters.gdn_reparam_init(self._gamma_init(c).float()).to(device))
+
+    @property
+    def beta(self):
+        if self._beta_fixed is not None:
+            return torch.as_tensor(self._beta_fixed() if callable(self._beta_fixed) else self._beta_fixed)
+        return parameters.gdn_reparam_value(self.reparam_beta, minimum=1e-6)
+
+    @property
+    def gamma(self):
+        if self._gamma_fixed is not None:
+            return torch.as_tensor(self._gamma_fixed() if callable(self._gamma_fixed) else self._gamma_fixed)
+        return parameters.gdn_reparam_value(self.reparam_gamma, minimum=0.0)
+
+    def forward(self, inputs):
+        if inputs.dim() < 2:
+            raise ValueError(f"Input tensor must have at least rank 2, received shape {tuple(inputs.shape)}.")
+        x = inputs
+        if self.data_format == "channels_first" and x.dim() > 2:
+            x = x.movedim(1, -1)
+        self.build(x.shape[-1], x.device)
+        beta, gamma = self.beta.to(x.device), self.gamma.to(x.device)
+        y = _GDNFunction.apply(x.contiguous(), beta, gamma, self.inverse, self.rectify, self.alpha,
+                               self.epsilon)
+        if self.data_format == "channels_first" and y.dim() > 2:
+            y = y.movedim(-1, 1)
+        return y

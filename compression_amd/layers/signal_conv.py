@@ -1,0 +1,121 @@
+"""`SignalConv2D` (python/layers/signal_conv.py:61-1028) for the configurations the
+target models use: 2-D, non-separable, `same_zeros`, explicit-padding paths."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import functional, parameters
+from .gdn import GDN
+
+__all__ = ["SignalConv2D"]
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else tuple(int(s) for s in v)
+
+
+class SignalConv2D(torch.nn.Module):
+    """Same constructor arguments as the reference (signal_conv.py:279-296).  Weights:
+    `kernel_real`/`kernel_imag` (kernel_parameter="rdft") or `kernel`
+    (kernel_parameter="variable"), and `bias` (signal_conv_test.py:38-40)."""
+
+    def __init__(self, filters, kernel_support, corr=False, strides_down=1, strides_up=1,
+                 padding="valid", extra_pad_end=True, channel_separable=False,
+                 data_format="channels_last", activation=None, use_bias=False, use_explicit=True,
+                 kernel_parameter="rdft", bias_parameter="variable", kernel_initializer=None,
+                 bias_initializer=None, in_channels=None):
+        super().__init__()
+        self.filters = int(filters)
+        self.kernel_support = _pair(kernel_support)
+        self.corr = bool(corr)
+        self.strides_down, self.strides_up = _pair(strides_down), _pair(strides_up)
+        self.padding = str(padding).lower()
+        if self.padding not in ("valid", "same_zeros", "same_reflect"):
+            raise ValueError(f"Unsupported padding mode: '{padding}'.")
+        self.extra_pad_end = bool(extra_pad_end)
+        self.channel_separable = bool(channel_separable)
+        self.data_format = data_format
+        self.activation = activation
+        self.use_bias = bool(use_bias)
+        self.use_explicit = bool(use_explicit)
+        if kernel_parameter not in ("rdft", "variable"):
+            raise ValueError("kernel_parameter must be 'rdft' or 'variable'")
+        self.kernel_parameter = kernel_parameter
+        self._kernel_init, self._bias_init = kernel_initializer, bias_initializer
+        self.kernel_real = self.kernel_imag = self.kernel_variable = self.bias = None
+        self._check_implemented()
+        if in_channels is not None:
+            self.build(int(in_channels))
+
+    def _check_implemented(self):
+        ok = (self.padding == "same_zeros" and not self.channel_separable and self.use_explicit
+              and self.extra_pad_end and self.strides_down[0] == self.strides_down[1]
+              and self.strides_up[0] == self.strides_up[1]
+              and (self.strides_down[0] == 1 or self.strides_up[0] == 1))
+        if not ok:
+            raise NotImplementedError(
+                f"The provided combination of {type(self).__name__} arguments is not currently "
+                f"implemented (filters={self.filters}, kernel_support={self.kernel_support}, "
+                f"corr={self.corr}, strides_down={self.strides_down}, strides_up={self.strides_up}, "
+                f"channel_separable={self.channel_separable}, data_format={self.data_format}, "
+                f"padding={self.padding}). The HIP path covers 2-D `same_zeros` with explicit padding.")
+
+    def build(self, cin, device=None):
+        if self.kernel_real is not None or self.kernel_variable is not None:
+            return
+        kh, kw = self.kernel_support
+        if self._kernel_init is not None:
+            k = self._kernel_init((kh, kw, cin, self.filters))
+        else:
+            # Keras VarianceScaling(scale=1, fan_in, truncated normal) — signal_conv.py default
+            std = math.sqrt(1.0 / (kh * kw * cin)) / 0.87962566103423978
+            k = torch.empty(kh, kw, cin, self.filters)
+            torch.nn.init.trunc_normal_(k, std=std, a=-2 * std, b=2 * std)
+        k = k.float()
+        if self.kernel_parameter == "rdft":
+            real, imag = parameters.rdft_from_kernel(k)
+            self.kernel_real = torch.nn.Parameter(real.to(device))
+            self.kernel_imag = torch.nn.Parameter(imag.to(device))
+        else:
+            self.kernel_variable = torch.nn.Parameter(k.to(device))
+        if self.use_bias:
+            b = self._bias_init((self.filters,)) if self._bias_init else torch.zeros(self.filters)
+            self.bias = torch.nn.Parameter(b.float().to(device))
+
+    @property
+    def kernel(self):
+        if self.kernel_variable is not None:
+            return self.kernel_variable
+        if self.kernel_real is None:
+            raise RuntimeError("Kernel is not initialized yet. Call build().")
+        return parameters.kernel_from_rdft(self.kernel_real, self.kernel_imag, self.kernel_support)
+
+    def forward(self, inputs):
+        if inputs.dim() != 4:
+            raise ValueError(f"Input tensor must have rank 4, received shape {tuple(inputs.shape)}.")
+        x = inputs.movedim(1, -1) if self.data_format == "channels_first" else inputs
+        self.build(x.shape[-1], x.device)
+        kernel = self.kernel
+        act = self.activation
+        fused = "relu" if act in (torch.relu, torch.nn.functional.relu, "relu") or isinstance(
+            act, torch.nn.ReLU) else None
+        corr, up, down = self.corr, self.strides_up[0], self.strides_down[0]
+        odd = all(s % 2 == 1 for s in self.kernel_support)
+        if corr and up != 1:
+            if not odd:
+                self._check_implemented_fail()
+            corr, kernel = False, kernel.flip(0, 1)            # signal_conv.py:875-880
+        if corr:
+            y = functional.conv2d_down(x, kernel, self.bias, down, fused)
+        else:
+            y = functional.conv2d_up(x, kernel, self.bias, up, fused)
+            if down != 1:
+                y = y[:, ::down, ::down]
+        if act is not None and fused is None:
+            y = act(y)
+        return y.movedim(-1, 1) if self.data_format == "channels_first" else y
+
+    def _check_implemented_fail(self):
+        raise NotImplementedError("cross-correlation with upsampling needs odd-length kernels")

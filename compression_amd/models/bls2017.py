@@ -1,0 +1,88 @@
+"""Ballé, Laparra, Simoncelli 2017 model (models/bls2017.py:55-190): analysis /
+synthesis transforms + factorized-prior entropy bottleneck.  Class and layer names,
+kernel supports and strides follow the reference; compress()/decompress() take a
+BATCH of images (the reference's single-image signatures are the B = 1 case)."""
+from __future__ import annotations
+
+import torch
+
+from .. import distributions, entropy_models, layers
+
+__all__ = ["AnalysisTransform", "SynthesisTransform", "BLS2017Model"]
+
+
+class AnalysisTransform(torch.nn.Module):
+    def __init__(self, num_filters):
+        super().__init__()
+        C = num_filters
+        self.layer_0 = layers.SignalConv2D(C, (9, 9), corr=True, strides_down=4, padding="same_zeros",
+                                           use_bias=True, activation=layers.GDN(), in_channels=3)
+        self.layer_1 = layers.SignalConv2D(C, (5, 5), corr=True, strides_down=2, padding="same_zeros",
+                                           use_bias=True, activation=layers.GDN(), in_channels=C)
+        self.layer_2 = layers.SignalConv2D(C, (5, 5), corr=True, strides_down=2, padding="same_zeros",
+                                           use_bias=False, activation=None, in_channels=C)
+
+    def forward(self, x):
+        return self.layer_2(self.layer_1(self.layer_0(x / 255.0)))
+
+
+class SynthesisTransform(torch.nn.Module):
+    def __init__(self, num_filters):
+        super().__init__()
+        C = num_filters
+        self.layer_0 = layers.SignalConv2D(C, (5, 5), corr=False, strides_up=2, padding="same_zeros",
+                                           use_bias=True, activation=layers.GDN(inverse=True), in_channels=C)
+        self.layer_1 = layers.SignalConv2D(C, (5, 5), corr=False, strides_up=2, padding="same_zeros",
+                                           use_bias=True, activation=layers.GDN(inverse=True), in_channels=C)
+        self.layer_2 = layers.SignalConv2D(3, (9, 9), corr=False, strides_up=4, padding="same_zeros",
+                                           use_bias=True, activation=None, in_channels=C)
+
+    def forward(self, y):
+        return self.layer_2(self.layer_1(self.layer_0(y))) * 255.0
+
+
+class BLS2017Model(torch.nn.Module):
+    def __init__(self, lmbda=0.01, num_filters=128, compute_dtype=torch.float32):
+        super().__init__()
+        self.lmbda = lmbda
+        self.compute_dtype = compute_dtype
+        self.analysis_transform = AnalysisTransform(num_filters)
+        self.synthesis_transform = SynthesisTransform(num_filters)
+        self.prior = distributions.NoisyDeepFactorized(batch_shape=(num_filters,))
+        self.entropy_model = None
+
+    def forward(self, x, training=True):
+        """(loss, bpp, mse) — bls2017.py:109-125."""
+        em = entropy_models.ContinuousBatchedEntropyModel(self.prior, coding_rank=3, compression=False,
+                                                          bottleneck_dtype=self.compute_dtype)
+        x = x.to(self.compute_dtype)
+        y = self.analysis_transform(x)
+        y_hat, bits = em(y, training=training)
+        x_hat = self.synthesis_transform(y_hat.to(self.compute_dtype))
+        num_pixels = x.shape[0] * x.shape[1] * x.shape[2]
+        bpp = bits.sum() / num_pixels
+        mse = torch.mean((x.float() - x_hat.float()) ** 2).to(bpp.dtype)
+        return bpp + self.lmbda * mse, bpp, mse
+
+    def init_compression(self):
+        """What `fit()` does after training (bls2017.py:157-162): fix the range-coding tables."""
+        self.entropy_model = entropy_models.ContinuousBatchedEntropyModel(
+            self.prior, coding_rank=3, compression=True, bottleneck_dtype=self.compute_dtype)
+        return self
+
+    @torch.no_grad()
+    def compress(self, x):
+        """x: uint8 [B, H, W, 3] (or [H, W, 3]) -> (strings[B], x_shape, y_shape) — bls2017.py:164-176."""
+        if x.dim() == 3:
+            x = x[None]
+        x = x.to(self.compute_dtype)
+        y = self.analysis_transform(x)
+        return self.entropy_model.compress(y), tuple(x.shape[1:-1]), tuple(y.shape[1:-1])
+
+    @torch.no_grad()
+    def decompress(self, string, x_shape, y_shape):
+        """-> uint8 [B, H, W, 3] — bls2017.py:178-190."""
+        y_hat = self.entropy_model.decompress(string, y_shape)
+        x_hat = self.synthesis_transform(y_hat)
+        x_hat = x_hat[:, :x_shape[0], :x_shape[1], :]
+        return torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)

@@ -1,0 +1,136 @@
+"""Ballé, Minnen, Singh, Hwang, Johnston 2018 scale-hyperprior model
+(models/bmshj2018.py:53-264)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import distributions, entropy_models, layers
+
+__all__ = ["AnalysisTransform", "SynthesisTransform", "HyperAnalysisTransform",
+           "HyperSynthesisTransform", "BMSHJ2018Model"]
+
+
+def _conv(C, k, cin, **kw):
+    return layers.SignalConv2D(C, (k, k), padding="same_zeros", in_channels=cin, **kw)
+
+
+class AnalysisTransform(torch.nn.Module):
+    def __init__(self, num_filters):
+        super().__init__()
+        C = num_filters
+        self.layer_0 = _conv(C, 5, 3, corr=True, strides_down=2, use_bias=True, activation=layers.GDN())
+        self.layer_1 = _conv(C, 5, C, corr=True, strides_down=2, use_bias=True, activation=layers.GDN())
+        self.layer_2 = _conv(C, 5, C, corr=True, strides_down=2, use_bias=True, activation=layers.GDN())
+        self.layer_3 = _conv(C, 5, C, corr=True, strides_down=2, use_bias=True, activation=None)
+
+    def forward(self, x):
+        return self.layer_3(self.layer_2(self.layer_1(self.layer_0(x / 255.0))))
+
+
+class SynthesisTransform(torch.nn.Module):
+    def __init__(self, num_filters):
+        super().__init__()
+        C = num_filters
+        g = lambda: layers.GDN(inverse=True)
+        self.layer_0 = _conv(C, 5, C, corr=False, strides_up=2, use_bias=True, activation=g())
+        self.layer_1 = _conv(C, 5, C, corr=False, strides_up=2, use_bias=True, activation=g())
+        self.layer_2 = _conv(C, 5, C, corr=False, strides_up=2, use_bias=True, activation=g())
+        self.layer_3 = _conv(3, 5, C, corr=False, strides_up=2, use_bias=True, activation=None)
+
+    def forward(self, y):
+        return self.layer_3(self.layer_2(self.layer_1(self.layer_0(y)))) * 255.0
+
+
+class HyperAnalysisTransform(torch.nn.Module):
+    def __init__(self, num_filters):
+        super().__init__()
+        C = num_filters
+        self.layer_0 = _conv(C, 3, C, corr=True, strides_down=1, use_bias=True, activation="relu")
+        self.layer_1 = _conv(C, 5, C, corr=True, strides_down=2, use_bias=True, activation="relu")
+        self.layer_2 = _conv(C, 5, C, corr=True, strides_down=2, use_bias=False, activation=None)
+
+    def forward(self, y):
+        return self.layer_2(self.layer_1(self.layer_0(y)))
+
+
+class HyperSynthesisTransform(torch.nn.Module):
+    def __init__(self, num_filters):
+        super().__init__()
+        C = num_filters
+        kw = dict(corr=False, use_bias=True, kernel_parameter="variable")
+        self.layer_0 = _conv(C, 5, C, strides_up=2, activation="relu", **kw)
+        self.layer_1 = _conv(C, 5, C, strides_up=2, activation="relu", **kw)
+        self.layer_2 = _conv(C, 3, C, strides_up=1, activation=None, **kw)
+
+    def forward(self, z):
+        return self.layer_2(self.layer_1(self.layer_0(z)))
+
+
+class BMSHJ2018Model(torch.nn.Module):
+    def __init__(self, lmbda=0.01, num_filters=192, num_scales=64, scale_min=0.11, scale_max=256.0,
+                 compute_dtype=torch.float32):
+        super().__init__()
+        self.lmbda, self.num_scales = lmbda, num_scales
+        self.compute_dtype = compute_dtype
+        offset = math.log(scale_min)
+        factor = (math.log(scale_max) - math.log(scale_min)) / (num_scales - 1.0)
+        self.scale_fn = lambda i: torch.exp(offset + factor * i)
+        self.analysis_transform = AnalysisTransform(num_filters)
+        self.synthesis_transform = SynthesisTransform(num_filters)
+        self.hyper_analysis_transform = HyperAnalysisTransform(num_filters)
+        self.hyper_synthesis_transform = HyperSynthesisTransform(num_filters)
+        self.hyperprior = distributions.NoisyDeepFactorized(batch_shape=(num_filters,))
+        self.entropy_model = self.side_entropy_model = None
+
+    def _models(self, compression):
+        em = entropy_models.LocationScaleIndexedEntropyModel(
+            distributions.NoisyNormal, self.num_scales, self.scale_fn, coding_rank=3,
+            compression=compression, bottleneck_dtype=self.compute_dtype)
+        side = entropy_models.ContinuousBatchedEntropyModel(
+            self.hyperprior, coding_rank=3, compression=compression, bottleneck_dtype=self.compute_dtype)
+        return em, side
+
+    def forward(self, x, training=True):
+        em, side = self._models(False)
+        x = x.to(self.compute_dtype)
+        y = self.analysis_transform(x)
+        z = self.hyper_analysis_transform(torch.abs(y))
+        z_hat, side_bits = side(z, training=training)
+        indexes = self.hyper_synthesis_transform(z_hat.to(self.compute_dtype))
+        y_hat, bits = em(y, indexes, training=training)
+        x_hat = self.synthesis_transform(y_hat.to(self.compute_dtype))
+        num_pixels = x.shape[0] * x.shape[1] * x.shape[2]
+        bpp = (bits.sum() + side_bits.sum()) / num_pixels
+        mse = torch.mean((x.float() - x_hat.float()) ** 2).to(bpp.dtype)
+        return bpp + self.lmbda * mse, bpp, mse
+
+    def init_compression(self):
+        self.entropy_model, self.side_entropy_model = self._models(True)
+        return self
+
+    @torch.no_grad()
+    def compress(self, x):
+        """uint8 [B, H, W, 3] -> (string[B], side_string[B], x_shape, y_shape, z_shape) —
+        bmshj2018.py:219-240."""
+        if x.dim() == 3:
+            x = x[None]
+        x = x.to(self.compute_dtype)
+        y = self.analysis_transform(x)
+        z = self.hyper_analysis_transform(torch.abs(y))
+        x_shape, y_shape, z_shape = tuple(x.shape[1:-1]), tuple(y.shape[1:-1]), tuple(z.shape[1:-1])
+        z_hat = self.side_entropy_model.quantize(z)
+        indexes = self.hyper_synthesis_transform(z_hat)[:, :y_shape[0], :y_shape[1], :]
+        side_string = self.side_entropy_model.compress(z)
+        string = self.entropy_model.compress(y, indexes)
+        return string, side_string, x_shape, y_shape, z_shape
+
+    @torch.no_grad()
+    def decompress(self, string, side_string, x_shape, y_shape, z_shape):
+        """bmshj2018.py:242-264: the y stream can only be decoded after z (strict two-phase order)."""
+        z_hat = self.side_entropy_model.decompress(side_string, z_shape)
+        indexes = self.hyper_synthesis_transform(z_hat)[:, :y_shape[0], :y_shape[1], :]
+        y_hat = self.entropy_model.decompress(string, indexes)
+        x_hat = self.synthesis_transform(y_hat)[:, :x_shape[0], :x_shape[1], :]
+        return torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)

@@ -101,3 +101,16 @@ def empirical_bits(lookup: np.ndarray, symbols: np.ndarray) -> float:
         q = np.diff(cdf.astype(np.int64))[s[ok]]
         bits += float(np.sum(abs(sp) - np.log2(np.maximum(q, 1))))
     return bits
+
+
+def lowpass_images(batch: int, height: int, width: int, seed: int = 2) -> np.ndarray:
+    """uint8 [batch, height, width, 3] low-pass-filtered noise (stand-in for Kodak-shaped
+    images)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.standard_normal((batch, height + 16, width + 16, 3)).astype(np.float32)
+    k = np.hanning(17).astype(np.float32)
+    k /= k.sum()
+    for axis in (1, 2):
+        x = np.apply_along_axis(lambda v: np.convolve(v, k, mode="valid"), axis, x)
+    x = (x - x.min()) / (x.max() - x.min())
+    return np.round(255 * x).astype(np.uint8)

@@ -1,0 +1,76 @@
+"""GPU tier: end-to-end compress/decompress of the two target models (BASELINE
+configs 1 and 4 at reduced batch): transforms + entropy coding through the HIP path,
+byte parity of the coded strings against the CPU oracle given the same latents."""
+import numpy as np
+import pytest
+import torch
+
+import compression_amd as tfc
+from compression_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bls2017_single_image_plumbing(port):
+    """Config 1: one 256x256x3 image through analysis -> coder -> synthesis."""
+    torch.manual_seed(0)
+    model = tfc.models.BLS2017Model(num_filters=192).cuda().init_compression()
+    x = torch.from_numpy(synthetic.lowpass_images(1, 256, 256))[0].cuda()
+    string, x_shape, y_shape = model.compress(x)
+    assert string.shape == (1,) and x_shape == (256, 256) and y_shape == (16, 16)
+    x_hat = model.decompress(string, x_shape, y_shape)
+    assert x_hat.shape == (1, 256, 256, 3) and x_hat.dtype == torch.uint8
+    # the coded string is exactly what the oracle produces for the same latents and tables
+    em = model.entropy_model
+    y = model.analysis_transform(x[None].float())
+    off = em.quantization_offset
+    sym = torch.round(y - off.cuda() if off is not None else y).to(torch.int32).cpu()
+    sym = sym.reshape(1, -1) - em.cdf_offset.repeat(16 * 16)
+    want, _, _ = port.encode(em.cdf.numpy(), sym.numpy())
+    assert bytes(string[0]) == want[0]
+    # decode side: decompress(compress(x)) equals synthesis(quantize(y))
+    ref = model.synthesis_transform(em.quantize(y))
+    ref = torch.clamp(torch.round(ref), 0, 255).to(torch.uint8)
+    assert torch.equal(x_hat, ref)
+
+
+def test_bls2017_batch_and_odd_sizes():
+    torch.manual_seed(1)
+    model = tfc.models.BLS2017Model(num_filters=64).cuda().init_compression()
+    x = torch.from_numpy(synthetic.lowpass_images(3, 100, 77)).cuda()
+    strings, x_shape, y_shape = model.compress(x)
+    assert strings.shape == (3,) and y_shape == (7, 5)
+    x_hat = model.decompress(strings, x_shape, y_shape)
+    assert x_hat.shape == (3, 100, 77, 3)
+    one, _, _ = model.compress(x[1])
+    assert bytes(one[0]) == bytes(strings[1])      # batch element == single-image call
+
+
+def test_bmshj2018_roundtrip_kodak_shape():
+    """Config 4 at batch 2: 768x512 images through the hyperprior model."""
+    torch.manual_seed(2)
+    model = tfc.models.BMSHJ2018Model(num_filters=192).cuda().init_compression()
+    x = torch.from_numpy(synthetic.lowpass_images(2, 512, 768)).cuda()
+    string, side_string, x_shape, y_shape, z_shape = model.compress(x)
+    assert string.shape == side_string.shape == (2,)
+    assert y_shape == (32, 48) and z_shape == (8, 12)
+    x_hat = model.decompress(string, side_string, x_shape, y_shape, z_shape)
+    assert x_hat.shape == (2, 512, 768, 3)
+    # determinism: the decoder reproduces the encoder's quantised latents
+    y = model.analysis_transform(x.float())
+    z = model.hyper_analysis_transform(torch.abs(y))
+    z_hat = model.side_entropy_model.quantize(z)
+    idx = model.hyper_synthesis_transform(z_hat)[:, :32, :48]
+    y_hat = model.entropy_model.decompress(string, idx)
+    assert torch.equal(y_hat, torch.round(y))
+    bpp = 8 * sum(len(bytes(s)) for s in list(string) + list(side_string)) / (2 * 512 * 768)
+    assert 0 < bpp < 24
+
+
+def test_training_forward_runs():
+    torch.manual_seed(3)
+    model = tfc.models.BLS2017Model(num_filters=32).cuda()
+    x = torch.from_numpy(synthetic.lowpass_images(2, 64, 64)).cuda().float()
+    with torch.no_grad():
+        loss, bpp, mse = model(x, training=False)
+    assert torch.isfinite(loss) and bpp > 0 and mse >= 0
