@@ -127,6 +127,63 @@ def cpu_baseline(lookup, value, total_bytes_gpu):
     }
 
 
+def model_workload(args, world, rank, device, distributed):
+    """Full compress + decompress of a target model on synthetic images (BASELINE configs
+    1/4/5); informational — the headline line is the c2 workload."""
+    import torch.distributed as dist
+    dtype = torch.bfloat16 if args.model_dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    if args.workload == "bls2017":
+        model = tfc.models.BLS2017Model(num_filters=192, compute_dtype=dtype)
+        batch, hw = args.batch or 512, (256, 256)
+    else:
+        model = tfc.models.BMSHJ2018Model(num_filters=192, compute_dtype=dtype)
+        batch, hw = args.batch or 128, (512, 768)
+    model = model.to(device).init_compression()
+    base = torch.from_numpy(synthetic.lowpass_images(8, hw[0], hw[1], seed=2 + rank)).to(device)
+    x = base.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
+
+    def step():
+        out = model.compress(x)
+        return out, model.decompress(*out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, x_hat = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert x_hat.shape == x.shape
+    nbytes = sum(len(bytes(s)) for arr in out if isinstance(arr, np.ndarray) for s in arr.reshape(-1))
+    if rank == 0:
+        pixels = world * batch * hw[0] * hw[1]
+        print(json.dumps({
+            "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
+            "value": round(pixels / 1e6 / (elapsed / args.steps), 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.model_dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload} compress+decompress, {batch} images of "
+                                   f"{hw[1]}x{hw[0]} per GPU, 192 filters, random-init weights",
+                       "parallelism": f"batch-sharded x{world}"},
+            "bits_per_pixel": round(8.0 * nbytes / (batch * hw[0] * hw[1]), 4),
+        }))
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +191,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--escape-fraction", type=float, default=0.0)
+    ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
+                    help="c2 (default, the headline): coder round trip; bls2017 / bmshj2018: "
+                         "full model compress+decompress (informational)")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU for the model workloads")
+    ap.add_argument("--model-dtype", default="bf16", choices=["bf16", "f32"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,6 +208,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+
+    if args.workload != "c2":
+        return model_workload(args, world, rank, device, distributed)
 
     lookup = build_tables(device)
     value = synthetic.sample_symbols(lookup, STREAMS, ELEMS, seed=rank,

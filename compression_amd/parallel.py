@@ -1,0 +1,55 @@
+"""Multi-GPU plumbing: the hot path shards over the batch dimension (one code stream
+per image, no cross-stream state — cc/kernels/range_coder_kernels.cc:225-226), so the
+only communication is the batch split and a variable-length gather of the coded bytes.
+One process per GPU; `torch.distributed` with backend "nccl" (= RCCL over xGMI) on
+GPUs, "gloo" in the CPU tests."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_range", "gather_encoded", "broadcast_tables"]
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of `total` units for `rank` (sizes differ by at most 1)."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_encoded(blob: torch.Tensor, offsets: torch.Tensor, group=None):
+    """All-gathers per-rank packed byte strings.
+
+    blob: uint8 [total_bytes_r], offsets: int64 [streams_r + 1] (as produced by
+    tfc_encoder_finalize).  Returns (blob_all uint8, offsets_all int64 [sum streams + 1])
+    with ranks concatenated in rank order — identical to what a single process coding
+    the whole batch would have produced.  Two collectives: lengths, then padded bytes."""
+    world = dist.get_world_size(group)
+    device = blob.device
+    lengths = (offsets[1:] - offsets[:-1]).to(torch.int64)
+    meta = torch.tensor([lengths.numel(), int(offsets[-1])], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    max_streams = max(int(m[0]) for m in metas)
+    max_bytes = max(int(m[1]) for m in metas)
+    pad_len = torch.zeros(max_streams, dtype=torch.int64, device=device)
+    pad_len[:lengths.numel()] = lengths
+    pad_blob = torch.zeros(max(max_bytes, 1), dtype=torch.uint8, device=device)
+    pad_blob[:blob.numel()] = blob
+    all_len = [torch.zeros_like(pad_len) for _ in range(world)]
+    all_blob = [torch.zeros_like(pad_blob) for _ in range(world)]
+    dist.all_gather(all_len, pad_len, group=group)
+    dist.all_gather(all_blob, pad_blob, group=group)
+    lens = torch.cat([all_len[r][:int(metas[r][0])] for r in range(world)])
+    blobs = torch.cat([all_blob[r][:int(metas[r][1])] for r in range(world)])
+    offs = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=device)
+    offs[1:] = torch.cumsum(lens, 0)
+    return blobs, offs
+
+
+def broadcast_tables(module: torch.nn.Module, src: int = 0, group=None):
+    """Replicates weights and range-coding tables from `src` (tables must be shared, never
+    rebuilt per rank: continuous_base.py:175-184)."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
