@@ -178,12 +178,14 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
     }
     if (replay) {
       // ---- checked loop: wide rows, escapes, partial batches ----------------
+      // stage-1 bounds (the row itself, or its pivots) are fetched one symbol ahead
+      unsigned int hi = static_cast<unsigned int>(tab[__builtin_amdgcn_readlane(row.x, 0) + lane]);
       for (int n = 0; n < cnt; ++n) {
-        const int x = __builtin_amdgcn_readlane(row.x, n);
+        const unsigned int hi_next = static_cast<unsigned int>(
+            tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
         const int z = __builtin_amdgcn_readlane(row.z, n);
         const int escsym = __builtin_amdgcn_readlane(row.w, n);
-        const unsigned int hi = static_cast<unsigned int>(tab[x + lane]);
-        unsigned int dig =
+        const unsigned int dig =
             static_cast<unsigned int>(__builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
         int sym;
         const int chunk = z >> 16;
@@ -213,6 +215,7 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
           st.pos = 0;
           fast_window_load(w, lane);
         }
+        hi = hi_next;
       }
     }
     w.wbase += st.pos;
