@@ -57,8 +57,12 @@ __device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned in
                                   unsigned int dig) {
   const unsigned long long PB = static_cast<unsigned long long>(st.s) * hi + hi;
   const unsigned int B = static_cast<unsigned int>(PB >> 16);
-  const unsigned int A = static_cast<unsigned int>(
+  unsigned int A = static_cast<unsigned int>(
       __builtin_amdgcn_update_dpp(static_cast<int>(a0), static_cast<int>(B), 0x138, 0xF, 0xF, false));
+  // Keep the wave_shr move a separate v_mov_b32_dpp: when a0 is the constant 0, LLVM's DPP
+  // combine folds it into the consumers as `v_subrev_u32_dpp ... wave_shr:1 bound_ctrl:1`,
+  // which returned wrong lanes on gfx950 (ROCm 7.2) — caught by the K3/K4/K6 vectors.
+  asm volatile("" : "+v"(A));
   const unsigned int b = B - 1u;
   const unsigned int t1 = b - A;
   const unsigned int Dn = st.D - A;
@@ -174,6 +178,28 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
         hi_cur = hi_next;
       }
       replay = __ballot(outv == row.w) != 0;      // an escape symbol was decoded: redo with checks
+      if (replay) st = saved;
+    } else if (cnt == 64) {
+      // ---- speculative, branch-free batch with wide rows: every symbol takes the two-stage
+      // route (pivots -> chunk -> entries); for a narrow row the "pivots" are the row itself
+      // with chunk 1, so the same straight-line code serves both (no per-symbol branch).
+      unsigned int hi_cur = static_cast<unsigned int>(tab[__builtin_amdgcn_readlane(row.x, 0) + lane]);
+#pragma unroll
+      for (int n = 0; n < 64; ++n) {
+        const unsigned int hi_next = static_cast<unsigned int>(
+            tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
+        const unsigned int dig =
+            static_cast<unsigned int>(__builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
+        unsigned int a0;
+        const int c = pivot_step(st, hi_cur, &a0);
+        const int chunk = __builtin_amdgcn_readlane(row.z, n) >> 16;
+        const int first = __builtin_amdgcn_readlane(row.y, n) + c * chunk;
+        const unsigned int hi2 = static_cast<unsigned int>(tab[first + 1 + lane]);
+        const int L = select_step(st, hi2, a0, dig);
+        outv = tfc_writelane(c * chunk + L, n, outv);
+        hi_cur = hi_next;
+      }
+      replay = __ballot(outv == row.w) != 0;
       if (replay) st = saved;
     }
     if (replay) {
