@@ -160,53 +160,13 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
 
     fast_window_load(w, lane);
     st.pos = 0;
-    const FastDecState saved = st;
     int outv = 0;
-    bool replay = true;
+    // stage-1 bounds (the row itself, or its pivots) are fetched one symbol ahead
+    unsigned int hi_cur = static_cast<unsigned int>(tab[__builtin_amdgcn_readlane(row.x, 0) + lane]);
 
-    if (cnt == 64 && !anywide) {
-      // ---- speculative, branch-free batch: all rows narrow ------------------
-      unsigned int hi_cur = static_cast<unsigned int>(tab[__builtin_amdgcn_readlane(row.x, 0) + lane]);
-#pragma unroll
-      for (int n = 0; n < 64; ++n) {
-        const unsigned int hi_next = static_cast<unsigned int>(
-            tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
-        const unsigned int dig =
-            static_cast<unsigned int>(__builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
-        const int L = select_step(st, hi_cur, 0u, dig);
-        outv = tfc_writelane(L, n, outv);
-        hi_cur = hi_next;
-      }
-      replay = __ballot(outv == row.w) != 0;      // an escape symbol was decoded: redo with checks
-      if (replay) st = saved;
-    } else if (cnt == 64) {
-      // ---- speculative, branch-free batch with wide rows: every symbol takes the two-stage
-      // route (pivots -> chunk -> entries); for a narrow row the "pivots" are the row itself
-      // with chunk 1, so the same straight-line code serves both (no per-symbol branch).
-      unsigned int hi_cur = static_cast<unsigned int>(tab[__builtin_amdgcn_readlane(row.x, 0) + lane]);
-#pragma unroll
-      for (int n = 0; n < 64; ++n) {
-        const unsigned int hi_next = static_cast<unsigned int>(
-            tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
-        const unsigned int dig =
-            static_cast<unsigned int>(__builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
-        unsigned int a0;
-        const int c = pivot_step(st, hi_cur, &a0);
-        const int chunk = __builtin_amdgcn_readlane(row.z, n) >> 16;
-        const int first = __builtin_amdgcn_readlane(row.y, n) + c * chunk;
-        const unsigned int hi2 = static_cast<unsigned int>(tab[first + 1 + lane]);
-        const int L = select_step(st, hi2, a0, dig);
-        outv = tfc_writelane(c * chunk + L, n, outv);
-        hi_cur = hi_next;
-      }
-      replay = __ballot(outv == row.w) != 0;
-      if (replay) st = saved;
-    }
-    if (replay) {
-      // ---- checked loop: wide rows, escapes, partial batches ----------------
-      // stage-1 bounds (the row itself, or its pivots) are fetched one symbol ahead
-      unsigned int hi = static_cast<unsigned int>(tab[__builtin_amdgcn_readlane(row.x, 0) + lane]);
-      for (int n = 0; n < cnt; ++n) {
+    // ---- checked loop: wide rows, escapes, partial batches -------------------
+    auto checked = [&](int n0, int n1) {
+      for (int n = n0; n < n1; ++n) {
         const unsigned int hi_next = static_cast<unsigned int>(
             tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
         const int z = __builtin_amdgcn_readlane(row.z, n);
@@ -216,10 +176,10 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
         int sym;
         const int chunk = z >> 16;
         if (chunk <= 1) {
-          sym = select_step(st, hi, 0u, dig);
+          sym = select_step(st, hi_cur, 0u, dig);
         } else {
           unsigned int a0;
-          const int c = pivot_step(st, hi, &a0);
+          const int c = pivot_step(st, hi_cur, &a0);
           const int cdf0 = __builtin_amdgcn_readlane(row.y, n);
           const unsigned int hi2 = static_cast<unsigned int>(tab[cdf0 + c * chunk + 1 + lane]);
           sym = c * chunk + select_step(st, hi2, a0, dig);
@@ -233,16 +193,101 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
           while (--nb >= 0) v |= fast_bit(st, w) << nb;
           const int neg = fast_bit(st, w);
           sym = neg ? -v : v + escsym - 1;
+          if (st.pos >= 40u) {          // keep digits ahead in the window register
+            w.wbase += st.pos;
+            st.pos = 0;
+            fast_window_load(w, lane);
+          }
         }
         outv = tfc_writelane(sym, n, outv);
-        if (st.pos >= 48u) {
-          // keep at least 16 digits ahead in the window register
-          w.wbase += st.pos;
-          st.pos = 0;
-          fast_window_load(w, lane);
-        }
-        hi = hi_next;
+        hi_cur = hi_next;
       }
+    };
+
+    if (cnt == 64) {
+      // Level 1: the whole batch speculatively, fully unrolled (immediate lane indices, no
+      // branch).  Level 2, only if an escape symbol turned up: blocks of 8 symbols with a
+      // check after each block; a block containing an escape is replayed from its saved
+      // start state by the checked loop (level 3), which decodes the Elias-gamma bits.
+      const FastDecState saved64 = st;
+      const unsigned int hi_saved64 = hi_cur;
+      if (!anywide) {
+#pragma unroll
+        for (int n = 0; n < 64; ++n) {
+          const unsigned int hi_next = static_cast<unsigned int>(
+              tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
+          const unsigned int dig = static_cast<unsigned int>(
+              __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
+          const int L = select_step(st, hi_cur, 0u, dig);
+          outv = tfc_writelane(L, n, outv);
+          hi_cur = hi_next;
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 64; ++n) {
+          const unsigned int hi_next = static_cast<unsigned int>(
+              tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
+          const unsigned int dig = static_cast<unsigned int>(
+              __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
+          unsigned int a0;
+          const int c = pivot_step(st, hi_cur, &a0);
+          const int chunk = __builtin_amdgcn_readlane(row.z, n) >> 16;
+          const int first = __builtin_amdgcn_readlane(row.y, n) + c * chunk;
+          const unsigned int hi2 = static_cast<unsigned int>(tab[first + 1 + lane]);
+          const int L = select_step(st, hi2, a0, dig);
+          outv = tfc_writelane(c * chunk + L, n, outv);
+          hi_cur = hi_next;
+        }
+      }
+      if (__ballot(outv == row.w) != 0) {
+        st = saved64;
+        hi_cur = hi_saved64;
+        for (int blk = 0; blk < 8; ++blk) {
+          const int n0 = blk * 8;
+          const FastDecState saved = st;
+          const unsigned int hi_saved = hi_cur;
+          if (!anywide) {
+  #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int n = n0 + i;
+              const unsigned int hi_next = static_cast<unsigned int>(
+                  tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
+              const unsigned int dig = static_cast<unsigned int>(
+                  __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
+              const int L = select_step(st, hi_cur, 0u, dig);
+              outv = tfc_writelane(L, n, outv);
+              hi_cur = hi_next;
+            }
+          } else {
+            // every symbol takes the two-stage route (pivots -> chunk -> entries); for a narrow
+            // row the "pivots" are the row itself with chunk 1, so one code path serves both.
+  #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int n = n0 + i;
+              const unsigned int hi_next = static_cast<unsigned int>(
+                  tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
+              const unsigned int dig = static_cast<unsigned int>(
+                  __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
+              unsigned int a0;
+              const int c = pivot_step(st, hi_cur, &a0);
+              const int chunk = __builtin_amdgcn_readlane(row.z, n) >> 16;
+              const int first = __builtin_amdgcn_readlane(row.y, n) + c * chunk;
+              const unsigned int hi2 = static_cast<unsigned int>(tab[first + 1 + lane]);
+              const int L = select_step(st, hi2, a0, dig);
+              outv = tfc_writelane(c * chunk + L, n, outv);
+              hi_cur = hi_next;
+            }
+          }
+          const unsigned long long hits = __ballot(outv == row.w) & (0xFFull << n0);
+          if (hits != 0) {
+            st = saved;
+            hi_cur = hi_saved;
+            checked(n0, n0 + 8);
+          }
+        }
+      }
+    } else {
+      checked(0, cnt);
     }
     w.wbase += st.pos;
     st.pos = 0;
