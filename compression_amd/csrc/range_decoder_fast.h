@@ -53,9 +53,20 @@ __device__ inline void fast_window_load(DecWindow& w, int lane) {
 // One candidate-per-lane selection step.  hi = upper bound held by this lane,
 // a0 = lower offset of lane 0's candidate (0 for a whole narrow row).
 // Returns the winning lane; updates the state.
+// (span * hi) >> 16 with span = s + 1, as ONE v_mad_u64_u32 (s * hi + hi) + v_alignbit.  The
+// addend is made opaque so that LLVM does not refactor it into (s + 1) * hi, which needs a
+// 33-bit multiplicand and two multiplies.
+__device__ inline unsigned int scale_bound(unsigned int s, unsigned int hi) {
+  unsigned int add = hi;
+  asm volatile("" : "+v"(add));
+  const unsigned long long P = static_cast<unsigned long long>(s) * hi + add;
+  return static_cast<unsigned int>(P >> 16);
+}
+
 __device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned int a0,
                                   unsigned int dig) {
-  const unsigned long long PB = static_cast<unsigned long long>(st.s) * hi + hi;
+  const unsigned int Bq = scale_bound(st.s, hi);
+  const unsigned long long PB = static_cast<unsigned long long>(Bq) << 16;
   const unsigned int B = static_cast<unsigned int>(PB >> 16);
   unsigned int A = static_cast<unsigned int>(
       __builtin_amdgcn_update_dpp(static_cast<int>(a0), static_cast<int>(B), 0x138, 0xF, 0xF, false));
@@ -81,11 +92,15 @@ __device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned in
 // Coarse step over pivots: finds the chunk, no state update.  Returns chunk
 // index and the chunk's lower offset (B of the previous pivot, 0 for chunk 0).
 __device__ inline int pivot_step(const FastDecState& st, unsigned int pivot, unsigned int* a0) {
-  const unsigned long long PB = static_cast<unsigned long long>(st.s) * pivot + pivot;
-  const unsigned int B = static_cast<unsigned int>(PB >> 16);
+  const unsigned int B = scale_bound(st.s, pivot);
   const unsigned long long hit = __ballot(st.D <= B - 1u) | (1ull << 63);
   const int L = __builtin_ctzll(hit);
-  *a0 = L == 0 ? 0u : static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(B), (L - 1) & 63));
+  // lower offset of chunk L = B of the previous pivot (0 for chunk 0): shift B down one lane
+  // first, then one readlane — no branch on L == 0.
+  unsigned int prev = static_cast<unsigned int>(
+      __builtin_amdgcn_update_dpp(0, static_cast<int>(B), 0x138, 0xF, 0xF, false));
+  asm volatile("" : "+v"(prev));
+  *a0 = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(prev), L));
   return L;
 }
 
