@@ -96,16 +96,39 @@ def gdn_forward_bandwidth(device, steps=20):
             "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm"}
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU
+    quota (a pool larger than the quota only gets throttled by CFS bandwidth control)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period) + 0.5))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(q / period + 0.5))
+        except (OSError, ValueError):
+            pass
+    return n, (min(n, quota) if quota else n), quota
+
+
 def cpu_baseline(lookup, value, total_bytes_gpu):
     """Reference coder core (oracle/_ref) or its restatement on the host cores,
     sharded over streams like the reference's ThreadPool::ParallelFor.
     This is the ONLY place bench.py touches oracle/."""
     from oracle import oracle
     lib = oracle.best()
-    cores = os.cpu_count() or 1
+    hw_threads, cores, quota = usable_cores()
+    # keep this process's own OpenMP / torch worker threads from spinning next to the pool
+    torch.set_num_threads(1)
+    time.sleep(1.0)
     pixels = value.shape[0] * PIXELS_PER_STREAM
     best = None
-    # all hardware threads vs one thread per physical core: report the faster
+    # the usable core count and half of it (SMT siblings): report the faster
     for threads in sorted({cores, max(cores // 2, 1)}, reverse=True):
         enc, dec, total, ok = lib.bench_roundtrip(lookup, value, threads=threads, reps=16)
         assert ok, "CPU baseline round trip failed"
@@ -123,7 +146,8 @@ def cpu_baseline(lookup, value, total_bytes_gpu):
         "best_repetition_mpixels_s": round(pixels / 1e6 / rt_min, 2),
         "sample": f"full batch ({value.shape[0]} streams x {value.shape[1]} symbols) x 16 repetitions "
                   f"(first discarded), streams sharded over a persistent pool of {threads} host "
-                  f"threads ({cores} hardware threads on the box), median encode+decode time",
+                  f"threads ({hw_threads} hardware threads visible, cgroup CPU quota "
+                  f"{quota if quota else 'none'}), median encode+decode time",
         "encode_ms": round(1e3 * enc_s, 3), "decode_ms": round(1e3 * dec_s, 3),
         "one_thread_mpixels_s": round(one_thread, 2),
         "bytes_identical_to_gpu": bool(total == total_bytes_gpu),
