@@ -36,10 +36,25 @@ struct DevBuf {
   ~DevBuf() { release(); }
   hipError_t alloc(size_t n, hipStream_t s) {
     release();
+    keep_pool_memory();
     st = s;
     bytes = n;
     if (n == 0) n = 16;
     return hipMallocAsync(&p, n, s);
+  }
+  // The default stream-ordered pool hands freed memory back to the driver at the next
+  // synchronisation unless its release threshold is raised; every encode/decode call would
+  // then pay a fresh driver allocation for its slabs.  Done once per device.
+  static void keep_pool_memory() {
+    static thread_local int done_for = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev == done_for) return;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+      unsigned long long keep = ~0ull;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    done_for = dev;
   }
   void release() {
     if (p) (void)hipFreeAsync(p, st);

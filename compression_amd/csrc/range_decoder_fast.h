@@ -40,14 +40,38 @@ struct DecWindow {
   const uint8_t* src;
   long long len;
   unsigned int wbase;   // digit index held by lane 0 of reg
-  int reg;
+  int reg;              // digits wbase .. wbase + 63
+  int next;             // digits wbase + 64 .. wbase + 127, fetched one batch ahead
 };
 
-__device__ inline void fast_window_load(DecWindow& w, int lane) {
-  const long long b = 2ll * (static_cast<long long>(w.wbase) + lane);
+__device__ inline int fast_window_fetch(const DecWindow& w, unsigned int first, int lane) {
+  const long long b = 2ll * (static_cast<long long>(first) + lane);
   const unsigned int hi = b < w.len ? w.src[b] : 0u;
   const unsigned int lo = b + 1 < w.len ? w.src[b + 1] : 0u;
-  w.reg = static_cast<int>((hi << 8) | lo);
+  return static_cast<int>((hi << 8) | lo);
+}
+
+// Synchronous (re)load of both registers at wbase.
+__device__ inline void fast_window_load(DecWindow& w, int lane) {
+  w.reg = fast_window_fetch(w, w.wbase, lane);
+  w.next = fast_window_fetch(w, w.wbase + 64u, lane);
+}
+
+// Advances the window by `shift` (0..64) consumed digits without waiting for HBM: the new
+// register is stitched from reg/next with two ds_bpermute, and the following 64 digits are
+// requested now, to be used a whole batch later.
+__device__ inline void fast_window_advance(DecWindow& w, unsigned int shift, int lane) {
+  const int idx = (lane + static_cast<int>(shift)) & 63;
+  const int from_reg = __builtin_amdgcn_ds_bpermute(idx << 2, w.reg);
+  const int from_next = __builtin_amdgcn_ds_bpermute(idx << 2, w.next);
+  const bool in_reg = lane + static_cast<int>(shift) < 64;
+  // shift == 64 moves `next` into place unchanged (idx == lane)
+  const int stitched = in_reg ? from_reg : from_next;
+  w.wbase += shift;
+  w.reg = stitched;
+  // digits wbase+64.. : lanes that still come from the old `next` plus newly fetched ones
+  const int fresh = fast_window_fetch(w, w.wbase + 64u, lane);
+  w.next = fresh;
 }
 
 // One candidate-per-lane selection step.  hi = upper bound held by this lane,
@@ -173,7 +197,7 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
     const int cnt = static_cast<int>(min<int64_t>(64, p.elems - j0));
     const bool anywide = __ballot(valid && (row.z >> 16) > 1) != 0;
 
-    fast_window_load(w, lane);
+    if (j0 == 0) fast_window_load(w, lane); else fast_window_advance(w, st.pos, lane);
     st.pos = 0;
     int outv = 0;
     // stage-1 bounds (the row itself, or its pivots) are fetched one symbol ahead
@@ -209,9 +233,8 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
           const int neg = fast_bit(st, w);
           sym = neg ? -v : v + escsym - 1;
           if (st.pos >= 40u) {          // keep digits ahead in the window register
-            w.wbase += st.pos;
+            fast_window_advance(w, st.pos, lane);
             st.pos = 0;
-            fast_window_load(w, lane);
           }
         }
         outv = tfc_writelane(sym, n, outv);
@@ -304,11 +327,10 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
     } else {
       checked(0, cnt);
     }
-    w.wbase += st.pos;
-    st.pos = 0;
     if (valid) dst.store(s * p.elems + j, t, outv);
   }
 
+  w.wbase += st.pos;
   if (lane == 0) {
     // back to the (base, span-1, window, digits pulled) form the other kernels use
     const long long b = 2ll * w.wbase;

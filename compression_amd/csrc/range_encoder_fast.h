@@ -198,28 +198,48 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
   int count = 0;                                   // calls queued in ring[0..count)
   const int ntab = p.tab.ntab;
   int ch0 = 0;                                     // channel of the batch's first symbol
+  // Symbols (and table indices) are fetched one batch ahead so that the HBM latency of the
+  // next 64 symbols hides behind the chain phase of the current ones.
+  auto fetch = [&](int64_t j0, int ch, int* t_out) -> int32_t {
+    const int64_t j = j0 + lane;
+    if (j >= p.elems) { *t_out = 0; return 0; }
+    const int64_t pos = s * p.elems + j;
+    int t;
+    if (p.index) {
+      t = min(max(p.index[pos], 0), ntab - 1);     // range errors were reported by the counting pass
+    } else {
+      t = static_cast<int>((static_cast<unsigned int>(ch) + static_cast<unsigned int>(lane)) %
+                           static_cast<unsigned int>(ntab));
+    }
+    *t_out = t;
+    return src.load(pos, t);
+  };
+  int t_next = 0;
+  int32_t v_next = fetch(0, 0, &t_next);
   for (int64_t j0 = 0; j0 < p.elems; j0 += 64) {
     // ---- vector phase ----------------------------------------------------
     const int64_t j = j0 + lane;
     const bool valid = j < p.elems;
+    const int t = t_next;
+    const int32_t v = v_next;
+    {
+      const int ch_n = static_cast<int>((static_cast<unsigned int>(ch0) + 64u) % static_cast<unsigned int>(ntab));
+      v_next = fetch(j0 + 64, ch_n, &t_next);
+    }
     Call c;
     c.lo16 = 0; c.hi16 = 1; c.gamma = 0; c.neg = 0; c.bad = 0;
-    if (valid) {
-      const int64_t pos = s * p.elems + j;
-      int t;
-      if (p.index) {
-        t = min(max(p.index[pos], 0), ntab - 1);   // range errors were reported by the counting pass
-      } else {
-        t = static_cast<int>((static_cast<unsigned int>(ch0) + static_cast<unsigned int>(lane)) %
-                             static_cast<unsigned int>(ntab));
-      }
-      c = classify_normalised(T, rows[t], src.load(pos, t));
-    }
+    if (valid) c = classify_normalised(T, rows[t], v);
     ch0 = static_cast<int>((static_cast<unsigned int>(ch0) + 64u) % static_cast<unsigned int>(ntab));
     const unsigned int word = static_cast<unsigned int>(c.lo16) |
                               ((static_cast<unsigned int>(c.hi16) - 1u) << 16);
     const unsigned long long esc = __ballot(valid && c.gamma > 0);
     const int cnt = static_cast<int>(min<int64_t>(64, p.elems - j0));
+    if (esc == 0 && count == 0 && cnt == 64) {
+      // common case: exactly one call per symbol and nothing queued — feed the chain phase
+      // straight from registers, no trip through the LDS queue
+      consume_calls<true>(st, o, word, 64, lane);
+      continue;
+    }
     if (esc == 0) {
       if (valid) ring[count + lane] = word;
       count += cnt;
