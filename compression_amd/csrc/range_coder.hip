@@ -380,32 +380,65 @@ __device__ inline int escape_calls(int32_t gamma) {
   return 2 * nb + 2;
 }
 
-// Counting + validation pass: fully parallel, one thread per element.
+// Counting + validation pass: fully parallel and HBM-bound (one coalesced read of the
+// symbols).  Only the row's symbol count and escape flag are needed, so they are staged in
+// LDS ((nsym << 1) | escape per table) instead of gathering table entries.
+constexpr int kCountTile = 4096;      // elements of one stream per workgroup
+constexpr int kCountLdsRows = 8192;
+
 template <typename Src>
 __global__ void __launch_bounds__(256) enc_count_kernel(EncParams p, Src src) {
-  const int64_t tiles = (p.elems + 255) / 256;
-  const int64_t s = blockIdx.x / tiles;
-  const int64_t j = (blockIdx.x % tiles) * 256 + threadIdx.x;
-  unsigned int calls = 0;
-  if (j < p.elems) {
-    const int64_t pos = s * p.elems + j;
-    int t;
-    bool bad_index = false;
-    if (p.index) {
-      t = p.index[pos];
-      if (t < 0 || t >= p.tab.ntab) { bad_index = true; t = 0; }
-    } else {
-      t = static_cast<int>(j % p.tab.ntab);
-    }
-    const int2 row = p.tab.rows[t];
-    auto T = [&](int i) { return p.tab.data[i]; };
-    const Call c = classify(T, row, src.load(pos, t));
-    if (bad_index || c.bad) atomicMin(p.first_error, static_cast<unsigned long long>(pos));
-    calls = 1 + (c.gamma > 0 ? escape_calls(c.gamma) : 0);
-  }
-  // block reduce (4 waves)
-  for (int off = 32; off > 0; off >>= 1) calls += __shfl_down(calls, off, 64);
+  __shared__ int rowinfo[kCountLdsRows];
   __shared__ unsigned int part[4];
+  const bool in_lds = p.tab.ntab <= kCountLdsRows;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < p.tab.ntab; i += 256) {
+      const int2 r = p.tab.rows[i];
+      rowinfo[i] = ((r.y - 2) << 1) | (p.tab.data[r.x] < 0 ? 1 : 0);
+    }
+    __syncthreads();
+  }
+  const int64_t tiles = (p.elems + kCountTile - 1) / kCountTile;
+  const int64_t s = blockIdx.x / tiles;
+  const int64_t j0 = (blockIdx.x % tiles) * kCountTile;
+  const unsigned int ntab = static_cast<unsigned int>(p.tab.ntab);
+  unsigned int ch = static_cast<unsigned int>((j0 + threadIdx.x) % ntab);
+  const unsigned int step = 256u % ntab;
+  unsigned int calls = 0;
+  for (int k = 0; k < kCountTile / 256; ++k) {
+    const int64_t j = j0 + k * 256 + threadIdx.x;
+    if (j < p.elems) {
+      const int64_t pos = s * p.elems + j;
+      int t = static_cast<int>(ch);
+      bool bad = false;
+      if (p.index) {
+        t = p.index[pos];
+        if (t < 0 || t >= p.tab.ntab) { bad = true; t = 0; }
+      }
+      int info;
+      if (in_lds) {
+        info = rowinfo[t];
+      } else {
+        const int2 r = p.tab.rows[t];
+        info = ((r.y - 2) << 1) | (p.tab.data[r.x] < 0 ? 1 : 0);
+      }
+      const int nsym = info >> 1;
+      const int32_t v = src.load(pos, t);
+      unsigned int c = 1;
+      if (info & 1) {
+        const int vmax = nsym - 1;                  // last interval is the escape symbol
+        const int gamma = v < 0 ? -v : (v >= vmax ? v - vmax + 1 : 0);
+        if (gamma > 0) c += escape_calls(gamma);
+      } else if (v < 0 || v >= nsym) {
+        bad = true;
+      }
+      if (bad) atomicMin(p.first_error, static_cast<unsigned long long>(pos));
+      calls += c;
+    }
+    ch += step;
+    if (ch >= ntab) ch -= ntab;
+  }
+  for (int off = 32; off > 0; off >>= 1) calls += __shfl_down(calls, off, 64);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = calls;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -683,6 +716,26 @@ __global__ void scan_lengths_kernel(const long long* length, int64_t streams, lo
   if (threadIdx.x == 0) off[streams] = carry;
 }
 
+// Wave-cooperative byte copy with 4-byte stores: dst is brought to dword alignment, the
+// (generally misaligned) source is read as aligned dwords and funnel-shifted.  The source
+// slabs carry >= 4 bytes of slack behind every stream, so reading one dword past n is safe.
+__device__ inline void wave_copy(uint8_t* dst, const uint8_t* src, unsigned int n, int lane) {
+  const unsigned int head = min(n, static_cast<unsigned int>((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3));
+  if (lane < static_cast<int>(head)) dst[lane] = src[lane];
+  dst += head; src += head; n -= head;
+  const unsigned int nd = n >> 2;
+  const unsigned int sh = static_cast<unsigned int>(reinterpret_cast<uintptr_t>(src) & 3) * 8;
+  const unsigned int* s32 = reinterpret_cast<const unsigned int*>(reinterpret_cast<uintptr_t>(src) & ~uintptr_t{3});
+  unsigned int* d32 = reinterpret_cast<unsigned int*>(dst);
+  if (sh == 0) {
+    for (unsigned int i = lane; i < nd; i += 64) d32[i] = s32[i];
+  } else {
+    for (unsigned int i = lane; i < nd; i += 64) d32[i] = (s32[i] >> sh) | (s32[i + 1] << (32 - sh));
+  }
+  const unsigned int rem = n & 3;
+  if (lane < static_cast<int>(rem)) dst[4 * nd + lane] = src[4 * nd + lane];
+}
+
 // One wave per stream: copy the stream's chunk pieces then its tail.
 __global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const ChunkRef* chunks,
                                                          int nchunks, const Tail* tail,
@@ -693,9 +746,8 @@ __global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const
   uint8_t* dst = blob + off[s];
   long long done = 0;
   for (int c = 0; c < nchunks; ++c) {
-    const uint8_t* src = chunks[c].data + chunks[c].off[s];
     const unsigned int n = chunks[c].len[s];
-    for (unsigned int i = lane; i < n; i += 64) dst[done + i] = src[i];
+    wave_copy(dst + done, chunks[c].data + chunks[c].off[s], n, lane);
     done += n;
   }
   const Tail t = tail[s];
@@ -1023,7 +1075,7 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   p.chunk_len = ch.len.as<unsigned int>();
   p.overflow_flag = e->oflag.as<unsigned int>();
 
-  const int64_t tiles = ceil_div(elems, 256);
+  const int64_t tiles = ceil_div(elems, kCountTile);
   if (e->streams * tiles >= (int64_t{1} << 31)) return fail("encode call too large for one launch");
   hipLaunchKernelGGL((enc_count_kernel<Src>), dim3(static_cast<unsigned>(e->streams * tiles)),
                      dim3(256), 0, st, p, src);
