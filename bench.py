@@ -90,10 +90,32 @@ def gdn_forward_bandwidth(device, steps=20):
     avg_ms = ms / max(n, 1)
     nbytes = 2 * x.numel() * x.element_size()
     gbs = nbytes / 1e9 / (avg_ms / 1e3)
+    # backward: x, g in; dx out is the algorithmic minimum (3 tensors); the three passes
+    # actually move 4 + 4 + 2 tensors (T and R are materialised once and re-read).
+    from compression_amd.layers import gdn_backward
+    g = torch.randn(M, C, device=device).bfloat16()
+    for _ in range(2):
+        gdn_backward(x, g, beta, gamma)
+    torch.cuda.synchronize()
+    _lib.lib().tfc_profile_enable(1)
+    for _ in range(steps):
+        gdn_backward(x, g, beta, gamma)
+    torch.cuda.synchronize()
+    passes = {}
+    for name in ("gdn_backward_t", "gdn_backward_dx", "gdn_backward_params"):
+        pms, pn = profile_query(name)
+        passes[name] = round(pms / max(pn, 1), 4)
+    _lib.lib().tfc_profile_enable(0)
+    bwd_ms = sum(passes.values())
+    bwd_bytes = 3 * x.numel() * x.element_size()
     return {"workload": "GDN fwd, [262144, 192] bf16 (= 256x192x32x32), alpha=1, eps=1",
             "kernel_ms": round(avg_ms, 4), "algorithmic_bytes": nbytes,
             "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm"}
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm",
+            "backward": {"kernel_ms": round(bwd_ms, 4), "passes_ms": passes,
+                         "algorithmic_bytes": bwd_bytes,
+                         "achieved": round(bwd_bytes / 1e9 / (bwd_ms / 1e3), 1) if bwd_ms else None,
+                         "unit": "GB/s"}}
 
 
 def usable_cores():
