@@ -90,8 +90,8 @@ def gdn_forward_bandwidth(device, steps=20):
     avg_ms = ms / max(n, 1)
     nbytes = 2 * x.numel() * x.element_size()
     gbs = nbytes / 1e9 / (avg_ms / 1e3)
-    # backward: x, g in; dx out is the algorithmic minimum (3 tensors); the three passes
-    # actually move 4 + 4 + 2 tensors (T and R are materialised once and re-read).
+    # backward: x, g in; dx out is the algorithmic minimum (3 tensors).  The fused kernel
+    # (x, g -> T, dx) plus the parameter pass (x, T -> dgamma, dbeta) move 4 + 2 tensors.
     from compression_amd.layers import gdn_backward
     g = torch.randn(M, C, device=device).bfloat16()
     for _ in range(2):
@@ -102,9 +102,10 @@ def gdn_forward_bandwidth(device, steps=20):
         gdn_backward(x, g, beta, gamma)
     torch.cuda.synchronize()
     passes = {}
-    for name in ("gdn_backward_t", "gdn_backward_dx", "gdn_backward_params"):
+    for name in ("gdn_backward_fused", "gdn_backward_t", "gdn_backward_dx", "gdn_backward_params"):
         pms, pn = profile_query(name)
-        passes[name] = round(pms / max(pn, 1), 4)
+        if pn:
+            passes[name] = round(pms / pn, 4)
     _lib.lib().tfc_profile_enable(0)
     bwd_ms = sum(passes.values())
     bwd_bytes = 3 * x.numel() * x.element_size()
@@ -112,10 +113,30 @@ def gdn_forward_bandwidth(device, steps=20):
             "kernel_ms": round(avg_ms, 4), "algorithmic_bytes": nbytes,
             "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm",
+            "traffic": pmc_traffic("gdn_fwd_bf16_kernel<6, 0>"),
             "backward": {"kernel_ms": round(bwd_ms, 4), "passes_ms": passes,
                          "algorithmic_bytes": bwd_bytes,
                          "achieved": round(bwd_bytes / 1e9 / (bwd_ms / 1e3), 1) if bwd_ms else None,
                          "unit": "GB/s"}}
+
+
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+
+
+def pmc_traffic(kernel_substring):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes
+    (tools/pmc_on_box.sh; same bench command).  Counter unit is KiB.  Corrections as
+    MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-B read requests as 64 B
+    (x2; calibrated in the same passes on torch's fp32->bf16 copy of a 201 MB tensor: reported
+    98322 KiB, true 196608 KiB), WRITE_SIZE is exact on that kernel's 98304 KiB output."""
+    try:
+        table = json.load(open(PMC_FILE))
+    except OSError:
+        return None
+    for name, ctrs in table.items():
+        if kernel_substring in name and "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs:
+            return int((2.0 * ctrs["FETCH_SIZE"]["mean"] + ctrs["WRITE_SIZE"]["mean"]) * 1024)
+    return None
 
 
 def usable_cores():
@@ -338,7 +359,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": pmc_traffic("dec_fast_kernel" if dom == "dec_kernel" else "enc_fast_kernel"),
+                "traffic_source": "profiles/r01_d_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes of this command; 2*FETCH + WRITE, KiB -> bytes)",
+                "algorithmic_bytes": int(dom_bytes),
                 "note": "latency-bound serial chain per stream (512 chains); see DESIGN.md",
             },
         }

@@ -1,0 +1,504 @@
+// GDN / IGDN backward for gfx950: dx, dbeta, dgamma of python/layers/gdn.py:371-421 (the
+// reference differentiates those ops with TF autodiff; there is no hand-written gradient).
+//
+//   n = beta + U Gamma,  y = x n^s  (s = -eps GDN / +eps IGDN),  g = dL/dy
+//   T = dL/dn = s g y / n,   R = g n^s
+//   dx = R + (T Gamma^T) d|x|^alpha/dx,   dbeta = sum_p T,   dgamma = U^T T
+#include "gdn_common.h"
+
+namespace tfc {
+
+// ---------------------------------------------------------------------------
+// bf16 backward, passes 1 and 2 fused (C <= 192: both fragment images fit the 160 KB LDS).
+// T leaves pass 1 in exactly the register layout the MFMA wants as its B operand (that is what
+// the permuted K order buys), so dx = R + (T Gamma^T) du/dx is contracted straight from
+// registers: x and g are read once, T (for the parameter gradients) and dx written once.
+// The second contraction runs in two halves of the output tiles to stay under 256 VGPRs.
+// LDS: [image of Gamma^T | image of Gamma | beta].
+// ---------------------------------------------------------------------------
+template <int KT, bool PLAIN>
+__global__ void __launch_bounds__(512) gdn_bwd_fused_bf16_kernel(GdnParams p) {
+  constexpr int C = KT * 32;
+  constexpr int KS = KT * 2;
+  constexpr int IMG = KT * KS * 64;       // fragments per image
+  extern __shared__ unsigned char smem[];
+  const bf16x8* afrag = reinterpret_cast<const bf16x8*>(smem);
+  const bf16x8* bfrag2 = afrag + IMG;
+  const float* beta_s = reinterpret_cast<const float*>(smem + sizeof(bf16x8) * 2 * IMG);
+  {
+    const u32x4* src = static_cast<const u32x4*>(p.image);
+    u32x4* dstv = reinterpret_cast<u32x4*>(smem);
+    constexpr int n16 = 2 * IMG + (C * 4) / 16;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dstv[i] = src[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5;
+  const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = static_cast<long long>(gridDim.x) * (blockDim.x >> 6);
+  const unsigned short* x = static_cast<const unsigned short*>(p.x);
+  const unsigned short* g = static_cast<const unsigned short*>(p.g);
+  unsigned short* tout = static_cast<unsigned short*>(p.y2);
+  unsigned short* dx = static_cast<unsigned short*>(p.y);
+
+  for (long long tile = wave; tile < p.tiles; tile += nwaves) {
+    const long long pix = tile * 32 + (lane & 31);
+    const bool live = pix < p.pixels;
+    const long long row = (live ? pix : p.pixels - 1) * C;
+    auto frag_load = [&](const unsigned short* base, int s) -> u32x4 {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(base + row + 16 * s + 8 * h);
+      const auto s0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+      return u32x4{s0[0], s1[0], s0[1], s1[1]};
+    };
+    auto frag_store = [&](unsigned short* base, int s, u32x4 out) {
+      const auto s0 = __builtin_amdgcn_permlane32_swap(out.x, out.z, false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(out.y, out.w, false, false);
+      if (live) *reinterpret_cast<u32x4*>(base + row + 16 * s + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+    };
+    auto elem = [&](const u32x4& f, int half, int r) -> float {
+      const unsigned int word = f[2 * half + (r >> 1)];
+      return __uint_as_float((r & 1) ? (word & 0xFFFF0000u) : (word << 16));
+    };
+    u32x4 xr[KS], gr[KS];
+    asm volatile("" ::: "memory");   // keep the (tile-invariant) LDS fragment loads inside the loop
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xr[s] = frag_load(x, s);
+
+    // ---- contraction 1: n = beta + U Gamma ----
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      u32x4 u = xr[s];
+      if (PLAIN) {
+        u &= 0x7FFF7FFFu;
+      } else {
+        asm volatile("" : "+v"(u));   // no CSE of this unpack with the epilogues' (live-range bloat)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float lo = fmaxf(bf16_bits_to_float(u[w] & 0xFFFFu), p.relu_floor);
+          const float hi = fmaxf(__uint_as_float(u[w] & 0xFFFF0000u), p.relu_floor);
+          u[w] = pack_bf16(gdn_u(lo, p.a2), gdn_u(hi, p.a2));
+        }
+      }
+      const bf16x8 b = __builtin_bit_cast(bf16x8, u);
+      // g is fetched late (its 48 registers do not fit next to x, the accumulators and the A
+      // fragments for the whole contraction): the loads fly under the last K-steps' MFMAs.
+      if (s == (KS > 3 ? KS - 3 : 0)) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) gr[k] = frag_load(g, k);
+      }
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[(t * KS + s) * 64 + lane], b, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // n = acc + beta, in place and ahead of the variant switch (the loads are common to the four
+    // variants; left inside, they are hoisted above the switch all at once: 96 registers)
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][4 * q + r] += b4[r];
+      }
+      // pin the sums here: IR-level sinking would otherwise keep the beta loads live and
+      // redo the add at each use
+      asm volatile("" : "+v"(acc[t]));
+    }
+    // ---- T (overwrites g in registers) and R (kept packed) ----
+    u32x4 rr[KS];
+    auto pass1 = [&](auto inv, auto epsh) {
+      constexpr bool INV = decltype(inv)::value, EPSH = decltype(epsh)::value;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int t = s >> 1;
+        u32x4 tq, rq;
+        // Opaque copies: without them the unpacking of all 2 x 96 elements, identical in the four
+        // variants, is hoisted above the variant switch and costs ~190 live registers.
+        u32x4 xs = xr[s], gs = gr[s];
+        asm volatile("" : "+v"(xs), "+v"(gs));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int q = 2 * (s & 1) + half;
+          float tv[4], rv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float xv = elem(xs, half, r);
+            if (!PLAIN) xv = fmaxf(xv, p.relu_floor);
+            const float gv = elem(gs, half, r);
+            float pw, c;
+            gdn_grad_factors<INV, EPSH>(acc[t][4 * q + r], &pw, &c);
+            tv[r] = c * gv * xv;
+            rv[r] = gv * pw;
+          }
+          tq[2 * half] = pack_bf16(tv[0], tv[1]);
+          tq[2 * half + 1] = pack_bf16(tv[2], tv[3]);
+          rq[2 * half] = pack_bf16(rv[0], rv[1]);
+          rq[2 * half + 1] = pack_bf16(rv[2], rv[3]);
+        }
+        // pin T and R as packed words now (otherwise R = g * pw is sunk to its use in the dx
+        // epilogue and the unpacked pw / g floats stay live across the second contraction)
+        asm volatile("" : "+v"(tq), "+v"(rq));
+        gr[s] = tq;
+        rr[s] = rq;
+      }
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    if (p.inverse) {
+      if (p.eps_half) pass1(TT{}, TT{}); else pass1(TT{}, FF{});
+    } else {
+      if (p.eps_half) pass1(FF{}, TT{}); else pass1(FF{}, FF{});
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) frag_store(tout, s, gr[s]);
+
+    // ---- contraction 2: (T Gamma^T), output tiles in two groups ----
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      constexpr int G0 = (KT + 1) / 2;
+      const int t0 = grp == 0 ? 0 : G0;
+      const int nt = grp == 0 ? G0 : KT - G0;
+      f32x16 acc2[G0];
+#pragma unroll
+      for (int t = 0; t < G0; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, gr[s]);
+#pragma unroll
+        for (int t = 0; t < G0; ++t)
+          if (t < nt)
+            acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag2[((t0 + t) * KS + s) * 64 + lane], b,
+                                                               acc2[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int t = 0; t < G0; ++t) {
+        if (t >= nt) continue;
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+          const int s = 2 * (t0 + t) + sh;
+          u32x4 out;
+          u32x4 xs = xr[s], rs = rr[s];
+          asm volatile("" : "+v"(xs), "+v"(rs));
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int q = 2 * sh + half;
+            float dv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              dv[r] = gdn_dx<PLAIN>(elem(xs, half, r), elem(rs, half, r), acc2[t][4 * q + r],
+                                    p.relu_floor, p.a2);
+            out[2 * half] = pack_bf16(dv[0], dv[1]);
+            out[2 * half + 1] = pack_bf16(dv[2], dv[3]);
+          }
+          asm volatile("" : "+v"(out));
+          rr[s] = out;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) frag_store(dx, s, rr[s]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Parameter gradients:  dgamma[j][i] = sum_p u_j[p] T_i[p],  dbeta[i] = sum_p T_i[p].
+// A [C x C] = U^T T contraction over PIXELS: both MFMA operands need, per lane, consecutive
+// pixels of one channel, i.e. the transpose of the channels-last tensors.  A block stages
+// 64 pixels of u and T through LDS (bf16: written transposed [channel][pixel] so that a
+// fragment is one ds_read_b128; f32: copied as is, fragments are conflict-free ds_read_b32),
+// its four waves own the (j-tile, i-tile) pairs of one parity class each (so every fragment
+// read feeds up to KT/2 MFMAs), and each block leaves a [C*C + C] partial that
+// gdn_param_reduce_kernel sums in a fixed order (deterministic, no float atomics).
+// ---------------------------------------------------------------------------
+constexpr int PG_PIX = 64;        // pixels per LDS stage
+constexpr int PG_STRIDE = 72;     // bf16 elements per transposed LDS row (144 B: b128 reads conflict-free)
+
+template <typename T, int KT>
+__global__ void __launch_bounds__(256) gdn_param_grad_kernel(GdnParams p, float* partial) {
+  constexpr int C = KT * 32;
+  constexpr int NH = (KT + 1) / 2;
+  constexpr bool BF = sizeof(T) == 2;
+  extern __shared__ unsigned char smem[];
+  // bf16: uT[C][PG_STRIDE], tT[C][PG_STRIDE] (u16); f32: us[PG_PIX][C], ts[PG_PIX][C] (float)
+  unsigned short* uT = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* tT = uT + C * PG_STRIDE;
+  float* us = reinterpret_cast<float*>(smem);
+  float* ts = us + PG_PIX * C;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wj = w >> 1, wi = w & 1, i32 = lane & 31, h = lane >> 5;
+  const T* x = static_cast<const T*>(p.x);
+  const T* tsrc = static_cast<const T*>(p.g);   // T = dL/dn from pass 1
+
+  f32x16 acc[NH][NH];
+#pragma unroll
+  for (int a = 0; a < NH; ++a)
+#pragma unroll
+    for (int b = 0; b < NH; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f;
+
+  const long long stages = (p.pixels + PG_PIX - 1) / PG_PIX;
+  for (long long st = blockIdx.x; st < stages; st += gridDim.x) {
+    const long long p0 = st * PG_PIX;
+    __syncthreads();
+    if (BF) {
+      // chunk = 8 channels of one pixel; consecutive lanes take consecutive pixels so that the
+      // transposed 2-byte LDS writes of a wave fall in one 128-byte row segment.
+      constexpr int chunks = PG_PIX * C / 8;
+      for (int c = tid; c < chunks; c += 256) {
+        const int px = c % PG_PIX, cg = c / PG_PIX;
+        u32x4 xv = u32x4{0, 0, 0, 0}, tv = u32x4{0, 0, 0, 0};
+        if (p0 + px < p.pixels) {
+          xv = *reinterpret_cast<const u32x4*>(x + (p0 + px) * C + 8 * cg);
+          tv = *reinterpret_cast<const u32x4*>(tsrc + (p0 + px) * C + 8 * cg);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned int xb = (e & 1) ? (xv[e >> 1] >> 16) : (xv[e >> 1] & 0xFFFFu);
+          const unsigned int tb = (e & 1) ? (tv[e >> 1] >> 16) : (tv[e >> 1] & 0xFFFFu);
+          float f = bf16_bits_to_float(xb);
+          if (p.rectify) f = fmaxf(f, 0.f);
+          f = p.alpha2 ? f * f : fabsf(f);
+          uT[(8 * cg + e) * PG_STRIDE + px] = static_cast<unsigned short>(float_to_bf16_bits(f));
+          tT[(8 * cg + e) * PG_STRIDE + px] = static_cast<unsigned short>(tb);
+        }
+      }
+    } else {
+      constexpr int chunks = PG_PIX * C / 4;
+      for (int c = tid; c < chunks; c += 256) {
+        const int px = c / (C / 4), cg = c % (C / 4);
+        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, tv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p0 + px < p.pixels) {
+          xv = *reinterpret_cast<const f32x4*>(x + (p0 + px) * C + 4 * cg);
+          tv = *reinterpret_cast<const f32x4*>(tsrc + (p0 + px) * C + 4 * cg);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float f = xv[e];
+          if (p.rectify) f = fmaxf(f, 0.f);
+          xv[e] = p.alpha2 ? f * f : fabsf(f);
+        }
+        *reinterpret_cast<f32x4*>(us + px * C + 4 * cg) = xv;
+        *reinterpret_cast<f32x4*>(ts + px * C + 4 * cg) = tv;
+      }
+    }
+    __syncthreads();
+    // dbeta: thread c sums column c of the staged T tile
+    if (tid < C) {
+      if (BF) {
+#pragma unroll
+        for (int k = 0; k < PG_PIX / 8; ++k) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(tT + tid * PG_STRIDE + 8 * k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum += bf16_bits_to_float(v[e] & 0xFFFFu) + bf16_bits_to_float(v[e] >> 16);
+        }
+      } else {
+#pragma unroll 8
+        for (int k = 0; k < PG_PIX; ++k) bsum += ts[k * C + tid];
+      }
+    }
+    if (BF) {
+#pragma unroll
+      for (int ks = 0; ks < PG_PIX / 16; ++ks) {
+        bf16x8 af[NH], bfr[NH];
+#pragma unroll
+        for (int a = 0; a < NH; ++a) {
+          const int jt = wj + 2 * a, it = wi + 2 * a;
+          if (jt < KT) af[a] = *reinterpret_cast<const bf16x8*>(uT + (32 * jt + i32) * PG_STRIDE + 16 * ks + 8 * h);
+          if (it < KT) bfr[a] = *reinterpret_cast<const bf16x8*>(tT + (32 * it + i32) * PG_STRIDE + 16 * ks + 8 * h);
+        }
+#pragma unroll
+        for (int a = 0; a < NH; ++a)
+#pragma unroll
+          for (int b = 0; b < NH; ++b)
+            if (wj + 2 * a < KT && wi + 2 * b < KT)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int k2 = 0; k2 < PG_PIX / 2; ++k2) {
+        float af[NH], bfr[NH];
+#pragma unroll
+        for (int a = 0; a < NH; ++a) {
+          const int jt = wj + 2 * a, it = wi + 2 * a;
+          af[a] = jt < KT ? us[(2 * k2 + h) * C + 32 * jt + i32] : 0.f;
+          bfr[a] = it < KT ? ts[(2 * k2 + h) * C + 32 * it + i32] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < NH; ++a)
+#pragma unroll
+          for (int b = 0; b < NH; ++b)
+            if (wj + 2 * a < KT && wi + 2 * b < KT)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+  float* out = partial + static_cast<size_t>(blockIdx.x) * (C * C + C);
+#pragma unroll
+  for (int a = 0; a < NH; ++a)
+#pragma unroll
+    for (int b = 0; b < NH; ++b) {
+      const int jt = wj + 2 * a, it = wi + 2 * b;
+      if (jt < KT && it < KT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * h;
+          out[j * C + 32 * it + i32] = acc[a][b][r];
+        }
+      }
+    }
+  if (tid < C) out[C * C + tid] = bsum;
+}
+
+// dgamma / dbeta += sum over block partials (fixed order).
+__global__ void gdn_param_reduce_kernel(const float* partial, int blocks, int C, float* dgamma,
+                                        float* dbeta) {
+  const int n = C * C + C;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[static_cast<size_t>(b) * n + idx];
+  if (idx < C * C) dgamma[idx] += s; else dbeta[idx - C * C] += s;
+}
+
+template <typename T, int KT>
+int launch_param_grad(GdnParams p, float* dgamma, float* dbeta, hipStream_t st) {
+  constexpr int C = KT * 32;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long long stages = ceil_div(p.pixels, static_cast<long long>(PG_PIX));
+  const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(stages, cus)));
+  const size_t lds = sizeof(T) == 2 ? sizeof(unsigned short) * 2 * C * PG_STRIDE : sizeof(float) * 2 * PG_PIX * C;
+  DevBuf partial;
+  TFC_HIP(partial.alloc(sizeof(float) * static_cast<size_t>(blocks) * (C * C + C), st));
+  {
+    KernelTimer timer("gdn_backward_params", st);
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_param_grad_kernel<T, KT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((gdn_param_grad_kernel<T, KT>), dim3(blocks), dim3(256), lds, st, p, partial.as<float>());
+  }
+  const int n = C * C + C;
+  hipLaunchKernelGGL(gdn_param_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial.as<float>(),
+                     blocks, C, dgamma, dbeta);
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int KT, bool PLAIN>
+int launch_gdn_bwd_fused_variant(GdnParams p, hipStream_t st) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long long want = ceil_div(p.tiles, 8);
+  const unsigned blocks = static_cast<unsigned>(std::max<long long>(1, std::min<long long>(want, cus)));
+  constexpr int IMG = KT * KT * 2 * 64;
+  const size_t lds = sizeof(bf16x8) * 2 * IMG + sizeof(float) * KT * 32;
+  DevBuf image;
+  TFC_HIP(image.alloc(lds, st));
+  // Gamma^T image, then the Gamma image; beta lands behind the second one
+  hipLaunchKernelGGL(gdn_prep_bf16_kernel, dim3((IMG + 255) / 256), dim3(256), 0, st, p.gamma, p.beta,
+                     KT * 32, 0, image.as<bf16x8>());
+  hipLaunchKernelGGL(gdn_prep_bf16_kernel, dim3((IMG + 255) / 256), dim3(256), 0, st, p.gamma, p.beta,
+                     KT * 32, 1, image.as<bf16x8>() + IMG);
+  p.image = image.p;
+  KernelTimer timer("gdn_backward_fused", st);
+  TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_bwd_fused_bf16_kernel<KT, PLAIN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  hipLaunchKernelGGL((gdn_bwd_fused_bf16_kernel<KT, PLAIN>), dim3(blocks), dim3(512), lds, st, p);
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int KT>
+int launch_gdn_bwd_fused(GdnParams p, hipStream_t st) {
+  p.relu_floor = p.rectify ? 0.f : -__builtin_inff();
+  p.a2 = p.alpha2 ? 1.f : 0.f;
+  if (!p.rectify && !p.alpha2) return launch_gdn_bwd_fused_variant<KT, true>(p, st);
+  return launch_gdn_bwd_fused_variant<KT, false>(p, st);
+}
+
+// bf16 with C <= 192: fused kernel (x, g -> T, dx) + parameter pass.  Otherwise three passes
+// (all reading / writing each tensor once):
+//   1. MODE_BWD_T:   x, g        -> T (= dL/dn), R (= g n^s)
+//   2. MODE_BWD_DX:  T, R, x     -> dx
+//   3. param grads:  x, T        -> dgamma, dbeta
+template <int KT>
+int run_gdn_backward(GdnParams p, const void* g, void* dx, int dtype, float* dbeta, float* dgamma,
+                     hipStream_t st) {
+  const size_t bytes = static_cast<size_t>(p.pixels) * p.C * (dtype == 1 ? 2 : 4);
+  DevBuf tbuf, rbuf;
+  TFC_HIP(tbuf.alloc(bytes, st));
+  if constexpr (KT <= 6) {
+    if (dtype == 1) {
+      GdnParams f = p;
+      f.g = g; f.y = dx; f.y2 = tbuf.p;
+      if (int rc = launch_gdn_bwd_fused<KT>(f, st)) return rc;
+      GdnParams c = p;
+      c.g = tbuf.p;
+      return launch_param_grad<unsigned short, KT>(c, dgamma, dbeta, st);
+    }
+  }
+  if constexpr (KT > 6) {
+    if (dtype != 1) return fail("tfc_gdn_backward: float32 path supports up to 192 channels");
+  }
+  TFC_HIP(rbuf.alloc(bytes, st));
+  GdnParams a = p;
+  a.g = g; a.y = tbuf.p; a.y2 = rbuf.p;
+  constexpr int DT = KT <= 6 ? 1 : 2;   // two-pass path: f32 (C <= 192) or bf16 with C > 192
+  if (int rc = launch_gdn<KT, MODE_BWD_T, DT>(a, dtype, st)) return rc;
+  GdnParams b = p;
+  b.x = tbuf.p; b.r = rbuf.p; b.xraw = p.x; b.y = dx;
+  if (int rc = launch_gdn<KT, MODE_BWD_DX, DT>(b, dtype, st)) return rc;
+  GdnParams c = p;
+  c.g = tbuf.p;
+  if constexpr (KT <= 6) return launch_param_grad<float, KT>(c, dgamma, dbeta, st);
+  else return launch_param_grad<unsigned short, KT>(c, dgamma, dbeta, st);
+}
+
+}  // namespace tfc
+
+extern "C" int tfc_gdn_backward(const void* x, const void* g, void* dx, int dtype, int64_t pixels,
+                                int64_t channels, const float* beta, const float* gamma, int inverse,
+                                int rectify, int alpha_mode, int eps_mode, float* dbeta, float* dgamma,
+                                void* stream) {
+  using namespace tfc;
+  if (dtype != 0 && dtype != 1) return fail("tfc_gdn_backward: dtype must be 0 (float32) or 1 (bfloat16)");
+  if (alpha_mode != 1 && alpha_mode != 2) return fail("tfc_gdn_backward: alpha must be 1 or 2");
+  if (eps_mode != 0 && eps_mode != 1) return fail("tfc_gdn_backward: epsilon must be 1 or 0.5");
+  if (channels <= 0 || channels % 32 != 0 || channels > 256)
+    return fail("tfc_gdn_backward: channels must be a multiple of 32, at most 256 (got %lld)",
+                static_cast<long long>(channels));
+  if (dtype == 0 && channels > 192)
+    return fail("tfc_gdn_backward: float32 path supports up to 192 channels (Gamma must fit in LDS)");
+  if (pixels == 0) return 0;
+  GdnParams p{};
+  p.x = x; p.beta = beta; p.gamma = gamma;
+  p.pixels = pixels; p.C = static_cast<int>(channels);
+  p.inverse = inverse; p.rectify = rectify; p.alpha2 = alpha_mode == 2; p.eps_half = eps_mode == 1;
+  p.tiles = ceil_div(pixels, 32);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (channels / 32) {
+    case 1: return run_gdn_backward<1>(p, g, dx, dtype, dbeta, dgamma, st);
+    case 2: return run_gdn_backward<2>(p, g, dx, dtype, dbeta, dgamma, st);
+    case 3: return run_gdn_backward<3>(p, g, dx, dtype, dbeta, dgamma, st);
+    case 4: return run_gdn_backward<4>(p, g, dx, dtype, dbeta, dgamma, st);
+    case 5: return run_gdn_backward<5>(p, g, dx, dtype, dbeta, dgamma, st);
+    case 6: return run_gdn_backward<6>(p, g, dx, dtype, dbeta, dgamma, st);
+    case 7: return run_gdn_backward<7>(p, g, dx, dtype, dbeta, dgamma, st);
+    default: return run_gdn_backward<8>(p, g, dx, dtype, dbeta, dgamma, st);
+  }
+}

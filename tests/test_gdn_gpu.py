@@ -118,17 +118,19 @@ def test_gdn_backward_f32(C, inverse, rectify, alpha, eps):
     assert np.max(np.abs(dgamma.cpu().numpy() - wg)) <= 1e-4 * max(1.0, np.max(np.abs(wg)))
 
 
-@pytest.mark.parametrize("C", [64, 192, 256])
-@pytest.mark.parametrize("inverse", [False, True])
-def test_gdn_backward_bf16(C, inverse):
+@pytest.mark.parametrize("C", [64, 160, 192, 256])     # <= 192: fused kernel; 256: three passes
+@pytest.mark.parametrize("inverse,rectify,alpha,eps", [
+    (False, False, 1, 1), (True, False, 1, 1), (False, True, 2, 0.5), (True, True, 1, 0.5),
+    (False, False, 2, 1)])
+def test_gdn_backward_bf16(C, inverse, rectify, alpha, eps):
     from compression_amd.layers import gdn_backward
     torch.manual_seed(6)
     x = torch.randn(5, 41, C).bfloat16()
     g = torch.randn(5, 41, C).bfloat16()
     beta, gamma = params(C, 2)
-    dx, dbeta, dgamma = gdn_backward(x.cuda(), g.cuda(), beta, gamma, inverse)
+    dx, dbeta, dgamma = gdn_backward(x.cuda(), g.cuda(), beta, gamma, inverse, rectify, alpha, eps)
     wx, wb, wg = ref_gdn_grads(x.float().reshape(-1, C).numpy(), g.float().reshape(-1, C).numpy(),
-                               beta.numpy(), gamma.bfloat16().float().numpy(), inverse, False, 1, 1)
+                               beta.numpy(), gamma.bfloat16().float().numpy(), inverse, rectify, alpha, eps)
     # bf16 storage of T, R and dx: a few bf16 ulps relative to the tensor scale
     assert np.max(np.abs(dx.float().cpu().numpy().reshape(-1, C) - wx)) <= 2 ** -6 * np.max(np.abs(wx))
     assert np.max(np.abs(dbeta.cpu().numpy() - wb)) <= 2 ** -6 * np.max(np.abs(wb)) + 0.05
