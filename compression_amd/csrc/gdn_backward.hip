@@ -250,52 +250,86 @@ __global__ void __launch_bounds__(256) gdn_param_grad_kernel(GdnParams p, float*
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bsum = 0.f;
 
-  const long long stages = (p.pixels + PG_PIX - 1) / PG_PIX;
-  for (long long st = blockIdx.x; st < stages; st += gridDim.x) {
+  // Software pipeline: the next stage's global loads are issued into registers before the MFMAs
+  // of the current one and written to LDS after them.
+  //   bf16: chunk = 8 channels of one pixel, consecutive lanes = consecutive pixels; thread owns
+  //         chunks tid + 256 k (k < KT): pixel tid & 63, channel group (tid >> 6) + 4 k.
+  //   f32:  chunk = 4 channels of one pixel, channel group fastest (coalesced, conflict-free).
+  constexpr int NCH = BF ? KT : 2 * KT;
+  u32x4 xq[NCH], tq[NCH];
+  auto fetch = [&](long long st) {
     const long long p0 = st * PG_PIX;
-    __syncthreads();
-    if (BF) {
-      // chunk = 8 channels of one pixel; consecutive lanes take consecutive pixels so that the
-      // transposed 2-byte LDS writes of a wave fall in one 128-byte row segment.
-      constexpr int chunks = PG_PIX * C / 8;
-      for (int c = tid; c < chunks; c += 256) {
-        const int px = c % PG_PIX, cg = c / PG_PIX;
-        u32x4 xv = u32x4{0, 0, 0, 0}, tv = u32x4{0, 0, 0, 0};
-        if (p0 + px < p.pixels) {
-          xv = *reinterpret_cast<const u32x4*>(x + (p0 + px) * C + 8 * cg);
-          tv = *reinterpret_cast<const u32x4*>(tsrc + (p0 + px) * C + 8 * cg);
-        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const unsigned int xb = (e & 1) ? (xv[e >> 1] >> 16) : (xv[e >> 1] & 0xFFFFu);
-          const unsigned int tb = (e & 1) ? (tv[e >> 1] >> 16) : (tv[e >> 1] & 0xFFFFu);
-          float f = bf16_bits_to_float(xb);
-          if (p.rectify) f = fmaxf(f, 0.f);
-          f = p.alpha2 ? f * f : fabsf(f);
-          uT[(8 * cg + e) * PG_STRIDE + px] = static_cast<unsigned short>(float_to_bf16_bits(f));
-          tT[(8 * cg + e) * PG_STRIDE + px] = static_cast<unsigned short>(tb);
-        }
-      }
-    } else {
-      constexpr int chunks = PG_PIX * C / 4;
-      for (int c = tid; c < chunks; c += 256) {
-        const int px = c / (C / 4), cg = c % (C / 4);
-        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, tv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p0 + px < p.pixels) {
-          xv = *reinterpret_cast<const f32x4*>(x + (p0 + px) * C + 4 * cg);
-          tv = *reinterpret_cast<const f32x4*>(tsrc + (p0 + px) * C + 4 * cg);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float f = xv[e];
-          if (p.rectify) f = fmaxf(f, 0.f);
-          xv[e] = p.alpha2 ? f * f : fabsf(f);
-        }
-        *reinterpret_cast<f32x4*>(us + px * C + 4 * cg) = xv;
-        *reinterpret_cast<f32x4*>(ts + px * C + 4 * cg) = tv;
+    for (int k = 0; k < NCH; ++k) {
+      const int c = tid + 256 * k;
+      const int px = BF ? (c % PG_PIX) : (c / (C / 4));
+      const int off = BF ? 8 * (c / PG_PIX) : 4 * (c % (C / 4));
+      xq[k] = u32x4{0, 0, 0, 0};
+      tq[k] = u32x4{0, 0, 0, 0};
+      if (p0 + px < p.pixels) {
+        xq[k] = *reinterpret_cast<const u32x4*>(x + (p0 + px) * C + off);
+        tq[k] = *reinterpret_cast<const u32x4*>(tsrc + (p0 + px) * C + off);
       }
     }
+  };
+  const bool plain = !p.rectify && !p.alpha2;
+  const float relu_floor = p.rectify ? 0.f : -__builtin_inff();
+  const float a2 = p.alpha2 ? 1.f : 0.f;
+  auto stage_to_lds = [&]() {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = tid + 256 * k;
+      if (BF) {
+        const int px = c % PG_PIX, cg = c / PG_PIX;
+        u32x4 uv = xq[k];
+        if (plain) {
+          uv &= 0x7FFF7FFFu;
+        } else {
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) {
+            const float lo = fmaxf(bf16_bits_to_float(uv[w2] & 0xFFFFu), relu_floor);
+            const float hi = fmaxf(__uint_as_float(uv[w2] & 0xFFFF0000u), relu_floor);
+            uv[w2] = pack_bf16(gdn_u(lo, a2), gdn_u(hi, a2));
+          }
+        }
+        // Pixel pairs: the even lane of a pair ends up with channels 0..3 of both pixels, the odd
+        // lane with channels 4..7, each as (even pixel | odd pixel << 16) words: four 4-byte LDS
+        // writes per tensor instead of eight 2-byte ones.
+        const bool odd = px & 1;
+        auto pair_store = [&](const u32x4& v, unsigned short* base) {
+          const unsigned int send0 = odd ? v[0] : v[2], send1 = odd ? v[1] : v[3];
+          const unsigned int keep0 = odd ? v[2] : v[0], keep1 = odd ? v[3] : v[1];
+          unsigned int recv0 = __builtin_amdgcn_update_dpp(0u, send0, 0xB1, 0xF, 0xF, false);
+          unsigned int recv1 = __builtin_amdgcn_update_dpp(0u, send1, 0xB1, 0xF, 0xF, false);
+          asm volatile("" : "+v"(recv0), "+v"(recv1));
+          const unsigned int e0 = odd ? recv0 : keep0, o0 = odd ? keep0 : recv0;
+          const unsigned int e1 = odd ? recv1 : keep1, o1 = odd ? keep1 : recv1;
+          unsigned int* dst = reinterpret_cast<unsigned int*>(base + (8 * cg + (odd ? 4 : 0)) * PG_STRIDE + (px & ~1));
+          dst[0 * PG_STRIDE / 2] = __builtin_amdgcn_perm(o0, e0, 0x05040100u);
+          dst[1 * PG_STRIDE / 2] = __builtin_amdgcn_perm(o0, e0, 0x07060302u);
+          dst[2 * PG_STRIDE / 2] = __builtin_amdgcn_perm(o1, e1, 0x05040100u);
+          dst[3 * PG_STRIDE / 2] = __builtin_amdgcn_perm(o1, e1, 0x07060302u);
+        };
+        pair_store(uv, uT);
+        pair_store(tq[k], tT);
+      } else {
+        const int px = c / (C / 4), cg = c % (C / 4);
+        f32x4 xv = __builtin_bit_cast(f32x4, xq[k]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = plain ? fabsf(xv[e]) : gdn_u(fmaxf(xv[e], relu_floor), a2);
+        *reinterpret_cast<f32x4*>(us + px * C + 4 * cg) = xv;
+        *reinterpret_cast<u32x4*>(ts + px * C + 4 * cg) = tq[k];
+      }
+    }
+  };
+
+  const long long stages = (p.pixels + PG_PIX - 1) / PG_PIX;
+  if (blockIdx.x < stages) fetch(blockIdx.x);
+  for (long long st = blockIdx.x; st < stages; st += gridDim.x) {
+    __syncthreads();          // the previous stage's fragment reads are done
+    stage_to_lds();
     __syncthreads();
+    if (st + gridDim.x < stages) fetch(st + gridDim.x);
     // dbeta: thread c sums column c of the staged T tile
     if (tid < C) {
       if (BF) {
