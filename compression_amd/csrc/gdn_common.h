@@ -162,6 +162,20 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
   const unsigned short* x = static_cast<const unsigned short*>(p.x);
   unsigned short* y = static_cast<unsigned short*>(p.y);
 
+  // Forward, C <= 192: the next tile's x is fetched into spare registers while this tile is
+  // contracted (+4 % on C3).  Measured alternatives that did NOT pay (profiles/r01_e_gdn_notes.md):
+  // double-buffered A fragments, and fully coalesced tile I/O staged through LDS (a plain copy
+  // gains 20 % from coalescing, but the LDS round trips cost more than that here).
+  constexpr bool PREFETCH = MODE == MODE_FWD && (KT <= 5 || (PLAIN && KT == 6));
+  u32x4 xn[PREFETCH ? KS : 1];
+  auto fetch = [&](long long tile) {
+    const long long pix = tile * 32 + (lane & 31);
+    const long long row = (pix < p.pixels ? pix : p.pixels - 1) * C;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xn[PREFETCH ? s : 0] = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
+  };
+  if (PREFETCH && wave < p.tiles) fetch(wave);
+
   for (long long tile = wave; tile < p.tiles; tile += nwaves) {
     const long long pix = tile * 32 + (lane & 31);
     const bool live = pix < p.pixels;
@@ -174,11 +188,12 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
       // the inner halves between lanes l and l+32 so that the lane ends up with channels
       // 16s + 4h + {0..3} and 16s + 4h + 8 + {0..3} — twice the bytes per cache line touched
       // by one load instruction compared with two 8-byte loads.
-      const u32x4 v = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
+      const u32x4 v = PREFETCH ? xn[PREFETCH ? s : 0] : *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
       const auto s0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
       const auto s1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
       xr[s] = u32x4{s0[0], s1[0], s0[1], s1[1]};
     }
+    if (PREFETCH && tile + nwaves < p.tiles) fetch(tile + nwaves);
     f32x16 acc[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
