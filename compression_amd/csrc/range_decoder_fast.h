@@ -30,11 +30,26 @@ namespace tfc {
 //   w: escape symbol index (nsym - 1) if the row has negative precision, else -1
 struct DecRow { int x, y, z, w; };
 
+// span - 1 is kept unnormalised-aware: after a renormalisation span = (t + 1) << 16 exactly, so
+// the next bound (span * hi) >> 16 is just t * hi + hi with NO shift.  Keeping t and the shift
+// amount (instead of the shifted value) takes the compare + select that would build
+// (t << 16) | 0xFFFF out of the per-symbol dependency chain: the multiply starts from t as soon
+// as it is read from the winning lane, and the shift amount (decided by one scalar bit test)
+// is only needed after the multiply.
 struct FastDecState {   // wave-uniform
   unsigned int D;       // window - base
-  unsigned int s;       // span - 1
+  unsigned int t;       // span - 1 = sh ? t : (t << 16) | 0xFFFF
+  unsigned int sh;      // 16: t is span - 1 itself; 0: the span was just renormalised
   unsigned int pos;     // digits consumed since the window register was loaded
 };
+
+__device__ inline unsigned int span_minus1(const FastDecState& st) {
+  return st.sh ? st.t : ((st.t << 16) | 0xFFFFu);
+}
+__device__ inline void set_span_minus1(FastDecState& st, unsigned int s) {
+  st.t = s;
+  st.sh = 16u;
+}
 
 struct DecWindow {
   const uint8_t* src;
@@ -74,77 +89,303 @@ __device__ inline void fast_window_advance(DecWindow& w, unsigned int shift, int
   w.next = fresh;
 }
 
-// One candidate-per-lane selection step.  hi = upper bound held by this lane,
-// a0 = lower offset of lane 0's candidate (0 for a whole narrow row).
-// Returns the winning lane; updates the state.
-// (span * hi) >> 16 with span = s + 1, as ONE v_mad_u64_u32 (s * hi + hi) + v_alignbit.  The
-// addend is made opaque so that LLVM does not refactor it into (s + 1) * hi, which needs a
-// 33-bit multiplicand and two multiplies.
-__device__ inline unsigned int scale_bound(unsigned int s, unsigned int hi) {
+// ---- candidate-per-lane selection --------------------------------------------------------
+// One wave per SIMD.  Measured on MI355X (tools/ubench/dec_step.hip, profiles/r01_f_dec_step.txt):
+//   * every instruction occupies ~4.1 cycles of the wave whatever its type, s_nop wait states
+//     included, so the chain is written for instruction COUNT;
+//   * an SALU instruction reading an SGPR that a VALU instruction wrote (v_cmp mask, v_readlane)
+//     costs +16 cycles that other VALU work cannot hide, and v_readlane whose LANE SELECT was
+//     written by SALU costs +20.  The textbook "ballot, s_ff1, v_readlane" selection pays both.
+// Hence: the first candidate that contains the offset is found through EXEC — v_cmpx makes the
+// hit lanes the active ones, v_readfirstlane reads the winner's successor state (and its lane
+// id), one s_mov restores EXEC — and NOTHING coming out of it is ever touched by SALU
+// arithmetic: the digit position, the renormalisation shift and the fine-stage table address
+// are all carried per lane and read the same way.
+//   * B = (span * hi) >> 16 with span = s + 1, as ONE v_mad_u64_u32 (s * hi + hi) + v_alignbit.
+//     The addend is made opaque so that LLVM does not refactor it into (s + 1) * hi, which
+//     needs a 33-bit multiplicand and two multiplies.
+//   * A = B of the previous lane: v_mov_b32_dpp wave_shr:1 bound_ctrl:1 (lane 0 reads 0),
+//     written by hand — LLVM's DPP combine folds the builtin into
+//     `v_subrev_u32_dpp ... wave_shr:1 bound_ctrl:1`, which returned wrong lanes (ROCm 7.2;
+//     caught by the K3/K4/K6 vectors).  Two instructions sit between the write of B and the
+//     DPP read (the wait states it needs).
+//   * b = B - 1 is formed explicitly: for s = 2^32 - 1 and hi = 2^16 the bound B = 2^32 wraps
+//     to 0, and only D <= B - 1 / span' - 1 = (B - 1) - A survive that (K3 pins this).
+// The semantics of the hand-written instructions are checked on the device by
+// tools/ubench/asm_semantics.hip.
+__device__ inline unsigned long long scale_product(unsigned int s, unsigned int hi) {
   unsigned int add = hi;
   asm volatile("" : "+v"(add));
-  const unsigned long long P = static_cast<unsigned long long>(s) * hi + add;
-  return static_cast<unsigned int>(P >> 16);
+  return static_cast<unsigned long long>(s) * hi + add;
 }
 
-__device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned int a0,
-                                  unsigned int dig) {
-  const unsigned int Bq = scale_bound(st.s, hi);
-  const unsigned long long PB = static_cast<unsigned long long>(Bq) << 16;
-  const unsigned int B = static_cast<unsigned int>(PB >> 16);
-  unsigned int A = static_cast<unsigned int>(
-      __builtin_amdgcn_update_dpp(static_cast<int>(a0), static_cast<int>(B), 0x138, 0xF, 0xF, false));
-  // Keep the wave_shr move a separate v_mov_b32_dpp: when a0 is the constant 0, LLVM's DPP
-  // combine folds it into the consumers as `v_subrev_u32_dpp ... wave_shr:1 bound_ctrl:1`,
-  // which returned wrong lanes on gfx950 (ROCm 7.2) — caught by the K3/K4/K6 vectors.
-  asm volatile("" : "+v"(A));
-  const unsigned int b = B - 1u;
-  const unsigned int t1 = b - A;
-  const unsigned int Dn = st.D - A;
-  const bool ren = t1 < 65536u;
-  const unsigned int s2 = ren ? ((t1 << 16) | 0xFFFFu) : t1;
+struct Bounds { unsigned int b, A, t1, posv; };   // per lane; posv = digit position, broadcast
+
+// a0 = lower offset of lane 0's candidate (0 when ZERO_A0: a whole row).
+template <bool ZERO_A0>
+__device__ inline Bounds bounds_step(const FastDecState& st, unsigned int hi, unsigned int a0) {
+  const unsigned long long P = scale_product(st.t, hi);
+  const unsigned int plo = static_cast<unsigned int>(P), phi = static_cast<unsigned int>(P >> 32);
+  Bounds o;
+  unsigned int B;
+  if (ZERO_A0) {
+    asm("v_alignbit_b32 %0, %5, %6, %8\n\t"
+        "v_add_u32 %1, -1, %0\n\t"
+        "v_mov_b32 %4, %7\n\t"
+        "v_mov_b32_dpp %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_sub_u32 %3, %1, %2"
+        : "=&v"(B), "=&v"(o.b), "=&v"(o.A), "=&v"(o.t1), "=&v"(o.posv)
+        : "v"(phi), "v"(plo), "s"(st.pos), "s"(st.sh));
+  } else {
+    asm("v_alignbit_b32 %0, %5, %6, %8\n\t"
+        "v_add_u32 %1, -1, %0\n\t"
+        "v_mov_b32 %4, %7\n\t"
+        "v_mov_b32 %2, %9\n\t"
+        "v_mov_b32_dpp %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_sub_u32 %3, %1, %2"
+        : "=&v"(B), "=&v"(o.b), "=&v"(o.A), "=&v"(o.t1), "=&v"(o.posv)
+        : "v"(phi), "v"(plo), "s"(st.pos), "s"(st.sh), "s"(a0));
+  }
+  return o;
+}
+
+// Digit at the current position (lane select = pos mod 64 in hardware; written by
+// v_readfirstlane at least five instructions earlier, see select_step).
+__device__ inline unsigned int window_digit(const DecWindow& w, const FastDecState& st) {
+  unsigned int dig;
+  asm("v_readlane_b32 %0, %1, %2" : "=s"(dig) : "v"(w.reg), "s"(st.pos));
+  return dig;
+}
+
+// Moves the state to the first candidate containing the offset and returns `tag` of that lane
+// (its symbol).  No candidate (damaged input only): EXEC is empty and lane 0 is read.
+template <bool ZERO_A0>
+__device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned int a0, unsigned int dig,
+                                  int tag) {
+  const Bounds o = bounds_step<ZERO_A0>(st, hi, a0);
+  const unsigned int Dn = st.D - o.A;
+  const bool ren = o.t1 < 65536u;
   const unsigned int D2 = ren ? ((Dn << 16) | dig) : Dn;
-  const unsigned long long renmask = __ballot(ren);
-  const unsigned long long hit = __ballot(st.D <= b) | (1ull << 63);   // damaged input: take lane 63
-  const int L = __builtin_ctzll(hit);
-  st.s = __builtin_amdgcn_readlane(static_cast<int>(s2), L);
-  st.D = __builtin_amdgcn_readlane(static_cast<int>(D2), L);
-  st.pos += static_cast<unsigned int>((renmask >> L) & 1ull);
+  const unsigned int P2 = o.posv + (ren ? 1u : 0u);
+  const unsigned int SH = ren ? 0u : 16u;
+  int L;
+  // Output order = safety margin for "VALU writes SGPR -> use" wait states, which the compiler
+  // cannot see inside asm: pos (v_readlane lane select: 4) first, t and D (plain operands: 2) last.
+  asm volatile("v_cmpx_le_u32 vcc, %5, %6\n\t"
+               "s_nop 4\n\t"      // wait states before v_readfirstlane sees the new EXEC (see below)
+               "v_readfirstlane_b32 %0, %7\n\t"
+               "v_readfirstlane_b32 %1, %8\n\t"
+               "v_readfirstlane_b32 %2, %9\n\t"
+               "v_readfirstlane_b32 %3, %10\n\t"
+               "v_readfirstlane_b32 %4, %11\n\t"
+               "s_mov_b64 exec, -1"
+               : "=&s"(st.pos), "=&s"(L), "=&s"(st.sh), "=&s"(st.t), "=&s"(st.D)
+               : "s"(st.D), "v"(o.b), "v"(P2), "v"(tag), "v"(SH), "v"(o.t1), "v"(D2)
+               : "vcc");
   return L;
 }
 
-// Coarse step over pivots: finds the chunk, no state update.  Returns chunk
-// index and the chunk's lower offset (B of the previous pivot, 0 for chunk 0).
-__device__ inline int pivot_step(const FastDecState& st, unsigned int pivot, unsigned int* a0) {
-  const unsigned int B = scale_bound(st.s, pivot);
-  const unsigned long long hit = __ballot(st.D <= B - 1u) | (1ull << 63);
-  const int L = __builtin_ctzll(hit);
-  // lower offset of chunk L = B of the previous pivot (0 for chunk 0): shift B down one lane
-  // first, then one readlane — no branch on L == 0.
-  unsigned int prev = static_cast<unsigned int>(
-      __builtin_amdgcn_update_dpp(0, static_cast<int>(B), 0x138, 0xF, 0xF, false));
-  asm volatile("" : "+v"(prev));
-  *a0 = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(prev), L));
-  return L;
+// ---- the narrow-row step, hand-scheduled -----------------------------------------------
+// 27 instruction slots per symbol.  The distances the hardware needs — 2 slots between a VALU
+// write of an SGPR and its use as an operand, 4 before its use as a v_readlane lane select, 2
+// before a DPP read of a fresh VGPR — are covered by useful instructions.  Between v_cmpx and
+// the first v_readfirstlane that must see the new EXEC the hardware does NOT interlock:
+// 3 slots pass tools/ubench/cmpx_hazard.hip, but the decoder itself needed 4 (found with the
+// K4/K6 vectors), so 5 are kept: the read of the row two symbols ahead, the output write of the
+// PREVIOUS symbol, the LDS wait (all ignore EXEC) and one s_nop 1.  Temporaries are fixed registers (v40-v55) so that
+// the upper bounds can be double-buffered in two 64-bit pairs whose high halves stay zero — the
+// v_mad_u64_u32 addend — without a copy; a run of steps is therefore ONE asm statement.
+//   v[40:41] / v[42:43]  current / next row's upper bounds (alternating), high halves 0
+//   v[44:45] product   v46 B   v47 b   v48 A   v49 t1   v50 pos   v51 Dn, D2   v52 tmp
+//   v53 pos'   v54 shift'   v55 LDS address
+// N2 = (symbol index + 2) & 63, CUR/NXT = 40/42 or 42/40, OUTPREV = the deferred output write.
+#define TFC_DEC_STEP(N2, CUR, NXT, OUTPREV)                                                   \
+  "v_lshl_add_u32 v55, %[sx], 2, %[lane4]\n\t"                                                \
+  "ds_read_b32 v" #NXT ", v55\n\t"                                                            \
+  "v_readlane_b32 %[dig], %[wreg], %[pos]\n\t"                                                \
+  "v_mad_u64_u32 v[44:45], vcc, v" #CUR ", %[t], v[" #CUR ":" TFC_STR(TFC_INC(CUR)) "]\n\t"    \
+  "v_alignbit_b32 v46, v45, v44, %[sh]\n\t"                                                   \
+  "v_add_u32 v47, -1, v46\n\t"                                                                \
+  "v_mov_b32 v50, %[pos]\n\t"                                                                 \
+  "v_mov_b32_dpp v48, v46 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+  "v_sub_u32 v49, v47, v48\n\t"                                                               \
+  "v_sub_u32 v51, %[D], v48\n\t"                                                              \
+  "v_cmp_gt_u32 vcc, %[k64], v49\n\t"                                                         \
+  "v_lshl_or_b32 v52, v51, 16, %[dig]\n\t"                                                    \
+  "v_cndmask_b32 v51, v51, v52, vcc\n\t"                                                      \
+  "v_cndmask_b32 v54, %[c16], %[zero], vcc\n\t"                                                 \
+  "v_addc_co_u32 v53, vcc, 0, v50, vcc\n\t"                                                   \
+  "v_cmpx_le_u32 vcc, %[D], v47\n\t"                                                          \
+  "v_readlane_b32 %[sx], %[rowx], " #N2 "\n\t"                                                \
+  OUTPREV                                                                                     \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+  "s_nop 1\n\t"                                                                               \
+  "v_readfirstlane_b32 %[pos], v53\n\t"                                                       \
+  "v_readfirstlane_b32 %[L], %[lanev]\n\t"                                                    \
+  "v_readfirstlane_b32 %[sh], v54\n\t"                                                        \
+  "v_readfirstlane_b32 %[t], v49\n\t"                                                         \
+  "v_readfirstlane_b32 %[D], v51\n\t"                                                         \
+  "s_mov_b64 exec, -1\n\t"
+#define TFC_STR2(x) #x
+#define TFC_STR(x) TFC_STR2(x)
+#define TFC_INC(x) TFC_INC_##x
+#define TFC_INC_40 41
+#define TFC_INC_42 43
+#define TFC_OUT(N) "v_writelane_b32 %[out], %[L], " #N "\n\t"
+#define TFC_NOOUT "s_nop 0\n\t"
+// eight steps for symbols a..h (i, j = the two after); FIRST = output filler of the first step
+#define TFC_DEC_STEP8(FIRST, a, b, c, d, e, f, g, h, i, j)                                     \
+  TFC_DEC_STEP(c, 40, 42, FIRST) TFC_DEC_STEP(d, 42, 40, TFC_OUT(a))                           \
+  TFC_DEC_STEP(e, 40, 42, TFC_OUT(b)) TFC_DEC_STEP(f, 42, 40, TFC_OUT(c))                      \
+  TFC_DEC_STEP(g, 40, 42, TFC_OUT(d)) TFC_DEC_STEP(h, 42, 40, TFC_OUT(e))                      \
+  TFC_DEC_STEP(i, 40, 42, TFC_OUT(f)) TFC_DEC_STEP(j, 42, 40, TFC_OUT(g))
+#define TFC_DEC_STEP64 \
+  TFC_DEC_STEP8(TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9) \
+  TFC_DEC_STEP8(TFC_OUT(7), 8, 9, 10, 11, 12, 13, 14, 15, 16, 17) \
+  TFC_DEC_STEP8(TFC_OUT(15), 16, 17, 18, 19, 20, 21, 22, 23, 24, 25) \
+  TFC_DEC_STEP8(TFC_OUT(23), 24, 25, 26, 27, 28, 29, 30, 31, 32, 33) \
+  TFC_DEC_STEP8(TFC_OUT(31), 32, 33, 34, 35, 36, 37, 38, 39, 40, 41) \
+  TFC_DEC_STEP8(TFC_OUT(39), 40, 41, 42, 43, 44, 45, 46, 47, 48, 49) \
+  TFC_DEC_STEP8(TFC_OUT(47), 48, 49, 50, 51, 52, 53, 54, 55, 56, 57) \
+  TFC_DEC_STEP8(TFC_OUT(55), 56, 57, 58, 59, 60, 61, 62, 63, 0, 1)
+// ---- the two-stage step (a batch that contains rows wider than 64 symbols) ---------------
+// Stage 1 over the row's 64 pivots finds the chunk: its lower offset (B of the previous pivot)
+// and its first symbol c0 = lane * chunk are read through EXEC; stage 2 is the narrow step on
+// the chunk's entries tab[first + c0 + lane], whose LDS read is the one dependent load of the
+// step (~60 cycles, partly covered).  v56 c0 candidates, v57/v58 LDS addresses, v[60:61] stage-2
+// bounds (high half 0), v62 symbol of each stage-2 lane.  N = symbol index.
+#define TFC_DEC_WSTEP(N, N2, CUR, NXT, OUTPREV)                                               \
+  "v_lshl_add_u32 v55, %[sx], 2, %[lane4]\n\t"                                                \
+  "ds_read_b32 v" #NXT ", v55\n\t"                                                            \
+  "v_readlane_b32 %[dig], %[wreg], %[pos]\n\t"                                                \
+  "v_mad_u64_u32 v[44:45], vcc, v" #CUR ", %[t], v[" #CUR ":" TFC_STR(TFC_INC(CUR)) "]\n\t"    \
+  "v_readlane_b32 %[chunk], %[chunkv], " #N "\n\t"                                            \
+  "v_readlane_b32 %[first], %[firstv], " #N "\n\t"                                            \
+  "v_alignbit_b32 v46, v45, v44, %[sh]\n\t"                                                   \
+  "v_add_u32 v47, -1, v46\n\t"                                                                \
+  "v_mul_u32_u24 v56, %[chunk], %[lanev]\n\t"                                                 \
+  "v_mov_b32_dpp v48, v46 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+  "v_lshl_add_u32 v58, %[first], 2, %[lane4]\n\t"                                             \
+  "v_cmpx_le_u32 vcc, %[D], v47\n\t"                                                          \
+  "v_readlane_b32 %[sx], %[rowx], " #N2 "\n\t"                                                \
+  OUTPREV                                                                                     \
+  "s_nop 2\n\t"                                                                               \
+  "v_readfirstlane_b32 %[c0], v56\n\t"                                                        \
+  "v_readfirstlane_b32 %[a0], v48\n\t"                                                        \
+  "s_mov_b64 exec, -1\n\t"                                                                    \
+  "v_lshl_add_u32 v57, %[c0], 2, v58\n\t"                                                     \
+  "ds_read_b32 v60, v57\n\t"                                                                  \
+  "v_add_u32 v62, %[c0], %[lanev]\n\t"                                                        \
+  "v_mov_b32 v50, %[pos]\n\t"                                                                 \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+  "v_mad_u64_u32 v[44:45], vcc, v60, %[t], v[60:61]\n\t"                                      \
+  "v_alignbit_b32 v46, v45, v44, %[sh]\n\t"                                                   \
+  "v_add_u32 v47, -1, v46\n\t"                                                                \
+  "v_mov_b32 v48, %[a0]\n\t"                                                                  \
+  "v_mov_b32_dpp v48, v46 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                          \
+  "v_sub_u32 v49, v47, v48\n\t"                                                               \
+  "v_sub_u32 v51, %[D], v48\n\t"                                                              \
+  "v_cmp_gt_u32 vcc, %[k64], v49\n\t"                                                         \
+  "v_lshl_or_b32 v52, v51, 16, %[dig]\n\t"                                                    \
+  "v_cndmask_b32 v51, v51, v52, vcc\n\t"                                                      \
+  "v_cndmask_b32 v54, %[c16], %[zero], vcc\n\t"                                               \
+  "v_addc_co_u32 v53, vcc, 0, v50, vcc\n\t"                                                   \
+  "v_cmpx_le_u32 vcc, %[D], v47\n\t"                                                          \
+  "s_nop 4\n\t"                                                                               \
+  "v_readfirstlane_b32 %[pos], v53\n\t"                                                       \
+  "v_readfirstlane_b32 %[L], v62\n\t"                                                         \
+  "v_readfirstlane_b32 %[sh], v54\n\t"                                                        \
+  "v_readfirstlane_b32 %[t], v49\n\t"                                                         \
+  "v_readfirstlane_b32 %[D], v51\n\t"                                                         \
+  "s_mov_b64 exec, -1\n\t"
+#define TFC_DEC_WSTEP8(FIRST, a, b, c, d, e, f, g, h, i, j)                                    \
+  TFC_DEC_WSTEP(a, c, 40, 42, FIRST) TFC_DEC_WSTEP(b, d, 42, 40, TFC_OUT(a))                   \
+  TFC_DEC_WSTEP(c, e, 40, 42, TFC_OUT(b)) TFC_DEC_WSTEP(d, f, 42, 40, TFC_OUT(c))              \
+  TFC_DEC_WSTEP(e, g, 40, 42, TFC_OUT(d)) TFC_DEC_WSTEP(f, h, 42, 40, TFC_OUT(e))              \
+  TFC_DEC_WSTEP(g, i, 40, 42, TFC_OUT(f)) TFC_DEC_WSTEP(h, j, 42, 40, TFC_OUT(g))
+#define TFC_DEC_WSTEP64 \
+  TFC_DEC_WSTEP8(TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9) \
+  TFC_DEC_WSTEP8(TFC_OUT(7), 8, 9, 10, 11, 12, 13, 14, 15, 16, 17) \
+  TFC_DEC_WSTEP8(TFC_OUT(15), 16, 17, 18, 19, 20, 21, 22, 23, 24, 25) \
+  TFC_DEC_WSTEP8(TFC_OUT(23), 24, 25, 26, 27, 28, 29, 30, 31, 32, 33) \
+  TFC_DEC_WSTEP8(TFC_OUT(31), 32, 33, 34, 35, 36, 37, 38, 39, 40, 41) \
+  TFC_DEC_WSTEP8(TFC_OUT(39), 40, 41, 42, 43, 44, 45, 46, 47, 48, 49) \
+  TFC_DEC_WSTEP8(TFC_OUT(47), 48, 49, 50, 51, 52, 53, 54, 55, 56, 57) \
+  TFC_DEC_WSTEP8(TFC_OUT(55), 56, 57, 58, 59, 60, 61, 62, 63, 0, 1)
+#define TFC_DEC_WPROLOGUE(FIRSTROW) TFC_DEC_PROLOGUE(FIRSTROW) "v_mov_b32 v61, 0\n\t"
+#define TFC_DEC_WOPERANDS(P_st, P_hi, P_out, P_rowx, P_wreg, P_lane4, P_lanev, P_c0, P_c16, P_sx, P_dig, P_L, \
+                          P_chunkv, P_firstv, P_chunk, P_first, P_a0, P_cc)                               \
+  : [t] "+s"(P_st.t), [D] "+s"(P_st.D), [pos] "+s"(P_st.pos), [sh] "+s"(P_st.sh), [out] "+v"(P_out),      \
+    [hi] "+v"(P_hi), [sx] "=&s"(P_sx), [dig] "=&s"(P_dig), [L] "=&s"(P_L), [chunk] "=&s"(P_chunk),        \
+    [first] "=&s"(P_first), [a0] "=&s"(P_a0), [c0] "=&s"(P_cc)                                            \
+  : [rowx] "v"(P_rowx), [wreg] "v"(P_wreg), [lane4] "v"(P_lane4), [lanev] "v"(P_lanev), [zero] "v"(P_c0), \
+    [c16] "v"(P_c16), [k64] "s"(65536u), [chunkv] "v"(P_chunkv), [firstv] "v"(P_firstv)                   \
+  : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",         \
+    "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v61", "v62"
+// FIRSTROW = index of the run's second symbol (its row is read ahead of the first step)
+#define TFC_DEC_PROLOGUE(FIRSTROW) \
+  "v_readlane_b32 %[sx], %[rowx], " #FIRSTROW "\n\tv_mov_b32 v40, %[hi]\n\tv_mov_b32 v41, 0\n\tv_mov_b32 v43, 0\n\t"
+#define TFC_DEC_EPILOGUE(LAST) "v_writelane_b32 %[out], %[L], " #LAST "\n\tv_mov_b32 %[hi], v40"
+#define TFC_DEC_OPERANDS(P_st, P_hi, P_out, P_rowx, P_wreg, P_lane4, P_lanev, P_c0, P_c16, P_sx, P_dig, P_L) \
+  : [t] "+s"(P_st.t), [D] "+s"(P_st.D), [pos] "+s"(P_st.pos), [sh] "+s"(P_st.sh), [out] "+v"(P_out),      \
+    [hi] "+v"(P_hi), [sx] "=&s"(P_sx), [dig] "=&s"(P_dig), [L] "=&s"(P_L)                                 \
+  : [rowx] "v"(P_rowx), [wreg] "v"(P_wreg), [lane4] "v"(P_lane4), [lanev] "v"(P_lanev), [zero] "v"(P_c0),   \
+    [c16] "v"(P_c16), [k64] "s"(65536u)                                                                   \
+  : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",         \
+    "v51", "v52", "v53", "v54", "v55"
+
+// Coarse step over pivots: finds the chunk, no state update.  Everything the fine stage needs
+// from the chosen pivot lane is read through EXEC: the chunk's lower offset (B of the previous
+// pivot, 0 for chunk 0), and two per-lane values the caller prepared (table address of the
+// chunk's first entry, first symbol of the chunk).
+__device__ inline void pivot_step(const FastDecState& st, unsigned int pivot, int v0, int v1,
+                                  unsigned int* a0, int* r0, int* r1) {
+  const unsigned long long P = scale_product(st.t, pivot);
+  const unsigned int plo = static_cast<unsigned int>(P), phi = static_cast<unsigned int>(P >> 32);
+  unsigned int B, b, prev;
+  asm volatile("v_alignbit_b32 %0, %6, %7, %9\n\t"
+               "v_add_u32 %1, -1, %0\n\t"
+               "s_nop 0\n\t"
+               "v_mov_b32_dpp %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_cmpx_le_u32 vcc, %8, %1\n\t"
+               "s_nop 4\n\t"
+               "v_readfirstlane_b32 %3, %2\n\t"
+               "v_readfirstlane_b32 %4, %10\n\t"
+               "v_readfirstlane_b32 %5, %11\n\t"
+               "s_mov_b64 exec, -1"
+               : "=&v"(B), "=&v"(b), "=&v"(prev), "=&s"(*a0), "=&s"(*r0), "=&s"(*r1)
+               : "v"(phi), "v"(plo), "s"(st.D), "s"(st.sh), "v"(v0), "v"(v1)
+               : "vcc");
 }
 
 // Binary digit with the uniform cdf {0,1,2} at precision 1
 // (range_coder_kernels.cc:449-471 via DecodeLinearly), on the offset state.
 __device__ inline int fast_bit(FastDecState& st, const DecWindow& w) {
-  const unsigned long long span = static_cast<unsigned long long>(st.s) + 1;
+  const unsigned long long span = static_cast<unsigned long long>(span_minus1(st)) + 1;
   const unsigned long long target = (static_cast<unsigned long long>(st.D) + 1) << 1;
   const unsigned int bit = target <= span ? 0u : 1u;
   const unsigned int A = static_cast<unsigned int>((span * bit) >> 1);
   const unsigned int b = static_cast<unsigned int>(((span * (bit + 1)) >> 1) - 1);
   st.D -= A;
-  st.s = b - A;
-  if ((st.s >> 16) == 0) {
-    const unsigned int dig = __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u));
-    st.s = (st.s << 16) | 0xFFFFu;
+  unsigned int s = b - A;
+  if ((s >> 16) == 0) {
+    const unsigned int dig = window_digit(w, st);
+    s = (s << 16) | 0xFFFFu;
     st.D = (st.D << 16) | dig;
     ++st.pos;
   }
+  set_span_minus1(st, s);
   return static_cast<int>(bit);
+}
+
+// LLVM's uniformity analysis marks the results of an asm statement with read-write ("+s")
+// operands divergent; the state is re-declared uniform after each run (a handful of
+// instructions per 64 symbols).
+__device__ inline void reassert_uniform(FastDecState& st) {
+  st.t = __builtin_amdgcn_readfirstlane(st.t);
+  st.D = __builtin_amdgcn_readfirstlane(st.D);
+  st.pos = __builtin_amdgcn_readfirstlane(st.pos);
+  st.sh = __builtin_amdgcn_readfirstlane(st.sh);
 }
 
 template <typename Dst>
@@ -164,7 +405,7 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
 
   const uint4 st0 = p.state[s];
   FastDecState st;
-  st.s = __builtin_amdgcn_readfirstlane(st0.y);
+  set_span_minus1(st, __builtin_amdgcn_readfirstlane(st0.y));
   st.D = __builtin_amdgcn_readfirstlane(st0.z) - __builtin_amdgcn_readfirstlane(st0.x);
   st.pos = 0;
   DecWindow w;
@@ -200,29 +441,55 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
     if (j0 == 0) fast_window_load(w, lane); else fast_window_advance(w, st.pos, lane);
     st.pos = 0;
     int outv = 0;
+    // operands of the hand-scheduled step: LDS byte address of tab[lane], and 0 / 16 in VGPRs
+    // (opaque, so that they stay registers)
+    unsigned int lane4 = static_cast<unsigned int>(reinterpret_cast<size_t>(
+                             (__attribute__((address_space(3))) int32_t*)tab)) + 4u * lane;
+    unsigned int vzero = 0u, vsixteen = 16u;
+    asm volatile("" : "+v"(lane4), "+v"(vzero), "+v"(vsixteen));
+    // per-symbol row constants as vectors, so that the per-symbol code only READS lanes of them
+    // (no scalar arithmetic on values that came out of a vector instruction, see the header)
+    const int chunkv = row.z >> 16;        // symbols per pivot (1: narrow row)
+    const int first1v = row.y + 1;         // table index of the row's first upper bound
     // stage-1 bounds (the row itself, or its pivots) are fetched one symbol ahead
     unsigned int hi_cur = static_cast<unsigned int>(tab[__builtin_amdgcn_readlane(row.x, 0) + lane]);
 
-    // ---- checked loop: wide rows, escapes, partial batches -------------------
+    auto fetch_hi = [&](int n) {
+      return static_cast<unsigned int>(tab[__builtin_amdgcn_readlane(row.x, n & 63) + lane]);
+    };
+    // One symbol of a narrow row (<= 64 symbols): candidates = the row itself.
+    auto narrow_step = [&](int n) {
+      const unsigned int hi_next = fetch_hi(n + 1);
+      const unsigned int dig = window_digit(w, st);
+      const int sym = select_step<true>(st, hi_cur, 0u, dig, lane);
+      hi_cur = hi_next;
+      return sym;
+    };
+    // One symbol by the two-stage route: 64 pivots -> chunk -> the chunk's entries.  A narrow
+    // row goes through it as chunk size 1 (its "pivots" are the row), so a batch that contains
+    // any wide row can run one branch-free code path.
+    auto wide_step = [&](int n) {
+      const unsigned int hi_next = fetch_hi(n + 1);
+      const unsigned int dig = window_digit(w, st);
+      const int chunk = __builtin_amdgcn_readlane(chunkv, n);
+      const int first1 = __builtin_amdgcn_readlane(first1v, n);
+      const int sym0v = __mul24(lane, chunk);
+      int idxv = first1 + lane;            // + chunk start below: kept a VECTOR add on purpose
+      asm volatile("" : "+v"(idxv));
+      unsigned int a0;
+      int cstart, cstart2;
+      pivot_step(st, hi_cur, sym0v, sym0v, &a0, &cstart, &cstart2);
+      const unsigned int hi2 = static_cast<unsigned int>(tab[idxv + cstart]);
+      const int sym = select_step<false>(st, hi2, a0, dig, cstart2 + lane);
+      hi_cur = hi_next;
+      return sym;
+    };
+
+    // ---- checked loop: escapes and partial batches ----------------------------
     auto checked = [&](int n0, int n1) {
       for (int n = n0; n < n1; ++n) {
-        const unsigned int hi_next = static_cast<unsigned int>(
-            tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
-        const int z = __builtin_amdgcn_readlane(row.z, n);
         const int escsym = __builtin_amdgcn_readlane(row.w, n);
-        const unsigned int dig =
-            static_cast<unsigned int>(__builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
-        int sym;
-        const int chunk = z >> 16;
-        if (chunk <= 1) {
-          sym = select_step(st, hi_cur, 0u, dig);
-        } else {
-          unsigned int a0;
-          const int c = pivot_step(st, hi_cur, &a0);
-          const int cdf0 = __builtin_amdgcn_readlane(row.y, n);
-          const unsigned int hi2 = static_cast<unsigned int>(tab[cdf0 + c * chunk + 1 + lane]);
-          sym = c * chunk + select_step(st, hi2, a0, dig);
-        }
+        int sym = anywide ? wide_step(n) : narrow_step(n);
         if (sym == escsym) {
           // Elias-gamma escape (range_coder_kernels.cc:449-471); the unary prefix
           // is bounded so that damaged input cannot spin.
@@ -238,7 +505,6 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
           }
         }
         outv = tfc_writelane(sym, n, outv);
-        hi_cur = hi_next;
       }
     };
 
@@ -250,32 +516,21 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
       const FastDecState saved64 = st;
       const unsigned int hi_saved64 = hi_cur;
       if (!anywide) {
-#pragma unroll
-        for (int n = 0; n < 64; ++n) {
-          const unsigned int hi_next = static_cast<unsigned int>(
-              tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
-          const unsigned int dig = static_cast<unsigned int>(
-              __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
-          const int L = select_step(st, hi_cur, 0u, dig);
-          outv = tfc_writelane(L, n, outv);
-          hi_cur = hi_next;
-        }
+        unsigned int sx, dg;
+        int L;
+        reassert_uniform(st);
+        asm volatile(TFC_DEC_PROLOGUE(1) TFC_DEC_STEP64 TFC_DEC_EPILOGUE(63)
+                     TFC_DEC_OPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L));
+        reassert_uniform(st);
+        outv &= 63;   // no-op for symbols of narrow rows; keeps damaged input inside the row range
       } else {
-#pragma unroll
-        for (int n = 0; n < 64; ++n) {
-          const unsigned int hi_next = static_cast<unsigned int>(
-              tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
-          const unsigned int dig = static_cast<unsigned int>(
-              __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
-          unsigned int a0;
-          const int c = pivot_step(st, hi_cur, &a0);
-          const int chunk = __builtin_amdgcn_readlane(row.z, n) >> 16;
-          const int first = __builtin_amdgcn_readlane(row.y, n) + c * chunk;
-          const unsigned int hi2 = static_cast<unsigned int>(tab[first + 1 + lane]);
-          const int L = select_step(st, hi2, a0, dig);
-          outv = tfc_writelane(c * chunk + L, n, outv);
-          hi_cur = hi_next;
-        }
+        unsigned int sx, dg, ck, fs, a0, cc;
+        int L;
+        reassert_uniform(st);
+        asm volatile(TFC_DEC_WPROLOGUE(1) TFC_DEC_WSTEP64 TFC_DEC_EPILOGUE(63)
+                     TFC_DEC_WOPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L,
+                                       chunkv, first1v, ck, fs, a0, cc));
+        reassert_uniform(st);
       }
       if (__ballot(outv == row.w) != 0) {
         st = saved64;
@@ -285,36 +540,43 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
           const FastDecState saved = st;
           const unsigned int hi_saved = hi_cur;
           if (!anywide) {
-  #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const int n = n0 + i;
-              const unsigned int hi_next = static_cast<unsigned int>(
-                  tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
-              const unsigned int dig = static_cast<unsigned int>(
-                  __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
-              const int L = select_step(st, hi_cur, 0u, dig);
-              outv = tfc_writelane(L, n, outv);
-              hi_cur = hi_next;
+            // eight hand-scheduled steps; the block index selects the output lanes
+            unsigned int sx, dg;
+            int L;
+            reassert_uniform(st);
+            switch (blk) {
+#define TFC_BLK(B, FIRSTROW, LAST, S) case B: asm volatile(TFC_DEC_PROLOGUE(FIRSTROW) S TFC_DEC_EPILOGUE(LAST) \
+                     TFC_DEC_OPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L)); break;
+              TFC_BLK(0, 1, 7, TFC_DEC_STEP8(TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9))
+              TFC_BLK(1, 9, 15, TFC_DEC_STEP8(TFC_NOOUT, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17))
+              TFC_BLK(2, 17, 23, TFC_DEC_STEP8(TFC_NOOUT, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25))
+              TFC_BLK(3, 25, 31, TFC_DEC_STEP8(TFC_NOOUT, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33))
+              TFC_BLK(4, 33, 39, TFC_DEC_STEP8(TFC_NOOUT, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41))
+              TFC_BLK(5, 41, 47, TFC_DEC_STEP8(TFC_NOOUT, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49))
+              TFC_BLK(6, 49, 55, TFC_DEC_STEP8(TFC_NOOUT, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57))
+              TFC_BLK(7, 57, 63, TFC_DEC_STEP8(TFC_NOOUT, 56, 57, 58, 59, 60, 61, 62, 63, 0, 1))
+#undef TFC_BLK
             }
+            reassert_uniform(st);
           } else {
-            // every symbol takes the two-stage route (pivots -> chunk -> entries); for a narrow
-            // row the "pivots" are the row itself with chunk 1, so one code path serves both.
-  #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const int n = n0 + i;
-              const unsigned int hi_next = static_cast<unsigned int>(
-                  tab[__builtin_amdgcn_readlane(row.x, (n + 1) & 63) + lane]);
-              const unsigned int dig = static_cast<unsigned int>(
-                  __builtin_amdgcn_readlane(w.reg, static_cast<int>(st.pos & 63u)));
-              unsigned int a0;
-              const int c = pivot_step(st, hi_cur, &a0);
-              const int chunk = __builtin_amdgcn_readlane(row.z, n) >> 16;
-              const int first = __builtin_amdgcn_readlane(row.y, n) + c * chunk;
-              const unsigned int hi2 = static_cast<unsigned int>(tab[first + 1 + lane]);
-              const int L = select_step(st, hi2, a0, dig);
-              outv = tfc_writelane(c * chunk + L, n, outv);
-              hi_cur = hi_next;
+            unsigned int sx, dg, ck, fs, a0, cc;
+            int L;
+            reassert_uniform(st);
+            switch (blk) {
+#define TFC_WBLK(B, FIRSTROW, LAST, S) case B: asm volatile(TFC_DEC_WPROLOGUE(FIRSTROW) S TFC_DEC_EPILOGUE(LAST) \
+                     TFC_DEC_WOPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L, \
+                                       chunkv, first1v, ck, fs, a0, cc)); break;
+              TFC_WBLK(0, 1, 7, TFC_DEC_WSTEP8(TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9))
+              TFC_WBLK(1, 9, 15, TFC_DEC_WSTEP8(TFC_NOOUT, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17))
+              TFC_WBLK(2, 17, 23, TFC_DEC_WSTEP8(TFC_NOOUT, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25))
+              TFC_WBLK(3, 25, 31, TFC_DEC_WSTEP8(TFC_NOOUT, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33))
+              TFC_WBLK(4, 33, 39, TFC_DEC_WSTEP8(TFC_NOOUT, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41))
+              TFC_WBLK(5, 41, 47, TFC_DEC_WSTEP8(TFC_NOOUT, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49))
+              TFC_WBLK(6, 49, 55, TFC_DEC_WSTEP8(TFC_NOOUT, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57))
+              TFC_WBLK(7, 57, 63, TFC_DEC_WSTEP8(TFC_NOOUT, 56, 57, 58, 59, 60, 61, 62, 63, 0, 1))
+#undef TFC_WBLK
             }
+            reassert_uniform(st);
           }
           const unsigned long long hits = __ballot(outv == row.w) & (0xFFull << n0);
           if (hits != 0) {
@@ -339,7 +601,7 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
       const long long q = b + i;
       window = (window << 8) | ((q >= 0 && q < w.len) ? w.src[q] : 0u);
     }
-    p.state[s] = make_uint4(window - st.D, st.s, window, w.wbase);
+    p.state[s] = make_uint4(window - st.D, span_minus1(st), window, w.wbase);
   }
 }
 
