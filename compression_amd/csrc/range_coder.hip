@@ -1269,8 +1269,7 @@ extern "C" int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total
                      dim3(kBlock), 0, st, n, d_refs.as<ChunkRef>(), static_cast<int>(refs.size()),
                      tail.as<Tail>(), e->offsets.as<long long>(), e->blob.as<uint8_t>());
   TFC_HIP(hipGetLastError());
-  TFC_HIP(hipStreamSynchronize(st));
-  e->chunks.clear();
+  e->chunks.clear();     // stream-ordered frees: no need to wait for the pack kernel here
   e->total = total;
   e->finalized = true;
   *total_bytes = total;
@@ -1306,7 +1305,9 @@ extern "C" void tfc_encoder_destroy(tfc_encoder* e) { delete e; }
 struct tfc_decoder {
   const tfc_tables* tables = nullptr;
   int64_t streams = 0;
-  DevBuf blob, offsets, state, status;
+  DevBuf blob, offsets, state, status;     // blob / offsets: owned copies of host input only
+  const uint8_t* blob_p = nullptr;         // device bytes the kernels read (owned or borrowed)
+  const long long* off_p = nullptr;
 };
 
 extern "C" int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob,
@@ -1319,25 +1320,26 @@ extern "C" int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob,
   std::unique_ptr<tfc_decoder> d(new tfc_decoder);
   d->tables = tables;
   d->streams = streams;
-  const hipMemcpyKind k = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  int64_t total = 0;
   if (src_on_device) {
-    TFC_HIP(hipMemcpyAsync(&total, offsets + streams, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    TFC_HIP(hipStreamSynchronize(st));
+    // Borrowed, like the reference's decoder, which reads its source in place and requires the
+    // caller to keep it alive (cc/lib/range_coder.h:74-77): no copy, no size read-back, no sync.
+    d->blob_p = blob;
+    d->off_p = reinterpret_cast<const long long*>(offsets);
   } else {
-    total = offsets[streams];
+    const int64_t total = offsets[streams];
+    TFC_HIP(d->offsets.alloc(sizeof(int64_t) * (streams + 1), st));
+    TFC_HIP(hipMemcpyAsync(d->offsets.p, offsets, sizeof(int64_t) * (streams + 1), hipMemcpyHostToDevice, st));
+    TFC_HIP(d->blob.alloc(static_cast<size_t>(total), st));
+    if (total) TFC_HIP(hipMemcpyAsync(d->blob.p, blob, static_cast<size_t>(total), hipMemcpyHostToDevice, st));
+    d->blob_p = d->blob.as<uint8_t>();
+    d->off_p = d->offsets.as<long long>();
   }
-  TFC_HIP(d->offsets.alloc(sizeof(int64_t) * (streams + 1), st));
-  TFC_HIP(hipMemcpyAsync(d->offsets.p, offsets, sizeof(int64_t) * (streams + 1), k, st));
-  TFC_HIP(d->blob.alloc(static_cast<size_t>(total), st));
-  if (total) TFC_HIP(hipMemcpyAsync(d->blob.p, blob, static_cast<size_t>(total), k, st));
   TFC_HIP(d->state.alloc(sizeof(uint4) * std::max<int64_t>(streams, 1), st));
   TFC_HIP(d->status.alloc(sizeof(unsigned long long), st));
   TFC_HIP(hipMemsetAsync(d->status.p, 0xFF, sizeof(unsigned long long), st));
   if (streams)
     hipLaunchKernelGGL(dec_open_kernel, dim3(static_cast<unsigned>(ceil_div(streams, 256))),
-                       dim3(256), 0, st, d->blob.as<uint8_t>(), d->offsets.as<long long>(),
-                       streams, d->state.as<uint4>());
+                       dim3(256), 0, st, d->blob_p, d->off_p, streams, d->state.as<uint4>());
   if (!src_on_device) TFC_HIP(hipStreamSynchronize(st));  // host buffers may go away
   *out = d.release();
   return 0;
@@ -1357,8 +1359,8 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   p.index = index;
   p.streams = d->streams;
   p.elems = elems;
-  p.blob = d->blob.as<uint8_t>();
-  p.off = d->offsets.as<long long>();
+  p.blob = d->blob_p;
+  p.off = d->off_p;
   p.state = d->state.as<uint4>();
   p.first_error = d->status.as<unsigned long long>();
   const size_t lds = table_lds_bytes(t);
@@ -1420,7 +1422,7 @@ extern "C" int tfc_decoder_finalize(tfc_decoder* d, uint8_t* ok, void* stream) {
   TFC_HIP(d_ok.alloc(std::max<int64_t>(n, 1), st));
   if (n)
     hipLaunchKernelGGL(dec_close_kernel, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256),
-                       0, st, d->state.as<uint4>(), d->offsets.as<long long>(), n,
+                       0, st, d->state.as<uint4>(), d->off_p, n,
                        d_ok.as<uint8_t>());
   TFC_HIP(hipMemcpyAsync(&first_error, d->status.p, sizeof(first_error), hipMemcpyDeviceToHost, st));
   if (n) TFC_HIP(hipMemcpyAsync(ok, d_ok.p, n, hipMemcpyDeviceToHost, st));

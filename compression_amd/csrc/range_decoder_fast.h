@@ -59,11 +59,16 @@ struct DecWindow {
   int next;             // digits wbase + 64 .. wbase + 127, fetched one batch ahead
 };
 
+// Branch-free on purpose: with `b < len ? src[b] : 0` the compiler puts each byte load in its own
+// block and waits for it at the join, which exposed two full HBM latencies per 64-symbol batch.
+// Addresses are clamped into the stream instead and the value is masked afterwards, so the loads
+// are issued back to back and nobody waits for them until the digits are used a batch later.
 __device__ inline int fast_window_fetch(const DecWindow& w, unsigned int first, int lane) {
   const long long b = 2ll * (static_cast<long long>(first) + lane);
-  const unsigned int hi = b < w.len ? w.src[b] : 0u;
-  const unsigned int lo = b + 1 < w.len ? w.src[b + 1] : 0u;
-  return static_cast<int>((hi << 8) | lo);
+  const long long last = w.len - 1;                       // w.src is readable on [0, max(len, 1))
+  const unsigned int hi = w.src[b < last ? b : (last < 0 ? 0 : last)];
+  const unsigned int lo = w.src[b + 1 < last ? b + 1 : (last < 0 ? 0 : last)];
+  return static_cast<int>(((b < w.len ? hi : 0u) << 8) | (b + 1 < w.len ? lo : 0u));
 }
 
 // Synchronous (re)load of both registers at wbase.
@@ -320,7 +325,7 @@ __device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned in
     [first] "=&s"(P_first), [a0] "=&s"(P_a0), [c0] "=&s"(P_cc)                                            \
   : [rowx] "v"(P_rowx), [wreg] "v"(P_wreg), [lane4] "v"(P_lane4), [lanev] "v"(P_lanev), [zero] "v"(P_c0), \
     [c16] "v"(P_c16), [k64] "s"(65536u), [chunkv] "v"(P_chunkv), [firstv] "v"(P_firstv)                   \
-  : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",         \
+  : "vcc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",         \
     "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v61", "v62"
 // FIRSTROW = index of the run's second symbol (its row is read ahead of the first step)
 #define TFC_DEC_PROLOGUE(FIRSTROW) \
@@ -331,7 +336,7 @@ __device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned in
     [hi] "+v"(P_hi), [sx] "=&s"(P_sx), [dig] "=&s"(P_dig), [L] "=&s"(P_L)                                 \
   : [rowx] "v"(P_rowx), [wreg] "v"(P_wreg), [lane4] "v"(P_lane4), [lanev] "v"(P_lanev), [zero] "v"(P_c0),   \
     [c16] "v"(P_c16), [k64] "s"(65536u)                                                                   \
-  : "vcc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",         \
+  : "vcc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",         \
     "v51", "v52", "v53", "v54", "v55"
 
 // Coarse step over pivots: finds the chunk, no state update.  Everything the fine stage needs
@@ -410,8 +415,9 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
   st.pos = 0;
   DecWindow w;
   const long long o0 = p.off[s];
-  w.src = p.blob + o0;
   w.len = p.off[s + 1] - o0;
+  // an empty stream reads (and discards) one byte of the offsets array instead of blob[o0]
+  w.src = w.len > 0 ? p.blob + o0 : reinterpret_cast<const uint8_t*>(p.off);
   w.wbase = __builtin_amdgcn_readfirstlane(st0.w);
   const int ntab = p.tab.ntab;
   int ch0 = 0;

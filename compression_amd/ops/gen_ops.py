@@ -237,6 +237,9 @@ def create_range_decoder(encoded, lookup) -> DecoderHandle:
         offsets = offsets.to(device, torch.int64).contiguous()
         _lib.check(_lib.lib().tfc_decoder_create(tables.ptr, blob.data_ptr(), offsets.data_ptr(),
                                                 streams, 1, _lib.stream_ptr(), C.byref(out)))
+        handle = DecoderHandle(shape, tables, device, out)
+        handle._keep += [blob, offsets]     # the decoder reads them in place (borrowed)
+        return handle
     else:
         blob, off, shape = blob_from_strings(encoded)
         streams = len(off) - 1

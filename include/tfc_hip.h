@@ -119,8 +119,11 @@ void tfc_encoder_destroy(tfc_encoder* e);
 /* CreateRangeDecoder — cc/ops/range_coder_ops.cc:137-153,
  * cc/kernels/range_coder_kernels.cc:597-619.  blob/offsets describe `streams`
  * byte strings (offsets int64 [streams+1]); src_on_device says where they
- * live.  The decoder keeps its own device copy (the reference ref-holds the
- * tensor instead, range_coder_kernels.cc:475-478). */
+ * live.  Host input is copied to the device.  Device input is BORROWED: like
+ * the reference, which ref-holds the tensor and reads it in place
+ * (range_coder_kernels.cc:475-478; "caller must make sure `source` outlives",
+ * cc/lib/range_coder.h:74-77), the buffers must stay valid and unchanged until
+ * the decoder is destroyed. */
 int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob, const int64_t* offsets,
                        int64_t streams, int src_on_device, void* stream, tfc_decoder** out);
 
