@@ -26,6 +26,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,7 @@ struct ProfileEntry {
   int64_t launches = 0;
 };
 bool g_profile_on = false;
+std::mutex g_profile_mutex;      // encoders / decoders may run on several host threads
 std::vector<ProfileEntry>& profile_table() {
   static std::vector<ProfileEntry> t;
   return t;
@@ -83,6 +85,7 @@ KernelTimer::KernelTimer(const char* n, hipStream_t s) : name(n), st(s), on(g_pr
 KernelTimer::~KernelTimer() {
   if (!on) return;
   (void)hipEventRecord(b, st);
+  std::lock_guard<std::mutex> lock(g_profile_mutex);
   profile_entry(name).pending.emplace_back(a, b);
 }
 
@@ -91,6 +94,7 @@ KernelTimer::~KernelTimer() {
 using namespace tfc;
 
 extern "C" void tfc_profile_enable(int on) {
+  std::lock_guard<std::mutex> lock(g_profile_mutex);
   g_profile_on = on != 0;
   if (on) {
     for (auto& e : profile_table()) {
@@ -103,6 +107,7 @@ extern "C" void tfc_profile_enable(int on) {
 }
 
 extern "C" int tfc_profile_query(const char* kernel, double* total_ms, int64_t* launches) {
+  std::lock_guard<std::mutex> lock(g_profile_mutex);
   ProfileEntry& e = profile_entry(kernel);
   for (auto& p : e.pending) {
     float ms = 0;
@@ -1144,7 +1149,7 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
     if (!(force && force[0] == '1') && !tables->rows.empty() && fixed + ring <= 160 * 1024) {
       e->fast = true;
       const size_t fit = (160 * 1024 - fixed) / ring;
-      const size_t want = static_cast<size_t>(std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(streams, 256))));
+      const size_t want = static_cast<size_t>(std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(streams, 128))));
       e->fast_waves = static_cast<int>(std::min(fit, want));
       e->fast_lds = fixed + ring * e->fast_waves;
     }
@@ -1369,7 +1374,7 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   const char* force = std::getenv("TFC_FORCE_GENERIC");
   if (t->dec_fast_ok && fast_lds <= 160 * 1024 && !(force && force[0] == '1')) {
     KernelTimer timer("dec_kernel", st);
-    const int waves = static_cast<int>(std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(d->streams, 256))));
+    const int waves = static_cast<int>(std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(d->streams, 128))));
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(fast_lds)));
