@@ -1047,6 +1047,18 @@ TableView view_of(const tfc_tables* t) {
   return v;
 }
 
+// Waves (= code streams) that share one LDS copy of the tables.  4 keeps a lone 512-stream
+// launch at one wave per SIMD; TFC_WAVES_PER_BLOCK=8 trades that for twice the resident waves
+// when many launches are in flight (LDS, not registers, limits residency: ~70 KB per block).
+inline int64_t waves_per_block_limit() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("TFC_WAVES_PER_BLOCK");
+    const long n = e ? std::strtol(e, nullptr, 10) : 4;
+    return static_cast<int64_t>(n >= 1 && n <= 16 ? n : 4);
+  }();
+  return v;
+}
+
 template <typename Src>
 int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& src,
                hipStream_t st, const std::function<int(uint64_t)>& on_error) {
@@ -1149,7 +1161,7 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
     if (!(force && force[0] == '1') && !tables->rows.empty() && fixed + ring <= 160 * 1024) {
       e->fast = true;
       const size_t fit = (160 * 1024 - fixed) / ring;
-      const size_t want = static_cast<size_t>(std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(streams, 128))));
+      const size_t want = static_cast<size_t>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(streams, 64))));
       e->fast_waves = static_cast<int>(std::min(fit, want));
       e->fast_lds = fixed + ring * e->fast_waves;
     }
@@ -1374,7 +1386,7 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   const char* force = std::getenv("TFC_FORCE_GENERIC");
   if (t->dec_fast_ok && fast_lds <= 160 * 1024 && !(force && force[0] == '1')) {
     KernelTimer timer("dec_kernel", st);
-    const int waves = static_cast<int>(std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(d->streams, 128))));
+    const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(d->streams, 64))));
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(fast_lds)));
