@@ -225,3 +225,44 @@ def test_c2_full_size_roundtrip(tfc, port):
     assert (d == v).all() and ok.all()
     bits = 8 * sum(len(s) for s in got)
     assert bits > 0
+
+
+def test_steps_in_flight_on_separate_streams():
+    """Independent handles driven from several host threads / HIP streams at once (what
+    bench.py --inflight does) give byte-identical streams and exact round trips."""
+    from concurrent.futures import ThreadPoolExecutor
+    import compression_amd as tfc
+    from compression_amd import synthetic
+    from oracle import oracle
+    port = oracle.port()
+    pmfs, _ = synthetic.gaussian_pmfs(num_tables=24, octave=4.0)
+    cdfs = [port.pmf_to_quantized_cdf(p, 12) for p in pmfs]
+    lookup = synthetic.assemble_lookup(cdfs, 12, overflow=True)
+    values = [synthetic.sample_symbols(lookup, 64, 3000, seed=k, escape_fraction=0.01) for k in range(4)]
+    lt = torch.from_numpy(lookup)
+    tfc.create_range_encoder([1], lt)          # tables uploaded once, before the threads start
+
+    def step(k):
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream()
+        out = []
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                vt = torch.from_numpy(values[k]).cuda()
+                h = tfc.create_range_encoder([64], lt)
+                h = tfc.entropy_encode_channel(h, vt)
+                blob, offs = tfc.gen_ops._finalize_device(h)
+                d = tfc.create_range_decoder((blob, offs, (64,)), lt)
+                d, dec = tfc.entropy_decode_channel(d, [3000], torch.int32)
+                ok = tfc.entropy_decode_finalize(d)
+                out.append((blob.cpu().numpy().tobytes(), dec.cpu().numpy(), bool(ok.all())))
+            stream.synchronize()
+        return out
+
+    with ThreadPoolExecutor(4) as pool:
+        results = list(pool.map(step, range(4)))
+    for k, runs in enumerate(results):
+        want, _, _ = port.encode(lookup, values[k], threads=2)
+        for blob, dec, ok in runs:
+            assert ok and (dec == values[k]).all()
+            assert blob == b"".join(want)
