@@ -13,6 +13,7 @@ from .ops.round_ops import round_st  # noqa: F401
 from .distributions import *  # noqa: F401,F403
 from .entropy_models import *  # noqa: F401,F403
 from .layers import *  # noqa: F401,F403
+from .util import PackedTensors  # noqa: F401
 
 __version__ = "0.1.0"
 from . import models  # noqa: F401,E402

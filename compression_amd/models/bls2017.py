@@ -42,6 +42,9 @@ class SynthesisTransform(torch.nn.Module):
 
 
 class BLS2017Model(torch.nn.Module):
+    # layout of the .tfci container: [string, x_shape, y_shape] (bls2017.py:164-176, 280-283)
+    num_strings, num_packed = 1, 3
+
     def __init__(self, lmbda=0.01, num_filters=128, compute_dtype=torch.float32):
         super().__init__()
         self.lmbda = lmbda
@@ -86,3 +89,10 @@ class BLS2017Model(torch.nn.Module):
         x_hat = self.synthesis_transform(y_hat)
         x_hat = x_hat[:, :x_shape[0], :x_shape[1], :]
         return torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+
+
+if __name__ == "__main__":      # python -m compression_amd.models.bls2017 compress in.png out.tfci
+    import sys
+
+    from .codec_io import main
+    sys.exit(main(BLS2017Model))

@@ -1,0 +1,99 @@
+"""File-level compress / decompress of the two models and their command line
+(models/bls2017.py:273-323, models/bmshj2018.py:348-398): PNG in, `.tfci` out and back.
+The container is the reference's PackedTensors layout — bls2017: [string, x_shape,
+y_shape]; bmshj2018: [string, side_string, x_shape, y_shape, z_shape] — so files are
+interchangeable with ones a reference model of the same weights would write."""
+from __future__ import annotations
+
+import argparse
+
+import numpy as np
+import torch
+
+from ..util import PackedTensors
+
+__all__ = ["read_png", "write_png", "compress_file", "decompress_file", "main"]
+
+
+def read_png(filename) -> torch.Tensor:
+    """uint8 [H, W, 3] (bls2017.py:39-43)."""
+    from PIL import Image
+    with Image.open(filename) as im:
+        return torch.from_numpy(np.asarray(im.convert("RGB"), dtype=np.uint8).copy())
+
+
+def write_png(filename, image) -> None:
+    """bls2017.py:46-50."""
+    from PIL import Image
+    arr = image.detach().cpu().numpy() if isinstance(image, torch.Tensor) else np.asarray(image)
+    Image.fromarray(arr.astype(np.uint8), "RGB").save(filename, format="PNG")
+
+
+def _pack(tensors) -> PackedTensors:
+    packed = PackedTensors()
+    packed.pack([np.asarray(t, dtype=object) if isinstance(t, np.ndarray) and t.dtype == object
+                 else np.asarray(t, dtype=np.int32) for t in tensors])
+    return packed
+
+
+def compress_file(model, input_file, output_file, verbose=False):
+    """bls2017.py:273-307: one image -> .tfci; returns the container bytes."""
+    x = read_png(input_file)
+    device = next(model.parameters()).device
+    tensors = model.compress(x.to(device))
+    packed = _pack(tensors)
+    data = packed.string
+    with open(output_file, "wb") as f:
+        f.write(data)
+    if verbose:
+        x_hat = model.decompress(*tensors)[0].float().cpu()
+        mse = torch.mean((x.float() - x_hat) ** 2).item()
+        psnr = 10.0 * np.log10(255.0 ** 2 / mse) if mse > 0 else float("inf")
+        print(f"Mean squared error: {mse:0.4f}")
+        print(f"PSNR (dB): {psnr:0.2f}")
+        print(f"Bits per pixel: {len(data) * 8 / (x.shape[0] * x.shape[1]):0.4f}")
+    return data
+
+
+def decompress_file(model, input_file, output_file=None):
+    """bls2017.py:310-323: .tfci -> uint8 [H, W, 3] (and a PNG if output_file is given)."""
+    with open(input_file, "rb") as f:
+        packed = PackedTensors(f.read())
+    nstrings = model.num_strings
+    dtypes = [bytes] * nstrings + [np.int32] * (model.num_packed - nstrings)
+    tensors = packed.unpack(dtypes)
+    strings = tensors[:nstrings]
+    shapes = [tuple(int(v) for v in t) for t in tensors[nstrings:]]
+    x_hat = model.decompress(*strings, *shapes)[0]
+    if output_file is not None:
+        write_png(output_file, x_hat)
+    return x_hat
+
+
+def main(model_cls, argv=None):
+    """`python -m compression_amd.models.bls2017 compress in.png out.tfci` / `decompress in.tfci out.png`.
+    --model_path takes a torch state_dict (the reference loads a saved Keras model); without
+    it the model keeps its initialisers, which is enough to exercise the path."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model_path", default=None)
+    ap.add_argument("--num_filters", type=int, default=192)
+    ap.add_argument("--verbose", "-V", action="store_true")
+    ap.add_argument("--seed", type=int, default=0, help="initialiser seed when no --model_path is given")
+    sub = ap.add_subparsers(dest="command", required=True)
+    for name in ("compress", "decompress"):
+        sp = sub.add_parser(name)
+        sp.add_argument("input_file")
+        sp.add_argument("output_file", nargs="?")
+    args = ap.parse_args(argv)
+    torch.manual_seed(args.seed)
+    model = model_cls(num_filters=args.num_filters)
+    if args.model_path:
+        model.load_state_dict(torch.load(args.model_path, map_location="cpu"))
+    model = model.cuda().init_compression()
+    if args.command == "compress":
+        compress_file(model, args.input_file, args.output_file or args.input_file + ".tfci", args.verbose)
+    else:
+        decompress_file(model, args.input_file, args.output_file or args.input_file + ".png")
+    return 0
+
+

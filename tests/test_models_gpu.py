@@ -74,3 +74,28 @@ def test_training_forward_runs():
     with torch.no_grad():
         loss, bpp, mse = model(x, training=False)
     assert torch.isfinite(loss) and bpp > 0 and mse >= 0
+
+
+@pytest.mark.parametrize("which", ["bls2017", "bmshj2018"])
+def test_tfci_file_round_trip(which, tmp_path):
+    """PNG -> .tfci -> PNG through the file helpers (bls2017.py:273-323): the container parses
+    back to exactly the tensors compress() produced and decodes to the same image."""
+    from compression_amd import PackedTensors, models, synthetic
+    torch.manual_seed(0)
+    model = (models.BLS2017Model(num_filters=64) if which == "bls2017"
+             else models.BMSHJ2018Model(num_filters=64)).cuda().init_compression()
+    img = torch.from_numpy(synthetic.lowpass_images(1, 96, 80, seed=5)[0])
+    models.write_png(tmp_path / "in.png", img)
+    assert torch.equal(models.read_png(tmp_path / "in.png"), img)
+    data = models.compress_file(model, tmp_path / "in.png", tmp_path / "out.tfci")
+    direct = model.compress(img.cuda())
+    ns = model.num_strings
+    unpacked = PackedTensors(data).unpack([bytes] * ns + [np.int32] * (model.num_packed - ns))
+    for got, want in zip(unpacked[:ns], direct[:ns]):
+        assert [bytes(b) for b in got] == [bytes(b) for b in np.asarray(want, dtype=object).reshape(-1)]
+    for got, want in zip(unpacked[ns:], direct[ns:]):
+        assert tuple(got.tolist()) == tuple(want)
+    x_hat = models.decompress_file(model, tmp_path / "out.tfci", tmp_path / "rec.png")
+    assert torch.equal(x_hat.cpu(), model.decompress(*direct)[0].cpu())
+    assert torch.equal(models.read_png(tmp_path / "rec.png"), x_hat.cpu())
+    assert x_hat.shape == img.shape
