@@ -393,6 +393,10 @@ __device__ inline void reassert_uniform(FastDecState& st) {
   st.sh = __builtin_amdgcn_readfirstlane(st.sh);
 }
 
+#ifdef TFC_PHASE_TIMING
+__device__ unsigned long long g_dec_phase[4];
+#endif
+
 template <typename Dst>
 __global__ void dec_fast_kernel(DecParams p, Dst dst) {
   extern __shared__ int32_t lds[];
@@ -422,8 +426,14 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
   const int ntab = p.tab.ntab;
   int ch0 = 0;
 
+#ifdef TFC_PHASE_TIMING
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   for (int64_t j0 = 0; j0 < p.elems; j0 += 64) {
     // ---- vector phase: row of every symbol of the batch ---------------------
+#ifdef TFC_PHASE_TIMING
+    const unsigned long long tb0 = __builtin_readcyclecounter();
+#endif
     const int64_t j = j0 + lane;
     const bool valid = j < p.elems;
     int t = 0;
@@ -514,6 +524,10 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
       }
     };
 
+#ifdef TFC_PHASE_TIMING
+    const unsigned long long tb1 = __builtin_readcyclecounter();
+    if (s == 0 && lane == 0) g_dec_phase[0] += tb1 - tb0;
+#endif
     if (cnt == 64) {
       // Level 1: the whole batch speculatively, fully unrolled (immediate lane indices, no
       // branch).  Level 2, only if an escape symbol turned up: blocks of 8 symbols with a
@@ -595,8 +609,20 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
     } else {
       checked(0, cnt);
     }
+#ifdef TFC_PHASE_TIMING
+    const unsigned long long tb2 = __builtin_readcyclecounter();
+    if (s == 0 && lane == 0) g_dec_phase[1] += tb2 - tb1;
+#endif
     if (valid) dst.store(s * p.elems + j, t, outv);
+#ifdef TFC_PHASE_TIMING
+    if (s == 0 && lane == 0) g_dec_phase[2] += __builtin_readcyclecounter() - tb2;
+#endif
   }
+#ifdef TFC_PHASE_TIMING
+  if (s == 0 && lane == 0)
+    printf("dec stream 0: total %llu cycles for %lld symbols: batch prologue %llu, steps %llu, store %llu\n",
+           __builtin_readcyclecounter() - t_begin, (long long)p.elems, g_dec_phase[0], g_dec_phase[1], g_dec_phase[2]);
+#endif
 
   w.wbase += st.pos;
   if (lane == 0) {

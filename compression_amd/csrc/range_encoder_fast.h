@@ -40,6 +40,9 @@ struct FastSink {
   unsigned int ndig;        // digits already stored
   unsigned int cap_dig;
   unsigned int overflow;
+#ifdef TFC_PHASE_TIMING
+  bool is0;
+#endif
 };
 
 __device__ inline unsigned short be16(unsigned int d) {
@@ -61,6 +64,15 @@ __device__ inline void sink_run(FastSink& o, unsigned int first, unsigned int fi
 
 __device__ inline unsigned long long brev64(unsigned long long x) { return __builtin_bitreverse64(x); }
 
+#ifdef TFC_PHASE_TIMING   // debug: cycles per phase of stream 0, printed at kernel end
+__device__ unsigned long long g_enc_phase[4];
+#define TFC_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define TFC_ACC(slot, a, b) do { if (o.is0 && lane == 0) g_enc_phase[slot] += (b) - (a); } while (0)
+#else
+#define TFC_TICK(var)
+#define TFC_ACC(slot, a, b)
+#endif
+
 // Chain + digit phase for m (1..64) queued calls; lane n holds call n in `w`.
 template <bool FULL>
 __device__ inline void consume_calls(FastEncState& st, FastSink& o, unsigned int w, int m,
@@ -71,6 +83,7 @@ __device__ inline void consume_calls(FastEncState& st, FastSink& o, unsigned int
   const unsigned long long addB =
       static_cast<unsigned long long>(static_cast<long long>(hi) - 65536ll);
 
+  TFC_TICK(tc0);
   unsigned int s_in = st.span_m1, b_in = st.base;   // only lane 0's copy is used as is
   unsigned int s_out = 0, b_out = 0, A = 0, bs = 0, t1 = 0;
   auto sweep = [&]() {
@@ -93,6 +106,8 @@ __device__ inline void consume_calls(FastEncState& st, FastSink& o, unsigned int
     for (int it = 0; it < m; ++it) sweep();
   }
 
+  TFC_TICK(tc1);
+  TFC_ACC(1, tc0, tc1);
   // ---- digit phase --------------------------------------------------------
   const bool act = lane < m;
   const bool flag = act && (t1 < 65536u);          // this call shifted a digit out
@@ -162,6 +177,8 @@ __device__ inline void consume_calls(FastEncState& st, FastSink& o, unsigned int
   }
   st.span_m1 = __builtin_amdgcn_readlane(static_cast<int>(s_out), m - 1);
   st.base = __builtin_amdgcn_readlane(static_cast<int>(b_out), m - 1);
+  TFC_TICK(tc2);
+  TFC_ACC(2, tc1, tc2);
 }
 
 template <typename Src>
@@ -193,6 +210,10 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
   o.cap_dig = static_cast<unsigned int>((p.chunk_off[s + 1] - off0) >> 1);
   o.ndig = 0;
   o.overflow = 0;
+#ifdef TFC_PHASE_TIMING
+  o.is0 = s == 0;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
 
   auto T = [&](int i) -> int32_t { return tab[i]; };
   int count = 0;                                   // calls queued in ring[0..count)
@@ -218,6 +239,7 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
   int32_t v_next = fetch(0, 0, &t_next);
   for (int64_t j0 = 0; j0 < p.elems; j0 += 64) {
     // ---- vector phase ----------------------------------------------------
+    TFC_TICK(tv0);
     const int64_t j = j0 + lane;
     const bool valid = j < p.elems;
     const int t = t_next;
@@ -237,6 +259,8 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
     if (esc == 0 && count == 0 && cnt == 64) {
       // common case: exactly one call per symbol and nothing queued — feed the chain phase
       // straight from registers, no trip through the LDS queue
+      TFC_TICK(tv1);
+      TFC_ACC(0, tv0, tv1);
       consume_calls<true>(st, o, word, 64, lane);
       continue;
     }
@@ -289,6 +313,11 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
   }
   if (count > 0) consume_calls<false>(st, o, lane < count ? ring[lane] : 0x00000000u, count, lane);
 
+#ifdef TFC_PHASE_TIMING
+  if (s == 0 && lane == 0)
+    printf("enc stream 0: total %llu cycles for %lld symbols: vector %llu, chain %llu, digit %llu\n",
+           __builtin_readcyclecounter() - t_begin, (long long)p.elems, g_enc_phase[0], g_enc_phase[1], g_enc_phase[2]);
+#endif
   if (lane == 0) {
     p.state[s] = make_uint4(st.base, st.span_m1, st.pend, st.run);
     p.chunk_len[s] = 2u * o.ndig;

@@ -290,6 +290,193 @@ __global__ void __launch_bounds__(64 * kConvWaves) conv_kernel(const T* x, const
     }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 main kernel, second generation.  The first kernel above (still used for f32) reads its
+// six A fragments from LDS for every 6 MFMAs, which saturates LDS (4 waves x 6 KB per K step),
+// and waits for each K step's B load.  Here
+//   * a wave owns MT pixel tiles (MT * 32 pixels) x TILES column tiles, so an A fragment read
+//     feeds MT MFMAs (MT = 2: 12 accumulators = 192 AGPRs, one wave per SIMD);
+//   * A fragments are double-buffered in registers (the next K step's reads fly under this
+//     step's MFMAs) and B fragments are fetched PF K steps ahead into a register ring;
+//   * weight chunks are double-buffered in LDS: the next chunk travels global -> registers while
+//     the current one is consumed, registers -> LDS at the chunk boundary (one barrier).
+// ---------------------------------------------------------------------------
+#ifndef TFC_CONV_PF
+#define TFC_CONV_PF 4
+#endif
+#ifndef TFC_CONV_CHUNK
+#define TFC_CONV_CHUNK 4
+#endif
+constexpr int kPF = TFC_CONV_PF;         // B fragments in flight per pixel tile
+constexpr int kChunk2 = TFC_CONV_CHUNK;  // K steps per LDS weight buffer (multiple of kPF)
+
+template <int TILES, int MT>
+__global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const void* packed,
+                                                        const float* bias, __bf16* y, ConvGeom c) {
+  extern __shared__ unsigned char smem[];          // 2 x kChunk2 * TILES * 64 fragments of 16 B
+  constexpr int CHUNK_FRAGS = kChunk2 * TILES * 64;
+  constexpr int STAGE = (CHUNK_FRAGS + 255) / 256;  // 16-byte pieces each thread moves per chunk
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int h = lane >> 5;
+  const int group = blockIdx.x % c.groups;
+  const long long pblock = blockIdx.x / c.groups;
+  const long long M = c.N * c.OHq * c.OWq;
+
+  long long nn[MT];
+  int qy[MT], qx[MT];
+  bool live[MT];
+  long long mm[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) {
+    const long long m = ((pblock * 4 + wid) * MT + p) * 32 + (lane & 31);
+    live[p] = m < M;
+    mm[p] = live[p] ? m : M - 1;
+    qx[p] = static_cast<int>(mm[p] % c.OWq);
+    qy[p] = static_cast<int>((mm[p] / c.OWq) % c.OHq);
+    nn[p] = mm[p] / (static_cast<long long>(c.OWq) * c.OHq);
+  }
+  const int cb = c.small_cin ? 1 : c.Cin / 16;
+
+  // B fragment of pixel tile p at K step ks: 8 input values at K offset 8h, zero outside the image
+  auto bload = [&](int ks, int p) -> u32x4 {
+    const __bf16* src;
+    bool ok = live[p];
+    if (c.small_cin) {
+      const int uy = ks / c.kw4, seg = ks % c.kw4;
+      src = x + ((nn[p] * c.Hp + (qy[p] * c.sd + uy)) * c.Wp + qx[p] * c.sd) * 4 + seg * 16 + 8 * h;
+    } else {
+      const int tap = ks / cb;
+      const int uy = tap / c.Ux, ux = tap % c.Ux;
+      const int iy = qy[p] * c.sd + uy - c.py0, ix = qx[p] * c.sd + ux - c.px0;
+      ok = ok && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W;
+      src = x + ((nn[p] * c.H + (ok ? iy : 0)) * c.W + (ok ? ix : 0)) * c.Cin + (ks % cb) * 16 + 8 * h;
+    }
+    u32x4 v = *reinterpret_cast<const u32x4*>(src);      // always a valid address
+    if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+    return v;
+  };
+
+  f32x16 acc[MT][TILES];
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.f;
+
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(
+      static_cast<const unsigned char*>(packed) + static_cast<size_t>(group) * c.ksteps * TILES * 64 * 16);
+  const int nchunks = (c.ksteps + kChunk2 - 1) / kChunk2;
+  const long long wtotal = static_cast<long long>(c.ksteps) * TILES * 64;   // fragments of this group
+
+  u32x4 stage[STAGE];
+  auto wfetch = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < STAGE; ++i) {
+      const long long f = static_cast<long long>(chunk) * CHUNK_FRAGS + i * 256 + threadIdx.x;
+      stage[i] = (i * 256 + static_cast<int>(threadIdx.x) < CHUNK_FRAGS && f < wtotal) ? wsrc[f]
+                                                                                       : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto wstore = [&](int buf) {
+    u32x4* dst = reinterpret_cast<u32x4*>(smem) + buf * CHUNK_FRAGS;
+#pragma unroll
+    for (int i = 0; i < STAGE; ++i)
+      if (i * 256 + static_cast<int>(threadIdx.x) < CHUNK_FRAGS) dst[i * 256 + threadIdx.x] = stage[i];
+  };
+
+  // prologue: chunk 0 into buffer 0, first PF B fragments
+  wfetch(0);
+  wstore(0);
+  u32x4 bq[kPF][MT];
+#pragma unroll
+  for (int k = 0; k < kPF; ++k)
+#pragma unroll
+    for (int p = 0; p < MT; ++p) bq[k][p] = bload(min(k, c.ksteps - 1), p);
+  __syncthreads();
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < nchunks) wfetch(chunk + 1);
+    const bf16x8* abase = reinterpret_cast<const bf16x8*>(smem) + buf * CHUNK_FRAGS + lane;
+    bf16x8 af[2][TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) af[0][t] = abase[t * 64];
+#pragma unroll
+    for (int kk = 0; kk < kChunk2; ++kk) {
+      const int ks = chunk * kChunk2 + kk;
+      if (kk + 1 < kChunk2) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) af[(kk + 1) & 1][t] = abase[((kk + 1) * TILES + t) * 64];
+      }
+      bf16x8 bfrag[MT];
+#pragma unroll
+      for (int p = 0; p < MT; ++p) bfrag[p] = __builtin_bit_cast(bf16x8, bq[kk % kPF][p]);
+      // refill the ring slot: K step ks + PF (weights beyond ksteps are zero, any valid B will do)
+#pragma unroll
+      for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = bload(min(ks + kPF, c.ksteps - 1), p);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int p = 0; p < MT; ++p)
+          acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][t], bfrag[p], acc[p][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (chunk + 1 < nchunks) wstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel mm[p] ----
+  const int colbase = group * TILES * 32;
+  const bool vec4 = (c.Cout & 3) == 0;       // 4 consecutive columns = 4 channels of one phase
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col0 = colbase + 32 * t + 8 * q + 4 * h;
+      const int co = col0 % c.Cout, phase = col0 / c.Cout;
+      f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bias && col0 < c.cols) {
+        if (vec4) {
+          b4 = *reinterpret_cast<const f32x4*>(bias + co);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b4[r] = col0 + r < c.cols ? bias[(col0 + r) % c.Cout] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < MT; ++p) {
+        if (!live[p] || col0 >= c.cols) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[p][t][4 * q + r] + b4[r];
+          if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (vec4) {
+          // su == 1: phase 0, (oy, ox) = (qy, qx); else depth-to-space of the column's phase
+          const int oy = qy[p] * c.su + phase / c.su, ox = qx[p] * c.su + phase % c.su;
+          u32x2 o;
+          o.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          o.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          *reinterpret_cast<u32x2*>(y + ((nn[p] * c.OH + oy) * c.OW + ox) * c.Cout + co) = o;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = col0 + r;
+            if (col >= c.cols) continue;
+            const int co1 = col % c.Cout, ph1 = col / c.Cout;
+            const int oy = qy[p] * c.su + ph1 / c.su, ox = qx[p] * c.su + ph1 % c.su;
+            y[((nn[p] * c.OH + oy) * c.OW + ox) * c.Cout + co1] = static_cast<__bf16>(v[r]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // one column tile at a time (register pressure)
+  }
+}
+
 template <typename T>
 int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom c, PackGeom g,
              hipStream_t st) {
@@ -318,6 +505,42 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
     xin = padded.as<T>();
   }
   const long long M = c.N * c.OHq * c.OWq;
+  if constexpr (std::is_same<T, __bf16>::value) if (!c.small_cin) {
+    // second-generation kernel (not for the image layer: its K is only a few dozen steps and the
+    // first kernel, which stages all of them at once, is faster there); 2 pixel tiles per wave
+    // when that still fills the chip
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int mt = ceil_div(M, 256) * c.groups >= 2 * cus ? 2 : 1;
+    const long long pb = ceil_div(M, 128 * mt);
+    if (pb * c.groups >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
+    const dim3 grid2(static_cast<unsigned>(pb * c.groups));
+    const size_t lds2 = static_cast<size_t>(2) * kChunk2 * c.tiles * 64 * 16;
+    KernelTimer timer("conv2d", st);
+#define TFC_CONV2_LAUNCH(NT, MTV)                                                                  \
+    do {                                                                                           \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<NT, MTV>),       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2))); \
+      hipLaunchKernelGGL((conv_bf16_kernel<NT, MTV>), grid2, dim3(256), lds2, st,                  \
+                         static_cast<const __bf16*>(static_cast<const void*>(xin)), packed.p, bias,  \
+                         static_cast<__bf16*>(y), c);                                              \
+    } while (0)
+#define TFC_CONV2_CASE(NT) case NT: if (mt == 2) TFC_CONV2_LAUNCH(NT, 2); else TFC_CONV2_LAUNCH(NT, 1); break
+    switch (c.tiles) {
+      TFC_CONV2_CASE(1);
+      TFC_CONV2_CASE(2);
+      TFC_CONV2_CASE(3);
+      TFC_CONV2_CASE(4);
+      TFC_CONV2_CASE(5);
+      default:
+        TFC_CONV2_CASE(6);
+    }
+#undef TFC_CONV2_CASE
+#undef TFC_CONV2_LAUNCH
+    TFC_HIP(hipGetLastError());
+    return 0;
+  }
   const long long pblocks = ceil_div(M, 32 * kConvWaves);
   if (pblocks * c.groups >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
   const dim3 grid(static_cast<unsigned>(pblocks * c.groups));
