@@ -1,6 +1,6 @@
 // Fast multi-stream range ENCODER for gfx950 — included by range_coder.hip.
 //
-// Cost model (tools/ubench_chain.hip, MI355X): one wave issues one instruction
+// Cost model (tools/ubench/chain.hip, MI355X): one wave issues one instruction
 // per ~4.1 cycles whatever its type, so cycles/symbol ~= 4 x instructions on the
 // serial path.  This kernel keeps exactly the interval recurrence serial and
 // makes everything else wave-parallel:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One C2 encode + decode with the kernels built with -DTFC_PHASE_TIMING (see tools/dbg_build.sh):
+"""One C2 encode + decode with the kernels built with -DTFC_PHASE_TIMING (see tools/rebuild_coder_with_flags.sh):
 stream 0 prints its cycle split per phase."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

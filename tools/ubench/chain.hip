@@ -1,6 +1,6 @@
 // Single-wave dependent-chain latency probes for gfx950 (design input for the
 // range coder: its per-symbol cost is a chain of ~10-30 such instructions).
-// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_chain.hip -o /tmp/ubench && /tmp/ubench
+// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/chain.hip -o /tmp/ubench && /tmp/ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
