@@ -12,7 +12,7 @@ import torch
 
 from .. import _lib
 from ..distributions import helpers
-from ..ops import gen_ops, math_ops, round_ops
+from ..ops import bottleneck_ops, gen_ops, math_ops, round_ops
 from . import continuous_base
 
 __all__ = ["ContinuousBatchedEntropyModel", "EntropyBottleneck"]
@@ -88,6 +88,13 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
     def forward(self, bottleneck, training=True):
         """(bottleneck_perturbed, bits) — continuous_batched.py:291-322."""
         bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
+        base = getattr(self.prior, "base", None)
+        ltm = self.laplace_tail_mass
+        if (training and not self.expected_grads and not torch.is_tensor(ltm) and ltm == 0
+                and bottleneck_ops.fused_factorized_supported(base, bottleneck, self.coding_rank)):
+            # one fused HIP kernel each way: noise add + likelihood + bits (csrc/factorized_bits.hip)
+            noise = torch.rand_like(bottleneck) - 0.5
+            return bottleneck_ops.factorized_bits(bottleneck, base, self.coding_rank, noise)
         log_prob_fn = functools.partial(self._log_prob, self.prior)
         if training:
             log_probs, perturbed = math_ops.perturb_and_apply(

@@ -1,0 +1,89 @@
+"""Fused training-time forward/backward of the entropy bottleneck with a deep factorized
+prior (continuous_batched.py:291-322 + uniform_noise.py:117-156 + deep_factorized.py:166-194)
+on the HIP kernels of csrc/factorized_bits.hip."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+__all__ = ["factorized_bits", "pack_factorized_params", "fused_factorized_supported"]
+
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
+_BUILT = {(3, 3), (4, 3), (3, 5)}          # (layers, width) the library instantiates
+
+
+def fused_factorized_supported(base, bottleneck, coding_rank) -> bool:
+    """True if (prior, tensor) can take the fused path: equal hidden widths the library was
+    built for, channels-last tensor on a HIP device whose coding unit is everything but the
+    leading batch dimensions, one set of MLP weights per channel."""
+    nf = getattr(base, "num_filters", None)
+    if not nf or len(set(nf)) != 1 or (len(nf) + 1, nf[0]) not in _BUILT:
+        return False
+    if not bottleneck.is_cuda or bottleneck.dtype not in _DTYPE_CODE:
+        return False
+    bs = tuple(base.batch_shape)
+    if len(bs) != 1 or bottleneck.dim() < 1 or bottleneck.shape[-1] != bs[0] or bs[0] > 512:
+        return False
+    return 1 <= coding_rank <= bottleneck.dim()
+
+
+def pack_factorized_params(base) -> torch.Tensor:
+    """[channels, P] float32 of the reparameterised MLP weights in the kernel's layout
+    (differentiable: the chain rule through softplus / tanh stays with autograd)."""
+    sp, th = torch.nn.functional.softplus, torch.tanh
+    K = len(base.num_filters) + 1
+    C = base.matrices[0].shape[0]
+    parts = [sp(base.matrices[0]).reshape(C, -1), base.biases[0].reshape(C, -1), th(base.factors[0]).reshape(C, -1)]
+    for l in range(1, K - 1):
+        parts += [sp(base.matrices[l]).reshape(C, -1), base.biases[l].reshape(C, -1),
+                  th(base.factors[l]).reshape(C, -1)]
+    parts += [sp(base.matrices[K - 1]).reshape(C, -1), base.biases[K - 1].reshape(C, -1)]
+    return torch.cat(parts, dim=1).to(torch.float32).contiguous()
+
+
+class _FactorizedBits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, noise, params, layers, width, units, elems):
+        _lib.require_device()
+        y = y.contiguous()
+        y_hat = torch.empty_like(y)
+        bits = torch.empty(units, dtype=torch.float32, device=y.device)
+        channels = params.shape[0]
+        _lib.check(_lib.lib().tfc_factorized_bits_forward(
+            y.data_ptr(), noise.data_ptr() if noise is not None else None, y_hat.data_ptr(),
+            _DTYPE_CODE[y.dtype], units, elems, channels, params.data_ptr(), layers, width, None,
+            bits.data_ptr(), _lib.stream_ptr()))
+        ctx.save_for_backward(y_hat, params)
+        ctx.meta = (layers, width, units, elems)
+        return y_hat, bits
+
+    @staticmethod
+    def backward(ctx, g_yhat, g_bits):
+        y_hat, params = ctx.saved_tensors
+        layers, width, units, elems = ctx.meta
+        dy = torch.empty_like(y_hat)
+        dparams = torch.zeros_like(params)
+        gb = (g_bits if g_bits is not None else torch.zeros(units, device=y_hat.device)).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().tfc_factorized_bits_backward(
+            y_hat.data_ptr(), _DTYPE_CODE[y_hat.dtype], units, elems, params.shape[0], params.data_ptr(),
+            layers, width, gb.data_ptr(), dy.data_ptr(), dparams.data_ptr(), _lib.stream_ptr()))
+        if g_yhat is not None:
+            dy = dy + g_yhat
+        return dy, None, dparams, None, None, None, None
+
+
+def factorized_bits(bottleneck, base, coding_rank, noise=None):
+    """(y_hat, bits): y_hat = bottleneck + noise (noise None: bottleneck itself), bits summed over
+    the last `coding_rank` dimensions, shape = the leading dimensions."""
+    lead = bottleneck.shape[:bottleneck.dim() - coding_rank]
+    units = 1
+    for s in lead:
+        units *= int(s)
+    elems = bottleneck.numel() // max(units, 1)
+    params = pack_factorized_params(base).to(bottleneck.device)
+    if noise is not None:
+        noise = noise.to(bottleneck.dtype).contiguous()
+    y_hat, bits = _FactorizedBits.apply(bottleneck, noise, params, len(base.num_filters) + 1,
+                                        int(base.num_filters[0]), units, elems)
+    return y_hat, bits.reshape(lead)

@@ -233,6 +233,33 @@ int tfc_conv2d_up(const void* x, const void* w, const float* bias, void* y, int 
                   int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout,
                   int kh, int kw, int stride, int activation, void* stream);
 
+/* ------------------------------------------------------------------------ */
+/* Training-time entropy bottleneck (deep factorized prior), fused          */
+/* ------------------------------------------------------------------------ */
+
+/* ContinuousBatchedEntropyModel.__call__(training=True) with a NoisyDeepFactorized prior and
+ * expected_grads=False — python/entropy_models/continuous_batched.py:291-322,
+ * python/ops/math_ops.py:157-216, python/distributions/uniform_noise.py:117-156,
+ * python/distributions/deep_factorized.py:166-194:
+ *   y_hat = y + noise;  log p = log(c(y_hat + .5) - c(y_hat - .5)),  c = sigmoid(logits(.));
+ *   bits[u] = -sum over unit u of log p / ln 2.
+ * y, noise (or NULL: y_hat = y), y_hat DEV [units, elems] dtype (0 f32, 1 bf16), channels
+ * innermost (elems % channels == 0, channels <= 512).  The per-channel MLP has `layers` layers
+ * 1 -> width -> ... -> 1; params DEV f32 [channels, P] holds the REPARAMETERISED values
+ * (softplus(matrix), bias, tanh(factor)) per channel: layer 0 m[W] b[W] a[W]; middle layers
+ * m[W][W] (row = output) b[W] a[W]; last layer m[W] b[1].  log_prob DEV f32 [units, elems] or
+ * NULL; bits DEV f32 [units].  Built for (layers, width) = (3,3), (4,3), (3,5). */
+int tfc_factorized_bits_forward(const void* y, const void* noise, void* y_hat, int dtype,
+                                int64_t units, int64_t elems, int64_t channels, const float* params,
+                                int layers, int width, float* log_prob, float* bits, void* stream);
+
+/* Gradients of the above: gbits DEV f32 [units] = dL/dbits; dy DEV [units, elems] dtype =
+ * dL/dy_hat through the likelihood (the caller adds the straight path); dparams DEV f32
+ * [channels, P] is ADDED to (gradients w.r.t. the reparameterised values). */
+int tfc_factorized_bits_backward(const void* y_hat, int dtype, int64_t units, int64_t elems,
+                                 int64_t channels, const float* params, int layers, int width,
+                                 const float* gbits, void* dy, float* dparams, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,3 +170,63 @@ def test_indexed_bits_close_to_rate():
     _, bits = em(y, idx, training=False)
     n = 8 * len(bytes(em.compress(y, idx)[()]))
     assert float(bits) < n <= 1.01 * float(bits)
+
+
+@pytest.mark.parametrize("num_filters,dtype", [((3, 3), torch.float32), ((3, 3, 3), torch.float32),
+                                                ((5, 5), torch.float32), ((3, 3), torch.bfloat16)])
+def test_fused_training_bottleneck_matches_torch_path(num_filters, dtype):
+    """csrc/factorized_bits.hip against the op-by-op evaluation of continuous_batched.py:291-322
+    (torch autograd through uniform_noise.py:117-156 / deep_factorized.py:166-194): same perturbed
+    tensor, bits within 1e-5 relative (f32), gradients w.r.t. the input and every prior parameter."""
+    from compression_amd.ops import bottleneck_ops
+    torch.manual_seed(11)
+    C = 48
+    prior = tfc.NoisyDeepFactorized(batch_shape=(C,), num_filters=num_filters).cuda()
+    with torch.no_grad():
+        for prm in prior.parameters():
+            prm.add_(0.3 * torch.randn_like(prm))
+    y = (3.0 * torch.randn(3, 5, 7, C, device="cuda")).to(dtype).requires_grad_(True)
+    noise = (torch.rand(3, 5, 7, C, device="cuda") - 0.5).to(dtype)
+    w = torch.tensor([1.0, -2.0, 0.5], device="cuda")
+
+    def reference():
+        y_hat = y + noise
+        lp = prior.log_prob(y_hat.to(torch.float32))
+        return y_hat, lp.sum(dim=(1, 2, 3)) / -float(np.log(2.0))
+
+    def fused():
+        return bottleneck_ops.factorized_bits(y, prior.base, 3, noise)
+
+    outs = []
+    for fn in (reference, fused):
+        y.grad = None
+        prior.zero_grad()
+        y_hat, bits = fn()
+        ((bits * w).sum() + (y_hat.float() ** 2).sum() * 1e-3).backward()
+        outs.append((y_hat.detach(), bits.detach(), y.grad.detach().float().clone(),
+                     [p.grad.detach().clone() for p in prior.parameters()]))
+    (yr, br, gr, pr), (yf, bf, gf, pf) = outs
+    assert torch.equal(yr, yf)
+    tol = 1e-5 if dtype == torch.float32 else 1e-5
+    assert torch.allclose(br, bf, rtol=tol, atol=1e-3)
+    gtol = 2e-4 if dtype == torch.float32 else 2e-2       # bf16: dy is stored in bf16
+    assert torch.allclose(gr, gf, rtol=gtol, atol=gtol * gr.abs().max().item())
+    for a, b in zip(pr, pf):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3 * max(a.abs().max().item(), 1e-3))
+
+
+def test_entropy_model_training_call_uses_fused_path():
+    """ContinuousBatchedEntropyModel(training=True): bits agree with the eval-free torch evaluation of
+    the same perturbed tensor and gradients reach the prior."""
+    torch.manual_seed(12)
+    C = 32
+    prior = tfc.NoisyDeepFactorized(batch_shape=(C,)).cuda()
+    em = tfc.ContinuousBatchedEntropyModel(prior, coding_rank=3, compression=False)
+    y = torch.randn(2, 6, 6, C, device="cuda", requires_grad=True)
+    y_hat, bits = em(y, training=True)
+    assert y_hat.shape == y.shape and bits.shape == (2,)
+    assert (y_hat - y).abs().max() <= 0.5
+    want = prior.log_prob(y_hat.detach()).sum(dim=(1, 2, 3)) / -float(np.log(2.0))
+    assert torch.allclose(bits.detach(), want, rtol=1e-5, atol=1e-3)
+    bits.sum().backward()
+    assert y.grad is not None and all(p.grad is not None and torch.isfinite(p.grad).all() for p in prior.parameters())
