@@ -1,0 +1,311 @@
+// SignalConv2D weight gradient for gfx950 (the input gradient of either direction is the
+// forward kernel of the other direction with the kernel's channel axes swapped; see
+// layers/functional.py).  One contraction serves both directions:
+//
+//   G[t][a][b] = sum over n, q of  A[n, q*s + t - k/2, a] * B[n, q, b]        (zero outside A)
+//
+//   analysis  y = corr_down(x, w, s):  dw[t][ci][co] = G with A = x,  B = dy          (python/layers/
+//   synthesis y = conv_up(x, w, s):    dw[t][ci][co] = G^T with A = dy, B = x          signal_conv.py:663-690, 778-847)
+//
+// Per kernel tap t this is an [a x b] = A_t^T B contraction over PIXELS, the shape of the GDN
+// parameter gradient (gdn_backward.hip): a workgroup owns one tap and a strided set of 64-pixel
+// stages of B's grid, stages both operands through LDS transposed ([channel][pixel]; bf16 as
+// pixel pairs, software-pipelined), its four waves own the (a-tile, b-tile) parity classes, and
+// it leaves one [a x b] partial; a second kernel sums the partials of a tap in a fixed order.
+// Channel counts: multiples of 32 up to 256, or <= 4 (the image side of the first / last layer:
+// one zero-padded 32-row tile, element-wise staging).  bf16: v_mfma_f32_32x32x16_bf16; f32:
+// v_mfma_f32_32x32x2_f32 (exact products, fp32 accumulation either way).
+// Roofline: MFMA-bound, 2 * taps * M * a * b FLOP — the forward pass's count.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "../../include/tfc_hip.h"
+#include "common.h"
+
+namespace tfc {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int WG_PIX = 64;       // pixels per LDS stage
+constexpr int WG_STRIDE = 72;    // bf16 elements per transposed LDS row (144 B: conflict-free b128 reads)
+
+struct WgradGeom {
+  const void* A;
+  const void* B;
+  long long N;
+  int HA, WA, CA;        // A: the tensor read at q*s + t - k/2
+  int HB, WB, CB;        // B: the tensor on the q grid
+  int kh, kw, stride;
+  int chunks;            // workgroups per tap
+  float* partial;        // [kh*kw][chunks][CA][CB]
+};
+
+// KTA / KTB = 32-channel tiles of A / B (1 with CA <= 4 = narrow tensor)
+template <typename T, int KTA, int KTB>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int RA = KTA * 32, RB = KTB * 32;          // LDS rows
+  constexpr int NHA = (KTA + 1) / 2, NHB = (KTB + 1) / 2;
+  extern __shared__ unsigned char smem[];
+  // bf16: aT[RA][WG_STRIDE], bT[RB][WG_STRIDE] (u16); f32: as[WG_PIX][RA], bs[WG_PIX][RB]
+  unsigned short* aT = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* bT = aT + RA * WG_STRIDE;
+  float* as = reinterpret_cast<float*>(smem);
+  float* bs = as + WG_PIX * RA;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wa = w >> 1, wb = w & 1, i32 = lane & 31, h = lane >> 5;
+  const int tap = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
+  const int ty = tap / g.kw, tx = tap % g.kw;
+  const T* A = static_cast<const T*>(g.A);
+  const T* B = static_cast<const T*>(g.B);
+  const long long M = g.N * g.HB * g.WB;
+  const bool narrowA = g.CA < 32, narrowB = g.CB < 32;
+
+  f32x16 acc[NHA][NHB];
+#pragma unroll
+  for (int a = 0; a < NHA; ++a)
+#pragma unroll
+    for (int b = 0; b < NHB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // source row of pixel m of the stage: B row m; A row at the tap's offset (or -1: zero)
+  auto rows = [&](long long m, long long* rowA, long long* rowB) {
+    *rowB = m < M ? m : -1;
+    *rowA = -1;
+    if (m < M) {
+      const int qx = static_cast<int>(m % g.WB);
+      const int qy = static_cast<int>((m / g.WB) % g.HB);
+      const long long n = m / (static_cast<long long>(g.WB) * g.HB);
+      const int iy = qy * g.stride + ty - g.kh / 2, ix = qx * g.stride + tx - g.kw / 2;
+      if (iy >= 0 && iy < g.HA && ix >= 0 && ix < g.WA) *rowA = (n * g.HA + iy) * g.WA + ix;
+    }
+  };
+
+  // wide tensors: 16-byte chunks held in registers one stage ahead
+  constexpr int NA = BF ? KTA : 2 * KTA, NB = BF ? KTB : 2 * KTB;
+  u32x4 aq[NA], bq[NB];
+  auto fetch = [&](long long st) {
+    const long long m0 = st * WG_PIX;
+    if (!narrowA) {
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const int c = tid + 256 * k;
+        const int px = BF ? (c % WG_PIX) : (c / (RA / 4));
+        const int off = BF ? 8 * (c / WG_PIX) : 4 * (c % (RA / 4));
+        long long ra, rb;
+        rows(m0 + px, &ra, &rb);
+        aq[k] = ra >= 0 ? *reinterpret_cast<const u32x4*>(A + ra * g.CA + off) : u32x4{0, 0, 0, 0};
+      }
+    }
+    if (!narrowB) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int c = tid + 256 * k;
+        const int px = BF ? (c % WG_PIX) : (c / (RB / 4));
+        const int off = BF ? 8 * (c / WG_PIX) : 4 * (c % (RB / 4));
+        long long ra, rb;
+        rows(m0 + px, &ra, &rb);
+        bq[k] = rb >= 0 ? *reinterpret_cast<const u32x4*>(B + rb * g.CB + off) : u32x4{0, 0, 0, 0};
+      }
+    }
+  };
+  // pixel pairs -> 4-byte transposed LDS writes (see gdn_backward.hip)
+  auto pair_store = [&](const u32x4& v, unsigned short* base, int px, int cg) {
+    const bool odd = px & 1;
+    const unsigned int send0 = odd ? v[0] : v[2], send1 = odd ? v[1] : v[3];
+    const unsigned int keep0 = odd ? v[2] : v[0], keep1 = odd ? v[3] : v[1];
+    unsigned int recv0 = __builtin_amdgcn_update_dpp(0u, send0, 0xB1, 0xF, 0xF, false);
+    unsigned int recv1 = __builtin_amdgcn_update_dpp(0u, send1, 0xB1, 0xF, 0xF, false);
+    asm volatile("" : "+v"(recv0), "+v"(recv1));
+    const unsigned int e0 = odd ? recv0 : keep0, o0 = odd ? keep0 : recv0;
+    const unsigned int e1 = odd ? recv1 : keep1, o1 = odd ? keep1 : recv1;
+    unsigned int* dst = reinterpret_cast<unsigned int*>(base + (8 * cg + (odd ? 4 : 0)) * WG_STRIDE + (px & ~1));
+    dst[0 * WG_STRIDE / 2] = __builtin_amdgcn_perm(o0, e0, 0x05040100u);
+    dst[1 * WG_STRIDE / 2] = __builtin_amdgcn_perm(o0, e0, 0x07060302u);
+    dst[2 * WG_STRIDE / 2] = __builtin_amdgcn_perm(o1, e1, 0x05040100u);
+    dst[3 * WG_STRIDE / 2] = __builtin_amdgcn_perm(o1, e1, 0x07060302u);
+  };
+  // narrow tensor (<= 4 channels): one element per thread-iteration, rows >= C stay zero
+  auto stage_narrow = [&](const T* src, int C, bool isA, long long st) {
+    const long long m0 = st * WG_PIX;
+    for (int idx = tid; idx < WG_PIX * 32; idx += 256) {
+      const int px = idx % WG_PIX, ch = idx / WG_PIX;
+      long long ra, rb;
+      rows(m0 + px, &ra, &rb);
+      const long long r = isA ? ra : rb;
+      T v = T(0.f);
+      if (ch < C && r >= 0) v = src[r * C + ch];
+      if constexpr (BF) {
+        (isA ? aT : bT)[ch * WG_STRIDE + px] = __builtin_bit_cast(unsigned short, v);
+      } else {
+        (isA ? as : bs)[px * (isA ? RA : RB) + ch] = static_cast<float>(v);
+      }
+    }
+  };
+  auto stage_to_lds = [&](long long st) {
+    if (narrowA) {
+      stage_narrow(A, g.CA, true, st);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const int c = tid + 256 * k;
+        if (BF) pair_store(aq[k], aT, c % WG_PIX, c / WG_PIX);
+        else *reinterpret_cast<u32x4*>(as + (c / (RA / 4)) * RA + 4 * (c % (RA / 4))) = aq[k];
+      }
+    }
+    if (narrowB) {
+      stage_narrow(B, g.CB, false, st);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int c = tid + 256 * k;
+        if (BF) pair_store(bq[k], bT, c % WG_PIX, c / WG_PIX);
+        else *reinterpret_cast<u32x4*>(bs + (c / (RB / 4)) * RB + 4 * (c % (RB / 4))) = bq[k];
+      }
+    }
+  };
+
+  const long long stages = (M + WG_PIX - 1) / WG_PIX;
+  if (chunk < stages) fetch(chunk);
+  for (long long st = chunk; st < stages; st += g.chunks) {
+    __syncthreads();
+    stage_to_lds(st);
+    __syncthreads();
+    if (st + g.chunks < stages) fetch(st + g.chunks);
+    if (BF) {
+#pragma unroll
+      for (int ks = 0; ks < WG_PIX / 16; ++ks) {
+        bf16x8 af[NHA], bfr[NHB];
+#pragma unroll
+        for (int a = 0; a < NHA; ++a)
+          if (wa + 2 * a < KTA)
+            af[a] = *reinterpret_cast<const bf16x8*>(aT + (32 * (wa + 2 * a) + i32) * WG_STRIDE + 16 * ks + 8 * h);
+#pragma unroll
+        for (int b = 0; b < NHB; ++b)
+          if (wb + 2 * b < KTB)
+            bfr[b] = *reinterpret_cast<const bf16x8*>(bT + (32 * (wb + 2 * b) + i32) * WG_STRIDE + 16 * ks + 8 * h);
+#pragma unroll
+        for (int a = 0; a < NHA; ++a)
+#pragma unroll
+          for (int b = 0; b < NHB; ++b)
+            if (wa + 2 * a < KTA && wb + 2 * b < KTB)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int k2 = 0; k2 < WG_PIX / 2; ++k2) {
+        float af[NHA], bfr[NHB];
+#pragma unroll
+        for (int a = 0; a < NHA; ++a)
+          af[a] = wa + 2 * a < KTA ? as[(2 * k2 + h) * RA + 32 * (wa + 2 * a) + i32] : 0.f;
+#pragma unroll
+        for (int b = 0; b < NHB; ++b)
+          bfr[b] = wb + 2 * b < KTB ? bs[(2 * k2 + h) * RB + 32 * (wb + 2 * b) + i32] : 0.f;
+#pragma unroll
+        for (int a = 0; a < NHA; ++a)
+#pragma unroll
+          for (int b = 0; b < NHB; ++b)
+            if (wa + 2 * a < KTA && wb + 2 * b < KTB)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+  float* out = g.partial + (static_cast<size_t>(tap) * g.chunks + chunk) * g.CA * g.CB;
+#pragma unroll
+  for (int a = 0; a < NHA; ++a)
+#pragma unroll
+    for (int b = 0; b < NHB; ++b) {
+      const int at = wa + 2 * a, bt = wb + 2 * b;
+      if (at < KTA && bt < KTB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ca = 32 * at + (r & 3) + 8 * (r >> 2) + 4 * h, cb = 32 * bt + i32;
+          if (ca < g.CA && cb < g.CB) out[ca * g.CB + cb] = acc[a][b][r];
+        }
+      }
+    }
+}
+
+// dw[t][ci][co] += sum over chunks of G (or its transpose)
+__global__ void conv_wgrad_reduce_kernel(const float* partial, int taps, int chunks, int CA, int CB,
+                                         int transpose, float* dw) {
+  const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  const long long n = static_cast<long long>(taps) * CA * CB;
+  if (idx >= n) return;
+  const int t = static_cast<int>(idx / (CA * CB));
+  const int rem = static_cast<int>(idx % (CA * CB));
+  const int ca = rem / CB, cb = rem % CB;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[(static_cast<size_t>(t) * chunks + c) * CA * CB + rem];
+  if (transpose) dw[(static_cast<long long>(t) * CB + cb) * CA + ca] += s;
+  else dw[idx] += s;
+}
+
+template <typename T, int KTA, int KTB>
+int launch_wgrad(WgradGeom g, int transpose, float* dw, hipStream_t st) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int taps = g.kh * g.kw;
+  const long long stages = ceil_div(g.N * g.HB * g.WB, static_cast<long long>(WG_PIX));
+  g.chunks = static_cast<int>(std::max<long long>(1, std::min<long long>(stages, ceil_div(2 * cus, taps))));
+  DevBuf partial;
+  TFC_HIP(partial.alloc(sizeof(float) * static_cast<size_t>(taps) * g.chunks * g.CA * g.CB, st));
+  g.partial = partial.as<float>();
+  const size_t lds = sizeof(T) == 2 ? sizeof(unsigned short) * (KTA + KTB) * 32 * WG_STRIDE
+                                    : sizeof(float) * WG_PIX * (KTA + KTB) * 32;
+  {
+    KernelTimer timer("conv2d_wgrad", st);
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, KTA, KTB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, KTA, KTB>), dim3(static_cast<unsigned>(taps * g.chunks)), dim3(256),
+                       lds, st, g);
+  }
+  const long long n = static_cast<long long>(taps) * g.CA * g.CB;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
+                     g.partial, taps, g.chunks, g.CA, g.CB, transpose, dw);
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+inline int tiles_of(int64_t c) { return c <= 4 ? 1 : static_cast<int>(c / 32); }
+
+template <typename T>
+int dispatch_wgrad(WgradGeom g, int transpose, float* dw, hipStream_t st) {
+  const int ka = tiles_of(g.CA), kb = tiles_of(g.CB);
+#define TFC_WG(KA, KB) if (ka == KA && kb == KB) return launch_wgrad<T, KA, KB>(g, transpose, dw, st)
+#define TFC_WG_ROW(KA) TFC_WG(KA, 1); TFC_WG(KA, 2); TFC_WG(KA, 4); TFC_WG(KA, 6); TFC_WG(KA, 8)
+  TFC_WG_ROW(1); TFC_WG_ROW(2); TFC_WG_ROW(4); TFC_WG_ROW(6); TFC_WG_ROW(8);
+#undef TFC_WG_ROW
+#undef TFC_WG
+  return fail("tfc_conv2d_wgrad: channel pair (%d, %d) is not built (each side: <= 4 channels, or 32, 64, 128, "
+              "192 or 256)", g.CA, g.CB);
+}
+
+}  // namespace tfc
+
+extern "C" int tfc_conv2d_wgrad(const void* a, const void* b, float* dw, int dtype, int64_t n, int64_t ha,
+                                int64_t wa, int64_t ca, int64_t hb, int64_t wb, int64_t cb, int kh, int kw,
+                                int stride, int transpose, void* stream) {
+  using namespace tfc;
+  if (dtype != 0 && dtype != 1) return fail("tfc_conv2d_wgrad: dtype must be 0 (float32) or 1 (bfloat16)");
+  if (kh < 1 || kw < 1 || stride < 1 || ca < 1 || cb < 1) return fail("tfc_conv2d_wgrad: bad geometry");
+  auto ok = [](int64_t c) { return c <= 4 || (c % 32 == 0 && c <= 256); };
+  if (!ok(ca) || !ok(cb))
+    return fail("tfc_conv2d_wgrad: channel counts must be <= 4 or multiples of 32 up to 256 (got %lld, %lld)",
+                static_cast<long long>(ca), static_cast<long long>(cb));
+  if (n == 0 || hb == 0 || wb == 0) return 0;
+  WgradGeom g{};
+  g.A = a; g.B = b; g.N = n;
+  g.HA = static_cast<int>(ha); g.WA = static_cast<int>(wa); g.CA = static_cast<int>(ca);
+  g.HB = static_cast<int>(hb); g.WB = static_cast<int>(wb); g.CB = static_cast<int>(cb);
+  g.kh = kh; g.kw = kw; g.stride = stride;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == 1 ? dispatch_wgrad<__bf16>(g, transpose, dw, st) : dispatch_wgrad<float>(g, transpose, dw, st);
+}

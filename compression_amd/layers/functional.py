@@ -57,14 +57,74 @@ def _conv(fn_name, x, kernel, bias, stride, activation, up):
     return y
 
 
+def conv2d_wgrad(a, b, kernel_support, stride, transpose):
+    """Weight gradient kernel: G[t][ca][cb] = sum A[n, q*s + t - k/2, ca] B[n, q, cb] as a float32
+    [kh, kw, Cin, Cout] tensor (transpose=True: A carries Cout, B carries Cin)."""
+    _lib.require_device()
+    a, b = a.contiguous(), b.contiguous()
+    kh, kw = kernel_support
+    n, ha, wa, ca = a.shape
+    _, hb, wb, cb = b.shape
+    shape = (kh, kw, cb, ca) if transpose else (kh, kw, ca, cb)
+    dw = torch.zeros(shape, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().tfc_conv2d_wgrad(
+        a.data_ptr(), b.data_ptr(), dw.data_ptr(), _DTYPE_CODE[a.dtype], n, ha, wa, ca, hb, wb, cb,
+        kh, kw, int(stride), int(bool(transpose)), _lib.stream_ptr()))
+    return dw
+
+
+class _ConvFunction(torch.autograd.Function):
+    """Differentiable wrapper of the two conv entry points (the reference differentiates
+    signal_conv.py:663-690 / 778-847 with TF autodiff):
+      dx  = the OTHER direction's forward kernel on dy with the kernel's channel axes swapped,
+      dw  = tfc_conv2d_wgrad,   dbias = sum of dy over pixels."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, stride, activation, up):
+        y = _conv("tfc_conv2d_up" if up else "tfc_conv2d_down", x, kernel, bias, stride, activation, up)
+        ctx.save_for_backward(x, kernel, y if activation == "relu" else None)
+        ctx.meta = (stride, activation, up, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, kernel, y = ctx.saved_tensors
+        stride, activation, up, has_bias = ctx.meta
+        gy = gy.to(x.dtype).contiguous()
+        if activation == "relu":
+            gy = gy * (y > 0)
+        kh, kw = kernel.shape[:2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            kt = kernel.permute(0, 1, 3, 2)
+            if up:
+                dx = _conv("tfc_conv2d_down", gy, kt, None, stride, None, False)
+            else:
+                dx = _conv("tfc_conv2d_up", gy, kt, None, stride, None, True)[:, :x.shape[1], :x.shape[2]]
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad(gy, x, (kh, kw), stride, True) if up else conv2d_wgrad(x, gy, (kh, kw), stride, False)
+            dw = dw.to(kernel.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = gy.float().sum(dim=(0, 1, 2))
+        return dx, dw, db, None, None, None
+
+
+def _conv_dispatch(x, kernel, bias, stride, activation, up):
+    needs = torch.is_grad_enabled() and (x.requires_grad or kernel.requires_grad
+                                         or (bias is not None and bias.requires_grad))
+    if needs:
+        return _ConvFunction.apply(x, kernel, bias, stride, activation, up)
+    return _conv("tfc_conv2d_up" if up else "tfc_conv2d_down", x, kernel, bias, stride, activation, up)
+
+
 def conv2d_down(x, kernel, bias=None, stride=1, activation=None):
     """Analysis correlation (signal_conv.py:663-690): NHWC x, HWIO kernel, `same_zeros`."""
-    return _conv("tfc_conv2d_down", x, kernel, bias, stride, activation, False)
+    return _conv_dispatch(x, kernel, bias, stride, activation, False)
 
 
 def conv2d_up(x, kernel, bias=None, stride=1, activation=None):
     """Synthesis transposed convolution (signal_conv.py:778-847, extra_pad_end=True)."""
-    return _conv("tfc_conv2d_up", x, kernel, bias, stride, activation, True)
+    return _conv_dispatch(x, kernel, bias, stride, activation, True)
 
 
 def gdn_backward(x, grad, beta, gamma, inverse=False, rectify=False, alpha=1, epsilon=1):

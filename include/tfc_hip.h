@@ -233,6 +233,19 @@ int tfc_conv2d_up(const void* x, const void* w, const float* bias, void* y, int 
                   int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout,
                   int kh, int kw, int stride, int activation, void* stream);
 
+/* Weight gradient of either direction (the reference relies on TF autodiff of
+ * signal_conv.py:663-690 / 778-847).  G[t][ca][cb] = sum_{n,q} A[n, q*stride + t - k/2, ca] *
+ * B[n, q, cb] with zeros outside A; q runs over B's grid.
+ *   analysis  y = tfc_conv2d_down(x, w):  dw = G            with A = x  [n,ha,wa,ca=Cin],  B = dy [n,hb,wb,cb=Cout]
+ *   synthesis y = tfc_conv2d_up(x, w):    dw = G transposed with A = dy [n,ha,wa,ca=Cout], B = x  [n,hb,wb,cb=Cin]
+ * (transpose = 1 writes dw[t][cb][ca]).  dw DEV f32 [kh,kw,Cin,Cout] is ADDED to.  a, b DEV dtype
+ * (0 f32, 1 bf16); channel counts <= 4 or multiples of 32 up to 256.  The INPUT gradient needs no
+ * entry point of its own: dx of tfc_conv2d_down is tfc_conv2d_up(dy, w with its channel axes
+ * swapped) cropped to the input size, and dx of tfc_conv2d_up is tfc_conv2d_down(dy, same). */
+int tfc_conv2d_wgrad(const void* a, const void* b, float* dw, int dtype, int64_t n, int64_t ha,
+                     int64_t wa, int64_t ca, int64_t hb, int64_t wb, int64_t cb, int kh, int kw,
+                     int stride, int transpose, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* Training-time entropy bottleneck (deep factorized prior), fused          */
 /* ------------------------------------------------------------------------ */
