@@ -244,14 +244,15 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
     const bool valid = j < p.elems;
     const int t = t_next;
     const int32_t v = v_next;
-    {
-      const int ch_n = static_cast<int>((static_cast<unsigned int>(ch0) + 64u) % static_cast<unsigned int>(ntab));
-      v_next = fetch(j0 + 64, ch_n, &t_next);
-    }
     Call c;
     c.lo16 = 0; c.hi16 = 1; c.gamma = 0; c.neg = 0; c.bad = 0;
     if (valid) c = classify_normalised(T, rows[t], v);
     ch0 = static_cast<int>((static_cast<unsigned int>(ch0) + 64u) % static_cast<unsigned int>(ntab));
+    // The next batch's symbols are requested only now, after this batch's have been consumed:
+    // the wait for THESE symbols is an `s_waitcnt vmcnt(0)` (stores of the digit phase make the
+    // outstanding count unknown), which would otherwise also wait for the request just issued
+    // and expose a full memory latency per batch.  The chain phase below covers it.
+    v_next = fetch(j0 + 64, ch0, &t_next);
     const unsigned int word = static_cast<unsigned int>(c.lo16) |
                               ((static_cast<unsigned int>(c.hi16) - 1u) << 16);
     const unsigned long long esc = __ballot(valid && c.gamma > 0);
