@@ -56,25 +56,33 @@ struct DecWindow {
   long long len;
   unsigned int wbase;   // digit index held by lane 0 of reg
   int reg;              // digits wbase .. wbase + 63
-  int next;             // digits wbase + 64 .. wbase + 127, fetched one batch ahead
+  // digits wbase + 64 .. wbase + 127, requested one batch ahead and kept as RAW bytes: anything
+  // computed from a load result makes the compiler wait for the load on the spot, so the bytes are
+  // only combined (window_next) when the following batch stitches its window.
+  unsigned int next_hi, next_lo;
+  bool next_hi_ok, next_lo_ok;
 };
 
 // Branch-free on purpose: with `b < len ? src[b] : 0` the compiler puts each byte load in its own
-// block and waits for it at the join, which exposed two full HBM latencies per 64-symbol batch.
-// Addresses are clamped into the stream instead and the value is masked afterwards, so the loads
-// are issued back to back and nobody waits for them until the digits are used a batch later.
-__device__ inline int fast_window_fetch(const DecWindow& w, unsigned int first, int lane) {
+// block and waits for it at the join.  Addresses are clamped into the stream instead and the
+// value is masked afterwards (in window_next / fast_window_fetch).
+__device__ inline void fast_window_request(DecWindow& w, unsigned int first, int lane) {
   const long long b = 2ll * (static_cast<long long>(first) + lane);
   const long long last = w.len - 1;                       // w.src is readable on [0, max(len, 1))
-  const unsigned int hi = w.src[b < last ? b : (last < 0 ? 0 : last)];
-  const unsigned int lo = w.src[b + 1 < last ? b + 1 : (last < 0 ? 0 : last)];
-  return static_cast<int>(((b < w.len ? hi : 0u) << 8) | (b + 1 < w.len ? lo : 0u));
+  w.next_hi = w.src[b < last ? b : (last < 0 ? 0 : last)];
+  w.next_lo = w.src[b + 1 < last ? b + 1 : (last < 0 ? 0 : last)];
+  w.next_hi_ok = b < w.len;
+  w.next_lo_ok = b + 1 < w.len;
+}
+__device__ inline int window_next(const DecWindow& w) {
+  return static_cast<int>(((w.next_hi_ok ? w.next_hi : 0u) << 8) | (w.next_lo_ok ? w.next_lo : 0u));
 }
 
 // Synchronous (re)load of both registers at wbase.
 __device__ inline void fast_window_load(DecWindow& w, int lane) {
-  w.reg = fast_window_fetch(w, w.wbase, lane);
-  w.next = fast_window_fetch(w, w.wbase + 64u, lane);
+  fast_window_request(w, w.wbase, lane);
+  w.reg = window_next(w);
+  fast_window_request(w, w.wbase + 64u, lane);
 }
 
 // Advances the window by `shift` (0..64) consumed digits without waiting for HBM: the new
@@ -83,15 +91,12 @@ __device__ inline void fast_window_load(DecWindow& w, int lane) {
 __device__ inline void fast_window_advance(DecWindow& w, unsigned int shift, int lane) {
   const int idx = (lane + static_cast<int>(shift)) & 63;
   const int from_reg = __builtin_amdgcn_ds_bpermute(idx << 2, w.reg);
-  const int from_next = __builtin_amdgcn_ds_bpermute(idx << 2, w.next);
+  const int from_next = __builtin_amdgcn_ds_bpermute(idx << 2, window_next(w));
   const bool in_reg = lane + static_cast<int>(shift) < 64;
   // shift == 64 moves `next` into place unchanged (idx == lane)
-  const int stitched = in_reg ? from_reg : from_next;
   w.wbase += shift;
-  w.reg = stitched;
-  // digits wbase+64.. : lanes that still come from the old `next` plus newly fetched ones
-  const int fresh = fast_window_fetch(w, w.wbase + 64u, lane);
-  w.next = fresh;
+  w.reg = in_reg ? from_reg : from_next;
+  fast_window_request(w, w.wbase + 64u, lane);
 }
 
 // ---- candidate-per-lane selection --------------------------------------------------------
