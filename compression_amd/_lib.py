@@ -40,6 +40,10 @@ SIGNATURES = {
     "tfc_range_encode": (_int, [_vp, _vp, _int, _vp, _vp, _int, _int, _int, _vp,
                                 C.POINTER(_vp), C.POINTER(_i64)]),
     "tfc_range_decode": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    "tfc_unbounded_index_range_encode": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _int, _int,
+                                                _vp, C.POINTER(_vp), C.POINTER(_i64)]),
+    "tfc_unbounded_index_range_decode": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _int,
+                                                _int, _vp, _vp]),
     "tfc_free": (None, [_vp]),
     "tfc_pmf_to_quantized_cdf": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
     "tfc_gdn_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp]),

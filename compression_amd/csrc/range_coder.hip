@@ -1477,6 +1477,28 @@ __device__ inline long long cdf_row_of(const Broadcast& b, long long k) {
   return off;
 }
 
+// RangeEncoder::Finalize (cc/lib/range_coder.cc:266-307) behind the digits already stored:
+// returns the stream length.  One lane.
+__device__ inline unsigned int finalize_bytes(const EncoderState& st, const DigitSink& o, uint8_t* out) {
+  unsigned int n = o.nbytes;
+  uint8_t* dst = out + n;
+  if (st.pend_digit != 0) {
+    dst[0] = (st.pend_digit >> 8) & 0xFF; ++n;
+    if ((st.pend_digit & 0xFF) != 0) { dst[1] = st.pend_digit & 0xFF; ++n; }
+  } else if (st.base != 0) {
+    const unsigned int top = st.base + st.span_m1;
+    const unsigned int r24 = ((st.base - 1) >> 24) + 1;
+    if (r24 <= (top >> 24)) {
+      dst[0] = r24 & 0xFF; ++n;
+    } else {
+      const unsigned int r16 = ((st.base - 1) >> 16) + 1;
+      dst[0] = (r16 >> 8) & 0xFF; ++n;
+      if ((r16 & 0xFF) != 0) { dst[1] = r16 & 0xFF; ++n; }
+    }
+  }
+  return n;
+}
+
 struct LegacyEncParams {
   const int16_t* data;
   const int32_t* cdf;
@@ -1533,26 +1555,7 @@ __global__ void __launch_bounds__(64) legacy_enc_kernel(LegacyEncParams p) {
     }
   }
   sink_flush(o, lane);
-  if (lane == 0) {
-    // RangeEncoder::Finalize
-    unsigned int n = o.nbytes;
-    uint8_t* dst = p.out + n;
-    if (st.pend_digit != 0) {
-      dst[0] = (st.pend_digit >> 8) & 0xFF; ++n;
-      if ((st.pend_digit & 0xFF) != 0) { dst[1] = st.pend_digit & 0xFF; ++n; }
-    } else if (st.base != 0) {
-      const unsigned int top = st.base + st.span_m1;
-      const unsigned int r24 = ((st.base - 1) >> 24) + 1;
-      if (r24 <= (top >> 24)) {
-        dst[0] = r24 & 0xFF; ++n;
-      } else {
-        const unsigned int r16 = ((st.base - 1) >> 16) + 1;
-        dst[0] = (r16 >> 8) & 0xFF; ++n;
-        if ((r16 & 0xFF) != 0) { dst[1] = r16 & 0xFF; ++n; }
-      }
-    }
-    *p.out_len = n;
-  }
+  if (lane == 0) *p.out_len = finalize_bytes(st, o, p.out);
 }
 
 struct LegacyDecParams {
@@ -1592,6 +1595,162 @@ __global__ void __launch_bounds__(64) legacy_dec_kernel(LegacyDecParams p) {
       outv = tfc_writelane(sym, n, outv);
     }
     if (k < p.total) p.out[k] = static_cast<int16_t>(outv);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Deprecated UnboundedIndexRangeEncode / Decode
+// (cc/kernels/unbounded_index_range_coding_kernels.cc:185-249, 307-367): ONE stream for the
+// whole tensor, so one wave; the per-element table work (row, clamping, overflow value, the
+// two cdf entries) is done 64 elements at a time across the lanes, the interval updates
+// are the serial part.  Out-of-range values: the row's last symbol, then the digit count
+// (unary in units of the largest digit) and the digits of the overflow value, least
+// significant first, each a uniform `overflow_width`-bit symbol.
+// ---------------------------------------------------------------------------
+struct UnboundedParams {
+  const int32_t* data;        // encode
+  int32_t* out_values;        // decode
+  const int32_t* index;
+  const int32_t* cdf;
+  const int32_t* cdf_size;
+  const int32_t* offset;
+  long long total, rows, width;
+  int precision, overflow_width;
+  uint8_t* out;               // encode
+  unsigned int cap;
+  unsigned int* out_len;
+  const uint8_t* bytes;       // decode
+  long long nbytes;
+};
+
+__global__ void __launch_bounds__(64) unbounded_enc_kernel(UnboundedParams p) {
+  const int lane = threadIdx.x;
+  EncoderState st{0u, 0xFFFFFFFFu, 0u, 0u};
+  DigitSink o;
+  o.dst = p.out; o.cap = p.cap; o.nbytes = 0; o.n = 0; o.reg = 0; o.overflow = 0;
+  const int sh = 16 - p.precision, osh = 16 - p.overflow_width;
+  const unsigned int max_overflow = (1u << p.overflow_width) - 1u;
+  for (long long k0 = 0; k0 < p.total; k0 += 64) {
+    const long long k = k0 + lane;
+    int lo = 0, hi = 0, clamped = 0;
+    unsigned int ovf = 0;
+    if (k < p.total) {
+      const long long row = min<long long>(max(p.index[k], 0), p.rows - 1);   // debug_level 0: DCHECK only
+      const int max_value = p.cdf_size[row] - 2;
+      int value = p.data[k] - p.offset[row];
+      if (value < 0) {
+        ovf = static_cast<unsigned int>(-2 * value - 1);
+        value = max_value;
+      } else if (value >= max_value) {
+        ovf = static_cast<unsigned int>(2 * (value - max_value));
+        value = max_value;
+      }
+      clamped = value == max_value;
+      lo = p.cdf[row * p.width + value] << sh;
+      hi = p.cdf[row * p.width + value + 1] << sh;
+    }
+    const int cnt = static_cast<int>(min<long long>(64, p.total - k0));
+    for (int n = 0; n < cnt; ++n) {
+      enc_update(st, __builtin_amdgcn_readlane(lo, n), __builtin_amdgcn_readlane(hi, n), o, lane);
+      if (__builtin_amdgcn_readlane(clamped, n)) {
+        const unsigned int v = __builtin_amdgcn_readlane(static_cast<int>(ovf), n);
+        int widths = 0;
+        while (widths * p.overflow_width < 32 && (v >> (widths * p.overflow_width)) != 0) ++widths;
+        unsigned int val = static_cast<unsigned int>(widths);
+        while (val >= max_overflow) {
+          enc_update(st, max_overflow << osh, (max_overflow + 1u) << osh, o, lane);
+          val -= max_overflow;
+        }
+        enc_update(st, val << osh, (val + 1u) << osh, o, lane);
+        for (int j = 0; j < widths; ++j) {
+          const unsigned int d = (v >> (j * p.overflow_width)) & max_overflow;
+          enc_update(st, d << osh, (d + 1u) << osh, o, lane);
+        }
+      }
+    }
+  }
+  sink_flush(o, lane);
+  if (lane == 0) *p.out_len = o.overflow ? 0xFFFFFFFFu : finalize_bytes(st, o, p.out);
+}
+
+// One uniform symbol of `width` bits: cdf = 0, 1, ..., 2^width at precision `width`; the
+// reference's search (first k with target <= span * k) in closed form.
+__device__ inline unsigned int dec_uniform(DecoderState& st, int width, DigitWindow& w, int lane) {
+  const unsigned long long span = static_cast<unsigned long long>(st.span_m1) + 1;
+  const unsigned long long target =
+      (static_cast<unsigned long long>(static_cast<unsigned int>(st.window - st.base)) + 1) << width;
+  unsigned long long sym = (target - 1) / span;
+  const unsigned long long last = (1ull << width) - 1;
+  if (sym > last) sym = last;                      // damaged input
+  dec_narrow(st, static_cast<unsigned int>(sym), static_cast<unsigned int>(sym) + 1u, width, w, lane);
+  return static_cast<unsigned int>(sym);
+}
+
+__global__ void __launch_bounds__(64) unbounded_dec_kernel(UnboundedParams p) {
+  const int lane = threadIdx.x;
+  DecoderState st{0u, 0xFFFFFFFFu, 0u};
+  DigitWindow w;
+  w.src = p.bytes; w.len = p.nbytes; w.pulls = 0; w.base = 0;
+  window_load(w, lane);
+  st.window = window_pull(w, lane) << 16;
+  st.window |= window_pull(w, lane);
+  const unsigned int max_overflow = (1u << p.overflow_width) - 1u;
+  for (long long k0 = 0; k0 < p.total; k0 += 64) {
+    const long long k = k0 + lane;
+    long long row = 0;
+    int ncdf = 3, off = 0;
+    if (k < p.total) {
+      row = min<long long>(max(p.index[k], 0), p.rows - 1);
+      ncdf = p.cdf_size[row];
+      off = p.offset[row];
+    }
+    const int cnt = static_cast<int>(min<long long>(64, p.total - k0));
+    int outv = 0;
+    for (int n = 0; n < cnt; ++n) {
+      const long long r = __builtin_amdgcn_readlane(static_cast<int>(row), n);
+      const int nc = __builtin_amdgcn_readlane(ncdf, n);
+      const int32_t* base = p.cdf + r * p.width;
+      auto T = [&](int i) -> int32_t { return base[i]; };
+      int value = dec_symbol(T, st, 0, nc, p.precision, w, lane);
+      const int max_value = nc - 2;
+      if (value == max_value) {
+        int widths = 0;
+        unsigned int val;
+        do {
+          val = dec_uniform(st, p.overflow_width, w, lane);
+          widths += static_cast<int>(val);
+        } while (val == max_overflow && widths < 64);
+        unsigned int ovf = 0;
+        for (int j = 0; j < widths; ++j) {
+          const unsigned int d = dec_uniform(st, p.overflow_width, w, lane);
+          if (j * p.overflow_width < 32) ovf |= d << (j * p.overflow_width);
+        }
+        value = static_cast<int>(ovf >> 1);
+        if (ovf & 1u) value = -value - 1; else value += max_value;
+      }
+      outv = tfc_writelane(value, n, outv);
+    }
+    if (k < p.total) p.out_values[k] = outv + off;
+  }
+}
+
+// CheckArgumentValues (unbounded_index_range_coding_kernels.cc:54-113): first offending
+// index position / cdf_size row / cdf row (min), bit 0 ends wrong, bit 1 not monotonic.
+__global__ void unbounded_check_kernel(const int32_t* index, long long total, const int32_t* cdf,
+                                       long long rows, long long width, const int32_t* cdf_size,
+                                       int precision, unsigned long long* first) {
+  const long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  if (i < total && (index[i] < 0 || rows <= index[i])) atomicMin(first, static_cast<unsigned long long>(i));
+  if (i < rows) {
+    const int n = cdf_size[i];
+    if (n < 3 || width < n) {
+      atomicMin(first + 1, static_cast<unsigned long long>(i));
+    } else {
+      const int32_t* s = cdf + i * width;
+      if (s[0] != 0 || s[n - 1] != (1 << precision)) atomicMin(first + 2, static_cast<unsigned long long>(i));
+      for (int j = 0; j + 1 < n; ++j)
+        if (s[j + 1] <= s[j]) { atomicMin(first + 3, static_cast<unsigned long long>(i)); break; }
+    }
   }
 }
 
@@ -1770,5 +1929,112 @@ extern "C" int tfc_range_decode(const uint8_t* encoded, int64_t encoded_len,
   hipLaunchKernelGGL(legacy_dec_kernel, dim3(1), dim3(64), 0, st, p);
   TFC_HIP(hipGetLastError());
   TFC_HIP(hipStreamSynchronize(st));  // `encoded` is a host buffer the caller may free
+  return 0;
+}
+
+// ===========================================================================
+// Deprecated UnboundedIndexRangeEncode / Decode
+// ===========================================================================
+
+namespace {
+
+int unbounded_validate(const char* who, const int32_t* index, int64_t total, const int32_t* cdf, int64_t rows,
+                       int64_t width, const int32_t* cdf_size, int precision, int overflow_width,
+                       int debug_level, hipStream_t st) {
+  if (!(0 < precision && precision <= 16)) return fail("`precision` must be in [1, 16]: %d", precision);
+  if (!(0 < overflow_width && overflow_width <= 16))
+    return fail("`overflow_width` must be in [1, 16]: %d", overflow_width);
+  if (debug_level != 0 && debug_level != 1) return fail("`debug_level` must be 0 or 1: %d", debug_level);
+  if (width < 3) return fail("'cdf' should be 2-D and cdf.dim_size(1) >= 3: [%lld,%lld]",
+                             static_cast<long long>(rows), static_cast<long long>(width));
+  if (rows < 1) return fail("%s: 'cdf' has no rows", who);
+  if (debug_level == 0) return 0;
+  DevBuf first;
+  TFC_HIP(first.alloc(4 * sizeof(unsigned long long), st));
+  TFC_HIP(hipMemsetAsync(first.p, 0xFF, 4 * sizeof(unsigned long long), st));
+  const long long n = std::max<long long>(total, rows);
+  hipLaunchKernelGGL(unbounded_check_kernel, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
+                     index, total, cdf, rows, width, cdf_size, precision, first.as<unsigned long long>());
+  unsigned long long h[4];
+  TFC_HIP(hipMemcpyAsync(h, first.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  if (h[0] != ~0ull) {
+    int32_t v = 0;
+    (void)hipMemcpy(&v, index + h[0], 4, hipMemcpyDeviceToHost);
+    return fail("'index' has a value not in [0, %lld): value=%d", static_cast<long long>(rows), v);
+  }
+  if (h[1] != ~0ull) {
+    int32_t v = 0;
+    (void)hipMemcpy(&v, cdf_size + h[1], 4, hipMemcpyDeviceToHost);
+    return fail("'cdf_size' has a value not in [3, %lld]: value=%d", static_cast<long long>(width), v);
+  }
+  if (h[2] != ~0ull) {
+    int32_t n0 = 0, ends[2] = {0, 0};
+    (void)hipMemcpy(&n0, cdf_size + h[2], 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&ends[0], cdf + h[2] * width, 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&ends[1], cdf + h[2] * width + n0 - 1, 4, hipMemcpyDeviceToHost);
+    return fail("Each cdf should start from 0 and end at %d: cdf[0]=%d, cdf[^1]=%d", 1 << precision, ends[0],
+                ends[1]);
+  }
+  if (h[3] != ~0ull) return fail("CDF is not monotonic");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tfc_unbounded_index_range_encode(const int32_t* data, const int32_t* index, int64_t total,
+                                                const int32_t* cdf, int64_t rows, int64_t width,
+                                                const int32_t* cdf_size, const int32_t* offset, int precision,
+                                                int overflow_width, int debug_level, void* stream,
+                                                uint8_t** out, int64_t* out_len) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  *out = nullptr;
+  *out_len = 0;
+  if (int rc = unbounded_validate("tfc_unbounded_index_range_encode", index, total, cdf, rows, width, cdf_size,
+                                  precision, overflow_width, debug_level, st))
+    return rc;
+  // worst case per element: the symbol, ceil(32 / w) digits and their count in unary — 2 bytes per call
+  const long long digits = (32 + overflow_width - 1) / overflow_width;
+  const unsigned long long cap64 = 2ull * total * (2 + 2 * digits) + 16;
+  if (cap64 >= (1ull << 32)) return fail("tfc_unbounded_index_range_encode: tensor too large for one stream");
+  DevBuf buf, len;
+  TFC_HIP(buf.alloc(cap64, st));
+  TFC_HIP(len.alloc(sizeof(unsigned int), st));
+  UnboundedParams p{};
+  p.data = data; p.index = index; p.cdf = cdf; p.cdf_size = cdf_size; p.offset = offset;
+  p.total = total; p.rows = rows; p.width = width; p.precision = precision; p.overflow_width = overflow_width;
+  p.out = buf.as<uint8_t>(); p.cap = static_cast<unsigned int>(cap64 - 8); p.out_len = len.as<unsigned int>();
+  hipLaunchKernelGGL(unbounded_enc_kernel, dim3(1), dim3(64), 0, st, p);
+  unsigned int n = 0;
+  TFC_HIP(hipMemcpyAsync(&n, len.p, sizeof(n), hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  if (n == 0xFFFFFFFFu) return fail("internal error: unbounded encoder ran out of output space");
+  uint8_t* host = static_cast<uint8_t*>(std::malloc(std::max<size_t>(n, 1)));
+  if (!host) return fail("out of host memory");
+  if (n) TFC_HIP(hipMemcpy(host, buf.p, n, hipMemcpyDeviceToHost));
+  *out = host;
+  *out_len = n;
+  return 0;
+}
+
+extern "C" int tfc_unbounded_index_range_decode(const uint8_t* encoded, int64_t encoded_len, const int32_t* index,
+                                                int64_t total, const int32_t* cdf, int64_t rows, int64_t width,
+                                                const int32_t* cdf_size, const int32_t* offset, int precision,
+                                                int overflow_width, int debug_level, int32_t* out, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = unbounded_validate("tfc_unbounded_index_range_decode", index, total, cdf, rows, width, cdf_size,
+                                  precision, overflow_width, debug_level, st))
+    return rc;
+  if (total == 0) return 0;
+  DevBuf bytes;
+  TFC_HIP(bytes.alloc(static_cast<size_t>(encoded_len), st));
+  if (encoded_len) TFC_HIP(hipMemcpyAsync(bytes.p, encoded, static_cast<size_t>(encoded_len), hipMemcpyHostToDevice, st));
+  UnboundedParams p{};
+  p.out_values = out; p.index = index; p.cdf = cdf; p.cdf_size = cdf_size; p.offset = offset;
+  p.total = total; p.rows = rows; p.width = width; p.precision = precision; p.overflow_width = overflow_width;
+  p.bytes = bytes.as<uint8_t>(); p.nbytes = encoded_len;
+  hipLaunchKernelGGL(unbounded_dec_kernel, dim3(1), dim3(64), 0, st, p);
+  TFC_HIP(hipGetLastError());
+  TFC_HIP(hipStreamSynchronize(st));      // the host copy of `encoded` may go away
   return 0;
 }

@@ -23,6 +23,7 @@ __all__ = [
     "entropy_decode_channel", "entropy_decode_finalize", "entropy_decode_index",
     "entropy_encode_channel", "entropy_encode_finalize", "entropy_encode_index",
     "pmf_to_quantized_cdf", "range_encode", "range_decode",
+    "unbounded_index_range_encode", "unbounded_index_range_decode",
 ]
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -376,4 +377,61 @@ def range_decode(encoded, shape, cdf, precision: int, debug_level: int = 1) -> t
         buf.ctypes.data, len(encoded), os_.ctypes.data, len(shape), cdf.data_ptr(),
         cs.ctypes.data, cdf.dim(), int(precision), int(debug_level), _lib.stream_ptr(),
         out.data_ptr()))
+    return out
+
+
+def _unbounded_args(index, cdf, cdf_size, offset, device):
+    """Shape checks of CheckArgumentShapes (unbounded_index_range_coding_kernels.cc:115-143)."""
+    index, cdf = _dev_i32(index, device), _dev_i32(cdf, device)
+    cdf_size, offset = _dev_i32(cdf_size, device), _dev_i32(offset, device)
+    if cdf.dim() != 2 or cdf.shape[1] < 3:
+        raise ValueError(f"'cdf' should be 2-D and cdf.dim_size(1) >= 3: {list(cdf.shape)}")
+    if cdf_size.dim() != 1 or cdf_size.shape[0] != cdf.shape[0]:
+        raise ValueError("'cdf_size' should be 1-D and its length should match the number of rows in 'cdf': "
+                         f"{list(cdf_size.shape)}")
+    if offset.dim() != 1 or offset.shape[0] != cdf.shape[0]:
+        raise ValueError("'offset' should be 1-D and its length should match the number of rows in 'cdf': "
+                         f"offset.shape={list(offset.shape)}, cdf.shape={list(cdf.shape)}")
+    return index, cdf, cdf_size, offset
+
+
+def unbounded_index_range_encode(data, index, cdf, cdf_size, offset, precision: int, overflow_width: int,
+                                 debug_level: int = 1) -> bytes:
+    """UnboundedIndexRangeEncode (deprecated op, cc/ops/range_coding_ops.cc / kernels
+    unbounded_index_range_coding_kernels.cc:146-249) -> one byte string for the whole tensor."""
+    device = _lib.require_device()
+    index, cdf, cdf_size, offset = _unbounded_args(index, cdf, cdf_size, offset, device)
+    data = _dev_i32(data, device)
+    if data.shape != index.shape:
+        raise ValueError(f"`data` and `index` should have the same shape: data.shape={list(data.shape)}, "
+                         f"index.shape={list(index.shape)}")
+    out, n = C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().tfc_unbounded_index_range_encode(
+        data.data_ptr(), index.data_ptr(), data.numel(), cdf.data_ptr(), cdf.shape[0], cdf.shape[1],
+        cdf_size.data_ptr(), offset.data_ptr(), int(precision), int(overflow_width), int(debug_level),
+        _lib.stream_ptr(), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out.value, n.value) if n.value else b""
+    finally:
+        _lib.lib().tfc_free(out)
+
+
+def unbounded_index_range_decode(encoded, index, cdf, cdf_size, offset, precision: int, overflow_width: int,
+                                 debug_level: int = 1) -> torch.Tensor:
+    """UnboundedIndexRangeDecode -> int32 tensor shaped like `index`
+    (unbounded_index_range_coding_kernels.cc:259-367)."""
+    device = _lib.require_device()
+    if isinstance(encoded, np.ndarray):
+        if encoded.shape != ():
+            raise ValueError(f"`encoded` should be a scalar: {list(encoded.shape)}")
+        encoded = encoded[()]
+    if not isinstance(encoded, (bytes, bytearray)):
+        raise ValueError("`encoded` should be a scalar: expected a byte string")
+    index, cdf, cdf_size, offset = _unbounded_args(index, cdf, cdf_size, offset, device)
+    out = torch.empty(index.shape, dtype=torch.int32, device=device)
+    buf = np.frombuffer(bytes(encoded), np.uint8).copy() if len(encoded) else np.zeros(1, np.uint8)
+    _lib.check(_lib.lib().tfc_unbounded_index_range_decode(
+        buf.ctypes.data, len(encoded), index.data_ptr(), index.numel(), cdf.data_ptr(), cdf.shape[0],
+        cdf.shape[1], cdf_size.data_ptr(), offset.data_ptr(), int(precision), int(overflow_width),
+        int(debug_level), out.data_ptr(), _lib.stream_ptr()))
     return out

@@ -172,6 +172,24 @@ int tfc_range_decode(const uint8_t* encoded, int64_t encoded_len, const int64_t*
                      int nd, const int32_t* cdf, const int64_t* cdf_shape, int nc,
                      int precision, int debug_level, void* stream, int16_t* out);
 
+/* Deprecated UnboundedIndexRangeEncode / UnboundedIndexRangeDecode —
+ * cc/kernels/unbounded_index_range_coding_kernels.cc:146-249, 259-367 (checks :54-143).  ONE stream for
+ * the whole tensor: element i uses row index[i] of cdf DEV int32 [rows, width] (the first cdf_size[row]
+ * entries are the table), is shifted by offset[row], and values outside [0, cdf_size - 2) are coded as the
+ * row's last symbol followed by a variable-length code in `overflow_width`-bit digits.  data / index /
+ * out DEV int32 with `total` elements; cdf_size, offset DEV int32 [rows].  debug_level 1 validates index,
+ * cdf_size and the tables (same messages as the reference).  Encode returns a malloc'ed HOST buffer the
+ * caller frees with tfc_free(); decode takes HOST bytes.  Both synchronise. */
+int tfc_unbounded_index_range_encode(const int32_t* data, const int32_t* index, int64_t total,
+                                     const int32_t* cdf, int64_t rows, int64_t width,
+                                     const int32_t* cdf_size, const int32_t* offset, int precision,
+                                     int overflow_width, int debug_level, void* stream, uint8_t** out,
+                                     int64_t* out_len);
+int tfc_unbounded_index_range_decode(const uint8_t* encoded, int64_t encoded_len, const int32_t* index,
+                                     int64_t total, const int32_t* cdf, int64_t rows, int64_t width,
+                                     const int32_t* cdf_size, const int32_t* offset, int precision,
+                                     int overflow_width, int debug_level, int32_t* out, void* stream);
+
 void tfc_free(void* p);
 
 /* ------------------------------------------------------------------------ */

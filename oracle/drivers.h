@@ -392,4 +392,126 @@ inline bool legacy_decode(const uint8_t* bytes, int64_t nbytes, const int64_t* o
   return true;
 }
 
+
+// ---- deprecated UnboundedIndexRangeEncode / Decode ------------------------------------
+// cc/kernels/unbounded_index_range_coding_kernels.cc:54-143 (argument checks), :185-249 (encode),
+// :307-367 (decode).  One stream for the whole tensor; out-of-range values are clamped to the
+// row's last symbol and followed by a variable-length code in `overflow_width`-bit digits:
+// the digit count in unary-of-max-digits form, then the digits, least significant first; the
+// overflow value is 2(v - max) for v >= max and -2v - 1 for v < 0.
+inline bool unbounded_check(const int32_t* index, int64_t total, const int32_t* cdf, int64_t rows,
+                            int64_t width, const int32_t* cdf_size, int prec, int debug_level,
+                            std::string* err) {
+  if (width < 3) { *err = "'cdf' should be 2-D and cdf.dim_size(1) >= 3"; return false; }
+  if (debug_level <= 0) return true;
+  for (int64_t i = 0; i < total; ++i)                               // CheckIndex :54-63
+    if (index[i] < 0 || rows <= index[i]) {
+      std::ostringstream os;
+      os << "'index' has a value not in [0, " << rows << "): value=" << index[i];
+      *err = os.str();
+      return false;
+    }
+  for (int64_t i = 0; i < rows; ++i)                                // CheckCdfSize :65-74
+    if (cdf_size[i] < 3 || width < cdf_size[i]) {
+      std::ostringstream os;
+      os << "'cdf_size' has a value not in [3, " << width << "]: value=" << cdf_size[i];
+      *err = os.str();
+      return false;
+    }
+  const int32_t upper = 1 << prec;                                  // CheckCdf :76-101
+  for (int64_t i = 0; i < rows; ++i) {
+    const int32_t* s = cdf + i * width;
+    const int32_t n = cdf_size[i];
+    if (s[0] != 0 || s[n - 1] != upper) {
+      std::ostringstream os;
+      os << "Each cdf should start from 0 and end at " << upper << ": cdf[0]=" << s[0]
+         << ", cdf[^1]=" << s[n - 1];
+      *err = os.str();
+      return false;
+    }
+    for (int32_t j = 0; j + 1 < n; ++j)
+      if (s[j + 1] <= s[j]) { *err = "CDF is not monotonic"; return false; }
+  }
+  return true;
+}
+
+template <typename Core>
+inline bool unbounded_encode(const int32_t* data, const int32_t* index, int64_t total, const int32_t* cdf,
+                             int64_t rows, int64_t width, const int32_t* cdf_size, const int32_t* offset,
+                             int prec, int overflow_width, int debug_level, std::string* out,
+                             std::string* err) {
+  if (!unbounded_check(index, total, cdf, rows, width, cdf_size, prec, debug_level, err)) return false;
+  typename Core::Enc e;
+  const uint32_t max_overflow = (1u << overflow_width) - 1;
+  for (int64_t i = 0; i < total; ++i) {
+    const int32_t row = index[i];
+    const int32_t max_value = cdf_size[row] - 2;
+    int32_t value = data[i] - offset[row];
+    uint32_t overflow = 0;
+    if (value < 0) {
+      overflow = static_cast<uint32_t>(-2 * value - 1);
+      value = max_value;
+    } else if (value >= max_value) {
+      overflow = static_cast<uint32_t>(2 * (value - max_value));
+      value = max_value;
+    }
+    const int32_t* s = cdf + static_cast<int64_t>(row) * width;
+    Core::encode(e, s[value], s[value + 1], prec, out);
+    if (value == max_value) {
+      int32_t widths = 0;
+      while (widths * overflow_width < 32 && (overflow >> (widths * overflow_width)) != 0) ++widths;
+      uint32_t val = static_cast<uint32_t>(widths);
+      while (val >= max_overflow) {
+        Core::encode(e, max_overflow, max_overflow + 1, overflow_width, out);
+        val -= max_overflow;
+      }
+      Core::encode(e, val, val + 1, overflow_width, out);
+      for (int32_t j = 0; j < widths; ++j) {
+        const uint32_t d = (overflow >> (j * overflow_width)) & max_overflow;
+        Core::encode(e, d, d + 1, overflow_width, out);
+      }
+    }
+  }
+  Core::flush(e, out);
+  return true;
+}
+
+template <typename Core>
+inline bool unbounded_decode(const uint8_t* bytes, int64_t nbytes, const int32_t* index, int64_t total,
+                             const int32_t* cdf, int64_t rows, int64_t width, const int32_t* cdf_size,
+                             const int32_t* offset, int prec, int overflow_width, int debug_level,
+                             int32_t* out, std::string* err) {
+  if (!unbounded_check(index, total, cdf, rows, width, cdf_size, prec, debug_level, err)) return false;
+  std::vector<uint8_t> copy(bytes, bytes + nbytes);
+  copy.push_back(0);
+  typename Core::Dec d;
+  Core::open(d, copy.data(), static_cast<size_t>(nbytes));
+  const uint32_t max_overflow = (1u << overflow_width) - 1;
+  std::vector<int32_t> digits((1 << overflow_width) + 1);
+  for (size_t i = 0; i < digits.size(); ++i) digits[i] = static_cast<int32_t>(i);
+  for (int64_t i = 0; i < total; ++i) {
+    const int32_t row = index[i];
+    const int32_t max_value = cdf_size[row] - 2;
+    const int32_t* s = cdf + static_cast<int64_t>(row) * width;
+    int32_t value = Core::decode(d, s, max_value + 2, prec);
+    if (value == max_value) {
+      int32_t widths = 0;
+      uint32_t val;
+      do {
+        val = static_cast<uint32_t>(Core::decode(d, digits.data(), static_cast<int64_t>(digits.size()), overflow_width));
+        widths += static_cast<int32_t>(val);
+      } while (val == max_overflow && widths < 64);      // bounded: damaged input cannot spin
+      uint32_t overflow = 0;
+      for (int32_t j = 0; j < widths; ++j) {
+        const uint32_t v = static_cast<uint32_t>(Core::decode(d, digits.data(), static_cast<int64_t>(digits.size()), overflow_width));
+        if (j * overflow_width < 32) overflow |= v << (j * overflow_width);
+      }
+      value = static_cast<int32_t>(overflow >> 1);
+      if (overflow & 1) value = -value - 1; else value += max_value;
+    }
+    out[i] = value + offset[row];
+  }
+  return true;
+}
+
 }  // namespace tfc_oracle

@@ -156,6 +156,29 @@ def main():
         leg[name + "_precision"] = np.int32(prec)
         leg[name + "_bytes"] = np.frombuffer(enc, np.uint8).copy()
     np.savez_compressed(os.path.join(GOLD, "legacy_broadcast.npz"), **leg)
+
+    # ---- deprecated UnboundedIndexRangeEncode ---------------------------------
+    # (drivers restated from unbounded_index_range_coding_kernels.cc over the compiled core)
+    unb = {}
+    rng = np.random.Generator(np.random.PCG64(78))
+    rows, width, prec = 6, 14, 11
+    cdf = np.zeros((rows, width), np.int32)
+    size = np.zeros(rows, np.int32)
+    for r in range(rows):
+        n = int(rng.integers(3, width + 1))
+        size[r] = n
+        cuts = np.sort(rng.choice(np.arange(1, 1 << prec), n - 2, replace=False))
+        cdf[r, :n] = np.concatenate([[0], cuts, [1 << prec]])
+    offset = rng.integers(-6, 6, rows).astype(np.int32)
+    index = rng.integers(0, rows, (5, 41)).astype(np.int32)
+    data = rng.integers(-30, 45, (5, 41)).astype(np.int32)
+    data[0, :4] = [-70000, 70000, 2 ** 30, -(2 ** 30)]          # long overflow codes
+    unb.update(cdf=cdf, cdf_size=size, offset=offset, index=index, data=data, precision=np.int32(prec))
+    for ow in (1, 2, 4, 7, 16):
+        enc = ref.unbounded_index_range_encode(data, index, cdf, size, offset, prec, ow)
+        assert (ref.unbounded_index_range_decode(enc, index, cdf, size, offset, prec, ow) == data).all()
+        unb[f"w{ow}_bytes"] = np.frombuffer(enc, np.uint8).copy()
+    np.savez_compressed(os.path.join(GOLD, "unbounded_index.npz"), **unb)
     print("golden vectors written to", GOLD)
 
 

@@ -68,6 +68,10 @@ class CoderLib:
         f("decoder_free", None, C.c_void_p)
         f("range_encode", C.c_int64, _i16p, _i64p, C.c_int, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int64)
         f("range_decode", C.c_int, _u8p, C.c_int64, _i64p, C.c_int, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _i16p)
+        f("unbounded_index_range_encode", C.c_int64, _i32p, _i32p, C.c_int64, _i32p, C.c_int64, C.c_int64,
+          _i32p, _i32p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int64)
+        f("unbounded_index_range_decode", C.c_int, _u8p, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int64,
+          C.c_int64, _i32p, _i32p, C.c_int, C.c_int, C.c_int, _i32p)
         f("pmf_to_quantized_cdf", C.c_int, _f32p, C.c_int64, C.c_int64, C.c_int, _i32p)
         f("bench_roundtrip", C.c_int, _i32p, C.c_int, C.c_int64, C.c_int64, _i32p, C.c_int64,
           C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -209,6 +213,42 @@ class CoderLib:
                                 _ptr(cdf, _i32p), _ptr(cs, _i64p), cdf.ndim, precision,
                                 debug_level, _ptr(out, _i16p))
         if rc:
+            raise ValueError(self._err())
+        return out
+
+    # -- deprecated unbounded-index ops -------------------------------------------------
+    def unbounded_index_range_encode(self, data, index, cdf, cdf_size, offset, precision: int,
+                                     overflow_width: int, debug_level: int = 1) -> bytes:
+        data = np.ascontiguousarray(data, np.int32)
+        index = np.ascontiguousarray(index, np.int32)
+        cdf = np.ascontiguousarray(cdf, np.int32)
+        cdf_size = np.ascontiguousarray(cdf_size, np.int32)
+        offset = np.ascontiguousarray(offset, np.int32)
+        cap = 8 * data.size + 16
+        while True:
+            out = np.zeros(cap, np.uint8)
+            n = self._unbounded_index_range_encode(
+                _ptr(data, _i32p), _ptr(index, _i32p), data.size, _ptr(cdf, _i32p), cdf.shape[0],
+                cdf.shape[1], _ptr(cdf_size, _i32p), _ptr(offset, _i32p), precision, overflow_width,
+                debug_level, _ptr(out, _u8p), cap)
+            if n < 0:
+                raise ValueError(self._err())
+            if n <= cap:
+                return out[:n].tobytes()
+            cap = int(n)
+
+    def unbounded_index_range_decode(self, data: bytes, index, cdf, cdf_size, offset, precision: int,
+                                     overflow_width: int, debug_level: int = 1):
+        index = np.ascontiguousarray(index, np.int32)
+        cdf = np.ascontiguousarray(cdf, np.int32)
+        cdf_size = np.ascontiguousarray(cdf_size, np.int32)
+        offset = np.ascontiguousarray(offset, np.int32)
+        buf = np.frombuffer(data, np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+        out = np.zeros(index.shape, np.int32)
+        if self._unbounded_index_range_decode(
+                _ptr(buf, _u8p), len(data), _ptr(index, _i32p), index.size, _ptr(cdf, _i32p),
+                cdf.shape[0], cdf.shape[1], _ptr(cdf_size, _i32p), _ptr(offset, _i32p), precision,
+                overflow_width, debug_level, _ptr(out, _i32p)):
             raise ValueError(self._err())
         return out
 

@@ -154,6 +154,34 @@ int SYM(range_decode)(const uint8_t* bytes, int64_t nbytes, const int64_t* out_s
   return 0;
 }
 
+// ---- deprecated UnboundedIndexRangeEncode / Decode -------------------------------------
+int64_t SYM(unbounded_index_range_encode)(const int32_t* data, const int32_t* index, int64_t total,
+                                          const int32_t* cdf, int64_t rows, int64_t width,
+                                          const int32_t* cdf_size, const int32_t* offset, int precision,
+                                          int overflow_width, int debug_level, uint8_t* out, int64_t cap) {
+  std::string s, err;
+  if (!tfc_oracle::unbounded_encode<Core>(data, index, total, cdf, rows, width, cdf_size, offset, precision,
+                                          overflow_width, debug_level, &s, &err)) {
+    g_err = err;
+    return -1;
+  }
+  if (static_cast<int64_t>(s.size()) <= cap && !s.empty()) std::memcpy(out, s.data(), s.size());
+  return static_cast<int64_t>(s.size());
+}
+
+int SYM(unbounded_index_range_decode)(const uint8_t* bytes, int64_t nbytes, const int32_t* index,
+                                      int64_t total, const int32_t* cdf, int64_t rows, int64_t width,
+                                      const int32_t* cdf_size, const int32_t* offset, int precision,
+                                      int overflow_width, int debug_level, int32_t* out) {
+  std::string err;
+  if (!tfc_oracle::unbounded_decode<Core>(bytes, nbytes, index, total, cdf, rows, width, cdf_size, offset,
+                                          precision, overflow_width, debug_level, out, &err)) {
+    g_err = err;
+    return 1;
+  }
+  return 0;
+}
+
 // ---- PmfToQuantizedCdf -----------------------------------------------------
 // pmf [rows, n] float32 -> cdf [rows, n + 1] int32.  Validation as in
 // pmf_to_cdf_kernels.cc:58-86.

@@ -266,3 +266,34 @@ def test_steps_in_flight_on_separate_streams():
         for blob, dec, ok in runs:
             assert ok and (dec == values[k]).all()
             assert blob == b"".join(want)
+
+
+def test_unbounded_index_ops(tfc, golden, port):
+    """Deprecated UnboundedIndexRangeEncode/Decode on the device: golden bytes, random vs oracle,
+    argument checks (unbounded_index_range_coding_kernels.cc:54-143)."""
+    g = golden("unbounded_index.npz")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    args = (t(g["index"]), t(g["cdf"]), t(g["cdf_size"]), t(g["offset"]), int(g["precision"]))
+    for ow in (1, 2, 4, 7, 16):
+        want = g[f"w{ow}_bytes"].tobytes()
+        assert tfc.unbounded_index_range_encode(t(g["data"]), *args, ow) == want
+        back = tfc.unbounded_index_range_decode(want, *args, ow)
+        assert back.shape == g["index"].shape and (back.cpu().numpy() == g["data"]).all()
+    rng = np.random.default_rng(5)
+    index = rng.integers(0, 6, 3000).astype(np.int32)
+    data = np.round(rng.normal(0, 6, 3000)).astype(np.int32)
+    want = port.unbounded_index_range_encode(data, index, g["cdf"], g["cdf_size"], g["offset"], 11, 3)
+    assert tfc.unbounded_index_range_encode(t(data), t(index), *args[1:], 3) == want
+    assert (tfc.unbounded_index_range_decode(want, t(index), *args[1:], 3).cpu().numpy() == data).all()
+    bad = g["index"].copy()
+    bad[0, 0] = -1
+    with pytest.raises(ValueError, match=r"'index' has a value not in \[0, 6\): value=-1"):
+        tfc.unbounded_index_range_encode(t(g["data"]), t(bad), *args[1:], 4)
+    with pytest.raises(ValueError, match="same shape"):
+        tfc.unbounded_index_range_encode(t(g["data"][:2]), *args, 4)
+    with pytest.raises(ValueError, match="overflow_width"):
+        tfc.unbounded_index_range_encode(t(g["data"]), *args, 17)
+    bad_cdf = g["cdf"].copy()
+    bad_cdf[1, 0] = 1
+    with pytest.raises(ValueError, match="Each cdf should start from 0 and end at 2048"):
+        tfc.unbounded_index_range_decode(b"\x00", args[0], t(bad_cdf), *args[2:], 4)
