@@ -11,6 +11,7 @@ handle (plus a zero-copy device view on the handle).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -62,20 +63,24 @@ _TABLE_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
 _TABLE_CACHE_SIZE = 32
 
 
+_TABLE_CACHE_LOCK = threading.Lock()      # handles may be created from several host threads
+
+
 def _tables_for(lookup) -> _Tables:
     lookup = torch.as_tensor(lookup)
     if lookup.dtype != torch.int32:
         raise TypeError(f"`lookup` must be int32, got {lookup.dtype}")
     key = (lookup.data_ptr(), lookup._version, tuple(lookup.shape), str(lookup.device))
-    hit = _TABLE_CACHE.get(key)
-    if hit is not None and hit[0] is lookup:
-        _TABLE_CACHE.move_to_end(key)
-        return hit[1]
-    tables = _Tables(lookup)
-    _TABLE_CACHE[key] = (lookup, tables)   # holding `lookup` pins data_ptr
-    while len(_TABLE_CACHE) > _TABLE_CACHE_SIZE:
-        _TABLE_CACHE.popitem(last=False)
-    return tables
+    with _TABLE_CACHE_LOCK:
+        hit = _TABLE_CACHE.get(key)
+        if hit is not None and hit[0] is lookup:
+            _TABLE_CACHE.move_to_end(key)
+            return hit[1]
+        tables = _Tables(lookup)
+        _TABLE_CACHE[key] = (lookup, tables)   # holding `lookup` pins data_ptr
+        while len(_TABLE_CACHE) > _TABLE_CACHE_SIZE:
+            _TABLE_CACHE.popitem(last=False)
+        return tables
 
 
 class EncoderHandle:
