@@ -327,6 +327,10 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
   int qy[MT], qx[MT];
   bool live[MT];
   long long mm[MT];
+  // per lane, fixed for the whole K loop: element offset of (n, qy*sd - py0, qx*sd - px0, 8h) and
+  // the two coordinates the taps are added to (kept as int: the bounds test is two unsigned compares)
+  long long base_off[MT];
+  int iy0[MT], ix0[MT];
 #pragma unroll
   for (int p = 0; p < MT; ++p) {
     const long long m = ((pblock * 4 + wid) * MT + p) * 32 + (lane & 31);
@@ -335,26 +339,33 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
     qx[p] = static_cast<int>(mm[p] % c.OWq);
     qy[p] = static_cast<int>((mm[p] / c.OWq) % c.OHq);
     nn[p] = mm[p] / (static_cast<long long>(c.OWq) * c.OHq);
+    iy0[p] = qy[p] * c.sd - c.py0;
+    ix0[p] = qx[p] * c.sd - c.px0;
+    base_off[p] = ((nn[p] * c.H + iy0[p]) * c.W + ix0[p]) * c.Cin + 8 * h;
   }
-  const int cb = c.small_cin ? 1 : c.Cin / 16;
+  const int cb = c.Cin / 16;
+  // 16 zero bytes behind the packed weights: where lanes outside the image (or the tensor) read
+  const __bf16* zeros = reinterpret_cast<const __bf16*>(
+      static_cast<const unsigned char*>(packed) + static_cast<size_t>(c.groups) * c.ksteps * TILES * 64 * 16);
 
-  // B fragment of pixel tile p at K step ks: 8 input values at K offset 8h, zero outside the image
-  auto bload = [&](int ks, int p) -> u32x4 {
-    const __bf16* src;
-    bool ok = live[p];
-    if (c.small_cin) {
-      const int uy = ks / c.kw4, seg = ks % c.kw4;
-      src = x + ((nn[p] * c.Hp + (qy[p] * c.sd + uy)) * c.Wp + qx[p] * c.sd) * 4 + seg * 16 + 8 * h;
-    } else {
-      const int tap = ks / cb;
-      const int uy = tap / c.Ux, ux = tap % c.Ux;
-      const int iy = qy[p] * c.sd + uy - c.py0, ix = qx[p] * c.sd + ux - c.px0;
-      ok = ok && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W;
-      src = x + ((nn[p] * c.H + (ok ? iy : 0)) * c.W + (ok ? ix : 0)) * c.Cin + (ks % cb) * 16 + 8 * h;
+  // Position of a K step inside the (tap row, tap column, 16-channel block) order, advanced
+  // incrementally: the per-step divisions by runtime Cin / kernel width were the single largest
+  // block of non-MFMA instructions in the loop.
+  struct KPos { int uy, ux, cbi; long long off; };      // off = (uy * W + ux) * Cin + 16 * cbi
+  const long long row_step = static_cast<long long>(c.W - c.Ux) * c.Cin + 16;   // last tap of a row -> next row
+  auto advance = [&](KPos& k) {
+    k.off += 16;                       // next channel block, or the next pixel of the row: contiguous
+    if (++k.cbi == cb) {
+      k.cbi = 0;
+      if (++k.ux == c.Ux) { k.ux = 0; ++k.uy; k.off += row_step - 16; }
     }
-    u32x4 v = *reinterpret_cast<const u32x4*>(src);      // always a valid address
-    if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-    return v;
+  };
+  // B fragment of pixel tile p at K position k: 8 input values at K offset 8h, zero outside the image
+  auto bload = [&](const KPos& k, int p) -> u32x4 {
+    const bool ok = live[p] && static_cast<unsigned int>(iy0[p] + k.uy) < static_cast<unsigned int>(c.H) &&
+                    static_cast<unsigned int>(ix0[p] + k.ux) < static_cast<unsigned int>(c.W) && k.uy < c.Uy;
+    const __bf16* src = ok ? x + base_off[p] + k.off : zeros;
+    return *reinterpret_cast<const u32x4*>(src);
   };
 
   f32x16 acc[MT][TILES];
@@ -390,10 +401,13 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
   wfetch(0);
   wstore(0);
   u32x4 bq[kPF][MT];
+  KPos kpre{0, 0, 0, 0};               // position of the next B fragment to request
 #pragma unroll
-  for (int k = 0; k < kPF; ++k)
+  for (int k = 0; k < kPF; ++k) {
 #pragma unroll
-    for (int p = 0; p < MT; ++p) bq[k][p] = bload(min(k, c.ksteps - 1), p);
+    for (int p = 0; p < MT; ++p) bq[k][p] = bload(kpre, p);
+    advance(kpre);
+  }
   __syncthreads();
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -405,7 +419,6 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
     for (int t = 0; t < TILES; ++t) af[0][t] = abase[t * 64];
 #pragma unroll
     for (int kk = 0; kk < kChunk2; ++kk) {
-      const int ks = chunk * kChunk2 + kk;
       if (kk + 1 < kChunk2) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) af[(kk + 1) & 1][t] = abase[((kk + 1) * TILES + t) * 64];
@@ -413,9 +426,10 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
       bf16x8 bfrag[MT];
 #pragma unroll
       for (int p = 0; p < MT; ++p) bfrag[p] = __builtin_bit_cast(bf16x8, bq[kk % kPF][p]);
-      // refill the ring slot: K step ks + PF (weights beyond ksteps are zero, any valid B will do)
+      // refill the ring slot with K step ks + PF (past the last tap row: zeros)
 #pragma unroll
-      for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = bload(min(ks + kPF, c.ksteps - 1), p);
+      for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = bload(kpre, p);
+      advance(kpre);
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -490,7 +504,8 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
 
   DevBuf packed, padded;
   const long long frags = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
-  TFC_HIP(packed.alloc(static_cast<size_t>(frags) * FB, st));
+  TFC_HIP(packed.alloc(static_cast<size_t>(frags) * FB + 16, st));
+  TFC_HIP(hipMemsetAsync(static_cast<unsigned char*>(packed.p) + static_cast<size_t>(frags) * FB, 0, 16, st));
   hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(static_cast<unsigned>(ceil_div(frags, 256))),
                      dim3(256), 0, st, w, g, c, packed.p);
   const T* xin = static_cast<const T*>(x);
