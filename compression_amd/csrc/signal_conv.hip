@@ -423,18 +423,17 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
 #pragma unroll
         for (int t = 0; t < TILES; ++t) af[(kk + 1) & 1][t] = abase[((kk + 1) * TILES + t) * 64];
       }
-      bf16x8 bfrag[MT];
-#pragma unroll
-      for (int p = 0; p < MT; ++p) bfrag[p] = __builtin_bit_cast(bf16x8, bq[kk % kPF][p]);
-      // refill the ring slot with K step ks + PF (past the last tap row: zeros)
-#pragma unroll
-      for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = bload(kpre, p);
-      advance(kpre);
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int p = 0; p < MT; ++p)
-          acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][t], bfrag[p], acc[p][t], 0, 0, 0);
+          acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              af[kk & 1][t], __builtin_bit_cast(bf16x8, bq[kk % kPF][p]), acc[p][t], 0, 0, 0);
+      // refill the ring slot with K step ks + PF (past the last tap row: zeros); after the MFMAs
+      // that read it so that no copy of the slot is needed
+#pragma unroll
+      for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = bload(kpre, p);
+      advance(kpre);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (chunk + 1 < nchunks) wstore(buf ^ 1);
