@@ -9,7 +9,7 @@ HBM: CreateRangeEncoder -> EntropyEncodeChannel -> EntropyEncodeFinalize ->
 CreateRangeDecoder -> EntropyDecodeChannel -> EntropyDecodeFinalize, all through
 the C ABI (libtfc_hip.so).  Prints ONE JSON line on rank 0.
 
-Steps are independent batches, so `--inflight D` (default 4) of them are in flight at a
+Steps are independent batches, so `--inflight D` (default 6) of them are in flight at a
 time, each on its own host thread and HIP stream: one 512-stream step only puts one wave on
 half of the GPU's 1024 SIMDs and every wave spends a third of its time in un-hideable
 scalar/vector synchronisation stalls, which co-resident waves of other steps fill.  The
@@ -32,6 +32,12 @@ import json
 import os
 import sys
 import time
+
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
+# kernels that share a queue serialise: with the steps in flight below (plus torch's own streams)
+# that capped the round trip at ~10 Gpixels/s; 16 queues lift it to ~12.5-13.  Read at runtime
+# initialisation, so it has to be in the environment before torch touches the device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -268,7 +274,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="independent steps in flight (host threads x HIP streams); 1 = serial")
     ap.add_argument("--escape-fraction", type=float, default=0.0)
     ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
