@@ -44,6 +44,7 @@ SIGNATURES = {
                                                 _vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "tfc_unbounded_index_range_decode": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                                 _int, _vp, _vp]),
+    "tfc_stochastic_round": (_int, [_vp, _int, _i64, C.c_float, _vp, _i64, _vp, _vp]),
     "tfc_free": (None, [_vp]),
     "tfc_pmf_to_quantized_cdf": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
     "tfc_gdn_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp]),

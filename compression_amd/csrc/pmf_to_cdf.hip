@@ -8,17 +8,23 @@
 //
 // The reference keeps the candidates in a sorted vector and re-inserts the
 // touched item BEHIND every item with an equal key (find_if + rotate), i.e. a
-// FIFO among ties; its initial order among ties is whatever libstdc++'s
-// std::sort produces (disclaimed as platform-dependent,
-// cc/ops/pmf_to_cdf_ops.cc:45-49).  Here ties are ordered by (key, ticket):
-// tickets start as the symbol index and a touched item takes the next ticket,
-// which is exactly the reference's behaviour under a stable initial sort.
+// FIFO among ties; its initial order among ties is whatever std::sort
+// produces.  Ties are the normal case (symmetric tables: pmf[i] == pmf[n-1-i])
+// and decide which symbol of a tied pair is adjusted, so the initial order is
+// reproduced too: lane 0 runs libstdc++'s introsort (sort_order.h, the library
+// the reference's Linux builds use) over (key, symbol) in LDS — serial, but a
+// table is built once per model — and the resulting rank is the item's first
+// ticket; a touched item takes the next ticket.  Selection is then a
+// wave-wide arg-min over (key, ticket), which visits items in exactly the
+// order of the reference's vector.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 
 #include "../../include/tfc_hip.h"
 #include "common.h"
+#include "sort_order.h"
 
 namespace tfc {
 
@@ -52,6 +58,21 @@ __device__ void rebalance(const float* pmf, int n, int steps, int* v, double* ke
     key[i] = key_of<SHRINK>(static_cast<double>(pmf[i]), v[i]);
     ticket[i] = static_cast<unsigned int>(i);
   }
+  __syncthreads();
+  // initial order: position p of the sorted sequence holds symbol ticket[p]
+  if (lane == 0) {
+    using Before = typename std::conditional<SHRINK, KeyAscending, KeyDescending>::type;
+    SortOrder<Before>{key, ticket, Before{}}.sort(n);
+  }
+  __syncthreads();
+  // invert into rank-by-symbol (through the key array, which is rebuilt afterwards)
+  unsigned int* rank = reinterpret_cast<unsigned int*>(key);
+  for (int pos = lane; pos < n; pos += 64) rank[ticket[pos]] = static_cast<unsigned int>(pos);
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) ticket[i] = rank[i];
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) key[i] = key_of<SHRINK>(static_cast<double>(pmf[i]), v[i]);
+  __syncthreads();
   unsigned int next_ticket = static_cast<unsigned int>(n);
   for (int it = 0; it < steps; ++it) {
     Best b;

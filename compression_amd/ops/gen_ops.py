@@ -25,6 +25,7 @@ __all__ = [
     "entropy_encode_channel", "entropy_encode_finalize", "entropy_encode_index",
     "pmf_to_quantized_cdf", "range_encode", "range_decode",
     "unbounded_index_range_encode", "unbounded_index_range_decode",
+    "stochastic_round",
 ]
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -439,4 +440,30 @@ def unbounded_index_range_decode(encoded, index, cdf, cdf_size, offset, precisio
         buf.ctypes.data, len(encoded), index.data_ptr(), index.numel(), cdf.data_ptr(), cdf.shape[0],
         cdf.shape[1], cdf_size.data_ptr(), offset.data_ptr(), int(precision), int(overflow_width),
         int(debug_level), out.data_ptr(), _lib.stream_ptr()))
+    return out
+
+
+def stochastic_round(inputs, step_size, seed) -> torch.Tensor:
+    """StochasticRound (cc/ops/quantization_ops.cc:21-44, quantization_kernels.cc:47-96): rounds
+    `inputs / step_size` down or up with probability equal to the fractional part; int32, same shape.
+
+    `seed`: int32 values of any shape — equal seeds give the reference's results bit for bit (one
+    xoshiro256+ stream in flat element order); an empty seed seeds from the clock."""
+    device = _lib.require_device()
+    inputs = torch.as_tensor(inputs)
+    if inputs.dtype not in _DTYPE_CODE:
+        raise TypeError(f"`inputs` must be bfloat16, float16 or float32: {inputs.dtype}")
+    step = torch.as_tensor(step_size)
+    if step.dim() != 0:
+        raise ValueError("step_size must be a scalar.")
+    seed = np.ascontiguousarray(
+        seed.detach().cpu().numpy() if isinstance(seed, torch.Tensor) else np.asarray(seed, dtype=np.int64))
+    if seed.size and (seed.min() < -2**31 or seed.max() > 2**31 - 1):
+        raise TypeError("`seed` must hold int32 values")
+    seed = seed.astype(np.int32).reshape(-1)
+    inputs = inputs.to(device).contiguous()
+    out = torch.empty(inputs.shape, dtype=torch.int32, device=device)
+    _lib.check(_lib.lib().tfc_stochastic_round(
+        inputs.data_ptr(), _DTYPE_CODE[inputs.dtype], inputs.numel(), float(step),
+        seed.ctypes.data if seed.size else None, seed.size, out.data_ptr(), _lib.stream_ptr()))
     return out

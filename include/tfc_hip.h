@@ -190,6 +190,16 @@ int tfc_unbounded_index_range_decode(const uint8_t* encoded, int64_t encoded_len
                                      const int32_t* cdf_size, const int32_t* offset, int precision,
                                      int overflow_width, int debug_level, int32_t* out, void* stream);
 
+/* StochasticRound — cc/ops/quantization_ops.cc:21-44, cc/kernels/quantization_kernels.cc:47-96.
+ * outputs[i] = floor(inputs[i] / step_size), plus 1 when the i-th draw of ONE xoshiro256+ generator
+ * (seeded from `seed` with the C++ standard's seed_seq; 24-bit draws in [0, 1)) is below the fractional
+ * part — the same draw for the same flat position as the reference's serial loop, so results are
+ * identical for identical seeds.  inputs DEV float32 (dtype 0) / bfloat16 (1) / float16 (2), n elements;
+ * seed HOST int32[seed_len]; seed_len 0 seeds from the clock (quantization_kernels.cc:75-81); outputs DEV
+ * int32.  Asynchronous on `stream`. */
+int tfc_stochastic_round(const void* inputs, int dtype, int64_t n, float step_size,
+                         const int32_t* seed, int64_t seed_len, int32_t* outputs, void* stream);
+
 void tfc_free(void* p);
 
 /* ------------------------------------------------------------------------ */

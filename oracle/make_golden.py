@@ -30,6 +30,55 @@ def mt19937_mod5(n):
     return (vals % 5).astype(np.int32)
 
 
+# StochasticRound fixtures: inputs come from a formula (so only the outputs are stored) and cover four
+# waves of the GPU kernel with a ragged tail.
+STOCHASTIC_N = 50001
+STOCHASTIC_CASES = {  # name: (dtype code, step_size, seed)
+    "f32_step1": (0, 1.0, (123, 456)),
+    "f32_step075": (0, 0.75, (7,)),
+    "bf16_step1": (1, 1.0, tuple(range(1, 11))),
+    "f16_step05": (2, 0.5, (-5, 2 ** 31 - 1)),
+}
+
+
+def stochastic_inputs(n, code):
+    """Values in [-100, 100): float32 array (code 0) or (uint16 bit patterns, code) for bfloat16 / float16."""
+    i = np.arange(n, dtype=np.uint64)
+    x = (((i * np.uint64(2654435761)) % np.uint64(1 << 32)).astype(np.float64) / 2.0 ** 32 * 200.0 - 100.0)
+    x = x.astype(np.float32)
+    x[::97] = np.round(x[::97])          # exact integers stay put
+    x[5::101] = np.floor(x[5::101]) + 0.5
+    if code == 0:
+        return x
+    if code == 1:
+        return ((x.view(np.uint32) >> 16).astype(np.uint16), 1)
+    return (x.astype(np.float16).view(np.uint16), 2)
+
+
+def pmf_cases():
+    """[(pmf [rows, n] float32, precision)]: exactly symmetric Gaussian / Laplacian tables (tied pairs),
+    flat and two-level tables (almost everything tied), random tables, over- and under-normalised."""
+    from scipy.stats import laplace, norm
+    rng = np.random.Generator(np.random.PCG64(2024))
+    cases = []
+    for dist in (norm, laplace):
+        for scale in np.exp(np.linspace(np.log(0.11), np.log(64), 14)):
+            half = int(np.ceil(scale * 6)) + 1
+            x = np.arange(-half, half + 1)
+            pmf = (dist.cdf((x + .5) / scale) - dist.cdf((x - .5) / scale)).astype(np.float32)
+            cases.append((np.maximum(pmf, pmf[::-1])[None], 12 if len(cases) % 3 else 16))
+    for n in (2, 16, 17, 33, 100, 257):
+        cases.append((np.full((1, n), 1.0 / n, np.float32), 10))
+        two = np.where(np.arange(n) % 3 == 0, 2.0, 1.0).astype(np.float32)
+        cases.append(((two / two.sum())[None] * np.float32(1.3), 12))
+        cases.append(((two / two.sum())[None] * np.float32(0.6), 12))
+    for n in (5, 64, 300):
+        w = rng.random((4, n)) ** 2 + 1e-4
+        for s in (0.5, 1.0, 1.7):
+            cases.append(((w / w.sum(-1, keepdims=True) * s).astype(np.float32), 12))
+    return cases
+
+
 def main():
     ref = oracle.reference()
     assert ref is not None, "oracle/_ref not built (needs /root/reference)"
@@ -179,6 +228,23 @@ def main():
         assert (ref.unbounded_index_range_decode(enc, index, cdf, size, offset, prec, ow) == data).all()
         unb[f"w{ow}_bytes"] = np.frombuffer(enc, np.uint8).copy()
     np.savez_compressed(os.path.join(GOLD, "unbounded_index.npz"), **unb)
+    # ---- PmfToQuantizedCdf (the reference kernel file itself, compiled behind oracle/shim) ----
+    # Tie-heavy on purpose: which of two equal-penalty symbols is adjusted depends on std::sort's order.
+    pc = {}
+    for k, (pmf, prec) in enumerate(pmf_cases()):
+        pc[f"pmf{k}"] = pmf
+        pc[f"precision{k}"] = np.int32(prec)
+        pc[f"cdf{k}"] = ref.pmf_to_quantized_cdf(pmf, prec)
+    pc["count"] = np.int32(k + 1)
+    np.savez_compressed(os.path.join(GOLD, "pmf_to_cdf.npz"), **pc)
+
+    # ---- StochasticRound (the reference kernel file itself, compiled behind oracle/shim) ----
+    sr = {}
+    for name, (code, step, seed) in STOCHASTIC_CASES.items():
+        out = ref.stochastic_round(stochastic_inputs(STOCHASTIC_N, code), step, seed)
+        assert np.abs(out).max() < 2 ** 15
+        sr[name] = out.astype(np.int16)
+    np.savez_compressed(os.path.join(GOLD, "stochastic_round.npz"), **sr)
     print("golden vectors written to", GOLD)
 
 

@@ -32,7 +32,7 @@ def build(force: bool = False) -> None:
     target = os.path.join(_HERE, "libtfc_oracle.so")
     if force or not os.path.exists(target) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(target)
-        for f in ("tfc_oracle.cc", "coder_core.h", "drivers.h", "pmf_to_cdf.h")
+        for f in ("tfc_oracle.cc", "coder_core.h", "drivers.h", "pmf_to_cdf.h", "quantization.h")
     ):
         subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
     elif os.path.isdir("/root/reference") and not os.path.exists(
@@ -73,6 +73,7 @@ class CoderLib:
         f("unbounded_index_range_decode", C.c_int, _u8p, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int64,
           C.c_int64, _i32p, _i32p, C.c_int, C.c_int, C.c_int, _i32p)
         f("pmf_to_quantized_cdf", C.c_int, _f32p, C.c_int64, C.c_int64, C.c_int, _i32p)
+        f("stochastic_round", C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_float, _i32p, C.c_int64, _i32p)
         f("bench_roundtrip", C.c_int, _i32p, C.c_int, C.c_int64, C.c_int64, _i32p, C.c_int64,
           C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
           _i64p, C.POINTER(C.c_int))
@@ -261,6 +262,24 @@ class CoderLib:
         if self._pmf_to_quantized_cdf(_ptr(pmf, _f32p), rows, n, precision, _ptr(out, _i32p)):
             raise ValueError(self._err())
         return out.reshape(pmf.shape[:-1] + (n + 1,))
+
+
+    # -- quantization ------------------------------------------------------
+    def stochastic_round(self, inputs, step_size: float, seed):
+        """`inputs`: float32 array, or uint16 bit patterns with dtype_code 1 (bfloat16) / 2 (float16)
+        given as a (bits, code) tuple.  quantization_kernels.cc:47-96."""
+        code = 0
+        if isinstance(inputs, tuple):
+            inputs, code = inputs
+            inputs = np.ascontiguousarray(inputs, np.uint16)
+        else:
+            inputs = np.ascontiguousarray(inputs, np.float32)
+        seed = np.ascontiguousarray(seed, np.int32).reshape(-1)
+        out = np.zeros(inputs.shape, np.int32)
+        if self._stochastic_round(inputs.ctypes.data, code, inputs.size, float(step_size), _ptr(seed, _i32p),
+                                  seed.size, _ptr(out, _i32p)):
+            raise ValueError(self._err())
+        return out
 
 
 _cache = {}

@@ -8,10 +8,10 @@
 // only claimed for builds against the same libstdc++ (the reference makes the
 // same caveat, cc/ops/pmf_to_cdf_ops.cc:45-49).
 //
-// Parity status: PINNED ONLY BY INVARIANTS — TensorFlow is not installable
-// here, so the op itself cannot be run; the reference's tests for this op
-// check invariants only (pmf_to_cdf_kernels_test.cc:70-97), which
-// tests/test_pmf_to_cdf.py ports.
+// Parity status: PINNED — oracle/Makefile compiles the reference's own kernel file
+// (cc/kernels/pmf_to_cdf_kernels.cc) verbatim behind a small OpKernel shim (oracle/shim/tensorflow)
+// into oracle/_ref; tests/test_oracle.py checks restatement == that op on tie-heavy inputs and both ==
+// tests/golden/pmf_to_cdf.npz (generated from it by oracle/make_golden.py).
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -21,6 +21,12 @@ using Core = tfc_oracle::OracleCore;
 #endif
 #include "drivers.h"
 #include "pmf_to_cdf.h"
+#ifdef TFC_USE_REF
+#include <memory>
+#include "tensorflow/core/framework/op_kernel.h"  // oracle/shim: registry of the reference's kernels
+#else
+#include "quantization.h"
+#endif
 
 using tfc_oracle::StreamDecoder;
 using tfc_oracle::StreamEncoder;
@@ -187,6 +193,21 @@ int SYM(unbounded_index_range_decode)(const uint8_t* bytes, int64_t nbytes, cons
 // pmf_to_cdf_kernels.cc:58-86.
 int SYM(pmf_to_quantized_cdf)(const float* pmf, int64_t rows, int64_t n, int precision,
                               int32_t* cdf) {
+#ifdef TFC_USE_REF
+  // the reference's own PmfToCdfOp (pmf_to_cdf_kernels.cc, compiled verbatim behind oracle/shim)
+  auto it = tfc_shim::registry().find({"PmfToQuantizedCdf", std::type_index(typeid(void))});
+  if (it == tfc_shim::registry().end()) { g_err = "PmfToQuantizedCdf: reference kernel not registered"; return 1; }
+  tensorflow::OpKernelConstruction construction;
+  construction.int_attrs["precision"] = precision;
+  std::unique_ptr<tensorflow::OpKernel> op(it->second(&construction));
+  if (!construction.status.ok()) { g_err = construction.status.message(); return 1; }
+  tensorflow::OpKernelContext ctx;
+  ctx.inputs.emplace_back(const_cast<float*>(pmf), tensorflow::TensorShape({rows, n}));
+  ctx.output = tensorflow::Tensor(cdf, tensorflow::TensorShape({rows, n + 1}));
+  op->Compute(&ctx);
+  if (!ctx.status.ok()) { g_err = ctx.status.message(); return 1; }
+  return 0;
+#endif
   if (!(0 < precision && precision <= 16)) { g_err = "`precision` must be in [1, 16]"; return 1; }
   if (n <= 1) { g_err = "`pmf` size should be at least 2 in the last axis."; return 1; }
   for (int64_t i = 0; i < rows * n; ++i)
@@ -197,6 +218,67 @@ int SYM(pmf_to_quantized_cdf)(const float* pmf, int64_t rows, int64_t n, int pre
   for (int64_t r = 0; r < rows; ++r)
     tfc_oracle::pmf_row_to_cdf(pmf + r * n, n, precision, cdf + r * (n + 1));
   return 0;
+}
+
+// StochasticRound; dtype 0 float32, 1 bfloat16, 2 float16 (bit patterns).  Empty seed (clock) is not
+// offered: there is nothing to compare.
+int SYM(stochastic_round)(const void* x, int dtype, int64_t n, float step, const int32_t* seed,
+                          int64_t seed_len, int32_t* out) {
+  if (dtype < 0 || dtype > 2 || seed_len <= 0) {
+    g_err = "stochastic_round: dtype must be 0..2 and the seed non-empty";
+    return 1;
+  }
+#ifdef TFC_USE_REF
+  const std::type_index ti = dtype == 0   ? std::type_index(typeid(float))
+                             : dtype == 1 ? std::type_index(typeid(tensorflow::bfloat16))
+                                          : std::type_index(typeid(Eigen::half));
+  auto it = tfc_shim::registry().find({"StochasticRound", ti});
+  if (it == tfc_shim::registry().end()) {
+    g_err = "stochastic_round: reference kernel not registered";
+    return 1;
+  }
+  tensorflow::OpKernelConstruction construction;
+  std::unique_ptr<tensorflow::OpKernel> op(it->second(&construction));
+  tensorflow::OpKernelContext ctx;
+  ctx.inputs.emplace_back(const_cast<void*>(x), tensorflow::TensorShape({n}));
+  ctx.inputs.emplace_back(&step, tensorflow::TensorShape());
+  ctx.inputs.emplace_back(const_cast<int32_t*>(seed), tensorflow::TensorShape({seed_len}));
+  ctx.output = tensorflow::Tensor(out, tensorflow::TensorShape({n}));
+  op->Compute(&ctx);
+  if (!ctx.status.ok()) {
+    g_err = ctx.status.message();
+    return 1;
+  }
+  return 0;
+#else
+  std::vector<float> wide(static_cast<size_t>(n));
+  for (int64_t i = 0; i < n; ++i) {
+    if (dtype == 0) {
+      wide[i] = static_cast<const float*>(x)[i];
+    } else {
+      const uint16_t h = static_cast<const uint16_t*>(x)[i];
+      uint32_t u;
+      if (dtype == 1) {
+        u = static_cast<uint32_t>(h) << 16;
+      } else {  // IEEE half -> float through the exponent re-bias; subnormals via scaling
+        const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16;
+        const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+        if (e == 0) {
+          float f = static_cast<float>(m) * 0x1.0p-24f;
+          std::memcpy(&u, &f, 4);
+          u |= sign;
+        } else if (e == 31) {
+          u = sign | 0x7F800000u | (m << 13);
+        } else {
+          u = sign | ((e + 112u) << 23) | (m << 13);
+        }
+      }
+      std::memcpy(&wide[i], &u, 4);
+    }
+  }
+  tfc_oracle::stochastic_round(wide.data(), n, step, seed, seed_len, out);
+  return 0;
+#endif
 }
 
 }  // extern "C"

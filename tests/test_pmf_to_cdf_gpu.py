@@ -1,7 +1,7 @@
-"""GPU tier: PmfToQuantizedCdf kernel — the reference's own invariant tests
-(pmf_to_cdf_kernels_test.cc:70-143) plus equality with the CPU oracle on
-tie-free inputs (ties are platform-specific in the reference, see
-compression_amd/csrc/pmf_to_cdf.hip)."""
+"""GPU tier: PmfToQuantizedCdf kernel — equality with tables produced by the reference's own kernel
+file (tests/golden/pmf_to_cdf.npz, tie-heavy: symmetric, flat and two-level tables), the reference's
+invariant tests (pmf_to_cdf_kernels_test.cc:70-143) and equality with the CPU oracle on random and on
+tied inputs."""
 import numpy as np
 import pytest
 import torch
@@ -26,6 +26,28 @@ def test_invariants_and_oracle_equality(port):
                 want = port.pmf_to_quantized_cdf(pmf, prec)
                 # random continuous masses have no exact ties
                 assert (cdf == want).all(), (prec, n, scale)
+
+
+def test_golden_tables_with_ties(golden):
+    import compression_amd as tfc
+    g = golden("pmf_to_cdf.npz")
+    for k in range(int(g["count"])):
+        pmf, prec = g[f"pmf{k}"], int(g[f"precision{k}"])
+        cdf = tfc.pmf_to_quantized_cdf(torch.from_numpy(pmf).cuda(), prec).cpu().numpy()
+        assert (cdf == g[f"cdf{k}"]).all(), (k, pmf.shape, prec)
+
+
+def test_tied_inputs_match_oracle(port):
+    """Few distinct masses => long runs of equal penalties, rows up to 1500 wide (the quicksort part of
+    the order runs many levels deep)."""
+    import compression_amd as tfc
+    rng = np.random.default_rng(11)
+    for n in (3, 40, 333, 1500):
+        for scale in (0.4, 1.0, 1.6):
+            pmf = rng.integers(0, 5, (5, n)).astype(np.float32) + np.float32(0.01)
+            pmf = pmf / pmf.sum(-1, keepdims=True) * np.float32(scale)
+            cdf = tfc.pmf_to_quantized_cdf(torch.from_numpy(pmf).cuda(), 12).cpu().numpy()
+            assert (cdf == port.pmf_to_quantized_cdf(pmf, 12)).all(), (n, scale)
 
 
 def test_validation():
