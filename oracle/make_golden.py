@@ -1,6 +1,7 @@
-"""TEST INFRASTRUCTURE — regenerates tests/golden/*.npz from the reference's own
-range coder core (oracle/_ref/libtfc_ref.so, compiled verbatim from
-/root/reference/tensorflow_compression/cc/lib/range_coder.cc).
+"""TEST INFRASTRUCTURE — regenerates tests/golden/*.npz from the reference's own code
+(oracle/_ref/libtfc_ref.so: cc/lib/range_coder.cc and the op kernel files
+cc/kernels/{range_coder,pmf_to_cdf,quantization}_kernels.cc compiled verbatim from /root/reference
+behind the shim headers in oracle/shim).
 
 Run in the build container (needs /root/reference):  python oracle/make_golden.py
 The vectors are committed so that the GPU box (no /root/reference) and the
@@ -53,6 +54,19 @@ def stochastic_inputs(n, code):
     if code == 1:
         return ((x.view(np.uint32) >> 16).astype(np.uint16), 1)
     return (x.astype(np.float16).view(np.uint16), 2)
+
+
+def ops_roundtrip(ref, lookup, value, index):
+    """Strings from the reference's OWN op kernels (CreateRangeEncoder -> EntropyEncode{Channel,Index} ->
+    EntropyEncodeFinalize, range_coder_kernels.cc compiled verbatim behind oracle/shim), decoded back with
+    its decoder ops; the restated drivers over the compiled core must give the same bytes."""
+    streams, elems = value.shape
+    strings = ref.ops_encode(lookup, [streams], [(value, index)])
+    outs, ok = ref.ops_decode(lookup, strings, [streams], [([elems], index)])
+    assert (outs[0] == value).all() and ok.all()
+    again, blob, offs = ref.encode(lookup, value, index=index, threads=1)
+    assert again == strings
+    return strings, blob, offs
 
 
 def pmf_cases():
@@ -126,9 +140,7 @@ def main():
     cdfs = [port.pmf_to_quantized_cdf(p, 12) for p in pmfs]
     lookup = synthetic.assemble_lookup(cdfs, 12, overflow=True)
     val = synthetic.sample_symbols(lookup, streams=6, elems=1000, seed=11, escape_fraction=0.02)
-    strings, blob, offs = ref.encode(lookup, val, threads=1)
-    dec, ok = ref.decode(lookup, strings, 1000)
-    assert (dec == val).all() and ok.all()
+    strings, blob, offs = ops_roundtrip(ref, lookup, val, None)
     rng = np.random.Generator(np.random.PCG64(5))
     idx = rng.integers(0, 24, size=val.shape).astype(np.int32)
     val_i = np.zeros_like(val)
@@ -140,9 +152,7 @@ def main():
         val_i[m] = np.maximum(s, 0)
     esc = rng.random(val.shape) < 0.02
     val_i = np.where(esc, rng.integers(-3000, 3000, size=val.shape), val_i).astype(np.int32)
-    strings_i, blob_i, offs_i = ref.encode(lookup, val_i, index=idx, threads=1)
-    dec_i, ok_i = ref.decode(lookup, strings_i, 1000, index=idx)
-    assert (dec_i == val_i).all() and ok_i.all()
+    strings_i, blob_i, offs_i = ops_roundtrip(ref, lookup, val_i, idx)
     np.savez_compressed(
         os.path.join(GOLD, "streams_escape.npz"), lookup=lookup, value=val, blob=blob, offsets=offs,
         index=idx, value_indexed=val_i, blob_indexed=blob_i, offsets_indexed=offs_i)
@@ -167,9 +177,7 @@ def main():
             c = rowsM[j % 5]
             u = rng.integers(0, 1 << prec, size=3)
             v[:, j] = np.searchsorted(c, u, side="right") - 1
-        strs, b, o = ref.encode(mat, v)
-        d, okk = ref.decode(mat, strs, 777)
-        assert (d == v).all() and okk.all()
+        strs, b, o = ops_roundtrip(ref, mat, v, None)
         sweep[f"p{prec}_lookup"] = mat
         sweep[f"p{prec}_value"] = v
         sweep[f"p{prec}_blob"] = b

@@ -46,7 +46,19 @@ def _ptr(a, typ):
 
 
 class CoderLib:
-    """One of the two oracle libraries, addressed by symbol prefix."""
+    """One of the two oracle libraries, addressed by symbol prefix.
+
+    The legacy / deprecated op methods run the restated drivers (over this library's coder core); on the
+    reference library, `use_op_kernels()` returns a view whose methods run the reference's own op kernels
+    (range_coding_kernels.cc, unbounded_index_range_coding_kernels.cc compiled verbatim) instead."""
+
+    def use_op_kernels(self):
+        assert self.kind == "reference"
+        import copy
+        view = copy.copy(self)
+        for name in ("range_encode", "range_decode", "unbounded_index_range_encode", "unbounded_index_range_decode"):
+            setattr(view, "_" + name, getattr(self, "_op_" + name))
+        return view
 
     def __init__(self, path: str, prefix: str):
         self.path = path
@@ -77,6 +89,21 @@ class CoderLib:
         f("bench_roundtrip", C.c_int, _i32p, C.c_int, C.c_int64, C.c_int64, _i32p, C.c_int64,
           C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
           _i64p, C.POINTER(C.c_int))
+
+        if self.kind == "reference":   # the reference's own op kernels, oracle/tfc_oracle.cc (TFC_USE_REF)
+            f("ops_encoder_create", C.c_void_p, _i64p, C.c_int, _i32p, C.c_int, C.c_int64, C.c_int64)
+            f("ops_encoder_encode", C.c_int, C.c_void_p, _i32p, _i32p, _i64p, C.c_int)
+            f("ops_encoder_finalize", C.c_int64, C.c_void_p, _u8p, C.c_int64, _i64p)
+            f("ops_decoder_create", C.c_void_p, _u8p, _i64p, _i64p, C.c_int, _i32p, C.c_int, C.c_int64, C.c_int64)
+            f("ops_decoder_decode", C.c_int, C.c_void_p, _i64p, C.c_int, _i32p, _i32p)
+            f("ops_decoder_finalize", C.c_int, C.c_void_p, _u8p)
+            f("ops_free", None, C.c_void_p)
+            f("op_range_encode", C.c_int64, _i16p, _i64p, C.c_int, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int64)
+            f("op_range_decode", C.c_int, _u8p, C.c_int64, _i64p, C.c_int, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _i16p)
+            f("op_unbounded_index_range_encode", C.c_int64, _i32p, _i32p, C.c_int64, _i32p, C.c_int64, C.c_int64,
+              _i32p, _i32p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int64)
+            f("op_unbounded_index_range_decode", C.c_int, _u8p, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int64,
+              C.c_int64, _i32p, _i32p, C.c_int, C.c_int, C.c_int, _i32p)
 
     def _f(self, name, restype, *argtypes):
         fn = getattr(self._l, self._p + name)
@@ -263,6 +290,66 @@ class CoderLib:
             raise ValueError(self._err())
         return out.reshape(pmf.shape[:-1] + (n + 1,))
 
+
+    # -- the reference's op kernels themselves (reference build only) -------
+    def ops_encode(self, lookup, handle_shape, calls):
+        """CreateRangeEncoder -> EntropyEncode{Channel,Index} per (value, index|None) in `calls` ->
+        EntropyEncodeFinalize, all through range_coder_kernels.cc compiled verbatim.  Returns the strings
+        (flat list over the handle shape)."""
+        lookup = np.ascontiguousarray(lookup, np.int32)
+        lookup, rank, rows, cols = self._lookup_args(lookup)
+        hs = np.asarray(handle_shape, np.int64).reshape(-1)
+        h = self._ops_encoder_create(_ptr(hs, _i64p), hs.size, _ptr(lookup, _i32p), rank, rows, cols)
+        if not h:
+            raise ValueError(self._err())
+        try:
+            for value, index in calls:
+                value = np.ascontiguousarray(value, np.int32)
+                index = None if index is None else np.ascontiguousarray(index, np.int32)
+                shape = np.asarray(value.shape, np.int64)
+                if self._ops_encoder_encode(h, _ptr(value, _i32p), _ptr(index, _i32p), _ptr(shape, _i64p), shape.size):
+                    raise ValueError(self._err())
+            count = int(np.prod(hs)) if hs.size else 1
+            offs = np.zeros(count + 1, np.int64)
+            blob = np.zeros(1 << 16, np.uint8)
+            total = self._ops_encoder_finalize(h, _ptr(blob, _u8p), blob.size, _ptr(offs, _i64p))
+            if total < 0:
+                raise ValueError(self._err())
+            if total > blob.size:
+                blob = np.zeros(total, np.uint8)
+                self._ops_encoder_finalize(h, _ptr(blob, _u8p), blob.size, _ptr(offs, _i64p))
+            raw = blob.tobytes()
+            return [raw[offs[i]:offs[i + 1]] for i in range(count)]
+        finally:
+            self._ops_free(h)
+
+    def ops_decode(self, lookup, strings, handle_shape, calls):
+        """CreateRangeDecoder -> EntropyDecode{Channel,Index} per (suffix_shape, index|None) ->
+        EntropyDecodeFinalize.  Returns ([decoded arrays], ok flags)."""
+        lookup = np.ascontiguousarray(lookup, np.int32)
+        lookup, rank, rows, cols = self._lookup_args(lookup)
+        hs = np.asarray(handle_shape, np.int64).reshape(-1)
+        blob = np.frombuffer(b"".join(strings) + b"\0", np.uint8).copy()
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in strings])]).astype(np.int64)
+        h = self._ops_decoder_create(_ptr(blob, _u8p), _ptr(offs, _i64p), _ptr(hs, _i64p), hs.size,
+                                     _ptr(lookup, _i32p), rank, rows, cols)
+        if not h:
+            raise ValueError(self._err())
+        try:
+            outs = []
+            for suffix, index in calls:
+                suffix = np.asarray(suffix, np.int64).reshape(-1)
+                out = np.zeros(tuple(hs) + tuple(suffix), np.int32)
+                index = None if index is None else np.ascontiguousarray(index, np.int32)
+                if self._ops_decoder_decode(h, _ptr(suffix, _i64p), suffix.size, _ptr(index, _i32p), _ptr(out, _i32p)):
+                    raise ValueError(self._err())
+                outs.append(out)
+            ok = np.zeros(max(len(strings), 1), np.uint8)
+            if self._ops_decoder_finalize(h, _ptr(ok, _u8p)):
+                raise ValueError(self._err())
+            return outs, ok[:len(strings)].astype(bool)
+        finally:
+            self._ops_free(h)
 
     # -- quantization ------------------------------------------------------
     def stochastic_round(self, inputs, step_size: float, seed):

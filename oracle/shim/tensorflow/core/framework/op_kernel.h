@@ -15,7 +15,9 @@
 #include <vector>
 
 #include "tensorflow/core/framework/tensor.h"
+#include "tensorflow/core/framework/tensor_util.h"
 #include "tensorflow/core/framework/types.h"
+#include "tensorflow/core/framework/variant.h"
 #include "tensorflow/core/lib/core/threadpool.h"
 #include "tensorflow/core/platform/status.h"
 
@@ -36,14 +38,37 @@ class OpKernelConstruction {
 class OpKernelContext {
  public:
   std::vector<Tensor> inputs;
-  Tensor output;          // caller-provided storage for output 0
+  std::vector<std::string> input_names;   // for input("name", &tensor)
+  std::vector<Tensor> outputs;            // filled by allocate_output / set_output
+  Tensor output;                          // caller-provided storage for output 0, when set by the caller
+  bool caller_output = false;
   Status status;
   const Tensor& input(int i) const { return inputs[i]; }
-  Status allocate_output(int, const TensorShape&, Tensor** out) {
-    *out = &output;
+  Status input(const char* name, const Tensor** out) const {
+    for (size_t i = 0; i < input_names.size(); ++i)
+      if (input_names[i] == name) {
+        *out = &inputs[i];
+        return Status();
+      }
+    return errors::InvalidArgument("no input named ", name);
+  }
+  int num_inputs() const { return static_cast<int>(inputs.size()); }
+  Status allocate_output(int i, const TensorShape& shape, Tensor** out) {
+    if (i == 0 && caller_output) {
+      *out = &output;
+      return Status();
+    }
+    if (static_cast<int>(outputs.size()) <= i) outputs.resize(i + 1);
+    outputs[i] = Tensor(shape);
+    *out = &outputs[i];
     return Status();
   }
+  void set_output(int i, const Tensor& t) {
+    if (static_cast<int>(outputs.size()) <= i) outputs.resize(i + 1);
+    outputs[i] = t;
+  }
   void SetStatus(const Status& s) { status = s; }
+  void CtxFailure(const Status& s) { status = s; }
   DeviceBase* device() { return &device_; }
 
  private:
@@ -97,3 +122,9 @@ inline tfc_shim::KernelDef Name(const char* n) {
   do { if (!(cond)) { (ctx)->SetStatus(st); return; } } while (0)
 #define OP_REQUIRES_OK(ctx, expr) \
   do { ::tensorflow::Status s__ = (expr); if (!s__.ok()) { (ctx)->SetStatus(s__); return; } } while (0)
+#define OP_REQUIRES_VALUE(lhs, ctx, rexpr)                                   \
+  do {                                                                       \
+    auto v__ = (rexpr);                                                      \
+    if (!v__.ok()) { (ctx)->SetStatus(v__.status()); return; }               \
+    lhs = std::move(v__.value());                                            \
+  } while (0)

@@ -1,8 +1,10 @@
-// Build shim (test infrastructure) for the 16-bit float element types. Not product code.
+// Build shim (test infrastructure) for the element types TF names. Not product code.
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <string>
 namespace tensorflow {
+using tstring = std::string;
 struct bfloat16 {
   uint16_t bits;
   explicit operator float() const {

@@ -1,0 +1,3 @@
+// Build shim (test infrastructure). Not product code.
+#pragma once
+#include "tensorflow/core/platform/status.h"

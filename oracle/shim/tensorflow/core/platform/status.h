@@ -3,8 +3,10 @@
 #include <sstream>
 #include <string>
 #include "absl/status/status.h"
+#include "absl/status/statusor.h"
 namespace tensorflow {
 using Status = absl::Status;
+template <class T> using StatusOr = absl::StatusOr<T>;
 namespace errors {
 template <class... A>
 Status InvalidArgument(const A&... parts) {
@@ -14,3 +16,8 @@ Status InvalidArgument(const A&... parts) {
 }
 }  // namespace errors
 }  // namespace tensorflow
+#define TF_RETURN_IF_ERROR(expr)              \
+  do {                                        \
+    ::tensorflow::Status s__ = (expr);        \
+    if (!s__.ok()) return s__;                \
+  } while (0)

@@ -22,6 +22,7 @@ using Core = tfc_oracle::OracleCore;
 #include "drivers.h"
 #include "pmf_to_cdf.h"
 #ifdef TFC_USE_REF
+#include <map>
 #include <memory>
 #include "tensorflow/core/framework/op_kernel.h"  // oracle/shim: registry of the reference's kernels
 #else
@@ -202,8 +203,9 @@ int SYM(pmf_to_quantized_cdf)(const float* pmf, int64_t rows, int64_t n, int pre
   std::unique_ptr<tensorflow::OpKernel> op(it->second(&construction));
   if (!construction.status.ok()) { g_err = construction.status.message(); return 1; }
   tensorflow::OpKernelContext ctx;
-  ctx.inputs.emplace_back(const_cast<float*>(pmf), tensorflow::TensorShape({rows, n}));
+  ctx.inputs.emplace_back(pmf, tensorflow::TensorShape({rows, n}));
   ctx.output = tensorflow::Tensor(cdf, tensorflow::TensorShape({rows, n + 1}));
+  ctx.caller_output = true;
   op->Compute(&ctx);
   if (!ctx.status.ok()) { g_err = ctx.status.message(); return 1; }
   return 0;
@@ -244,6 +246,7 @@ int SYM(stochastic_round)(const void* x, int dtype, int64_t n, float step, const
   ctx.inputs.emplace_back(&step, tensorflow::TensorShape());
   ctx.inputs.emplace_back(const_cast<int32_t*>(seed), tensorflow::TensorShape({seed_len}));
   ctx.output = tensorflow::Tensor(out, tensorflow::TensorShape({n}));
+  ctx.caller_output = true;
   op->Compute(&ctx);
   if (!ctx.status.ok()) {
     g_err = ctx.status.message();
@@ -280,6 +283,207 @@ int SYM(stochastic_round)(const void* x, int dtype, int64_t n, float step, const
   return 0;
 #endif
 }
+
+#ifdef TFC_USE_REF
+// ---- the reference's OWN op kernels (cc/kernels/range_coder_kernels.cc compiled verbatim) -------
+// CreateRangeEncoder -> EntropyEncodeChannel / EntropyEncodeIndex -> EntropyEncodeFinalize and the
+// decoder counterparts, run through the OpKernel shim on caller memory.
+}  // extern "C" (helpers below are C++)
+namespace {
+namespace tf = tensorflow;
+struct OpsHandle {
+  std::vector<int32_t> lookup;      // the kernels keep spans into the lookup tensor
+  std::vector<std::string> strings;  // decoder input
+  tf::Tensor lookup_tensor, handle, encoded;
+};
+bool run_op(const char* name, tf::OpKernelContext* ctx, const std::map<std::string, int>& attrs = {}) {
+  auto it = tfc_shim::registry().find({name, std::type_index(typeid(void))});
+  if (it == tfc_shim::registry().end()) { g_err = std::string(name) + ": reference kernel not registered"; return false; }
+  tf::OpKernelConstruction construction;
+  construction.int_attrs = attrs;
+  std::unique_ptr<tf::OpKernel> op(it->second(&construction));
+  if (!construction.status.ok()) { g_err = construction.status.message(); return false; }
+  op->Compute(ctx);
+  if (!ctx->status.ok()) { g_err = ctx->status.message(); return false; }
+  return true;
+}
+tf::TensorShape shape_of(const int64_t* d, int n) { return tf::TensorShape(std::vector<int64_t>(d, d + n)); }
+void set_lookup(OpsHandle* h, const int32_t* lookup, int rank, int64_t rows, int64_t cols) {
+  const int64_t n = rank == 1 ? cols : rows * cols;
+  h->lookup.assign(lookup, lookup + n);
+  h->lookup_tensor = tf::Tensor(h->lookup.data(), rank == 1 ? tf::TensorShape({cols}) : tf::TensorShape({rows, cols}));
+}
+}  // namespace
+extern "C" {
+
+void* SYM(ops_encoder_create)(const int64_t* handle_shape, int nh, const int32_t* lookup, int rank,
+                              int64_t rows, int64_t cols) {
+  auto h = std::make_unique<OpsHandle>();
+  set_lookup(h.get(), lookup, rank, rows, cols);
+  std::vector<int32_t> dims(handle_shape, handle_shape + nh);
+  tf::OpKernelContext ctx;
+  ctx.inputs.emplace_back(dims.data(), tf::TensorShape({nh}));
+  ctx.inputs.push_back(h->lookup_tensor);
+  if (!run_op("CreateRangeEncoder", &ctx)) return nullptr;
+  h->handle = ctx.outputs.at(0);
+  return h.release();
+}
+
+// value / index: int32 with shape[nd] = handle shape + suffix; index may be null (channel mode).
+int SYM(ops_encoder_encode)(void* handle, const int32_t* value, const int32_t* index, const int64_t* shape, int nd) {
+  auto* h = static_cast<OpsHandle*>(handle);
+  tf::OpKernelContext ctx;
+  ctx.inputs.push_back(h->handle);
+  ctx.input_names = {"handle"};
+  if (index != nullptr) {
+    ctx.inputs.emplace_back(index, shape_of(shape, nd));
+    ctx.input_names.push_back("index");
+  }
+  ctx.inputs.emplace_back(value, shape_of(shape, nd));
+  ctx.input_names.push_back("value");
+  if (!run_op(index ? "EntropyEncodeIndex" : "EntropyEncodeChannel", &ctx)) return 1;
+  h->handle = ctx.outputs.at(0);
+  return 0;
+}
+
+// Writes the strings back to back into blob (capacity cap) and their offsets[count + 1]; returns the
+// total size (call again with a larger blob if it exceeds cap), -1 on error.
+int64_t SYM(ops_encoder_finalize)(void* handle, uint8_t* blob, int64_t cap, int64_t* offsets) {
+  auto* h = static_cast<OpsHandle*>(handle);
+  if (h->strings.empty()) {
+    tf::OpKernelContext ctx;
+    ctx.inputs.push_back(h->handle);
+    if (!run_op("EntropyEncodeFinalize", &ctx)) return -1;
+    auto out = ctx.outputs.at(0).flat<tf::tstring>();
+    for (int64_t i = 0; i < out.size(); ++i) h->strings.push_back(out(i));
+  }
+  int64_t total = 0;
+  for (size_t i = 0; i < h->strings.size(); ++i) {
+    offsets[i] = total;
+    if (total + static_cast<int64_t>(h->strings[i].size()) <= cap)
+      std::memcpy(blob + total, h->strings[i].data(), h->strings[i].size());
+    total += static_cast<int64_t>(h->strings[i].size());
+  }
+  offsets[h->strings.size()] = total;
+  return total;
+}
+
+void* SYM(ops_decoder_create)(const uint8_t* blob, const int64_t* offsets, const int64_t* handle_shape, int nh,
+                              const int32_t* lookup, int rank, int64_t rows, int64_t cols) {
+  auto h = std::make_unique<OpsHandle>();
+  set_lookup(h.get(), lookup, rank, rows, cols);
+  const tf::TensorShape shape = shape_of(handle_shape, nh);
+  for (int64_t i = 0; i < shape.num_elements(); ++i)
+    h->strings.emplace_back(reinterpret_cast<const char*>(blob) + offsets[i], static_cast<size_t>(offsets[i + 1] - offsets[i]));
+  h->encoded = tf::Tensor(h->strings.data(), shape);
+  tf::OpKernelContext ctx;
+  ctx.inputs.push_back(h->encoded);
+  ctx.inputs.push_back(h->lookup_tensor);
+  if (!run_op("CreateRangeDecoder", &ctx)) return nullptr;
+  h->handle = ctx.outputs.at(0);
+  return h.release();
+}
+
+// out: int32 [handle shape + suffix]; index null (channel mode) or the same shape.
+int SYM(ops_decoder_decode)(void* handle, const int64_t* suffix, int ns, const int32_t* index, int32_t* out) {
+  auto* h = static_cast<OpsHandle*>(handle);
+  std::vector<int32_t> dims(suffix, suffix + ns);
+  tf::TensorShape full = h->handle.shape();
+  full.AppendShape(shape_of(suffix, ns));
+  tf::OpKernelContext ctx;
+  ctx.inputs.push_back(h->handle);
+  ctx.input_names = {"handle"};
+  if (index != nullptr) {
+    ctx.inputs.emplace_back(index, full);
+    ctx.input_names.push_back("index");
+  }
+  ctx.inputs.emplace_back(dims.data(), tf::TensorShape({ns}));
+  ctx.input_names.push_back("shape");
+  if (!run_op(index ? "EntropyDecodeIndex" : "EntropyDecodeChannel", &ctx)) return 1;
+  h->handle = ctx.outputs.at(0);
+  auto got = ctx.outputs.at(1).flat<int32_t>();
+  std::memcpy(out, got.data(), static_cast<size_t>(got.size()) * sizeof(int32_t));
+  return 0;
+}
+
+int SYM(ops_decoder_finalize)(void* handle, uint8_t* ok) {
+  auto* h = static_cast<OpsHandle*>(handle);
+  tf::OpKernelContext ctx;
+  ctx.inputs.push_back(h->handle);
+  if (!run_op("EntropyDecodeFinalize", &ctx)) return 1;
+  auto got = ctx.outputs.at(0).flat<bool>();
+  for (int64_t i = 0; i < got.size(); ++i) ok[i] = got(i) ? 1 : 0;
+  return 0;
+}
+
+void SYM(ops_free)(void* handle) { delete static_cast<OpsHandle*>(handle); }
+
+// Legacy RangeEncode / RangeDecode ops (range_coding_kernels.cc + range_coding_kernels_util.cc).
+int64_t SYM(op_range_encode)(const int16_t* data, const int64_t* data_shape, int nd, const int32_t* cdf,
+                             const int64_t* cdf_shape, int nc, int precision, int debug_level, uint8_t* out,
+                             int64_t cap) {
+  tf::OpKernelContext ctx;
+  ctx.inputs.emplace_back(data, shape_of(data_shape, nd));
+  ctx.inputs.emplace_back(cdf, shape_of(cdf_shape, nc));
+  if (!run_op("RangeEncode", &ctx, {{"precision", precision}, {"debug_level", debug_level}})) return -1;
+  const std::string& s = ctx.outputs.at(0).scalar<tf::tstring>()();
+  if (static_cast<int64_t>(s.size()) <= cap && !s.empty()) std::memcpy(out, s.data(), s.size());
+  return static_cast<int64_t>(s.size());
+}
+
+int SYM(op_range_decode)(const uint8_t* bytes, int64_t nbytes, const int64_t* out_shape, int nd,
+                         const int32_t* cdf, const int64_t* cdf_shape, int nc, int precision, int debug_level,
+                         int16_t* out) {
+  std::string encoded(reinterpret_cast<const char*>(bytes), static_cast<size_t>(nbytes));
+  std::vector<int32_t> dims(out_shape, out_shape + nd);
+  tf::OpKernelContext ctx;
+  ctx.inputs.emplace_back(&encoded, tf::TensorShape());
+  ctx.inputs.emplace_back(dims.data(), tf::TensorShape({nd}));
+  ctx.inputs.emplace_back(cdf, shape_of(cdf_shape, nc));
+  if (!run_op("RangeDecode", &ctx, {{"precision", precision}, {"debug_level", debug_level}})) return 1;
+  auto got = ctx.outputs.at(0).flat<int16_t>();
+  std::memcpy(out, got.data(), static_cast<size_t>(got.size()) * sizeof(int16_t));
+  return 0;
+}
+
+// Deprecated UnboundedIndexRangeEncode / Decode ops (unbounded_index_range_coding_kernels.cc).
+int64_t SYM(op_unbounded_index_range_encode)(const int32_t* data, const int32_t* index, int64_t total,
+                                             const int32_t* cdf, int64_t rows, int64_t width,
+                                             const int32_t* cdf_size, const int32_t* offset, int precision,
+                                             int overflow_width, int debug_level, uint8_t* out, int64_t cap) {
+  tf::OpKernelContext ctx;
+  ctx.inputs.emplace_back(data, tf::TensorShape({total}));
+  ctx.inputs.emplace_back(index, tf::TensorShape({total}));
+  ctx.inputs.emplace_back(cdf, tf::TensorShape({rows, width}));
+  ctx.inputs.emplace_back(cdf_size, tf::TensorShape({rows}));
+  ctx.inputs.emplace_back(offset, tf::TensorShape({rows}));
+  if (!run_op("UnboundedIndexRangeEncode", &ctx,
+              {{"precision", precision}, {"overflow_width", overflow_width}, {"debug_level", debug_level}}))
+    return -1;
+  const std::string& s = ctx.outputs.at(0).flat<tf::tstring>()(0);
+  if (static_cast<int64_t>(s.size()) <= cap && !s.empty()) std::memcpy(out, s.data(), s.size());
+  return static_cast<int64_t>(s.size());
+}
+
+int SYM(op_unbounded_index_range_decode)(const uint8_t* bytes, int64_t nbytes, const int32_t* index,
+                                         int64_t total, const int32_t* cdf, int64_t rows, int64_t width,
+                                         const int32_t* cdf_size, const int32_t* offset, int precision,
+                                         int overflow_width, int debug_level, int32_t* out) {
+  std::string encoded(reinterpret_cast<const char*>(bytes), static_cast<size_t>(nbytes));
+  tf::OpKernelContext ctx;
+  ctx.inputs.emplace_back(&encoded, tf::TensorShape());
+  ctx.inputs.emplace_back(index, tf::TensorShape({total}));
+  ctx.inputs.emplace_back(cdf, tf::TensorShape({rows, width}));
+  ctx.inputs.emplace_back(cdf_size, tf::TensorShape({rows}));
+  ctx.inputs.emplace_back(offset, tf::TensorShape({rows}));
+  if (!run_op("UnboundedIndexRangeDecode", &ctx,
+              {{"precision", precision}, {"overflow_width", overflow_width}, {"debug_level", debug_level}}))
+    return 1;
+  auto got = ctx.outputs.at(0).flat<int32_t>();
+  std::memcpy(out, got.data(), static_cast<size_t>(got.size()) * sizeof(int32_t));
+  return 0;
+}
+#endif  // TFC_USE_REF
 
 }  // extern "C"
 
