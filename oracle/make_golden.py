@@ -56,6 +56,12 @@ def stochastic_inputs(n, code):
     return (x.astype(np.float16).view(np.uint16), 2)
 
 
+def unbounded_safe_limit(overflow_width):
+    """Largest |value| (minus slack for offsets) the reference's UnboundedIndexRangeEncode handles without
+    shifting a uint32 by 32 or more."""
+    return (1 << (overflow_width * (31 // overflow_width) - 1)) - 64
+
+
 def ops_roundtrip(ref, lookup, value, index):
     """Strings from the reference's OWN op kernels (CreateRangeEncoder -> EntropyEncode{Channel,Index} ->
     EntropyEncodeFinalize, range_coder_kernels.cc compiled verbatim behind oracle/shim), decoded back with
@@ -205,9 +211,12 @@ def main():
         full = np.broadcast_to(cdf, dshape + (m + 1,))
         u = rng.integers(0, 1 << prec, size=dshape)
         data = (np.sum(full[..., 1:] <= u[..., None], axis=-1)).astype(np.int16)
-        enc = ref.range_encode(data, cdf, prec)
-        back = ref.range_decode(enc, dshape, cdf, prec)
+        # the reference's RangeEncode / RangeDecode op kernels (range_coding_kernels.cc compiled verbatim);
+        # the restated drivers over the compiled core must agree
+        enc = ref.use_op_kernels().range_encode(data, cdf, prec)
+        back = ref.use_op_kernels().range_decode(enc, dshape, cdf, prec)
         assert (back == data).all()
+        assert enc == ref.range_encode(data, cdf, prec)
         leg[name + "_data"] = data
         leg[name + "_cdf"] = cdf
         leg[name + "_precision"] = np.int32(prec)
@@ -231,10 +240,20 @@ def main():
     data = rng.integers(-30, 45, (5, 41)).astype(np.int32)
     data[0, :4] = [-70000, 70000, 2 ** 30, -(2 ** 30)]          # long overflow codes
     unb.update(cdf=cdf, cdf_size=size, offset=offset, index=index, data=data, precision=np.int32(prec))
+    ops = ref.use_op_kernels()   # unbounded_index_range_coding_kernels.cc compiled verbatim
     for ow in (1, 2, 4, 7, 16):
         enc = ref.unbounded_index_range_encode(data, index, cdf, size, offset, prec, ow)
         assert (ref.unbounded_index_range_decode(enc, index, cdf, size, offset, prec, ow) == data).all()
         unb[f"w{ow}_bytes"] = np.frombuffer(enc, np.uint8).copy()
+        # The reference op counts digits with `overflow >> (widths * overflow_width)` (:229), which shifts
+        # a uint32 by >= 32 (undefined; an endless loop on x86) once the overflow needs more than
+        # floor(31 / width) digits.  Inside that domain the op itself produces the golden bytes; the
+        # full-range bytes above come from the restated driver, which counts in 64 bits.
+        safe = np.clip(data, -unbounded_safe_limit(ow), unbounded_safe_limit(ow))
+        enc = ops.unbounded_index_range_encode(safe, index, cdf, size, offset, prec, ow)
+        assert enc == ref.unbounded_index_range_encode(safe, index, cdf, size, offset, prec, ow)
+        assert (ops.unbounded_index_range_decode(enc, index, cdf, size, offset, prec, ow) == safe).all()
+        unb[f"w{ow}_safe_bytes"] = np.frombuffer(enc, np.uint8).copy()
     np.savez_compressed(os.path.join(GOLD, "unbounded_index.npz"), **unb)
     # ---- PmfToQuantizedCdf (the reference kernel file itself, compiled behind oracle/shim) ----
     # Tie-heavy on purpose: which of two equal-penalty symbols is adjusted depends on std::sort's order.

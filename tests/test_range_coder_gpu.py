@@ -279,6 +279,12 @@ def test_unbounded_index_ops(tfc, golden, port):
         assert tfc.unbounded_index_range_encode(t(g["data"]), *args, ow) == want
         back = tfc.unbounded_index_range_decode(want, *args, ow)
         assert back.shape == g["index"].shape and (back.cpu().numpy() == g["data"]).all()
+        # bytes written by the reference's own op kernel (values inside the range its digit count is defined on)
+        from oracle.make_golden import unbounded_safe_limit
+        safe = np.clip(g["data"], -unbounded_safe_limit(ow), unbounded_safe_limit(ow))
+        want = g[f"w{ow}_safe_bytes"].tobytes()
+        assert tfc.unbounded_index_range_encode(t(safe), *args, ow) == want
+        assert (tfc.unbounded_index_range_decode(want, *args, ow).cpu().numpy() == safe).all()
     rng = np.random.default_rng(5)
     index = rng.integers(0, 6, 3000).astype(np.int32)
     data = np.round(rng.normal(0, 6, 3000)).astype(np.int32)
