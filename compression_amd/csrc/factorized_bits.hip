@@ -22,6 +22,7 @@
 
 #include "../../include/tfc_hip.h"
 #include "common.h"
+#include "reduce_rows.h"
 
 namespace tfc {
 
@@ -266,14 +267,6 @@ __global__ void __launch_bounds__(512) factorized_backward_kernel(BitsParams p) 
   }
 }
 
-__global__ void factorized_dparam_reduce_kernel(const float* dpartial, int blocks, int n, float* dparams) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += dpartial[static_cast<long long>(b) * n + idx];
-  dparams[idx] += s;
-}
-
 int plan_blocks(long long units, long long elems, int channels, int* threads, int* blocks_per_unit) {
   if (channels < 1 || channels > 512) return fail("tfc_factorized_bits: channels must be in [1, 512]");
   if (elems % channels != 0) return fail("tfc_factorized_bits: elements per unit must be a multiple of channels");
@@ -322,8 +315,7 @@ int run_backward(BitsParams p, float* dparams, hipStream_t st) {
     hipLaunchKernelGGL((factorized_backward_kernel<T, K, W>), dim3(static_cast<unsigned>(blocks)), dim3(p.threads),
                        lds, st, p);
   }
-  hipLaunchKernelGGL(factorized_dparam_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.dpartial,
-                     static_cast<int>(blocks), n, dparams);
+  launch_sum_rows(p.dpartial, blocks, n, n, dparams, st);   // dparams += block partials, fixed order
   TFC_HIP(hipGetLastError());
   return 0;
 }

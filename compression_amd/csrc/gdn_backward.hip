@@ -5,6 +5,7 @@
 //   T = dL/dn = s g y / n,   R = g n^s
 //   dx = R + (T Gamma^T) d|x|^alpha/dx,   dbeta = sum_p T,   dgamma = U^T T
 #include "gdn_common.h"
+#include "reduce_rows.h"
 
 namespace tfc {
 
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(512) gdn_bwd_fused_bf16_kernel(GdnParams p) {
 // fragment is one ds_read_b128; f32: copied as is, fragments are conflict-free ds_read_b32),
 // its four waves own the (j-tile, i-tile) pairs of one parity class each (so every fragment
 // read feeds up to KT/2 MFMAs), and each block leaves a [C*C + C] partial that
-// gdn_param_reduce_kernel sums in a fixed order (deterministic, no float atomics).
+// sum_rows_kernel (reduce_rows.h) sums in a fixed order (deterministic, no float atomics).
 // ---------------------------------------------------------------------------
 constexpr int PG_PIX = 64;        // pixels per LDS stage
 constexpr int PG_STRIDE = 72;     // bf16 elements per transposed LDS row (144 B: b128 reads conflict-free)
@@ -397,17 +398,6 @@ __global__ void __launch_bounds__(256) gdn_param_grad_kernel(GdnParams p, float*
   if (tid < C) out[C * C + tid] = bsum;
 }
 
-// dgamma / dbeta += sum over block partials (fixed order).
-__global__ void gdn_param_reduce_kernel(const float* partial, int blocks, int C, float* dgamma,
-                                        float* dbeta) {
-  const int n = C * C + C;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[static_cast<size_t>(b) * n + idx];
-  if (idx < C * C) dgamma[idx] += s; else dbeta[idx - C * C] += s;
-}
-
 template <typename T, int KT>
 int launch_param_grad(GdnParams p, float* dgamma, float* dbeta, hipStream_t st) {
   constexpr int C = KT * 32;
@@ -419,15 +409,13 @@ int launch_param_grad(GdnParams p, float* dgamma, float* dbeta, hipStream_t st) 
   const size_t lds = sizeof(T) == 2 ? sizeof(unsigned short) * 2 * C * PG_STRIDE : sizeof(float) * 2 * PG_PIX * C;
   DevBuf partial;
   TFC_HIP(partial.alloc(sizeof(float) * static_cast<size_t>(blocks) * (C * C + C), st));
-  {
-    KernelTimer timer("gdn_backward_params", st);
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_param_grad_kernel<T, KT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((gdn_param_grad_kernel<T, KT>), dim3(blocks), dim3(256), lds, st, p, partial.as<float>());
-  }
-  const int n = C * C + C;
-  hipLaunchKernelGGL(gdn_param_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial.as<float>(),
-                     blocks, C, dgamma, dbeta);
+  KernelTimer timer("gdn_backward_params", st);   // gradient kernel + the reduction of its partials
+  TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_param_grad_kernel<T, KT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  hipLaunchKernelGGL((gdn_param_grad_kernel<T, KT>), dim3(blocks), dim3(256), lds, st, p, partial.as<float>());
+  // dgamma / dbeta += the block partials, summed in a fixed order
+  launch_sum_rows(partial.as<float>(), blocks, C * C + C, C * C, dgamma, st);
+  launch_sum_rows(partial.as<float>() + C * C, blocks, C * C + C, C, dbeta, st);
   TFC_HIP(hipGetLastError());
   return 0;
 }

@@ -146,15 +146,6 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
   bf16x8* afrag = reinterpret_cast<bf16x8*>(smem);
   float* beta_s = reinterpret_cast<float*>(smem + sizeof(bf16x8) * KT * KS * 64);
 
-  {
-    // fragment image (built once per call by gdn_prep_bf16_kernel): linear 16-byte copy
-    const u32x4* src = static_cast<const u32x4*>(p.image);
-    u32x4* dstv = reinterpret_cast<u32x4*>(smem);
-    constexpr int n16 = KT * KS * 64 + (C * 4) / 16;
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dstv[i] = src[i];
-  }
-  __syncthreads();
-
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5;
   const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -163,9 +154,10 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
   unsigned short* y = static_cast<unsigned short*>(p.y);
 
   // Forward, C <= 192: the next tile's x is fetched into spare registers while this tile is
-  // contracted (+4 % on C3).  Measured alternatives that did NOT pay (profiles/r01_e_gdn_notes.md):
-  // double-buffered A fragments, and fully coalesced tile I/O staged through LDS (a plain copy
-  // gains 20 % from coalescing, but the LDS round trips cost more than that here).
+  // contracted (+4 % on C3), and the first tile's x is requested before the fragment image is
+  // copied into LDS, so the HBM latency of the first tile overlaps that copy.  Measured
+  // alternatives that did NOT pay (profiles/r01_e_gdn_notes.md): double-buffered A fragments, and
+  // fully coalesced tile I/O staged through LDS.
   constexpr bool PREFETCH = MODE == MODE_FWD && (KT <= 5 || (PLAIN && KT == 6));
   u32x4 xn[PREFETCH ? KS : 1];
   auto fetch = [&](long long tile) {
@@ -174,7 +166,28 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) xn[PREFETCH ? s : 0] = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
   };
-  if (PREFETCH && wave < p.tiles) fetch(wave);
+  {
+    // fragment image (built once per call by gdn_prep_bf16_kernel): linear 16-byte copy.  Its loads are
+    // issued first and the first tile's x right behind them, so the wait before the LDS writes covers
+    // the image only (loads complete in order) and the x latency runs under the copy.
+    const u32x4* src = static_cast<const u32x4*>(p.image);
+    u32x4* dstv = reinterpret_cast<u32x4*>(smem);
+    constexpr int n16 = KT * KS * 64 + (C * 4) / 16;
+    constexpr int PER = (n16 + 511) / 512;   // the kernel is launched with 512 threads
+    u32x4 img[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = threadIdx.x + k * 512;
+      if (i < n16) img[k] = src[i];
+    }
+    if (PREFETCH && wave < p.tiles) fetch(wave);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = threadIdx.x + k * 512;
+      if (i < n16) dstv[i] = img[k];
+    }
+  }
+  __syncthreads();
 
   for (long long tile = wave; tile < p.tiles; tile += nwaves) {
     const long long pix = tile * 32 + (lane & 31);
