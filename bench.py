@@ -9,7 +9,7 @@ HBM: CreateRangeEncoder -> EntropyEncodeChannel -> EntropyEncodeFinalize ->
 CreateRangeDecoder -> EntropyDecodeChannel -> EntropyDecodeFinalize, all through
 the C ABI (libtfc_hip.so).  Prints ONE JSON line on rank 0.
 
-Steps are independent batches, so `--inflight D` (default 6) of them are in flight at a
+Steps are independent batches, so `--inflight D` (default 8) of them are in flight at a
 time, each on its own host thread and HIP stream: one 512-stream step only puts one wave on
 half of the GPU's 1024 SIMDs and every wave spends a third of its time in un-hideable
 scalar/vector synchronisation stalls, which co-resident waves of other steps fill.  The
@@ -153,6 +153,33 @@ def pmc_traffic(kernel_substring):
     return None
 
 
+SQ_FILE = os.path.join(ROOT, "profiles", "r01_m_sq_inflight1.json")
+
+
+def valu_issue_floor(ms_per_step):
+    """What bounds the coder: VALU issue.  SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves; committed
+    rocprofv3 --pmc pass of this command, tools/sq_on_box.sh) of the encoder + decoder launches of one
+    step, spread over all SIMDs, is the time a step needs if every SIMD issued vector instructions
+    without a gap."""
+    try:
+        table = json.load(open(SQ_FILE))
+    except OSError:
+        return None
+    quads = {}
+    for name, row in table.items():
+        for key in ("enc_fast_kernel", "dec_fast_kernel"):
+            if key in name:
+                quads[key] = row.get("SQ_ACTIVE_INST_VALU")
+    if len(quads) != 2 or None in quads.values():
+        return None
+    simds, clock_hz = 256 * 4, 2.4e9
+    floor_ms = 1e3 * 4.0 * sum(quads.values()) / simds / clock_hz
+    return {"valu_quad_cycles_per_step": {k: int(v) for k, v in quads.items()},
+            "simds": simds, "clock_ghz": 2.4, "floor_ms_per_step": round(floor_ms, 4),
+            "frac": round(floor_ms / ms_per_step, 4),
+            "source": "profiles/r01_m_sq_inflight1.json (SQ_ACTIVE_INST_VALU, rocprofv3 --pmc)"}
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU
     quota (a pool larger than the quota only gets throttled by CFS bandwidth control)."""
@@ -274,7 +301,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=6,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="independent steps in flight (host threads x HIP streams); 1 = serial")
     ap.add_argument("--escape-fraction", type=float, default=0.0)
     ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
@@ -438,6 +465,7 @@ def main():
                 "path_gbytes_s_in_flight": round((alg_enc + alg_dec) * args.steps / 1e9 / elapsed, 2),
             },
         }
+        out["valu_issue_bound"] = valu_issue_floor(1e3 * elapsed / args.steps)
         if world == 1:
             out["gdn_fwd"] = gdn_forward_bandwidth(device)
         if not args.no_cpu_baseline and world == 1:

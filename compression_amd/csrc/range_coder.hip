@@ -132,7 +132,7 @@ struct tfc_tables {
   std::vector<int32_t> host;       // raw lookup
   std::vector<int2> rows;          // (start of header, ints incl. header)
   DevBuf d_data, d_rows;
-  DevBuf d_fast;                   // same layout, cdf entries scaled to 16-bit precision
+  DevBuf d_fast, d_rows_fast;      // encoder LDS image (uint16, entries scaled to 16-bit precision) + its rows
   DevBuf d_dec_image, d_dec_dir;   // decoder LDS image: d_fast + pad + pivot arrays; row directory
   int dec_words = 0;
   bool dec_fast_ok = false;
@@ -210,9 +210,20 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       const int sh = 16 - std::abs(t->host[r.x]);
       for (int i = 1; i < r.y; ++i) fast[r.x + i] = t->host[r.x + i] << sh;
     }
-    TFC_HIP(t->d_fast.alloc(sizeof(int32_t) * std::max<int64_t>(total, 1), st));
-    if (total)
-      TFC_HIP(hipMemcpyAsync(t->d_fast.p, fast.data(), sizeof(int32_t) * total,
+    // Encoder image: 16 bits per entry.  A scaled entry is at most 65536 and only ever used as
+    // "lower" (< 65536) or as "upper - 1" (the coder call word holds upper - 1), so it is stored modulo
+    // 2^16; whether a row has the escape symbol moves from the header's sign into the row directory.
+    // Half the LDS of the int32 image = twice the encoder workgroups per CU.
+    std::vector<uint16_t> fast16(std::max<int64_t>(total, 1));
+    for (int64_t i = 0; i < total; ++i) fast16[i] = static_cast<uint16_t>(fast[i]);
+    std::vector<int2> rows_fast(t->rows);
+    for (int2& r : rows_fast)
+      if (t->host[r.x] < 0) r.y |= static_cast<int>(0x80000000u);
+    TFC_HIP(t->d_fast.alloc(sizeof(uint16_t) * fast16.size(), st));
+    TFC_HIP(hipMemcpyAsync(t->d_fast.p, fast16.data(), sizeof(uint16_t) * fast16.size(), hipMemcpyHostToDevice, st));
+    TFC_HIP(t->d_rows_fast.alloc(sizeof(int2) * std::max<size_t>(rows_fast.size(), 1), st));
+    if (!rows_fast.empty())
+      TFC_HIP(hipMemcpyAsync(t->d_rows_fast.p, rows_fast.data(), sizeof(int2) * rows_fast.size(),
                              hipMemcpyHostToDevice, st));
     // Decoder image: the scaled table, 64 words of padding (lanes past a row's end
     // read harmless data), then 64 pivots per wide row (> 64 symbols).
@@ -272,7 +283,8 @@ constexpr size_t kLdsTableBytes = 144 * 1024;
 struct DecRow;
 struct TableView {
   const int32_t* data;
-  const int32_t* fast;   // cdf entries pre-scaled to 16-bit precision (headers unchanged)
+  const uint16_t* fast16;     // encoder LDS image: entries scaled to 16-bit precision, modulo 2^16
+  const int2* rows_fast;      // (offset, length | escape row << 31) per table, for that image
   const int32_t* dec_image;   // decoder LDS image (see tfc_tables_create)
   const struct DecRow* dec_dir;
   int dec_words;
@@ -376,6 +388,36 @@ __device__ inline Call classify(const TabFn& T, const int2 row, int32_t v) {
 template <typename TabFn>
 __device__ inline Call classify_normalised(const TabFn& T, const int2 row, int32_t v) {
   return classify_impl<true>(T, row, v);
+}
+
+// The same classification on the encoder's 16-bit LDS image (tfc_tables_create): hi16 is the upper
+// bound modulo 2^16 — its only use is "upper - 1" in the call word, which is right either way.
+__device__ inline Call classify_fast(const uint16_t* tab, const int2 row, int32_t v) {
+  Call c;
+  c.gamma = 0;
+  c.neg = 0;
+  c.bad = 0;
+  const int len = row.y & 0x7FFFFFFF;
+  int32_t sym = v;
+  if (row.y >= 0) {
+    if (v < 0 || v >= len - 2) {
+      c.bad = 2;
+      sym = 0;
+    }
+  } else {
+    const int32_t vmax = len - 3;
+    if (v < 0) {
+      c.neg = 1;
+      c.gamma = -v;
+      sym = vmax;
+    } else if (v >= vmax) {
+      c.gamma = v - vmax + 1;
+      sym = vmax;
+    }
+  }
+  c.lo16 = tab[row.x + 1 + sym];
+  c.hi16 = tab[row.x + 2 + sym];
+  return c;
 }
 
 __device__ inline int escape_calls(int32_t gamma) {
@@ -1037,7 +1079,8 @@ size_t table_lds_bytes(const tfc_tables* t) {
 TableView view_of(const tfc_tables* t) {
   TableView v;
   v.data = t->d_data.as<int32_t>();
-  v.fast = t->d_fast.as<int32_t>();
+  v.fast16 = t->d_fast.as<uint16_t>();
+  v.rows_fast = t->d_rows_fast.as<int2>();
   v.dec_image = t->d_dec_image.as<int32_t>();
   v.dec_dir = t->d_dec_dir.as<DecRow>();
   v.dec_words = t->dec_words;
@@ -1047,9 +1090,22 @@ TableView view_of(const tfc_tables* t) {
   return v;
 }
 
+// LDS requested per workgroup of the fast kernels: what they need, or TFC_MIN_LDS_KB if that is more.
+// The dispatcher packs as many workgroups of a launch onto a CU as fit; asking for > 80 KB keeps a lone
+// launch at one workgroup (one wave per SIMD) per CU — lower latency for a single step, at the price of
+// half the residency when several steps are in flight.
+inline size_t lds_request(size_t need) {
+  static const size_t floor_bytes = [] {
+    const char* e = std::getenv("TFC_MIN_LDS_KB");
+    const long n = e ? std::strtol(e, nullptr, 10) : 0;
+    return static_cast<size_t>(n > 0 && n <= 160 ? n : 0) * 1024;
+  }();
+  return std::max(need, floor_bytes);
+}
+
 // Waves (= code streams) that share one LDS copy of the tables.  4 keeps a lone 512-stream
-// launch at one wave per SIMD; TFC_WAVES_PER_BLOCK=8 trades that for twice the resident waves
-// when many launches are in flight (LDS, not registers, limits residency: ~70 KB per block).
+// launch at one wave per SIMD; TFC_WAVES_PER_BLOCK=8 puts 8 streams behind one table copy (measured
+// slower, also with many launches in flight).
 inline int64_t waves_per_block_limit() {
   static const int64_t v = [] {
     const char* e = std::getenv("TFC_WAVES_PER_BLOCK");
@@ -1112,10 +1168,10 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
     KernelTimer timer("enc_kernel", st);
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_fast_kernel<Src>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(e->fast_lds)));
+                                static_cast<int>(lds_request(e->fast_lds))));
     hipLaunchKernelGGL((enc_fast_kernel<Src>),
                        dim3(static_cast<unsigned>(ceil_div(e->streams, e->fast_waves))),
-                       dim3(64 * e->fast_waves), e->fast_lds, st, p, src);
+                       dim3(64 * e->fast_waves), lds_request(e->fast_lds), st, p, src);
   } else {
     KernelTimer timer("enc_kernel", st);
     if (lds) {
@@ -1154,7 +1210,7 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
   e->streams = streams;
   {
     // LDS plan of enc_fast_kernel: tables + row directory + one call ring per wave.
-    const size_t fixed = sizeof(int32_t) * ((tables->host.size() + 1) & ~size_t{1}) +
+    const size_t fixed = sizeof(uint16_t) * ((tables->host.size() + 3) & ~size_t{3}) +
                          sizeof(int2) * tables->rows.size();
     const size_t ring = sizeof(unsigned int) * kRingWords;
     const char* force = std::getenv("TFC_FORCE_GENERIC");
@@ -1389,10 +1445,10 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
     const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(d->streams, 64))));
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(fast_lds)));
+                                static_cast<int>(lds_request(fast_lds))));
     hipLaunchKernelGGL((dec_fast_kernel<Dst>),
                        dim3(static_cast<unsigned>(ceil_div(d->streams, waves))), dim3(64 * waves),
-                       fast_lds, st, p, dst);
+                       lds_request(fast_lds), st, p, dst);
   } else {
     KernelTimer timer("dec_kernel", st);
     if (lds) {

@@ -26,7 +26,13 @@
 namespace tfc {
 
 constexpr int kMaxCallsPerSymbol = 64;                         // 1 + 2*30 + 2 rounded up
-constexpr int kRingWords = 64 + 64 * kMaxCallsPerSymbol;        // leftover + one batch
+// Call queue of a wave: < 64 calls left over from the previous batch plus what is being queued.  It is
+// deliberately small — a batch whose escape codes do not fit is queued in several passes — because
+// LDS, not registers, decides how many workgroups share a CU: with a worst-case queue (64 x 64 calls,
+// 16.6 KB per wave) only ONE encoder workgroup fitted beside the tables and encode-only launches in
+// flight stopped at 57 % of the VALU-issue floor.
+constexpr int kRingWords = 256;
+static_assert(kRingWords >= 64 + kMaxCallsPerSymbol, "one symbol's calls must fit behind the leftovers");
 
 struct FastEncState {       // wave-uniform
   unsigned int base;
@@ -75,7 +81,7 @@ __device__ unsigned long long g_enc_phase[4];
 
 // Chain + digit phase for m (1..64) queued calls; lane n holds call n in `w`.
 template <bool FULL>
-__device__ inline void consume_calls(FastEncState& st, FastSink& o, unsigned int w, int m,
+__device__ __attribute__((always_inline)) inline void consume_calls(FastEncState& st, FastSink& o, unsigned int w, int m,
                                      int lane) {
   const unsigned int lo = w & 0xFFFFu;
   const unsigned int hi = (w >> 16) + 1u;
@@ -185,11 +191,20 @@ template <typename Src>
 __global__ void enc_fast_kernel(EncParams p, Src src) {
   extern __shared__ int32_t lds[];
   const int waves = blockDim.x >> 6;
-  int32_t* tab = lds;                                       // p.tab.total ints (pre-normalised)
-  int2* rows = reinterpret_cast<int2*>(lds + ((p.tab.total + 1) & ~1));
+  // 16-bit table image, row directory, one call queue per wave
+  const int words = (p.tab.total + 3) >> 2 << 1;            // image size in 32-bit words (8-byte multiple)
+  const uint16_t* tab = reinterpret_cast<const uint16_t*>(lds);
+  int2* rows = reinterpret_cast<int2*>(lds + words);
   unsigned int* rings = reinterpret_cast<unsigned int*>(rows + p.tab.ntab);
-  for (int i = threadIdx.x; i < p.tab.total; i += blockDim.x) tab[i] = p.tab.fast[i];
-  for (int i = threadIdx.x; i < p.tab.ntab; i += blockDim.x) rows[i] = p.tab.rows[i];
+  {
+    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(p.tab.fast16);
+    const int pairs = (p.tab.total + 1) >> 1;               // the device buffer holds total (>= 1) entries
+    for (int i = threadIdx.x; i < pairs; i += blockDim.x) {
+      // the last pair of an odd-sized image would read 2 bytes past the buffer: fetch that entry alone
+      lds[i] = (2 * i + 1 < p.tab.total) ? static_cast<int32_t>(src32[i]) : static_cast<int32_t>(p.tab.fast16[2 * i]);
+    }
+  }
+  for (int i = threadIdx.x; i < p.tab.ntab; i += blockDim.x) rows[i] = p.tab.rows_fast[i];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -215,7 +230,6 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
 
-  auto T = [&](int i) -> int32_t { return tab[i]; };
   int count = 0;                                   // calls queued in ring[0..count)
   const int ntab = p.tab.ntab;
   int ch0 = 0;                                     // channel of the batch's first symbol
@@ -246,7 +260,7 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
     const int32_t v = v_next;
     Call c;
     c.lo16 = 0; c.hi16 = 1; c.gamma = 0; c.neg = 0; c.bad = 0;
-    if (valid) c = classify_normalised(T, rows[t], v);
+    if (valid) c = classify_fast(tab, rows[t], v);
     ch0 = static_cast<int>((static_cast<unsigned int>(ch0) + 64u) % static_cast<unsigned int>(ntab));
     // The next batch's symbols are requested only now, after this batch's have been consumed:
     // the wait for THESE symbols is an `s_waitcnt vmcnt(0)` (stores of the digit phase make the
@@ -265,52 +279,68 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
       consume_calls<true>(st, o, word, 64, lane);
       continue;
     }
+    // Queue this batch's calls.  Without escapes that is one call per symbol; with escapes the lanes are
+    // queued in order, as many per pass as the queue has room for (incl is monotone, so the lanes that
+    // fit are a prefix of the remaining ones; at least one fits: fewer than 64 calls are left queued
+    // and a symbol makes at most 63).  After every pass the queue is drained 64 calls at a time.
+    int nb = 0, ncalls = 0, incl = 0;
+    int first = 64, before = 0;                    // lanes below `first` are queued; their calls
     if (esc == 0) {
       if (valid) ring[count + lane] = word;
       count += cnt;
     } else {
-      const int nb = c.gamma > 0 ? 31 - __clz(c.gamma) : 0;
-      const int ncalls = valid ? (c.gamma > 0 ? 2 * nb + 3 : 1) : 0;
-      int incl = ncalls;
+      nb = c.gamma > 0 ? 31 - __clz(c.gamma) : 0;
+      ncalls = valid ? (c.gamma > 0 ? 2 * nb + 3 : 1) : 0;
+      incl = ncalls;
       for (int d = 1; d < 64; d <<= 1) {
         const int up = __shfl_up(incl, d, 64);
         if (lane >= d) incl += up;
       }
-      const int total = __shfl(incl, 63, 64);
-      unsigned int* q = ring + count + (incl - ncalls);
-      if (valid) {
-        q[0] = word;
-        if (c.gamma > 0) {
-          // Elias gamma: nb zeros, then the nb+1 bits of gamma MSB first, then the sign;
-          // every bit is a call [bit, bit+1) / 2  ==  [bit<<15, (bit+1)<<15) / 2^16.
-          for (int i = 0; i < nb; ++i) q[1 + i] = 0x7FFFu << 16;
-          for (int i = nb; i >= 0; --i) {
-            const unsigned int bit = (static_cast<unsigned int>(c.gamma) >> i) & 1u;
-            q[1 + nb + (nb - i)] = bit ? (0x8000u | (0xFFFFu << 16)) : (0x7FFFu << 16);
+      first = 0;
+    }
+    do {
+      if (first < 64) {
+        const int room = kRingWords - count;
+        const unsigned long long fits = __ballot(lane >= first && incl - before <= room);
+        const int upto = first + __popcll(fits);
+        unsigned int* q = ring + count + (incl - ncalls - before);
+        if (valid && lane >= first && lane < upto) {
+          q[0] = word;
+          if (c.gamma > 0) {
+            // Elias gamma: nb zeros, then the nb+1 bits of gamma MSB first, then the sign;
+            // every bit is a call [bit, bit+1) / 2  ==  [bit<<15, (bit+1)<<15) / 2^16.
+            for (int i = 0; i < nb; ++i) q[1 + i] = 0x7FFFu << 16;
+            for (int i = nb; i >= 0; --i) {
+              const unsigned int bit = (static_cast<unsigned int>(c.gamma) >> i) & 1u;
+              q[1 + nb + (nb - i)] = bit ? (0x8000u | (0xFFFFu << 16)) : (0x7FFFu << 16);
+            }
+            q[2 * nb + 2] = c.neg ? (0x8000u | (0xFFFFu << 16)) : (0x7FFFu << 16);
           }
-          q[2 * nb + 2] = c.neg ? (0x8000u | (0xFFFFu << 16)) : (0x7FFFu << 16);
         }
+        const int queued = __shfl(incl, upto - 1, 64) - before;
+        count += queued;
+        before += queued;
+        first = upto;
       }
-      count += total;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- chain + digit phases, 64 calls at a time -------------------------
-    int head = 0;
-    while (count - head >= 64) {
-      consume_calls<true>(st, o, ring[head + lane], 64, lane);
-      head += 64;
-    }
-    if (head != 0) {
-      const int left = count - head;
-      const unsigned int keep = lane < left ? ring[head + lane] : 0u;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (lane < left) ring[lane] = keep;
-      count = left;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
+      // ---- chain + digit phases, 64 calls at a time; fewer than 64 stay queued ----
+      int head = 0;
+      while (count - head >= 64) {
+        consume_calls<true>(st, o, ring[head + lane], 64, lane);
+        head += 64;
+      }
+      if (head != 0) {
+        const int left = count - head;
+        const unsigned int keep = lane < left ? ring[head + lane] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < left) ring[lane] = keep;
+        count = left;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    } while (first < 64);
   }
   if (count > 0) consume_calls<false>(st, o, lane < count ? ring[lane] : 0x00000000u, count, lane);
 

@@ -79,6 +79,27 @@ def test_streams_escape_golden(tfc, golden):
     assert (d == g["value_indexed"]).all() and ok.all()
 
 
+def test_dense_long_escapes(tfc, golden, port):
+    """Every symbol is an escape with a long Elias-gamma code (up to 61 extra coder calls): a batch of 64
+    symbols queues up to ~3900 calls, far more than the encoder's 256-entry call queue holds, so the queue
+    is filled and drained in several passes per batch.  Mixed with in-range symbols at other densities."""
+    lookup = golden("streams_escape.npz")["lookup"]
+    rng = np.random.default_rng(21)
+    for density, elems in ((1.0, 333), (0.5, 700), (0.1, 1500)):
+        big = rng.integers(1 << 12, 1 << 30, (4, elems)) * rng.choice([-1, 1], (4, elems))
+        small = rng.integers(0, 3, (4, elems))
+        value = np.where(rng.random((4, elems)) < density, big, small).astype(np.int32)
+        index = rng.integers(0, 24, value.shape).astype(np.int32)
+        for idx in (None, index):
+            want = port.encode(lookup, value, index=idx)[0]
+            got, _ = hip_encode(tfc, lookup, value, index=idx)
+            assert got == want, (density, idx is None)
+            d, ok = hip_decode(tfc, lookup, got, elems, index=idx)
+            assert (d == value).all() and ok.all()
+        got3, _ = hip_encode(tfc, lookup, value, calls=3)       # leftovers carried across calls
+        assert got3 == port.encode(lookup, value, calls=3)[0]
+
+
 def test_precision_sweep_golden(tfc, golden):
     g = golden("precision_sweep.npz")
     for prec in (1, 2, 5, 8, 12, 16):
