@@ -134,7 +134,7 @@ def gdn_forward_bandwidth(device, steps=20):
                          "unit": "GB/s"}}
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_k_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_n_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_substring):
@@ -456,7 +456,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic("dec_fast_kernel" if dom == "dec_kernel" else "enc_fast_kernel"),
-                "traffic_source": "profiles/r01_k_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                "traffic_source": "profiles/r01_n_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
                                   "WRITE_SIZE passes of this command; 2*FETCH + WRITE, KiB -> bytes)",
                 "algorithmic_bytes": int(dom_bytes),
                 "note": "serial chain per stream (512 chains): VALU-issue / synchronisation bound, not "

@@ -435,7 +435,9 @@ constexpr int kCountLdsRows = 8192;
 
 template <typename Src>
 __global__ void __launch_bounds__(256) enc_count_kernel(EncParams p, Src src) {
-  __shared__ int rowinfo[kCountLdsRows];
+  // rowinfo[min(ntab, kCountLdsRows)], sized at launch: this kernel runs beside the coding kernels of
+  // other steps, and LDS it does not need is LDS their workgroups cannot get
+  extern __shared__ int rowinfo[];
   __shared__ unsigned int part[4];
   const bool in_lds = p.tab.ntab <= kCountLdsRows;
   if (in_lds) {
@@ -1150,8 +1152,9 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
 
   const int64_t tiles = ceil_div(elems, kCountTile);
   if (e->streams * tiles >= (int64_t{1} << 31)) return fail("encode call too large for one launch");
+  const size_t count_lds = p.tab.ntab <= kCountLdsRows ? sizeof(int) * p.tab.ntab : 0;
   hipLaunchKernelGGL((enc_count_kernel<Src>), dim3(static_cast<unsigned>(e->streams * tiles)),
-                     dim3(256), 0, st, p, src);
+                     dim3(256), count_lds, st, p, src);
   hipLaunchKernelGGL(enc_offsets_kernel, dim3(1), dim3(1024), 0, st, p.calls, p.state,
                      e->fast ? 1 : 0, e->streams, ch.off.as<long long>(),
                      status.as<unsigned long long>() + 1);
