@@ -9,7 +9,7 @@ HBM: CreateRangeEncoder -> EntropyEncodeChannel -> EntropyEncodeFinalize ->
 CreateRangeDecoder -> EntropyDecodeChannel -> EntropyDecodeFinalize, all through
 the C ABI (libtfc_hip.so).  Prints ONE JSON line on rank 0.
 
-Steps are independent batches, so `--inflight D` (default 8) of them are in flight at a
+Steps are independent batches, so `--inflight D` (default 16) of them are in flight at a
 time, each on its own host thread and HIP stream: one 512-stream step only puts one wave on
 half of the GPU's 1024 SIMDs and every wave spends a third of its time in un-hideable
 scalar/vector synchronisation stalls, which co-resident waves of other steps fill.  The
@@ -153,31 +153,33 @@ def pmc_traffic(kernel_substring):
     return None
 
 
-SQ_FILE = os.path.join(ROOT, "profiles", "r01_m_sq_inflight1.json")
+SQ_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r01_o_sq_inflight1.json", "r01_m_sq_inflight1.json")]
 
 
-def valu_issue_floor(ms_per_step):
+def valu_issue_floor(ms_per_step, throughput_mode):
     """What bounds the coder: VALU issue.  SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves; committed
-    rocprofv3 --pmc pass of this command, tools/sq_on_box.sh) of the encoder + decoder launches of one
+    rocprofv3 --pmc passes of this command, tools/sq_on_box.sh) of the encoder + decoder launches of one
     step, spread over all SIMDs, is the time a step needs if every SIMD issued vector instructions
     without a gap."""
-    try:
-        table = json.load(open(SQ_FILE))
-    except OSError:
-        return None
+    want = ("enc_quad_kernel" if throughput_mode else "enc_fast_kernel", "dec_fast_kernel")
     quads = {}
-    for name, row in table.items():
-        for key in ("enc_fast_kernel", "dec_fast_kernel"):
-            if key in name:
-                quads[key] = row.get("SQ_ACTIVE_INST_VALU")
-    if len(quads) != 2 or None in quads.values():
+    for path in SQ_FILES:
+        try:
+            table = json.load(open(path))
+        except OSError:
+            continue
+        for name, row in table.items():
+            for key in want:
+                if key in name and key not in quads and row.get("SQ_ACTIVE_INST_VALU"):
+                    quads[key] = row["SQ_ACTIVE_INST_VALU"]
+    if len(quads) != 2:
         return None
     simds, clock_hz = 256 * 4, 2.4e9
     floor_ms = 1e3 * 4.0 * sum(quads.values()) / simds / clock_hz
     return {"valu_quad_cycles_per_step": {k: int(v) for k, v in quads.items()},
             "simds": simds, "clock_ghz": 2.4, "floor_ms_per_step": round(floor_ms, 4),
             "frac": round(floor_ms / ms_per_step, 4),
-            "source": "profiles/r01_m_sq_inflight1.json (SQ_ACTIVE_INST_VALU, rocprofv3 --pmc)"}
+            "source": "profiles/r01_o_sq_inflight1.json, r01_m_sq_inflight1.json (SQ_ACTIVE_INST_VALU, rocprofv3 --pmc)"}
 
 
 def usable_cores():
@@ -301,7 +303,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=8,
+    ap.add_argument("--inflight", type=int, default=16,
                     help="independent steps in flight (host threads x HIP streams); 1 = serial")
     ap.add_argument("--escape-fraction", type=float, default=0.0)
     ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
@@ -373,7 +375,11 @@ def main():
     pool = ThreadPoolExecutor(max(inflight, 1))
     run_steps(args.warmup, 1)
     if inflight > 1:
+        # several steps in flight = the library's throughput mode (four code streams per wave where a
+        # kernel for it exists); the serial pass below runs in the default latency mode
+        tfc.set_throughput_mode(True)
         run_steps(max(args.warmup, inflight), inflight)     # warm every stream / thread
+        tfc.set_throughput_mode(False)
 
     # serial pass: per-kernel durations with the GPU to one launch at a time
     _lib.lib().tfc_profile_enable(1)
@@ -384,6 +390,7 @@ def main():
     _lib.lib().tfc_profile_enable(0)
     # the timed region: exactly --steps steps
     if inflight > 1:
+        tfc.set_throughput_mode(True)
         _lib.lib().tfc_profile_enable(1)
         elapsed, results = run_steps(args.steps, inflight)
         cenc_ms, cenc_n = profile_query("enc_kernel")
@@ -441,6 +448,7 @@ def main():
                 "escape_fraction": args.escape_fraction,
                 "parallelism": f"batch-sharded x{world}",
                 "steps_in_flight": inflight,
+                "library_mode": "throughput (tfc_set_throughput_mode(1))" if inflight > 1 else "latency (default)",
             },
             "bits_per_pixel": round(8.0 * total_bytes / (STREAMS * PIXELS_PER_STREAM), 5),
             "bits_per_symbol": round(8.0 * total_bytes / symbols, 4),
@@ -465,7 +473,7 @@ def main():
                 "path_gbytes_s_in_flight": round((alg_enc + alg_dec) * args.steps / 1e9 / elapsed, 2),
             },
         }
-        out["valu_issue_bound"] = valu_issue_floor(1e3 * elapsed / args.steps)
+        out["valu_issue_bound"] = valu_issue_floor(1e3 * elapsed / args.steps, inflight > 1)
         if world == 1:
             out["gdn_fwd"] = gdn_forward_bandwidth(device)
         if not args.no_cpu_baseline and world == 1:

@@ -20,6 +20,8 @@ SIGNATURES = {
     "tfc_abi_version": (_int, []),
     "tfc_last_error": (C.c_char_p, []),
     "tfc_profile_enable": (None, [_int]),
+    "tfc_set_throughput_mode": (None, [_int]),
+    "tfc_get_throughput_mode": (_int, []),
     "tfc_profile_query": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "tfc_tables_create": (_int, [_vp, _int, _i64, _i64, _vp, C.POINTER(_vp)]),
     "tfc_tables_count": (_i64, [_vp]),

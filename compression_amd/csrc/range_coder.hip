@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -92,6 +93,18 @@ KernelTimer::~KernelTimer() {
 }  // namespace tfc
 
 using namespace tfc;
+
+namespace {
+std::atomic<int>& throughput_mode() {
+  static std::atomic<int> mode{[] {
+    const char* e = std::getenv("TFC_THROUGHPUT_MODE");
+    return e && e[0] == '1' ? 1 : 0;
+  }()};
+  return mode;
+}
+}  // namespace
+extern "C" void tfc_set_throughput_mode(int on) { throughput_mode().store(on ? 1 : 0); }
+extern "C" int tfc_get_throughput_mode(void) { return throughput_mode().load(); }
 
 extern "C" void tfc_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_profile_mutex);
@@ -493,6 +506,7 @@ __global__ void __launch_bounds__(256) enc_count_kernel(EncParams p, Src src) {
   if (threadIdx.x == 0) {
     const unsigned int tot = part[0] + part[1] + part[2] + part[3];
     atomicAdd(&p.calls[s], static_cast<unsigned long long>(tot));
+    atomicAdd(p.first_error + 2, static_cast<unsigned long long>(tot));   // status[2]: calls of all streams
   }
 }
 
@@ -675,6 +689,7 @@ __global__ void __launch_bounds__(kBlock) enc_kernel(EncParams p, Src src) {
 
 }  // namespace tfc
 #include "range_encoder_fast.h"
+#include "range_encoder_quad.h"
 namespace tfc {
 
 // ---- finalize -------------------------------------------------------------
@@ -1131,7 +1146,7 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   TFC_HIP(calls.alloc(sizeof(unsigned long long) * e->streams, st));
   TFC_HIP(status.alloc(sizeof(unsigned long long) * 3, st));
   TFC_HIP(hipMemsetAsync(calls.p, 0, sizeof(unsigned long long) * e->streams, st));
-  // status[0] = first error position, [1] = total capacity, [2] = overflow flag
+  // status[0] = first error position, [1] = total capacity, [2] = coder calls of all streams
   const unsigned long long init[3] = {~0ull, 0ull, 0ull};
   TFC_HIP(hipMemcpyAsync(status.p, init, sizeof(init), hipMemcpyHostToDevice, st));
   TFC_HIP(ch.off.alloc(sizeof(long long) * (e->streams + 1), st));
@@ -1167,7 +1182,20 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   p.chunk = ch.data.as<uint8_t>();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(e->streams, kWavesPerBlock));
-  if (e->fast) {
+  // throughput mode and exactly one call per symbol everywhere (no escape codes in this call): four
+  // streams per wave (range_encoder_quad.h)
+  if (e->fast && throughput_mode().load() != 0 && elems > 0 &&
+      host_status[2] == static_cast<unsigned long long>(e->streams) * static_cast<unsigned long long>(elems)) {
+    KernelTimer timer("enc_kernel", st);
+    const size_t quad_lds = e->fast_lds - sizeof(unsigned int) * kRingWords * e->fast_waves;   // no call queues
+    const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(e->streams, 4))));
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_quad_kernel<Src>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds_request(quad_lds))));
+    hipLaunchKernelGGL((enc_quad_kernel<Src>),
+                       dim3(static_cast<unsigned>(ceil_div(e->streams, 4 * waves))),
+                       dim3(64 * waves), lds_request(quad_lds), st, p, src);
+  } else if (e->fast) {
     KernelTimer timer("enc_kernel", st);
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_fast_kernel<Src>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,

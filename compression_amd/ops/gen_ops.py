@@ -26,6 +26,7 @@ __all__ = [
     "pmf_to_quantized_cdf", "range_encode", "range_decode",
     "unbounded_index_range_encode", "unbounded_index_range_decode",
     "stochastic_round",
+    "set_throughput_mode", "get_throughput_mode",
 ]
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -467,3 +468,14 @@ def stochastic_round(inputs, step_size, seed) -> torch.Tensor:
         inputs.data_ptr(), _DTYPE_CODE[inputs.dtype], inputs.numel(), float(step),
         seed.ctypes.data if seed.size else None, seed.size, out.data_ptr(), _lib.stream_ptr()))
     return out
+
+
+def set_throughput_mode(on: bool) -> None:
+    """Process-wide hint (include/tfc_hip.h, tfc_set_throughput_mode): prefer kernels that put several
+    code streams on one wave — more aggregate throughput with several independent calls in flight on
+    different HIP streams, longer latency of a single call.  Same bytes either way."""
+    _lib.lib().tfc_set_throughput_mode(1 if on else 0)
+
+
+def get_throughput_mode() -> bool:
+    return bool(_lib.lib().tfc_get_throughput_mode())

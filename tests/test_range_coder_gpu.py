@@ -100,6 +100,48 @@ def test_dense_long_escapes(tfc, golden, port):
         assert got3 == port.encode(lookup, value, calls=3)[0]
 
 
+def test_throughput_mode_same_bytes(tfc, golden, port):
+    """tfc_set_throughput_mode(1): escape-free encode calls take the four-streams-per-wave kernel
+    (csrc/range_encoder_quad.h).  Same bytes as the oracle for stream counts that do not fill a wave,
+    lengths that are not multiples of 16 / 32 symbols, index mode, the golden precision sweep, and handles
+    whose calls alternate between the two kernels (a call with escapes falls back to one stream per wave)."""
+    esc = golden("streams_escape.npz")
+    sweep = golden("precision_sweep.npz")
+    rng = np.random.default_rng(33)
+    tfc.set_throughput_mode(True)
+    try:
+        assert tfc.get_throughput_mode()
+        for prec in (1, 2, 5, 8, 12, 16):
+            lk, v = sweep[f"p{prec}_lookup"], sweep[f"p{prec}_value"]
+            got, _ = hip_encode(tfc, lk, v)
+            assert got == split_blob(sweep[f"p{prec}_blob"], sweep[f"p{prec}_offsets"]), prec
+        lookup = esc["lookup"]
+        rows = synthetic.lookup_rows(lookup)
+        for streams, elems in ((1, 1), (1, 15), (2, 16), (3, 17), (4, 31), (5, 32), (7, 33), (9, 1000), (64, 777)):
+            value = synthetic.sample_symbols(lookup, streams, elems, seed=streams * 1000 + elems)   # no escapes
+            assert hip_encode(tfc, lookup, value)[0] == port.encode(lookup, value)[0], (streams, elems)
+            index = rng.integers(0, len(rows), value.shape).astype(np.int32)
+            vi = np.zeros_like(value)
+            for t, (sp, cdf) in enumerate(rows):
+                m = index == t
+                vi[m] = rng.integers(0, len(cdf) - 2, int(m.sum()))
+            assert hip_encode(tfc, lookup, vi, index=index)[0] == port.encode(lookup, vi, index=index)[0]
+        # three calls on one handle: quad kernel, then a call with escapes (fast kernel), then quad again
+        a = synthetic.sample_symbols(lookup, 6, 480, seed=1)
+        b = esc["value"][:, :480]
+        c = synthetic.sample_symbols(lookup, 6, 480, seed=2)
+        h = tfc.create_range_encoder([6], torch.as_tensor(lookup))
+        for part in (a, b, c):
+            h = tfc.entropy_encode_channel(h, dev(part))
+        got = [bytes(x) for x in tfc.entropy_encode_finalize(h).reshape(-1)]
+        assert got == port.encode(lookup, np.concatenate([a, b, c], axis=1), calls=3)[0]
+        d, ok = hip_decode(tfc, lookup, got, 1440)
+        assert (d == np.concatenate([a, b, c], axis=1)).all() and ok.all()
+    finally:
+        tfc.set_throughput_mode(False)
+    assert not tfc.get_throughput_mode()
+
+
 def test_precision_sweep_golden(tfc, golden):
     g = golden("precision_sweep.npz")
     for prec in (1, 2, 5, 8, 12, 16):
