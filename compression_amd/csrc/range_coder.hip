@@ -833,6 +833,7 @@ struct DecParams {
   const long long* off;            // [streams + 1]
   uint4* state;                    // base, span_m1, window, pulls
   unsigned long long* first_error; // index range error
+  const unsigned int* only_flagged; // dec_fast_kernel: if set, decode only streams with a nonzero flag
 };
 
 // 64 upcoming big-endian digits of the stream, one per lane.
@@ -1018,6 +1019,7 @@ __global__ void __launch_bounds__(kBlock) dec_kernel(DecParams p, Dst dst) {
 
 }  // namespace tfc
 #include "range_decoder_fast.h"
+#include "range_decoder_quad.h"
 namespace tfc {
 
 // Reads the first four bytes of every stream (RangeDecoder ctor,
@@ -1467,12 +1469,37 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   p.off = d->off_p;
   p.state = d->state.as<uint4>();
   p.first_error = d->status.as<unsigned long long>();
+  p.only_flagged = nullptr;
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
   const size_t fast_lds = sizeof(int32_t) * ((t->dec_words + 3) & ~3) + sizeof(int4) * t->rows.size();
   const char* force = std::getenv("TFC_FORCE_GENERIC");
-  if (t->dec_fast_ok && fast_lds <= 160 * 1024 && !(force && force[0] == '1')) {
+  const bool fast_ok = t->dec_fast_ok && fast_lds <= 160 * 1024 && !(force && force[0] == '1');
+  DevBuf redo;
+  static const bool quad_decoder = [] {
+    const char* q = std::getenv("TFC_DEC_QUAD");
+    return q && q[0] == '1';
+  }();
+  if (fast_ok && quad_decoder && throughput_mode().load() != 0) {
+    // EXPERIMENTAL (TFC_DEC_QUAD=1): four streams per wave (range_decoder_quad.h).  Streams that met an
+    // escape symbol are flagged and keep their start state; dec_fast_kernel below decodes exactly those.
+    // Correct (the GPU tests pass with it) but not used: measured 20 ms for the bench step alone and
+    // 24 ms per launch with 16 steps in flight, against 4.3 / 7-9 ms for dec_fast_kernel — its step is a
+    // chain of ~9 dependent LDS round trips (~1000 cycles per symbol and row), and the waves that would
+    // hide that do not exist at this batch size.
     KernelTimer timer("dec_kernel", st);
+    TFC_HIP(redo.alloc(sizeof(unsigned int) * d->streams, st));
+    TFC_HIP(hipMemsetAsync(redo.p, 0, sizeof(unsigned int) * d->streams, st));
+    const size_t quad_lds = sizeof(int32_t) * ((t->host.size() + 64 + 3) & ~size_t{3}) + sizeof(int4) * t->rows.size();
+    const int waves = static_cast<int>(std::min<int64_t>(8, std::max<int64_t>(1, ceil_div(d->streams, 4))));
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_quad_kernel<Dst>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds)));
+    hipLaunchKernelGGL((dec_quad_kernel<Dst>), dim3(static_cast<unsigned>(ceil_div(d->streams, 4 * waves))),
+                       dim3(64 * waves), quad_lds, st, p, dst, redo.as<unsigned int>());
+    p.only_flagged = redo.as<unsigned int>();
+  }
+  if (fast_ok) {
+    KernelTimer timer(p.only_flagged ? "dec_kernel_redo" : "dec_kernel", st);
     const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(d->streams, 64))));
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -416,6 +416,7 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
   const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int64_t s = static_cast<int64_t>(blockIdx.x) * waves + wid;
   if (s >= p.streams) return;
+  if (p.only_flagged != nullptr && p.only_flagged[s] == 0) return;   // second pass of throughput mode
 
   const uint4 st0 = p.state[s];
   FastDecState st;
