@@ -9,7 +9,7 @@ HBM: CreateRangeEncoder -> EntropyEncodeChannel -> EntropyEncodeFinalize ->
 CreateRangeDecoder -> EntropyDecodeChannel -> EntropyDecodeFinalize, all through
 the C ABI (libtfc_hip.so).  Prints ONE JSON line on rank 0.
 
-Steps are independent batches, so `--inflight D` (default 16) of them are in flight at a
+Steps are independent batches, so `--inflight D` (default: up to 16, at most the usable host cores - 4, balanced over the steps) of them are in flight at a
 time, each on its own host thread and HIP stream: one 512-stream step only puts one wave on
 half of the GPU's 1024 SIMDs and every wave spends a third of its time in un-hideable
 scalar/vector synchronisation stalls, which co-resident waves of other steps fill.  The
@@ -134,7 +134,7 @@ def gdn_forward_bandwidth(device, steps=20):
                          "unit": "GB/s"}}
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_n_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_o_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_substring):
@@ -300,11 +300,12 @@ def model_workload(args, world, rank, device, distributed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=16,
-                    help="independent steps in flight (host threads x HIP streams); 1 = serial")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="independent steps in flight (host threads x HIP streams); 1 = serial, "
+                         "0 = up to 16, balanced over --steps")
     ap.add_argument("--escape-fraction", type=float, default=0.0)
     ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
                     help="c2 (default, the headline): coder round trip; bls2017 / bmshj2018: "
@@ -370,7 +371,17 @@ def main():
             torch.cuda.synchronize()
         return time.perf_counter() - t0, results
 
-    inflight = max(1, min(args.inflight, args.steps))
+    if args.inflight > 0:
+        inflight = max(1, min(args.inflight, args.steps))
+    else:
+        # Up to 16 in flight, but every step in flight is a host thread that spins in the HIP runtime
+        # while it waits, so leave a few of the usable cores (cgroup quota) free: a pool as large as the
+        # quota gets throttled (measured on a 16-core quota: 12 in flight 17.5-18.0 Gpixels/s, 16 in
+        # flight 18.7 on a quiet host but 9-11 on a loaded one).  Then balance, so that the steps split
+        # into full rounds (20 steps: 2 rounds of 10).
+        cap = max(1, min(16, usable_cores()[1] - 4))
+        rounds = -(-args.steps // cap)
+        inflight = max(1, -(-args.steps // rounds))
     side_streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
     pool = ThreadPoolExecutor(max(inflight, 1))
     run_steps(args.warmup, 1)
@@ -464,7 +475,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic("dec_fast_kernel" if dom == "dec_kernel" else "enc_fast_kernel"),
-                "traffic_source": "profiles/r01_n_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                "traffic_source": "profiles/r01_o_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
                                   "WRITE_SIZE passes of this command; 2*FETCH + WRITE, KiB -> bytes)",
                 "algorithmic_bytes": int(dom_bytes),
                 "note": "serial chain per stream (512 chains): VALU-issue / synchronisation bound, not "
