@@ -17,16 +17,19 @@
 //   shifted in.  hi_k is the row's cdf entry pre-scaled to 16-bit precision (the decoder image).
 //
 // STATUS: experimental, off by default (TFC_DEC_QUAD=1 with throughput mode).  It is bit-exact (the GPU
-// tests pass with it) and needs 3-4x fewer vector instructions per symbol, but one step is ~1000 cycles
-// of dependent LDS round trips per symbol and row, and 128 waves per launch cannot hide that: 20 ms for
-// the bench step against 4.3 ms (profiles/r01_o_notes.md).  A latency-engineered version (row
-// information prefetched per batch, winner state through DPP instead of ds_bpermute) is the next step.
+// tests pass with it) and needs 3-4x fewer vector instructions per symbol, but one step is still ~800
+// cycles per symbol and row (multiply -> ballot -> two ds_bpermute per search stage, 1.7 stages per symbol
+// on the bench tables), and 128 waves per launch cannot hide that: 16.7 ms for the bench step against
+// 4.3 ms (profiles/r01_o_notes.md).  It pays below ~250 cycles per symbol and row.
 //
 // Escape symbols are not decoded here: a stream that meets one is flagged in `redo`, keeps its start
 // state, and is decoded again by dec_fast_kernel (launched right behind with the flags as a mask).
 #pragma once
+#include <type_traits>
 
 namespace tfc {
+
+template <int N> using QuadIdx = std::integral_constant<int, N>;
 
 struct QuadDigits {          // per lane: one digit of the row's window
   const uint8_t* src;        // row-uniform
@@ -121,49 +124,92 @@ __global__ void dec_quad_kernel(DecParams p, Dst dst, unsigned int* redo) {
     const int cnt = static_cast<int>(min<int64_t>(16, p.elems - j0));
     int outv = 0;
 
-    for (int n = 0; n < cnt; ++n) {
-      const int tn = __builtin_amdgcn_ds_bpermute(rowbase4 + (n << 2), t);    // the row's symbol n
-      const DecRow row = dir[tn];
-      const int nsym = row.z & 0xFFFF;
-      const int cdf0 = row.y;
-      // ---- staged search: stride 256, 16, 1 ------------------------------------------------
+    // ---- off the per-symbol chain: the rows of the batch and their first-stage candidates --------
+    // Lane i reads the directory entry of ITS symbol; entry n reaches the row's lanes through
+    // row_newbcast:n (a DPP move, no LDS round trip).  The first-stage candidates of all 16 symbols
+    // depend on the tables only, not on the coder state, so their 16 LDS reads are issued here, back to
+    // back; the per-symbol chain below then consists of the multiply, one ballot and two ds_bpermute,
+    // plus one dependent table read per further stage of a wide row.
+    const DecRow mine = dir[t];
+    int cdf0s[16], nsyms[16];
+    unsigned int hi1[16];
+    auto prefetch = [&](auto nc) __attribute__((always_inline)) {
+      constexpr int n = decltype(nc)::value;
+      cdf0s[n] = __builtin_amdgcn_update_dpp(0, mine.y, 0x150 + n, 0xF, 0xF, false);
+      nsyms[n] = __builtin_amdgcn_update_dpp(0, mine.z, 0x150 + n, 0xF, 0xF, false) & 0xFFFF;
+      const int stride = nsyms[n] > 256 ? 256 : (nsyms[n] > 16 ? 16 : 1);
+      hi1[n] = static_cast<unsigned int>(tab[cdf0s[n] + min((i + 1) * stride, nsyms[n])]);
+    };
+    const int escs = mine.w;
+
+    // one candidate evaluation: the row's first lane whose upper bound covers D, its A and b
+    auto evaluate = [&](unsigned int hi, unsigned int A0, int* win, unsigned int* Aw, unsigned int* bw)
+                        __attribute__((always_inline)) {
+      const unsigned long long prod = static_cast<unsigned long long>(span) * hi + hi;   // (span + 1) * hi
+      const unsigned int B = static_cast<unsigned int>(prod >> 16);
+      const unsigned int b = B - 1u;
+      const unsigned int m16 = static_cast<unsigned int>(__ballot(D <= b) >> shift) & 0xFFFFu;
+      *win = m16 ? __builtin_ctz(m16) : 15;           // no candidate: damaged input only
+      const unsigned int A = __builtin_amdgcn_update_dpp(A0, B, 0x111, 0xF, 0xF, false);   // row_shr:1
+      *Aw = static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(rowbase4 + (*win << 2), static_cast<int>(A)));
+      *bw = static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(rowbase4 + (*win << 2), static_cast<int>(b)));
+    };
+
+    auto step = [&](auto nc) __attribute__((always_inline)) {
+      constexpr int n = decltype(nc)::value;
+      const int nsym = nsyms[n], cdf0 = cdf0s[n];
+      const unsigned int dig = static_cast<unsigned int>(
+          __builtin_amdgcn_ds_bpermute(rowbase4 + ((pos & 15u) << 2), w.reg));
       int stride = nsym > 256 ? 256 : (nsym > 16 ? 16 : 1);
-      int lo = 0;                                   // symbols known to lie below the hit
-      unsigned int A0 = 0;                          // B of entry `lo`
-      unsigned int Aw, bw;
       int win;
-      while (true) {
-        const int k = min(lo + (i + 1) * stride, nsym);
-        const unsigned int hi = static_cast<unsigned int>(tab[cdf0 + k]);
-        const unsigned long long prod = (static_cast<unsigned long long>(span) + 1ull) * hi;
-        const unsigned int B = static_cast<unsigned int>(prod >> 16);
-        const unsigned int b = B - 1u;
-        const unsigned int m16 = static_cast<unsigned int>(__ballot(D <= b) >> shift) & 0xFFFFu;
-        win = m16 ? __builtin_ctz(m16) : 15;        // no candidate: damaged input only
-        const unsigned int A = __builtin_amdgcn_update_dpp(A0, B, 0x111, 0xF, 0xF, false);   // row_shr:1
-        Aw = static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(rowbase4 + (win << 2), static_cast<int>(A)));
-        bw = static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(rowbase4 + (win << 2), static_cast<int>(b)));
-        if (__ballot(stride > 1) == 0) break;       // every row is at its last stage
-        // rows still searching narrow down; rows already at stride 1 repeat the same result
-        if (stride > 1) {
-          lo += win * stride;
-          A0 = Aw;
-          stride >>= 4;
+      unsigned int Aw, bw;
+      evaluate(hi1[n], 0u, &win, &Aw, &bw);
+      int lo = 0;
+      // further stages (stride 16, then 1) for the rows that need them; the others keep their result
+      while (__ballot(stride > 1) != 0) {
+        const bool more = stride > 1;
+        const int lo2 = lo + win * stride;
+        const int stride2 = stride >> 4;
+        const int k = min(lo2 + (i + 1) * stride2, nsym);
+        const unsigned int hi = static_cast<unsigned int>(tab[cdf0 + (more ? k : 0)]);
+        int win2;
+        unsigned int Aw2, bw2;
+        evaluate(hi, Aw, &win2, &Aw2, &bw2);
+        if (more) {
+          lo = lo2;
+          stride = stride2;
+          win = win2;
+          Aw = Aw2;
+          bw = bw2;
         }
       }
       const int sym = min(lo + win, nsym - 1);
-      // ---- successor state -------------------------------------------------------------------
-      const unsigned int dig = static_cast<unsigned int>(
-          __builtin_amdgcn_ds_bpermute(rowbase4 + ((pos & 15u) << 2), w.reg));
+      // ---- successor state ---------------------------------------------------------------------
       const unsigned int Dn = D - Aw;
       const unsigned int t1 = bw - Aw;
       const bool ren = t1 < 65536u;
       D = ren ? ((Dn << 16) | dig) : Dn;
       span = ren ? ((t1 << 16) | 0xFFFFu) : t1;
       pos += ren ? 1u : 0u;
-      escaped |= sym == row.w;
+      const int esc_n = __builtin_amdgcn_update_dpp(0, escs, 0x150 + n, 0xF, 0xF, false);
+      escaped |= sym == esc_n;
       if (i == n) outv = sym;
+    };
+    auto guarded = [&](auto nc) __attribute__((always_inline)) {
+      if (decltype(nc)::value < cnt) step(nc);
+    };
+#define TFC_QUAD_EACH(F)                                                                     \
+    F(QuadIdx<0>{}); F(QuadIdx<1>{}); F(QuadIdx<2>{}); F(QuadIdx<3>{}); F(QuadIdx<4>{});         \
+    F(QuadIdx<5>{}); F(QuadIdx<6>{}); F(QuadIdx<7>{}); F(QuadIdx<8>{}); F(QuadIdx<9>{});         \
+    F(QuadIdx<10>{}); F(QuadIdx<11>{}); F(QuadIdx<12>{}); F(QuadIdx<13>{}); F(QuadIdx<14>{});    \
+    F(QuadIdx<15>{});
+    TFC_QUAD_EACH(prefetch)
+    if (cnt == 16) {
+      TFC_QUAD_EACH(step)
+    } else {
+      TFC_QUAD_EACH(guarded)
     }
+#undef TFC_QUAD_EACH
     if (valid && live && !escaped) dst.store(s * p.elems + j, t, outv);
   }
 
