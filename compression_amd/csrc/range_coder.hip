@@ -1020,6 +1020,7 @@ __global__ void __launch_bounds__(kBlock) dec_kernel(DecParams p, Dst dst) {
 }  // namespace tfc
 #include "range_decoder_fast.h"
 #include "range_decoder_quad.h"
+#include "range_decoder_tput.h"
 namespace tfc {
 
 // Reads the first four bytes of every stream (RangeDecoder ctor,
@@ -1498,7 +1499,21 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
                        dim3(64 * waves), quad_lds, st, p, dst, redo.as<unsigned int>());
     p.only_flagged = redo.as<unsigned int>();
   }
-  if (fast_ok) {
+  static const bool tput_decoder = [] {
+    const char* q = std::getenv("TFC_DEC_TPUT");
+    return q && q[0] == '1';
+  }();
+  if (fast_ok && tput_decoder && !p.only_flagged && throughput_mode().load() != 0) {
+    // EXPERIMENTAL (TFC_DEC_TPUT=1): winner first, successor state on the scalar unit, 16 waves per
+    // table copy (range_decoder_tput.h).  Bit-exact, not used: 14.9 ms for the bench step alone,
+    // 21-23 ms per launch in flight (profiles/r01_o_notes.md).
+    KernelTimer timer("dec_kernel", st);
+    const int waves = static_cast<int>(std::min<int64_t>(16, std::max<int64_t>(1, d->streams)));
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_tput_kernel<Dst>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fast_lds)));
+    hipLaunchKernelGGL((dec_tput_kernel<Dst>), dim3(static_cast<unsigned>(ceil_div(d->streams, waves))),
+                       dim3(64 * waves), fast_lds, st, p, dst);
+  } else if (fast_ok) {
     KernelTimer timer(p.only_flagged ? "dec_kernel_redo" : "dec_kernel", st);
     const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(d->streams, 64))));
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
