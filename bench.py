@@ -379,7 +379,9 @@ def main():
         # quota gets throttled (measured on a 16-core quota: 12 in flight 17.5-18.0 Gpixels/s, 16 in
         # flight 18.7 on a quiet host but 9-11 on a loaded one).  Then balance, so that the steps split
         # into full rounds (20 steps: 2 rounds of 10).
-        cap = max(1, min(16, usable_cores()[1] - 4))
+        # Ranks of one node share the host cores.
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        cap = max(1, min(16, (usable_cores()[1] - 4) // max(local_world, 1)))
         rounds = -(-args.steps // cap)
         inflight = max(1, -(-args.steps // rounds))
     side_streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
