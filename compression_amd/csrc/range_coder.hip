@@ -1185,13 +1185,13 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   p.chunk = ch.data.as<uint8_t>();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(e->streams, kWavesPerBlock));
-  // throughput mode and exactly one call per symbol everywhere (no escape codes in this call): four
-  // streams per wave (range_encoder_quad.h)
-  if (e->fast && throughput_mode().load() != 0 && elems > 0 &&
-      host_status[2] == static_cast<unsigned long long>(e->streams) * static_cast<unsigned long long>(elems)) {
+  // throughput mode: four streams per wave (range_encoder_quad.h)
+  if (e->fast && throughput_mode().load() != 0 && elems > 0) {
     KernelTimer timer("enc_kernel", st);
-    const size_t quad_lds = e->fast_lds - sizeof(unsigned int) * kRingWords * e->fast_waves;   // no call queues
     const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(e->streams, 4))));
+    // tables + row directory + one small call queue per row (4 per wave)
+    const size_t quad_lds = e->fast_lds - sizeof(unsigned int) * kRingWords * e->fast_waves +
+                            sizeof(unsigned int) * 4 * kQuadQueue * waves;
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_quad_kernel<Src>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds_request(quad_lds))));

@@ -11,13 +11,20 @@
 // range_encoder_fast.h) runs per row on 16-bit slices of the same three ballots; the per-stream
 // bookkeeping that is wave-uniform in enc_fast_kernel is row-uniform here and lives in VGPRs.
 //
-// Used when the counting pass found exactly one coder call per symbol (no escape codes in this call):
-// then a batch is 16 symbols per stream and needs no call queue.  Streams with escapes take
-// enc_fast_kernel.  The stream state written back is the same, so calls of either kind can follow each
-// other on one handle.
+// A group is 16 symbols per stream.  Without escape codes that is 16 calls per row and they go from
+// registers straight into one round (16 sweeps + digit phase).  A group in which some row has an escape
+// (its Elias-gamma bits are up to 62 extra calls) goes through a small per-row call queue in LDS: the
+// row's lanes are queued in order, as many as fit, and every row takes rounds of up to 16 calls from its
+// queue until all rows are through; rows that are done idle (a round with 0 calls changes nothing).  The
+// queues are empty again at the end of the group, so the next escape-free group is back on the direct
+// path.  The stream state written back is the one enc_fast_kernel uses, so calls handled by either
+// kernel can follow each other on one handle.
 #pragma once
 
 namespace tfc {
+
+constexpr int kQuadQueue = 96;     // calls a row can queue: one symbol makes at most 63
+static_assert(kQuadQueue >= kMaxCallsPerSymbol, "one symbol's calls must fit the row queue");
 
 struct QuadSink {           // row-uniform
   unsigned short* dst;
@@ -49,6 +56,7 @@ __global__ void enc_quad_kernel(EncParams p, Src src) {
   const int words = (p.tab.total + 3) >> 2 << 1;
   const uint16_t* tab = reinterpret_cast<const uint16_t*>(lds);
   int2* rows = reinterpret_cast<int2*>(lds + words);
+  unsigned int* queues = reinterpret_cast<unsigned int*>(rows + p.tab.ntab);   // [waves][4][kQuadQueue]
   {
     const uint32_t* src32 = reinterpret_cast<const uint32_t*>(p.tab.fast16);
     const int pairs = (p.tab.total + 1) >> 1;
@@ -95,13 +103,17 @@ __global__ void enc_quad_kernel(EncParams p, Src src) {
   // entries: the digit stores make the outstanding-load count unknowable, so the wait before that is
   // `s_waitcnt vmcnt(0)` and must find only loads that are a whole iteration (~4500 cycles, more than
   // an HBM latency) old.
-  auto bounds = [&](int64_t j, int32_t v, int t, unsigned int* lo, unsigned int* hi) {
+  auto bounds = [&](int64_t j, int32_t v, int t, unsigned int* lo, unsigned int* hi, int* gamma, int* neg) {
     *lo = 0;
     *hi = 1;
+    *gamma = 0;
+    *neg = 0;
     if (live && j < p.elems) {
       const Call c = classify_fast(tab, rows[t], v);
       *lo = static_cast<unsigned int>(c.lo16);
       *hi = ((static_cast<unsigned int>(c.hi16) - 1u) & 0xFFFFu) + 1u;    // upper bound, 65536 restored
+      *gamma = c.gamma;
+      *neg = c.neg;
     }
   };
   const unsigned int ch_step = 16u % static_cast<unsigned int>(ntab);
@@ -113,10 +125,11 @@ __global__ void enc_quad_kernel(EncParams p, Src src) {
   const int shift = seg * 16;
   const unsigned int below_me = (1u << i) - 1u;
 
-  // one round: chain + digit phase for the calls (lo, hi) of symbols j0 .. j0 + 15 of every row
-  auto round = [&](int64_t j0, unsigned int lo, unsigned int hi) __attribute__((always_inline)) {
-    const bool valid = live && j0 + i < p.elems;    // idle rows never emit
-    const int cnt = static_cast<int>(min<int64_t>(16, p.elems - j0));
+  unsigned int* rq = queues + ((threadIdx.x >> 6) * 4 + seg) * kQuadQueue;      // this row's call queue
+
+  // one round: chain + digit phase for the first `cnt` (row-uniform, 0..16) calls (lo, hi) of every row
+  auto round = [&](unsigned int lo, unsigned int hi, int cnt) __attribute__((always_inline)) {
+    const bool valid = i < cnt;
     // ---- chain phase: 16 sweeps, row_shr:1 ----------------------------------------------
     const unsigned long long addA = lo;
     const unsigned long long addB = static_cast<unsigned long long>(static_cast<long long>(hi) - 65536ll);
@@ -203,25 +216,97 @@ __global__ void enc_quad_kernel(EncParams p, Src src) {
         }
       }
     }
-    if (cnt == 16) {        // the row's last lane, broadcast inside the row (row_newbcast:15)
+    if (__ballot(cnt != 16) == 0) {   // the row's last lane, broadcast inside the row (row_newbcast:15)
       span = __builtin_amdgcn_update_dpp(0u, s_out, 0x15F, 0xF, 0xF, false);
       base = __builtin_amdgcn_update_dpp(0u, b_out, 0x15F, 0xF, 0xF, false);
-    } else {
-      span = static_cast<unsigned int>(__shfl(static_cast<int>(s_out), (lane & 48) + cnt - 1, 64));
-      base = static_cast<unsigned int>(__shfl(static_cast<int>(b_out), (lane & 48) + cnt - 1, 64));
+    } else {                          // rows with fewer calls: their last call's lane; none: unchanged
+      const int last = (lane & 48) + max(cnt, 1) - 1;
+      const unsigned int sn = static_cast<unsigned int>(__shfl(static_cast<int>(s_out), last, 64));
+      const unsigned int bn = static_cast<unsigned int>(__shfl(static_cast<int>(b_out), last, 64));
+      span = cnt > 0 ? sn : span;
+      base = cnt > 0 ? bn : base;
+    }
+  };
+
+  // the 16 symbols j0 .. j0 + 15 of every row: one round straight from registers, or through the queues
+  auto emit_group = [&](int64_t j0, unsigned int lo, unsigned int hi, int gamma, int neg)
+                        __attribute__((always_inline)) {
+    const bool valid = live && j0 + i < p.elems;
+    const bool queued_mode = __ballot(valid && gamma > 0) != 0;
+    unsigned int rlo = lo, rhi = hi;
+    int rcnt = live ? static_cast<int>(min<int64_t>(16, max<int64_t>(0, p.elems - j0))) : 0;
+    int nb = 0, ncalls = 0, incl = 0;
+    int first = 16, before = 0;                 // lanes below `first` are queued; their calls
+    int qcount = 0, qhead = 0;                  // row queue: calls queued / taken
+    if (queued_mode) {
+      nb = gamma > 0 ? 31 - __clz(gamma) : 0;
+      ncalls = valid ? (gamma > 0 ? 2 * nb + 3 : 1) : 0;
+      incl = ncalls;                            // inclusive scan inside the row (zeros shifted in)
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+      first = 0;
+    }
+    while (true) {
+      if (queued_mode) {
+        // rows whose queue is used up take their next lanes: a prefix of the remaining ones (incl is
+        // monotone), at least one (a symbol makes at most 63 calls)
+        const bool refill = qhead == qcount && first < 16;
+        const unsigned int fits = static_cast<unsigned int>(
+            __ballot(refill && i >= first && incl - before <= kQuadQueue) >> shift) & 0xFFFFu;
+        const int upto = first + __popc(fits);
+        if (refill && valid && i >= first && i < upto) {
+          unsigned int* q = rq + (incl - ncalls - before);
+          q[0] = (lo & 0xFFFFu) | ((hi - 1u) << 16);
+          if (gamma > 0) {
+            // Elias gamma: nb zeros, then the nb+1 bits of gamma MSB first, then the sign; every bit is
+            // a call [bit, bit+1) / 2  ==  [bit<<15, (bit+1)<<15) / 2^16 (range_coder_kernels.cc:290-322)
+            for (int k = 0; k < nb; ++k) q[1 + k] = 0x7FFFu << 16;
+            for (int k = nb; k >= 0; --k) {
+              const unsigned int bit = (static_cast<unsigned int>(gamma) >> k) & 1u;
+              q[1 + nb + (nb - k)] = bit ? (0x8000u | (0xFFFFu << 16)) : (0x7FFFu << 16);
+            }
+            q[2 * nb + 2] = neg ? (0x8000u | (0xFFFFu << 16)) : (0x7FFFu << 16);
+          }
+        }
+        const int got = __shfl(incl, (lane & 48) + max(upto, 1) - 1, 64) - before;   // calls of lanes < upto
+        if (refill) {
+          qcount = upto > first ? got : 0;
+          qhead = 0;
+          before += qcount;
+          first = upto;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        rcnt = min(16, qcount - qhead);
+        const unsigned int word = i < rcnt ? rq[qhead + i] : 0u;
+        rlo = word & 0xFFFFu;
+        rhi = (word >> 16) + 1u;
+        qhead += rcnt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (__ballot(rcnt > 0) == 0) break;     // every row is through
+      }
+      round(rlo, rhi, rcnt);
+      if (!queued_mode) break;
     }
   };
 
   for (int64_t j0 = 0; j0 < p.elems; j0 += 32) {
     unsigned int loA, hiA, loB, hiB;
-    bounds(j0 + i, vA, tA, &loA, &hiA);
-    bounds(j0 + 16 + i, vB, tB, &loB, &hiB);
+    int gA, nA, gB, nB;
+    bounds(j0 + i, vA, tA, &loA, &hiA, &gA, &nA);
+    bounds(j0 + 16 + i, vB, tB, &loB, &hiB, &gB, &nB);
     chA = advance(advance(chA));
     chB = advance(advance(chB));
     vA = fetch(j0 + 32, static_cast<int>(chA), &tA);
     vB = fetch(j0 + 48, static_cast<int>(chB), &tB);
-    round(j0, loA, hiA);
-    if (j0 + 16 < p.elems) round(j0 + 16, loB, hiB);
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < 2; ++g) {               // one copy of the round's code for both groups
+      if (j0 + 16 * g < p.elems)
+        emit_group(j0 + 16 * g, g ? loB : loA, g ? hiB : hiA, g ? gB : gA, g ? nB : nA);
+    }
   }
 
   if (live && i == 0) {

@@ -45,7 +45,7 @@ int tfc_profile_query(const char* kernel, double* total_ms, int64_t* launches);
 /* Process-wide scheduling hint (no reference counterpart: the reference's ops shard streams over the
  * intra-op thread pool, range_coder_kernels.cc:212-267).  0 (default): one code stream per wave —
  * shortest time for one encode call on an otherwise idle GPU.  1: kernels that put several streams on a
- * wave are preferred where they exist (escape-free encode calls: four streams per wave) — fewer
+ * wave are preferred where they exist (encode calls: four streams per wave) — fewer
  * instructions issued per symbol, i.e. more aggregate throughput when several independent calls are in
  * flight on different HIP streams, at a longer latency of each call.  The bytes produced are identical.
  * Initial value: environment variable TFC_THROUGHPUT_MODE. */

@@ -101,10 +101,10 @@ def test_dense_long_escapes(tfc, golden, port):
 
 
 def test_throughput_mode_same_bytes(tfc, golden, port):
-    """tfc_set_throughput_mode(1): escape-free encode calls take the four-streams-per-wave kernel
+    """tfc_set_throughput_mode(1): encode calls take the four-streams-per-wave kernel
     (csrc/range_encoder_quad.h).  Same bytes as the oracle for stream counts that do not fill a wave,
-    lengths that are not multiples of 16 / 32 symbols, index mode, the golden precision sweep, and handles
-    whose calls alternate between the two kernels (a call with escapes falls back to one stream per wave)."""
+    lengths that are not multiples of 16 / 32 symbols, index mode, the golden precision sweep and escape
+    streams, dense long escape codes, and several calls on one handle."""
     esc = golden("streams_escape.npz")
     sweep = golden("precision_sweep.npz")
     rng = np.random.default_rng(33)
@@ -126,7 +126,16 @@ def test_throughput_mode_same_bytes(tfc, golden, port):
                 m = index == t
                 vi[m] = rng.integers(0, len(cdf) - 2, int(m.sum()))
             assert hip_encode(tfc, lookup, vi, index=index)[0] == port.encode(lookup, vi, index=index)[0]
-        # three calls on one handle: quad kernel, then a call with escapes (fast kernel), then quad again
+        # escape codes inside the four-streams-per-wave kernel: per-row call queues, several passes per group
+        for density, elems in ((1.0, 333), (0.3, 700), (0.02, 3000)):
+            big = rng.integers(1 << 6, 1 << 30, (7, elems)) * rng.choice([-1, 1], (7, elems))
+            small = synthetic.sample_symbols(lookup, 7, elems, seed=elems)
+            value = np.where(rng.random((7, elems)) < density, big, small).astype(np.int32)
+            assert hip_encode(tfc, lookup, value)[0] == port.encode(lookup, value)[0], density
+            index = rng.integers(0, len(rows), value.shape).astype(np.int32)
+            assert hip_encode(tfc, lookup, value, index=index)[0] == port.encode(lookup, value, index=index)[0]
+        assert hip_encode(tfc, lookup, esc["value"])[0] == split_blob(esc["blob"], esc["offsets"])
+        # three calls on one handle: escape-free, with escapes, escape-free
         a = synthetic.sample_symbols(lookup, 6, 480, seed=1)
         b = esc["value"][:, :480]
         c = synthetic.sample_symbols(lookup, 6, 480, seed=2)
