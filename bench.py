@@ -9,13 +9,15 @@ HBM: CreateRangeEncoder -> EntropyEncodeChannel -> EntropyEncodeFinalize ->
 CreateRangeDecoder -> EntropyDecodeChannel -> EntropyDecodeFinalize, all through
 the C ABI (libtfc_hip.so).  Prints ONE JSON line on rank 0.
 
-Steps are independent batches, so `--inflight D` (default: up to 16, at most the usable host cores - 4, balanced over the steps) of them are in flight at a
-time, each on its own host thread and HIP stream: one 512-stream step only puts one wave on
-half of the GPU's 1024 SIMDs and every wave spends a third of its time in un-hideable
-scalar/vector synchronisation stalls, which co-resident waves of other steps fill.  The
-timed region still contains EXACTLY `--steps` complete steps; `serial` in the output is
-the same measurement with one step at a time (the per-kernel durations used for the
-roofline line are taken there, where a launch has the GPU to itself).
+Steps are independent batches, so `--inflight D` (default 32) of them are kept in flight, each on
+its own HIP stream, all enqueued by ONE host thread through the library's stream-ordered path
+(throughput-mode handles: one code stream per lane, range errors deferred, finalize on the device, the
+decoder reads the encoder's device-resident strings): a 512-stream step is 8 waves, so the chip only
+fills with many steps resident at once.  Every slot in flight codes its own seeded tensor.  The
+timed region contains EXACTLY `--steps` complete steps; `serial` in the output is one step at a time
+with latency-mode handles (one wave per stream).  After the timed region every step's decoded tensor
+is compared with its input, and slot 0's bytes with the CPU reference's bytes (sha256 over all 512
+streams).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -73,14 +75,49 @@ def profile_query(name):
     return ms.value, n.value
 
 
-def one_step(lookup_t, value_t):
-    h = tfc.create_range_encoder([STREAMS], lookup_t)
+def one_step(lookup_t, value_t, mode):
+    """CreateRangeEncoder .. EntropyDecodeFinalize on the current HIP stream, nothing read back."""
+    h = tfc.create_range_encoder([STREAMS], lookup_t, mode=mode, deferred_errors=True)
     h = tfc.entropy_encode_channel(h, value_t)
-    blob, offsets = tfc.gen_ops._finalize_device(h)
-    d = tfc.create_range_decoder((blob, offsets, (STREAMS,)), lookup_t)
+    h = tfc.entropy_encode_finalize_device(h)
+    d = tfc.create_range_decoder(h, lookup_t, mode=mode)
     d, decoded = tfc.entropy_decode_channel(d, [ELEMS], torch.int32)
-    ok = tfc.entropy_decode_finalize(d)
-    return blob, offsets, decoded, ok
+    ok = tfc.entropy_decode_finalize_device(d)
+    return h, d, decoded, ok
+
+
+def sample_symbols_device(lookup, seed, device, escape_fraction=0.0):
+    """[STREAMS, ELEMS] int32 symbols on the device: uniform `precision`-bit draws inverted through each
+    channel's CDF (same law as synthetic.sample_symbols, drawn with torch's generator so that 32 slots
+    take milliseconds instead of minutes)."""
+    rows = synthetic.lookup_rows(lookup)
+    ntab = len(rows)
+    width = max(len(c) for _, c in rows)
+    table = np.full((ntab, width), np.iinfo(np.int32).max, np.int64)
+    for t, (_, c) in enumerate(rows):
+        table[t, :len(c)] = c
+    nsym = torch.tensor([len(c) - 1 for _, c in rows], device=device)
+    esc = torch.tensor([sp < 0 for sp, _ in rows], device=device)
+    table_t = torch.from_numpy(table).to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + seed)
+    u = torch.randint(0, 1 << PRECISION, (STREAMS, ELEMS), generator=gen, device=device)
+    col_tab = torch.arange(ELEMS, device=device) % ntab
+    # searchsorted per channel: bring the channel axis first
+    reps = ELEMS // ntab
+    uu = u.view(STREAMS, reps, ntab).permute(2, 0, 1).reshape(ntab, -1).contiguous()
+    sym = torch.searchsorted(table_t, uu, right=True) - 1
+    top = torch.where(esc, nsym - 2, nsym - 1).clamp(min=0)[:, None]   # fold the escape symbol onto its neighbour
+    sym = torch.minimum(sym, top).clamp(min=0)
+    out = sym.view(ntab, STREAMS, reps).permute(1, 2, 0).reshape(STREAMS, ELEMS)
+    if escape_fraction > 0:
+        mask = torch.rand((STREAMS, ELEMS), generator=gen, device=device) < escape_fraction
+        mask &= esc[col_tab][None, :]
+        lens = (nsym - 1)[col_tab][None, :]
+        geo = torch.empty((STREAMS, ELEMS), device=device).geometric_(0.2, generator=gen).long()
+        neg = torch.randint(0, 2, (STREAMS, ELEMS), generator=gen, device=device).bool()
+        out = torch.where(mask, torch.where(neg, -geo, lens + geo), out)
+    return out.to(torch.int32).contiguous()
 
 
 def gdn_forward_bandwidth(device, steps=20):
@@ -127,25 +164,56 @@ def gdn_forward_bandwidth(device, steps=20):
             "kernel_ms": round(avg_ms, 4), "algorithmic_bytes": nbytes,
             "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm",
-            "traffic": pmc_traffic("gdn_fwd_bf16_kernel<6, 0, true>"),
+            "traffic": pmc_traffic("gdn_fwd_bf16_kernel", PMC_PROFILE, GDN_SOURCES),
             "backward": {"kernel_ms": round(bwd_ms, 4), "passes_ms": passes,
                          "algorithmic_bytes": bwd_bytes,
                          "achieved": round(bwd_bytes / 1e9 / (bwd_ms / 1e3), 1) if bwd_ms else None,
                          "unit": "GB/s"}}
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_o_pmc_traffic.json")
+CODER_SOURCES = ["compression_amd/csrc/range_coder.hip", "compression_amd/csrc/range_lanes.h",
+                 "compression_amd/csrc/range_encoder_fast.h", "compression_amd/csrc/range_decoder_fast.h"]
+GDN_SOURCES = ["compression_amd/csrc/gdn.hip", "compression_amd/csrc/gdn_common.h",
+               "compression_amd/csrc/gdn_backward.hip"]
 
 
-def pmc_traffic(kernel_substring):
+def source_hashes(paths):
+    """git blob hashes (sha1 of "blob <len>\\0" + content) of the kernel sources a profile was taken on."""
+    import hashlib
+    out = {}
+    for rel in paths:
+        try:
+            data = open(os.path.join(ROOT, rel), "rb").read()
+        except OSError:
+            out[rel] = None
+            continue
+        out[rel] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
+def load_profile(name, sources):
+    """A committed rocprofv3 --pmc summary (tools/pmc_summary.py / sq_summary.py stamp it with the git
+    blob hashes of the kernel sources it was measured on), or None when the sources have changed since:
+    a counter figure of other code is not a measurement of this run."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except OSError:
+        return None
+    stamp = table.get("_sources")
+    now = source_hashes(sources)
+    if not stamp or any(stamp.get(k) != v for k, v in now.items()):
+        return None
+    return table
+
+
+def pmc_traffic(kernel_substring, profile, sources):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes
     (tools/pmc_on_box.sh; same bench command).  Counter unit is KiB.  Corrections as
     MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-B read requests as 64 B
     (x2; calibrated in the same passes on torch's fp32->bf16 copy of a 201 MB tensor: reported
     98322 KiB, true 196608 KiB), WRITE_SIZE is exact on that kernel's 98304 KiB output."""
-    try:
-        table = json.load(open(PMC_FILE))
-    except OSError:
+    table = load_profile(profile, sources)
+    if table is None:
         return None
     for name, ctrs in table.items():
         if kernel_substring in name and "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs:
@@ -153,33 +221,31 @@ def pmc_traffic(kernel_substring):
     return None
 
 
-SQ_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r01_o_sq_inflight1.json", "r01_m_sq_inflight1.json")]
+PMC_PROFILE = "r02_pmc_traffic.json"
+SQ_PROFILE = "r02_sq_inflight.json"
 
 
-def valu_issue_floor(ms_per_step, throughput_mode):
-    """What bounds the coder: VALU issue.  SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves; committed
-    rocprofv3 --pmc passes of this command, tools/sq_on_box.sh) of the encoder + decoder launches of one
-    step, spread over all SIMDs, is the time a step needs if every SIMD issued vector instructions
-    without a gap."""
-    want = ("enc_quad_kernel" if throughput_mode else "enc_fast_kernel", "dec_fast_kernel")
+def valu_issue_floor(ms_per_step, kernels):
+    """Vector-issue floor of a step: SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves; committed
+    rocprofv3 --pmc pass of this command, tools/sq_on_box.sh) of the encoder + decoder launches of one
+    step, spread over all SIMDs = the time a step needs if every SIMD issued vector instructions without
+    a gap.  None when the profile was taken on other sources."""
+    table = load_profile(SQ_PROFILE, CODER_SOURCES)
+    if table is None:
+        return None
     quads = {}
-    for path in SQ_FILES:
-        try:
-            table = json.load(open(path))
-        except OSError:
-            continue
-        for name, row in table.items():
-            for key in want:
-                if key in name and key not in quads and row.get("SQ_ACTIVE_INST_VALU"):
-                    quads[key] = row["SQ_ACTIVE_INST_VALU"]
-    if len(quads) != 2:
+    for name, row in table.items():
+        for key in kernels:
+            if key in name and key not in quads and isinstance(row, dict) and row.get("SQ_ACTIVE_INST_VALU"):
+                quads[key] = row["SQ_ACTIVE_INST_VALU"]
+    if len(quads) != len(kernels):
         return None
     simds, clock_hz = 256 * 4, 2.4e9
     floor_ms = 1e3 * 4.0 * sum(quads.values()) / simds / clock_hz
     return {"valu_quad_cycles_per_step": {k: int(v) for k, v in quads.items()},
             "simds": simds, "clock_ghz": 2.4, "floor_ms_per_step": round(floor_ms, 4),
             "frac": round(floor_ms / ms_per_step, 4),
-            "source": "profiles/r01_o_sq_inflight1.json, r01_m_sq_inflight1.json (SQ_ACTIVE_INST_VALU, rocprofv3 --pmc)"}
+            "source": f"profiles/{SQ_PROFILE} (SQ_ACTIVE_INST_VALU, rocprofv3 --pmc)"}
 
 
 def usable_cores():
@@ -202,7 +268,7 @@ def usable_cores():
     return n, (min(n, quota) if quota else n), quota
 
 
-def cpu_baseline(lookup, value, total_bytes_gpu):
+def cpu_baseline(lookup, value, gpu_blob_sha256, gpu_offsets_sha256):
     """Reference coder core (oracle/_ref) or its restatement on the host cores,
     sharded over streams like the reference's ThreadPool::ParallelFor.
     This is the ONLY place bench.py touches oracle/."""
@@ -226,6 +292,11 @@ def cpu_baseline(lookup, value, total_bytes_gpu):
     rt, threads, enc_s, dec_s, total, rt_min = best
     e1, d1, _, _ = lib.bench_roundtrip(lookup, value[:8], threads=1, reps=3)
     one_thread = (8 * PIXELS_PER_STREAM / 1e6) / float(np.median((e1 + d1)[1:]))
+    # the bytes themselves: all streams, compared by hash with what the GPU produced for the same input
+    import hashlib
+    _, cpu_blob, cpu_offs = lib.encode(lookup, value, threads=threads)
+    same = (hashlib.sha256(np.ascontiguousarray(cpu_blob).tobytes()).hexdigest() == gpu_blob_sha256 and
+            hashlib.sha256(np.ascontiguousarray(cpu_offs, np.int64).tobytes()).hexdigest() == gpu_offsets_sha256)
     return {
         "value": round(pixels / 1e6 / rt, 2), "unit": "Mpixels/s", "cores": threads,
         "kind": lib.kind,
@@ -236,7 +307,8 @@ def cpu_baseline(lookup, value, total_bytes_gpu):
                   f"{quota if quota else 'none'}), median encode+decode time",
         "encode_ms": round(1e3 * enc_s, 3), "decode_ms": round(1e3 * dec_s, 3),
         "one_thread_mpixels_s": round(one_thread, 2),
-        "bytes_identical_to_gpu": bool(total == total_bytes_gpu),
+        "bytes_identical_to_gpu": bool(same),
+        "bytes_compared": f"sha256 of the packed blob ({int(total)} bytes, {value.shape[0]} streams) and of its offsets",
     }
 
 
@@ -303,9 +375,8 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=0,
-                    help="independent steps in flight (host threads x HIP streams); 1 = serial, "
-                         "0 = up to 16, balanced over --steps")
+    ap.add_argument("--inflight", type=int, default=32,
+                    help="independent steps in flight (HIP streams, one host thread); 1 = serial")
     ap.add_argument("--escape-fraction", type=float, default=0.0)
     ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
                     help="c2 (default, the headline): coder round trip; bls2017 / bmshj2018: "
@@ -329,100 +400,85 @@ def main():
         return model_workload(args, world, rank, device, distributed)
 
     lookup = build_tables(device)
-    value = synthetic.sample_symbols(lookup, STREAMS, ELEMS, seed=rank,
-                                     escape_fraction=args.escape_fraction, escape_seed=1000 + rank)
     lookup_t = torch.from_numpy(lookup)            # tables are uploaded once (cached per tensor)
-    value_t = torch.from_numpy(value).to(device)   # inputs resident in HBM
-
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
-
-    def run_steps(total_steps, inflight):
-        """Exactly `total_steps` steps, `inflight` at a time; returns (seconds, last results)."""
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if inflight <= 1:
-            for _ in range(total_steps):
-                res = one_step(lookup_t, value_t)
-            results = [res]
-        else:
-            ticket = iter(range(total_steps))
-            lock = threading.Lock()
-
-            def worker(stream):
-                torch.cuda.set_device(local_rank)
-                res = None
-                with torch.cuda.stream(stream):
-                    while True:
-                        with lock:
-                            if next(ticket, None) is None:
-                                break
-                        res = one_step(lookup_t, value_t)
-                    stream.synchronize()
-                return res
-
-            results = [r for r in pool.map(worker, side_streams[:inflight]) if r is not None]
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
-        return time.perf_counter() - t0, results
-
-    if args.inflight > 0:
-        inflight = max(1, min(args.inflight, args.steps))
-    else:
-        # Up to 16 in flight, but every step in flight is a host thread that spins in the HIP runtime
-        # while it waits, so leave a few of the usable cores (cgroup quota) free: a pool as large as the
-        # quota gets throttled (measured on a 16-core quota: 12 in flight 17.5-18.0 Gpixels/s, 16 in
-        # flight 18.7 on a quiet host but 9-11 on a loaded one).  Then balance, so that the steps split
-        # into full rounds (20 steps: 2 rounds of 10).
-        # Ranks of one node share the host cores.
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        cap = max(1, min(16, (usable_cores()[1] - 4) // max(local_world, 1)))
-        rounds = -(-args.steps // cap)
-        inflight = max(1, -(-args.steps // rounds))
+    inflight = max(1, min(args.inflight, args.steps))
+    # every slot in flight codes its own tensor (inputs resident in HBM)
+    slots = [sample_symbols_device(lookup, 1000 * rank + k, device, args.escape_fraction) for k in range(inflight)]
     side_streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
-    pool = ThreadPoolExecutor(max(inflight, 1))
-    run_steps(args.warmup, 1)
-    if inflight > 1:
-        # several steps in flight = the library's throughput mode (four code streams per wave where a
-        # kernel for it exists); the serial pass below runs in the default latency mode
-        tfc.set_throughput_mode(True)
-        run_steps(max(args.warmup, inflight), inflight)     # warm every stream / thread
-        tfc.set_throughput_mode(False)
+    torch.cuda.synchronize()
 
-    # serial pass: per-kernel durations with the GPU to one launch at a time
+    def run_steps(total_steps, depth, mode):
+        """Exactly `total_steps` steps, `depth` in flight, enqueued by this one thread; returns
+        (seconds, per-step results)."""
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        results = []
+        t0 = time.perf_counter()
+        if depth <= 1:
+            for k in range(total_steps):
+                results.append(one_step(lookup_t, slots[0], mode) + (0,))
+                torch.cuda.current_stream().synchronize()
+        else:
+            for k in range(total_steps):
+                with torch.cuda.stream(side_streams[k % depth]):
+                    results.append(one_step(lookup_t, slots[k % depth], mode) + (k % depth,))
+        t_enqueued = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0, results, t_enqueued
+
+    def verify(results):
+        """Parity gate (outside the timed region): every step's round trip is exact, the sanity flags
+        are true, and no deferred error is pending."""
+        for h, d, dec_r, ok_r, slot in results:
+            tfc.entropy_decode_status(d)
+            tfc.entropy_encode_status(h)
+            assert bool(ok_r.all()), "EntropyDecodeFinalize reported a failed stream"
+            assert torch.equal(dec_r.reshape(STREAMS, ELEMS), slots[slot]), "decode(encode(x)) != x"
+
+    flight_mode = "throughput" if inflight > 1 else "latency"
+    _, res, _ = run_steps(max(args.warmup, 1), 1, "latency")
+    verify(res)
+    if inflight > 1:
+        _, res, _ = run_steps(max(args.warmup, inflight), inflight, flight_mode)     # warm every stream and the pool
+        verify(res)
+    del res
+
+    # serial pass: one step at a time, latency-mode handles; per-kernel durations with the GPU to one launch
     _lib.lib().tfc_profile_enable(1)
     serial_steps = min(args.steps, 5) if inflight > 1 else args.steps
-    serial_elapsed, results = run_steps(serial_steps, 1)
+    serial_elapsed, results, _ = run_steps(serial_steps, 1, "latency")
     enc_ms, enc_n = profile_query("enc_kernel")
     dec_ms, dec_n = profile_query("dec_kernel")
     _lib.lib().tfc_profile_enable(0)
+    verify(results)
     # the timed region: exactly --steps steps
     if inflight > 1:
-        tfc.set_throughput_mode(True)
+        del results
         _lib.lib().tfc_profile_enable(1)
-        elapsed, results = run_steps(args.steps, inflight)
+        elapsed, results, t_enqueued = run_steps(args.steps, inflight, flight_mode)
         cenc_ms, cenc_n = profile_query("enc_kernel")
         cdec_ms, cdec_n = profile_query("dec_kernel")
         _lib.lib().tfc_profile_enable(0)
+        verify(results)
     else:
-        elapsed, cenc_ms, cenc_n, cdec_ms, cdec_n = serial_elapsed, enc_ms, enc_n, dec_ms, dec_n
-    pool.shutdown()
+        elapsed, cenc_ms, cenc_n, cdec_ms, cdec_n, t_enqueued = serial_elapsed, enc_ms, enc_n, dec_ms, dec_n, 0.0
     if distributed:
         t = torch.tensor([elapsed, serial_elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, serial_elapsed = float(t[0].item()), float(t[1].item())
-    blob, offsets, decoded, ok = results[-1]
-
-    # parity gate (outside the timed region): round trip is exact, sanity flags true
-    for _, _, dec_r, ok_r in results:
-        assert bool(ok_r.all()), "EntropyDecodeFinalize reported a failed stream"
-        assert torch.equal(dec_r.reshape(STREAMS, ELEMS), value_t), "decode(encode(x)) != x"
-    total_bytes = int(offsets[-1].item())
+    # slot 0's bytes, for the comparison with the CPU reference
+    import hashlib
+    h0 = next(r[0] for r in results if r[4] == 0)
+    strings = tfc.entropy_encode_finalize(h0)
+    blob0 = h0.blob.cpu().numpy()
+    offs0 = h0.offsets.cpu().numpy().astype(np.int64)
+    total_bytes = int(offs0[-1])
+    del strings, results
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -440,6 +496,9 @@ def main():
         dom, dom_ms, dom_bytes = ("dec_kernel", dec_tr, alg_dec) if dec_tr >= enc_tr else (
             "enc_kernel", enc_tr, alg_enc)
         achieved = dom_bytes / 1e9 / (dom_ms / 1e3) if dom_ms > 0 else 0.0
+        lanes = inflight > 1
+        dom_symbol = {("dec_kernel", True): "dec_lanes_kernel", ("enc_kernel", True): "enc_lanes_kernel",
+                      ("dec_kernel", False): "dec_fast_kernel", ("enc_kernel", False): "enc_fast_kernel"}[(dom, lanes)]
         out = {
             "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
             "value": round(value_mpix, 2),
@@ -461,37 +520,47 @@ def main():
                 "escape_fraction": args.escape_fraction,
                 "parallelism": f"batch-sharded x{world}",
                 "steps_in_flight": inflight,
-                "library_mode": "throughput (tfc_set_throughput_mode(1))" if inflight > 1 else "latency (default)",
+                "host_threads": 1,
+                "distinct_inputs": inflight,
+                "library_mode": "TFC_MODE_THROUGHPUT handles (one code stream per lane), deferred errors, "
+                                "device finalize" if lanes else "TFC_MODE_LATENCY handles (one wave per stream)",
             },
             "bits_per_pixel": round(8.0 * total_bytes / (STREAMS * PIXELS_PER_STREAM), 5),
             "bits_per_symbol": round(8.0 * total_bytes / symbols, 4),
             "gsymbols_per_s_roundtrip": round(world * symbols / 1e9 / (elapsed / args.steps), 3),
-            "kernels_ms": {"enc_kernel": round(enc_avg, 4), "dec_kernel": round(dec_avg, 4)},
+            "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 4),
+            "kernels_ms": {"enc_kernel": round(enc_avg, 4), "dec_kernel": round(dec_avg, 4),
+                           "note": "latency-mode kernels, one launch at a time"},
             "kernels_ms_in_flight": {"enc_kernel": round(cenc_ms / max(cenc_n, 1), 4),
                                      "dec_kernel": round(cdec_ms / max(cdec_n, 1), 4)},
             "serial": {"ms_per_step": round(1e3 * serial_elapsed / serial_steps, 4),
                        "mpixels_s": round(pixels_all / 1e6 / (serial_elapsed / serial_steps), 2),
-                       "steps": serial_steps},
+                       "steps": serial_steps, "library_mode": "TFC_MODE_LATENCY"},
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
+                "bound": "hbm", "kernel": dom_symbol, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic("dec_fast_kernel" if dom == "dec_kernel" else "enc_fast_kernel"),
-                "traffic_source": "profiles/r01_o_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                  "WRITE_SIZE passes of this command; 2*FETCH + WRITE, KiB -> bytes)",
+                "traffic": pmc_traffic(dom_symbol, PMC_PROFILE, CODER_SOURCES),
+                "traffic_source": f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "this command; 2*FETCH + WRITE, KiB -> bytes); null = taken on other sources",
                 "algorithmic_bytes": int(dom_bytes),
-                "note": "serial chain per stream (512 chains): VALU-issue / synchronisation bound, not "
-                        "HBM bound; per-launch duration = HIP-event average over the timed region, where "
-                        "launches of the other steps in flight share the SIMDs (serial: kernels_ms); see DESIGN.md",
+                "note": "serial chain per stream: latency bound (a launch is 8 waves), not HBM bound; per-launch "
+                        "duration = HIP-event average over the timed region, where the launches of the other "
+                        "steps in flight are co-resident; the aggregate rate of all steps in flight is "
+                        "path_gbytes_s_in_flight; see DESIGN.md",
                 "path_gbytes_s_in_flight": round((alg_enc + alg_dec) * args.steps / 1e9 / elapsed, 2),
             },
         }
-        out["valu_issue_bound"] = valu_issue_floor(1e3 * elapsed / args.steps, inflight > 1)
+        out["valu_issue_bound"] = valu_issue_floor(
+            1e3 * elapsed / args.steps, ("enc_lanes_kernel", "dec_lanes_kernel") if lanes else ("enc_fast_kernel", "dec_fast_kernel"))
         if world == 1:
             out["gdn_fwd"] = gdn_forward_bandwidth(device)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(lookup, value, total_bytes)
+            out["cpu_baseline"] = cpu_baseline(lookup, slots[0].cpu().numpy(),
+                                               hashlib.sha256(blob0.tobytes()).hexdigest(),
+                                               hashlib.sha256(offs0.tobytes()).hexdigest())
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+            assert out["cpu_baseline"]["bytes_identical_to_gpu"], "GPU bytes differ from the CPU reference's"
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

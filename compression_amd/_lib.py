@@ -20,24 +20,31 @@ SIGNATURES = {
     "tfc_abi_version": (_int, []),
     "tfc_last_error": (C.c_char_p, []),
     "tfc_profile_enable": (None, [_int]),
-    "tfc_set_throughput_mode": (None, [_int]),
-    "tfc_get_throughput_mode": (_int, []),
+    "tfc_set_default_mode": (_int, [_int]),
+    "tfc_get_default_mode": (_int, []),
     "tfc_profile_query": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "tfc_tables_create": (_int, [_vp, _int, _i64, _i64, _vp, C.POINTER(_vp)]),
     "tfc_tables_count": (_i64, [_vp]),
     "tfc_tables_destroy": (None, [_vp]),
     "tfc_encoder_create": (_int, [_vp, _i64, _vp, C.POINTER(_vp)]),
+    "tfc_encoder_set_mode": (_int, [_vp, _int]),
+    "tfc_encoder_set_deferred_errors": (_int, [_vp, _int]),
     "tfc_encoder_encode": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "tfc_encoder_encode_quantized": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
     "tfc_encoder_encode_quantized_indexed": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _vp]),
     "tfc_encoder_finalize": (_int, [_vp, _vp, C.POINTER(_i64)]),
+    "tfc_encoder_finalize_device": (_int, [_vp, _vp]),
+    "tfc_encoder_status": (_int, [_vp, _vp, C.POINTER(_i64)]),
     "tfc_encoder_result": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "tfc_encoder_read": (_int, [_vp, _vp, _vp, _int, _vp]),
     "tfc_encoder_destroy": (None, [_vp]),
     "tfc_decoder_create": (_int, [_vp, _vp, _vp, _i64, _int, _vp, C.POINTER(_vp)]),
+    "tfc_decoder_set_mode": (_int, [_vp, _int]),
     "tfc_decoder_decode": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "tfc_decoder_decode_dequantized": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
     "tfc_decoder_finalize": (_int, [_vp, _vp, _vp]),
+    "tfc_decoder_finalize_device": (_int, [_vp, _vp, _vp]),
+    "tfc_decoder_status": (_int, [_vp, _vp]),
     "tfc_decoder_destroy": (None, [_vp]),
     "tfc_range_encode": (_int, [_vp, _vp, _int, _vp, _vp, _int, _int, _int, _vp,
                                 C.POINTER(_vp), C.POINTER(_i64)]),

@@ -95,16 +95,23 @@ KernelTimer::~KernelTimer() {
 using namespace tfc;
 
 namespace {
-std::atomic<int>& throughput_mode() {
+std::atomic<int>& default_mode() {
   static std::atomic<int> mode{[] {
-    const char* e = std::getenv("TFC_THROUGHPUT_MODE");
-    return e && e[0] == '1' ? 1 : 0;
+    const char* e = std::getenv("TFC_DEFAULT_MODE");
+    if (e && !std::strcmp(e, "latency")) return TFC_MODE_LATENCY;
+    if (e && !std::strcmp(e, "throughput")) return TFC_MODE_THROUGHPUT;
+    return TFC_MODE_AUTO;
   }()};
   return mode;
 }
 }  // namespace
-extern "C" void tfc_set_throughput_mode(int on) { throughput_mode().store(on ? 1 : 0); }
-extern "C" int tfc_get_throughput_mode(void) { return throughput_mode().load(); }
+extern "C" int tfc_set_default_mode(int mode) {
+  if (mode != TFC_MODE_AUTO && mode != TFC_MODE_LATENCY && mode != TFC_MODE_THROUGHPUT)
+    return fail("unknown mode %d", mode);
+  default_mode().store(mode);
+  return 0;
+}
+extern "C" int tfc_get_default_mode(void) { return default_mode().load(); }
 
 extern "C" void tfc_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_profile_mutex);
@@ -149,6 +156,10 @@ struct tfc_tables {
   DevBuf d_dec_image, d_dec_dir;   // decoder LDS image: d_fast + pad + pivot arrays; row directory
   int dec_words = 0;
   bool dec_fast_ok = false;
+  // lane-per-stream kernels (range_lanes.h): one LDS image; the encoder uses its first lane_enc_bytes
+  DevBuf d_lane_image;
+  int lane_enc_bytes = 0, lane_dec_bytes = 0;
+  bool lanes_ok = false;
   int max_abs_prec = 0;
   bool any_escape = false;
   int64_t max_row = 0;
@@ -249,6 +260,9 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       const int cdf0 = r.x + 1;
       const int chunk = (nsym + 63) / 64;
       if (chunk > 64) ok = false;
+      // a zero-width FIRST symbol has the upper bound 0, whose "bound - 1" form wraps and matches every
+      // offset: such tables keep the generic decoder (64-bit comparison, range_coder.h:204-222)
+      if (nsym > 1 && fast[cdf0 + 1] == 0) ok = false;
       int4 d;
       d.y = cdf0;
       d.z = nsym | (std::max(chunk, 1) << 16);
@@ -273,6 +287,67 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       TFC_HIP(hipMemcpyAsync(t->d_dec_dir.p, dir.data(), sizeof(int4) * dir.size(),
                              hipMemcpyHostToDevice, st));
     TFC_HIP(hipStreamSynchronize(st));
+  }
+  {
+    // Image of the lane-per-stream kernels: directory (one entry per table + the binary row of the
+    // escape bits), 16-bit scaled cdf entries (modulo 2^16: only a row's last entry is 2^16), then per
+    // row the bitmap of its boundaries over [0, 2^precision) and the running count of boundaries
+    // before each 64-bit word.  Rows must be strictly increasing (rank = popcount) — rows with
+    // zero-width symbols keep the wave-per-stream kernels.
+    const size_t ntab = t->rows.size();
+    bool ok = ntab > 0;
+    size_t cdf_entries = 3, words = 1;
+    for (const int2& r : t->rows) {
+      const int prec = std::abs(t->host[r.x]);
+      const int nsym = r.y - 2;
+      if (nsym > 65535) ok = false;
+      for (int k = 1; ok && k <= nsym; ++k)
+        if (t->host[r.x + 1 + k] <= t->host[r.x + k]) ok = false;
+      cdf_entries += static_cast<size_t>(nsym + 1);
+      words += std::max<size_t>(1, (size_t{1} << prec) / 64);
+    }
+    const size_t dir_bytes = sizeof(tfc::LaneRow) * (ntab + 1);
+    const size_t cdf_bytes = (2 * cdf_entries + 15) & ~size_t{15};
+    const size_t enc_bytes = dir_bytes + cdf_bytes;
+    const size_t dec_bytes = enc_bytes + 8 * words + ((2 * words + 15) & ~size_t{15});
+    if (dec_bytes > 160 * 1024) ok = false;
+    if (ok) {
+      std::vector<uint8_t> image(dec_bytes, 0);
+      tfc::LaneRow* dir = reinterpret_cast<tfc::LaneRow*>(image.data());
+      uint16_t* cdf16 = reinterpret_cast<uint16_t*>(image.data() + dir_bytes);
+      uint64_t* bits = reinterpret_cast<uint64_t*>(image.data() + enc_bytes);
+      uint16_t* cum = reinterpret_cast<uint16_t*>(image.data() + enc_bytes + 8 * words);
+      size_t ce = 0, wo = 0;
+      auto add_row = [&](tfc::LaneRow& d, const int32_t* cdf, int nsym, int prec, bool esc) {
+        const size_t nw = std::max<size_t>(1, (size_t{1} << prec) / 64);
+        d.cdf = static_cast<unsigned int>(dir_bytes + 2 * ce);
+        d.bits = static_cast<unsigned int>(enc_bytes + 8 * wo);
+        d.cum = static_cast<unsigned int>(enc_bytes + 8 * words + 2 * wo);
+        d.info = static_cast<unsigned int>(nsym) | (static_cast<unsigned int>(16 - prec) << 16) |
+                 (esc ? 0x80000000u : 0u);
+        for (int k = 0; k <= nsym; ++k) cdf16[ce + k] = static_cast<uint16_t>(cdf[k] << (16 - prec));
+        for (int k = 0; k < nsym; ++k) bits[wo + (cdf[k] >> 6)] |= uint64_t{1} << (cdf[k] & 63);
+        unsigned int run = 0;
+        for (size_t w = 0; w < nw; ++w) {
+          cum[wo + w] = static_cast<uint16_t>(run);
+          run += static_cast<unsigned int>(__builtin_popcountll(bits[wo + w]));
+        }
+        ce += static_cast<size_t>(nsym + 1);
+        wo += nw;
+      };
+      for (size_t i = 0; i < ntab; ++i) {
+        const int2 r = t->rows[i];
+        add_row(dir[i], &t->host[r.x + 1], r.y - 2, std::abs(t->host[r.x]), t->host[r.x] < 0);
+      }
+      const int32_t binary_cdf[3] = {0, 1, 2};
+      add_row(dir[ntab], binary_cdf, 2, 1, false);
+      TFC_HIP(t->d_lane_image.alloc(image.size(), st));
+      TFC_HIP(hipMemcpyAsync(t->d_lane_image.p, image.data(), image.size(), hipMemcpyHostToDevice, st));
+      TFC_HIP(hipStreamSynchronize(st));
+      t->lane_enc_bytes = static_cast<int>(enc_bytes);
+      t->lane_dec_bytes = static_cast<int>(dec_bytes);
+      t->lanes_ok = true;
+    }
   }
   TFC_HIP(hipStreamSynchronize(st));
   *out = t.release();
@@ -310,6 +385,9 @@ struct TableView {
 struct SymInt32 {          // plain int32 symbols
   const int32_t* value;
   __device__ int32_t load(int64_t pos, int /*table*/) const { return value[pos]; }
+  // split form for kernels that request an element before they know its table
+  __device__ int32_t raw(int64_t pos) const { return value[pos]; }
+  __device__ int32_t quant(int32_t r, int /*table*/) const { return r; }
 };
 
 template <typename T>
@@ -332,8 +410,10 @@ struct SymQuant {
   const T* y;
   const float* qoffset;        // may be null
   const int32_t* cdf_offset;
-  __device__ int32_t load(int64_t pos, int table) const {
-    float f = to_float<T>(y[pos]);
+  __device__ int32_t load(int64_t pos, int table) const { return quant(y[pos], table); }
+  __device__ T raw(int64_t pos) const { return y[pos]; }
+  __device__ int32_t quant(T r, int table) const {
+    float f = to_float<T>(r);
     if (qoffset) f = to_float<T>(from_float<T>(f - to_float<T>(from_float<T>(qoffset[table]))));
     return static_cast<int32_t>(rintf(f)) - cdf_offset[table];
   }
@@ -689,16 +769,19 @@ __global__ void __launch_bounds__(kBlock) enc_kernel(EncParams p, Src src) {
 
 }  // namespace tfc
 #include "range_encoder_fast.h"
-#include "range_encoder_quad.h"
 namespace tfc {
 
 // ---- finalize -------------------------------------------------------------
 
 struct ChunkRef {
   const uint8_t* data;
-  const long long* off;
+  const long long* off;      // start of every stream's piece, or null: stream s starts at s * stride
   const unsigned int* len;
+  long long stride;
 };
+__device__ inline const uint8_t* chunk_piece(const ChunkRef& c, int64_t s) {
+  return c.data + (c.off ? c.off[s] : s * c.stride);
+}
 
 // Tail of every stream per RangeEncoder::Finalize (range_coder.cc:266-307); one
 // thread per stream.  tail[s] = {head bytes (<= 2), 0xFFFF digits to insert,
@@ -811,7 +894,7 @@ __global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const
   long long done = 0;
   for (int c = 0; c < nchunks; ++c) {
     const unsigned int n = chunks[c].len[s];
-    wave_copy(dst + done, chunks[c].data + chunks[c].off[s], n, lane);
+    wave_copy(dst + done, chunk_piece(chunks[c], s), n, lane);
     done += n;
   }
   const Tail t = tail[s];
@@ -1019,8 +1102,7 @@ __global__ void __launch_bounds__(kBlock) dec_kernel(DecParams p, Dst dst) {
 
 }  // namespace tfc
 #include "range_decoder_fast.h"
-#include "range_decoder_quad.h"
-#include "range_decoder_tput.h"
+#include "range_lanes.h"
 namespace tfc {
 
 // Reads the first four bytes of every stream (RangeDecoder ctor,
@@ -1072,19 +1154,32 @@ __global__ void fill_state_kernel(uint4* state, int64_t n, uint4 v) {
 
 struct EncChunk {
   DevBuf data, off, len;
+  long long stride = 0;         // lane kernels: stream s starts at s * stride (off unused)
 };
+
+// Kernel family of a handle (fixed at its first coding call; the families keep different state
+// encodings between calls).
+enum Family { kGeneric = 0, kFast = 1, kLanes = 2 };
 
 struct tfc_encoder {
   const tfc_tables* tables = nullptr;
   int64_t streams = 0;
-  bool fast = false;            // fast kernels (and their state encoding) are in use
+  int mode = TFC_MODE_AUTO;
+  int family = -1;              // Family, chosen by the first encode call
+  bool fast = false;            // wave-per-stream fast kernels are possible for these tables
   int fast_waves = 0;           // waves per workgroup for the fast kernels
   size_t fast_lds = 0;
+  bool deferred = false;        // range errors are reported by finalize / status instead of encode
+  bool poisoned = false;        // a range error was reported: the streams are no longer meaningful
+  int64_t elems_last = 0;       // geometry of the call the recorded error belongs to
+  bool indexed_last = false;
   DevBuf state;                 // uint4 [streams]
   DevBuf oflag;                 // unsigned int: a kernel ran out of slab space (internal error)
+  DevBuf status;                // u64[4]: first error position, its value, its index, coder calls
   std::vector<EncChunk> chunks;
   // results
   bool finalized = false;
+  bool total_known = false;
   DevBuf blob, offsets;
   int64_t total = 0;
 };
@@ -1135,38 +1230,150 @@ inline int64_t waves_per_block_limit() {
   return v;
 }
 
+// Which kernels a handle uses.  The lane-per-stream kernels issue ~1 vector instruction per symbol
+// and 64 streams against 15-28 and 1 for the wave-per-stream kernels, but a lone call takes
+// elems x ~400 cycles against elems x ~90-160: they win when the streams of all calls in flight
+// outnumber the chip's SIMDs several times.  AUTO decides on the stream count of the handle alone;
+// a caller that keeps many calls in flight asks for TFC_MODE_THROUGHPUT.
+int select_family(const tfc_tables* t, int mode, int64_t streams, int64_t elems, bool fast_ok) {
+  const char* force = std::getenv("TFC_FORCE_GENERIC");
+  if (force && force[0] == '1') return kGeneric;
+  const bool lanes_ok = t->lanes_ok && elems < (int64_t{1} << 31);
+  if (mode == TFC_MODE_AUTO) mode = tfc_get_default_mode();
+  if (mode == TFC_MODE_THROUGHPUT && lanes_ok) return kLanes;
+  if (mode == TFC_MODE_AUTO && lanes_ok && streams >= 4096) return kLanes;
+  return fast_ok ? kFast : kGeneric;
+}
+
+// Streams per workgroup of the lane kernels: one wave (64 streams) until the launch fills the chip,
+// so that a 512-stream call spreads over eight CUs (and XCDs), then more waves behind each LDS image.
+inline int lanes_block(int64_t streams) {
+  const int64_t waves = ceil_div(streams, 64);
+  const int64_t per = std::min<int64_t>(8, std::max<int64_t>(1, waves / 256));
+  return static_cast<int>(64 * per);
+}
+
+// Slab bytes per stream that a lane-encoder call can never exceed, from the table headers alone (no
+// counting pass, no read-back).  A call emits at most one 16-bit digit; and a call of probability P
+// shrinks the span by at most 1 + log2(1/P) bits, a digit leaves every 16 bits: a symbol of a
+// precision-p row costs <= p + 1 bits, each of the <= 64 binary calls of an escape code
+// 1 + 2^-15 bits.  `carry` covers digits an earlier call left delayed.
+unsigned int lanes_slab_bytes(const tfc_tables* t, int64_t elems) {
+  const long long carry = 80;
+  long long bytes = 2 * elems;
+  if (t->any_escape) bytes = (elems * (t->max_abs_prec + 1 + 65) + 7) / 8 + 8;
+  bytes = (bytes + carry + 15) & ~15ll;
+  return static_cast<unsigned int>(std::min<long long>(bytes, 0xFFFFFFF0ll));
+}
+
+// Records value / index of the first range error next to its position (stream-ordered, so the
+// inputs are still alive whatever the caller does after the encode call returns).
 template <typename Src>
-int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& src,
-               hipStream_t st, const std::function<int(uint64_t)>& on_error) {
+__global__ void enc_error_kernel(unsigned long long* status, Src src, const int32_t* index,
+                                 int64_t elems, int ntab) {
+  const unsigned long long pos = status[0];
+  if (pos == ~0ull || status[3] != 0ull) return;
+  int t = static_cast<int>((pos % static_cast<unsigned long long>(elems)) % static_cast<unsigned long long>(ntab));
+  long long ix = 0;
+  if (index) {
+    ix = index[pos];
+    t = (ix < 0 || ix >= ntab) ? 0 : static_cast<int>(ix);
+  }
+  status[1] = static_cast<unsigned long long>(static_cast<long long>(src.load(static_cast<int64_t>(pos), t)));
+  status[2] = static_cast<unsigned long long>(ix);
+  status[3] = 1ull;
+}
+
+// Builds the reference's range-error text for the element at `pos`.
+int range_error_text(const tfc_tables* t, bool has_index, int32_t idx, int64_t channel,
+                     int32_t value) {
+  const int64_t ntab = static_cast<int64_t>(t->rows.size());
+  if (has_index && (idx < 0 || idx >= ntab))
+    return fail("index=%d not in range [0, %lld)", idx, static_cast<long long>(ntab));
+  const int2 row = t->rows[has_index ? idx : channel];
+  return fail("value=%d not in range [0, %d)", value, row.y - 2);
+}
+
+int encoder_error(tfc_encoder* e, const unsigned long long* host_status) {
+  e->poisoned = true;
+  const unsigned long long pos = host_status[0];
+  const int64_t ch = static_cast<int64_t>((pos % static_cast<unsigned long long>(std::max<int64_t>(e->elems_last, 1))) %
+                                          e->tables->rows.size());
+  return range_error_text(e->tables, e->indexed_last, static_cast<int32_t>(static_cast<long long>(host_status[2])),
+                          ch, static_cast<int32_t>(static_cast<long long>(host_status[1])));
+}
+
+template <typename Src>
+int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& src, hipStream_t st) {
   if (e->finalized) return fail("encoder handle was already finalized");
+  if (e->poisoned) return fail("encoder handle met a range error in an earlier call");
   if (elems < 0) return fail("negative element count");
   if (e->streams == 0 || elems == 0) return 0;
   const tfc_tables* t = e->tables;
   if (t->rows.empty()) return fail("index=0 not in range [0, 0)");
+  if (e->family < 0) e->family = select_family(t, e->mode, e->streams, elems, e->fast);
+  if (e->family == kLanes && elems >= (int64_t{1} << 31)) return fail("encode call too large for this handle");
+  e->elems_last = elems;
+  e->indexed_last = index != nullptr;
 
   EncChunk ch;
-  DevBuf calls, status;
-  TFC_HIP(calls.alloc(sizeof(unsigned long long) * e->streams, st));
-  TFC_HIP(status.alloc(sizeof(unsigned long long) * 3, st));
-  TFC_HIP(hipMemsetAsync(calls.p, 0, sizeof(unsigned long long) * e->streams, st));
-  // status[0] = first error position, [1] = total capacity, [2] = coder calls of all streams
-  const unsigned long long init[3] = {~0ull, 0ull, 0ull};
-  TFC_HIP(hipMemcpyAsync(status.p, init, sizeof(init), hipMemcpyHostToDevice, st));
-  TFC_HIP(ch.off.alloc(sizeof(long long) * (e->streams + 1), st));
   TFC_HIP(ch.len.alloc(sizeof(unsigned int) * e->streams, st));
-
   EncParams p;
   p.tab = view_of(t);
   p.index = index;
   p.streams = e->streams;
   p.elems = elems;
-  p.calls = calls.as<unsigned long long>();
-  p.first_error = status.as<unsigned long long>();
+  p.calls = nullptr;
+  p.first_error = e->status.as<unsigned long long>();
   p.state = e->state.as<uint4>();
   p.chunk = nullptr;
-  p.chunk_off = ch.off.as<long long>();
+  p.chunk_off = nullptr;
   p.chunk_len = ch.len.as<unsigned int>();
   p.overflow_flag = e->oflag.as<unsigned int>();
+  unsigned long long host_status[4] = {~0ull, 0ull, 0ull, 0ull};
+
+  if (e->family == kLanes) {
+    // one kernel, no counting pass, no read-back unless the caller wants range errors now
+    LaneArgs la;
+    la.image = t->d_lane_image.as<uint32_t>();
+    la.bytes = t->lane_enc_bytes;
+    la.ntab = p.tab.ntab;
+    la.cap = lanes_slab_bytes(t, elems);
+    ch.stride = la.cap;
+    TFC_HIP(ch.data.alloc(static_cast<size_t>(la.cap) * e->streams, st));
+    p.chunk = ch.data.as<uint8_t>();
+    const int block = lanes_block(e->streams);
+    {
+      KernelTimer timer("enc_kernel", st);
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_lanes_kernel<Src>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, la.bytes));
+      hipLaunchKernelGGL((enc_lanes_kernel<Src>), dim3(static_cast<unsigned>(ceil_div(e->streams, block))),
+                         dim3(block), la.bytes, st, p, src, la);
+    }
+    hipLaunchKernelGGL((enc_error_kernel<Src>), dim3(1), dim3(1), 0, st, p.first_error, src, index, elems,
+                       p.tab.ntab);
+    TFC_HIP(hipGetLastError());
+    e->chunks.push_back(std::move(ch));
+    if (!e->deferred) {
+      TFC_HIP(hipMemcpyAsync(host_status, e->status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
+      TFC_HIP(hipStreamSynchronize(st));
+      if (host_status[0] != ~0ull) return encoder_error(e, host_status);
+    }
+    return 0;
+  }
+
+  // wave-per-stream families: validation + exact output bound first (one read-back)
+  DevBuf calls, cstat;
+  TFC_HIP(calls.alloc(sizeof(unsigned long long) * e->streams, st));
+  TFC_HIP(cstat.alloc(sizeof(unsigned long long) * 3, st));
+  TFC_HIP(hipMemsetAsync(calls.p, 0, sizeof(unsigned long long) * e->streams, st));
+  // cstat[0] = first error position, [1] = total capacity, [2] = coder calls of all streams
+  const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+  TFC_HIP(hipMemcpyAsync(cstat.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  TFC_HIP(ch.off.alloc(sizeof(long long) * (e->streams + 1), st));
+  p.calls = calls.as<unsigned long long>();
+  p.first_error = cstat.as<unsigned long long>();
+  p.chunk_off = ch.off.as<long long>();
 
   const int64_t tiles = ceil_div(elems, kCountTile);
   if (e->streams * tiles >= (int64_t{1} << 31)) return fail("encode call too large for one launch");
@@ -1174,31 +1381,31 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   hipLaunchKernelGGL((enc_count_kernel<Src>), dim3(static_cast<unsigned>(e->streams * tiles)),
                      dim3(256), count_lds, st, p, src);
   hipLaunchKernelGGL(enc_offsets_kernel, dim3(1), dim3(1024), 0, st, p.calls, p.state,
-                     e->fast ? 1 : 0, e->streams, ch.off.as<long long>(),
-                     status.as<unsigned long long>() + 1);
-  unsigned long long host_status[3];
-  TFC_HIP(hipMemcpyAsync(host_status, status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
+                     e->family == kFast ? 1 : 0, e->streams, ch.off.as<long long>(),
+                     cstat.as<unsigned long long>() + 1);
+  unsigned long long count_status[3];
+  TFC_HIP(hipMemcpyAsync(count_status, cstat.p, sizeof(count_status), hipMemcpyDeviceToHost, st));
   TFC_HIP(hipStreamSynchronize(st));
-  if (host_status[0] != ~0ull) return on_error(host_status[0]);
+  if (count_status[0] != ~0ull) {
+    // nothing was appended; fetch the offending element for the message
+    TFC_HIP(hipMemcpyAsync(e->status.p, count_status, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((enc_error_kernel<Src>), dim3(1), dim3(1), 0, st, e->status.as<unsigned long long>(), src,
+                       index, elems, p.tab.ntab);
+    TFC_HIP(hipMemcpyAsync(host_status, e->status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
+    const unsigned long long clear[4] = {~0ull, 0ull, 0ull, 0ull};
+    TFC_HIP(hipStreamSynchronize(st));
+    TFC_HIP(hipMemcpyAsync(e->status.p, clear, sizeof(clear), hipMemcpyHostToDevice, st));
+    TFC_HIP(hipStreamSynchronize(st));
+    const int rc = encoder_error(e, host_status);
+    e->poisoned = false;      // the validation pass runs before anything is appended
+    return rc;
+  }
 
-  TFC_HIP(ch.data.alloc(host_status[1], st));
+  TFC_HIP(ch.data.alloc(count_status[1], st));
   p.chunk = ch.data.as<uint8_t>();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(e->streams, kWavesPerBlock));
-  // throughput mode: four streams per wave (range_encoder_quad.h)
-  if (e->fast && throughput_mode().load() != 0 && elems > 0) {
-    KernelTimer timer("enc_kernel", st);
-    const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(e->streams, 4))));
-    // tables + row directory + one small call queue per row (4 per wave)
-    const size_t quad_lds = e->fast_lds - sizeof(unsigned int) * kRingWords * e->fast_waves +
-                            sizeof(unsigned int) * 4 * kQuadQueue * waves;
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_quad_kernel<Src>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds_request(quad_lds))));
-    hipLaunchKernelGGL((enc_quad_kernel<Src>),
-                       dim3(static_cast<unsigned>(ceil_div(e->streams, 4 * waves))),
-                       dim3(64 * waves), lds_request(quad_lds), st, p, src);
-  } else if (e->fast) {
+  if (e->family == kFast) {
     KernelTimer timer("enc_kernel", st);
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_fast_kernel<Src>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1221,16 +1428,6 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   return 0;
 }
 
-// Builds the reference's range-error text for the element at `pos`.
-int range_error_text(const tfc_tables* t, bool has_index, int32_t idx, int64_t channel,
-                     int32_t value) {
-  const int64_t ntab = static_cast<int64_t>(t->rows.size());
-  if (has_index && (idx < 0 || idx >= ntab))
-    return fail("index=%d not in range [0, %lld)", idx, static_cast<long long>(ntab));
-  const int2 row = t->rows[has_index ? idx : channel];
-  return fail("value=%d not in range [0, %d)", value, row.y - 2);
-}
-
 }  // namespace
 
 extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, void* stream,
@@ -1247,8 +1444,7 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
     const size_t fixed = sizeof(uint16_t) * ((tables->host.size() + 3) & ~size_t{3}) +
                          sizeof(int2) * tables->rows.size();
     const size_t ring = sizeof(unsigned int) * kRingWords;
-    const char* force = std::getenv("TFC_FORCE_GENERIC");
-    if (!(force && force[0] == '1') && !tables->rows.empty() && fixed + ring <= 160 * 1024) {
+    if (!tables->rows.empty() && fixed + ring <= 160 * 1024) {
       e->fast = true;
       const size_t fit = (160 * 1024 - fixed) / ring;
       const size_t want = static_cast<size_t>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(streams, 64))));
@@ -1259,6 +1455,9 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
   TFC_HIP(e->state.alloc(sizeof(uint4) * std::max<int64_t>(streams, 1), st));
   TFC_HIP(e->oflag.alloc(sizeof(unsigned int), st));
   TFC_HIP(hipMemsetAsync(e->oflag.p, 0, sizeof(unsigned int), st));
+  TFC_HIP(e->status.alloc(sizeof(unsigned long long) * 4, st));
+  TFC_HIP(hipMemsetAsync(e->status.p, 0, sizeof(unsigned long long) * 4, st));
+  TFC_HIP(hipMemsetAsync(e->status.p, 0xFF, sizeof(unsigned long long), st));
   if (streams)
     hipLaunchKernelGGL(fill_state_kernel, dim3(static_cast<unsigned>(ceil_div(streams, 256))),
                        dim3(256), 0, st, e->state.as<uint4>(), streams,
@@ -1267,46 +1466,33 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
   return 0;
 }
 
+extern "C" int tfc_encoder_set_mode(tfc_encoder* e, int mode) {
+  if (mode != TFC_MODE_AUTO && mode != TFC_MODE_LATENCY && mode != TFC_MODE_THROUGHPUT)
+    return fail("unknown mode %d", mode);
+  if (e->family >= 0) return fail("the mode of a handle is fixed by its first coding call");
+  e->mode = mode;
+  return 0;
+}
+
+extern "C" int tfc_encoder_set_deferred_errors(tfc_encoder* e, int on) {
+  e->deferred = on != 0;
+  return 0;
+}
+
 extern "C" int tfc_encoder_encode(tfc_encoder* e, const int32_t* value, const int32_t* index,
                                   int64_t elems, void* stream) {
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  SymInt32 src{value};
-  auto on_error = [&](uint64_t pos) -> int {
-    int32_t v = 0, ix = 0;
-    if (hipMemcpy(&v, value + pos, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("value out of range");
-    if (index && hipMemcpy(&ix, index + pos, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("index out of range");
-    const int64_t ch = static_cast<int64_t>((pos % elems) % e->tables->rows.size());
-    return range_error_text(e->tables, index != nullptr, ix, ch, v);
-  };
-  return run_encode(e, index, elems, src, st, on_error);
+  return run_encode(e, index, elems, SymInt32{value}, static_cast<hipStream_t>(stream));
 }
 
 namespace {
-
-template <typename T>
-int encode_quantized_t(tfc_encoder* e, const void* y, const float* qoffset, const int32_t* index,
-                       const int32_t* cdf_offset, int64_t elems, hipStream_t st) {
-  SymQuant<T> src{static_cast<const T*>(y), qoffset, cdf_offset};
-  auto on_error = [&](uint64_t pos) -> int {
-    int32_t ix = 0;
-    if (index && hipMemcpy(&ix, index + pos, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("index out of range");
-    const int64_t ntab = static_cast<int64_t>(e->tables->rows.size());
-    if (index && (ix < 0 || ix >= ntab))
-      return fail("index=%d not in range [0, %lld)", ix, static_cast<long long>(ntab));
-    return fail("value=<quantized element %llu> not in range [0, %d)",
-                static_cast<unsigned long long>(pos),
-                e->tables->rows[index ? ix : (pos % elems) % ntab].y - 2);
-  };
-  return run_encode(e, index, elems, src, st, on_error);
-}
 
 int dispatch_quantized(tfc_encoder* e, const void* y, int dtype, const float* qoffset,
                        const int32_t* index, const int32_t* cdf_offset, int64_t elems,
                        hipStream_t st) {
   switch (dtype) {
-    case 0: return encode_quantized_t<float>(e, y, qoffset, index, cdf_offset, elems, st);
-    case 1: return encode_quantized_t<__hip_bfloat16>(e, y, qoffset, index, cdf_offset, elems, st);
-    case 2: return encode_quantized_t<__half>(e, y, qoffset, index, cdf_offset, elems, st);
+    case 0: return run_encode(e, index, elems, SymQuant<float>{static_cast<const float*>(y), qoffset, cdf_offset}, st);
+    case 1: return run_encode(e, index, elems, SymQuant<__hip_bfloat16>{static_cast<const __hip_bfloat16*>(y), qoffset, cdf_offset}, st);
+    case 2: return run_encode(e, index, elems, SymQuant<__half>{static_cast<const __half*>(y), qoffset, cdf_offset}, st);
     default: return fail("unsupported dtype code %d", dtype);
   }
 }
@@ -1332,25 +1518,28 @@ extern "C" int tfc_encoder_encode_quantized_indexed(tfc_encoder* e, const void* 
                             static_cast<hipStream_t>(stream));
 }
 
-extern "C" int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total_bytes) {
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (e->finalized) {
-    *total_bytes = e->total;
-    return 0;
-  }
+namespace {
+
+// Tail + lengths + offsets on the device; `exact` = synchronise to size the blob exactly, otherwise
+// the blob gets the slabs' total capacity and nothing is read back.
+int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
+  if (e->finalized) return 0;
   const int64_t n = e->streams;
   TFC_HIP(e->offsets.alloc(sizeof(long long) * (n + 1), st));
   if (n == 0) {
     TFC_HIP(hipMemsetAsync(e->offsets.p, 0, sizeof(long long), st));
     TFC_HIP(e->blob.alloc(0, st));
     e->total = 0;
+    e->total_known = true;
     e->finalized = true;
-    *total_bytes = 0;
     return 0;
   }
   std::vector<ChunkRef> refs;
-  for (auto& c : e->chunks)
-    refs.push_back(ChunkRef{c.data.as<uint8_t>(), c.off.as<long long>(), c.len.as<unsigned int>()});
+  size_t capacity = 4 * static_cast<size_t>(n);      // Finalize bytes (<= 2 per stream) + slack
+  for (auto& c : e->chunks) {
+    refs.push_back(ChunkRef{c.data.as<uint8_t>(), c.off.as<long long>(), c.len.as<unsigned int>(), c.stride});
+    capacity += c.data.bytes;
+  }
   DevBuf d_refs, tail, length;
   TFC_HIP(d_refs.alloc(sizeof(ChunkRef) * std::max<size_t>(refs.size(), 1), st));
   if (!refs.empty())
@@ -1360,26 +1549,70 @@ extern "C" int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total
   TFC_HIP(length.alloc(sizeof(long long) * n, st));
   const unsigned tb = static_cast<unsigned>(ceil_div(n, 256));
   hipLaunchKernelGGL(enc_tail_kernel, dim3(tb), dim3(256), 0, st, e->state.as<uint4>(), n,
-                     d_refs.as<ChunkRef>(), static_cast<int>(refs.size()), e->fast ? 1 : 0,
+                     d_refs.as<ChunkRef>(), static_cast<int>(refs.size()), e->family == kFast ? 1 : 0,
                      tail.as<Tail>(), length.as<long long>());
   hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, length.as<long long>(), n,
                      e->offsets.as<long long>());
-  long long total = 0;
-  unsigned int oflag = 0;
-  TFC_HIP(hipMemcpyAsync(&total, e->offsets.as<long long>() + n, sizeof(long long),
-                         hipMemcpyDeviceToHost, st));
-  TFC_HIP(hipMemcpyAsync(&oflag, e->oflag.p, sizeof(oflag), hipMemcpyDeviceToHost, st));
-  TFC_HIP(hipStreamSynchronize(st));
-  if (oflag) return fail("internal error: an encoder kernel ran out of output slab space");
-  TFC_HIP(e->blob.alloc(static_cast<size_t>(total), st));
+  if (exact) {
+    long long total = 0;
+    unsigned int oflag = 0;
+    unsigned long long host_status[4];
+    TFC_HIP(hipMemcpyAsync(&total, e->offsets.as<long long>() + n, sizeof(long long),
+                           hipMemcpyDeviceToHost, st));
+    TFC_HIP(hipMemcpyAsync(&oflag, e->oflag.p, sizeof(oflag), hipMemcpyDeviceToHost, st));
+    TFC_HIP(hipMemcpyAsync(host_status, e->status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
+    TFC_HIP(hipStreamSynchronize(st));
+    if (host_status[0] != ~0ull) return encoder_error(e, host_status);
+    if (oflag) return fail("internal error: an encoder kernel ran out of output slab space");
+    capacity = static_cast<size_t>(total);
+    e->total = total;
+    e->total_known = true;
+  }
+  TFC_HIP(e->blob.alloc(capacity, st));
   hipLaunchKernelGGL(enc_pack_kernel, dim3(static_cast<unsigned>(ceil_div(n, kWavesPerBlock))),
                      dim3(kBlock), 0, st, n, d_refs.as<ChunkRef>(), static_cast<int>(refs.size()),
                      tail.as<Tail>(), e->offsets.as<long long>(), e->blob.as<uint8_t>());
   TFC_HIP(hipGetLastError());
   e->chunks.clear();     // stream-ordered frees: no need to wait for the pack kernel here
-  e->total = total;
   e->finalized = true;
-  *total_bytes = total;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total_bytes) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (e->finalized && !e->total_known) {
+    const int rc = tfc_encoder_status(e, stream, total_bytes);
+    return rc;
+  }
+  if (finalize_impl(e, st, true)) return 1;
+  *total_bytes = e->total;
+  return 0;
+}
+
+extern "C" int tfc_encoder_finalize_device(tfc_encoder* e, void* stream) {
+  return finalize_impl(e, static_cast<hipStream_t>(stream), false);
+}
+
+extern "C" int tfc_encoder_status(tfc_encoder* e, void* stream, int64_t* total_bytes) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned int oflag = 0;
+  unsigned long long host_status[4];
+  long long total = 0;
+  TFC_HIP(hipMemcpyAsync(&oflag, e->oflag.p, sizeof(oflag), hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipMemcpyAsync(host_status, e->status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
+  if (e->finalized && !e->total_known)
+    TFC_HIP(hipMemcpyAsync(&total, e->offsets.as<long long>() + e->streams, sizeof(long long),
+                           hipMemcpyDeviceToHost, st));
+  TFC_HIP(hipStreamSynchronize(st));
+  if (host_status[0] != ~0ull) return encoder_error(e, host_status);
+  if (oflag) return fail("internal error: an encoder kernel ran out of output slab space");
+  if (e->finalized && !e->total_known) {
+    e->total = total;
+    e->total_known = true;
+  }
+  if (total_bytes) *total_bytes = e->finalized ? e->total : -1;
   return 0;
 }
 
@@ -1393,6 +1626,7 @@ extern "C" int tfc_encoder_result(const tfc_encoder* e, const uint8_t** blob, co
 extern "C" int tfc_encoder_read(const tfc_encoder* e, uint8_t* blob_dst, int64_t* offsets_dst,
                                 int dst_on_device, void* stream) {
   if (!e->finalized) return fail("encoder handle is not finalized");
+  if (!e->total_known) return fail("tfc_encoder_status must read the size of a device-finalized handle first");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const hipMemcpyKind k = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   if (offsets_dst)
@@ -1412,6 +1646,8 @@ extern "C" void tfc_encoder_destroy(tfc_encoder* e) { delete e; }
 struct tfc_decoder {
   const tfc_tables* tables = nullptr;
   int64_t streams = 0;
+  int mode = TFC_MODE_AUTO;
+  int family = -1;
   DevBuf blob, offsets, state, status;     // blob / offsets: owned copies of host input only
   const uint8_t* blob_p = nullptr;         // device bytes the kernels read (owned or borrowed)
   const long long* off_p = nullptr;
@@ -1452,6 +1688,14 @@ extern "C" int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob,
   return 0;
 }
 
+extern "C" int tfc_decoder_set_mode(tfc_decoder* d, int mode) {
+  if (mode != TFC_MODE_AUTO && mode != TFC_MODE_LATENCY && mode != TFC_MODE_THROUGHPUT)
+    return fail("unknown mode %d", mode);
+  d->mode = mode;      // the decoder state has one encoding: the mode may change between calls
+  d->family = -1;
+  return 0;
+}
+
 namespace {
 
 template <typename Dst>
@@ -1474,47 +1718,23 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
   const size_t fast_lds = sizeof(int32_t) * ((t->dec_words + 3) & ~3) + sizeof(int4) * t->rows.size();
-  const char* force = std::getenv("TFC_FORCE_GENERIC");
-  const bool fast_ok = t->dec_fast_ok && fast_lds <= 160 * 1024 && !(force && force[0] == '1');
-  DevBuf redo;
-  static const bool quad_decoder = [] {
-    const char* q = std::getenv("TFC_DEC_QUAD");
-    return q && q[0] == '1';
-  }();
-  if (fast_ok && quad_decoder && throughput_mode().load() != 0) {
-    // EXPERIMENTAL (TFC_DEC_QUAD=1): four streams per wave (range_decoder_quad.h).  Streams that met an
-    // escape symbol are flagged and keep their start state; dec_fast_kernel below decodes exactly those.
-    // Correct (the GPU tests pass with it) but not used: measured 20 ms for the bench step alone and
-    // 24 ms per launch with 16 steps in flight, against 4.3 / 7-9 ms for dec_fast_kernel — its step is a
-    // chain of ~9 dependent LDS round trips (~1000 cycles per symbol and row), and the waves that would
-    // hide that do not exist at this batch size.
+  const bool fast_ok = t->dec_fast_ok && fast_lds <= 160 * 1024;
+  const int family = select_family(t, d->mode, d->streams, elems, fast_ok);
+  d->family = family;
+  if (family == kLanes) {
     KernelTimer timer("dec_kernel", st);
-    TFC_HIP(redo.alloc(sizeof(unsigned int) * d->streams, st));
-    TFC_HIP(hipMemsetAsync(redo.p, 0, sizeof(unsigned int) * d->streams, st));
-    const size_t quad_lds = sizeof(int32_t) * ((t->host.size() + 64 + 3) & ~size_t{3}) + sizeof(int4) * t->rows.size();
-    const int waves = static_cast<int>(std::min<int64_t>(8, std::max<int64_t>(1, ceil_div(d->streams, 4))));
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_quad_kernel<Dst>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds)));
-    hipLaunchKernelGGL((dec_quad_kernel<Dst>), dim3(static_cast<unsigned>(ceil_div(d->streams, 4 * waves))),
-                       dim3(64 * waves), quad_lds, st, p, dst, redo.as<unsigned int>());
-    p.only_flagged = redo.as<unsigned int>();
-  }
-  static const bool tput_decoder = [] {
-    const char* q = std::getenv("TFC_DEC_TPUT");
-    return q && q[0] == '1';
-  }();
-  if (fast_ok && tput_decoder && !p.only_flagged && throughput_mode().load() != 0) {
-    // EXPERIMENTAL (TFC_DEC_TPUT=1): winner first, successor state on the scalar unit, 16 waves per
-    // table copy (range_decoder_tput.h).  Bit-exact, not used: 14.9 ms for the bench step alone,
-    // 21-23 ms per launch in flight (profiles/r01_o_notes.md).
+    LaneArgs la;
+    la.image = t->d_lane_image.as<uint32_t>();
+    la.bytes = t->lane_dec_bytes;
+    la.ntab = p.tab.ntab;
+    la.cap = 0;
+    const int block = lanes_block(d->streams);
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_lanes_kernel<Dst>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, la.bytes));
+    hipLaunchKernelGGL((dec_lanes_kernel<Dst>), dim3(static_cast<unsigned>(ceil_div(d->streams, block))),
+                       dim3(block), la.bytes, st, p, dst, la);
+  } else if (family == kFast) {
     KernelTimer timer("dec_kernel", st);
-    const int waves = static_cast<int>(std::min<int64_t>(16, std::max<int64_t>(1, d->streams)));
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_tput_kernel<Dst>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fast_lds)));
-    hipLaunchKernelGGL((dec_tput_kernel<Dst>), dim3(static_cast<unsigned>(ceil_div(d->streams, waves))),
-                       dim3(64 * waves), fast_lds, st, p, dst);
-  } else if (fast_ok) {
-    KernelTimer timer(p.only_flagged ? "dec_kernel_redo" : "dec_kernel", st);
     const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(d->streams, 64))));
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1560,23 +1780,35 @@ extern "C" int tfc_decoder_decode_dequantized(tfc_decoder* d, const int32_t* ind
   }
 }
 
-extern "C" int tfc_decoder_finalize(tfc_decoder* d, uint8_t* ok, void* stream) {
+extern "C" int tfc_decoder_finalize_device(tfc_decoder* d, uint8_t* ok_dev, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t n = d->streams;
-  unsigned long long first_error = ~0ull;
-  DevBuf d_ok;
-  TFC_HIP(d_ok.alloc(std::max<int64_t>(n, 1), st));
   if (n)
     hipLaunchKernelGGL(dec_close_kernel, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256),
-                       0, st, d->state.as<uint4>(), d->off_p, n,
-                       d_ok.as<uint8_t>());
+                       0, st, d->state.as<uint4>(), d->off_p, n, ok_dev);
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tfc_decoder_status(tfc_decoder* d, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned long long first_error = ~0ull;
   TFC_HIP(hipMemcpyAsync(&first_error, d->status.p, sizeof(first_error), hipMemcpyDeviceToHost, st));
-  if (n) TFC_HIP(hipMemcpyAsync(ok, d_ok.p, n, hipMemcpyDeviceToHost, st));
   TFC_HIP(hipStreamSynchronize(st));
   if (first_error != ~0ull)
     return fail("index=<element %llu> not in range [0, %lld)", first_error,
                 static_cast<long long>(d->tables->rows.size()));
   return 0;
+}
+
+extern "C" int tfc_decoder_finalize(tfc_decoder* d, uint8_t* ok, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = d->streams;
+  DevBuf d_ok;
+  TFC_HIP(d_ok.alloc(std::max<int64_t>(n, 1), st));
+  if (tfc_decoder_finalize_device(d, d_ok.as<uint8_t>(), stream)) return 1;
+  if (n) TFC_HIP(hipMemcpyAsync(ok, d_ok.p, n, hipMemcpyDeviceToHost, st));
+  return tfc_decoder_status(d, stream);
 }
 
 extern "C" void tfc_decoder_destroy(tfc_decoder* d) { delete d; }

@@ -18,4 +18,8 @@ struct EncoderState {
   unsigned int pend_bytes;
 };
 
+// Directory entry of the lane-per-stream kernels' LDS image (range_lanes.h): byte offsets inside the
+// image.  info = nsym | (16 - precision) << 16 | has_escape << 31
+struct LaneRow { unsigned int cdf, bits, cum, info; };
+
 }  // namespace tfc

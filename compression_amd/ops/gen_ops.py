@@ -26,8 +26,18 @@ __all__ = [
     "pmf_to_quantized_cdf", "range_encode", "range_decode",
     "unbounded_index_range_encode", "unbounded_index_range_decode",
     "stochastic_round",
-    "set_throughput_mode", "get_throughput_mode",
+    "set_default_mode", "get_default_mode",
+    "entropy_encode_finalize_device", "entropy_encode_status",
+    "entropy_decode_finalize_device", "entropy_decode_status",
 ]
+
+_MODES = {None: 0, "auto": 0, "latency": 1, "throughput": 2}
+
+
+def _mode_code(mode) -> int:
+    if mode not in _MODES:
+        raise ValueError(f"mode must be one of 'auto', 'latency', 'throughput': {mode!r}")
+    return _MODES[mode]
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
@@ -89,7 +99,7 @@ class EncoderHandle:
     """Stands in for the DT_VARIANT handle tensor of CreateRangeEncoder
     (cc/kernels/range_coder_kernels.cc:62-78, 484-507)."""
 
-    def __init__(self, shape, tables: _Tables, device):
+    def __init__(self, shape, tables: _Tables, device, mode=None, deferred_errors=False):
         self.shape = tuple(int(s) for s in shape)
         self.tables = tables
         self.device = device
@@ -98,6 +108,10 @@ class EncoderHandle:
         _lib.check(_lib.lib().tfc_encoder_create(tables.ptr, self.streams, _lib.stream_ptr(),
                                                 C.byref(out)))
         self.ptr = out
+        if _mode_code(mode):
+            _lib.check(_lib.lib().tfc_encoder_set_mode(out, _mode_code(mode)))
+        if deferred_errors:
+            _lib.check(_lib.lib().tfc_encoder_set_deferred_errors(out, 1))
         self._keep = []       # inputs of in-flight kernels
         self.blob = None      # after finalize: device uint8 [total]
         self.offsets = None   # after finalize: device int64 [streams + 1]
@@ -139,10 +153,14 @@ def _shape_list(shape):
     return shape
 
 
-def create_range_encoder(shape, lookup) -> EncoderHandle:
-    """CreateRangeEncoder(shape, lookup) -> handle."""
+def create_range_encoder(shape, lookup, mode=None, deferred_errors=False) -> EncoderHandle:
+    """CreateRangeEncoder(shape, lookup) -> handle.
+
+    `mode` ('auto' | 'latency' | 'throughput', include/tfc_hip.h TFC_MODE_*) picks the kernel
+    family — same bytes either way; `deferred_errors` makes throughput-mode encode calls fully
+    asynchronous (range errors surface at finalize / entropy_encode_status)."""
     device = _lib.require_device()
-    return EncoderHandle(_shape_list(shape), _tables_for(lookup), device)
+    return EncoderHandle(_shape_list(shape), _tables_for(lookup), device, mode, deferred_errors)
 
 
 def _check_prefix(handle_shape, value_shape, what="value"):
@@ -196,6 +214,23 @@ def _finalize_device(handle: EncoderHandle):
     return handle.blob, handle.offsets
 
 
+def entropy_encode_finalize_device(handle: EncoderHandle) -> EncoderHandle:
+    """EntropyEncodeFinalize without any host synchronisation: the packed strings stay in HBM inside
+    the handle; pass the handle itself to create_range_decoder (stream-ordered), and call
+    entropy_encode_status / entropy_encode_finalize when the host needs errors or bytes."""
+    if handle.streams == 0:
+        raise ValueError(f"`handle` is empty: {list(handle.shape)}")
+    _lib.check(_lib.lib().tfc_encoder_finalize_device(handle.ptr, _lib.stream_ptr()))
+    return handle
+
+
+def entropy_encode_status(handle: EncoderHandle) -> int:
+    """Synchronises; raises a deferred range error, returns the total byte count (-1 before finalize)."""
+    total = C.c_int64()
+    _lib.check(_lib.lib().tfc_encoder_status(handle.ptr, _lib.stream_ptr(), C.byref(total)))
+    return int(total.value)
+
+
 def strings_from_blob(blob, offsets, shape):
     """(uint8 blob, int64 offsets) -> numpy object array of bytes with `shape`."""
     blob_h = blob.detach().cpu().numpy().tobytes()
@@ -229,12 +264,28 @@ def blob_from_strings(strings):
     return blob, off, arr.shape
 
 
-def create_range_decoder(encoded, lookup) -> DecoderHandle:
+def create_range_decoder(encoded, lookup, mode=None) -> DecoderHandle:
     """CreateRangeDecoder(encoded, lookup) -> handle.  `encoded` is a container
-    of bytes (any shape) or a (device blob, device offsets, shape) triple."""
+    of bytes (any shape), a (device blob, device offsets, shape) triple, or a finalized
+    EncoderHandle (its device-resident strings are read in place)."""
+    handle = _create_range_decoder(encoded, lookup)
+    if _mode_code(mode):
+        _lib.check(_lib.lib().tfc_decoder_set_mode(handle.ptr, _mode_code(mode)))
+    return handle
+
+
+def _create_range_decoder(encoded, lookup) -> DecoderHandle:
     device = _lib.require_device()
     tables = _tables_for(lookup)
     out = C.c_void_p()
+    if isinstance(encoded, EncoderHandle):
+        blob_p, off_p = C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().tfc_encoder_result(encoded.ptr, C.byref(blob_p), C.byref(off_p)))
+        _lib.check(_lib.lib().tfc_decoder_create(tables.ptr, blob_p, off_p, encoded.streams, 1,
+                                                _lib.stream_ptr(), C.byref(out)))
+        handle = DecoderHandle(encoded.shape, tables, device, out)
+        handle._keep.append(encoded)        # the decoder reads the encoder's blob in place
+        return handle
     if isinstance(encoded, tuple) and len(encoded) == 3 and isinstance(encoded[0], torch.Tensor):
         blob, offsets, shape = encoded
         shape = tuple(int(s) for s in shape)
@@ -300,6 +351,21 @@ def entropy_decode_finalize(handle: DecoderHandle) -> torch.Tensor:
     _lib.check(_lib.lib().tfc_decoder_finalize(handle.ptr, ok.ctypes.data, _lib.stream_ptr()))
     handle._keep.clear()
     return torch.from_numpy(ok.astype(bool)).reshape(handle.shape)
+
+
+def entropy_decode_finalize_device(handle: DecoderHandle) -> torch.Tensor:
+    """EntropyDecodeFinalize without host synchronisation -> uint8 device tensor shaped like handle
+    (1 = the weak end-of-stream check passed); entropy_decode_status reports a deferred index error."""
+    if handle.streams == 0:
+        raise ValueError(f"`handle` is empty: {list(handle.shape)}")
+    ok = torch.empty(handle.streams, dtype=torch.uint8, device=handle.device)
+    _lib.check(_lib.lib().tfc_decoder_finalize_device(handle.ptr, ok.data_ptr(), _lib.stream_ptr()))
+    return ok.reshape(handle.shape)
+
+
+def entropy_decode_status(handle: DecoderHandle) -> None:
+    _lib.check(_lib.lib().tfc_decoder_status(handle.ptr, _lib.stream_ptr()))
+    handle._keep.clear()
 
 
 def pmf_to_quantized_cdf(pmf, precision: int) -> torch.Tensor:
@@ -470,12 +536,11 @@ def stochastic_round(inputs, step_size, seed) -> torch.Tensor:
     return out
 
 
-def set_throughput_mode(on: bool) -> None:
-    """Process-wide hint (include/tfc_hip.h, tfc_set_throughput_mode): prefer kernels that put several
-    code streams on one wave — more aggregate throughput with several independent calls in flight on
-    different HIP streams, longer latency of a single call.  Same bytes either way."""
-    _lib.lib().tfc_set_throughput_mode(1 if on else 0)
+def set_default_mode(mode) -> None:
+    """Process-wide default kernel family for handles created without `mode`
+    (include/tfc_hip.h, tfc_set_default_mode)."""
+    _lib.check(_lib.lib().tfc_set_default_mode(_mode_code(mode)))
 
 
-def get_throughput_mode() -> bool:
-    return bool(_lib.lib().tfc_get_throughput_mode())
+def get_default_mode() -> str:
+    return ("auto", "latency", "throughput")[_lib.lib().tfc_get_default_mode()]

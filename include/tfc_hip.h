@@ -42,15 +42,22 @@ const char* tfc_last_error(void);
 void tfc_profile_enable(int on);
 int tfc_profile_query(const char* kernel, double* total_ms, int64_t* launches);
 
-/* Process-wide scheduling hint (no reference counterpart: the reference's ops shard streams over the
- * intra-op thread pool, range_coder_kernels.cc:212-267).  0 (default): one code stream per wave —
- * shortest time for one encode call on an otherwise idle GPU.  1: kernels that put several streams on a
- * wave are preferred where they exist (encode calls: four streams per wave) — fewer
- * instructions issued per symbol, i.e. more aggregate throughput when several independent calls are in
- * flight on different HIP streams, at a longer latency of each call.  The bytes produced are identical.
- * Initial value: environment variable TFC_THROUGHPUT_MODE. */
-void tfc_set_throughput_mode(int on);
-int tfc_get_throughput_mode(void);
+/* Kernel family of a coder handle (no reference counterpart: the reference's ops shard streams over the
+ * intra-op thread pool, range_coder_kernels.cc:212-267).  The bytes / symbols produced are identical.
+ *   TFC_MODE_LATENCY     one code stream per 64-lane wave: shortest time for one call on an idle GPU
+ *                        (elems x ~90 cycles encode, ~160 decode), 15-28 vector instructions per symbol;
+ *   TFC_MODE_THROUGHPUT  one code stream per LANE: ~1 instruction per symbol and 64 streams, elems x
+ *                        ~400 cycles per call — for callers that keep many independent calls in flight
+ *                        on different HIP streams, or code thousands of streams per call;
+ *   TFC_MODE_AUTO        by the stream count of the handle (throughput kernels from 4096 streams).
+ * Tables the throughput kernels cannot hold (LDS image > 160 KB, rows with zero-width symbols) fall
+ * back to the latency kernels.  The process-wide default applies to handles left at TFC_MODE_AUTO;
+ * its initial value comes from the environment variable TFC_DEFAULT_MODE = latency | throughput. */
+#define TFC_MODE_AUTO 0
+#define TFC_MODE_LATENCY 1
+#define TFC_MODE_THROUGHPUT 2
+int tfc_set_default_mode(int mode);
+int tfc_get_default_mode(void);
 
 /* ------------------------------------------------------------------------ */
 /* CDF tables                                                               */
@@ -79,13 +86,23 @@ void tfc_tables_destroy(tfc_tables* t);
 int tfc_encoder_create(const tfc_tables* tables, int64_t streams, void* stream,
                        tfc_encoder** out);
 
+/* Selects the kernel family (TFC_MODE_*); only before the first encode call on the handle. */
+int tfc_encoder_set_mode(tfc_encoder* e, int mode);
+/* on = 1: encode calls never synchronise; an "index=… / value=… not in range" failure is recorded
+ * on the device and returned by tfc_encoder_finalize / tfc_encoder_status instead of by the encode
+ * call that met it (throughput-mode handles only; latency-mode calls validate before coding and
+ * always report at once).  After such a failure the handle's streams are meaningless. */
+int tfc_encoder_set_deferred_errors(tfc_encoder* e, int on);
+
 /* EntropyEncodeChannel (index == NULL) / EntropyEncodeIndex —
  * cc/ops/range_coder_ops.cc:69-127, cc/kernels/range_coder_kernels.cc:191-272,
  * 290-322.  value/index: DEV int32 [streams, elems] row-major.  Appends to
  * every stream; may be called repeatedly on one handle.  Range errors
- * ("index=… not in range", "value=… not in range") are detected by a
- * validation pass before anything is appended; this call synchronises once to
- * read the pass result (and the exact output bound). */
+ * ("index=… not in range", "value=… not in range"): latency-mode handles run a
+ * validation pass before anything is appended and synchronise once to read its
+ * result (and the exact output bound); throughput-mode handles code in one
+ * kernel and synchronise once afterwards to read the error word, unless
+ * tfc_encoder_set_deferred_errors(e, 1). */
 int tfc_encoder_encode(tfc_encoder* e, const int32_t* value, const int32_t* index,
                        int64_t elems, void* stream);
 
@@ -113,6 +130,13 @@ int tfc_encoder_encode_quantized_indexed(tfc_encoder* e, const void* y, int dtyp
  * byte count.  Synchronises. */
 int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total_bytes);
 
+/* The same without any host synchronisation: the packed blob is allocated at the slabs' capacity and
+ * the total (= offsets[streams]) stays on the device; tfc_encoder_result is valid afterwards, a
+ * decoder can be created on it at once (stream-ordered).  tfc_encoder_status synchronises, returns
+ * deferred failures and the total byte count (total_bytes may be NULL). */
+int tfc_encoder_finalize_device(tfc_encoder* e, void* stream);
+int tfc_encoder_status(tfc_encoder* e, void* stream, int64_t* total_bytes);
+
 /* After finalize: device views of the packed result (owned by the handle):
  * blob DEV uint8 [total_bytes], offsets DEV int64 [streams + 1]. */
 int tfc_encoder_result(const tfc_encoder* e, const uint8_t** blob, const int64_t** offsets);
@@ -137,6 +161,9 @@ void tfc_encoder_destroy(tfc_encoder* e);
 int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob, const int64_t* offsets,
                        int64_t streams, int src_on_device, void* stream, tfc_decoder** out);
 
+/* Selects the kernel family (TFC_MODE_*) of the following decode calls. */
+int tfc_decoder_set_mode(tfc_decoder* d, int mode);
+
 /* EntropyDecodeChannel (index == NULL) / EntropyDecodeIndex —
  * cc/ops/range_coder_ops.cc:155-237, cc/kernels/range_coder_kernels.cc:360-429,
  * 449-471.  index DEV int32 [streams, elems] or NULL; out DEV int32
@@ -158,6 +185,10 @@ int tfc_decoder_decode_dequantized(tfc_decoder* d, const int32_t* index, void* y
  * end-of-stream check passed).  Also reports a deferred "index=… not in
  * range" failure of a previous decode call.  Synchronises. */
 int tfc_decoder_finalize(tfc_decoder* d, uint8_t* ok, void* stream);
+/* The same in two stream-ordered halves: the weak check into ok DEV uint8 [streams] without
+ * synchronising, and the deferred index failure (synchronises). */
+int tfc_decoder_finalize_device(tfc_decoder* d, uint8_t* ok, void* stream);
+int tfc_decoder_status(tfc_decoder* d, void* stream);
 void tfc_decoder_destroy(tfc_decoder* d);
 
 /* ------------------------------------------------------------------------ */
@@ -218,9 +249,10 @@ void tfc_free(void* p);
 
 /* cc/ops/pmf_to_cdf_ops.cc:28-57, cc/kernels/pmf_to_cdf_kernels.cc:58-208.
  * pmf DEV float32 [rows, n] -> cdf DEV int32 [rows, n+1]; every symbol >= 1,
- * cdf[:,0] = 0, cdf[:,n] = 1 << precision.  Ties between equal penalties are
- * broken towards the lower symbol index (the reference's own tie order is
- * libstdc++-specific and disclaimed, pmf_to_cdf_ops.cc:45-49). */
+ * cdf[:,0] = 0, cdf[:,n] = 1 << precision.  Which of several symbols with EQUAL penalty is adjusted
+ * follows the order libstdc++'s std::sort leaves them in (csrc/sort_order.h reproduces its introsort),
+ * i.e. the tables of the reference built with libstdc++; the reference itself disclaims portability of
+ * that order across standard libraries (pmf_to_cdf_ops.cc:45-49). */
 int tfc_pmf_to_quantized_cdf(const float* pmf, int64_t rows, int64_t n, int precision,
                              int32_t* cdf, void* stream);
 

@@ -11,10 +11,15 @@ from conftest import split_blob
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def tfc():
+@pytest.fixture(scope="module", params=["latency", "throughput"])
+def tfc(request):
+    """Every test of this module runs under both kernel families (include/tfc_hip.h TFC_MODE_*):
+    one wave per stream and one lane per stream.  Same bytes, same symbols."""
     import compression_amd
-    return compression_amd
+    compression_amd.set_default_mode(request.param)
+    assert compression_amd.get_default_mode() == request.param
+    yield compression_amd
+    compression_amd.set_default_mode("auto")
 
 
 def dev(a, dtype=torch.int32):
@@ -100,55 +105,124 @@ def test_dense_long_escapes(tfc, golden, port):
         assert got3 == port.encode(lookup, value, calls=3)[0]
 
 
-def test_throughput_mode_same_bytes(tfc, golden, port):
-    """tfc_set_throughput_mode(1): encode calls take the four-streams-per-wave kernel
-    (csrc/range_encoder_quad.h).  Same bytes as the oracle for stream counts that do not fill a wave,
-    lengths that are not multiples of 16 / 32 symbols, index mode, the golden precision sweep and escape
-    streams, dense long escape codes, and several calls on one handle."""
+def test_small_shapes_both_modes(tfc, golden, port):
+    """Stream counts that do not fill a wave / a workgroup, lengths around the kernels' batch sizes,
+    index mode, escape codes at several densities, and several calls on one handle."""
     esc = golden("streams_escape.npz")
-    sweep = golden("precision_sweep.npz")
     rng = np.random.default_rng(33)
-    tfc.set_throughput_mode(True)
-    try:
-        assert tfc.get_throughput_mode()
-        for prec in (1, 2, 5, 8, 12, 16):
-            lk, v = sweep[f"p{prec}_lookup"], sweep[f"p{prec}_value"]
-            got, _ = hip_encode(tfc, lk, v)
-            assert got == split_blob(sweep[f"p{prec}_blob"], sweep[f"p{prec}_offsets"]), prec
-        lookup = esc["lookup"]
-        rows = synthetic.lookup_rows(lookup)
-        for streams, elems in ((1, 1), (1, 15), (2, 16), (3, 17), (4, 31), (5, 32), (7, 33), (9, 1000), (64, 777)):
-            value = synthetic.sample_symbols(lookup, streams, elems, seed=streams * 1000 + elems)   # no escapes
-            assert hip_encode(tfc, lookup, value)[0] == port.encode(lookup, value)[0], (streams, elems)
-            index = rng.integers(0, len(rows), value.shape).astype(np.int32)
-            vi = np.zeros_like(value)
-            for t, (sp, cdf) in enumerate(rows):
-                m = index == t
-                vi[m] = rng.integers(0, len(cdf) - 2, int(m.sum()))
-            assert hip_encode(tfc, lookup, vi, index=index)[0] == port.encode(lookup, vi, index=index)[0]
-        # escape codes inside the four-streams-per-wave kernel: per-row call queues, several passes per group
-        for density, elems in ((1.0, 333), (0.3, 700), (0.02, 3000)):
-            big = rng.integers(1 << 6, 1 << 30, (7, elems)) * rng.choice([-1, 1], (7, elems))
-            small = synthetic.sample_symbols(lookup, 7, elems, seed=elems)
-            value = np.where(rng.random((7, elems)) < density, big, small).astype(np.int32)
-            assert hip_encode(tfc, lookup, value)[0] == port.encode(lookup, value)[0], density
-            index = rng.integers(0, len(rows), value.shape).astype(np.int32)
-            assert hip_encode(tfc, lookup, value, index=index)[0] == port.encode(lookup, value, index=index)[0]
-        assert hip_encode(tfc, lookup, esc["value"])[0] == split_blob(esc["blob"], esc["offsets"])
-        # three calls on one handle: escape-free, with escapes, escape-free
-        a = synthetic.sample_symbols(lookup, 6, 480, seed=1)
-        b = esc["value"][:, :480]
-        c = synthetic.sample_symbols(lookup, 6, 480, seed=2)
-        h = tfc.create_range_encoder([6], torch.as_tensor(lookup))
-        for part in (a, b, c):
-            h = tfc.entropy_encode_channel(h, dev(part))
-        got = [bytes(x) for x in tfc.entropy_encode_finalize(h).reshape(-1)]
-        assert got == port.encode(lookup, np.concatenate([a, b, c], axis=1), calls=3)[0]
-        d, ok = hip_decode(tfc, lookup, got, 1440)
-        assert (d == np.concatenate([a, b, c], axis=1)).all() and ok.all()
-    finally:
-        tfc.set_throughput_mode(False)
-    assert not tfc.get_throughput_mode()
+    lookup = esc["lookup"]
+    rows = synthetic.lookup_rows(lookup)
+    for streams, elems in ((1, 1), (1, 15), (2, 16), (3, 17), (4, 31), (5, 32), (7, 33), (9, 1000), (64, 777),
+                           (65, 130), (130, 64)):
+        value = synthetic.sample_symbols(lookup, streams, elems, seed=streams * 1000 + elems)   # no escapes
+        want = port.encode(lookup, value)[0]
+        assert hip_encode(tfc, lookup, value)[0] == want, (streams, elems)
+        d, ok = hip_decode(tfc, lookup, want, elems)
+        assert (d == value).all() and ok.all(), (streams, elems)
+        index = rng.integers(0, len(rows), value.shape).astype(np.int32)
+        vi = np.zeros_like(value)
+        for t, (sp, cdf) in enumerate(rows):
+            m = index == t
+            vi[m] = rng.integers(0, len(cdf) - 2, int(m.sum()))
+        want = port.encode(lookup, vi, index=index)[0]
+        assert hip_encode(tfc, lookup, vi, index=index)[0] == want
+        d, ok = hip_decode(tfc, lookup, want, elems, index=index)
+        assert (d == vi).all() and ok.all(), (streams, elems)
+    for density, elems in ((1.0, 333), (0.3, 700), (0.02, 3000)):
+        big = rng.integers(1 << 6, 1 << 30, (7, elems)) * rng.choice([-1, 1], (7, elems))
+        small = synthetic.sample_symbols(lookup, 7, elems, seed=elems)
+        value = np.where(rng.random((7, elems)) < density, big, small).astype(np.int32)
+        want = port.encode(lookup, value)[0]
+        assert hip_encode(tfc, lookup, value)[0] == want, density
+        d, ok = hip_decode(tfc, lookup, want, elems)
+        assert (d == value).all() and ok.all(), density
+        index = rng.integers(0, len(rows), value.shape).astype(np.int32)
+        want = port.encode(lookup, value, index=index)[0]
+        assert hip_encode(tfc, lookup, value, index=index)[0] == want
+        d, ok = hip_decode(tfc, lookup, want, elems, index=index)
+        assert (d == value).all() and ok.all(), density
+    # extreme escape values: Elias-gamma codes of up to 2 * 29 + 2 binary calls.  (From gamma = 2^30 on the
+    # reference's own encoder loops forever: `gamma >= (1 << n)` with n = 31, range_coder_kernels.cc:311.)
+    value = np.array([[2**30 - 1, -(2**30 - 1), 2**29, -(2**29), 5, -1, 0, 1]], np.int32)
+    want = port.encode(lookup, value)[0]
+    assert hip_encode(tfc, lookup, value)[0] == want
+    d, ok = hip_decode(tfc, lookup, want, value.shape[1])
+    assert (d == value).all() and ok.all()
+    # three calls on one handle: escape-free, with escapes, escape-free
+    a = synthetic.sample_symbols(lookup, 6, 480, seed=1)
+    b = esc["value"][:, :480]
+    c = synthetic.sample_symbols(lookup, 6, 480, seed=2)
+    h = tfc.create_range_encoder([6], torch.as_tensor(lookup))
+    for part in (a, b, c):
+        h = tfc.entropy_encode_channel(h, dev(part))
+    got = [bytes(x) for x in tfc.entropy_encode_finalize(h).reshape(-1)]
+    assert got == port.encode(lookup, np.concatenate([a, b, c], axis=1), calls=3)[0]
+    d, ok = hip_decode(tfc, lookup, got, 1440)
+    assert (d == np.concatenate([a, b, c], axis=1)).all() and ok.all()
+    # ... and decoded by three calls on one decoder handle
+    arr = np.empty(6, dtype=object)
+    for i, x in enumerate(got):
+        arr[i] = x
+    hd = tfc.create_range_decoder(arr, torch.as_tensor(lookup))
+    parts = []
+    for _ in range(3):
+        hd, out = tfc.entropy_decode_channel(hd, [480], torch.int32)
+        parts.append(out.cpu().numpy())
+    assert (np.concatenate(parts, axis=1) == np.concatenate([a, b, c], axis=1)).all()
+    assert tfc.entropy_decode_finalize(hd).all()
+
+
+def test_modes_per_handle_and_device_finalize(tfc, port):
+    """Per-handle mode selection, the fully stream-ordered path (deferred range errors, device-side
+    finalize, decoder created on the encoder's device-resident strings) and the deferred error text."""
+    lookup = _tables(port, 24, 3.0)
+    lt = torch.as_tensor(lookup)
+    v = synthetic.sample_symbols(lookup, 70, 500, seed=5, escape_fraction=0.02)
+    want, _, _ = port.encode(lookup, v)
+    for mode in ("latency", "throughput", "auto"):
+        h = tfc.create_range_encoder([70], lt, mode=mode, deferred_errors=True)
+        h = tfc.entropy_encode_channel(h, dev(v))
+        h = tfc.entropy_encode_finalize_device(h)
+        hd = tfc.create_range_decoder(h, lt, mode=mode)
+        hd, out = tfc.entropy_decode_channel(hd, [500], torch.int32)
+        ok = tfc.entropy_decode_finalize_device(hd)
+        tfc.entropy_decode_status(hd)
+        assert tfc.entropy_encode_status(h) == sum(len(x) for x in want)
+        assert (out.cpu().numpy() == v).all() and bool(ok.cpu().numpy().all())
+        assert [bytes(x) for x in tfc.entropy_encode_finalize(h).reshape(-1)] == want, mode
+    with pytest.raises(ValueError, match="mode must be one of"):
+        tfc.create_range_encoder([1], lt, mode="fast")
+    # deferred range error: the encode call returns, finalize reports value and range
+    plain = torch.tensor([[8, 0, 100, 256, 256]], dtype=torch.int32)
+    h = tfc.create_range_encoder([3], plain, mode="throughput", deferred_errors=True)
+    h = tfc.entropy_encode_channel(h, dev(np.array([[0, 1], [0, 7], [1, 1]])))
+    with pytest.raises(ValueError, match=r"value=7 not in range \[0, 2\)"):
+        tfc.entropy_encode_finalize(h)
+    h = tfc.create_range_encoder([2], plain, mode="throughput", deferred_errors=True)
+    h = tfc.entropy_encode_index(h, dev(np.array([[0, 0], [0, 5]])), dev(np.array([[0, 1], [1, 1]])))
+    with pytest.raises(ValueError, match=r"index=5 not in range \[0, 1\)"):
+        tfc.entropy_encode_status(h)
+    # index error met by a decoder
+    hd = tfc.create_range_decoder(np.array([b"\x00\x00"], dtype=object), plain, mode="throughput")
+    hd, _ = tfc.entropy_decode_index(hd, dev(np.array([[0, 9, 0]])), [3], torch.int32)
+    with pytest.raises(ValueError, match="not in range"):
+        tfc.entropy_decode_finalize(hd)
+
+
+def test_zero_width_symbols_fall_back(tfc, port):
+    """Tables with zero-probability symbols (equal neighbouring cdf entries) cannot use the rank
+    bitmap of the lane-per-stream decoder: such handles take the wave-per-stream kernels whatever
+    the mode, with the same results."""
+    lookup = np.array([[-8, 0, 0, 100, 100, 200, 256, 256, 256],
+                       [8, 0, 64, 64, 64, 128, 256, 256, 256]], np.int32)
+    rng = np.random.default_rng(4)
+    value = np.empty((5, 400), np.int32)
+    value[:, 0::2] = rng.choice([1, 3, 4, 9, -3], (5, 200))      # row 0: symbols 1, 3 and escapes (4 = escape symbol)
+    value[:, 1::2] = rng.choice([0, 3, 4], (5, 200))            # row 1
+    want = port.encode(lookup, value)[0]
+    assert hip_encode(tfc, lookup, value)[0] == want
+    d, ok = hip_decode(tfc, lookup, want, 400)
+    assert (d == value).all() and ok.all()
 
 
 def test_precision_sweep_golden(tfc, golden):
@@ -290,9 +364,9 @@ def test_c2_full_size_roundtrip(tfc, port):
     lookup = _tables(port, 192, 24.0)
     v = synthetic.sample_symbols(lookup, 512, 16 * 16 * 192, seed=0, escape_fraction=0.01)
     got, h = hip_encode(tfc, lookup, v)
-    # byte parity against the oracle on a slice of the streams (all would take ~10 s of CPU)
-    want, _, _ = port.encode(lookup, v[:32], threads=8)
-    assert got[:32] == want
+    # byte parity against the oracle on ALL streams
+    want, _, _ = port.encode(lookup, v, threads=16)
+    assert got == want
     d, ok = hip_decode(tfc, lookup, got, v.shape[1])
     assert (d == v).all() and ok.all()
     bits = 8 * sum(len(s) for s in got)
