@@ -53,6 +53,11 @@ struct DevBuf {
     if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
       unsigned long long keep = ~0ull;
       (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      // Never let the pool hand a block that was freed on stream A to stream B by making B wait for
+      // A's pending work ("internal dependencies"): with independent coding steps in flight on different
+      // streams that silently chains them one behind the other.
+      int off = 0;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseAllowInternalDependencies, &off);
     }
     done_for = dev;
   }

@@ -158,7 +158,7 @@ struct tfc_tables {
   bool dec_fast_ok = false;
   // lane-per-stream kernels (range_lanes.h): one LDS image; the encoder uses its first lane_enc_bytes
   DevBuf d_lane_image;
-  int lane_enc_bytes = 0, lane_dec_bytes = 0;
+  int lane_enc_bytes = 0, lane_dec_bytes = 0, lane_precision = 0;
   bool lanes_ok = false;
   int max_abs_prec = 0;
   bool any_escape = false;
@@ -289,24 +289,25 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
     TFC_HIP(hipStreamSynchronize(st));
   }
   {
-    // Image of the lane-per-stream kernels: directory (one entry per table + the binary row of the
-    // escape bits), 16-bit scaled cdf entries (modulo 2^16: only a row's last entry is 2^16), then per
-    // row the bitmap of its boundaries over [0, 2^precision) and the running count of boundaries
-    // before each 64-bit word.  Rows must be strictly increasing (rank = popcount) — rows with
-    // zero-width symbols keep the wave-per-stream kernels.
+    // Image of the lane-per-stream kernels: directory (one entry per table), 16-bit scaled cdf entries
+    // (modulo 2^16: only a row's last entry is 2^16), then per row the bitmap of its boundaries over
+    // [0, 2^precision) and the running count of boundaries before each 64-bit word.  Rows must be strictly
+    // increasing (rank = popcount) and share one precision (the quotient scale is a kernel constant) —
+    // other tables keep the wave-per-stream kernels.
     const size_t ntab = t->rows.size();
     bool ok = ntab > 0;
-    size_t cdf_entries = 3, words = 1;
+    const int prec = ok ? std::abs(t->host[t->rows[0].x]) : 0;
+    size_t cdf_entries = 0, words = 0;
     for (const int2& r : t->rows) {
-      const int prec = std::abs(t->host[r.x]);
       const int nsym = r.y - 2;
-      if (nsym > 65535) ok = false;
+      if (std::abs(t->host[r.x]) != prec) ok = false;
+      if (nsym > 32767) ok = false;
       for (int k = 1; ok && k <= nsym; ++k)
         if (t->host[r.x + 1 + k] <= t->host[r.x + k]) ok = false;
       cdf_entries += static_cast<size_t>(nsym + 1);
       words += std::max<size_t>(1, (size_t{1} << prec) / 64);
     }
-    const size_t dir_bytes = sizeof(tfc::LaneRow) * (ntab + 1);
+    const size_t dir_bytes = sizeof(tfc::LaneRow) * ntab;
     const size_t cdf_bytes = (2 * cdf_entries + 15) & ~size_t{15};
     const size_t enc_bytes = dir_bytes + cdf_bytes;
     const size_t dec_bytes = enc_bytes + 8 * words + ((2 * words + 15) & ~size_t{15});
@@ -318,13 +319,17 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       uint64_t* bits = reinterpret_cast<uint64_t*>(image.data() + enc_bytes);
       uint16_t* cum = reinterpret_cast<uint16_t*>(image.data() + enc_bytes + 8 * words);
       size_t ce = 0, wo = 0;
-      auto add_row = [&](tfc::LaneRow& d, const int32_t* cdf, int nsym, int prec, bool esc) {
-        const size_t nw = std::max<size_t>(1, (size_t{1} << prec) / 64);
+      const size_t nw = std::max<size_t>(1, (size_t{1} << prec) / 64);
+      for (size_t i = 0; i < ntab; ++i) {
+        const int2 r = t->rows[i];
+        const int32_t* cdf = &t->host[r.x + 1];
+        const int nsym = r.y - 2;
+        const bool esc = t->host[r.x] < 0;
+        tfc::LaneRow& d = dir[i];
         d.cdf = static_cast<unsigned int>(dir_bytes + 2 * ce);
         d.bits = static_cast<unsigned int>(enc_bytes + 8 * wo);
         d.cum = static_cast<unsigned int>(enc_bytes + 8 * words + 2 * wo);
-        d.info = static_cast<unsigned int>(nsym) | (static_cast<unsigned int>(16 - prec) << 16) |
-                 (esc ? 0x80000000u : 0u);
+        d.info = static_cast<unsigned int>(esc ? nsym - 1 : nsym) | (esc ? 0x80000000u : 0u);
         for (int k = 0; k <= nsym; ++k) cdf16[ce + k] = static_cast<uint16_t>(cdf[k] << (16 - prec));
         for (int k = 0; k < nsym; ++k) bits[wo + (cdf[k] >> 6)] |= uint64_t{1} << (cdf[k] & 63);
         unsigned int run = 0;
@@ -334,18 +339,13 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
         }
         ce += static_cast<size_t>(nsym + 1);
         wo += nw;
-      };
-      for (size_t i = 0; i < ntab; ++i) {
-        const int2 r = t->rows[i];
-        add_row(dir[i], &t->host[r.x + 1], r.y - 2, std::abs(t->host[r.x]), t->host[r.x] < 0);
       }
-      const int32_t binary_cdf[3] = {0, 1, 2};
-      add_row(dir[ntab], binary_cdf, 2, 1, false);
       TFC_HIP(t->d_lane_image.alloc(image.size(), st));
       TFC_HIP(hipMemcpyAsync(t->d_lane_image.p, image.data(), image.size(), hipMemcpyHostToDevice, st));
       TFC_HIP(hipStreamSynchronize(st));
       t->lane_enc_bytes = static_cast<int>(enc_bytes);
       t->lane_dec_bytes = static_cast<int>(dec_bytes);
+      t->lane_precision = prec;
       t->lanes_ok = true;
     }
   }
@@ -388,6 +388,8 @@ struct SymInt32 {          // plain int32 symbols
   // split form for kernels that request an element before they know its table
   __device__ int32_t raw(int64_t pos) const { return value[pos]; }
   __device__ int32_t quant(int32_t r, int /*table*/) const { return r; }
+  __device__ const int32_t* base() const { return value; }
+  using raw_type = int32_t;
 };
 
 template <typename T>
@@ -412,6 +414,8 @@ struct SymQuant {
   const int32_t* cdf_offset;
   __device__ int32_t load(int64_t pos, int table) const { return quant(y[pos], table); }
   __device__ T raw(int64_t pos) const { return y[pos]; }
+  __device__ const T* base() const { return y; }
+  using raw_type = T;
   __device__ int32_t quant(T r, int table) const {
     float f = to_float<T>(r);
     if (qoffset) f = to_float<T>(from_float<T>(f - to_float<T>(from_float<T>(qoffset[table]))));
@@ -782,6 +786,16 @@ struct ChunkRef {
 __device__ inline const uint8_t* chunk_piece(const ChunkRef& c, int64_t s) {
   return c.data + (c.off ? c.off[s] : s * c.stride);
 }
+// The pieces of a handle travel to the finalize kernels BY VALUE (kernel arguments are captured at
+// launch): an asynchronous copy from a host vector would still be reading it after a stream-ordered
+// finalize has returned.  Handles with more encode calls than this take a synchronising copy.
+constexpr int kInlineChunks = 8;
+struct ChunkList {
+  ChunkRef inline_refs[kInlineChunks];
+  const ChunkRef* more;      // all of them, when there are more than kInlineChunks
+  int n;
+  __device__ const ChunkRef& operator[](int i) const { return more ? more[i] : inline_refs[i]; }
+};
 
 // Tail of every stream per RangeEncoder::Finalize (range_coder.cc:266-307); one
 // thread per stream.  tail[s] = {head bytes (<= 2), 0xFFFF digits to insert,
@@ -794,7 +808,7 @@ struct Tail {
   unsigned int nhead, nend, run;
 };
 
-__global__ void enc_tail_kernel(const uint4* state, int64_t streams, const ChunkRef* chunks,
+__global__ void enc_tail_kernel(const uint4* state, int64_t streams, const ChunkList chunks,
                                 int nchunks, int fast_state, Tail* tail, long long* length) {
   const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (s >= streams) return;
@@ -884,7 +898,7 @@ __device__ inline void wave_copy(uint8_t* dst, const uint8_t* src, unsigned int 
 }
 
 // One wave per stream: copy the stream's chunk pieces then its tail.
-__global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const ChunkRef* chunks,
+__global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const ChunkList chunks,
                                                          int nchunks, const Tail* tail,
                                                          const long long* off, uint8_t* blob) {
   const int lane = threadIdx.x & 63;
@@ -1017,6 +1031,10 @@ __device__ inline int dec_symbol(const TabFn& T, DecoderState& st, int cdf0, int
 struct OutInt32 {
   int32_t* out;
   __device__ void store(int64_t pos, int /*table*/, int32_t sym) const { out[pos] = sym; }
+  // split form for kernels that collect several elements per store
+  using elem = int32_t;
+  __device__ int32_t make(int /*table*/, int32_t sym) const { return sym; }
+  __device__ int32_t* ptr() const { return out; }
 };
 
 template <typename T>
@@ -1024,12 +1042,15 @@ struct OutDequant {
   T* y;
   const float* qoffset;
   const int32_t* cdf_offset;
-  __device__ void store(int64_t pos, int table, int32_t sym) const {
+  __device__ void store(int64_t pos, int table, int32_t sym) const { y[pos] = make(table, sym); }
+  using elem = T;
+  __device__ T make(int table, int32_t sym) const {
     // outputs = cast(symbols + cdf_offset, dtype) (+ quantization_offset)
     T v = from_float<T>(static_cast<float>(sym + cdf_offset[table]));
     if (qoffset) v = from_float<T>(to_float<T>(v) + to_float<T>(from_float<T>(qoffset[table])));
-    y[pos] = v;
+    return v;
   }
+  __device__ T* ptr() const { return y; }
 };
 
 template <bool LDS_TAB, typename Dst>
@@ -1238,7 +1259,10 @@ inline int64_t waves_per_block_limit() {
 int select_family(const tfc_tables* t, int mode, int64_t streams, int64_t elems, bool fast_ok) {
   const char* force = std::getenv("TFC_FORCE_GENERIC");
   if (force && force[0] == '1') return kGeneric;
-  const bool lanes_ok = t->lanes_ok && elems < (int64_t{1} << 31);
+  // the lane kernels address a stream's bytes with 32 bits, and their LDS plan (image + one wave's
+  // staging planes, any variant of the encoder) has to fit the CU
+  const bool lanes_ok = t->lanes_ok && elems < (int64_t{1} << 29) &&
+                        ((t->lane_enc_bytes + 1023) & ~1023) + EncWaveLds<int32_t>::kBytes <= 160 * 1024;
   if (mode == TFC_MODE_AUTO) mode = tfc_get_default_mode();
   if (mode == TFC_MODE_THROUGHPUT && lanes_ok) return kLanes;
   if (mode == TFC_MODE_AUTO && lanes_ok && streams >= 4096) return kLanes;
@@ -1258,26 +1282,39 @@ inline int lanes_block(int64_t streams) {
 // shrinks the span by at most 1 + log2(1/P) bits, a digit leaves every 16 bits: a symbol of a
 // precision-p row costs <= p + 1 bits, each of the <= 64 binary calls of an escape code
 // 1 + 2^-15 bits.  `carry` covers digits an earlier call left delayed.
-unsigned int lanes_slab_bytes(const tfc_tables* t, int64_t elems) {
+// With escape rows that worst case is ~10 bytes per symbol against ~0.5 produced, so a call first
+// runs with the no-escape bound (16 bits per symbol on average: exceeded only by streams that are
+// mostly long escape codes); a stream that outgrows it raises the handle's overflow flag, and the call
+// is repeated with the worst-case slab (handles that synchronise) or reported (deferred handles).
+unsigned int lanes_slab_bytes(const tfc_tables* t, int64_t elems, bool worst) {
   const long long carry = 80;
   long long bytes = 2 * elems;
-  if (t->any_escape) bytes = (elems * (t->max_abs_prec + 1 + 65) + 7) / 8 + 8;
+  if (t->any_escape && worst) bytes = (elems * (t->max_abs_prec + 1 + 65) + 7) / 8 + 8;
   bytes = (bytes + carry + 15) & ~15ll;
   return static_cast<unsigned int>(std::min<long long>(bytes, 0xFFFFFFF0ll));
 }
 
 // Records value / index of the first range error next to its position (stream-ordered, so the
-// inputs are still alive whatever the caller does after the encode call returns).
+// inputs are still alive whatever the caller does after the encode call returns).  One thread per job.
 template <typename Src>
-__global__ void enc_error_kernel(unsigned long long* status, Src src, const int32_t* index,
-                                 int64_t elems, int ntab) {
+struct EncErrJobs {
+  int64_t elems;
+  int ntab, n;
+  struct { unsigned long long* status; Src src; const int32_t* index; } job[EncLaneJobs<Src>::kMax];
+};
+template <typename Src>
+__global__ void enc_error_kernel(const EncErrJobs<Src> jobs) {
+  if (static_cast<int>(threadIdx.x) >= jobs.n) return;
+  unsigned long long* status = jobs.job[threadIdx.x].status;
+  const Src src = jobs.job[threadIdx.x].src;
+  const int32_t* index = jobs.job[threadIdx.x].index;
   const unsigned long long pos = status[0];
   if (pos == ~0ull || status[3] != 0ull) return;
-  int t = static_cast<int>((pos % static_cast<unsigned long long>(elems)) % static_cast<unsigned long long>(ntab));
+  int t = static_cast<int>((pos % static_cast<unsigned long long>(jobs.elems)) % static_cast<unsigned long long>(jobs.ntab));
   long long ix = 0;
   if (index) {
     ix = index[pos];
-    t = (ix < 0 || ix >= ntab) ? 0 : static_cast<int>(ix);
+    t = (ix < 0 || ix >= jobs.ntab) ? 0 : static_cast<int>(ix);
   }
   status[1] = static_cast<unsigned long long>(static_cast<long long>(src.load(static_cast<int64_t>(pos), t)));
   status[2] = static_cast<unsigned long long>(ix);
@@ -1303,16 +1340,119 @@ int encoder_error(tfc_encoder* e, const unsigned long long* host_status) {
                           ch, static_cast<int32_t>(static_cast<long long>(host_status[1])));
 }
 
+// Lane-per-stream family: n handles (same tables, same stream count) coded by one launch per
+// kMaxLaneJobs of them; no counting pass, no read-back unless a handle wants its range errors now.
 template <typename Src>
-int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& src, hipStream_t st) {
+int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int32_t* const* indexes,
+                      int64_t elems, hipStream_t st, bool worst_case_slab = false) {
+  constexpr int kMaxLaneJobs = EncLaneJobs<Src>::kMax;
+  const tfc_tables* t = es[0]->tables;
+  const int64_t streams = es[0]->streams;
+  const bool indexed = indexes && indexes[0];
+  LaneArgs la;
+  la.image = t->d_lane_image.as<uint32_t>();
+  la.bytes = t->lane_enc_bytes;
+  la.ntab = static_cast<int>(t->rows.size());
+  la.precision = t->lane_precision;
+  la.cap = lanes_slab_bytes(t, elems, worst_case_slab);
+  const bool speculative = t->any_escape && !worst_case_slab;
+  std::vector<DevBuf> backups(speculative ? n : 0);     // pre-call coder states of the handles that can retry
+  la.lds_image = (t->lane_enc_bytes + 1023) & ~1023;
+  using WaveLds = EncWaveLds<typename Src::raw_type>;
+  la.lds_wave = indexed ? WaveLds::kBytes : WaveLds::kIndex;
+  const int block = std::min(lanes_block(streams * n), 64 * ((160 * 1024 - la.lds_image) / la.lds_wave));
+  const int lds_bytes = la.lds_image + (block / 64) * la.lds_wave;
+  const void* fn = indexed ? reinterpret_cast<const void*>(&enc_lanes_kernel<true, Src>)
+                           : reinterpret_cast<const void*>(&enc_lanes_kernel<false, Src>);
+  TFC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  for (int g0 = 0; g0 < n; g0 += kMaxLaneJobs) {
+    const int gn = std::min(kMaxLaneJobs, n - g0);
+    EncLaneJobs<Src> jobs;
+    EncErrJobs<Src> errs;
+    jobs.streams = streams;
+    jobs.elems = elems;
+    jobs.blocks_per_job = static_cast<int>(ceil_div(streams, block));
+    jobs.n = gn;
+    errs.elems = elems;
+    errs.ntab = la.ntab;
+    errs.n = gn;
+    for (int k = 0; k < gn; ++k) {
+      tfc_encoder* e = es[g0 + k];
+      e->elems_last = elems;
+      e->indexed_last = indexed;
+      if (speculative && !e->deferred) {
+        TFC_HIP(backups[g0 + k].alloc(sizeof(uint4) * streams, st));
+        TFC_HIP(hipMemcpyAsync(backups[g0 + k].p, e->state.p, sizeof(uint4) * streams, hipMemcpyDeviceToDevice, st));
+      }
+      EncChunk ch;
+      TFC_HIP(ch.len.alloc(sizeof(unsigned int) * streams, st));
+      ch.stride = la.cap;
+      TFC_HIP(ch.data.alloc(static_cast<size_t>(la.cap) * streams, st));
+      EncLaneJob<Src>& J = jobs.job[k];
+      J.src = srcs[g0 + k];
+      J.index = indexed ? indexes[g0 + k] : nullptr;
+      J.state = e->state.as<uint4>();
+      J.chunk = ch.data.as<uint8_t>();
+      J.chunk_len = ch.len.as<unsigned int>();
+      J.first_error = e->status.as<unsigned long long>();
+      J.overflow_flag = e->oflag.as<unsigned int>();
+      errs.job[k].status = J.first_error;
+      errs.job[k].src = J.src;
+      errs.job[k].index = J.index;
+      e->chunks.push_back(std::move(ch));
+    }
+    {
+      KernelTimer timer("enc_kernel", st);
+      const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
+      if (indexed) hipLaunchKernelGGL((enc_lanes_kernel<true, Src>), grid, dim3(block), lds_bytes, st, jobs, la);
+      else hipLaunchKernelGGL((enc_lanes_kernel<false, Src>), grid, dim3(block), lds_bytes, st, jobs, la);
+    }
+    hipLaunchKernelGGL((enc_error_kernel<Src>), dim3(1), dim3(64), 0, st, errs);
+    TFC_HIP(hipGetLastError());
+  }
+  bool any_eager = false;
+  for (int k = 0; k < n; ++k) any_eager |= !es[k]->deferred;
+  if (any_eager) {
+    TFC_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < n; ++k) {
+      tfc_encoder* e = es[k];
+      if (e->deferred) continue;
+      unsigned long long host_status[4];
+      TFC_HIP(hipMemcpy(host_status, e->status.p, sizeof(host_status), hipMemcpyDeviceToHost));
+      if (host_status[0] != ~0ull) return encoder_error(e, host_status);
+      if (!speculative) continue;
+      unsigned int oflag = 0;
+      TFC_HIP(hipMemcpy(&oflag, e->oflag.p, sizeof(oflag), hipMemcpyDeviceToHost));
+      if (oflag) {
+        // a stream outgrew the speculative slab: back to the pre-call state, code again with the bound
+        // that cannot be exceeded
+        TFC_HIP(hipMemcpyAsync(e->state.p, backups[k].p, sizeof(uint4) * streams, hipMemcpyDeviceToDevice, st));
+        TFC_HIP(hipMemsetAsync(e->oflag.p, 0, sizeof(unsigned int), st));
+        e->chunks.pop_back();
+        const int32_t* ix = indexed ? indexes[k] : nullptr;
+        if (encode_lanes_many(&es[k], 1, &srcs[k], &ix, elems, st, true)) return 1;
+      }
+    }
+  }
+  return 0;
+}
+
+int encode_precheck(tfc_encoder* e, int64_t elems) {
   if (e->finalized) return fail("encoder handle was already finalized");
   if (e->poisoned) return fail("encoder handle met a range error in an earlier call");
   if (elems < 0) return fail("negative element count");
+  return 0;
+}
+
+template <typename Src>
+int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& src, hipStream_t st) {
+  if (encode_precheck(e, elems)) return 1;
   if (e->streams == 0 || elems == 0) return 0;
   const tfc_tables* t = e->tables;
   if (t->rows.empty()) return fail("index=0 not in range [0, 0)");
   if (e->family < 0) e->family = select_family(t, e->mode, e->streams, elems, e->fast);
-  if (e->family == kLanes && elems >= (int64_t{1} << 31)) return fail("encode call too large for this handle");
+  if (e->family == kLanes && elems >= (int64_t{1} << 29)) return fail("encode call too large for this handle");
+  if (e->family == kLanes) return encode_lanes_many(&e, 1, &src, &index, elems, st);
   e->elems_last = elems;
   e->indexed_last = index != nullptr;
 
@@ -1331,36 +1471,6 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   p.chunk_len = ch.len.as<unsigned int>();
   p.overflow_flag = e->oflag.as<unsigned int>();
   unsigned long long host_status[4] = {~0ull, 0ull, 0ull, 0ull};
-
-  if (e->family == kLanes) {
-    // one kernel, no counting pass, no read-back unless the caller wants range errors now
-    LaneArgs la;
-    la.image = t->d_lane_image.as<uint32_t>();
-    la.bytes = t->lane_enc_bytes;
-    la.ntab = p.tab.ntab;
-    la.cap = lanes_slab_bytes(t, elems);
-    ch.stride = la.cap;
-    TFC_HIP(ch.data.alloc(static_cast<size_t>(la.cap) * e->streams, st));
-    p.chunk = ch.data.as<uint8_t>();
-    const int block = lanes_block(e->streams);
-    {
-      KernelTimer timer("enc_kernel", st);
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_lanes_kernel<Src>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, la.bytes));
-      hipLaunchKernelGGL((enc_lanes_kernel<Src>), dim3(static_cast<unsigned>(ceil_div(e->streams, block))),
-                         dim3(block), la.bytes, st, p, src, la);
-    }
-    hipLaunchKernelGGL((enc_error_kernel<Src>), dim3(1), dim3(1), 0, st, p.first_error, src, index, elems,
-                       p.tab.ntab);
-    TFC_HIP(hipGetLastError());
-    e->chunks.push_back(std::move(ch));
-    if (!e->deferred) {
-      TFC_HIP(hipMemcpyAsync(host_status, e->status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
-      TFC_HIP(hipStreamSynchronize(st));
-      if (host_status[0] != ~0ull) return encoder_error(e, host_status);
-    }
-    return 0;
-  }
 
   // wave-per-stream families: validation + exact output bound first (one read-back)
   DevBuf calls, cstat;
@@ -1389,8 +1499,14 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   if (count_status[0] != ~0ull) {
     // nothing was appended; fetch the offending element for the message
     TFC_HIP(hipMemcpyAsync(e->status.p, count_status, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((enc_error_kernel<Src>), dim3(1), dim3(1), 0, st, e->status.as<unsigned long long>(), src,
-                       index, elems, p.tab.ntab);
+    EncErrJobs<Src> errs;
+    errs.elems = elems;
+    errs.ntab = p.tab.ntab;
+    errs.n = 1;
+    errs.job[0].status = e->status.as<unsigned long long>();
+    errs.job[0].src = src;
+    errs.job[0].index = index;
+    hipLaunchKernelGGL((enc_error_kernel<Src>), dim3(1), dim3(64), 0, st, errs);
     TFC_HIP(hipMemcpyAsync(host_status, e->status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
     const unsigned long long clear[4] = {~0ull, 0ull, 0ull, 0ull};
     TFC_HIP(hipStreamSynchronize(st));
@@ -1484,6 +1600,32 @@ extern "C" int tfc_encoder_encode(tfc_encoder* e, const int32_t* value, const in
   return run_encode(e, index, elems, SymInt32{value}, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int tfc_encoder_encode_many(int n, tfc_encoder* const* es, const int32_t* const* values,
+                                       const int32_t* const* indexes, int64_t elems, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return 0;
+  bool batch = elems > 0 && elems < (int64_t{1} << 29);
+  for (int k = 0; k < n; ++k) {
+    tfc_encoder* e = es[k];
+    if (encode_precheck(e, elems)) return 1;
+    if (e->tables != es[0]->tables || e->streams != es[0]->streams)
+      return fail("tfc_encoder_encode_many: handles must share tables and stream count");
+    if ((indexes && indexes[k]) != (indexes && indexes[0]))
+      return fail("tfc_encoder_encode_many: either all jobs carry an index or none");
+    if (e->streams == 0 || e->tables->rows.empty()) batch = false;
+    if (batch && e->family < 0) e->family = select_family(e->tables, e->mode, e->streams * n, elems, e->fast);
+    if (e->family != kLanes) batch = false;
+  }
+  if (!batch) {
+    for (int k = 0; k < n; ++k)
+      if (tfc_encoder_encode(es[k], values[k], indexes ? indexes[k] : nullptr, elems, stream)) return 1;
+    return 0;
+  }
+  std::vector<SymInt32> srcs(n);
+  for (int k = 0; k < n; ++k) srcs[k] = SymInt32{values[k]};
+  return encode_lanes_many(es, n, srcs.data(), indexes, elems, st);
+}
+
 namespace {
 
 int dispatch_quantized(tfc_encoder* e, const void* y, int dtype, const float* qoffset,
@@ -1535,21 +1677,28 @@ int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
     return 0;
   }
   std::vector<ChunkRef> refs;
-  size_t capacity = 4 * static_cast<size_t>(n);      // Finalize bytes (<= 2 per stream) + slack
+  size_t capacity = 4 * static_cast<size_t>(n) + 64;   // Finalize bytes (<= 2 per stream) + slack
   for (auto& c : e->chunks) {
     refs.push_back(ChunkRef{c.data.as<uint8_t>(), c.off.as<long long>(), c.len.as<unsigned int>(), c.stride});
     capacity += c.data.bytes;
   }
   DevBuf d_refs, tail, length;
-  TFC_HIP(d_refs.alloc(sizeof(ChunkRef) * std::max<size_t>(refs.size(), 1), st));
-  if (!refs.empty())
-    TFC_HIP(hipMemcpyAsync(d_refs.p, refs.data(), sizeof(ChunkRef) * refs.size(),
-                           hipMemcpyHostToDevice, st));
+  ChunkList list;
+  list.more = nullptr;
+  list.n = static_cast<int>(refs.size());
+  if (refs.size() <= static_cast<size_t>(kInlineChunks)) {
+    for (size_t i = 0; i < refs.size(); ++i) list.inline_refs[i] = refs[i];
+  } else {
+    TFC_HIP(d_refs.alloc(sizeof(ChunkRef) * refs.size(), st));
+    TFC_HIP(hipMemcpyAsync(d_refs.p, refs.data(), sizeof(ChunkRef) * refs.size(), hipMemcpyHostToDevice, st));
+    TFC_HIP(hipStreamSynchronize(st));               // `refs` goes away with this frame
+    list.more = d_refs.as<ChunkRef>();
+  }
   TFC_HIP(tail.alloc(sizeof(Tail) * n, st));
   TFC_HIP(length.alloc(sizeof(long long) * n, st));
   const unsigned tb = static_cast<unsigned>(ceil_div(n, 256));
   hipLaunchKernelGGL(enc_tail_kernel, dim3(tb), dim3(256), 0, st, e->state.as<uint4>(), n,
-                     d_refs.as<ChunkRef>(), static_cast<int>(refs.size()), e->family == kFast ? 1 : 0,
+                     list, static_cast<int>(refs.size()), e->family == kFast ? 1 : 0,
                      tail.as<Tail>(), length.as<long long>());
   hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, length.as<long long>(), n,
                      e->offsets.as<long long>());
@@ -1563,14 +1712,15 @@ int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
     TFC_HIP(hipMemcpyAsync(host_status, e->status.p, sizeof(host_status), hipMemcpyDeviceToHost, st));
     TFC_HIP(hipStreamSynchronize(st));
     if (host_status[0] != ~0ull) return encoder_error(e, host_status);
-    if (oflag) return fail("internal error: an encoder kernel ran out of output slab space");
-    capacity = static_cast<size_t>(total);
+    if (oflag) return fail("a stream outgrew its output slab (more than 16 bits per symbol on average with "
+                           "deferred errors on: encode with tfc_encoder_set_deferred_errors(e, 0))");
+    capacity = static_cast<size_t>(total) + 64;
     e->total = total;
     e->total_known = true;
   }
   TFC_HIP(e->blob.alloc(capacity, st));
   hipLaunchKernelGGL(enc_pack_kernel, dim3(static_cast<unsigned>(ceil_div(n, kWavesPerBlock))),
-                     dim3(kBlock), 0, st, n, d_refs.as<ChunkRef>(), static_cast<int>(refs.size()),
+                     dim3(kBlock), 0, st, n, list, static_cast<int>(refs.size()),
                      tail.as<Tail>(), e->offsets.as<long long>(), e->blob.as<uint8_t>());
   TFC_HIP(hipGetLastError());
   e->chunks.clear();     // stream-ordered frees: no need to wait for the pack kernel here
@@ -1607,7 +1757,8 @@ extern "C" int tfc_encoder_status(tfc_encoder* e, void* stream, int64_t* total_b
                            hipMemcpyDeviceToHost, st));
   TFC_HIP(hipStreamSynchronize(st));
   if (host_status[0] != ~0ull) return encoder_error(e, host_status);
-  if (oflag) return fail("internal error: an encoder kernel ran out of output slab space");
+  if (oflag) return fail("a stream outgrew its output slab (more than 16 bits per symbol on average with "
+                         "deferred errors on: encode with tfc_encoder_set_deferred_errors(e, 0))");
   if (e->finalized && !e->total_known) {
     e->total = total;
     e->total_known = true;
@@ -1698,6 +1849,67 @@ extern "C" int tfc_decoder_set_mode(tfc_decoder* d, int mode) {
 
 namespace {
 
+// Lane-per-stream family: n handles (same tables, same stream count) decoded by one launch per
+// kMaxLaneJobs of them.
+template <typename Dst>
+int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int32_t* const* indexes,
+                      int64_t elems, hipStream_t st) {
+  constexpr int kMaxLaneJobs = DecLaneJobs<Dst>::kMax;
+  const tfc_tables* t = ds[0]->tables;
+  const int64_t streams = ds[0]->streams;
+  const bool indexed = indexes && indexes[0];
+  LaneArgs la;
+  la.image = t->d_lane_image.as<uint32_t>();
+  la.bytes = t->lane_dec_bytes;
+  la.ntab = static_cast<int>(t->rows.size());
+  la.precision = t->lane_precision;
+  la.cap = 0;
+  la.lds_image = (t->lane_dec_bytes + 1023) & ~1023;
+  using WaveLds = DecWaveLds<typename Dst::elem>;
+  la.lds_wave = indexed ? WaveLds::kBytes : WaveLds::kIndex;
+  const int block = std::min(lanes_block(streams * n), 64 * ((160 * 1024 - la.lds_image) / la.lds_wave));
+  const int lds_bytes = la.lds_image + (block / 64) * la.lds_wave;
+  const void* fn = indexed ? reinterpret_cast<const void*>(&dec_lanes_kernel<true, Dst>)
+                           : reinterpret_cast<const void*>(&dec_lanes_kernel<false, Dst>);
+  TFC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  for (int g0 = 0; g0 < n; g0 += kMaxLaneJobs) {
+    const int gn = std::min(kMaxLaneJobs, n - g0);
+    DecLaneJobs<Dst> jobs;
+    jobs.streams = streams;
+    jobs.elems = elems;
+    jobs.blocks_per_job = static_cast<int>(ceil_div(streams, block));
+    jobs.n = gn;
+    for (int k = 0; k < gn; ++k) {
+      tfc_decoder* d = ds[g0 + k];
+      d->family = kLanes;
+      DecLaneJob<Dst>& J = jobs.job[k];
+      J.dst = dsts[g0 + k];
+      J.index = indexed ? indexes[g0 + k] : nullptr;
+      J.blob = d->blob_p;
+      J.off = d->off_p;
+      J.state = d->state.as<uint4>();
+      J.first_error = d->status.as<unsigned long long>();
+    }
+    KernelTimer timer("dec_kernel", st);
+    const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
+    if (indexed) hipLaunchKernelGGL((dec_lanes_kernel<true, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
+    else hipLaunchKernelGGL((dec_lanes_kernel<false, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
+  }
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+// Family of a decode call; lanes only when the tables' image plus one wave's staging fits the CU.
+template <typename Elem>
+int decoder_family(const tfc_decoder* d, int64_t streams_in_launch, int64_t elems, bool indexed, bool fast_ok) {
+  const tfc_tables* t = d->tables;
+  int family = select_family(t, d->mode, streams_in_launch, elems, fast_ok);
+  using WaveLds = DecWaveLds<Elem>;
+  const int need = ((t->lane_dec_bytes + 1023) & ~1023) + (indexed ? WaveLds::kBytes : WaveLds::kIndex);
+  if (family == kLanes && need > 160 * 1024) family = fast_ok ? kFast : kGeneric;
+  return family;
+}
+
 template <typename Dst>
 int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& dst,
                hipStream_t st) {
@@ -1719,20 +1931,10 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
   const size_t fast_lds = sizeof(int32_t) * ((t->dec_words + 3) & ~3) + sizeof(int4) * t->rows.size();
   const bool fast_ok = t->dec_fast_ok && fast_lds <= 160 * 1024;
-  const int family = select_family(t, d->mode, d->streams, elems, fast_ok);
+  const int family = decoder_family<typename Dst::elem>(d, d->streams, elems, index != nullptr, fast_ok);
   d->family = family;
   if (family == kLanes) {
-    KernelTimer timer("dec_kernel", st);
-    LaneArgs la;
-    la.image = t->d_lane_image.as<uint32_t>();
-    la.bytes = t->lane_dec_bytes;
-    la.ntab = p.tab.ntab;
-    la.cap = 0;
-    const int block = lanes_block(d->streams);
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_lanes_kernel<Dst>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, la.bytes));
-    hipLaunchKernelGGL((dec_lanes_kernel<Dst>), dim3(static_cast<unsigned>(ceil_div(d->streams, block))),
-                       dim3(block), la.bytes, st, p, dst, la);
+    return decode_lanes_many(&d, 1, &dst, &index, elems, st);
   } else if (family == kFast) {
     KernelTimer timer("dec_kernel", st);
     const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(d->streams, 64))));
@@ -1757,6 +1959,31 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
 }
 
 }  // namespace
+
+extern "C" int tfc_decoder_decode_many(int n, tfc_decoder* const* ds, const int32_t* const* indexes,
+                                       int32_t* const* outs, int64_t elems, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return 0;
+  if (elems < 0) return fail("negative element count");
+  bool batch = elems > 0 && elems < (int64_t{1} << 29);
+  for (int k = 0; k < n; ++k) {
+    const tfc_decoder* d = ds[k];
+    if (d->tables != ds[0]->tables || d->streams != ds[0]->streams)
+      return fail("tfc_decoder_decode_many: handles must share tables and stream count");
+    if ((indexes && indexes[k]) != (indexes && indexes[0]))
+      return fail("tfc_decoder_decode_many: either all jobs carry an index or none");
+    if (d->streams == 0 || d->tables->rows.empty()) batch = false;
+    if (batch && decoder_family<int32_t>(d, d->streams * n, elems, indexes && indexes[0], true) != kLanes) batch = false;
+  }
+  if (!batch) {
+    for (int k = 0; k < n; ++k)
+      if (tfc_decoder_decode(ds[k], indexes ? indexes[k] : nullptr, outs[k], elems, stream)) return 1;
+    return 0;
+  }
+  std::vector<OutInt32> dsts(n);
+  for (int k = 0; k < n; ++k) dsts[k] = OutInt32{outs[k]};
+  return decode_lanes_many(ds, n, dsts.data(), indexes, elems, st);
+}
 
 extern "C" int tfc_decoder_decode(tfc_decoder* d, const int32_t* index, int32_t* out,
                                   int64_t elems, void* stream) {

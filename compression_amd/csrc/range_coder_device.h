@@ -19,7 +19,8 @@ struct EncoderState {
 };
 
 // Directory entry of the lane-per-stream kernels' LDS image (range_lanes.h): byte offsets inside the
-// image.  info = nsym | (16 - precision) << 16 | has_escape << 31
-struct LaneRow { unsigned int cdf, bits, cum, info; };
+// image of the row's cdf entries, boundary bitmap and running counts, and
+//   info = limit | has_escape << 31,  limit = number of plain symbols (= index of the escape symbol).
+struct LaneRow { unsigned int cdf, info, bits, cum; };
 
 }  // namespace tfc

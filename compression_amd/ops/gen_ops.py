@@ -29,6 +29,7 @@ __all__ = [
     "set_default_mode", "get_default_mode",
     "entropy_encode_finalize_device", "entropy_encode_status",
     "entropy_decode_finalize_device", "entropy_decode_status",
+    "entropy_encode_channel_many", "entropy_decode_channel_many",
 ]
 
 _MODES = {None: 0, "auto": 0, "latency": 1, "throughput": 2}
@@ -181,6 +182,30 @@ def entropy_encode_channel(handle: EncoderHandle, value) -> EncoderHandle:
     _lib.check(_lib.lib().tfc_encoder_encode(handle.ptr, value.data_ptr(), None, elems,
                                              _lib.stream_ptr()))
     return handle
+
+
+def entropy_encode_channel_many(handles, values):
+    """EntropyEncodeChannel for several independent handles (same lookup, same shape) as ONE launch
+    (include/tfc_hip.h tfc_encoder_encode_many): same results as calling entropy_encode_channel on each."""
+    handles = list(handles)
+    if not handles:
+        return handles
+    vals = []
+    for h, v in zip(handles, values):
+        if h.streams == 0:
+            raise ValueError(f"`handle` is empty: handle.shape={list(h.shape)}")
+        v = _dev_i32(v, h.device)
+        _check_prefix(h.shape, v.shape)
+        vals.append(v)
+        h._keep.append(v)
+    elems = {v.numel() // h.streams for h, v in zip(handles, vals)}
+    if len(elems) != 1:
+        raise ValueError("entropy_encode_channel_many: all values must have the same shape")
+    n = len(handles)
+    hp = (C.c_void_p * n)(*[h.ptr for h in handles])
+    vp = (C.c_void_p * n)(*[v.data_ptr() for v in vals])
+    _lib.check(_lib.lib().tfc_encoder_encode_many(n, hp, vp, None, elems.pop(), _lib.stream_ptr()))
+    return handles
 
 
 def entropy_encode_index(handle: EncoderHandle, index, value) -> EncoderHandle:
@@ -336,6 +361,28 @@ def _decode(handle: DecoderHandle, index, shape, Tdecoded):
 def entropy_decode_channel(handle: DecoderHandle, shape, Tdecoded=torch.int32):
     """EntropyDecodeChannel(handle, shape, Tdecoded) -> (aliased handle, decoded)."""
     return _decode(handle, None, shape, Tdecoded)
+
+
+def entropy_decode_channel_many(handles, shape, Tdecoded=torch.int32):
+    """EntropyDecodeChannel for several independent handles as ONE launch
+    (tfc_decoder_decode_many) -> (handles, list of decoded tensors)."""
+    if Tdecoded not in (torch.int32, None):
+        raise TypeError("Tdecoded must be int32")
+    handles = list(handles)
+    if not handles:
+        return handles, []
+    suffix = _shape_list(shape)
+    elems = int(np.prod(suffix, dtype=np.int64))
+    outs = []
+    for h in handles:
+        if h.streams == 0:
+            raise ValueError(f"`handle` is empty: {list(h.shape)}")
+        outs.append(torch.empty(tuple(h.shape) + tuple(suffix), dtype=torch.int32, device=h.device))
+    n = len(handles)
+    hp = (C.c_void_p * n)(*[h.ptr for h in handles])
+    op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.lib().tfc_decoder_decode_many(n, hp, None, op, elems, _lib.stream_ptr()))
+    return handles, outs
 
 
 def entropy_decode_index(handle: DecoderHandle, index, shape, Tdecoded=torch.int32):

@@ -106,6 +106,15 @@ int tfc_encoder_set_deferred_errors(tfc_encoder* e, int on);
 int tfc_encoder_encode(tfc_encoder* e, const int32_t* value, const int32_t* index,
                        int64_t elems, void* stream);
 
+/* The same for n independent handles (same tables, same stream count, same elems; value[k] / index[k] of
+ * handle k) in ONE launch where the handles use the throughput kernels (TFC_MODE_THROUGHPUT, or
+ * TFC_MODE_AUTO with n * streams >= 4096): the hardware overlaps only a handful of kernels however many
+ * HIP streams carry them, and a 512-stream call is 8 waves, so independent calls fill the chip only
+ * as one grid.  Results are exactly those of n tfc_encoder_encode calls; other handles are coded by such
+ * calls one after the other. */
+int tfc_encoder_encode_many(int n, tfc_encoder* const* e, const int32_t* const* value,
+                            const int32_t* const* index, int64_t elems, void* stream);
+
 /* Fused quantise + encode, channel mode:
  *   sym = int32(rint(y - qoffset[c])) - cdf_offset[c],  c = j mod channels
  * i.e. ContinuousBatchedEntropyModel.compress's prologue
@@ -170,6 +179,10 @@ int tfc_decoder_set_mode(tfc_decoder* d, int mode);
  * [streams, elems].  Continues where the previous decode call stopped. */
 int tfc_decoder_decode(tfc_decoder* d, const int32_t* index, int32_t* out, int64_t elems,
                        void* stream);
+
+/* n independent handles in one launch (see tfc_encoder_encode_many); index may be NULL. */
+int tfc_decoder_decode_many(int n, tfc_decoder* const* d, const int32_t* const* index,
+                            int32_t* const* out, int64_t elems, void* stream);
 
 /* Fused decode + dequantise (continuous_batched.py:416-422 /
  * continuous_indexed.py:411-417):

@@ -192,6 +192,31 @@ def test_modes_per_handle_and_device_finalize(tfc, port):
         assert [bytes(x) for x in tfc.entropy_encode_finalize(h).reshape(-1)] == want, mode
     with pytest.raises(ValueError, match="mode must be one of"):
         tfc.create_range_encoder([1], lt, mode="fast")
+    # several independent handles in one launch: same strings as one call each
+    vals = [synthetic.sample_symbols(lookup, 70, 500, seed=20 + k, escape_fraction=0.02) for k in range(5)]
+    for mode in ("throughput", "latency"):
+        hs = [tfc.create_range_encoder([70], lt, mode=mode, deferred_errors=True) for _ in vals]
+        hs = tfc.entropy_encode_channel_many(hs, [dev(x) for x in vals])
+        hs = [tfc.entropy_encode_finalize_device(h) for h in hs]
+        ds = [tfc.create_range_decoder(h, lt, mode=mode) for h in hs]
+        ds, outs = tfc.entropy_decode_channel_many(ds, [500], torch.int32)
+        for x, h, d, out in zip(vals, hs, ds, outs):
+            assert bool(tfc.entropy_decode_finalize_device(d).cpu().numpy().all())
+            assert (out.cpu().numpy() == x).all()
+            assert [bytes(b) for b in tfc.entropy_encode_finalize(h).reshape(-1)] == port.encode(lookup, x)[0], mode
+    # streams that outgrow the speculative slab (more than 16 bits per symbol): coded again with the
+    # worst-case slab when the call synchronises, reported when errors are deferred
+    rng = np.random.default_rng(3)
+    big = (rng.integers(1 << 20, 1 << 29, (3, 400)) * rng.choice([-1, 1], (3, 400))).astype(np.int32)
+    want_big = port.encode(lookup, big)[0]
+    assert sum(map(len, want_big)) > 2 * big.size + 300
+    h = tfc.create_range_encoder([3], lt, mode="throughput")
+    h = tfc.entropy_encode_channel(h, dev(big))
+    assert [bytes(b) for b in tfc.entropy_encode_finalize(h).reshape(-1)] == want_big
+    h = tfc.create_range_encoder([3], lt, mode="throughput", deferred_errors=True)
+    h = tfc.entropy_encode_channel(h, dev(big))
+    with pytest.raises(ValueError, match="outgrew its output slab"):
+        tfc.entropy_encode_finalize(h)
     # deferred range error: the encode call returns, finalize reports value and range
     plain = torch.tensor([[8, 0, 100, 256, 256]], dtype=torch.int32)
     h = tfc.create_range_encoder([3], plain, mode="throughput", deferred_errors=True)
