@@ -122,6 +122,39 @@ struct DecLaneJobs {
   DecLaneJob<Dst> job[kMax];
 };
 
+// Global memory through address-space-1 pointers, at any alignment.  The pointers of a job come out of
+// the kernel-argument struct by a dynamic index, so hipcc takes them for generic ("flat") pointers —
+// and a flat access counts on lgkmcnt as well: every LDS read of the steps after a memory phase would
+// wait for the phase's global loads.
+typedef unsigned int lanes_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+struct __attribute__((packed)) LanePacked { T v; };
+#define TFC_AS1 __attribute__((address_space(1)))
+__device__ inline uint4 lanes_gload16(const void* p) {
+  const lanes_u32x4 v = reinterpret_cast<const TFC_AS1 LanePacked<lanes_u32x4>*>((const TFC_AS1 void*)p)->v;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline unsigned int lanes_gload8(const void* p) {
+  return *reinterpret_cast<const TFC_AS1 unsigned char*>((const TFC_AS1 void*)p);
+}
+__device__ inline void lanes_gstore16(void* p, const uint2& lo, const uint2& hi) {
+  lanes_u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+  reinterpret_cast<TFC_AS1 LanePacked<lanes_u32x4>*>((TFC_AS1 void*)p)->v = v;
+}
+// one element of 2 or 4 bytes, by its bits
+template <typename T>
+__device__ inline void lanes_gstore_elem(T* p, const T& v) {
+  if (sizeof(T) == 2) {
+    unsigned short bits;
+    __builtin_memcpy(&bits, &v, 2);
+    reinterpret_cast<TFC_AS1 LanePacked<unsigned short>*>((TFC_AS1 void*)p)->v = bits;
+  } else {
+    unsigned int bits;
+    __builtin_memcpy(&bits, &v, 4);
+    reinterpret_cast<TFC_AS1 LanePacked<unsigned int>*>((TFC_AS1 void*)p)->v = bits;
+  }
+}
+
 // Values loaded before the main loop are "used" here, so that hipcc waits for them HERE: it places
 // the s_waitcnt of a pending load at its first use, and a first use inside the loop means an
 // s_waitcnt vmcnt(0) — which also waits for every store in flight — in every iteration.
@@ -149,13 +182,18 @@ struct LaneWindow {
     unsigned int word = 0u;
 #pragma nounroll
     for (unsigned int k = 0; k < 4u; ++k)
-      if (q0 + k < len) word |= static_cast<unsigned int>(g[q0 + k]) << (8u * k);
+      if (q0 + k < len) word |= static_cast<unsigned int>(lanes_gload8(g + q0 + k)) << (8u * k);
     return word;
   }
   __device__ void request(unsigned int pos) {
     pbase = pos;
     if (pos + 8u * WORDS <= len) {
-      __builtin_memcpy(pend, g + pos, 8 * WORDS);
+#pragma unroll
+      for (int w = 0; w < WORDS; w += 2) {
+        const uint4 v = lanes_gload16(g + pos + 8u * w);
+        pend[w] = make_uint2(v.x, v.y);
+        pend[w + 1] = make_uint2(v.z, v.w);
+      }
     } else {
       // the stream ends inside the window (its last phases only): byte by byte, zero behind the end
       // (the word loops are unrolled so that `pend` stays in registers)
@@ -246,15 +284,11 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
   unsigned int dirp = 0u;           // channel mode: LDS offset of its directory entry
   unsigned int qn = 0u, g = 0u, neg = 0u;   // escape bits still to code: qn of them, from g then the sign
 
-  // digit `d` into the staging area (or, behind a full area — a long delayed run — straight to the slab)
+  // Digit `d` into the staging area, speculatively: it counts only if `on` advances the cursor.  The
+  // area holds what the kEncCadence steps between two phases can produce (two digits each); the run of
+  // digits behind a resolved long delay goes through put_run, which empties the area first.
   auto put = [&](unsigned int d, bool on) {
-    const unsigned short be = static_cast<unsigned short>(__builtin_bswap16(static_cast<unsigned short>(d)));
-    if (n < kEncDigitBytes) {
-      *reinterpret_cast<unsigned short*>(dstage + n) = be;          // speculative: counts only if n advances
-    } else if (on) {
-      if (wpos + n + 2u <= la.cap) __builtin_memcpy(out + wpos + n, &be, 2);
-      else overflow = 1u;
-    }
+    *reinterpret_cast<unsigned short*>(dstage + n) = __builtin_bswap16(static_cast<unsigned short>(d));
     n += on ? 2u : 0u;
   };
   auto flush = [&]() {
@@ -264,12 +298,21 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
         uint2 v[2];
         v[0] = reinterpret_cast<const uint2*>(dstage)[2 * c];
         v[1] = reinterpret_cast<const uint2*>(dstage)[2 * c + 1];
-        if (wpos + 16u * c + 16u <= la.cap) __builtin_memcpy(out + wpos + 16u * c, v, 16);
+        if (wpos + 16u * c + 16u <= la.cap) lanes_gstore16(out + wpos + 16u * c, v[0], v[1]);
         else overflow = 1u;
       }
     }
     wpos += n;
     n = 0u;
+  };
+  auto put_run = [&](unsigned int fill, unsigned int bytes) {
+    flush();
+    for (unsigned int k = 0; k < bytes; k += 2u) {
+      const unsigned short be = static_cast<unsigned short>(fill);       // 0x0000 / 0xFFFF: no byte order
+      if (wpos + 2u <= la.cap) lanes_gstore_elem(reinterpret_cast<unsigned short*>(out + wpos), be);
+      else overflow = 1u;
+      wpos += 2u;
+    }
   };
 
   for (unsigned int it = 0u; __any(j < elems || qn != 0u); ++it) {
@@ -284,42 +327,39 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
       }
       flush();
     }
-    if (j < elems || qn != 0u) {
-      unsigned int lo, hi;
-      if (qn == 0u) {
-        unsigned int dp = dirp;
-        if (INDEXED) {
-          int t = *reinterpret_cast<const int*>(iw.lds + (j * 4u - iw.base));
-          if (t < 0 || t >= la.ntab) {
-            atomicMin(first_error, static_cast<unsigned long long>(pos0 + j));
-            t = 0;
-          }
-          dp = 16u * static_cast<unsigned int>(t);
+    // ---- the call of this step: speculatively the next symbol as a plain one (reads stay inside the
+    // lane's window and the directory whatever j is); escapes, escape bits, range errors and idle lanes
+    // are sorted out behind a wave-uniform branch ---------------------------------------------------
+    unsigned int dp = dirp;
+    if (INDEXED) {
+      int t = *reinterpret_cast<const int*>(iw.lds + (j * 4u - iw.base));
+      t = (t < 0 || t >= la.ntab) ? -1 : t;
+      dp = t < 0 ? 0u : 16u * static_cast<unsigned int>(t);
+      if (__any(t < 0 && qn == 0u && j < elems)) {
+        if (t < 0 && qn == 0u && j < elems) atomicMin(first_error, static_cast<unsigned long long>(pos0 + j));
+      }
+    }
+    const int32_t v = src.quant(*reinterpret_cast<const Raw*>(vw.lds + (j * kRaw - vw.base)), static_cast<int>(dp >> 4));
+    const uint2 row = *reinterpret_cast<const uint2*>(lanes_lds + dp);   // cdf offset, limit | escape << 31
+    const unsigned int limit = row.y & 0x7FFFFFFFu;                      // first value that is not a plain symbol
+    const bool take = qn == 0u && j < elems;
+    const bool plain = static_cast<unsigned int>(v) < limit;             // negative values are not
+    unsigned int sym = plain ? static_cast<unsigned int>(v) : limit;
+    bool act = take;                 // this lane makes a coder call in this step
+    bool adv = take;                 // ... and moves on to the next symbol
+    unsigned int lo = 0u, hi = 0u;
+    if (__any(!(take && plain) && (qn != 0u || j < elems))) {
+      if (take && !plain) {
+        if (row.y >> 31) {
+          // escape: the row's last interval now, the Elias-gamma code of the excess in the next steps
+          neg = v < 0 ? 1u : 0u;
+          g = v < 0 ? 0u - static_cast<unsigned int>(v) : static_cast<unsigned int>(v) - limit + 1u;
+          qn = 2u * static_cast<unsigned int>(31 - __clz(static_cast<int>(g))) + 2u;
+        } else {
+          atomicMin(first_error, static_cast<unsigned long long>(pos0 + j));
+          sym = 0u;
         }
-        const int32_t v = src.quant(*reinterpret_cast<const Raw*>(vw.lds + (j * kRaw - vw.base)),
-                                    static_cast<int>(dp >> 4));
-        const uint2 row = *reinterpret_cast<const uint2*>(lanes_lds + dp);   // cdf offset, limit | escape << 31
-        const unsigned int limit = row.y & 0x7FFFFFFFu;                      // first value that is not a plain symbol
-        unsigned int sym = static_cast<unsigned int>(v);
-        if (sym >= limit) {                                                  // negative values included
-          if (row.y >> 31) {
-            // escape: the row's last interval, then the Elias-gamma code of the excess
-            neg = v < 0 ? 1u : 0u;
-            g = v < 0 ? 0u - static_cast<unsigned int>(v) : static_cast<unsigned int>(v) - limit + 1u;
-            qn = 2u * static_cast<unsigned int>(31 - __clz(static_cast<int>(g))) + 2u;
-            sym = limit;
-          } else {
-            atomicMin(first_error, static_cast<unsigned long long>(pos0 + j));
-            sym = 0u;
-          }
-        }
-        lo = lds_u16(lanes_lds, row.x + 2u * sym);
-        hi = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
-        hi = hi == 0u ? 65536u : hi;
-        ++j;
-        dirp += 16u;
-        dirp = dirp == dir_end ? 0u : dirp;
-      } else {
+      } else if (!take && qn != 0u) {
         // Elias-gamma code of g (floor(log2 g) zeros, the bits of g), then the sign bit
         // (range_coder_kernels.cc:304-321), each a call with the uniform binary cdf at precision 1.
         --qn;
@@ -327,34 +367,47 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
         const unsigned int bit = qn == 0u ? neg : (sft < 32u ? (g >> sft) & 1u : 0u);
         lo = bit << 15;
         hi = (bit + 1u) << 15;
+        act = true;
       }
-      // ---- RangeEncoder::Encode (range_coder.cc:37-264) on [lo, hi) / 2^16; pd = delay_ & 0xFFFF
-      // (0: state 0), pb = delay_ >> 16 -----------------------------------------------------------
-      const unsigned int a = scale16(s1, lo);
-      const unsigned int b = scale16(s1, hi) - 1u;
-      base += a;
-      s1 = b - a;
-      const bool wrapped = base < a;
-      const bool st1 = static_cast<unsigned int>(base + s1) < base;      // the carry is (still) undecided
-      const bool ren = (s1 >> 16) == 0u;
-      // state 1 -> 0: the delayed digit is decided (and the run of 0x0000 / 0xFFFF digits behind it)
-      const bool resolve = !st1 && pd != 0u;
-      put(wrapped ? pd : pd - 1u, resolve);
-      if (__any(resolve && pb != 0u)) {
-        if (resolve)
-          for (unsigned int k = 0; k < pb; k += 2u) put(wrapped ? 0u : 0xFFFFu, true);
-      }
-      pd = resolve ? 0u : pd;
-      pb = resolve ? 0u : pb;
-      // renormalisation
-      const unsigned int top = base >> 16;
-      base = ren ? base << 16 : base;
-      s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
-      const bool st1r = static_cast<unsigned int>(base + s1) < base;     // state after the shift
-      put(top, ren && !st1 && !st1r);
-      pd = (ren && !st1 && st1r) ? top + 1u : pd;
-      pb = (ren && st1) ? pb + 2u : pb;
     }
+    {
+      const unsigned int tlo = lds_u16(lanes_lds, row.x + 2u * sym);
+      const unsigned int thi = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
+      lo = take ? tlo : lo;
+      hi = take ? (thi == 0u ? 65536u : thi) : hi;
+    }
+    j += adv ? 1u : 0u;
+    if (!INDEXED) {
+      const unsigned int nd = dirp + 16u == dir_end ? 0u : dirp + 16u;
+      dirp = adv ? nd : dirp;
+    }
+    // ---- RangeEncoder::Encode (range_coder.cc:37-264) on [lo, hi) / 2^16; pd = delay_ & 0xFFFF
+    // (0: state 0), pb = delay_ >> 16; every update is a select on `act` --------------------------------
+    const unsigned int a = scale16(s1, lo);
+    const unsigned int b = scale16(s1, hi) - 1u;
+    const unsigned int base1 = base + a;
+    const unsigned int s11 = b - a;
+    const bool wrapped = base1 < a;
+    const bool st1 = static_cast<unsigned int>(base1 + s11) < base1;      // the carry is (still) undecided
+    const bool ren = act && (s11 >> 16) == 0u;
+    // state 1 -> 0: the delayed digit is decided (and the run of 0x0000 / 0xFFFF digits behind it)
+    const bool resolve = act && !st1 && pd != 0u;
+    put(wrapped ? pd : pd - 1u, resolve);
+    if (__any(resolve && pb != 0u)) {
+      if (resolve && pb != 0u) put_run(wrapped ? 0u : 0xFFFFu, pb);
+    }
+    pd = resolve ? 0u : pd;
+    pb = resolve ? 0u : pb;
+    // renormalisation
+    const unsigned int top = base1 >> 16;
+    const unsigned int base2 = ren ? base1 << 16 : base1;
+    const unsigned int s12 = ren ? (s11 << 16) | 0xFFFFu : s11;
+    const bool st1r = static_cast<unsigned int>(base2 + s12) < base2;     // state after the shift
+    put(top, ren && !st1 && !st1r);
+    pd = (ren && !st1 && st1r) ? top + 1u : pd;
+    pb = (ren && st1) ? pb + 2u : pb;
+    base = act ? base2 : base;
+    s1 = act ? s12 : s1;
   }
   flush();
   if (live) {
@@ -447,10 +500,10 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         uint2 v[2];
         v[0] = reinterpret_cast<const uint2*>(outq)[2 * c];
         v[1] = reinterpret_cast<const uint2*>(outq)[2 * c + 1];
-        __builtin_memcpy(reinterpret_cast<unsigned char*>(to) + 16 * c, v, 16);
+        lanes_gstore16(reinterpret_cast<unsigned char*>(to) + 16 * c, v[0], v[1]);
       }
     } else {
-      for (unsigned int e = 0; e < ko / kEs; ++e) to[e] = reinterpret_cast<const Elem*>(outq)[e];
+      for (unsigned int e = 0; e < ko / kEs; ++e) lanes_gstore_elem(to + e, reinterpret_cast<const Elem*>(outq)[e]);
     }
     ko = 0u;
   };

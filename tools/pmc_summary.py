@@ -10,6 +10,24 @@ import sys
 from collections import defaultdict
 
 
+def source_stamp():
+    """git blob hashes of the kernel sources the profile is taken on (bench.py compares them with the
+    tree it runs in and drops counter figures of other code)."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for rel in ("compression_amd/csrc/range_coder.hip", "compression_amd/csrc/range_lanes.h",
+                "compression_amd/csrc/range_encoder_fast.h", "compression_amd/csrc/range_decoder_fast.h",
+                "compression_amd/csrc/gdn.hip", "compression_amd/csrc/gdn_common.h",
+                "compression_amd/csrc/gdn_backward.hip"):
+        try:
+            data = open(os.path.join(root, rel), "rb").read()
+        except OSError:
+            continue
+        out[rel] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
 def collect(src):
     out = defaultdict(lambda: defaultdict(list))
     files = sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True))
@@ -34,7 +52,9 @@ def main():
                 merged[name][ctr] = {"launches": len(vals), "mean": sum(vals) / len(vals),
                                      "min": min(vals), "max": max(vals)}
     os.makedirs(os.path.dirname(dst), exist_ok=True)
+    merged["_sources"] = source_stamp()
     json.dump(merged, open(dst + ".json", "w"), indent=1, sort_keys=True)
+    del merged["_sources"]
     lines = ["# HBM traffic counters per kernel (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)", "",
              "Counter values as reported (KiB per dispatch); corrections are applied in bench.py / DESIGN.md.", "",
              "| kernel | launches | FETCH_SIZE mean | WRITE_SIZE mean |", "|---|---:|---:|---:|"]

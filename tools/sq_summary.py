@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from pmc_summary import collect  # noqa: E402
+from pmc_summary import collect, source_stamp  # noqa: E402
 
 
 def durations(src):
@@ -36,7 +36,9 @@ def main():
         if name in dur:
             rows[name]["duration_us"] = sum(dur[name]) / len(dur[name])
     os.makedirs(os.path.dirname(dst), exist_ok=True)
+    rows["_sources"] = source_stamp()
     json.dump(rows, open(dst + ".json", "w"), indent=1, sort_keys=True)
+    del rows["_sources"]
     cols = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS",
             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU"]
     lines = ["# SQ counters per kernel (rocprofv3 --pmc, one pass; *_CYCLES / ACTIVE / WAIT in quad-cycles summed over waves)",
