@@ -412,7 +412,9 @@ def main():
     inflight = max(1, min(args.inflight, args.steps))
     # every slot in flight codes its own tensor (inputs resident in HBM)
     slots = [sample_symbols_device(lookup, 1000 * rank + k, device, args.escape_fraction) for k in range(inflight)]
-    side_streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    # one stream: the launches of a group fill the chip on their own (a decoder workgroup takes a whole
+    # CU's LDS), groups on different streams would only queue behind each other's workgroups
+    side_streams = [torch.cuda.Stream(device=device)]
     torch.cuda.synchronize()
 
     def run_steps(total_steps, depth, mode):
@@ -429,7 +431,7 @@ def main():
                 results.append(one_step(lookup_t, slots[0], mode) + (0,))
                 torch.cuda.current_stream().synchronize()
         else:
-            # groups of `depth` steps, one launch per group and direction, groups alternating over two streams
+            # groups of `depth` steps, one launch per group and direction
             for g, k0 in enumerate(range(0, total_steps, depth)):
                 idx = [k % depth for k in range(k0, min(k0 + depth, total_steps))]
                 with torch.cuda.stream(side_streams[g % len(side_streams)]):

@@ -69,6 +69,13 @@ struct DevBuf {
   template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Non-owning view of a piece of a DevBuf (several small buffers of a handle share one allocation:
+// every stream-ordered allocation is a driver call on the host path of a coding step).
+struct DevView {
+  void* p = nullptr;
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 // Optional per-kernel timing (tfc_profile_enable): HIP events recorded on the
 // launch stream around the named kernel; read back by tfc_profile_query.
 struct KernelTimer {

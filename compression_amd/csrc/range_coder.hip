@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <type_traits>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -326,7 +327,7 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
         const int nsym = r.y - 2;
         const bool esc = t->host[r.x] < 0;
         tfc::LaneRow& d = dir[i];
-        d.cdf = static_cast<unsigned int>(dir_bytes + 2 * ce);
+        d.cdf = static_cast<unsigned int>(dir_bytes + 2 * ce) - 2u;     // of cdf[0], minus 2: lo / hi of symbol s at + 2 s + 2 / + 4
         d.bits = static_cast<unsigned int>(enc_bytes + 8 * wo);
         d.cum = static_cast<unsigned int>(enc_bytes + 8 * words + 2 * wo);
         d.info = static_cast<unsigned int>(esc ? nsym - 1 : nsym) | (esc ? 0x80000000u : 0u);
@@ -1129,8 +1130,9 @@ namespace tfc {
 // Reads the first four bytes of every stream (RangeDecoder ctor,
 // range_coder.h:79-83).
 __global__ void dec_open_kernel(const uint8_t* blob, const long long* off, int64_t streams,
-                                uint4* state) {
+                                uint4* state, unsigned long long* status) {
   const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (s == 0) *status = ~0ull;       // no index error met yet
   if (s >= streams) return;
   const uint8_t* src = blob + off[s];
   const long long len = off[s + 1] - off[s];
@@ -1162,9 +1164,17 @@ __global__ void dec_close_kernel(const uint4* state, const long long* off, int64
   ok[s] = good ? 1 : 0;
 }
 
-__global__ void fill_state_kernel(uint4* state, int64_t n, uint4 v) {
+// Initial coder state of every stream, plus the handle's status words (first error position = none,
+// value, index, filled flag) and overflow flag.
+__global__ void fill_state_kernel(uint4* state, int64_t n, uint4 v, unsigned long long* status,
+                                  unsigned int* oflag) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i < n) state[i] = v;
+  if (i == 0) {
+    status[0] = ~0ull;
+    status[1] = status[2] = status[3] = 0ull;
+    *oflag = 0u;
+  }
 }
 
 }  // namespace tfc
@@ -1176,6 +1186,8 @@ __global__ void fill_state_kernel(uint4* state, int64_t n, uint4 v) {
 struct EncChunk {
   DevBuf data, off, len;
   long long stride = 0;         // lane kernels: stream s starts at s * stride (off unused)
+  unsigned int* len_p = nullptr;    // the lengths: `len`, or the tail of `data` (lane kernels: one allocation)
+  size_t data_bytes = 0;
 };
 
 // Kernel family of a handle (fixed at its first coding call; the families keep different state
@@ -1194,9 +1206,10 @@ struct tfc_encoder {
   bool poisoned = false;        // a range error was reported: the streams are no longer meaningful
   int64_t elems_last = 0;       // geometry of the call the recorded error belongs to
   bool indexed_last = false;
-  DevBuf state;                 // uint4 [streams]
-  DevBuf oflag;                 // unsigned int: a kernel ran out of slab space (internal error)
-  DevBuf status;                // u64[4]: first error position, its value, its index, coder calls
+  DevBuf ctl;                   // one allocation behind the three views below
+  DevView state;                // uint4 [streams]
+  DevView oflag;                // unsigned int: a stream outgrew its output slab
+  DevView status;               // u64[4]: first error position, its value, its index, filled flag
   std::vector<EncChunk> chunks;
   // results
   bool finalized = false;
@@ -1385,15 +1398,16 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         TFC_HIP(hipMemcpyAsync(backups[g0 + k].p, e->state.p, sizeof(uint4) * streams, hipMemcpyDeviceToDevice, st));
       }
       EncChunk ch;
-      TFC_HIP(ch.len.alloc(sizeof(unsigned int) * streams, st));
       ch.stride = la.cap;
-      TFC_HIP(ch.data.alloc(static_cast<size_t>(la.cap) * streams, st));
+      ch.data_bytes = static_cast<size_t>(la.cap) * streams;
+      TFC_HIP(ch.data.alloc(ch.data_bytes + sizeof(unsigned int) * streams, st));
+      ch.len_p = reinterpret_cast<unsigned int*>(ch.data.as<uint8_t>() + ch.data_bytes);
       EncLaneJob<Src>& J = jobs.job[k];
       J.src = srcs[g0 + k];
       J.index = indexed ? indexes[g0 + k] : nullptr;
       J.state = e->state.as<uint4>();
       J.chunk = ch.data.as<uint8_t>();
-      J.chunk_len = ch.len.as<unsigned int>();
+      J.chunk_len = ch.len_p;
       J.first_error = e->status.as<unsigned long long>();
       J.overflow_flag = e->oflag.as<unsigned int>();
       errs.job[k].status = J.first_error;
@@ -1458,6 +1472,7 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
 
   EncChunk ch;
   TFC_HIP(ch.len.alloc(sizeof(unsigned int) * e->streams, st));
+  ch.len_p = ch.len.as<unsigned int>();
   EncParams p;
   p.tab = view_of(t);
   p.index = index;
@@ -1518,6 +1533,7 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   }
 
   TFC_HIP(ch.data.alloc(count_status[1], st));
+  ch.data_bytes = count_status[1];
   p.chunk = ch.data.as<uint8_t>();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(e->streams, kWavesPerBlock));
@@ -1568,16 +1584,13 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
       e->fast_lds = fixed + ring * e->fast_waves;
     }
   }
-  TFC_HIP(e->state.alloc(sizeof(uint4) * std::max<int64_t>(streams, 1), st));
-  TFC_HIP(e->oflag.alloc(sizeof(unsigned int), st));
-  TFC_HIP(hipMemsetAsync(e->oflag.p, 0, sizeof(unsigned int), st));
-  TFC_HIP(e->status.alloc(sizeof(unsigned long long) * 4, st));
-  TFC_HIP(hipMemsetAsync(e->status.p, 0, sizeof(unsigned long long) * 4, st));
-  TFC_HIP(hipMemsetAsync(e->status.p, 0xFF, sizeof(unsigned long long), st));
-  if (streams)
-    hipLaunchKernelGGL(fill_state_kernel, dim3(static_cast<unsigned>(ceil_div(streams, 256))),
-                       dim3(256), 0, st, e->state.as<uint4>(), streams,
-                       make_uint4(0u, 0xFFFFFFFFu, 0u, 0u));
+  TFC_HIP(e->ctl.alloc(64 + sizeof(uint4) * std::max<int64_t>(streams, 1), st));
+  e->status.p = e->ctl.p;
+  e->oflag.p = e->ctl.as<uint8_t>() + 32;
+  e->state.p = e->ctl.as<uint8_t>() + 64;
+  hipLaunchKernelGGL(fill_state_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, ceil_div(streams, 256)))),
+                     dim3(256), 0, st, e->state.as<uint4>(), streams, make_uint4(0u, 0xFFFFFFFFu, 0u, 0u),
+                     e->status.as<unsigned long long>(), e->oflag.as<unsigned int>());
   *out = e.release();
   return 0;
 }
@@ -1679,8 +1692,8 @@ int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
   std::vector<ChunkRef> refs;
   size_t capacity = 4 * static_cast<size_t>(n) + 64;   // Finalize bytes (<= 2 per stream) + slack
   for (auto& c : e->chunks) {
-    refs.push_back(ChunkRef{c.data.as<uint8_t>(), c.off.as<long long>(), c.len.as<unsigned int>(), c.stride});
-    capacity += c.data.bytes;
+    refs.push_back(ChunkRef{c.data.as<uint8_t>(), c.off.as<long long>(), c.len_p, c.stride});
+    capacity += c.data_bytes;
   }
   DevBuf d_refs, tail, length;
   ChunkList list;
@@ -1694,13 +1707,13 @@ int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
     TFC_HIP(hipStreamSynchronize(st));               // `refs` goes away with this frame
     list.more = d_refs.as<ChunkRef>();
   }
-  TFC_HIP(tail.alloc(sizeof(Tail) * n, st));
-  TFC_HIP(length.alloc(sizeof(long long) * n, st));
+  TFC_HIP(tail.alloc((sizeof(Tail) + sizeof(long long)) * n + 16, st));
+  long long* const length_p = reinterpret_cast<long long*>(tail.as<uint8_t>() + ((sizeof(Tail) * n + 15) & ~size_t{15}));
   const unsigned tb = static_cast<unsigned>(ceil_div(n, 256));
   hipLaunchKernelGGL(enc_tail_kernel, dim3(tb), dim3(256), 0, st, e->state.as<uint4>(), n,
                      list, static_cast<int>(refs.size()), e->family == kFast ? 1 : 0,
-                     tail.as<Tail>(), length.as<long long>());
-  hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, length.as<long long>(), n,
+                     tail.as<Tail>(), length_p);
+  hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, length_p, n,
                      e->offsets.as<long long>());
   if (exact) {
     long long total = 0;
@@ -1799,7 +1812,8 @@ struct tfc_decoder {
   int64_t streams = 0;
   int mode = TFC_MODE_AUTO;
   int family = -1;
-  DevBuf blob, offsets, state, status;     // blob / offsets: owned copies of host input only
+  DevBuf blob, offsets, ctl;               // blob / offsets: owned copies of host input only
+  DevView state, status;                   // uint4 [streams]; u64 first index error (views of ctl)
   const uint8_t* blob_p = nullptr;         // device bytes the kernels read (owned or borrowed)
   const long long* off_p = nullptr;
 };
@@ -1828,12 +1842,12 @@ extern "C" int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob,
     d->blob_p = d->blob.as<uint8_t>();
     d->off_p = d->offsets.as<long long>();
   }
-  TFC_HIP(d->state.alloc(sizeof(uint4) * std::max<int64_t>(streams, 1), st));
-  TFC_HIP(d->status.alloc(sizeof(unsigned long long), st));
-  TFC_HIP(hipMemsetAsync(d->status.p, 0xFF, sizeof(unsigned long long), st));
-  if (streams)
-    hipLaunchKernelGGL(dec_open_kernel, dim3(static_cast<unsigned>(ceil_div(streams, 256))),
-                       dim3(256), 0, st, d->blob_p, d->off_p, streams, d->state.as<uint4>());
+  TFC_HIP(d->ctl.alloc(16 + sizeof(uint4) * std::max<int64_t>(streams, 1), st));
+  d->status.p = d->ctl.p;
+  d->state.p = d->ctl.as<uint8_t>() + 16;
+  hipLaunchKernelGGL(dec_open_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, ceil_div(streams, 256)))),
+                     dim3(256), 0, st, d->blob_p, d->off_p, streams, d->state.as<uint4>(),
+                     d->status.as<unsigned long long>());
   if (!src_on_device) TFC_HIP(hipStreamSynchronize(st));  // host buffers may go away
   *out = d.release();
   return 0;

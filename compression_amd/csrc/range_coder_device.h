@@ -19,7 +19,8 @@ struct EncoderState {
 };
 
 // Directory entry of the lane-per-stream kernels' LDS image (range_lanes.h): byte offsets inside the
-// image of the row's cdf entries, boundary bitmap and running counts, and
+// image of the row's cdf entries (minus 2: the lower bound of symbol s is at cdf + 2 s + 2), boundary
+// bitmap and running counts, and
 //   info = limit | has_escape << 31,  limit = number of plain symbols (= index of the escape symbol).
 struct LaneRow { unsigned int cdf, info, bits, cum; };
 

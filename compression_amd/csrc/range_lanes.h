@@ -221,8 +221,8 @@ __host__ __device__ constexpr int lane_stride(int payload) {
 // Encoder
 // ---------------------------------------------------------------------------------------------
 
-constexpr unsigned int kEncCadence = 16;        // steps between memory phases
-constexpr unsigned int kEncDigitBytes = 64;     // digit bytes staged per lane between two phases
+constexpr unsigned int kEncCadence = 8;         // steps between memory phases
+constexpr unsigned int kEncDigitBytes = 32;     // digit bytes staged per lane between two phases (<= 2 digits per step)
 
 // LDS of one encoder wave: per lane digits, value window (2 cadences of elements), index window
 template <typename Raw>
@@ -237,6 +237,113 @@ struct EncWaveLds {
   static constexpr int kIndex = kValue + 64 * kValueStride;
   static constexpr int kBytes = kIndex + 64 * kIndexStride;
 };
+
+// ---- kEncCadence encoder steps, hand-scheduled ------------------------------------------------
+// The common case only: every lane codes a plain int32 symbol of a channel-mode row in every step.  Step
+// k + 1's table lookups (row -> cdf entries) are issued before step k's interval arithmetic, so the chain
+// never waits for LDS.  The interval update keeps the reference's state machine but as arithmetic on
+// 0/1 values (st = carry undecided, r = renormalise ...) instead of branches:
+//   base1 = base + a, d = pd - 1 + carry(base1)           the delayed digit, resolved if !st && pd != 0
+//   e = r & !st; em = e & !st' (emit top), sp = e & st' (delay top + 1), pb += 2 (r & st)
+// Both digits are written to the staging area speculatively; the cursor NA only moves when they count.
+// Escapes, values out of range and delayed runs (pb != 0 at a resolve) bump FLAG: the caller restores
+// the lane state and repeats the block with the generic steps.  Fixed temporaries v140-v175:
+// v[140:147] the block's values, v[148:149] / v[150:151] rows (cdf - 2, info), v[152:153] v[154:155] /
+// v[156:157] v[158:159] (lo, 0) (hi, 0) of even / odd steps.
+#define TFC_LENC_A(VAL, R0, R1, LO, HI, NEXTROW)                                            \
+  "v_add_u32 v170, 16, %[DIRP]\n\t"                                                       \
+  "v_cmp_eq_u32 vcc, %[DEND], v170\n\t"                                                   \
+  "v_cndmask_b32 %[DIRP], v170, %[DIR0], vcc\n\t"                                         \
+  NEXTROW                                                                                 \
+  "v_and_b32 v171, 0x7fffffff, v" #R1 "\n\t"                                              \
+  "v_cmp_ge_u32 vcc, v" #VAL ", v171\n\t"                                                 \
+  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
+  "v_min_u32 v172, v" #VAL ", v171\n\t"                                                   \
+  "v_lshl_add_u32 v172, v172, 1, v" #R0 "\n\t"                                            \
+  "ds_read_u16 v" #LO ", v172 offset:2\n\t"                                               \
+  "ds_read_u16 v" #HI ", v172 offset:4\n\t"
+#define TFC_LENC_B(LO, LOH, HI, HIH)                                                      \
+  "v_cmp_eq_u32 vcc, 0, v" #HI "\n\t"                                                     \
+  "v_mad_u64_u32 v[160:161], s[52:53], v" #LO ", %[S], v[" #LO ":" #LOH "]\n\t"             \
+  "v_cndmask_b32 v" #HI ", v" #HI ", %[V64K], vcc\n\t"                                    \
+  "v_alignbit_b32 v160, v161, v160, 16\n\t"                                               \
+  "v_mad_u64_u32 v[162:163], s[52:53], v" #HI ", %[S], v[" #HI ":" #HIH "]\n\t"             \
+  "v_add_co_u32 v164, vcc, %[BASE], v160\n\t"                                             \
+  "v_addc_co_u32 v167, vcc, -1, %[PD], vcc\n\t"                                           \
+  "v_alignbit_b32 v162, v163, v162, 16\n\t"                                               \
+  "v_add_u32 v162, -1, v162\n\t"                                                          \
+  "v_sub_u32 v165, v162, v160\n\t"                                                        \
+  "v_add_co_u32 v166, vcc, v164, v165\n\t"                                                \
+  "v_cndmask_b32 v168, %[PD], %[DIR0], vcc\n\t"                                           \
+  "v_cndmask_b32 v173, 1, 0, vcc\n\t"                                                     \
+  "v_perm_b32 v167, 0, v167, %[PERM]\n\t"                                                 \
+  "ds_write_b16 %[NA], v167\n\t"                                                          \
+  "v_min_u32 v169, 1, v168\n\t"                                                           \
+  "v_lshl_add_u32 %[NA], v169, 1, %[NA]\n\t"                                              \
+  "v_sub_u32 %[PD], %[PD], v168\n\t"                                                      \
+  "v_mul_u32_u24 v169, v169, %[PB]\n\t"                                                   \
+  "v_or_b32 %[FLAG], %[FLAG], v169\n\t"                                                   \
+  "v_cmp_gt_u32 vcc, %[K64K], v165\n\t"                                                   \
+  "v_lshlrev_b32 v168, 16, v164\n\t"                                                      \
+  "v_lshl_or_b32 v169, v165, 16, %[KFFFF]\n\t"                                            \
+  "v_cndmask_b32 %[BASE], v164, v168, vcc\n\t"                                            \
+  "v_cndmask_b32 %[S], v165, v169, vcc\n\t"                                               \
+  "v_cndmask_b32 v174, 0, 1, vcc\n\t"                                                     \
+  "v_add_co_u32 v166, vcc, %[BASE], %[S]\n\t"                                             \
+  "v_lshrrev_b32 v169, 16, v164\n\t"                                                      \
+  "v_and_b32 v168, v174, v173\n\t"                                                        \
+  "v_cndmask_b32 v175, 1, 0, vcc\n\t"                                                     \
+  "v_sub_u32 v174, v174, v168\n\t"                                                        \
+  "v_lshl_add_u32 %[PB], v174, 1, %[PB]\n\t"                                              \
+  "v_perm_b32 v166, 0, v169, %[PERM]\n\t"                                                 \
+  "ds_write_b16 %[NA], v166\n\t"                                                          \
+  "v_and_b32 v175, v168, v175\n\t"                                                        \
+  "v_lshl_add_u32 %[NA], v175, 1, %[NA]\n\t"                                              \
+  "v_sub_u32 v168, v168, v175\n\t"                                                        \
+  "v_add_u32 v169, 1, v169\n\t"                                                           \
+  "v_mad_u32_u24 %[PD], v168, v169, %[PD]\n\t"
+#define TFC_LENC_ROW_A "ds_read_b64 v[148:149], %[DIRP]\n\t"
+#define TFC_LENC_ROW_B "ds_read_b64 v[150:151], %[DIRP]\n\t"
+#define TFC_LENC_BLOCK                                                                    \
+  "ds_read2_b32 v[140:141], %[VP] offset1:1\n\t"                                          \
+  "ds_read2_b32 v[142:143], %[VP] offset0:2 offset1:3\n\t"                                \
+  "ds_read2_b32 v[144:145], %[VP] offset0:4 offset1:5\n\t"                                \
+  "ds_read2_b32 v[146:147], %[VP] offset0:6 offset1:7\n\t"                                \
+  TFC_LENC_ROW_A                                                                          \
+  "v_mov_b32 v153, 0\n\tv_mov_b32 v155, 0\n\tv_mov_b32 v157, 0\n\tv_mov_b32 v159, 0\n\t"  \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                              \
+  TFC_LENC_A(140, 148, 149, 152, 154, TFC_LENC_ROW_B)                                     \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                              \
+  TFC_LENC_A(141, 150, 151, 156, 158, TFC_LENC_ROW_A)                                     \
+  "s_waitcnt lgkmcnt(3)\n\t"                                                              \
+  TFC_LENC_B(152, 153, 154, 155)                                                          \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
+  TFC_LENC_A(142, 148, 149, 152, 154, TFC_LENC_ROW_B)                                     \
+  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
+  TFC_LENC_B(156, 157, 158, 159)                                                          \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
+  TFC_LENC_A(143, 150, 151, 156, 158, TFC_LENC_ROW_A)                                     \
+  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
+  TFC_LENC_B(152, 153, 154, 155)                                                          \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
+  TFC_LENC_A(144, 148, 149, 152, 154, TFC_LENC_ROW_B)                                     \
+  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
+  TFC_LENC_B(156, 157, 158, 159)                                                          \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
+  TFC_LENC_A(145, 150, 151, 156, 158, TFC_LENC_ROW_A)                                     \
+  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
+  TFC_LENC_B(152, 153, 154, 155)                                                          \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
+  TFC_LENC_A(146, 148, 149, 152, 154, TFC_LENC_ROW_B)                                     \
+  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
+  TFC_LENC_B(156, 157, 158, 159)                                                          \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
+  TFC_LENC_A(147, 150, 151, 156, 158, "")                                                 \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
+  TFC_LENC_B(152, 153, 154, 155)                                                          \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                              \
+  TFC_LENC_B(156, 157, 158, 159)                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"
 
 template <bool INDEXED, typename Src>
 __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> jobs, LaneArgs la) {
@@ -260,20 +367,25 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
   unsigned int base = st.x, s1 = st.y, pd = st.z, pb = st.w;
   lanes_pin(base, s1, pd, pb);
 
-  unsigned char* const wave_lds = lanes_lds + la.lds_image + (threadIdx.x >> 6) * la.lds_wave;
-  unsigned char* const dstage = wave_lds + L::kDigits + L::kDigitStride * lane;   // this lane's digit bytes
+  // the kernel's dynamic LDS starts at LDS address lds0 (0 unless static LDS ever gets added)
+  const unsigned int lds0 = static_cast<unsigned int>(reinterpret_cast<size_t>(
+      (__attribute__((address_space(3))) unsigned char*)lanes_lds));
+  const unsigned int wave_off = static_cast<unsigned int>(la.lds_image) + (threadIdx.x >> 6) * static_cast<unsigned int>(la.lds_wave);
+  const unsigned int ds_off = wave_off + L::kDigits + L::kDigitStride * lane;      // this lane's digit bytes
+  unsigned char* const dstage = lanes_lds + ds_off;
   unsigned char* const out = J.chunk + (live ? s : 0) * static_cast<int64_t>(la.cap);
   unsigned int wpos = 0u;          // slab bytes written by earlier phases
   unsigned int n = 0u;             // digit bytes produced since
   unsigned int overflow = 0u;
   LaneWindow<L::kValueWords> vw;
-  vw.lds = wave_lds + L::kValue + L::kValueStride * lane;
+  const unsigned int vw_off = wave_off + L::kValue + L::kValueStride * lane;
+  vw.lds = lanes_lds + vw_off;
   vw.g = reinterpret_cast<const unsigned char*>(src.base() + pos0);
   vw.len = elems * kRaw;
   vw.request(0u);
   LaneWindow<L::kIndexWords> iw;
   if (INDEXED) {
-    iw.lds = wave_lds + L::kIndex + L::kIndexStride * lane;
+    iw.lds = lanes_lds + wave_off + L::kIndex + L::kIndexStride * lane;
     iw.g = reinterpret_cast<const unsigned char*>(index + pos0);
     iw.len = elems * 4u;
     iw.request(0u);
@@ -315,18 +427,8 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
     }
   };
 
-  for (unsigned int it = 0u; __any(j < elems || qn != 0u); ++it) {
-    if ((it & (kEncCadence - 1u)) == 0u) {
-      // memory phase: park what the previous phase requested, request from the current position, store
-      // the digits of the last kEncCadence steps
-      vw.commit();
-      vw.request(j * kRaw);
-      if (INDEXED) {
-        iw.commit();
-        iw.request(j * 4u);
-      }
-      flush();
-    }
+  // one generic step: any lane state
+  auto step = [&]() {
     // ---- the call of this step: speculatively the next symbol as a plain one (reads stay inside the
     // lane's window and the directory whatever j is); escapes, escape bits, range errors and idle lanes
     // are sorted out behind a wave-uniform branch ---------------------------------------------------
@@ -340,13 +442,13 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
       }
     }
     const int32_t v = src.quant(*reinterpret_cast<const Raw*>(vw.lds + (j * kRaw - vw.base)), static_cast<int>(dp >> 4));
-    const uint2 row = *reinterpret_cast<const uint2*>(lanes_lds + dp);   // cdf offset, limit | escape << 31
+    const uint2 row = *reinterpret_cast<const uint2*>(lanes_lds + dp);   // cdf offset - 2, limit | escape << 31
     const unsigned int limit = row.y & 0x7FFFFFFFu;                      // first value that is not a plain symbol
     const bool take = qn == 0u && j < elems;
     const bool plain = static_cast<unsigned int>(v) < limit;             // negative values are not
     unsigned int sym = plain ? static_cast<unsigned int>(v) : limit;
     bool act = take;                 // this lane makes a coder call in this step
-    bool adv = take;                 // ... and moves on to the next symbol
+    const bool adv = take;           // ... and moves on to the next symbol
     unsigned int lo = 0u, hi = 0u;
     if (__any(!(take && plain) && (qn != 0u || j < elems))) {
       if (take && !plain) {
@@ -371,8 +473,8 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
       }
     }
     {
-      const unsigned int tlo = lds_u16(lanes_lds, row.x + 2u * sym);
-      const unsigned int thi = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
+      const unsigned int tlo = lds_u16(lanes_lds, row.x + 2u * sym + 2u);       // row.x = offset of cdf[0] - 2
+      const unsigned int thi = lds_u16(lanes_lds, row.x + 2u * sym + 4u);
       lo = take ? tlo : lo;
       hi = take ? (thi == 0u ? 65536u : thi) : hi;
     }
@@ -408,6 +510,48 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
     pb = (ren && st1) ? pb + 2u : pb;
     base = act ? base2 : base;
     s1 = act ? s12 : s1;
+  };
+
+  constexpr bool kFastBlock = !INDEXED && std::is_same<Src, SymInt32>::value;
+  while (__any(j < elems || qn != 0u)) {
+    {
+      // memory phase: park what the previous phase requested, request from the current position, store
+      // the digits of the last kEncCadence steps
+      vw.commit();
+      vw.request(j * kRaw);
+      if (INDEXED) {
+        iw.commit();
+        iw.request(j * 4u);
+      }
+      flush();
+    }
+    const bool busy = j < elems || qn != 0u;
+    if (kFastBlock && lds0 == 0u && !__any(busy && (j + kEncCadence > elems || qn != 0u))) {
+      const unsigned int base0 = base, s10 = s1, pd0 = pd, pb0 = pb, dirp0 = dirp;
+      unsigned int flag = 0u, na = ds_off;
+      if (busy) {
+        const unsigned int vp = vw_off + (j * 4u - vw.base);
+        asm volatile(TFC_LENC_BLOCK
+                     : [BASE] "+v"(base), [S] "+v"(s1), [PD] "+v"(pd), [PB] "+v"(pb), [NA] "+v"(na),
+                       [DIRP] "+v"(dirp), [FLAG] "+v"(flag)
+                     : [VP] "v"(vp), [DEND] "s"(dir_end), [DIR0] "v"(0u), [V64K] "v"(0x10000u), [K64K] "s"(0x10000u),
+                       [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
+                     : "vcc", "memory", "s52", "s53", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147",
+                       "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159",
+                       "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171",
+                       "v172", "v173", "v174", "v175");
+      }
+      if (!__any(flag != 0u)) {
+        if (busy) {
+          j += kEncCadence;
+          n = na - ds_off;
+        }
+        continue;
+      }
+      base = base0; s1 = s10; pd = pd0; pb = pb0; dirp = dirp0;     // an exception somewhere in the wave
+    }
+#pragma nounroll
+    for (unsigned int k = 0; k < kEncCadence; ++k) step();
   }
   flush();
   if (live) {
@@ -439,6 +583,89 @@ struct DecWaveLds {
   static constexpr int kBytes = kIndex + 64 * kIndexStride;
 };
 
+// ---- kDecCadence decoder steps, hand-scheduled ------------------------------------------------
+// The common case only: every lane decodes a plain symbol of a channel-mode row in every step.  A lone
+// wave pays ~4 cycles per instruction of any kind, so the block is written for instruction count
+// (~55 per step against ~100 from the compiler) and for LDS latency: the directory entry of step k + 1
+// and the code digit are requested before the quotient arithmetic of step k.  Anything else — an
+// escape symbol, an estimate that the verification rejects, damaged input — only bumps FLAG; the
+// caller then restores the lane state it saved and repeats the block with the generic steps.
+// LDS operands are absolute LDS addresses (the kernel's dynamic LDS starts at 0, checked by the
+// caller).  Temporaries are the fixed registers v100-v132 (register pairs and the 4-register row
+// buffers need known numbers): v[100:103] / v[104:107] rows (cdf - 2, info, bits, cum), v[120:121] = -1,
+// v[122:123] = (lo, 0), v[124:125] = (hi, 0).
+#define TFC_LDEC_ADVANCE                                                                  \
+  "v_add_u32 v108, 16, %[DIRP]\n\t"                                                       \
+  "v_cmp_eq_u32 vcc, %[DEND], v108\n\t"                                                   \
+  "v_cndmask_b32 %[DIRP], v108, %[DIR0], vcc\n\t"
+#define TFC_LDEC_STEP(ROW0, ROW1, ROW2, ROW3, PREFETCH, OUTOFF)                            \
+  TFC_LDEC_ADVANCE                                                                        \
+  PREFETCH                                                                                \
+  "ds_read_u16 v109, %[CP]\n\t"                                                           \
+  "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
+  "v_cvt_f32_u32 v111, %[S]\n\t"                                                          \
+  "v_rcp_f32 v111, v111\n\t"                                                              \
+  "v_add_f32 v110, 0.5, v110\n\t"                                                         \
+  "s_nop 0\n\t"                                                                           \
+  "v_mul_f32 v110, v110, v111\n\t"                                                        \
+  "v_mul_f32 v110, %[SCALE], v110\n\t"                                                    \
+  "v_cvt_u32_f32 v110, v110\n\t"                                                          \
+  "v_min_u32 v110, %[QMAX], v110\n\t"                                                     \
+  "v_lshrrev_b32 v111, 6, v110\n\t"                                                       \
+  "v_lshl_add_u32 v112, v111, 3, v" #ROW2 "\n\t"                                          \
+  "v_lshl_add_u32 v113, v111, 1, v" #ROW3 "\n\t"                                          \
+  "ds_read_b64 v[114:115], v112\n\t"                                                      \
+  "ds_read_u16 v116, v113\n\t"                                                            \
+  "v_not_b32 v110, v110\n\t"                                                              \
+  "v_lshrrev_b64 v[118:119], v110, v[120:121]\n\t"                                        \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                              \
+  "v_and_b32 v114, v114, v118\n\t"                                                        \
+  "v_and_b32 v115, v115, v119\n\t"                                                        \
+  "v_bcnt_u32_b32 v116, v114, v116\n\t"                                                   \
+  "v_bcnt_u32_b32 v116, v115, v116\n\t"                                                   \
+  "v_lshl_add_u32 v112, v116, 1, v" #ROW0 "\n\t"                                          \
+  "ds_read_u16 v122, v112\n\t"                                                            \
+  "ds_read_u16 v124, v112 offset:2\n\t"                                                   \
+  "v_xor_b32 v113, 0x80000000, v" #ROW1 "\n\t"                                            \
+  "v_add_u32 v117, -1, v116\n\t"                                                          \
+  "v_cmp_eq_u32 vcc, v117, v113\n\t"                                                      \
+  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
+  "ds_write_b32 %[OQ], v117 offset:" #OUTOFF "\n\t"                                       \
+  "v_perm_b32 v109, 0, v109, %[PERM]\n\t"                                                 \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                              \
+  "v_mad_u64_u32 v[126:127], vcc, v122, %[S], v[122:123]\n\t"                             \
+  "v_mad_u64_u32 v[128:129], vcc, v124, %[S], v[124:125]\n\t"                             \
+  "v_alignbit_b32 v126, v127, v126, 16\n\t"                                               \
+  "v_alignbit_b32 v128, v129, v128, 16\n\t"                                               \
+  "v_add_u32 v128, -1, v128\n\t"                                                          \
+  "v_cmp_eq_u32 vcc, 0, v124\n\t"                                                         \
+  "v_cndmask_b32 v128, v128, %[S], vcc\n\t"                                               \
+  "v_sub_u32 v130, %[D], v126\n\t"                                                        \
+  "v_sub_u32 v131, v128, v126\n\t"                                                        \
+  "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
+  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
+  "v_cmp_gt_u32 vcc, %[K64K], v131\n\t"                                                   \
+  "v_lshl_or_b32 v132, v130, 16, v109\n\t"                                                \
+  "v_cndmask_b32 %[D], v130, v132, vcc\n\t"                                               \
+  "v_lshl_or_b32 v132, v131, 16, %[KFFFF]\n\t"                                            \
+  "v_cndmask_b32 %[S], v131, v132, vcc\n\t"                                               \
+  "v_cndmask_b32 v132, 0, 2, vcc\n\t"                                                     \
+  "v_add_u32 %[CP], %[CP], v132\n\t"
+#define TFC_LDEC_READ_A "ds_read_b128 v[100:103], %[DIRP]\n\t"
+#define TFC_LDEC_READ_B "ds_read_b128 v[104:107], %[DIRP]\n\t"
+#define TFC_LDEC_BLOCK                                                                    \
+  "v_mov_b32 v120, -1\n\tv_mov_b32 v121, -1\n\tv_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t" \
+  TFC_LDEC_READ_A "s_waitcnt lgkmcnt(0)\n\t"                                              \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B, 0)                                   \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A, 4)                                   \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B, 8)                                   \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A, 12)                                  \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B, 16)                                  \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A, 20)                                  \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B, 24)                                  \
+  TFC_LDEC_STEP(104, 105, 106, 107, "", 28)                                               \
+  "s_waitcnt lgkmcnt(0)\n\t"
+
 template <bool INDEXED, typename Dst>
 __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> jobs, LaneArgs la) {
   extern __shared__ unsigned char lanes_lds[];
@@ -465,19 +692,24 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
   unsigned int pos_start = 2u * st.w;      // bytes consumed
   lanes_pin(D, s1, len, pos_start);
 
-  unsigned char* const wave_lds = lanes_lds + la.lds_image + (threadIdx.x >> 6) * la.lds_wave;
+  // the kernel's dynamic LDS starts at LDS address lds0 (0 unless static LDS ever gets added)
+  const unsigned int lds0 = static_cast<unsigned int>(reinterpret_cast<size_t>(
+      (__attribute__((address_space(3))) unsigned char*)lanes_lds));
+  const unsigned int wave_off = static_cast<unsigned int>(la.lds_image) + (threadIdx.x >> 6) * static_cast<unsigned int>(la.lds_wave);
   LaneWindow<L::kCodeWords> cw;
-  cw.lds = wave_lds + L::kCodes + L::kCodeStride * lane;
+  const unsigned int cw_off = wave_off + L::kCodes + L::kCodeStride * lane;
+  cw.lds = lanes_lds + cw_off;
   cw.g = J.blob + o0;
   cw.len = len;
   cw.request(pos_start);
   cw.base = pos_start;
-  const unsigned char* cp = cw.lds;      // LDS address of the next code digit: stream position cw.base + (cp - cw.lds)
-  unsigned char* const outq = wave_lds + L::kOut + L::kOutStride * lane;
+  unsigned int cp = cw_off;              // LDS offset of the next code digit: stream position cw.base + (cp - cw_off)
+  const unsigned int oq_off = wave_off + L::kOut + L::kOutStride * lane;
+  unsigned char* const outq = lanes_lds + oq_off;
   unsigned int ko = 0u;                  // bytes of decoded elements waiting in outq
   LaneWindow<L::kIndexWords> iw;
   if (INDEXED) {
-    iw.lds = wave_lds + L::kIndex + L::kIndexStride * lane;
+    iw.lds = lanes_lds + wave_off + L::kIndex + L::kIndexStride * lane;
     iw.g = reinterpret_cast<const unsigned char*>(index + pos0);
     iw.len = elems * 4u;
     iw.request(0u);
@@ -508,20 +740,8 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
     ko = 0u;
   };
 
-  for (unsigned int it = 0u; __any(j < elems); ++it) {
-    if ((it & (kDecCadence - 1u)) == 0u) {
-      // memory phase: park the code bytes requested at the previous phase, request from the current
-      // position, store the elements of the last kDecCadence steps
-      const unsigned int pos = cw.base + static_cast<unsigned int>(cp - cw.lds);
-      cw.commit();
-      cp = cw.lds + (pos - cw.base);
-      cw.request(pos);
-      if (INDEXED) {
-        iw.commit();
-        iw.request(j * 4u);
-      }
-      flush();
-    }
+  // one generic step: any mode, any lane state
+  auto step = [&]() {
     if (j < elems) {
       if (mode == 0u) {
         unsigned int dp = dirp;
@@ -533,8 +753,8 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
           }
           dp = 16u * static_cast<unsigned int>(t);
         }
-        const uint4 row = *reinterpret_cast<const uint4*>(lanes_lds + dp);   // cdf, limit | escape << 31, bits, cum
-        const unsigned int dig = __builtin_bswap16(*reinterpret_cast<const unsigned short*>(cp));
+        const uint4 row = *reinterpret_cast<const uint4*>(lanes_lds + dp);   // cdf - 2, limit | escape << 31, bits, cum
+        const unsigned int dig = __builtin_bswap16(*reinterpret_cast<const unsigned short*>(lanes_lds + cp));
         // ---- symbol first: quotient estimate -> rank among the row's boundaries ------------------
         const float fq = (static_cast<float>(D) + 0.5f) * __builtin_amdgcn_rcpf(static_cast<float>(s1)) * scale;
         const unsigned int q = min(static_cast<unsigned int>(fq), cp_max);
@@ -544,8 +764,8 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         const unsigned long long below = ~0ull >> (63u - (q & 63u));
         unsigned int sym = cum + static_cast<unsigned int>(__popcll(word & below)) - 1u;
         // ---- exact bounds; the reference's search condition A <= D < B verifies the estimate ----
-        unsigned int lo = lds_u16(lanes_lds, row.x + 2u * sym);
-        unsigned int hi = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
+        unsigned int lo = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
+        unsigned int hi = lds_u16(lanes_lds, row.x + 2u * sym + 4u);
         unsigned int A = scale16(s1, lo);
         unsigned int b = scale16(s1, hi) - 1u;      // B - 1
         b = hi == 0u ? s1 : b;                      // the row's last entry, 2^16, is stored as 0: B = span
@@ -557,8 +777,8 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
             if (D - A > b - A) {
               if (D < A) sym = sym > 0u ? sym - 1u : 0u;
               else sym = sym + 1u < nsym ? sym + 1u : nsym - 1u;
-              lo = lds_u16(lanes_lds, row.x + 2u * sym);
-              hi = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
+              lo = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
+              hi = lds_u16(lanes_lds, row.x + 2u * sym + 4u);
               A = scale16(s1, lo);
               b = scale16(s1, hi) - 1u;
               b = hi == 0u ? s1 : b;
@@ -571,7 +791,7 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         const bool ren = (s1 >> 16) == 0u;
         D = ren ? (D << 16) | dig : D;
         s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
-        cp += ren ? 2 : 0;
+        cp += ren ? 2u : 0u;
         // ---- the element (written speculatively: it counts only if the cursors advance) ------------
         const bool esc = sym == (row.y ^ 0x80000000u);      // the escape symbol of a row that has one
         *reinterpret_cast<Elem*>(outq + ko) = dst.make(static_cast<int>(dp >> 4), static_cast<int>(sym));
@@ -587,7 +807,7 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
       } else {
         // ---- one bit of an Elias-gamma escape code (range_coder_kernels.cc:449-471): the uniform
         // binary cdf {0, 1, 2} at precision 1 needs no table ------------------------------------------
-        const unsigned int dig = __builtin_bswap16(*reinterpret_cast<const unsigned short*>(cp));
+        const unsigned int dig = __builtin_bswap16(*reinterpret_cast<const unsigned short*>(lanes_lds + cp));
         const unsigned int half = scale16(s1, 32768u);          // B of the first interval
         const unsigned int bit = D >= half ? 1u : 0u;
         const unsigned int A = bit ? half : 0u;
@@ -597,7 +817,7 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         const bool ren = (s1 >> 16) == 0u;
         D = ren ? (D << 16) | dig : D;
         s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
-        cp += ren ? 2 : 0;
+        cp += ren ? 2u : 0u;
         bool done = false;
         if (mode == 1u) {
           // unary prefix, bounded so that damaged input cannot spin
@@ -626,12 +846,52 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         }
       }
     }
+  };
+
+  constexpr bool kFastBlock = !INDEXED && std::is_same<Dst, OutInt32>::value;
+  while (__any(j < elems)) {
+    {
+      // memory phase: park the code bytes requested at the previous phase, request from the current
+      // position, store the elements of the last kDecCadence steps
+      const unsigned int pos = cw.base + (cp - cw_off);
+      cw.commit();
+      cp = cw_off + (pos - cw.base);
+      cw.request(pos);
+      if (INDEXED) {
+        iw.commit();
+        iw.request(j * 4u);
+      }
+      flush();
+    }
+    if (kFastBlock && lds0 == 0u && !__any(j < elems && (j + kDecCadence > elems || mode != 0u))) {
+      const unsigned int D0 = D, s10 = s1, cp0 = cp, dirp0 = dirp;
+      unsigned int flag = 0u;
+      if (j < elems) {
+        asm volatile(TFC_LDEC_BLOCK
+                     : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [DIRP] "+v"(dirp), [FLAG] "+v"(flag)
+                     : [OQ] "v"(oq_off), [SCALE] "s"(scale), [QMAX] "s"(cp_max), [DEND] "s"(dir_end),
+                       [DIR0] "v"(0u), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
+                     : "vcc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+                       "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",
+                       "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132");
+      }
+      if (!__any(flag != 0u)) {
+        if (j < elems) {
+          j += kDecCadence;
+          ko = kDecCadence * kEs;
+        }
+        continue;
+      }
+      D = D0; s1 = s10; cp = cp0; dirp = dirp0;      // an exception somewhere in the wave: the generic steps
+    }
+#pragma nounroll
+    for (unsigned int k = 0; k < kDecCadence; ++k) step();
   }
   flush();
 
   if (live) {
     // back to the (base, span - 1, window, digits pulled) form shared with the other kernels
-    const unsigned int pos = cw.base + static_cast<unsigned int>(cp - cw.lds);
+    const unsigned int pos = cw.base + (cp - cw_off);
     const unsigned char* srcp = J.blob + o0;
     unsigned int window = 0u;
     for (int i = -4; i < 0; ++i) {

@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
   const int groups = getenv("NGROUPS") ? atoi(getenv("NGROUPS")) : 2;
   for (int depth : depths) {
     if (depth < 2) continue;
-    double best = 1e30;
+    double best = 1e30, best_host = 0;
     for (int rep = 0; rep < 3; ++rep) {
       const int rounds = 2;
       std::vector<tfc_encoder*> es;
@@ -185,7 +185,7 @@ int main(int argc, char** argv) {
       const int steps = rounds * groups * depth;
       if (dt / steps < best) {
         best = dt / steps;
-        if (rep == 2 || true) (void)th;
+        best_host = th / steps;
       }
       // check the last group's round trip
       std::vector<int32_t> back(streams * elems), want(streams * elems);
@@ -194,8 +194,8 @@ int main(int argc, char** argv) {
       if (memcmp(back.data(), want.data(), back.size() * 4) != 0) printf("ROUND TRIP MISMATCH at depth %d\n", depth);
       for (size_t k = 0; k < es.size(); ++k) { tfc_decoder_destroy(ds[k]); tfc_encoder_destroy(es[k]); }
     }
-    printf("mode %d, %3d steps per launch x %d groups in flight: %.3f ms/step  %.2f Gsym/s round trip\n", mode, depth,
-           groups, 1e3 * best, streams * elems / best / 1e9);
+    printf("mode %d, %3d steps per launch x %d groups in flight: %.3f ms/step (host enqueue %.3f)  %.2f Gsym/s round trip\n",
+           mode, depth, groups, 1e3 * best, 1e3 * best_host, streams * elems / best / 1e9);
   }
   return 0;
 }
