@@ -308,7 +308,10 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       cdf_entries += static_cast<size_t>(nsym + 1);
       words += std::max<size_t>(1, (size_t{1} << prec) / 64);
     }
-    const size_t dir_bytes = sizeof(tfc::LaneRow) * ntab;
+    // the directory repeats its first entries behind its end: a block of 8 steps reads 8 consecutive
+    // entries without a wrap test per step
+    constexpr size_t kDirRepeat = 8;
+    const size_t dir_bytes = sizeof(tfc::LaneRow) * (ntab + kDirRepeat);
     const size_t cdf_bytes = (2 * cdf_entries + 15) & ~size_t{15};
     const size_t enc_bytes = dir_bytes + cdf_bytes;
     const size_t dec_bytes = enc_bytes + 8 * words + ((2 * words + 15) & ~size_t{15});
@@ -341,6 +344,7 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
         ce += static_cast<size_t>(nsym + 1);
         wo += nw;
       }
+      for (size_t i = 0; i < kDirRepeat; ++i) dir[ntab + i] = dir[i % ntab];
       TFC_HIP(t->d_lane_image.alloc(image.size(), st));
       TFC_HIP(hipMemcpyAsync(t->d_lane_image.p, image.data(), image.size(), hipMemcpyHostToDevice, st));
       TFC_HIP(hipStreamSynchronize(st));

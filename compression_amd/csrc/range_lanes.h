@@ -251,9 +251,6 @@ struct EncWaveLds {
 // v[140:147] the block's values, v[148:149] / v[150:151] rows (cdf - 2, info), v[152:153] v[154:155] /
 // v[156:157] v[158:159] (lo, 0) (hi, 0) of even / odd steps.
 #define TFC_LENC_A(VAL, R0, R1, LO, HI, NEXTROW)                                            \
-  "v_add_u32 v170, 16, %[DIRP]\n\t"                                                       \
-  "v_cmp_eq_u32 vcc, %[DEND], v170\n\t"                                                   \
-  "v_cndmask_b32 %[DIRP], v170, %[DIR0], vcc\n\t"                                         \
   NEXTROW                                                                                 \
   "v_and_b32 v171, 0x7fffffff, v" #R1 "\n\t"                                              \
   "v_cmp_ge_u32 vcc, v" #VAL ", v171\n\t"                                                 \
@@ -263,15 +260,14 @@ struct EncWaveLds {
   "ds_read_u16 v" #LO ", v172 offset:2\n\t"                                               \
   "ds_read_u16 v" #HI ", v172 offset:4\n\t"
 #define TFC_LENC_B(LO, LOH, HI, HIH)                                                      \
-  "v_cmp_eq_u32 vcc, 0, v" #HI "\n\t"                                                     \
   "v_mad_u64_u32 v[160:161], s[52:53], v" #LO ", %[S], v[" #LO ":" #LOH "]\n\t"             \
-  "v_cndmask_b32 v" #HI ", v" #HI ", %[V64K], vcc\n\t"                                    \
-  "v_alignbit_b32 v160, v161, v160, 16\n\t"                                               \
   "v_mad_u64_u32 v[162:163], s[52:53], v" #HI ", %[S], v[" #HI ":" #HIH "]\n\t"             \
+  "v_alignbit_b32 v160, v161, v160, 16\n\t"                                               \
   "v_add_co_u32 v164, vcc, %[BASE], v160\n\t"                                             \
   "v_addc_co_u32 v167, vcc, -1, %[PD], vcc\n\t"                                           \
   "v_alignbit_b32 v162, v163, v162, 16\n\t"                                               \
   "v_add_u32 v162, -1, v162\n\t"                                                          \
+  "v_min_u32 v162, v162, %[S]\n\t"                                                        \
   "v_sub_u32 v165, v162, v160\n\t"                                                        \
   "v_add_co_u32 v166, vcc, v164, v165\n\t"                                                \
   "v_cndmask_b32 v168, %[PD], %[DIR0], vcc\n\t"                                           \
@@ -302,39 +298,39 @@ struct EncWaveLds {
   "v_sub_u32 v168, v168, v175\n\t"                                                        \
   "v_add_u32 v169, 1, v169\n\t"                                                           \
   "v_mad_u32_u24 %[PD], v168, v169, %[PD]\n\t"
-#define TFC_LENC_ROW_A "ds_read_b64 v[148:149], %[DIRP]\n\t"
-#define TFC_LENC_ROW_B "ds_read_b64 v[150:151], %[DIRP]\n\t"
+#define TFC_LENC_ROW_A(OFF) "ds_read_b64 v[148:149], %[DIRP] offset:" #OFF "\n\t"
+#define TFC_LENC_ROW_B(OFF) "ds_read_b64 v[150:151], %[DIRP] offset:" #OFF "\n\t"
 #define TFC_LENC_BLOCK                                                                    \
   "ds_read2_b32 v[140:141], %[VP] offset1:1\n\t"                                          \
   "ds_read2_b32 v[142:143], %[VP] offset0:2 offset1:3\n\t"                                \
   "ds_read2_b32 v[144:145], %[VP] offset0:4 offset1:5\n\t"                                \
   "ds_read2_b32 v[146:147], %[VP] offset0:6 offset1:7\n\t"                                \
-  TFC_LENC_ROW_A                                                                          \
+  TFC_LENC_ROW_A(0)                                                                       \
   "v_mov_b32 v153, 0\n\tv_mov_b32 v155, 0\n\tv_mov_b32 v157, 0\n\tv_mov_b32 v159, 0\n\t"  \
   "s_waitcnt lgkmcnt(0)\n\t"                                                              \
-  TFC_LENC_A(140, 148, 149, 152, 154, TFC_LENC_ROW_B)                                     \
+  TFC_LENC_A(140, 148, 149, 152, 154, TFC_LENC_ROW_B(16))                                     \
   "s_waitcnt lgkmcnt(2)\n\t"                                                              \
-  TFC_LENC_A(141, 150, 151, 156, 158, TFC_LENC_ROW_A)                                     \
+  TFC_LENC_A(141, 150, 151, 156, 158, TFC_LENC_ROW_A(32))                                     \
   "s_waitcnt lgkmcnt(3)\n\t"                                                              \
   TFC_LENC_B(152, 153, 154, 155)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(142, 148, 149, 152, 154, TFC_LENC_ROW_B)                                     \
+  TFC_LENC_A(142, 148, 149, 152, 154, TFC_LENC_ROW_B(48))                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
   TFC_LENC_B(156, 157, 158, 159)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(143, 150, 151, 156, 158, TFC_LENC_ROW_A)                                     \
+  TFC_LENC_A(143, 150, 151, 156, 158, TFC_LENC_ROW_A(64))                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
   TFC_LENC_B(152, 153, 154, 155)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(144, 148, 149, 152, 154, TFC_LENC_ROW_B)                                     \
+  TFC_LENC_A(144, 148, 149, 152, 154, TFC_LENC_ROW_B(80))                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
   TFC_LENC_B(156, 157, 158, 159)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(145, 150, 151, 156, 158, TFC_LENC_ROW_A)                                     \
+  TFC_LENC_A(145, 150, 151, 156, 158, TFC_LENC_ROW_A(96))                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
   TFC_LENC_B(152, 153, 154, 155)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(146, 148, 149, 152, 154, TFC_LENC_ROW_B)                                     \
+  TFC_LENC_A(146, 148, 149, 152, 154, TFC_LENC_ROW_B(112))                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
   TFC_LENC_B(156, 157, 158, 159)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
@@ -392,6 +388,7 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
   }
 
   const unsigned int dir_end = 16u * static_cast<unsigned int>(la.ntab);
+  const unsigned int dir_step = (16u * kEncCadence) % dir_end;
   unsigned int j = 0u;              // next symbol to take
   unsigned int dirp = 0u;           // channel mode: LDS offset of its directory entry
   unsigned int qn = 0u, g = 0u, neg = 0u;   // escape bits still to code: qn of them, from g then the sign
@@ -527,14 +524,13 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
     }
     const bool busy = j < elems || qn != 0u;
     if (kFastBlock && lds0 == 0u && !__any(busy && (j + kEncCadence > elems || qn != 0u))) {
-      const unsigned int base0 = base, s10 = s1, pd0 = pd, pb0 = pb, dirp0 = dirp;
+      const unsigned int base0 = base, s10 = s1, pd0 = pd, pb0 = pb;
       unsigned int flag = 0u, na = ds_off;
       if (busy) {
         const unsigned int vp = vw_off + (j * 4u - vw.base);
         asm volatile(TFC_LENC_BLOCK
-                     : [BASE] "+v"(base), [S] "+v"(s1), [PD] "+v"(pd), [PB] "+v"(pb), [NA] "+v"(na),
-                       [DIRP] "+v"(dirp), [FLAG] "+v"(flag)
-                     : [VP] "v"(vp), [DEND] "s"(dir_end), [DIR0] "v"(0u), [V64K] "v"(0x10000u), [K64K] "s"(0x10000u),
+                     : [BASE] "+v"(base), [S] "+v"(s1), [PD] "+v"(pd), [PB] "+v"(pb), [NA] "+v"(na), [FLAG] "+v"(flag)
+                     : [VP] "v"(vp), [DIRP] "v"(dirp), [DIR0] "v"(0u), [K64K] "s"(0x10000u),
                        [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
                      : "vcc", "memory", "s52", "s53", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147",
                        "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159",
@@ -545,10 +541,12 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
         if (busy) {
           j += kEncCadence;
           n = na - ds_off;
+          dirp += dir_step;                          // kEncCadence entries further, modulo the table count
+          dirp -= dirp >= dir_end ? dir_end : 0u;
         }
         continue;
       }
-      base = base0; s1 = s10; pd = pd0; pb = pb0; dirp = dirp0;     // an exception somewhere in the wave
+      base = base0; s1 = s10; pd = pd0; pb = pb0;                   // an exception somewhere in the wave
     }
 #pragma nounroll
     for (unsigned int k = 0; k < kEncCadence; ++k) step();
@@ -594,12 +592,7 @@ struct DecWaveLds {
 // caller).  Temporaries are the fixed registers v100-v132 (register pairs and the 4-register row
 // buffers need known numbers): v[100:103] / v[104:107] rows (cdf - 2, info, bits, cum), v[120:121] = -1,
 // v[122:123] = (lo, 0), v[124:125] = (hi, 0).
-#define TFC_LDEC_ADVANCE                                                                  \
-  "v_add_u32 v108, 16, %[DIRP]\n\t"                                                       \
-  "v_cmp_eq_u32 vcc, %[DEND], v108\n\t"                                                   \
-  "v_cndmask_b32 %[DIRP], v108, %[DIR0], vcc\n\t"
 #define TFC_LDEC_STEP(ROW0, ROW1, ROW2, ROW3, PREFETCH, OUTOFF)                            \
-  TFC_LDEC_ADVANCE                                                                        \
   PREFETCH                                                                                \
   "ds_read_u16 v109, %[CP]\n\t"                                                           \
   "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
@@ -617,12 +610,10 @@ struct DecWaveLds {
   "ds_read_b64 v[114:115], v112\n\t"                                                      \
   "ds_read_u16 v116, v113\n\t"                                                            \
   "v_not_b32 v110, v110\n\t"                                                              \
-  "v_lshrrev_b64 v[118:119], v110, v[120:121]\n\t"                                        \
   "s_waitcnt lgkmcnt(0)\n\t"                                                              \
-  "v_and_b32 v114, v114, v118\n\t"                                                        \
-  "v_and_b32 v115, v115, v119\n\t"                                                        \
-  "v_bcnt_u32_b32 v116, v114, v116\n\t"                                                   \
-  "v_bcnt_u32_b32 v116, v115, v116\n\t"                                                   \
+  "v_lshlrev_b64 v[118:119], v110, v[114:115]\n\t"                                        \
+  "v_bcnt_u32_b32 v116, v118, v116\n\t"                                                   \
+  "v_bcnt_u32_b32 v116, v119, v116\n\t"                                                   \
   "v_lshl_add_u32 v112, v116, 1, v" #ROW0 "\n\t"                                          \
   "ds_read_u16 v122, v112\n\t"                                                            \
   "ds_read_u16 v124, v112 offset:2\n\t"                                                   \
@@ -638,8 +629,7 @@ struct DecWaveLds {
   "v_alignbit_b32 v126, v127, v126, 16\n\t"                                               \
   "v_alignbit_b32 v128, v129, v128, 16\n\t"                                               \
   "v_add_u32 v128, -1, v128\n\t"                                                          \
-  "v_cmp_eq_u32 vcc, 0, v124\n\t"                                                         \
-  "v_cndmask_b32 v128, v128, %[S], vcc\n\t"                                               \
+  "v_min_u32 v128, v128, %[S]\n\t"                                                        \
   "v_sub_u32 v130, %[D], v126\n\t"                                                        \
   "v_sub_u32 v131, v128, v126\n\t"                                                        \
   "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
@@ -651,18 +641,18 @@ struct DecWaveLds {
   "v_cndmask_b32 %[S], v131, v132, vcc\n\t"                                               \
   "v_cndmask_b32 v132, 0, 2, vcc\n\t"                                                     \
   "v_add_u32 %[CP], %[CP], v132\n\t"
-#define TFC_LDEC_READ_A "ds_read_b128 v[100:103], %[DIRP]\n\t"
-#define TFC_LDEC_READ_B "ds_read_b128 v[104:107], %[DIRP]\n\t"
+#define TFC_LDEC_READ_A(OFF) "ds_read_b128 v[100:103], %[DIRP] offset:" #OFF "\n\t"
+#define TFC_LDEC_READ_B(OFF) "ds_read_b128 v[104:107], %[DIRP] offset:" #OFF "\n\t"
 #define TFC_LDEC_BLOCK                                                                    \
-  "v_mov_b32 v120, -1\n\tv_mov_b32 v121, -1\n\tv_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t" \
-  TFC_LDEC_READ_A "s_waitcnt lgkmcnt(0)\n\t"                                              \
-  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B, 0)                                   \
-  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A, 4)                                   \
-  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B, 8)                                   \
-  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A, 12)                                  \
-  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B, 16)                                  \
-  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A, 20)                                  \
-  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B, 24)                                  \
+  "v_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t"                                           \
+  TFC_LDEC_READ_A(0) "s_waitcnt lgkmcnt(0)\n\t"                                           \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(16), 0)                               \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(32), 4)                               \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(48), 8)                               \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(64), 12)                              \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(80), 16)                              \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(96), 20)                              \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(112), 24)                             \
   TFC_LDEC_STEP(104, 105, 106, 107, "", 28)                                               \
   "s_waitcnt lgkmcnt(0)\n\t"
 
@@ -718,6 +708,7 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
   const float scale = static_cast<float>(1u << la.precision);     // quotient scale: 2^precision
   const unsigned int cp_max = (1u << la.precision) - 1u;
   const unsigned int dir_end = 16u * static_cast<unsigned int>(la.ntab);
+  const unsigned int dir_step = (16u * kDecCadence) % dir_end;
   unsigned int j = 0u;
   unsigned int dirp = 0u;            // channel mode: LDS offset of the directory entry of symbol j
   unsigned int mode = 0u;            // 0 symbol, 1 unary prefix, 2 payload bits, 3 sign
@@ -864,13 +855,13 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
       flush();
     }
     if (kFastBlock && lds0 == 0u && !__any(j < elems && (j + kDecCadence > elems || mode != 0u))) {
-      const unsigned int D0 = D, s10 = s1, cp0 = cp, dirp0 = dirp;
+      const unsigned int D0 = D, s10 = s1, cp0 = cp;
       unsigned int flag = 0u;
       if (j < elems) {
         asm volatile(TFC_LDEC_BLOCK
-                     : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [DIRP] "+v"(dirp), [FLAG] "+v"(flag)
-                     : [OQ] "v"(oq_off), [SCALE] "s"(scale), [QMAX] "s"(cp_max), [DEND] "s"(dir_end),
-                       [DIR0] "v"(0u), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
+                     : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [FLAG] "+v"(flag)
+                     : [DIRP] "v"(dirp), [OQ] "v"(oq_off), [SCALE] "s"(scale), [QMAX] "s"(cp_max),
+                       [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
                      : "vcc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
                        "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",
                        "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132");
@@ -879,10 +870,12 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         if (j < elems) {
           j += kDecCadence;
           ko = kDecCadence * kEs;
+          dirp += dir_step;                          // kDecCadence entries further, modulo the table count
+          dirp -= dirp >= dir_end ? dir_end : 0u;
         }
         continue;
       }
-      D = D0; s1 = s10; cp = cp0; dirp = dirp0;      // an exception somewhere in the wave: the generic steps
+      D = D0; s1 = s10; cp = cp0;                    // an exception somewhere in the wave: the generic steps
     }
 #pragma nounroll
     for (unsigned int k = 0; k < kDecCadence; ++k) step();
