@@ -83,7 +83,8 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             return indexes
         strides = np.cumprod((self.index_ranges + (1,))[::-1])[::-1][1:]
         strides = torch.tensor(strides.copy(), dtype=torch.int32, device=indexes.device)
-        return torch.tensordot(indexes.movedim(self.channel_axis, -1), strides, dims=([-1], [0]))
+        # elementwise: integer matmul / tensordot has no HIP kernel ("addmm_cuda" not implemented for 'Int')
+        return (indexes.movedim(self.channel_axis, -1) * strides).sum(-1, dtype=torch.int32)
 
     def forward(self, bottleneck, indexes, training=True):
         bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
@@ -98,7 +99,8 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             perturbed = self.quantize(bottleneck)
             log_probs = self._log_prob(prior, perturbed)
         axes = tuple(range(-self.coding_rank, 0))
-        bits = log_probs.sum(dim=axes) / (-float(np.log(2.0)))
+        # coding_rank 0: nothing to reduce (torch's sum over an empty dim tuple reduces EVERYTHING)
+        bits = (log_probs.sum(dim=axes) if axes else log_probs) / (-float(np.log(2.0)))
         return perturbed, bits
 
     def quantize(self, bottleneck):

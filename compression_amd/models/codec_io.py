@@ -12,7 +12,7 @@ import torch
 
 from ..util import PackedTensors
 
-__all__ = ["read_png", "write_png", "compress_file", "decompress_file", "main"]
+__all__ = ["read_png", "write_png", "compress_file", "decompress_file", "load_checkpoint", "main"]
 
 
 def read_png(filename) -> torch.Tensor:
@@ -70,6 +70,30 @@ def decompress_file(model, input_file, output_file=None):
     return x_hat
 
 
+def load_checkpoint(model, state_dict):
+    """Loads a state_dict into `model` and leaves it ready to compress / decompress.
+
+    A checkpoint written AFTER `init_compression()` carries the range-coding tables (`_cdf`,
+    `_cdf_offset`, the quantization offset): like the reference, whose saved model holds them, they are
+    LOADED, never regenerated on the receiving side (continuous_base.py:175-184) — regenerated tables are
+    only bit-identical when the prior evaluates identically on both machines and software stacks.  The
+    entropy models are created first (so the buffers exist), their buffers take the stored shapes, then
+    everything is loaded strictly.  A checkpoint without tables gets them built from its prior."""
+    has_tables = any(k.rsplit(".", 1)[-1] in ("_cdf", "_cdf_offset") for k in state_dict)
+    if not has_tables:
+        model.load_state_dict(state_dict)
+        return model.init_compression()
+    model.init_compression()
+    own = dict(model.named_buffers())
+    for key, value in state_dict.items():
+        if key in own and own[key].shape != value.shape:
+            mod_name, _, buf_name = key.rpartition(".")
+            module = model.get_submodule(mod_name) if mod_name else model
+            module.register_buffer(buf_name, torch.zeros_like(value, device=own[key].device))
+    model.load_state_dict(state_dict)
+    return model
+
+
 def main(model_cls, argv=None):
     """`python -m compression_amd.models.bls2017 compress in.png out.tfci` / `decompress in.tfci out.png`.
     --model_path takes a torch state_dict (the reference loads a saved Keras model); without
@@ -86,10 +110,11 @@ def main(model_cls, argv=None):
         sp.add_argument("output_file", nargs="?")
     args = ap.parse_args(argv)
     torch.manual_seed(args.seed)
-    model = model_cls(num_filters=args.num_filters)
+    model = model_cls(num_filters=args.num_filters).cuda()
     if args.model_path:
-        model.load_state_dict(torch.load(args.model_path, map_location="cpu"))
-    model = model.cuda().init_compression()
+        model = load_checkpoint(model, torch.load(args.model_path, map_location="cpu"))
+    else:
+        model = model.init_compression()
     if args.command == "compress":
         compress_file(model, args.input_file, args.output_file or args.input_file + ".tfci", args.verbose)
     else:

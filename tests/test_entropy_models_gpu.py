@@ -161,6 +161,29 @@ def test_location_scale_indexed_roundtrip_and_parity(port):
     assert torch.allclose(em.decompress(s2, idx, loc=loc.cuda()).cpu(), torch.round(y - loc) + loc)
 
 
+def test_indexed_model_with_two_index_dimensions():
+    """index_ranges=(a, b), channel_axis=-1 (continuous_indexed.py:272-289): the flattened index is
+    computed on the device elementwise (integer tensordot has no HIP kernel), and coding_rank=0 keeps
+    per-element bits."""
+    torch.manual_seed(8)
+    em = tfc.ContinuousIndexedEntropyModel(
+        tfc.NoisyNormal, index_ranges=(4, 6), channel_axis=-1, coding_rank=1, compression=True,
+        parameter_fns=dict(loc=lambda i: i[..., 0].float() - 1.5, scale=lambda i: torch.exp(0.4 * i[..., 1].float())))
+    idx = torch.stack([torch.randint(0, 4, (5, 300)), torch.randint(0, 6, (5, 300))], dim=-1).float()
+    loc = idx[..., 0] - 1.5
+    y = loc + torch.randn(5, 300) * torch.exp(0.4 * idx[..., 1])
+    s = em.compress(y, idx)
+    assert s.shape == (5,)
+    assert torch.equal(em.decompress(s, idx).cpu(), torch.round(y))
+    flat = em._flatten_indexes(em._normalize_indexes(idx).cuda()).cpu()
+    assert torch.equal(flat, (idx[..., 0] * 6 + idx[..., 1]).to(torch.int32))
+    em0 = tfc.ContinuousIndexedEntropyModel(
+        tfc.NoisyNormal, index_ranges=(4, 6), channel_axis=-1, coding_rank=0,
+        parameter_fns=dict(loc=lambda i: i[..., 0].float() - 1.5, scale=lambda i: torch.exp(0.4 * i[..., 1].float())))
+    _, bits = em0(y, idx, training=False)
+    assert bits.shape == y.shape
+
+
 def test_indexed_bits_close_to_rate():
     torch.manual_seed(7)
     em = tfc.LocationScaleIndexedEntropyModel(tfc.NoisyNormal, num_scales=64, scale_fn=_scale_fn,

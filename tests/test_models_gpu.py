@@ -34,6 +34,29 @@ def test_bls2017_single_image_plumbing(port):
     assert torch.equal(x_hat, ref)
 
 
+def test_stored_tables_are_loaded_not_regenerated():
+    """A checkpoint saved after init_compression() carries the tables; the receiving side loads them
+    (continuous_base.py:175-184) — here the prior is changed AFTER the tables were fixed, so regenerated
+    tables would differ and decode garbage."""
+    from compression_amd.models import codec_io
+    torch.manual_seed(5)
+    sender = tfc.models.BLS2017Model(num_filters=64).cuda().init_compression()
+    with torch.no_grad():
+        for p in sender.prior.parameters():      # the prior drifts after the tables were built
+            p.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.cpu() for k, v in sender.state_dict().items()}
+    assert any(k.endswith("_cdf") for k in sd)
+    receiver = codec_io.load_checkpoint(tfc.models.BLS2017Model(num_filters=64).cuda(), sd)
+    assert torch.equal(receiver.entropy_model.cdf.cpu(), sender.entropy_model.cdf.cpu())
+    x = torch.from_numpy(synthetic.lowpass_images(2, 96, 64)).cuda()
+    strings, x_shape, y_shape = sender.compress(x)
+    assert torch.equal(receiver.decompress(strings, x_shape, y_shape), sender.decompress(strings, x_shape, y_shape))
+    # a checkpoint without tables builds them from its prior
+    plain = {k: v for k, v in sd.items() if not k.startswith("entropy_model.")}
+    fresh = codec_io.load_checkpoint(tfc.models.BLS2017Model(num_filters=64).cuda(), plain)
+    assert fresh.entropy_model.cdf.numel() > 0
+
+
 def test_bls2017_batch_and_odd_sizes():
     torch.manual_seed(1)
     model = tfc.models.BLS2017Model(num_filters=64).cuda().init_compression()

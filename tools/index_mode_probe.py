@@ -55,7 +55,7 @@ def worker(stream, n):
 
 
 for D in (1, 8, 12):
-    tfc.set_throughput_mode(D > 1)
+    tfc.set_default_mode("throughput" if D > 1 else "latency")
     K = 4 * D
     streams = [torch.cuda.Stream() for _ in range(D)]
     with ThreadPoolExecutor(D) as pool:
@@ -67,4 +67,4 @@ for D in (1, 8, 12):
         dt = time.perf_counter() - t0
     print(f"index mode, in flight {D:2d}: {dt * 1e3 / K:6.3f} ms/step = {S * E / 1e9 / (dt / K):6.2f} Gsymbols/s "
           f"({S * bench.PIXELS_PER_STREAM / 1e6 / (dt / K):8.0f} Mpixels/s at 0.75 symbols per pixel)")
-tfc.set_throughput_mode(False)
+tfc.set_default_mode("auto")
