@@ -84,13 +84,14 @@ def step_group(lookup_t, values, mode):
     """len(values) independent steps on the current HIP stream, nothing read back.  Every step has its own
     handles and strings; the coding calls of the group go to the GPU as one launch
     (entropy_encode_channel_many / entropy_decode_channel_many): the hardware overlaps only ~8 kernels
-    however many streams carry them, and one 512-stream call is 8 waves."""
-    hs = [tfc.create_range_encoder([STREAMS], lookup_t, mode=mode, deferred_errors=True) for _ in values]
+    however many streams carry them, and one 512-stream call is 8 waves.  Creation and finalisation of the
+    handles are batched the same way (one allocation and one small launch per group instead of per handle)."""
+    hs = tfc.create_range_encoders(len(values), [STREAMS], lookup_t, mode=mode, deferred_errors=True)
     hs = tfc.entropy_encode_channel_many(hs, values)
-    hs = [tfc.entropy_encode_finalize_device(h) for h in hs]
-    ds = [tfc.create_range_decoder(h, lookup_t, mode=mode) for h in hs]
+    hs = tfc.entropy_encode_finalize_device_many(hs)
+    ds = tfc.create_range_decoders(hs, lookup_t, mode=mode)
     ds, decoded = tfc.entropy_decode_channel_many(ds, [ELEMS], torch.int32)
-    oks = [tfc.entropy_decode_finalize_device(d) for d in ds]
+    oks = tfc.entropy_decode_finalize_device_many(ds)
     return list(zip(hs, ds, decoded, oks))
 
 
@@ -320,10 +321,30 @@ def cpu_baseline(lookup, value, gpu_blob_sha256, gpu_offsets_sha256):
     }
 
 
+def model_conv_flops(workload, batch, hw):
+    """2 M K N of every SignalConv2D of compress + decompress (synthesis counted on
+    its output grid, without the multiplies on inserted zeros)."""
+    h, w = hw
+    c = 192
+    def conv(pix, k, cin, cout):
+        return 2.0 * pix * k * k * cin * cout
+    if workload == "bls2017":
+        per = (conv(h * w / 16, 9, 3, c) + conv(h * w / 64, 5, c, c) + conv(h * w / 256, 5, c, c))
+        return batch * 2 * per                       # analysis + synthesis (mirror)
+    per = (conv(h * w / 4, 5, 3, c) + conv(h * w / 16, 5, c, c) + conv(h * w / 64, 5, c, c) + conv(h * w / 256, 5, c, c))
+    hyper = conv(h * w / 256, 3, c, c) + conv(h * w / 1024, 5, c, c) + conv(h * w / 4096, 5, c, c)
+    # compress: analysis + hyper analysis + hyper synthesis (indexes); decompress: hyper synthesis + synthesis
+    return batch * (2 * per + 3 * hyper)
+
+
 def model_workload(args, world, rank, device, distributed):
-    """Full compress + decompress of a target model on synthetic images (BASELINE configs
-    1/4/5); informational — the headline line is the c2 workload."""
+    """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5).
+    Multi-GPU (config 5): the batch is sharded, rank 0's weights and range-coding tables are broadcast
+    once (tables are shared, never rebuilt per rank: continuous_base.py:175-184), and every step ends with
+    the variable-length gather of the coded strings."""
     import torch.distributed as dist
+    from compression_amd import parallel
+    from compression_amd.ops import gen_ops
     dtype = torch.bfloat16 if args.model_dtype == "bf16" else torch.float32
     torch.manual_seed(0)
     if args.workload == "bls2017":
@@ -333,12 +354,23 @@ def model_workload(args, world, rank, device, distributed):
         model = tfc.models.BMSHJ2018Model(num_filters=192, compute_dtype=dtype)
         batch, hw = args.batch or 128, (512, 768)
     model = model.to(device).init_compression()
+    if distributed:
+        parallel.broadcast_tables(model)
     base = torch.from_numpy(synthetic.lowpass_images(8, hw[0], hw[1], seed=2 + rank)).to(device)
     x = base.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
 
     def step():
         out = model.compress(x)
-        return out, model.decompress(*out)
+        gathered = None
+        if distributed:
+            # the coded strings of the whole batch on every rank: lengths, then padded bytes (two all-gathers)
+            gathered = []
+            for arr in out:
+                if isinstance(arr, np.ndarray) and arr.dtype == object:
+                    blob, off, _ = gen_ops.blob_from_strings(arr)
+                    gathered.append(parallel.gather_encoded(torch.from_numpy(blob).to(device),
+                                                            torch.from_numpy(off).to(device)))
+        return out, model.decompress(*out), gathered
 
     for _ in range(args.warmup):
         step()
@@ -346,23 +378,35 @@ def model_workload(args, world, rank, device, distributed):
     if distributed:
         dist.barrier()
         torch.cuda.synchronize()
+    _lib.lib().tfc_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out, x_hat = step()
+        out, x_hat, gathered = step()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    kern = {name: profile_query(name) for name in ("enc_kernel", "dec_kernel", "conv2d", "gdn_forward")}
+    _lib.lib().tfc_profile_enable(0)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert x_hat.shape == x.shape
-    nbytes = sum(len(bytes(s)) for arr in out if isinstance(arr, np.ndarray) for s in arr.reshape(-1))
+    strings = [arr for arr in out if isinstance(arr, np.ndarray) and arr.dtype == object]
+    nbytes = sum(len(bytes(s)) for arr in strings for s in arr.reshape(-1))
+    if gathered:
+        assert int(gathered[0][1][-1]) >= sum(len(bytes(s)) for s in strings[0].reshape(-1))
     if rank == 0:
         pixels = world * batch * hw[0] * hw[1]
-        print(json.dumps({
+        ms = {k: (v[0] / max(v[1], 1), v[1] // max(args.steps, 1)) for k, v in kern.items()}
+        conv_ms_step = kern["conv2d"][0] / max(args.steps, 1)
+        flops = model_conv_flops(args.workload, batch, hw)
+        conv_tflops = flops / 1e12 / (conv_ms_step / 1e3) if conv_ms_step > 0 else 0.0
+        coder_ms_step = (kern["enc_kernel"][0] + kern["dec_kernel"][0]) / max(args.steps, 1)
+        symbols = sum(int(np.prod(a.shape)) for a in strings)      # streams; symbols per stream from the model
+        line = {
             "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
             "value": round(pixels / 1e6 / (elapsed / args.steps), 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -370,11 +414,66 @@ def model_workload(args, world, rank, device, distributed):
             "scaling": "weak", "vs_baseline": None, "dtype": args.model_dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload} compress+decompress, {batch} images of "
                                    f"{hw[1]}x{hw[0]} per GPU, 192 filters, random-init weights",
-                       "parallelism": f"batch-sharded x{world}"},
+                       "parallelism": f"batch-sharded x{world}",
+                       "collectives": "broadcast of weights + tables at setup; per step all-gather of string "
+                                      "lengths and padded bytes (RCCL)" if distributed else "none"},
             "bits_per_pixel": round(8.0 * nbytes / (batch * hw[0] * hw[1]), 4),
-        }))
+            "kernels_ms_per_step": {"conv2d": round(conv_ms_step, 3), "coder": round(coder_ms_step, 3),
+                                    "gdn_forward": round(kern["gdn_forward"][0] / max(args.steps, 1), 3)},
+            "roofline": {"bound": "mfma", "kernel": "conv2d (all SignalConv2D launches of a step)",
+                         "achieved": round(conv_tflops, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(conv_tflops / 2500.0, 4), "traffic": None,
+                         "algorithmic_flops": int(flops),
+                         "note": "dominant GPU kernel family of the step; the step itself is bounded by the host "
+                                 "glue between launches and by the coder's serial chains (kernels_ms_per_step)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = model_cpu_baseline(model, x, out, hw, batch)
+        print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()
+
+
+def model_cpu_baseline(model, x, out, hw, batch):
+    """The reference's coder (oracle/_ref, or its restatement) on the host cores, on the SAME symbols
+    the model coded: the main latent stream of a bounded sample of the batch.  The transforms have no
+    CPU leg here (the reference's are TensorFlow/Eigen, not installable): the figure is Mpixels/s of the
+    entropy-coding part only.  This and cpu_baseline() are the only places bench.py touches oracle/."""
+    from oracle import oracle
+    lib = oracle.best()
+    _, cores, _ = usable_cores()
+    sample = min(batch, 16)
+    with torch.no_grad():
+        y = model.analysis_transform(x[:sample].to(model.compute_dtype))
+        if hasattr(model, "side_entropy_model"):
+            z = model.hyper_analysis_transform(torch.abs(y))
+            z_hat = model.side_entropy_model.quantize(z)
+            idx = model.hyper_synthesis_transform(z_hat)[:, :y.shape[1], :y.shape[2], :]
+            em = model.entropy_model
+            flat = em._flatten_indexes(em._normalize_indexes(idx)).reshape(sample, -1).cpu().numpy()
+            sym = (torch.round(y.float()).to(torch.int32).reshape(sample, -1).cpu().numpy()
+                   - em.cdf_offset.numpy()[flat])
+            lookup = em.cdf.numpy()
+        else:
+            em = model.entropy_model
+            off = em.quantization_offset
+            yq = torch.round(y.float() - off.to(y.device).float() if off is not None else y.float()).to(torch.int32)
+            sym = yq.reshape(sample, -1).cpu().numpy() - np.tile(em.cdf_offset.numpy(), yq[0].numel() // em.cdf_offset.numel())
+            flat = None
+            lookup = em.cdf.numpy()
+    t0 = time.perf_counter()
+    strings, _, _ = lib.encode(lookup, sym, index=flat, threads=cores)
+    t1 = time.perf_counter()
+    dec, ok = lib.decode(lookup, strings, sym.shape[1], index=flat, threads=cores)
+    t2 = time.perf_counter()
+    assert ok.all() and (dec == sym).all()
+    mine = out[0].reshape(-1)[:sample]
+    return {"value": round(sample * hw[0] * hw[1] / 1e6 / (t2 - t0), 2), "unit": "Mpixels/s", "cores": cores,
+            "kind": lib.kind,
+            "sample": f"main latent stream of {sample} of the {batch} images (the symbols the model coded), "
+                      "range encode + decode only, one call each",
+            "encode_ms": round(1e3 * (t1 - t0), 2), "decode_ms": round(1e3 * (t2 - t1), 2),
+            "bytes_identical_to_gpu": bool([bytes(s) for s in mine] == strings)}
 
 
 def main():

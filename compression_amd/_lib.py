@@ -27,6 +27,7 @@ SIGNATURES = {
     "tfc_tables_count": (_i64, [_vp]),
     "tfc_tables_destroy": (None, [_vp]),
     "tfc_encoder_create": (_int, [_vp, _i64, _vp, C.POINTER(_vp)]),
+    "tfc_encoder_create_many": (_int, [_vp, _i64, _int, _vp, _vp]),
     "tfc_encoder_set_mode": (_int, [_vp, _int]),
     "tfc_encoder_set_deferred_errors": (_int, [_vp, _int]),
     "tfc_encoder_encode": (_int, [_vp, _vp, _vp, _i64, _vp]),
@@ -35,17 +36,20 @@ SIGNATURES = {
     "tfc_encoder_encode_quantized_indexed": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _vp]),
     "tfc_encoder_finalize": (_int, [_vp, _vp, C.POINTER(_i64)]),
     "tfc_encoder_finalize_device": (_int, [_vp, _vp]),
+    "tfc_encoder_finalize_device_many": (_int, [_int, _vp, _vp]),
     "tfc_encoder_status": (_int, [_vp, _vp, C.POINTER(_i64)]),
     "tfc_encoder_result": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "tfc_encoder_read": (_int, [_vp, _vp, _vp, _int, _vp]),
     "tfc_encoder_destroy": (None, [_vp]),
     "tfc_decoder_create": (_int, [_vp, _vp, _vp, _i64, _int, _vp, C.POINTER(_vp)]),
+    "tfc_decoder_create_many": (_int, [_vp, _int, _vp, _vp, _vp]),
     "tfc_decoder_set_mode": (_int, [_vp, _int]),
     "tfc_decoder_decode": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "tfc_decoder_decode_many": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
     "tfc_decoder_decode_dequantized": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
     "tfc_decoder_finalize": (_int, [_vp, _vp, _vp]),
     "tfc_decoder_finalize_device": (_int, [_vp, _vp, _vp]),
+    "tfc_decoder_finalize_device_many": (_int, [_int, _vp, _vp, _vp]),
     "tfc_decoder_status": (_int, [_vp, _vp]),
     "tfc_decoder_destroy": (None, [_vp]),
     "tfc_range_encode": (_int, [_vp, _vp, _int, _vp, _vp, _int, _int, _int, _vp,

@@ -813,8 +813,8 @@ struct Tail {
   unsigned int nhead, nend, run;
 };
 
-__global__ void enc_tail_kernel(const uint4* state, int64_t streams, const ChunkList chunks,
-                                int nchunks, int fast_state, Tail* tail, long long* length) {
+__device__ inline void enc_tail_one(const uint4* state, int64_t streams, const ChunkList& chunks,
+                                    int nchunks, int fast_state, Tail* tail, long long* length) {
   const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (s >= streams) return;
   const uint4 st = state[s];
@@ -857,8 +857,34 @@ __global__ void enc_tail_kernel(const uint4* state, int64_t streams, const Chunk
   for (int c = 0; c < nchunks; ++c) len += chunks[c].len[s];
   length[s] = len;
 }
+__global__ void enc_tail_kernel(const uint4* state, int64_t streams, const ChunkList chunks,
+                                int nchunks, int fast_state, Tail* tail, long long* length) {
+  enc_tail_one(state, streams, chunks, nchunks, fast_state, tail, length);
+}
 
-__global__ void scan_lengths_kernel(const long long* length, int64_t streams, long long* off) {
+// Finalize of n single-call handles of the lane family in three launches (blockIdx.y = handle): their
+// temporaries, offsets and packed blobs live at a fixed stride in ONE allocation.
+constexpr int kMaxFinalizeJobs = 64;
+struct FinalizeJobs {
+  int64_t streams;
+  int n;
+  uint8_t* base;             // job k: base + k * job_bytes = [Tail x streams][length x streams][offsets x (streams + 1)][blob]
+  long long job_bytes, length_off, offsets_off, blob_off;
+  struct { const uint4* state; ChunkRef chunk; } job[kMaxFinalizeJobs];
+};
+__device__ inline Tail* fin_tail(const FinalizeJobs& f, int k) { return reinterpret_cast<Tail*>(f.base + k * f.job_bytes); }
+__device__ inline long long* fin_length(const FinalizeJobs& f, int k) { return reinterpret_cast<long long*>(f.base + k * f.job_bytes + f.length_off); }
+__device__ inline long long* fin_offsets(const FinalizeJobs& f, int k) { return reinterpret_cast<long long*>(f.base + k * f.job_bytes + f.offsets_off); }
+__global__ void enc_tail_many_kernel(const FinalizeJobs f) {
+  const int k = blockIdx.y;
+  ChunkList one;
+  one.inline_refs[0] = f.job[k].chunk;
+  one.more = nullptr;
+  one.n = 1;
+  enc_tail_one(f.job[k].state, f.streams, one, 1, 0, fin_tail(f, k), fin_length(f, k));
+}
+
+__device__ inline void scan_lengths_one(const long long* length, int64_t streams, long long* off) {
   __shared__ long long carry;
   __shared__ long long tmp[1024];
   if (threadIdx.x == 0) carry = 0;
@@ -880,6 +906,12 @@ __global__ void scan_lengths_kernel(const long long* length, int64_t streams, lo
     __syncthreads();
   }
   if (threadIdx.x == 0) off[streams] = carry;
+}
+__global__ void scan_lengths_kernel(const long long* length, int64_t streams, long long* off) {
+  scan_lengths_one(length, streams, off);
+}
+__global__ void scan_lengths_many_kernel(const FinalizeJobs f) {
+  scan_lengths_one(fin_length(f, blockIdx.x), f.streams, fin_offsets(f, blockIdx.x));
 }
 
 // Wave-cooperative byte copy with 4-byte stores: dst is brought to dword alignment, the
@@ -903,9 +935,8 @@ __device__ inline void wave_copy(uint8_t* dst, const uint8_t* src, unsigned int 
 }
 
 // One wave per stream: copy the stream's chunk pieces then its tail.
-__global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const ChunkList chunks,
-                                                         int nchunks, const Tail* tail,
-                                                         const long long* off, uint8_t* blob) {
+__device__ inline void enc_pack_one(int64_t streams, const ChunkList& chunks, int nchunks, const Tail* tail,
+                                    const long long* off, uint8_t* blob) {
   const int lane = threadIdx.x & 63;
   const int64_t s = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (s >= streams) return;
@@ -922,6 +953,19 @@ __global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const
   for (unsigned long long i = lane; i < 2ull * t.run; i += 64) dst[done + i] = 0xFF;
   done += 2ll * t.run;
   if (lane < static_cast<int>(t.nend)) dst[done + lane] = t.end[lane];
+}
+__global__ void __launch_bounds__(kBlock) enc_pack_kernel(int64_t streams, const ChunkList chunks,
+                                                         int nchunks, const Tail* tail,
+                                                         const long long* off, uint8_t* blob) {
+  enc_pack_one(streams, chunks, nchunks, tail, off, blob);
+}
+__global__ void __launch_bounds__(kBlock) enc_pack_many_kernel(const FinalizeJobs f) {
+  const int k = blockIdx.y;
+  ChunkList one;
+  one.inline_refs[0] = f.job[k].chunk;
+  one.more = nullptr;
+  one.n = 1;
+  enc_pack_one(f.streams, one, 1, fin_tail(f, k), fin_offsets(f, k), f.base + k * f.job_bytes + f.blob_off);
 }
 
 // ---- decoder --------------------------------------------------------------
@@ -1133,8 +1177,8 @@ namespace tfc {
 
 // Reads the first four bytes of every stream (RangeDecoder ctor,
 // range_coder.h:79-83).
-__global__ void dec_open_kernel(const uint8_t* blob, const long long* off, int64_t streams,
-                                uint4* state, unsigned long long* status) {
+__device__ inline void dec_open_one(const uint8_t* blob, const long long* off, int64_t streams,
+                                    uint4* state, unsigned long long* status) {
   const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (s == 0) *status = ~0ull;       // no index error met yet
   if (s >= streams) return;
@@ -1144,10 +1188,30 @@ __global__ void dec_open_kernel(const uint8_t* blob, const long long* off, int64
   for (int i = 0; i < 4; ++i) w = (w << 8) | (i < len ? src[i] : 0u);
   state[s] = make_uint4(0u, 0xFFFFFFFFu, w, 2u);
 }
+__global__ void dec_open_kernel(const uint8_t* blob, const long long* off, int64_t streams,
+                                uint4* state, unsigned long long* status) {
+  dec_open_one(blob, off, streams, state, status);
+}
+// n decoders at once (blockIdx.y = handle): their control blocks ([status 16 B][state]) sit at a fixed
+// stride in one allocation
+constexpr int kMaxDecoderJobs = 64;
+struct DecoderJobs {
+  int64_t streams;
+  int n;
+  uint8_t* ctl;
+  long long ctl_bytes;
+  struct { const uint8_t* blob; const long long* off; uint8_t* ok; } job[kMaxDecoderJobs];
+};
+__global__ void dec_open_many_kernel(const DecoderJobs f) {
+  const int k = blockIdx.y;
+  uint8_t* ctl = f.ctl + k * f.ctl_bytes;
+  dec_open_one(f.job[k].blob, f.job[k].off, f.streams, reinterpret_cast<uint4*>(ctl + 16),
+               reinterpret_cast<unsigned long long*>(ctl));
+}
 
 // RangeDecoder::Finalize (range_coder.h:144-169).
-__global__ void dec_close_kernel(const uint4* state, const long long* off, int64_t streams,
-                                 uint8_t* ok) {
+__device__ inline void dec_close_one(const uint4* state, const long long* off, int64_t streams,
+                                     uint8_t* ok) {
   const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (s >= streams) return;
   const uint4 st = state[s];
@@ -1167,11 +1231,19 @@ __global__ void dec_close_kernel(const uint4* state, const long long* off, int64
   }
   ok[s] = good ? 1 : 0;
 }
+__global__ void dec_close_kernel(const uint4* state, const long long* off, int64_t streams,
+                                 uint8_t* ok) {
+  dec_close_one(state, off, streams, ok);
+}
+__global__ void dec_close_many_kernel(const DecoderJobs f) {
+  const int k = blockIdx.y;
+  dec_close_one(reinterpret_cast<const uint4*>(f.ctl + k * f.ctl_bytes + 16), f.job[k].off, f.streams, f.job[k].ok);
+}
 
 // Initial coder state of every stream, plus the handle's status words (first error position = none,
 // value, index, filled flag) and overflow flag.
-__global__ void fill_state_kernel(uint4* state, int64_t n, uint4 v, unsigned long long* status,
-                                  unsigned int* oflag) {
+__device__ inline void fill_state_one(uint4* state, int64_t n, uint4 v, unsigned long long* status,
+                                      unsigned int* oflag) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i < n) state[i] = v;
   if (i == 0) {
@@ -1179,6 +1251,16 @@ __global__ void fill_state_kernel(uint4* state, int64_t n, uint4 v, unsigned lon
     status[1] = status[2] = status[3] = 0ull;
     *oflag = 0u;
   }
+}
+__global__ void fill_state_kernel(uint4* state, int64_t n, uint4 v, unsigned long long* status,
+                                  unsigned int* oflag) {
+  fill_state_one(state, n, v, status, oflag);
+}
+// n encoder control blocks ([status 32 B][overflow flag .. 64 B][state]) at a fixed stride (blockIdx.y)
+__global__ void fill_state_many_kernel(uint8_t* ctl, long long ctl_bytes, int64_t n, uint4 v) {
+  uint8_t* c = ctl + blockIdx.y * ctl_bytes;
+  fill_state_one(reinterpret_cast<uint4*>(c + 64), n, v, reinterpret_cast<unsigned long long*>(c),
+                 reinterpret_cast<unsigned int*>(c + 32));
 }
 
 }  // namespace tfc
@@ -1210,7 +1292,8 @@ struct tfc_encoder {
   bool poisoned = false;        // a range error was reported: the streams are no longer meaningful
   int64_t elems_last = 0;       // geometry of the call the recorded error belongs to
   bool indexed_last = false;
-  DevBuf ctl;                   // one allocation behind the three views below
+  DevBuf ctl;                   // one allocation behind the three views below ...
+  std::shared_ptr<DevBuf> ctl_group;      // ... or a slice of the allocation shared by a create_many group
   DevView state;                // uint4 [streams]
   DevView oflag;                // unsigned int: a stream outgrew its output slab
   DevView status;               // u64[4]: first error position, its value, its index, filled flag
@@ -1218,7 +1301,9 @@ struct tfc_encoder {
   // results
   bool finalized = false;
   bool total_known = false;
-  DevBuf blob, offsets;
+  DevBuf blob_own, offsets_own;
+  std::shared_ptr<DevBuf> result_group;   // finalize_device_many: blob / offsets are slices of one allocation
+  DevView blob, offsets;
   int64_t total = 0;
 };
 
@@ -1599,6 +1684,100 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
   return 0;
 }
 
+// n handles with ONE allocation and ONE initialisation launch (the per-handle driver calls and small
+// kernels are a measurable part of a step once the coding kernels of a group share a launch).
+extern "C" int tfc_encoder_create_many(const tfc_tables* tables, int64_t streams, int n, void* stream,
+                                       tfc_encoder** out) {
+  if (!tables) return fail("tables is null");
+  if (streams < 0 || n < 0) return fail("negative count");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int k = 0; k < n; ++k) out[k] = nullptr;
+  if (n == 0) return 0;
+  const long long ctl_bytes = 64 + static_cast<long long>(sizeof(uint4)) * std::max<int64_t>(streams, 1);
+  auto group = std::make_shared<DevBuf>();
+  TFC_HIP(group->alloc(static_cast<size_t>(ctl_bytes) * n, st));
+  std::vector<std::unique_ptr<tfc_encoder>> made;
+  for (int k = 0; k < n; ++k) {
+    std::unique_ptr<tfc_encoder> e(new tfc_encoder);
+    e->tables = tables;
+    e->streams = streams;
+    const size_t fixed = sizeof(uint16_t) * ((tables->host.size() + 3) & ~size_t{3}) + sizeof(int2) * tables->rows.size();
+    const size_t ring = sizeof(unsigned int) * kRingWords;
+    if (!tables->rows.empty() && fixed + ring <= 160 * 1024) {
+      e->fast = true;
+      const size_t fit = (160 * 1024 - fixed) / ring;
+      const size_t want = static_cast<size_t>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(streams, 64))));
+      e->fast_waves = static_cast<int>(std::min(fit, want));
+      e->fast_lds = fixed + ring * e->fast_waves;
+    }
+    e->ctl_group = group;
+    uint8_t* c = group->as<uint8_t>() + k * ctl_bytes;
+    e->status.p = c;
+    e->oflag.p = c + 32;
+    e->state.p = c + 64;
+    made.push_back(std::move(e));
+  }
+  hipLaunchKernelGGL(fill_state_many_kernel,
+                     dim3(static_cast<unsigned>(std::max<int64_t>(1, ceil_div(streams, 256))), static_cast<unsigned>(n)),
+                     dim3(256), 0, st, group->as<uint8_t>(), ctl_bytes, streams, make_uint4(0u, 0xFFFFFFFFu, 0u, 0u));
+  TFC_HIP(hipGetLastError());
+  for (int k = 0; k < n; ++k) out[k] = made[k].release();
+  return 0;
+}
+
+// EntropyEncodeFinalize of n handles without host synchronisation, in three launches where every handle
+// holds exactly one piece from the lane-per-stream kernels (what tfc_encoder_encode_many leaves behind);
+// otherwise handle by handle.
+extern "C" int tfc_encoder_finalize_device_many(int n, tfc_encoder* const* es, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return 0;
+  bool batch = n <= kMaxFinalizeJobs;
+  for (int k = 0; k < n && batch; ++k) {
+    const tfc_encoder* e = es[k];
+    if (e->finalized || e->family != kLanes || e->chunks.size() != 1 || e->streams != es[0]->streams ||
+        e->streams == 0 || e->chunks[0].stride != es[0]->chunks[0].stride)
+      batch = false;
+  }
+  if (!batch) {
+    for (int k = 0; k < n; ++k)
+      if (tfc_encoder_finalize_device(es[k], stream)) return 1;
+    return 0;
+  }
+  const int64_t streams = es[0]->streams;
+  FinalizeJobs f;
+  f.streams = streams;
+  f.n = n;
+  const size_t cap = es[0]->chunks[0].data_bytes + 4 * static_cast<size_t>(streams) + 64;     // pieces + Finalize bytes + slack
+  f.length_off = static_cast<long long>((sizeof(Tail) * streams + 15) & ~size_t{15});
+  f.offsets_off = f.length_off + static_cast<long long>(sizeof(long long)) * streams;
+  f.blob_off = (f.offsets_off + static_cast<long long>(sizeof(long long)) * (streams + 1) + 15) & ~15ll;
+  f.job_bytes = (f.blob_off + static_cast<long long>(cap) + 255) & ~255ll;
+  auto group = std::make_shared<DevBuf>();
+  TFC_HIP(group->alloc(static_cast<size_t>(f.job_bytes) * n, st));
+  f.base = group->as<uint8_t>();
+  for (int k = 0; k < n; ++k) {
+    EncChunk& c = es[k]->chunks[0];
+    f.job[k].state = es[k]->state.as<uint4>();
+    f.job[k].chunk = ChunkRef{c.data.as<uint8_t>(), c.off.as<long long>(), c.len_p, c.stride};
+  }
+  hipLaunchKernelGGL(enc_tail_many_kernel, dim3(static_cast<unsigned>(ceil_div(streams, 256)), static_cast<unsigned>(n)),
+                     dim3(256), 0, st, f);
+  hipLaunchKernelGGL(scan_lengths_many_kernel, dim3(static_cast<unsigned>(n)), dim3(1024), 0, st, f);
+  hipLaunchKernelGGL(enc_pack_many_kernel,
+                     dim3(static_cast<unsigned>(ceil_div(streams, kWavesPerBlock)), static_cast<unsigned>(n)),
+                     dim3(kBlock), 0, st, f);
+  TFC_HIP(hipGetLastError());
+  for (int k = 0; k < n; ++k) {
+    tfc_encoder* e = es[k];
+    e->result_group = group;
+    e->offsets.p = f.base + k * f.job_bytes + f.offsets_off;
+    e->blob.p = f.base + k * f.job_bytes + f.blob_off;
+    e->chunks.clear();       // stream-ordered frees behind the pack launch
+    e->finalized = true;
+  }
+  return 0;
+}
+
 extern "C" int tfc_encoder_set_mode(tfc_encoder* e, int mode) {
   if (mode != TFC_MODE_AUTO && mode != TFC_MODE_LATENCY && mode != TFC_MODE_THROUGHPUT)
     return fail("unknown mode %d", mode);
@@ -1684,10 +1863,12 @@ namespace {
 int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
   if (e->finalized) return 0;
   const int64_t n = e->streams;
-  TFC_HIP(e->offsets.alloc(sizeof(long long) * (n + 1), st));
+  TFC_HIP(e->offsets_own.alloc(sizeof(long long) * (n + 1), st));
+  e->offsets.p = e->offsets_own.p;
   if (n == 0) {
     TFC_HIP(hipMemsetAsync(e->offsets.p, 0, sizeof(long long), st));
-    TFC_HIP(e->blob.alloc(0, st));
+    TFC_HIP(e->blob_own.alloc(0, st));
+    e->blob.p = e->blob_own.p;
     e->total = 0;
     e->total_known = true;
     e->finalized = true;
@@ -1735,7 +1916,8 @@ int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
     e->total = total;
     e->total_known = true;
   }
-  TFC_HIP(e->blob.alloc(capacity, st));
+  TFC_HIP(e->blob_own.alloc(capacity, st));
+  e->blob.p = e->blob_own.p;
   hipLaunchKernelGGL(enc_pack_kernel, dim3(static_cast<unsigned>(ceil_div(n, kWavesPerBlock))),
                      dim3(kBlock), 0, st, n, list, static_cast<int>(refs.size()),
                      tail.as<Tail>(), e->offsets.as<long long>(), e->blob.as<uint8_t>());
@@ -1817,6 +1999,7 @@ struct tfc_decoder {
   int mode = TFC_MODE_AUTO;
   int family = -1;
   DevBuf blob, offsets, ctl;               // blob / offsets: owned copies of host input only
+  std::shared_ptr<DevBuf> ctl_group;       // create_many: ctl is a slice of a shared allocation
   DevView state, status;                   // uint4 [streams]; u64 first index error (views of ctl)
   const uint8_t* blob_p = nullptr;         // device bytes the kernels read (owned or borrowed)
   const long long* off_p = nullptr;
@@ -1854,6 +2037,88 @@ extern "C" int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob,
                      d->status.as<unsigned long long>());
   if (!src_on_device) TFC_HIP(hipStreamSynchronize(st));  // host buffers may go away
   *out = d.release();
+  return 0;
+}
+
+// n decoders on the device-resident strings of n finalized encoders (borrowed, like tfc_decoder_create
+// with src_on_device): one allocation, one launch.
+extern "C" int tfc_decoder_create_many(const tfc_tables* tables, int n, tfc_encoder* const* from, void* stream,
+                                       tfc_decoder** out) {
+  if (!tables) return fail("tables is null");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int k = 0; k < n; ++k) out[k] = nullptr;
+  if (n <= 0) return 0;
+  for (int k = 0; k < n; ++k) {
+    if (!from[k]->finalized) return fail("encoder handle is not finalized");
+    if (from[k]->streams != from[0]->streams) return fail("tfc_decoder_create_many: handles must share the stream count");
+  }
+  const int64_t streams = from[0]->streams;
+  std::vector<std::unique_ptr<tfc_decoder>> made;
+  for (int g0 = 0; g0 < n; g0 += kMaxDecoderJobs) {
+    const int gn = std::min(kMaxDecoderJobs, n - g0);
+    DecoderJobs f;
+    f.streams = streams;
+    f.n = gn;
+    f.ctl_bytes = 16 + static_cast<long long>(sizeof(uint4)) * std::max<int64_t>(streams, 1);
+    auto group = std::make_shared<DevBuf>();
+    TFC_HIP(group->alloc(static_cast<size_t>(f.ctl_bytes) * gn, st));
+    f.ctl = group->as<uint8_t>();
+    for (int k = 0; k < gn; ++k) {
+      std::unique_ptr<tfc_decoder> d(new tfc_decoder);
+      d->tables = tables;
+      d->streams = streams;
+      d->blob_p = from[g0 + k]->blob.as<uint8_t>();
+      d->off_p = from[g0 + k]->offsets.as<long long>();
+      d->ctl_group = group;
+      d->status.p = f.ctl + k * f.ctl_bytes;
+      d->state.p = f.ctl + k * f.ctl_bytes + 16;
+      f.job[k].blob = d->blob_p;
+      f.job[k].off = d->off_p;
+      f.job[k].ok = nullptr;
+      made.push_back(std::move(d));
+    }
+    hipLaunchKernelGGL(dec_open_many_kernel,
+                       dim3(static_cast<unsigned>(std::max<int64_t>(1, ceil_div(streams, 256))), static_cast<unsigned>(gn)),
+                       dim3(256), 0, st, f);
+  }
+  TFC_HIP(hipGetLastError());
+  for (int k = 0; k < n; ++k) out[k] = made[k].release();
+  return 0;
+}
+
+// EntropyDecodeFinalize of n handles, no synchronisation: ok DEV uint8 [n, streams].
+extern "C" int tfc_decoder_finalize_device_many(int n, tfc_decoder* const* ds, uint8_t* ok, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return 0;
+  const int64_t streams = ds[0]->streams;
+  for (int g0 = 0; g0 < n; g0 += kMaxDecoderJobs) {
+    const int gn = std::min(kMaxDecoderJobs, n - g0);
+    // handles of one create_many group sit at a fixed stride; anything else goes handle by handle
+    bool strided = streams > 0 && ds[g0]->ctl_group != nullptr;
+    const long long ctl_bytes = 16 + static_cast<long long>(sizeof(uint4)) * std::max<int64_t>(streams, 1);
+    for (int k = 0; k < gn && strided; ++k)
+      if (ds[g0 + k]->ctl_group != ds[g0]->ctl_group || ds[g0 + k]->streams != streams ||
+          ds[g0 + k]->status.as<uint8_t>() != ds[g0]->status.as<uint8_t>() + k * ctl_bytes)
+        strided = false;
+    if (!strided) {
+      for (int k = 0; k < gn; ++k)
+        if (tfc_decoder_finalize_device(ds[g0 + k], ok + (g0 + k) * ds[g0 + k]->streams, stream)) return 1;
+      continue;
+    }
+    DecoderJobs f;
+    f.streams = streams;
+    f.n = gn;
+    f.ctl_bytes = ctl_bytes;
+    f.ctl = ds[g0]->status.as<uint8_t>();
+    for (int k = 0; k < gn; ++k) {
+      f.job[k].blob = ds[g0 + k]->blob_p;
+      f.job[k].off = ds[g0 + k]->off_p;
+      f.job[k].ok = ok + (g0 + k) * streams;
+    }
+    hipLaunchKernelGGL(dec_close_many_kernel,
+                       dim3(static_cast<unsigned>(ceil_div(streams, 256)), static_cast<unsigned>(gn)), dim3(256), 0, st, f);
+  }
+  TFC_HIP(hipGetLastError());
   return 0;
 }
 

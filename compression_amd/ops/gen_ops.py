@@ -30,6 +30,8 @@ __all__ = [
     "entropy_encode_finalize_device", "entropy_encode_status",
     "entropy_decode_finalize_device", "entropy_decode_status",
     "entropy_encode_channel_many", "entropy_decode_channel_many",
+    "create_range_encoders", "create_range_decoders",
+    "entropy_encode_finalize_device_many", "entropy_decode_finalize_device_many",
 ]
 
 _MODES = {None: 0, "auto": 0, "latency": 1, "throughput": 2}
@@ -100,14 +102,16 @@ class EncoderHandle:
     """Stands in for the DT_VARIANT handle tensor of CreateRangeEncoder
     (cc/kernels/range_coder_kernels.cc:62-78, 484-507)."""
 
-    def __init__(self, shape, tables: _Tables, device, mode=None, deferred_errors=False):
+    def __init__(self, shape, tables: _Tables, device, mode=None, deferred_errors=False, ptr=None):
         self.shape = tuple(int(s) for s in shape)
         self.tables = tables
         self.device = device
         self.streams = int(np.prod(self.shape, dtype=np.int64))
-        out = C.c_void_p()
-        _lib.check(_lib.lib().tfc_encoder_create(tables.ptr, self.streams, _lib.stream_ptr(),
-                                                C.byref(out)))
+        out = ptr
+        if out is None:
+            out = C.c_void_p()
+            _lib.check(_lib.lib().tfc_encoder_create(tables.ptr, self.streams, _lib.stream_ptr(),
+                                                    C.byref(out)))
         self.ptr = out
         if _mode_code(mode):
             _lib.check(_lib.lib().tfc_encoder_set_mode(out, _mode_code(mode)))
@@ -162,6 +166,18 @@ def create_range_encoder(shape, lookup, mode=None, deferred_errors=False) -> Enc
     asynchronous (range errors surface at finalize / entropy_encode_status)."""
     device = _lib.require_device()
     return EncoderHandle(_shape_list(shape), _tables_for(lookup), device, mode, deferred_errors)
+
+
+def create_range_encoders(n, shape, lookup, mode=None, deferred_errors=False):
+    """n independent CreateRangeEncoder handles of the same shape with one allocation and one launch
+    (tfc_encoder_create_many)."""
+    device = _lib.require_device()
+    tables = _tables_for(lookup)
+    shape = _shape_list(shape)
+    streams = int(np.prod(shape, dtype=np.int64))
+    ptrs = (C.c_void_p * n)()
+    _lib.check(_lib.lib().tfc_encoder_create_many(tables.ptr, streams, n, _lib.stream_ptr(), ptrs))
+    return [EncoderHandle(shape, tables, device, mode, deferred_errors, ptr=C.c_void_p(p)) for p in ptrs]
 
 
 def _check_prefix(handle_shape, value_shape, what="value"):
@@ -249,6 +265,17 @@ def entropy_encode_finalize_device(handle: EncoderHandle) -> EncoderHandle:
     return handle
 
 
+def entropy_encode_finalize_device_many(handles):
+    """entropy_encode_finalize_device for several handles: three launches in all for handles coded by
+    entropy_encode_channel_many (tfc_encoder_finalize_device_many)."""
+    handles = list(handles)
+    n = len(handles)
+    if n:
+        hp = (C.c_void_p * n)(*[h.ptr for h in handles])
+        _lib.check(_lib.lib().tfc_encoder_finalize_device_many(n, hp, _lib.stream_ptr()))
+    return handles
+
+
 def entropy_encode_status(handle: EncoderHandle) -> int:
     """Synchronises; raises a deferred range error, returns the total byte count (-1 before finalize)."""
     total = C.c_int64()
@@ -297,6 +324,28 @@ def create_range_decoder(encoded, lookup, mode=None) -> DecoderHandle:
     if _mode_code(mode):
         _lib.check(_lib.lib().tfc_decoder_set_mode(handle.ptr, _mode_code(mode)))
     return handle
+
+
+def create_range_decoders(encoders, lookup, mode=None):
+    """One CreateRangeDecoder per finalized EncoderHandle, reading its device-resident strings in place:
+    one allocation, one launch (tfc_decoder_create_many)."""
+    encoders = list(encoders)
+    n = len(encoders)
+    if n == 0:
+        return []
+    device = _lib.require_device()
+    tables = _tables_for(lookup)
+    ep = (C.c_void_p * n)(*[e.ptr for e in encoders])
+    ptrs = (C.c_void_p * n)()
+    _lib.check(_lib.lib().tfc_decoder_create_many(tables.ptr, n, ep, _lib.stream_ptr(), ptrs))
+    out = []
+    for e, p in zip(encoders, ptrs):
+        d = DecoderHandle(e.shape, tables, device, C.c_void_p(p))
+        d._keep.append(e)        # the decoder reads the encoder's blob in place
+        if _mode_code(mode):
+            _lib.check(_lib.lib().tfc_decoder_set_mode(d.ptr, _mode_code(mode)))
+        out.append(d)
+    return out
 
 
 def _create_range_decoder(encoded, lookup) -> DecoderHandle:
@@ -408,6 +457,17 @@ def entropy_decode_finalize_device(handle: DecoderHandle) -> torch.Tensor:
     ok = torch.empty(handle.streams, dtype=torch.uint8, device=handle.device)
     _lib.check(_lib.lib().tfc_decoder_finalize_device(handle.ptr, ok.data_ptr(), _lib.stream_ptr()))
     return ok.reshape(handle.shape)
+
+
+def entropy_decode_finalize_device_many(handles) -> torch.Tensor:
+    """entropy_decode_finalize_device for several handles of one shape -> uint8 device tensor
+    [len(handles), *shape], one launch for handles that came from create_range_decoders."""
+    handles = list(handles)
+    n = len(handles)
+    ok = torch.empty((n,) + tuple(handles[0].shape), dtype=torch.uint8, device=handles[0].device)
+    hp = (C.c_void_p * n)(*[h.ptr for h in handles])
+    _lib.check(_lib.lib().tfc_decoder_finalize_device_many(n, hp, ok.data_ptr(), _lib.stream_ptr()))
+    return ok
 
 
 def entropy_decode_status(handle: DecoderHandle) -> None:

@@ -86,6 +86,12 @@ void tfc_tables_destroy(tfc_tables* t);
 int tfc_encoder_create(const tfc_tables* tables, int64_t streams, void* stream,
                        tfc_encoder** out);
 
+/* n handles of `streams` streams each with one allocation and one launch (per-handle driver calls and
+ * small kernels are a measurable part of a step once the coding calls of a group share a launch);
+ * out: HOST tfc_encoder*[n].  Each handle is destroyed on its own. */
+int tfc_encoder_create_many(const tfc_tables* tables, int64_t streams, int n, void* stream,
+                            tfc_encoder** out);
+
 /* Selects the kernel family (TFC_MODE_*); only before the first encode call on the handle. */
 int tfc_encoder_set_mode(tfc_encoder* e, int mode);
 /* on = 1: encode calls never synchronise; an "index=… / value=… not in range" failure is recorded
@@ -144,6 +150,9 @@ int tfc_encoder_finalize(tfc_encoder* e, void* stream, int64_t* total_bytes);
  * decoder can be created on it at once (stream-ordered).  tfc_encoder_status synchronises, returns
  * deferred failures and the total byte count (total_bytes may be NULL). */
 int tfc_encoder_finalize_device(tfc_encoder* e, void* stream);
+/* ... of n handles: three launches in all where every handle holds one piece from the throughput kernels
+ * (what tfc_encoder_encode_many leaves), otherwise handle by handle. */
+int tfc_encoder_finalize_device_many(int n, tfc_encoder* const* e, void* stream);
 int tfc_encoder_status(tfc_encoder* e, void* stream, int64_t* total_bytes);
 
 /* After finalize: device views of the packed result (owned by the handle):
@@ -169,6 +178,11 @@ void tfc_encoder_destroy(tfc_encoder* e);
  * the decoder is destroyed. */
 int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob, const int64_t* offsets,
                        int64_t streams, int src_on_device, void* stream, tfc_decoder** out);
+
+/* n decoders on the device-resident strings of n finalized encoders (borrowed in place, like
+ * tfc_decoder_create with src_on_device = 1): one allocation, one launch; out: HOST tfc_decoder*[n]. */
+int tfc_decoder_create_many(const tfc_tables* tables, int n, tfc_encoder* const* from, void* stream,
+                            tfc_decoder** out);
 
 /* Selects the kernel family (TFC_MODE_*) of the following decode calls. */
 int tfc_decoder_set_mode(tfc_decoder* d, int mode);
@@ -201,6 +215,8 @@ int tfc_decoder_finalize(tfc_decoder* d, uint8_t* ok, void* stream);
 /* The same in two stream-ordered halves: the weak check into ok DEV uint8 [streams] without
  * synchronising, and the deferred index failure (synchronises). */
 int tfc_decoder_finalize_device(tfc_decoder* d, uint8_t* ok, void* stream);
+/* ... of n handles with the same stream count: ok DEV uint8 [n, streams]. */
+int tfc_decoder_finalize_device_many(int n, tfc_decoder* const* d, uint8_t* ok, void* stream);
 int tfc_decoder_status(tfc_decoder* d, void* stream);
 void tfc_decoder_destroy(tfc_decoder* d);
 

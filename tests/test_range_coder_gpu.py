@@ -195,15 +195,26 @@ def test_modes_per_handle_and_device_finalize(tfc, port):
     # several independent handles in one launch: same strings as one call each
     vals = [synthetic.sample_symbols(lookup, 70, 500, seed=20 + k, escape_fraction=0.02) for k in range(5)]
     for mode in ("throughput", "latency"):
-        hs = [tfc.create_range_encoder([70], lt, mode=mode, deferred_errors=True) for _ in vals]
-        hs = tfc.entropy_encode_channel_many(hs, [dev(x) for x in vals])
-        hs = [tfc.entropy_encode_finalize_device(h) for h in hs]
-        ds = [tfc.create_range_decoder(h, lt, mode=mode) for h in hs]
-        ds, outs = tfc.entropy_decode_channel_many(ds, [500], torch.int32)
-        for x, h, d, out in zip(vals, hs, ds, outs):
-            assert bool(tfc.entropy_decode_finalize_device(d).cpu().numpy().all())
-            assert (out.cpu().numpy() == x).all()
-            assert [bytes(b) for b in tfc.entropy_encode_finalize(h).reshape(-1)] == port.encode(lookup, x)[0], mode
+        for batched in (False, True):        # handle by handle / one allocation and launch per group
+            if batched:
+                hs = tfc.create_range_encoders(len(vals), [70], lt, mode=mode, deferred_errors=True)
+            else:
+                hs = [tfc.create_range_encoder([70], lt, mode=mode, deferred_errors=True) for _ in vals]
+            hs = tfc.entropy_encode_channel_many(hs, [dev(x) for x in vals])
+            if batched:
+                hs = tfc.entropy_encode_finalize_device_many(hs)
+                ds = tfc.create_range_decoders(hs, lt, mode=mode)
+            else:
+                hs = [tfc.entropy_encode_finalize_device(h) for h in hs]
+                ds = [tfc.create_range_decoder(h, lt, mode=mode) for h in hs]
+            ds, outs = tfc.entropy_decode_channel_many(ds, [500], torch.int32)
+            oks = (tfc.entropy_decode_finalize_device_many(ds) if batched
+                   else torch.stack([tfc.entropy_decode_finalize_device(d) for d in ds]))
+            assert oks.shape == (len(vals), 70) and bool(oks.cpu().numpy().all())
+            for x, h, d, out in zip(vals, hs, ds, outs):
+                tfc.entropy_decode_status(d)
+                assert (out.cpu().numpy() == x).all()
+                assert [bytes(b) for b in tfc.entropy_encode_finalize(h).reshape(-1)] == port.encode(lookup, x)[0], (mode, batched)
     # streams that outgrow the speculative slab (more than 16 bits per symbol): coded again with the
     # worst-case slab when the call synchronises, reported when errors are deferred
     rng = np.random.default_rng(3)

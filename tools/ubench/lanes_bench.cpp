@@ -92,6 +92,8 @@ int main(int argc, char** argv) {
   const int ngroups_max = getenv("NGROUPS") ? atoi(getenv("NGROUPS")) : 2;
   d_out.resize(maxd * ngroups_max);
   for (auto& o : d_out) CK(hipMalloc(&o, h.size() * 4));
+  uint8_t* d_ok;
+  CK(hipMalloc(&d_ok, (size_t)maxd * streams));
   std::vector<hipStream_t> st(std::max(maxd, 8));
   for (auto& s : st) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
 
@@ -159,23 +161,19 @@ int main(int argc, char** argv) {
         std::vector<tfc_decoder*> gd(depth);
         std::vector<const int32_t*> vals(depth);
         std::vector<int32_t*> outs(depth);
+        TF(tfc_encoder_create_many(tables, streams, depth, s, ge.data()));
         for (int k = 0; k < depth; ++k) {
-          TF(tfc_encoder_create(tables, streams, s, &ge[k]));
           TF(tfc_encoder_set_mode(ge[k], mode));
           TF(tfc_encoder_set_deferred_errors(ge[k], 1));
           vals[k] = d_val[k % nslots];
           outs[k] = d_out[(r % groups) * depth + k];
         }
         TF(tfc_encoder_encode_many(depth, ge.data(), vals.data(), nullptr, elems, s));
-        for (int k = 0; k < depth; ++k) {
-          TF(tfc_encoder_finalize_device(ge[k], s));
-          const uint8_t* blob;
-          const int64_t* offs;
-          TF(tfc_encoder_result(ge[k], &blob, &offs));
-          TF(tfc_decoder_create(tables, blob, offs, streams, 1, s, &gd[k]));
-          TF(tfc_decoder_set_mode(gd[k], mode));
-        }
+        TF(tfc_encoder_finalize_device_many(depth, ge.data(), s));
+        TF(tfc_decoder_create_many(tables, depth, ge.data(), s, gd.data()));
+        for (int k = 0; k < depth; ++k) TF(tfc_decoder_set_mode(gd[k], mode));
         TF(tfc_decoder_decode_many(depth, gd.data(), nullptr, outs.data(), elems, s));
+        TF(tfc_decoder_finalize_device_many(depth, gd.data(), d_ok, s));
         es.insert(es.end(), ge.begin(), ge.end());
         ds.insert(ds.end(), gd.begin(), gd.end());
       }
