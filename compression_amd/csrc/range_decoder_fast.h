@@ -511,6 +511,12 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
     // ---- checked loop: escapes and partial batches ----------------------------
     auto checked = [&](int n0, int n1) {
       for (int n = n0; n < n1; ++n) {
+        // the window register holds 64 digits: a symbol takes at most one, the escape code behind it
+        // at most five more (61 binary calls)
+        if (st.pos >= 56u) {
+          fast_window_advance(w, st.pos, lane);
+          st.pos = 0;
+        }
         const int escsym = __builtin_amdgcn_readlane(row.w, n);
         int sym = anywide ? wide_step(n) : narrow_step(n);
         if (sym == escsym) {
@@ -573,6 +579,13 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
         escape_in_last_batch = false;
         for (int blk = 0; blk < 8; ++blk) {
           const int n0 = blk * 8;
+          // With escape codes in the batch its 64 symbols can take more than the 64 digits of the window
+          // register (one digit per symbol only happens with symbols of probability <= 2^-16, plus up to
+          // five per escape code): a block starts with at least 16 digits ahead.
+          if (st.pos > 48u) {
+            fast_window_advance(w, st.pos, lane);
+            st.pos = 0;
+          }
           const FastDecState saved = st;
           const unsigned int hi_saved = hi_cur;
           if (!anywide) {

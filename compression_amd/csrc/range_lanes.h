@@ -250,16 +250,16 @@ struct EncWaveLds {
 // the lane state and repeats the block with the generic steps.  Fixed temporaries v140-v175:
 // v[140:147] the block's values, v[148:149] / v[150:151] rows (cdf - 2, info), v[152:153] v[154:155] /
 // v[156:157] v[158:159] (lo, 0) (hi, 0) of even / odd steps.
-#define TFC_LENC_A(VAL, R0, R1, LO, HI, NEXTROW)                                            \
+#define TFC_LENC_A(VAL, R0, R1, LO, HI, NEXTROW, NP)                                        \
   NEXTROW                                                                                 \
   "v_and_b32 v171, 0x7fffffff, v" #R1 "\n\t"                                              \
-  "v_cmp_ge_u32 vcc, v" #VAL ", v171\n\t"                                                 \
-  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
+  "v_cmp_ge_u32 " NP(VAL)                                                                 \
   "v_min_u32 v172, v" #VAL ", v171\n\t"                                                   \
   "v_lshl_add_u32 v172, v172, 1, v" #R0 "\n\t"                                            \
   "ds_read_u16 v" #LO ", v172 offset:2\n\t"                                               \
   "ds_read_u16 v" #HI ", v172 offset:4\n\t"
-#define TFC_LENC_B(LO, LOH, HI, HIH)                                                      \
+#define TFC_LENC_B(LO, LOH, HI, HIH, PRE)                                                 \
+  PRE                                                                                     \
   "v_mad_u64_u32 v[160:161], s[52:53], v" #LO ", %[S], v[" #LO ":" #LOH "]\n\t"             \
   "v_mad_u64_u32 v[162:163], s[52:53], v" #HI ", %[S], v[" #HI ":" #HIH "]\n\t"             \
   "v_alignbit_b32 v160, v161, v160, 16\n\t"                                               \
@@ -300,7 +300,16 @@ struct EncWaveLds {
   "v_mad_u32_u24 %[PD], v168, v169, %[PD]\n\t"
 #define TFC_LENC_ROW_A(OFF) "ds_read_b64 v[148:149], %[DIRP] offset:" #OFF "\n\t"
 #define TFC_LENC_ROW_B(OFF) "ds_read_b64 v[150:151], %[DIRP] offset:" #OFF "\n\t"
-#define TFC_LENC_BLOCK                                                                    \
+// A value that is not a plain symbol: (plain variant) bump FLAG, the block is repeated generically /
+// (freezing variant) the lane is taken out of this and the following steps and counts the steps it made
+#define TFC_LENC_NP_PLAIN(VAL) "vcc, v" #VAL ", v171\n\tv_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"
+#define TFC_LENC_PRE_PLAIN ""
+#define TFC_LENC_NP_FREEZE0(VAL) "s[58:59], v" #VAL ", v171\n\t"
+#define TFC_LENC_NP_FREEZE1(VAL) "s[60:61], v" #VAL ", v171\n\t"
+#define TFC_LENC_PRE_FREEZE0 "s_andn2_b64 exec, exec, s[58:59]\n\tv_add_u32 %[CNT], 1, %[CNT]\n\t"
+#define TFC_LENC_PRE_FREEZE1 "s_andn2_b64 exec, exec, s[60:61]\n\tv_add_u32 %[CNT], 1, %[CNT]\n\t"
+#define TFC_LENC_BLOCK(NP0, NP1, PRE0, PRE1)                                                                  \
+  "s_mov_b64 s[56:57], exec\n\t"                                                          \
   "ds_read2_b32 v[140:141], %[VP] offset1:1\n\t"                                          \
   "ds_read2_b32 v[142:143], %[VP] offset0:2 offset1:3\n\t"                                \
   "ds_read2_b32 v[144:145], %[VP] offset0:4 offset1:5\n\t"                                \
@@ -308,37 +317,38 @@ struct EncWaveLds {
   TFC_LENC_ROW_A(0)                                                                       \
   "v_mov_b32 v153, 0\n\tv_mov_b32 v155, 0\n\tv_mov_b32 v157, 0\n\tv_mov_b32 v159, 0\n\t"  \
   "s_waitcnt lgkmcnt(0)\n\t"                                                              \
-  TFC_LENC_A(140, 148, 149, 152, 154, TFC_LENC_ROW_B(16))                                     \
+  TFC_LENC_A(140, 148, 149, 152, 154, TFC_LENC_ROW_B(16), NP0)                                     \
   "s_waitcnt lgkmcnt(2)\n\t"                                                              \
-  TFC_LENC_A(141, 150, 151, 156, 158, TFC_LENC_ROW_A(32))                                     \
+  TFC_LENC_A(141, 150, 151, 156, 158, TFC_LENC_ROW_A(32), NP1)                                     \
   "s_waitcnt lgkmcnt(3)\n\t"                                                              \
-  TFC_LENC_B(152, 153, 154, 155)                                                          \
+  TFC_LENC_B(152, 153, 154, 155, PRE0)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(142, 148, 149, 152, 154, TFC_LENC_ROW_B(48))                                     \
+  TFC_LENC_A(142, 148, 149, 152, 154, TFC_LENC_ROW_B(48), NP0)                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(156, 157, 158, 159)                                                          \
+  TFC_LENC_B(156, 157, 158, 159, PRE1)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(143, 150, 151, 156, 158, TFC_LENC_ROW_A(64))                                     \
+  TFC_LENC_A(143, 150, 151, 156, 158, TFC_LENC_ROW_A(64), NP1)                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(152, 153, 154, 155)                                                          \
+  TFC_LENC_B(152, 153, 154, 155, PRE0)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(144, 148, 149, 152, 154, TFC_LENC_ROW_B(80))                                     \
+  TFC_LENC_A(144, 148, 149, 152, 154, TFC_LENC_ROW_B(80), NP0)                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(156, 157, 158, 159)                                                          \
+  TFC_LENC_B(156, 157, 158, 159, PRE1)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(145, 150, 151, 156, 158, TFC_LENC_ROW_A(96))                                     \
+  TFC_LENC_A(145, 150, 151, 156, 158, TFC_LENC_ROW_A(96), NP1)                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(152, 153, 154, 155)                                                          \
+  TFC_LENC_B(152, 153, 154, 155, PRE0)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(146, 148, 149, 152, 154, TFC_LENC_ROW_B(112))                                     \
+  TFC_LENC_A(146, 148, 149, 152, 154, TFC_LENC_ROW_B(112), NP0)                                     \
   "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(156, 157, 158, 159)                                                          \
+  TFC_LENC_B(156, 157, 158, 159, PRE1)                                                          \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(147, 150, 151, 156, 158, "")                                                 \
+  TFC_LENC_A(147, 150, 151, 156, 158, "", NP1)                                                 \
   "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_B(152, 153, 154, 155)                                                          \
+  TFC_LENC_B(152, 153, 154, 155, PRE0)                                                          \
   "s_waitcnt lgkmcnt(2)\n\t"                                                              \
-  TFC_LENC_B(156, 157, 158, 159)                                                          \
+  TFC_LENC_B(156, 157, 158, 159, PRE1)                                                          \
+  "s_mov_b64 exec, s[56:57]\n\t"                                                          \
   "s_waitcnt lgkmcnt(0)\n\t"
 
 template <bool INDEXED, typename Src>
@@ -392,6 +402,7 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
   unsigned int j = 0u;              // next symbol to take
   unsigned int dirp = 0u;           // channel mode: LDS offset of its directory entry
   unsigned int qn = 0u, g = 0u, neg = 0u;   // escape bits still to code: qn of them, from g then the sign
+  unsigned int saw_exception = 0u;          // this lane met a value that is not a plain symbol
 
   // Digit `d` into the staging area, speculatively: it counts only if `on` advances the cursor.  The
   // area holds what the kEncCadence steps between two phases can produce (two digits each); the run of
@@ -424,6 +435,37 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
     }
   };
 
+  // one coder call on [lo, hi) / 2^16 for the lanes with `act`
+  auto call = [&](unsigned int lo, unsigned int hi, bool act) __attribute__((always_inline)) {
+    // ---- RangeEncoder::Encode (range_coder.cc:37-264) on [lo, hi) / 2^16; pd = delay_ & 0xFFFF
+    // (0: state 0), pb = delay_ >> 16; every update is a select on `act` --------------------------------
+    const unsigned int a = scale16(s1, lo);
+    const unsigned int b = scale16(s1, hi) - 1u;
+    const unsigned int base1 = base + a;
+    const unsigned int s11 = b - a;
+    const bool wrapped = base1 < a;
+    const bool st1 = static_cast<unsigned int>(base1 + s11) < base1;      // the carry is (still) undecided
+    const bool ren = act && (s11 >> 16) == 0u;
+    // state 1 -> 0: the delayed digit is decided (and the run of 0x0000 / 0xFFFF digits behind it)
+    const bool resolve = act && !st1 && pd != 0u;
+    put(wrapped ? pd : pd - 1u, resolve);
+    if (__any(resolve && pb != 0u)) {
+      if (resolve && pb != 0u) put_run(wrapped ? 0u : 0xFFFFu, pb);
+    }
+    pd = resolve ? 0u : pd;
+    pb = resolve ? 0u : pb;
+    // renormalisation
+    const unsigned int top = base1 >> 16;
+    const unsigned int base2 = ren ? base1 << 16 : base1;
+    const unsigned int s12 = ren ? (s11 << 16) | 0xFFFFu : s11;
+    const bool st1r = static_cast<unsigned int>(base2 + s12) < base2;     // state after the shift
+    put(top, ren && !st1 && !st1r);
+    pd = (ren && !st1 && st1r) ? top + 1u : pd;
+    pb = (ren && st1) ? pb + 2u : pb;
+    base = act ? base2 : base;
+    s1 = act ? s12 : s1;
+  };
+
   // one generic step: any lane state
   auto step = [&]() {
     // ---- the call of this step: speculatively the next symbol as a plain one (reads stay inside the
@@ -449,6 +491,7 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
     unsigned int lo = 0u, hi = 0u;
     if (__any(!(take && plain) && (qn != 0u || j < elems))) {
       if (take && !plain) {
+        saw_exception = 1u;
         if (row.y >> 31) {
           // escape: the row's last interval now, the Elias-gamma code of the excess in the next steps
           neg = v < 0 ? 1u : 0u;
@@ -480,36 +523,16 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
       const unsigned int nd = dirp + 16u == dir_end ? 0u : dirp + 16u;
       dirp = adv ? nd : dirp;
     }
-    // ---- RangeEncoder::Encode (range_coder.cc:37-264) on [lo, hi) / 2^16; pd = delay_ & 0xFFFF
-    // (0: state 0), pb = delay_ >> 16; every update is a select on `act` --------------------------------
-    const unsigned int a = scale16(s1, lo);
-    const unsigned int b = scale16(s1, hi) - 1u;
-    const unsigned int base1 = base + a;
-    const unsigned int s11 = b - a;
-    const bool wrapped = base1 < a;
-    const bool st1 = static_cast<unsigned int>(base1 + s11) < base1;      // the carry is (still) undecided
-    const bool ren = act && (s11 >> 16) == 0u;
-    // state 1 -> 0: the delayed digit is decided (and the run of 0x0000 / 0xFFFF digits behind it)
-    const bool resolve = act && !st1 && pd != 0u;
-    put(wrapped ? pd : pd - 1u, resolve);
-    if (__any(resolve && pb != 0u)) {
-      if (resolve && pb != 0u) put_run(wrapped ? 0u : 0xFFFFu, pb);
-    }
-    pd = resolve ? 0u : pd;
-    pb = resolve ? 0u : pb;
-    // renormalisation
-    const unsigned int top = base1 >> 16;
-    const unsigned int base2 = ren ? base1 << 16 : base1;
-    const unsigned int s12 = ren ? (s11 << 16) | 0xFFFFu : s11;
-    const bool st1r = static_cast<unsigned int>(base2 + s12) < base2;     // state after the shift
-    put(top, ren && !st1 && !st1r);
-    pd = (ren && !st1 && st1r) ? top + 1u : pd;
-    pb = (ren && st1) ? pb + 2u : pb;
-    base = act ? base2 : base;
-    s1 = act ? s12 : s1;
+    call(lo, hi, act);
   };
 
+  // The main loop exists twice: with the plain block until the wave meets its first value that is not a
+  // plain symbol, with the freezing block (~5 % slower per step) from there on, so that each of the two
+  // hot loops is one contiguous piece of code.  Only such a value switches loops: the other exceptions
+  // (a long carry run here, a wrong rank estimate in the decoder) happen in every stream now and then.
   constexpr bool kFastBlock = !INDEXED && std::is_same<Src, SymInt32>::value;
+  auto run = [&](auto freeze_tag) __attribute__((always_inline)) {
+  constexpr bool kFreeze = decltype(freeze_tag)::value;
   while (__any(j < elems || qn != 0u)) {
     {
       // memory phase: park what the previous phase requested, request from the current position, store
@@ -523,26 +546,79 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
       flush();
     }
     const bool busy = j < elems || qn != 0u;
-    if (kFastBlock && lds0 == 0u && !__any(busy && (j + kEncCadence > elems || qn != 0u))) {
+    if (__builtin_expect(kFastBlock && lds0 == 0u && !__any(busy && (j + kEncCadence > elems || qn != 0u)), 1)) {
       const unsigned int base0 = base, s10 = s1, pd0 = pd, pb0 = pb;
-      unsigned int flag = 0u, na = ds_off;
+      unsigned int flag = 0u, na = ds_off, cnt = 0u;
       if (busy) {
         const unsigned int vp = vw_off + (j * 4u - vw.base);
-        asm volatile(TFC_LENC_BLOCK
-                     : [BASE] "+v"(base), [S] "+v"(s1), [PD] "+v"(pd), [PB] "+v"(pb), [NA] "+v"(na), [FLAG] "+v"(flag)
-                     : [VP] "v"(vp), [DIRP] "v"(dirp), [DIR0] "v"(0u), [K64K] "s"(0x10000u),
-                       [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
-                     : "vcc", "memory", "s52", "s53", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147",
-                       "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159",
-                       "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171",
-                       "v172", "v173", "v174", "v175");
+        // the plain block until this wave has met its first exception, the freezing one afterwards
+#define TFC_LENC_OPERANDS                                                                                          \
+                     : [BASE] "+v"(base), [S] "+v"(s1), [PD] "+v"(pd), [PB] "+v"(pb), [NA] "+v"(na), [FLAG] "+v"(flag), \
+                       [CNT] "+v"(cnt)                                                                                \
+                     : [VP] "v"(vp), [DIRP] "v"(dirp), [DIR0] "v"(0u), [K64K] "s"(0x10000u),                          \
+                       [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)                                                  \
+                     : "vcc", "memory", "s52", "s53", "s56", "s57", "s58", "s59", "s60", "s61", "v140", "v141", "v142", \
+                       "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", \
+                       "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", \
+                       "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175"
+        if constexpr (kFreeze) {
+          asm volatile(TFC_LENC_BLOCK(TFC_LENC_NP_FREEZE0, TFC_LENC_NP_FREEZE1, TFC_LENC_PRE_FREEZE0, TFC_LENC_PRE_FREEZE1)
+                       TFC_LENC_OPERANDS);
+        } else {
+          asm volatile(TFC_LENC_BLOCK(TFC_LENC_NP_PLAIN, TFC_LENC_NP_PLAIN, TFC_LENC_PRE_PLAIN, TFC_LENC_PRE_PLAIN)
+                       TFC_LENC_OPERANDS);
+          cnt = kEncCadence;
+        }
+#undef TFC_LENC_OPERANDS
       }
-      if (!__any(flag != 0u)) {
+      if (__builtin_expect(!__any(flag != 0u), 1)) {
+        if (__builtin_expect(!__any(busy && cnt != kEncCadence), 1)) {
+          if (busy) {
+            j += kEncCadence;
+            n = na - ds_off;
+            dirp += dir_step;                          // kEncCadence entries further, modulo the table count
+            dirp -= dirp >= dir_end ? dir_end : 0u;
+          }
+          continue;
+        }
+        // Some lanes stopped in front of a value that is not a plain symbol, after `cnt` steps.  Its
+        // calls now — the row's escape symbol, then the bits of the Elias-gamma code — in a loop of bare
+        // coder calls while the other lanes wait, as long as the digit area has room for two more digits
+        // (a code that does not fit goes on in the generic steps behind the next memory phase).
         if (busy) {
-          j += kEncCadence;
+          j += cnt;
           n = na - ds_off;
-          dirp += dir_step;                          // kEncCadence entries further, modulo the table count
-          dirp -= dirp >= dir_end ? dir_end : 0u;
+          dirp += 16u * cnt;
+        }
+        while (__any(busy && dirp >= dir_end)) dirp -= dirp >= dir_end ? dir_end : 0u;
+        const bool stopped = busy && cnt != kEncCadence;
+        unsigned int lo = 0u, hi = 0u;
+        if (stopped) {
+          const int32_t v = *reinterpret_cast<const int32_t*>(vw.lds + (j * 4u - vw.base));
+          const uint2 row = *reinterpret_cast<const uint2*>(lanes_lds + dirp);
+          const unsigned int limit = row.y & 0x7FFFFFFFu;
+          unsigned int sym = limit;
+          if (row.y >> 31) {
+            neg = v < 0 ? 1u : 0u;
+            g = v < 0 ? 0u - static_cast<unsigned int>(v) : static_cast<unsigned int>(v) - limit + 1u;
+            qn = 2u * static_cast<unsigned int>(31 - __clz(static_cast<int>(g))) + 2u;
+          } else {
+            atomicMin(first_error, static_cast<unsigned long long>(pos0 + j));
+            sym = 0u;
+          }
+          lo = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
+          hi = lds_u16(lanes_lds, row.x + 2u * sym + 4u);
+          hi = hi == 0u ? 65536u : hi;
+          ++j;
+          dirp = dirp + 16u == dir_end ? 0u : dirp + 16u;
+        }
+        call(lo, hi, stopped);
+        while (__any(qn != 0u && n + 4u <= kEncDigitBytes)) {
+          const bool on = qn != 0u && n + 4u <= kEncDigitBytes;
+          qn -= on ? 1u : 0u;
+          const unsigned int sft = qn - 1u;      // qn = 0: the sign
+          const unsigned int bit = qn == 0u ? neg : (sft < 32u ? (g >> sft) & 1u : 0u);
+          call(bit << 15, (bit + 1u) << 15, on);
         }
         continue;
       }
@@ -550,7 +626,11 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
     }
 #pragma nounroll
     for (unsigned int k = 0; k < kEncCadence; ++k) step();
+    if (kFastBlock && !kFreeze && __any(saw_exception != 0u)) return;      // such values are to be expected from here on
   }
+  };
+  run(std::false_type{});
+  if constexpr (kFastBlock) run(std::true_type{});
   flush();
   if (live) {
     J.state[s] = make_uint4(base, s1, pd, pb);
@@ -569,6 +649,8 @@ constexpr unsigned int kDecCadence = 8;
 // elements of one cadence, and the index window.
 template <typename Elem>
 struct DecWaveLds {
+  // two cadences of digits: the window parked at a memory phase starts at the position of the phase
+  // before it, and between two phases a lane consumes at most kDecCadence digits
   static constexpr int kCodeWords = 2 * kDecCadence * 2 / 8;
   static constexpr int kIndexWords = 2 * kDecCadence * 4 / 8;
   static constexpr int kOutBytes = kDecCadence * sizeof(Elem);
@@ -586,13 +668,16 @@ struct DecWaveLds {
 // wave pays ~4 cycles per instruction of any kind, so the block is written for instruction count
 // (~55 per step against ~100 from the compiler) and for LDS latency: the directory entry of step k + 1
 // and the code digit are requested before the quotient arithmetic of step k.  Anything else — an
-// escape symbol, an estimate that the verification rejects, damaged input — only bumps FLAG; the
-// caller then restores the lane state it saved and repeats the block with the generic steps.
+// estimate that the verification rejects, damaged input — only bumps FLAG; the caller then restores the
+// lane state it saved and repeats the block with the generic steps.  A lane that decodes an ESCAPE symbol
+// takes that step's state update and then sits out the rest of the block (EXEC): CNT is the number of
+// symbols a lane completed; the caller decodes the escape's bits in a short loop of its own and the lane
+// carries on, a few symbols behind its neighbours.
 // LDS operands are absolute LDS addresses (the kernel's dynamic LDS starts at 0, checked by the
 // caller).  Temporaries are the fixed registers v100-v132 (register pairs and the 4-register row
 // buffers need known numbers): v[100:103] / v[104:107] rows (cdf - 2, info, bits, cum), v[120:121] = -1,
 // v[122:123] = (lo, 0), v[124:125] = (hi, 0).
-#define TFC_LDEC_STEP(ROW0, ROW1, ROW2, ROW3, PREFETCH, OUTOFF)                            \
+#define TFC_LDEC_STEP(ROW0, ROW1, ROW2, ROW3, PREFETCH, OUTOFF, ESC1, ESC2)                \
   PREFETCH                                                                                \
   "ds_read_u16 v109, %[CP]\n\t"                                                           \
   "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
@@ -619,8 +704,7 @@ struct DecWaveLds {
   "ds_read_u16 v124, v112 offset:2\n\t"                                                   \
   "v_xor_b32 v113, 0x80000000, v" #ROW1 "\n\t"                                            \
   "v_add_u32 v117, -1, v116\n\t"                                                          \
-  "v_cmp_eq_u32 vcc, v117, v113\n\t"                                                      \
-  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
+  ESC1                                                                                    \
   "ds_write_b32 %[OQ], v117 offset:" #OUTOFF "\n\t"                                       \
   "v_perm_b32 v109, 0, v109, %[PERM]\n\t"                                                 \
   "s_waitcnt lgkmcnt(1)\n\t"                                                              \
@@ -640,20 +724,29 @@ struct DecWaveLds {
   "v_lshl_or_b32 v132, v131, 16, %[KFFFF]\n\t"                                            \
   "v_cndmask_b32 %[S], v131, v132, vcc\n\t"                                               \
   "v_cndmask_b32 v132, 0, 2, vcc\n\t"                                                     \
-  "v_add_u32 %[CP], %[CP], v132\n\t"
+  "v_add_u32 %[CP], %[CP], v132\n\t"                                                      \
+  ESC2
+// an escape symbol: (plain variant) bump FLAG, the whole block is repeated generically / (freezing variant)
+// remember the lanes, let them finish this step, then take them out of the rest of the block
+#define TFC_LDEC_ESC1_PLAIN "v_cmp_eq_u32 vcc, v117, v113\n\tv_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"
+#define TFC_LDEC_ESC2_PLAIN ""
+#define TFC_LDEC_ESC1_FREEZE "v_cmp_eq_u32 s[54:55], v117, v113\n\t"
+#define TFC_LDEC_ESC2_FREEZE "s_andn2_b64 exec, exec, s[54:55]\n\tv_add_u32 %[CNT], 1, %[CNT]\n\t"
 #define TFC_LDEC_READ_A(OFF) "ds_read_b128 v[100:103], %[DIRP] offset:" #OFF "\n\t"
 #define TFC_LDEC_READ_B(OFF) "ds_read_b128 v[104:107], %[DIRP] offset:" #OFF "\n\t"
-#define TFC_LDEC_BLOCK                                                                    \
+#define TFC_LDEC_BLOCK(ESC1, ESC2)                                                        \
+  "s_mov_b64 s[56:57], exec\n\t"                                                          \
   "v_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t"                                           \
   TFC_LDEC_READ_A(0) "s_waitcnt lgkmcnt(0)\n\t"                                           \
-  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(16), 0)                               \
-  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(32), 4)                               \
-  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(48), 8)                               \
-  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(64), 12)                              \
-  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(80), 16)                              \
-  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(96), 20)                              \
-  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(112), 24)                             \
-  TFC_LDEC_STEP(104, 105, 106, 107, "", 28)                                               \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(16), 0, ESC1, ESC2)                   \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(32), 4, ESC1, ESC2)                   \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(48), 8, ESC1, ESC2)                   \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(64), 12, ESC1, ESC2)                  \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(80), 16, ESC1, ESC2)                  \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(96), 20, ESC1, ESC2)                  \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(112), 24, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(104, 105, 106, 107, "", 28, ESC1, ESC2)                                   \
+  "s_mov_b64 exec, s[56:57]\n\t"                                                          \
   "s_waitcnt lgkmcnt(0)\n\t"
 
 template <bool INDEXED, typename Dst>
@@ -713,11 +806,12 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
   unsigned int dirp = 0u;            // channel mode: LDS offset of the directory entry of symbol j
   unsigned int mode = 0u;            // 0 symbol, 1 unary prefix, 2 payload bits, 3 sign
   unsigned int nb = 0u, val = 0u, esc_limit = 0u;
+  unsigned int saw_escape = 0u;      // this lane met an escape symbol
 
   // elements [j - ko / kEs, j) leave the staging area: a full cadence as 16-byte stores
   auto flush = [&]() {
     Elem* const to = dst.ptr() + (pos0 + j - ko / kEs);
-    if (ko == static_cast<unsigned int>(L::kOutBytes)) {
+    if (__builtin_expect(ko == static_cast<unsigned int>(L::kOutBytes), 1)) {
 #pragma unroll
       for (int c = 0; c < L::kOutBytes / 16; ++c) {
         uint2 v[2];
@@ -729,6 +823,51 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
       for (unsigned int e = 0; e < ko / kEs; ++e) lanes_gstore_elem(to + e, reinterpret_cast<const Elem*>(outq)[e]);
     }
     ko = 0u;
+  };
+
+  // one bit of an Elias-gamma escape code, for the lanes that are inside one (mode != 0)
+  auto bit_step = [&]() {
+    if (j < elems && mode != 0u) {
+        // ---- one bit of an Elias-gamma escape code (range_coder_kernels.cc:449-471): the uniform
+        // binary cdf {0, 1, 2} at precision 1 needs no table ------------------------------------------
+        const unsigned int dig = __builtin_bswap16(*reinterpret_cast<const unsigned short*>(lanes_lds + cp));
+        const unsigned int half = scale16(s1, 32768u);          // B of the first interval
+        const unsigned int bit = D >= half ? 1u : 0u;
+        const unsigned int A = bit ? half : 0u;
+        const unsigned int b = bit ? s1 : half - 1u;
+        D -= A;
+        s1 = b - A;
+        const bool ren = (s1 >> 16) == 0u;
+        D = ren ? (D << 16) | dig : D;
+        s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
+        cp += ren ? 2u : 0u;
+        bool done = false;
+        if (mode == 1u) {
+          // unary prefix, bounded so that damaged input cannot spin
+          if (bit == 0u) {
+            ++nb;
+            if (nb == 31u) { val = 1u << 31; mode = 2u; }
+          } else {
+            val = 1u << nb;
+            mode = nb != 0u ? 2u : 3u;
+          }
+        } else if (mode == 2u) {
+          --nb;
+          val |= bit << nb;
+          if (nb == 0u) mode = 3u;
+        } else {
+          done = true;
+        }
+        if (done) {
+          const unsigned int dp = INDEXED ? 16u * static_cast<unsigned int>(min(max(*reinterpret_cast<const int*>(iw.lds + (j * 4u - iw.base)), 0), la.ntab - 1)) : dirp;
+          const int outv = bit != 0u ? -static_cast<int>(val) : static_cast<int>(val) + static_cast<int>(esc_limit) - 1;
+          *reinterpret_cast<Elem*>(outq + ko) = dst.make(static_cast<int>(dp >> 4), outv);
+          ko += kEs;
+          ++j;
+          mode = 0u;
+          if (!INDEXED) dirp = dirp + 16u == dir_end ? 0u : dirp + 16u;
+        }
+    }
   };
 
   // one generic step: any mode, any lane state
@@ -785,6 +924,7 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         cp += ren ? 2u : 0u;
         // ---- the element (written speculatively: it counts only if the cursors advance) ------------
         const bool esc = sym == (row.y ^ 0x80000000u);      // the escape symbol of a row that has one
+        saw_escape |= esc ? 1u : 0u;
         *reinterpret_cast<Elem*>(outq + ko) = dst.make(static_cast<int>(dp >> 4), static_cast<int>(sym));
         ko += esc ? 0u : kEs;
         j += esc ? 0u : 1u;
@@ -796,50 +936,15 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
           dirp = esc ? dirp : nd;
         }
       } else {
-        // ---- one bit of an Elias-gamma escape code (range_coder_kernels.cc:449-471): the uniform
-        // binary cdf {0, 1, 2} at precision 1 needs no table ------------------------------------------
-        const unsigned int dig = __builtin_bswap16(*reinterpret_cast<const unsigned short*>(lanes_lds + cp));
-        const unsigned int half = scale16(s1, 32768u);          // B of the first interval
-        const unsigned int bit = D >= half ? 1u : 0u;
-        const unsigned int A = bit ? half : 0u;
-        const unsigned int b = bit ? s1 : half - 1u;
-        D -= A;
-        s1 = b - A;
-        const bool ren = (s1 >> 16) == 0u;
-        D = ren ? (D << 16) | dig : D;
-        s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
-        cp += ren ? 2u : 0u;
-        bool done = false;
-        if (mode == 1u) {
-          // unary prefix, bounded so that damaged input cannot spin
-          if (bit == 0u) {
-            ++nb;
-            if (nb == 31u) { val = 1u << 31; mode = 2u; }
-          } else {
-            val = 1u << nb;
-            mode = nb != 0u ? 2u : 3u;
-          }
-        } else if (mode == 2u) {
-          --nb;
-          val |= bit << nb;
-          if (nb == 0u) mode = 3u;
-        } else {
-          done = true;
-        }
-        if (done) {
-          const unsigned int dp = INDEXED ? 16u * static_cast<unsigned int>(min(max(*reinterpret_cast<const int*>(iw.lds + (j * 4u - iw.base)), 0), la.ntab - 1)) : dirp;
-          const int outv = bit != 0u ? -static_cast<int>(val) : static_cast<int>(val) + static_cast<int>(esc_limit) - 1;
-          *reinterpret_cast<Elem*>(outq + ko) = dst.make(static_cast<int>(dp >> 4), outv);
-          ko += kEs;
-          ++j;
-          mode = 0u;
-          if (!INDEXED) dirp = dirp + 16u == dir_end ? 0u : dirp + 16u;
-        }
+        bit_step();
       }
     }
   };
 
+  // the main loop twice, as in the encoder: plain block until the first escape symbol, freezing block after it
   constexpr bool kFastBlock = !INDEXED && std::is_same<Dst, OutInt32>::value;
+  auto run = [&](auto freeze_tag) __attribute__((always_inline)) {
+  constexpr bool kFreeze = decltype(freeze_tag)::value;
   while (__any(j < elems)) {
     {
       // memory phase: park the code bytes requested at the previous phase, request from the current
@@ -854,24 +959,55 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
       }
       flush();
     }
-    if (kFastBlock && lds0 == 0u && !__any(j < elems && (j + kDecCadence > elems || mode != 0u))) {
+    if (__builtin_expect(kFastBlock && lds0 == 0u && !__any(j < elems && (j + kDecCadence > elems || mode != 0u)), 1)) {
       const unsigned int D0 = D, s10 = s1, cp0 = cp;
-      unsigned int flag = 0u;
+      unsigned int flag = 0u, cnt = 0u;
       if (j < elems) {
-        asm volatile(TFC_LDEC_BLOCK
-                     : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [FLAG] "+v"(flag)
-                     : [DIRP] "v"(dirp), [OQ] "v"(oq_off), [SCALE] "s"(scale), [QMAX] "s"(cp_max),
-                       [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
-                     : "vcc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
-                       "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",
-                       "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132");
+        // the plain block until this wave has met its first escape symbol, the freezing one afterwards
+        // (the freeze costs ~10 % per step: a scalar EXEC update behind a vector compare, and the count)
+#define TFC_LDEC_OPERANDS                                                                                       \
+                     : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [FLAG] "+v"(flag), [CNT] "+v"(cnt)              \
+                     : [DIRP] "v"(dirp), [OQ] "v"(oq_off), [SCALE] "s"(scale), [QMAX] "s"(cp_max),               \
+                       [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)                       \
+                     : "vcc", "memory", "s54", "s55", "s56", "s57", "v100", "v101", "v102", "v103", "v104", "v105", \
+                       "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", \
+                       "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", \
+                       "v130", "v131", "v132"
+        if constexpr (kFreeze) {
+          asm volatile(TFC_LDEC_BLOCK(TFC_LDEC_ESC1_FREEZE, TFC_LDEC_ESC2_FREEZE) TFC_LDEC_OPERANDS);
+        } else {
+          asm volatile(TFC_LDEC_BLOCK(TFC_LDEC_ESC1_PLAIN, TFC_LDEC_ESC2_PLAIN) TFC_LDEC_OPERANDS);
+          cnt = kDecCadence;
+        }
+#undef TFC_LDEC_OPERANDS
       }
-      if (!__any(flag != 0u)) {
+      if (__builtin_expect(!__any(flag != 0u), 1)) {
+        if (__builtin_expect(!__any(j < elems && cnt != kDecCadence), 1)) {
+          if (j < elems) {
+            j += kDecCadence;
+            ko = kDecCadence * kEs;
+            dirp += dir_step;                        // kDecCadence entries further, modulo the table count
+            dirp -= dirp >= dir_end ? dir_end : 0u;
+          }
+          continue;
+        }
+        // some lanes met an escape symbol after `cnt` symbols: their Elias-gamma bits now, in a loop of
+        // bit steps only (the other lanes wait: ~10 short steps), then everybody goes on from its own j
         if (j < elems) {
-          j += kDecCadence;
-          ko = kDecCadence * kEs;
-          dirp += dir_step;                          // kDecCadence entries further, modulo the table count
-          dirp -= dirp >= dir_end ? dir_end : 0u;
+          j += cnt;
+          ko = cnt * kEs;
+          dirp += 16u * cnt;
+          if (cnt != kDecCadence) {
+            mode = 1u;
+            nb = 0u;
+            esc_limit = *reinterpret_cast<const unsigned int*>(lanes_lds + dirp + 4u) & 0x7FFFFFFFu;
+          }
+        }
+        while (__any(j < elems && dirp >= dir_end)) dirp -= dirp >= dir_end ? dir_end : 0u;
+        // ... as long as the lane stays within the kDecCadence digits a phase may consume (a long code
+        // behind a run of rare symbols finishes in the generic steps of the next phase)
+        while (__any(j < elems && mode != 0u && cp - cp0 < 2u * kDecCadence)) {
+          if (cp - cp0 < 2u * kDecCadence) bit_step();
         }
         continue;
       }
@@ -879,7 +1015,11 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
     }
 #pragma nounroll
     for (unsigned int k = 0; k < kDecCadence; ++k) step();
+    if (kFastBlock && !kFreeze && __any(saw_escape != 0u)) return;         // escapes are to be expected from here on
   }
+  };
+  run(std::false_type{});
+  if constexpr (kFastBlock) run(std::true_type{});
   flush();
 
   if (live) {

@@ -105,6 +105,26 @@ def test_dense_long_escapes(tfc, golden, port):
         assert got3 == port.encode(lookup, value, calls=3)[0]
 
 
+def test_rare_symbols_and_long_escapes(tfc, port):
+    """Precision-16 tables whose plain symbols have probability 2^-16 (one 16-bit digit per symbol) mixed
+    with escape codes of up to 60 bits.  In the one-lane-per-stream kernels a lane that meets an escape
+    finishes the code right behind its 8-step block only while the digits of that phase fit its staging
+    area / code window; here they often do not, and the code goes on behind the next memory phase."""
+    cdf = list(range(0, 9)) + [65535, 65536]          # symbols 0..7: width 1; 8: the bulk; 9: the escape bucket
+    lookup = np.array([[-16] + cdf, [-16] + cdf], np.int32)
+    rng = np.random.default_rng(77)
+    for streams, elems, p_esc, p_bulk in ((70, 900, 0.15, 0.1), (130, 400, 0.5, 0.0), (64, 1200, 0.03, 0.6)):
+        rare = rng.integers(0, 8, (streams, elems))
+        big = rng.integers(9, 1 << 30, (streams, elems)) * rng.choice([-1, 1], (streams, elems))
+        u = rng.random((streams, elems))
+        value = np.where(u < p_esc, big, np.where(u < p_esc + p_bulk, 8, rare)).astype(np.int32)
+        want = port.encode(lookup, value)[0]
+        got, _ = hip_encode(tfc, lookup, value)
+        assert got == want, (streams, elems)
+        d, ok = hip_decode(tfc, lookup, got, elems)
+        assert (d == value).all() and ok.all()
+
+
 def test_small_shapes_both_modes(tfc, golden, port):
     """Stream counts that do not fill a wave / a workgroup, lengths around the kernels' batch sizes,
     index mode, escape codes at several densities, and several calls on one handle."""
