@@ -613,12 +613,77 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
           dirp = dirp + 16u == dir_end ? 0u : dirp + 16u;
         }
         call(lo, hi, stopped);
-        while (__any(qn != 0u && n + 4u <= kEncDigitBytes)) {
-          const bool on = qn != 0u && n + 4u <= kEncDigitBytes;
-          qn -= on ? 1u : 0u;
-          const unsigned int sft = qn - 1u;      // qn = 0: the sign
-          const unsigned int bit = qn == 0u ? neg : (sft < 32u ? (g >> sft) & 1u : 0u);
-          call(bit << 15, (bit + 1u) << 15, on);
+        // The bits: one call per round on [0, 2^15) or [2^15, 2^16), i.e. a = 0 / half, b = half - 1 / s1 with
+        // half = (s1 + 1) >> 1; the interval update is the block's (TFC_LENC_B).  Hand-written: the compiler's
+        // version of this loop takes about twice the instructions.  EXEC drops a lane when its code is
+        // complete or its digit area has no room for two more digits; a lane with a carry run pending
+        // (pb != 0: its resolution may need put_run) does not enter / leaves and goes on in the generic steps.
+        if (qn != 0u && n + 4u <= kEncDigitBytes && pb == 0u) {
+          unsigned int na2 = ds_off + n;
+          asm volatile(
+              "s_mov_b64 s[56:57], exec\n\t"
+              "v_mov_b32 v108, %[G]\n\t"
+              "v_mov_b32 v109, 0\n\t"
+              "1:\n\t"
+              "v_add_u32 %[QN], -1, %[QN]\n\t"
+              "v_add_u32 v110, -1, %[QN]\n\t"
+              "v_lshrrev_b64 v[110:111], v110, v[108:109]\n\t"       // bit qn - 1 of g (0 from bit 32 on)
+              "v_and_b32 v110, 1, v110\n\t"
+              "v_cmp_eq_u32 vcc, 0, %[QN]\n\t"
+              "v_cndmask_b32 v110, v110, %[NEG], vcc\n\t"            // ... the sign at the end
+              "v_lshrrev_b32 v101, 1, %[S]\n\t"
+              "v_and_b32 v102, 1, %[S]\n\t"
+              "v_add_u32 v101, v101, v102\n\t"                       // half
+              "v_cmp_ne_u32 vcc, 0, v110\n\t"
+              "v_cndmask_b32 v160, 0, v101, vcc\n\t"                 // a
+              "v_add_u32 v162, -1, v101\n\t"
+              "v_cndmask_b32 v162, v162, %[S], vcc\n\t"              // b
+              "v_add_co_u32 v164, vcc, %[BASE], v160\n\t"
+              "v_addc_co_u32 v167, vcc, -1, %[PD], vcc\n\t"
+              "v_sub_u32 v165, v162, v160\n\t"
+              "v_add_co_u32 v166, vcc, v164, v165\n\t"
+              "v_cndmask_b32 v168, %[PD], %[DIR0], vcc\n\t"
+              "v_cndmask_b32 v173, 1, 0, vcc\n\t"
+              "v_perm_b32 v167, 0, v167, %[PERM]\n\t"
+              "ds_write_b16 %[NA], v167\n\t"
+              "v_min_u32 v169, 1, v168\n\t"
+              "v_lshl_add_u32 %[NA], v169, 1, %[NA]\n\t"
+              "v_sub_u32 %[PD], %[PD], v168\n\t"
+              "v_cmp_gt_u32 vcc, %[K64K], v165\n\t"
+              "v_lshlrev_b32 v168, 16, v164\n\t"
+              "v_lshl_or_b32 v169, v165, 16, %[KFFFF]\n\t"
+              "v_cndmask_b32 %[BASE], v164, v168, vcc\n\t"
+              "v_cndmask_b32 %[S], v165, v169, vcc\n\t"
+              "v_cndmask_b32 v174, 0, 1, vcc\n\t"
+              "v_add_co_u32 v166, vcc, %[BASE], %[S]\n\t"
+              "v_lshrrev_b32 v169, 16, v164\n\t"
+              "v_and_b32 v168, v174, v173\n\t"
+              "v_cndmask_b32 v175, 1, 0, vcc\n\t"
+              "v_sub_u32 v174, v174, v168\n\t"
+              "v_lshl_add_u32 %[PB], v174, 1, %[PB]\n\t"
+              "v_perm_b32 v166, 0, v169, %[PERM]\n\t"
+              "ds_write_b16 %[NA], v166\n\t"
+              "v_and_b32 v175, v168, v175\n\t"
+              "v_lshl_add_u32 %[NA], v175, 1, %[NA]\n\t"
+              "v_sub_u32 v168, v168, v175\n\t"
+              "v_add_u32 v169, 1, v169\n\t"
+              "v_mad_u32_u24 %[PD], v168, v169, %[PD]\n\t"
+              "v_cmp_ne_u32 s[54:55], 0, %[QN]\n\t"
+              "v_sub_u32 v107, %[NA], %[DSOFF]\n\t"
+              "v_cmp_ge_u32 vcc, %[ROOM], v107\n\t"
+              "s_and_b64 s[54:55], s[54:55], vcc\n\t"
+              "v_cmp_eq_u32 vcc, 0, %[PB]\n\t"
+              "s_and_b64 s[54:55], s[54:55], vcc\n\t"
+              "s_and_b64 exec, exec, s[54:55]\n\t"
+              "s_cbranch_execnz 1b\n\t"
+              "s_mov_b64 exec, s[56:57]\n\t"
+              "s_waitcnt lgkmcnt(0)\n\t"
+              : [BASE] "+v"(base), [S] "+v"(s1), [PD] "+v"(pd), [PB] "+v"(pb), [NA] "+v"(na2), [QN] "+v"(qn)
+              : [G] "v"(g), [NEG] "v"(neg), [DSOFF] "v"(ds_off), [DIR0] "v"(0u), [ROOM] "s"(kEncDigitBytes - 4u),
+                [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
+              : "vcc", "memory", "s54", "s55", "s56", "s57", "v101", "v102", "v107", "v108", "v109", "v110", "v111",
+                "v160", "v162", "v164", "v165", "v166", "v167", "v168", "v169", "v173", "v174", "v175");
+          n = na2 - ds_off;
         }
         continue;
       }
@@ -1004,10 +1069,84 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
           }
         }
         while (__any(j < elems && dirp >= dir_end)) dirp -= dirp >= dir_end ? dir_end : 0u;
-        // ... as long as the lane stays within the kDecCadence digits a phase may consume (a long code
-        // behind a run of rare symbols finishes in the generic steps of the next phase)
-        while (__any(j < elems && mode != 0u && cp - cp0 < 2u * kDecCadence)) {
-          if (cp - cp0 < 2u * kDecCadence) bit_step();
+        // The code as a bit string: z zeros, the z + 1 bits of the magnitude, the sign.  acc collects the
+        // bits behind the zeros, k counts all of them; the code is complete at k = 2 z + 2.  A lane stays
+        // in the loop (hand-written: the compiler's version of it takes twice the instructions) while the
+        // digits of this phase fit its code window; a long code behind a run of rare symbols goes on in
+        // the generic steps of the next phase, and so does a damaged one with 31 zeros.
+        {
+          unsigned int acc = 0u, k = 0u, z = 0u;
+          const bool pending = j < elems && mode != 0u;
+          const bool in = pending && cp - cp0 < 2u * kDecCadence;
+          if (in) {
+            // One binary call per round (the uniform cdf {0, 1, 2} at precision 1,
+            // range_coder_kernels.cc:449-471): half = B of the first interval = (s1 + 1) >> 1.  With acc = 0
+            // z follows k, so k = 2 z + 2 only happens with the leading one in acc.  EXEC drops a lane when
+            // its code is complete, its digits would leave the window, or it has seen 31 zeros.
+            asm volatile(
+                "s_mov_b64 s[56:57], exec\n\t"
+                "1:\n\t"
+                "ds_read_u16 v100, %[CP]\n\t"
+                "v_lshrrev_b32 v101, 1, %[S]\n\t"
+                "v_and_b32 v102, 1, %[S]\n\t"
+                "v_add_u32 v101, v101, v102\n\t"              // half
+                "v_cmp_ge_u32 vcc, %[D], v101\n\t"            // the bit
+                "v_cndmask_b32 v103, 0, v101, vcc\n\t"        // A
+                "v_add_u32 v104, -1, v101\n\t"
+                "v_cndmask_b32 v104, v104, %[S], vcc\n\t"     // B - 1
+                "v_sub_u32 %[D], %[D], v103\n\t"
+                "v_sub_u32 v104, v104, v103\n\t"              // span' - 1
+                "v_cndmask_b32 v105, 0, 1, vcc\n\t"
+                "v_lshl_or_b32 %[ACC], %[ACC], 1, v105\n\t"
+                "v_add_u32 %[K], 1, %[K]\n\t"
+                "v_cmp_gt_u32 vcc, %[K64K], v104\n\t"         // renormalise
+                "v_lshl_or_b32 v106, v104, 16, %[KFFFF]\n\t"
+                "v_cndmask_b32 %[S], v104, v106, vcc\n\t"
+                "v_cndmask_b32 v106, 0, 2, vcc\n\t"
+                "v_add_u32 %[CP], %[CP], v106\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_perm_b32 v100, 0, v100, %[PERM]\n\t"
+                "v_lshl_or_b32 v106, %[D], 16, v100\n\t"
+                "v_cndmask_b32 %[D], %[D], v106, vcc\n\t"
+                "v_cmp_eq_u32 vcc, 0, %[ACC]\n\t"
+                "v_cndmask_b32 %[Z], %[Z], %[K], vcc\n\t"
+                "v_lshl_add_u32 v107, %[Z], 1, 2\n\t"
+                "v_cmp_ne_u32 s[54:55], %[K], v107\n\t"       // code not complete
+                "v_sub_u32 v107, %[CP], %[CP0]\n\t"
+                "v_cmp_gt_u32 vcc, 16, v107\n\t"              // digits of this phase < kDecCadence
+                "s_and_b64 s[54:55], s[54:55], vcc\n\t"
+                "v_cmp_ne_u32 vcc, 31, %[Z]\n\t"
+                "s_and_b64 s[54:55], s[54:55], vcc\n\t"
+                "s_and_b64 exec, exec, s[54:55]\n\t"
+                "s_cbranch_execnz 1b\n\t"
+                "s_mov_b64 exec, s[56:57]\n\t"
+                : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [ACC] "+v"(acc), [K] "+v"(k), [Z] "+v"(z)
+                : [CP0] "v"(cp0), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
+                : "vcc", "memory", "s54", "s55", "s56", "s57", "v100", "v101", "v102", "v103", "v104", "v105",
+                  "v106", "v107");
+          }
+          const bool fin = in && k == 2u * z + 2u;
+          if (fin) {
+            const unsigned int val = acc >> 1;
+            const int outv = (acc & 1u) ? -static_cast<int>(val) : static_cast<int>(val) + static_cast<int>(esc_limit) - 1;
+            *reinterpret_cast<Elem*>(outq + ko) = dst.make(static_cast<int>(dirp >> 4), outv);
+            ko += kEs;
+            ++j;
+            mode = 0u;
+            dirp = dirp + 16u == dir_end ? 0u : dirp + 16u;
+          } else if (pending) {
+            // unfinished: over to the generic steps' form (mode, bits to go, value so far)
+            if (acc == 0u) {
+              mode = k == 31u ? 2u : 1u;
+              nb = k;
+              val = 1u << 31;
+            } else {
+              const unsigned int togo = z - (k - z - 1u);       // magnitude bits still to come
+              mode = togo != 0u ? 2u : 3u;
+              nb = togo;
+              val = acc << togo;
+            }
+          }
         }
         continue;
       }
