@@ -17,8 +17,14 @@ namespace tfc {
 // The second contraction runs in two halves of the output tiles to stay under 256 VGPRs.
 // LDS: [image of Gamma^T | image of Gamma | beta].
 // ---------------------------------------------------------------------------
+#ifndef TFC_GDN_BWD_THREADS
+#define TFC_GDN_BWD_THREADS 512
+#endif
+#ifndef TFC_GDN_BWD_SPLIT1
+#define TFC_GDN_BWD_SPLIT1 1
+#endif
 template <int KT, bool PLAIN>
-__global__ void __launch_bounds__(512) gdn_bwd_fused_bf16_kernel(GdnParams p) {
+__global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel(GdnParams p) {
   constexpr int C = KT * 32;
   constexpr int KS = KT * 2;
   constexpr int IMG = KT * KS * 64;       // fragments per image
@@ -67,96 +73,109 @@ __global__ void __launch_bounds__(512) gdn_bwd_fused_bf16_kernel(GdnParams p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) xr[s] = frag_load(x, s);
 
-    // ---- contraction 1: n = beta + U Gamma ----
-    f32x16 acc[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      u32x4 u = xr[s];
-      if (PLAIN) {
-        u &= 0x7FFF7FFFu;
-      } else {
-        asm volatile("" : "+v"(u));   // no CSE of this unpack with the epilogues' (live-range bloat)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const float lo = fmaxf(bf16_bits_to_float(u[w] & 0xFFFFu), p.relu_floor);
-          const float hi = fmaxf(__uint_as_float(u[w] & 0xFFFF0000u), p.relu_floor);
-          u[w] = pack_bf16(gdn_u(lo, p.a2), gdn_u(hi, p.a2));
-        }
-      }
-      const bf16x8 b = __builtin_bit_cast(bf16x8, u);
-      // g is fetched late (its 48 registers do not fit next to x, the accumulators and the A
-      // fragments for the whole contraction): the loads fly under the last K-steps' MFMAs.
-      if (s == (KS > 3 ? KS - 3 : 0)) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) gr[k] = frag_load(g, k);
-      }
-#pragma unroll
-      for (int t = 0; t < KT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[(t * KS + s) * 64 + lane], b, acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // n = acc + beta, in place and ahead of the variant switch (the loads are common to the four
-    // variants; left inside, they are hoisted above the switch all at once: 96 registers)
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][4 * q + r] += b4[r];
-      }
-      // pin the sums here: IR-level sinking would otherwise keep the beta loads live and
-      // redo the add at each use
-      asm volatile("" : "+v"(acc[t]));
-    }
-    // ---- T (overwrites g in registers) and R (kept packed) ----
+    // ---- contraction 1: n = beta + U Gamma, and T / R from it; in two groups of output tiles
+    // (TFC_GDN_BWD_SPLIT1: all of n at once needs 96 accumulator registers next to x, g and R
+    // and spills ~60 registers per lane to scratch: +1 tensor of HBM writes and reads) ----
     u32x4 rr[KS];
-    auto pass1 = [&](auto inv, auto epsh) {
-      constexpr bool INV = decltype(inv)::value, EPSH = decltype(epsh)::value;
+    constexpr int H0 = TFC_GDN_BWD_SPLIT1 ? (KT + 1) / 2 : KT;
+#pragma unroll
+    for (int grp = 0; grp < (TFC_GDN_BWD_SPLIT1 ? 2 : 1); ++grp) {
+      const int t0 = grp == 0 ? 0 : H0;
+      const int nt = grp == 0 ? H0 : KT - H0;
+      if (nt <= 0) continue;
+      f32x16 acc[H0];
+#pragma unroll
+      for (int t = 0; t < H0; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const int t = s >> 1;
-        u32x4 tq, rq;
-        // Opaque copies: without them the unpacking of all 2 x 96 elements, identical in the four
-        // variants, is hoisted above the variant switch and costs ~190 live registers.
-        u32x4 xs = xr[s], gs = gr[s];
-        asm volatile("" : "+v"(xs), "+v"(gs));
+        u32x4 u = xr[s];
+        if (PLAIN) {
+          u &= 0x7FFF7FFFu;
+        } else {
+          asm volatile("" : "+v"(u));   // no CSE of this unpack with the epilogues' (live-range bloat)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int q = 2 * (s & 1) + half;
-          float tv[4], rv[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float xv = elem(xs, half, r);
-            if (!PLAIN) xv = fmaxf(xv, p.relu_floor);
-            const float gv = elem(gs, half, r);
-            float pw, c;
-            gdn_grad_factors<INV, EPSH>(acc[t][4 * q + r], &pw, &c);
-            tv[r] = c * gv * xv;
-            rv[r] = gv * pw;
+          for (int w = 0; w < 4; ++w) {
+            const float lo = fmaxf(bf16_bits_to_float(u[w] & 0xFFFFu), p.relu_floor);
+            const float hi = fmaxf(__uint_as_float(u[w] & 0xFFFF0000u), p.relu_floor);
+            u[w] = pack_bf16(gdn_u(lo, p.a2), gdn_u(hi, p.a2));
           }
-          tq[2 * half] = pack_bf16(tv[0], tv[1]);
-          tq[2 * half + 1] = pack_bf16(tv[2], tv[3]);
-          rq[2 * half] = pack_bf16(rv[0], rv[1]);
-          rq[2 * half + 1] = pack_bf16(rv[2], rv[3]);
         }
-        // pin T and R as packed words now (otherwise R = g * pw is sunk to its use in the dx
-        // epilogue and the unpacked pw / g floats stay live across the second contraction)
-        asm volatile("" : "+v"(tq), "+v"(rq));
-        gr[s] = tq;
-        rr[s] = rq;
+        const bf16x8 b = __builtin_bit_cast(bf16x8, u);
+        // g is fetched late (its 48 registers do not fit next to x, the accumulators and the A
+        // fragments for the whole contraction): the loads fly under the last K-steps' MFMAs.
+        if (grp == 0 && s == (KS > 3 ? KS - 3 : 0)) {
+#pragma unroll
+          for (int k = 0; k < KS; ++k) gr[k] = frag_load(g, k);
+        }
+#pragma unroll
+        for (int t = 0; t < H0; ++t)
+          if (t < nt)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[((t0 + t) * KS + s) * 64 + lane], b, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    };
-    using TT = std::true_type;
-    using FF = std::false_type;
-    if (p.inverse) {
-      if (p.eps_half) pass1(TT{}, TT{}); else pass1(TT{}, FF{});
-    } else {
-      if (p.eps_half) pass1(FF{}, TT{}); else pass1(FF{}, FF{});
+      // n = acc + beta, in place and ahead of the variant switch (the loads are common to the four
+      // variants; left inside, they are hoisted above the switch all at once)
+#pragma unroll
+      for (int t = 0; t < H0; ++t) {
+        if (t >= nt) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * (t0 + t) + 8 * q + 4 * h);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][4 * q + r] += b4[r];
+        }
+        // pin the sums here: IR-level sinking would otherwise keep the beta loads live and
+        // redo the add at each use
+        asm volatile("" : "+v"(acc[t]));
+      }
+      // ---- T (overwrites g in registers) and R (kept packed) ----
+      auto pass1 = [&](auto inv, auto epsh) {
+        constexpr bool INV = decltype(inv)::value, EPSH = decltype(epsh)::value;
+#pragma unroll
+        for (int sl = 0; sl < 2 * H0; ++sl) {
+          if (sl >= 2 * nt) continue;
+          const int s = 2 * t0 + sl;
+          const int t = sl >> 1;
+          u32x4 tq, rq;
+          // Opaque copies: without them the unpacking of all elements, identical in the four
+          // variants, is hoisted above the variant switch and costs ~190 live registers.
+          u32x4 xs = xr[s], gs = gr[s];
+          asm volatile("" : "+v"(xs), "+v"(gs));
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int q = 2 * (s & 1) + half;
+            float tv[4], rv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float xv = elem(xs, half, r);
+              if (!PLAIN) xv = fmaxf(xv, p.relu_floor);
+              const float gv = elem(gs, half, r);
+              float pw, c;
+              gdn_grad_factors<INV, EPSH>(acc[t][4 * q + r], &pw, &c);
+              tv[r] = c * gv * xv;
+              rv[r] = gv * pw;
+            }
+            tq[2 * half] = pack_bf16(tv[0], tv[1]);
+            tq[2 * half + 1] = pack_bf16(tv[2], tv[3]);
+            rq[2 * half] = pack_bf16(rv[0], rv[1]);
+            rq[2 * half + 1] = pack_bf16(rv[2], rv[3]);
+          }
+          // pin T and R as packed words now (otherwise R = g * pw is sunk to its use in the dx
+          // epilogue and the unpacked pw / g floats stay live across the second contraction)
+          asm volatile("" : "+v"(tq), "+v"(rq));
+          gr[s] = tq;
+          rr[s] = rq;
+        }
+      };
+      using TT = std::true_type;
+      using FF = std::false_type;
+      if (p.inverse) {
+        if (p.eps_half) pass1(TT{}, TT{}); else pass1(TT{}, FF{});
+      } else {
+        if (p.eps_half) pass1(FF{}, TT{}); else pass1(FF{}, FF{});
+      }
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) frag_store(tout, s, gr[s]);
@@ -425,7 +444,7 @@ int launch_gdn_bwd_fused_variant(GdnParams p, hipStream_t st) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const long long want = ceil_div(p.tiles, 8);
+  const long long want = ceil_div(p.tiles, TFC_GDN_BWD_THREADS / 64);
   const unsigned blocks = static_cast<unsigned>(std::max<long long>(1, std::min<long long>(want, cus)));
   constexpr int IMG = KT * KT * 2 * 64;
   const size_t lds = sizeof(bf16x8) * 2 * IMG + sizeof(float) * KT * 32;
@@ -440,7 +459,7 @@ int launch_gdn_bwd_fused_variant(GdnParams p, hipStream_t st) {
   KernelTimer timer("gdn_backward_fused", st);
   TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_bwd_fused_bf16_kernel<KT, PLAIN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-  hipLaunchKernelGGL((gdn_bwd_fused_bf16_kernel<KT, PLAIN>), dim3(blocks), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((gdn_bwd_fused_bf16_kernel<KT, PLAIN>), dim3(blocks), dim3(TFC_GDN_BWD_THREADS), lds, st, p);
   TFC_HIP(hipGetLastError());
   return 0;
 }
