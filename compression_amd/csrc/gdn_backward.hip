@@ -17,11 +17,22 @@ namespace tfc {
 // The second contraction runs in two halves of the output tiles to stay under 256 VGPRs.
 // LDS: [image of Gamma^T | image of Gamma | beta].
 // ---------------------------------------------------------------------------
+// Build-time variants of the fused kernel, measured on C3 ([262144, 192] bf16, MI355X; tools/gdn_bwd_variants.sh,
+// profiles/r02_notes.md): 512 threads, n all at once (round 1): 143 us, 62 registers per lane spilled to scratch
+// (+1.2 tensors of HBM reads and +1.1 of writes); 512 threads, n in two groups: 108 us, no spills; 256 threads
+// (512 registers per lane, one wave per SIMD) + next tile's x, g prefetched: 105 us; + A fragments one K-step
+// ahead: 100 us (spills at 512 threads).
 #ifndef TFC_GDN_BWD_THREADS
-#define TFC_GDN_BWD_THREADS 512
+#define TFC_GDN_BWD_THREADS 256
 #endif
 #ifndef TFC_GDN_BWD_SPLIT1
 #define TFC_GDN_BWD_SPLIT1 1
+#endif
+#ifndef TFC_GDN_BWD_PREFETCH
+#define TFC_GDN_BWD_PREFETCH 1
+#endif
+#ifndef TFC_GDN_BWD_APIPE
+#define TFC_GDN_BWD_APIPE 1
 #endif
 template <int KT, bool PLAIN>
 __global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel(GdnParams p) {
@@ -49,20 +60,41 @@ __global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel
   unsigned short* tout = static_cast<unsigned short*>(p.y2);
   unsigned short* dx = static_cast<unsigned short*>(p.y);
 
-  for (long long tile = wave; tile < p.tiles; tile += nwaves) {
+  // TFC_GDN_BWD_PREFETCH: x and g of the wave's NEXT tile are requested (raw, 96 registers) before the
+  // work on the current one starts; needs the 512-register budget of a 256-thread block.
+  auto row_of = [&](long long tile) -> long long {
+    const long long pix = tile * 32 + (lane & 31);
+    return (pix < p.pixels ? pix : p.pixels - 1) * C;
+  };
+  auto to_frag = [&](const u32x4& v) -> u32x4 {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+    return u32x4{s0[0], s1[0], s0[1], s1[1]};
+  };
+  u32x4 xn[KS], gn[KS];
+  if (TFC_GDN_BWD_PREFETCH && wave < p.tiles) {
+    const long long row1 = row_of(wave);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xn[s] = *reinterpret_cast<const u32x4*>(x + row1 + 16 * s + 8 * h);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) gn[s] = *reinterpret_cast<const u32x4*>(g + row1 + 16 * s + 8 * h);
+  }
+
+  auto one_tile = [&](const long long tile) __attribute__((always_inline)) {
     const long long pix = tile * 32 + (lane & 31);
     const bool live = pix < p.pixels;
     const long long row = (live ? pix : p.pixels - 1) * C;
     auto frag_load = [&](const unsigned short* base, int s) -> u32x4 {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(base + row + 16 * s + 8 * h);
-      const auto s0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
-      return u32x4{s0[0], s1[0], s0[1], s1[1]};
+      return to_frag(*reinterpret_cast<const u32x4*>(base + row + 16 * s + 8 * h));
     };
     auto frag_store = [&](unsigned short* base, int s, u32x4 out) {
       const auto s0 = __builtin_amdgcn_permlane32_swap(out.x, out.z, false, false);
       const auto s1 = __builtin_amdgcn_permlane32_swap(out.y, out.w, false, false);
-      if (live) *reinterpret_cast<u32x4*>(base + row + 16 * s + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      // unconditional: lanes past the end hold a copy of the last pixel (clamped row) and store the same
+      // values to the same place.  A store under `if (live)` is a branch around it, and the compiler's
+      // s_waitcnt for the prefetched loads then assumes the path WITHOUT the stores behind them: it waits
+      // for everything in flight at the top of every tile.
+      *reinterpret_cast<u32x4*>(base + row + 16 * s + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
     };
     auto elem = [&](const u32x4& f, int half, int r) -> float {
       const unsigned int word = f[2 * half + (r >> 1)];
@@ -70,8 +102,22 @@ __global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel
     };
     u32x4 xr[KS], gr[KS];
     asm volatile("" ::: "memory");   // keep the (tile-invariant) LDS fragment loads inside the loop
+    if (TFC_GDN_BWD_PREFETCH) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xr[s] = frag_load(x, s);
+      for (int s = 0; s < KS; ++s) xr[s] = to_frag(xn[s]);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) gr[s] = to_frag(gn[s]);
+      if (tile + nwaves < p.tiles) {
+        const long long row1 = row_of(tile + nwaves);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xn[s] = *reinterpret_cast<const u32x4*>(x + row1 + 16 * s + 8 * h);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) gn[s] = *reinterpret_cast<const u32x4*>(g + row1 + 16 * s + 8 * h);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xr[s] = frag_load(x, s);
+    }
 
     // ---- contraction 1: n = beta + U Gamma, and T / R from it; in two groups of output tiles
     // (TFC_GDN_BWD_SPLIT1: all of n at once needs 96 accumulator registers next to x, g and R
@@ -84,6 +130,7 @@ __global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel
       const int nt = grp == 0 ? H0 : KT - H0;
       if (nt <= 0) continue;
       f32x16 acc[H0];
+      bf16x8 a_cur[H0], a_nxt[H0];
 #pragma unroll
       for (int t = 0; t < H0; ++t)
 #pragma unroll
@@ -105,14 +152,31 @@ __global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel
         const bf16x8 b = __builtin_bit_cast(bf16x8, u);
         // g is fetched late (its 48 registers do not fit next to x, the accumulators and the A
         // fragments for the whole contraction): the loads fly under the last K-steps' MFMAs.
-        if (grp == 0 && s == (KS > 3 ? KS - 3 : 0)) {
+        if (!TFC_GDN_BWD_PREFETCH && grp == 0 && s == (KS > 3 ? KS - 3 : 0)) {
 #pragma unroll
           for (int k = 0; k < KS; ++k) gr[k] = frag_load(g, k);
         }
+        if (TFC_GDN_BWD_APIPE) {
+          // A fragments one K-step ahead: their LDS latency runs under this step's MFMAs
+          if (s == 0) {
 #pragma unroll
-        for (int t = 0; t < H0; ++t)
-          if (t < nt)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[((t0 + t) * KS + s) * 64 + lane], b, acc[t], 0, 0, 0);
+            for (int t = 0; t < H0; ++t) if (t < nt) a_nxt[t] = afrag[((t0 + t) * KS) * 64 + lane];
+          }
+#pragma unroll
+          for (int t = 0; t < H0; ++t) a_cur[t] = a_nxt[t];
+          if (s + 1 < KS) {
+#pragma unroll
+            for (int t = 0; t < H0; ++t) if (t < nt) a_nxt[t] = afrag[((t0 + t) * KS + s + 1) * 64 + lane];
+          }
+#pragma unroll
+          for (int t = 0; t < H0; ++t)
+            if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[t], b, acc[t], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int t = 0; t < H0; ++t)
+            if (t < nt)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[((t0 + t) * KS + s) * 64 + lane], b, acc[t], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       // n = acc + beta, in place and ahead of the variant switch (the loads are common to the four
@@ -191,14 +255,31 @@ __global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel
       for (int t = 0; t < G0; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+      bf16x8 a2_cur[G0], a2_nxt[G0];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, gr[s]);
+        if (TFC_GDN_BWD_APIPE) {
+          if (s == 0) {
 #pragma unroll
-        for (int t = 0; t < G0; ++t)
-          if (t < nt)
-            acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag2[((t0 + t) * KS + s) * 64 + lane], b,
-                                                               acc2[t], 0, 0, 0);
+            for (int t = 0; t < G0; ++t) if (t < nt) a2_nxt[t] = bfrag2[((t0 + t) * KS) * 64 + lane];
+          }
+#pragma unroll
+          for (int t = 0; t < G0; ++t) a2_cur[t] = a2_nxt[t];
+          if (s + 1 < KS) {
+#pragma unroll
+            for (int t = 0; t < G0; ++t) if (t < nt) a2_nxt[t] = bfrag2[((t0 + t) * KS + s + 1) * 64 + lane];
+          }
+#pragma unroll
+          for (int t = 0; t < G0; ++t)
+            if (t < nt) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_cur[t], b, acc2[t], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int t = 0; t < G0; ++t)
+            if (t < nt)
+              acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag2[((t0 + t) * KS + s) * 64 + lane], b,
+                                                                 acc2[t], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -228,6 +309,17 @@ __global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) frag_store(dx, s, rr[s]);
+  };
+  if (TFC_GDN_BWD_PREFETCH) {
+    // The first tile apart: the loop is then entered with the same memory operations in flight as it is
+    // repeated with (the next tile's loads, then this tile's stores), and the compiler's s_waitcnt for the
+    // loads at the top of an iteration leaves the stores behind them alone.
+    if (wave < p.tiles) {
+      one_tile(wave);
+      for (long long tile = wave + nwaves; tile < p.tiles; tile += nwaves) one_tile(tile);
+    }
+  } else {
+    for (long long tile = wave; tile < p.tiles; tile += nwaves) one_tile(tile);
   }
 }
 

@@ -6,10 +6,12 @@ cp compression_amd/libtfc_hip.so /tmp/libtfc_hip.keep
 for v in ab/*/; do
   cp $v/libtfc_hip.so compression_amd/libtfc_hip.so
   echo "== $(basename $v)"
-  timeout -s KILL 120 python - <<'PY'
+  timeout -s KILL 300 python - <<'PY'
 import torch, bench
 r = bench.gdn_forward_bandwidth(torch.device("cuda:0"), steps=30)
 print(r["backward"])
+import subprocess, sys
+sys.exit(subprocess.call([sys.executable, "-m", "pytest", "tests/test_gdn_gpu.py", "-m", "gpu", "-x", "-q"]))
 PY
 done
 cp /tmp/libtfc_hip.keep compression_amd/libtfc_hip.so

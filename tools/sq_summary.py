@@ -41,6 +41,8 @@ def main():
     del rows["_sources"]
     cols = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS",
             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU"]
+    seen = {c for r in rows.values() for c in r}
+    cols = [c for c in cols if c in seen] + sorted(c for c in seen if c.startswith("SQ_") and c not in cols)
     lines = ["# SQ counters per kernel (rocprofv3 --pmc, one pass; *_CYCLES / ACTIVE / WAIT in quad-cycles summed over waves)",
              "", "| kernel | launches | duration us | " + " | ".join(cols) + " |", "|---|---:|---:|" + "---:|" * len(cols)]
     for name in sorted(rows, key=lambda k: -rows[k].get("SQ_WAVE_CYCLES", 0))[:12]:
