@@ -336,8 +336,16 @@ __global__ void __launch_bounds__(TFC_GDN_BWD_THREADS) gdn_bwd_fused_bf16_kernel
 constexpr int PG_PIX = 64;        // pixels per LDS stage
 constexpr int PG_STRIDE = 72;     // bf16 elements per transposed LDS row (144 B: b128 reads conflict-free)
 
+// Workgroups per CU the kernel is built for.  Two (bf16, up to 192 channels: 7 registers spill) were measured
+// SLOWER on C3, 97 us against 82 us: twice the block partials to write and to reduce outweigh the overlap
+// of the two barriers per stage.
+#ifndef TFC_GDN_PG_WGS
+#define TFC_GDN_PG_WGS 1
+#endif
 template <typename T, int KT>
-__global__ void __launch_bounds__(256) gdn_param_grad_kernel(GdnParams p, float* partial) {
+constexpr int pg_wgs() { return (sizeof(T) == 2 && KT <= 6) ? TFC_GDN_PG_WGS : 1; }
+template <typename T, int KT>
+__global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(GdnParams p, float* partial) {
   constexpr int C = KT * 32;
   constexpr int NH = (KT + 1) / 2;
   constexpr bool BF = sizeof(T) == 2;
@@ -516,7 +524,7 @@ int launch_param_grad(GdnParams p, float* dgamma, float* dbeta, hipStream_t st) 
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const long long stages = ceil_div(p.pixels, static_cast<long long>(PG_PIX));
-  const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(stages, cus)));
+  const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(stages, pg_wgs<T, KT>() * cus)));
   const size_t lds = sizeof(T) == 2 ? sizeof(unsigned short) * 2 * C * PG_STRIDE : sizeof(float) * 2 * PG_PIX * C;
   DevBuf partial;
   TFC_HIP(partial.alloc(sizeof(float) * static_cast<size_t>(blocks) * (C * C + C), st));
