@@ -1,13 +1,22 @@
 // GDN / IGDN forward entry point (kernels: gdn_common.h).
 #include "gdn_common.h"
 
-extern "C" int tfc_gdn_forward(const void* x, void* y, int dtype, int64_t pixels, int64_t channels,
-                               const float* beta, const float* gamma, int inverse, int rectify,
-                               int alpha_mode, int eps_mode, void* stream) {
+#include <cmath>
+
+namespace {
+int gdn_forward_any(const void* x, void* y, int dtype, int64_t pixels, int64_t channels, const float* beta,
+                    const float* gamma, int inverse, int rectify, int alpha_mode, int eps_mode, bool general,
+                    float alpha, float epsilon, void* stream) {
   using namespace tfc;
   if (dtype != 0 && dtype != 1) return fail("tfc_gdn_forward: dtype must be 0 (float32) or 1 (bfloat16)");
-  if (alpha_mode != 1 && alpha_mode != 2) return fail("tfc_gdn_forward: alpha must be 1 or 2");
-  if (eps_mode != 0 && eps_mode != 1) return fail("tfc_gdn_forward: epsilon must be 1 or 0.5");
+  if (!general) {
+    if (alpha_mode != 1 && alpha_mode != 2) return fail("tfc_gdn_forward: alpha must be 1 or 2");
+    if (eps_mode != 0 && eps_mode != 1) return fail("tfc_gdn_forward: epsilon must be 1 or 0.5");
+  } else {
+    if (!(alpha > 0.f) || !(epsilon > 0.f) || !std::isfinite(alpha) || !std::isfinite(epsilon))
+      return fail("tfc_gdn_forward_general: alpha and epsilon must be positive and finite (got %g, %g)",
+                  static_cast<double>(alpha), static_cast<double>(epsilon));
+  }
   if (channels <= 0 || channels % 32 != 0 || channels > 256)
     return fail("tfc_gdn_forward: channels must be a multiple of 32, at most 256 (got %lld)",
                 static_cast<long long>(channels));
@@ -16,6 +25,18 @@ extern "C" int tfc_gdn_forward(const void* x, void* y, int dtype, int64_t pixels
   p.x = x; p.y = y; p.beta = beta; p.gamma = gamma;
   p.pixels = pixels; p.C = static_cast<int>(channels);
   p.inverse = inverse; p.rectify = rectify; p.alpha2 = alpha_mode == 2; p.eps_half = eps_mode == 1;
+  if (general) {
+    p.gen = 1;
+    p.alpha = alpha;
+    p.eps_s = inverse ? epsilon : -epsilon;
+    // tf.pow of a negative base: real for an integer exponent, NaN otherwise
+    auto negative_base = [](float e) {
+      const bool integral = std::floor(e) == e && e < 16777216.f;
+      return !integral ? std::nanf("") : (std::fmod(e, 2.f) == 0.f ? 1.f : -1.f);
+    };
+    p.negf = negative_base(alpha);
+    p.negf_e = negative_base(epsilon);
+  }
   p.tiles = ceil_div(pixels, 32);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (channels / 32) {
@@ -29,4 +50,18 @@ extern "C" int tfc_gdn_forward(const void* x, void* y, int dtype, int64_t pixels
     default: return launch_gdn<8, MODE_FWD>(p, dtype, st);
   }
 }
+}  // namespace
 
+extern "C" int tfc_gdn_forward(const void* x, void* y, int dtype, int64_t pixels, int64_t channels,
+                               const float* beta, const float* gamma, int inverse, int rectify,
+                               int alpha_mode, int eps_mode, void* stream) {
+  return gdn_forward_any(x, y, dtype, pixels, channels, beta, gamma, inverse, rectify, alpha_mode, eps_mode, false,
+                         0.f, 0.f, stream);
+}
+
+extern "C" int tfc_gdn_forward_general(const void* x, void* y, int dtype, int64_t pixels, int64_t channels,
+                                       const float* beta, const float* gamma, int inverse, int rectify,
+                                       float alpha, float epsilon, void* stream) {
+  return gdn_forward_any(x, y, dtype, pixels, channels, beta, gamma, inverse, rectify, 1, 0, true, alpha, epsilon,
+                         stream);
+}

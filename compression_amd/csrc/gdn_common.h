@@ -51,6 +51,12 @@ struct GdnParams {
   int inverse, rectify, alpha2, eps_half;
   float relu_floor;     // 0 if rectify else -inf:  x' = max(x, relu_floor)
   float a2;             // 1 if alpha == 2 else 0
+  // general (learned) exponents, GEN kernels only: u = x'^alpha, y = x' n^eps_s  (gdn.py:377-416, tf.pow)
+  int gen;
+  float alpha;          // >= 1
+  float eps_s;          // -epsilon (GDN) / +epsilon (IGDN)
+  float negf;           // x'^alpha for x' < 0 is |x'|^alpha * negf: +1 / -1 for an even / odd integer alpha, else NaN
+  float negf_e;         // the same for n^epsilon
   long long tiles;      // ceil(pixels / 32)
   const void* image;    // fragment-ordered Gamma^T (+ beta) built by gdn_prep_*_kernel
   // backward passes (see the mode table above the kernels)
@@ -99,6 +105,16 @@ __device__ inline float gdn_u(float xe, float a2) {
   const float ax = fabsf(xe);
   return ax * fmaf(ax - 1.f, a2, 1.f);
 }
+// x'^alpha for any alpha > 0 as tf.pow gives it: v_log_f32 / v_exp_f32 (base 2, 1 ulp); 0 at x' = 0
+__device__ inline float gdn_u_gen(float xe, float alpha, float negf) {
+  const float m = __builtin_amdgcn_exp2f(alpha * __builtin_amdgcn_logf(fabsf(xe)));
+  return xe < 0.f ? m * negf : m;
+}
+// x' n^s, a negative n treated like a negative x' above
+__device__ inline float gdn_apply_gen(float x, float n, float eps_s, float negf_e) {
+  const float m = __builtin_amdgcn_exp2f(eps_s * __builtin_amdgcn_logf(fabsf(n)));
+  return x * (n < 0.f ? m * negf_e : m);
+}
 // d|x'|^alpha / dx':  sign(x') for alpha = 1, 2 x' for alpha = 2
 __device__ inline float gdn_du(float xe, float a2) {
   float sg = xe > 0.f ? 1.f : 0.f;
@@ -138,8 +154,9 @@ __device__ inline unsigned int float_to_bf16_bits(float f) {
 //   element e of lane (i = lane & 31, h = lane >> 5) at (t, s) is
 //   gamma[ch(s, h, e)][32 t + i],  ch(s, h, e) = 16 s + 4 h + (e & 3) + 8 (e >> 2).
 // ---------------------------------------------------------------------------
-template <int KT, int MODE, bool PLAIN>
+template <int KT, int MODE, bool PLAIN, bool GEN = false>
 __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
+  static_assert(!GEN || (MODE == MODE_FWD && !PLAIN), "general exponents: forward only");
   constexpr int C = KT * 32;
   constexpr int KS = KT * 2;
   extern __shared__ unsigned char smem[];
@@ -225,7 +242,8 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
           for (int w = 0; w < 4; ++w) {
             const float lo = fmaxf(bf16_bits_to_float(u[w] & 0xFFFFu), p.relu_floor);
             const float hi = fmaxf(__uint_as_float(u[w] & 0xFFFF0000u), p.relu_floor);
-            u[w] = pack_bf16(gdn_u(lo, p.a2), gdn_u(hi, p.a2));
+            u[w] = GEN ? pack_bf16(gdn_u_gen(lo, p.alpha, p.negf), gdn_u_gen(hi, p.alpha, p.negf))
+                       : pack_bf16(gdn_u(lo, p.a2), gdn_u(hi, p.a2));
           }
         }
       }
@@ -279,7 +297,7 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
             if (MODE == MODE_FWD) {
               float xv = elem(xr[s], half, r);
               if (!PLAIN) xv = fmaxf(xv, p.relu_floor);
-              yv[r] = gdn_apply<INV, EPSH>(xv, a + b4[r]);
+              yv[r] = GEN ? gdn_apply_gen(xv, a + b4[r], p.eps_s, p.negf_e) : gdn_apply<INV, EPSH>(xv, a + b4[r]);
             } else if (MODE == MODE_BWD_T) {
               float xv = elem(xr[s], half, r);
               if (!PLAIN) xv = fmaxf(xv, p.relu_floor);
@@ -305,7 +323,9 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
     };
     using T = std::true_type;
     using F = std::false_type;
-    if (p.inverse) {
+    if (GEN) {
+      epilogue(F{}, F{});
+    } else if (p.inverse) {
       if (p.eps_half) epilogue(T{}, T{}); else epilogue(T{}, F{});
     } else {
       if (p.eps_half) epilogue(F{}, T{}); else epilogue(F{}, F{});
@@ -318,8 +338,9 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
 // K index inside K-tile kt at step u (0..15), half h:  ch = 32 kt + 4 h + (u & 3) + 8 (u >> 2).
 // LDS: Gamma^T fragments [((t * KT + kt) * 4 + u4) * 64 + lane][4]  (4 consecutive steps u).
 // ---------------------------------------------------------------------------
-template <int KT, int MODE, bool PLAIN>
+template <int KT, int MODE, bool PLAIN, bool GEN = false>
 __global__ void __launch_bounds__(256) gdn_fwd_f32_kernel(GdnParams p) {
+  static_assert(!GEN || (MODE == MODE_FWD && !PLAIN), "general exponents: forward only");
   constexpr int C = KT * 32;
   extern __shared__ unsigned char smem[];
   f32x4* afrag = reinterpret_cast<f32x4*>(smem);
@@ -368,7 +389,8 @@ __global__ void __launch_bounds__(256) gdn_fwd_f32_kernel(GdnParams p) {
         f32x4 u = xr[kt][q];
         if (MODE != MODE_BWD_DX) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) u[e] = PLAIN ? fabsf(u[e]) : gdn_u(u[e], p.a2);
+          for (int e = 0; e < 4; ++e)
+            u[e] = PLAIN ? fabsf(u[e]) : GEN ? gdn_u_gen(u[e], p.alpha, p.negf) : gdn_u(u[e], p.a2);
         }
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
@@ -390,7 +412,9 @@ __global__ void __launch_bounds__(256) gdn_fwd_f32_kernel(GdnParams p) {
           if (MODE == MODE_FWD) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[r] = gdn_apply<INV, EPSH>(xr[t][q][r], acc[t][4 * q + r] + b4[r]);
+            for (int r = 0; r < 4; ++r)
+              out[r] = GEN ? gdn_apply_gen(xr[t][q][r], acc[t][4 * q + r] + b4[r], p.eps_s, p.negf_e)
+                           : gdn_apply<INV, EPSH>(xr[t][q][r], acc[t][4 * q + r] + b4[r]);
           } else if (MODE == MODE_BWD_T) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(static_cast<const float*>(p.g) + at);
@@ -414,7 +438,9 @@ __global__ void __launch_bounds__(256) gdn_fwd_f32_kernel(GdnParams p) {
     };
     using T = std::true_type;
     using F = std::false_type;
-    if (p.inverse) {
+    if (GEN) {
+      epilogue(F{}, F{});
+    } else if (p.inverse) {
       if (p.eps_half) epilogue(T{}, T{}); else epilogue(T{}, F{});
     } else {
       if (p.eps_half) epilogue(F{}, T{}); else epilogue(F{}, F{});
@@ -466,7 +492,7 @@ static __global__ void gdn_prep_f32_kernel(const float* gamma, const float* beta
 }
 
 // DTYPES: bit 0 = instantiate the float32 kernels, bit 1 = the bfloat16 ones.
-template <int KT, int MODE, bool PLAIN, int DTYPES>
+template <int KT, int MODE, bool PLAIN, int DTYPES, bool GEN = false>
 int launch_gdn_variant(GdnParams p, int dtype, hipStream_t st) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -488,9 +514,9 @@ int launch_gdn_variant(GdnParams p, int dtype, hipStream_t st) {
                        KT * 32, transposed, image.as<bf16x8>());
     p.image = image.p;
     KernelTimer timer(label, st);
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT, MODE, PLAIN>),
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT, MODE, PLAIN>), dim3(blocks), dim3(64 * waves_per_block), lds,
+    hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>), dim3(blocks), dim3(64 * waves_per_block), lds,
                        st, p);
    } else {
     return fail("tfc_gdn: bfloat16 kernel not built for this configuration");
@@ -504,9 +530,9 @@ int launch_gdn_variant(GdnParams p, int dtype, hipStream_t st) {
                          KT * 32, transposed, image.as<f32x4>());
       p.image = image.p;
       KernelTimer timer(label, st);
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_f32_kernel<KT, MODE, PLAIN>),
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_f32_kernel<KT, MODE, PLAIN, GEN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-      hipLaunchKernelGGL((gdn_fwd_f32_kernel<KT, MODE, PLAIN>), dim3(blocks), dim3(64 * waves_per_block), lds,
+      hipLaunchKernelGGL((gdn_fwd_f32_kernel<KT, MODE, PLAIN, GEN>), dim3(blocks), dim3(64 * waves_per_block), lds,
                          st, p);
     } else {
       return fail("tfc_gdn: float32 path supports up to 192 channels (Gamma must fit in LDS)");
@@ -520,6 +546,9 @@ template <int KT, int MODE, int DTYPES = 3>
 int launch_gdn(GdnParams p, int dtype, hipStream_t st) {
   p.relu_floor = p.rectify ? 0.f : -__builtin_inff();
   p.a2 = p.alpha2 ? 1.f : 0.f;
+  if constexpr (MODE == MODE_FWD) {
+    if (p.gen) return launch_gdn_variant<KT, MODE, false, DTYPES, true>(p, dtype, st);
+  }
   if (!p.rectify && !p.alpha2) return launch_gdn_variant<KT, MODE, true, DTYPES>(p, dtype, st);
   return launch_gdn_variant<KT, MODE, false, DTYPES>(p, dtype, st);
 }

@@ -15,8 +15,7 @@ def gdn_forward(x: torch.Tensor, beta: torch.Tensor, gamma: torch.Tensor, invers
     _lib.require_device()
     if x.dtype not in _DTYPE_CODE:
         raise TypeError(f"GDN kernel supports float32 and bfloat16, got {x.dtype}")
-    if alpha not in (1, 2) or epsilon not in (1, 0.5):
-        raise NotImplementedError("GDN kernel implements alpha in {1, 2} and epsilon in {1, .5}")
+    alpha, epsilon = float(alpha), float(epsilon)
     x = x.contiguous()
     C = x.shape[-1]
     beta = beta.detach().to(x.device, torch.float32).contiguous()
@@ -24,6 +23,12 @@ def gdn_forward(x: torch.Tensor, beta: torch.Tensor, gamma: torch.Tensor, invers
     if beta.shape != (C,) or gamma.shape != (C, C):
         raise ValueError(f"beta/gamma shapes {tuple(beta.shape)}/{tuple(gamma.shape)} do not match C={C}")
     y = torch.empty_like(x)
+    if alpha not in (1, 2) or epsilon not in (1, 0.5):
+        # general exponents (gdn.py:386-387, :411-412: tf.pow), the kernels' GEN variant
+        _lib.check(_lib.lib().tfc_gdn_forward_general(
+            x.data_ptr(), y.data_ptr(), _DTYPE_CODE[x.dtype], x.numel() // C, C, beta.data_ptr(),
+            gamma.data_ptr(), int(bool(inverse)), int(bool(rectify)), alpha, epsilon, _lib.stream_ptr()))
+        return y
     _lib.check(_lib.lib().tfc_gdn_forward(
         x.data_ptr(), y.data_ptr(), _DTYPE_CODE[x.dtype], x.numel() // C, C, beta.data_ptr(),
         gamma.data_ptr(), int(bool(inverse)), int(bool(rectify)), int(alpha),
@@ -128,8 +133,11 @@ def conv2d_up(x, kernel, bias=None, stride=1, activation=None):
 
 
 def gdn_backward(x, grad, beta, gamma, inverse=False, rectify=False, alpha=1, epsilon=1):
-    """Gradients of gdn_forward w.r.t. (x, beta, gamma) on the HIP kernel."""
+    """Gradients of gdn_forward w.r.t. (x, beta, gamma) on the HIP kernel (alpha in {1, 2}, epsilon in {1, .5};
+    the general exponents go through `gdn_general_composite`)."""
     _lib.require_device()
+    if alpha not in (1, 2) or epsilon not in (1, 0.5):
+        raise NotImplementedError("tfc_gdn_backward implements alpha in {1, 2} and epsilon in {1, .5}")
     x = x.contiguous()
     grad = grad.contiguous()
     C = x.shape[-1]
@@ -143,3 +151,18 @@ def gdn_backward(x, grad, beta, gamma, inverse=False, rectify=False, alpha=1, ep
         beta.data_ptr(), gamma.data_ptr(), int(bool(inverse)), int(bool(rectify)), int(alpha),
         1 if epsilon == 0.5 else 0, dbeta.data_ptr(), dgamma.data_ptr(), _lib.stream_ptr()))
     return dx, dbeta, dgamma
+
+
+def gdn_general_composite(x, beta, gamma, alpha, epsilon, inverse=False, rectify=False):
+    """The layer with general exponents as differentiable device tensor ops (float32 arithmetic): the
+    training path of learned alpha / epsilon, whose gradients d/dalpha and d/depsilon the fused backward
+    kernel does not produce.  Same formula and op order as gdn.py:377-416; the forward-only (inference)
+    path of the same configuration is `gdn_forward` on the HIP kernel."""
+    _lib.require_device()
+    xf = x.float()
+    if rectify:
+        xf = torch.relu(xf)
+    norm = torch.pow(xf, alpha) @ gamma.to(xf.device, torch.float32) + beta.to(xf.device, torch.float32)
+    norm = torch.pow(norm, epsilon)
+    y = xf * norm if inverse else xf / norm
+    return y.to(x.dtype)

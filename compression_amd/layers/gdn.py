@@ -27,30 +27,53 @@ class _GDNFunction(torch.autograd.Function):
 class GDN(torch.nn.Module):
     """y_i = x_i / (beta_i + sum_j gamma[j, i] |x_j|^alpha)^epsilon  (inverse: multiply).
 
-    Same constructor arguments as the reference layer (gdn.py:127-139); alpha and
-    epsilon are fixed scalars in {1, 2} / {1, .5} (the fast paths of gdn.py:377-416).
+    Same constructor arguments as the reference layer (gdn.py:127-139).  `alpha_parameter` /
+    `epsilon_parameter`: a number, a callable returning one, or None for a learned scalar
+    (`reparam_alpha`, minimum 1 / `reparam_epsilon`, minimum 1e-6; gdn.py:345-369).  Fixed alpha in
+    {1, 2} with epsilon in {1, .5} are the fused forward AND backward kernels (the fast paths of
+    gdn.py:377-416); any other value runs the forward kernel's general-exponent variant, and its
+    gradients (which include d/dalpha, d/depsilon) as device tensor ops (`functional.gdn_general_composite`).
     Weights: `reparam_beta` [C], `reparam_gamma` [C, C] (gdn_test.py:97-100), created
     on first call like a Keras `build`."""
 
     def __init__(self, inverse=False, rectify=False, data_format="channels_last",
                  alpha_parameter=1, beta_parameter=None, gamma_parameter=None,
-                 epsilon_parameter=1, beta_initializer=None, gamma_initializer=None,
-                 num_channels=None):
+                 epsilon_parameter=1, alpha_initializer=None, beta_initializer=None, gamma_initializer=None,
+                 epsilon_initializer=None, num_channels=None):
         super().__init__()
         if data_format not in ("channels_first", "channels_last"):
             raise ValueError(f"Unknown data format: '{data_format}'.")
-        if alpha_parameter not in (1, 2) or epsilon_parameter not in (1, 0.5):
-            raise NotImplementedError(
-                "The HIP GDN kernel implements alpha in {1, 2} and epsilon in {1, .5}.")
         self.inverse, self.rectify = bool(inverse), bool(rectify)
         self.data_format = data_format
-        self.alpha, self.epsilon = alpha_parameter, epsilon_parameter
+        self._alpha_fixed, self._epsilon_fixed = alpha_parameter, epsilon_parameter
         self._beta_fixed, self._gamma_fixed = beta_parameter, gamma_parameter
+        self._alpha_init = alpha_initializer or (lambda: torch.ones(()))
+        self._epsilon_init = epsilon_initializer or (lambda: torch.ones(()))
         self._beta_init = beta_initializer or (lambda c: torch.ones(c))
         self._gamma_init = gamma_initializer or (lambda c: 0.1 * torch.eye(c))
         self.reparam_beta = self.reparam_gamma = None
+        self.reparam_alpha = self.reparam_epsilon = None
+        if alpha_parameter is None:
+            self.reparam_alpha = torch.nn.Parameter(parameters.gdn_reparam_init(self._alpha_init().float()))
+        if epsilon_parameter is None:
+            self.reparam_epsilon = torch.nn.Parameter(parameters.gdn_reparam_init(self._epsilon_init().float()))
         if num_channels is not None:
             self.build(int(num_channels))
+
+    @property
+    def alpha(self):
+        """A Python number when fixed, a 0-d tensor when learned (gdn.py:318-321)."""
+        if self.reparam_alpha is not None:
+            return parameters.gdn_reparam_value(self.reparam_alpha, minimum=1.0)
+        v = self._alpha_fixed() if callable(self._alpha_fixed) else self._alpha_fixed
+        return v
+
+    @property
+    def epsilon(self):
+        if self.reparam_epsilon is not None:
+            return parameters.gdn_reparam_value(self.reparam_epsilon, minimum=1e-6)
+        v = self._epsilon_fixed() if callable(self._epsilon_fixed) else self._epsilon_fixed
+        return v
 
     def build(self, c, device=None):
         if self._beta_fixed is None and self.reparam_beta is None:
@@ -80,8 +103,22 @@ class GDN(torch.nn.Module):
             x = x.movedim(1, -1)
         self.build(x.shape[-1], x.device)
         beta, gamma = self.beta.to(x.device), self.gamma.to(x.device)
-        y = _GDNFunction.apply(x.contiguous(), beta, gamma, self.inverse, self.rectify, self.alpha,
-                               self.epsilon)
+        alpha, epsilon = self.alpha, self.epsilon
+        fast = (not torch.is_tensor(alpha) and not torch.is_tensor(epsilon)
+                and float(alpha) in (1.0, 2.0) and float(epsilon) in (1.0, 0.5))
+        needs_grad = torch.is_grad_enabled() and any(
+            torch.is_tensor(t) and t.requires_grad for t in (x, beta, gamma, alpha, epsilon))
+        if fast:
+            y = _GDNFunction.apply(x.contiguous(), beta, gamma, self.inverse, self.rectify,
+                                   int(alpha) if float(alpha) in (1.0, 2.0) else alpha,
+                                   1 if float(epsilon) == 1.0 else 0.5)
+        elif needs_grad:
+            a = alpha.to(x.device) if torch.is_tensor(alpha) else float(alpha)
+            e = epsilon.to(x.device) if torch.is_tensor(epsilon) else float(epsilon)
+            y = functional.gdn_general_composite(x, beta, gamma, a, e, self.inverse, self.rectify)
+        else:
+            y = functional.gdn_forward(x.contiguous(), beta, gamma, self.inverse, self.rectify,
+                                       float(alpha), float(epsilon))
         if self.data_format == "channels_first" and y.dim() > 2:
             y = y.movedim(-1, 1)
         return y

@@ -299,7 +299,18 @@ int tfc_gdn_forward(const void* x, void* y, int dtype, int64_t pixels, int64_t c
                     const float* beta, const float* gamma, int inverse, int rectify,
                     int alpha_mode, int eps_mode, void* stream);
 
-/* Backward of the above (the reference relies on TF autodiff).  g = dL/dy.
+/* The same layer with general (e.g. learned) exponents — python/layers/gdn.py:345-369 creates alpha
+ * (>= 1) and epsilon (>= 1e-6) as scalar parameters when the constructor gets None, and :386-387 /
+ * :411-412 then take `inputs ** alpha` and `norm_pool ** epsilon` with tf.pow:
+ *   u = x^alpha (rectify => x = max(x,0) first; a negative x gives NaN unless alpha is an integer, as tf.pow does)
+ *   y_i = x_i / n_i^epsilon  or  x_i * n_i^epsilon.
+ * alpha, epsilon: positive finite host scalars.  Forward only: the gradients of this variant (which include
+ * d/dalpha and d/depsilon) are composed from device tensor ops by the host layer, not by this library. */
+int tfc_gdn_forward_general(const void* x, void* y, int dtype, int64_t pixels, int64_t channels,
+                            const float* beta, const float* gamma, int inverse, int rectify,
+                            float alpha, float epsilon, void* stream);
+
+/* Backward of tfc_gdn_forward (the reference relies on TF autodiff).  g = dL/dy.
  * Outputs: dx (dtype) and float32 accumulators dbeta [channels], dgamma
  * [channels, channels] which are ADDED to (caller zeroes them). */
 int tfc_gdn_backward(const void* x, const void* g, void* dx, int dtype, int64_t pixels,

@@ -148,3 +148,95 @@ def test_gdn_module_autograd():
     grads = [p.grad for p in layer.parameters()]
     assert grads and all(g is not None and torch.isfinite(g).all() for g in grads)
     assert any(g.abs().sum() > 0 for g in grads)
+
+
+def ref_gdn_general(x, beta, gamma, inverse, rectify, alpha, eps):
+    """gdn.py:377-416 with the tf.pow paths (`inputs ** alpha`, `norm_pool ** epsilon`), in float64."""
+    x = x.astype(np.float64)
+    if rectify:
+        x = np.maximum(x, 0)
+    with np.errstate(invalid="ignore"):
+        u = np.power(x, alpha)
+    n = u @ gamma.astype(np.float64) + beta.astype(np.float64)
+    n = np.power(n, eps)
+    return x * n if inverse else x / n
+
+
+@pytest.mark.parametrize("C", [32, 96, 192])
+@pytest.mark.parametrize("inverse,rectify,alpha,eps", [
+    (False, True, 1.5, 0.7), (True, True, 1.25, 0.3), (True, False, 3.0, 1.0), (True, False, 2.0, 0.8),
+    (False, True, 1.0, 0.25)])
+def test_gdn_general_exponents_f32(C, inverse, rectify, alpha, eps):
+    """General (learned-style) alpha / epsilon: the forward kernel's tf.pow variant against float64.
+    Without rectify only integer alphas are real for negative inputs (tf.pow, numpy.power alike); with an odd
+    one the norm pool can be negative or near zero, so that case multiplies (IGDN) instead of dividing."""
+    from compression_amd.layers import gdn_forward
+    torch.manual_seed(5)
+    x = torch.randn(4, 9, 7, C)
+    beta, gamma = params(C, 6)
+    y = gdn_forward(x.cuda(), beta, gamma, inverse, rectify, alpha, eps).cpu().numpy()
+    want = ref_gdn_general(x.numpy(), beta.numpy(), gamma.numpy(), inverse, rectify, alpha, eps)
+    assert np.isfinite(want).all()
+    assert np.max(np.abs(y - want)) <= 1e-5 * max(1.0, np.max(np.abs(want)))
+
+
+def test_gdn_general_negative_base_is_nan():
+    """x ** 1.5 of a negative x is NaN (tf.pow): every output channel whose norm pool sees it is NaN."""
+    from compression_amd.layers import gdn_forward
+    C = 32
+    x = torch.rand(2, 3, C) + 0.5
+    x[0, 1, 4] = -0.75
+    beta, gamma = params(C, 7)
+    y = gdn_forward(x.cuda(), beta, gamma, False, False, 1.5, 1.0).cpu()
+    assert torch.isnan(y[0, 1]).all() and not torch.isnan(y[0, 0]).any() and not torch.isnan(y[1]).any()
+
+
+def test_gdn_general_bf16():
+    from compression_amd.layers import gdn_forward
+    torch.manual_seed(8)
+    C = 192
+    x = torch.randn(3, 40, C).bfloat16()
+    beta, gamma = params(C, 9)
+    y = gdn_forward(x.cuda(), beta, gamma, False, True, 1.3, 0.6).float().cpu().numpy()
+    xf = np.maximum(x.float().numpy().astype(np.float64), 0)
+    u = torch.from_numpy(np.power(xf, 1.3)).bfloat16().double().numpy()      # the kernel rounds u to bf16 for the MFMA
+    n = u @ gamma.bfloat16().double().numpy() + beta.double().numpy()
+    want = xf / np.power(n, 0.6)
+    assert np.max(np.abs(y - want) / (np.abs(want) + 1e-3)) <= 2 ** -6
+
+
+def test_gdn_layer_learned_alpha_epsilon():
+    """alpha_parameter=None / epsilon_parameter=None: learned scalars (gdn.py:345-369).  Gradients of
+    x, beta, gamma, alpha, epsilon against float64 autograd of the same formula; the no-grad call of the
+    same layer runs the forward kernel and agrees with the composite."""
+    import compression_amd as tfc
+    torch.manual_seed(10)
+    C = 64
+    layer = tfc.layers.GDN(rectify=True, alpha_parameter=None, epsilon_parameter=None,
+                           alpha_initializer=lambda: torch.tensor(1.4), epsilon_initializer=lambda: torch.tensor(0.6),
+                           num_channels=C).cuda()
+    assert abs(float(layer.alpha.detach()) - 1.4) < 1e-5 and abs(float(layer.epsilon.detach()) - 0.6) < 1e-5
+    names = {n for n, _ in layer.named_parameters()}
+    assert {"reparam_alpha", "reparam_epsilon", "reparam_beta", "reparam_gamma"} <= names
+    x = (torch.rand(2, 5, 6, C, device="cuda") * 2 - 0.5).requires_grad_(True)
+    w = torch.randn(2, 5, 6, C, device="cuda")
+    y = layer(x)
+    (y * w).sum().backward()
+    # float64 reference
+    xd = x.detach().double().requires_grad_(True)
+    a = layer.alpha.detach().double().requires_grad_(True)
+    e = layer.epsilon.detach().double().requires_grad_(True)
+    b = layer.beta.detach().double().requires_grad_(True)
+    g = layer.gamma.detach().double().requires_grad_(True)
+    xr = torch.relu(xd)
+    yd = xr / torch.pow(torch.pow(xr, a) @ g + b, e)
+    (yd * w.double()).sum().backward()
+    assert torch.allclose(y.double(), yd, atol=1e-5)
+    assert torch.allclose(x.grad.double(), xd.grad, atol=1e-4, rtol=1e-4)
+    # parameters: chain through the reparameterisation  value = variable^2 - pedestal
+    for rep, grad in ((layer.reparam_alpha, a.grad), (layer.reparam_epsilon, e.grad)):
+        want = grad * 2 * rep.detach().double()
+        assert torch.allclose(rep.grad.double(), want, rtol=1e-3, atol=1e-4), (rep.grad, want)
+    with torch.no_grad():
+        y_kernel = layer(x.detach())
+    assert torch.allclose(y_kernel, y.detach(), atol=1e-5)
