@@ -43,6 +43,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int kConvWaves = 4;          // pixel tiles (32 px) per workgroup
 constexpr int kMaxTiles = 6;           // 32-column tiles per column group (192 columns)
+constexpr int kMaxGroups = 16;         // column groups that can carry their own tap sub-rectangle
 
 struct ConvGeom {
   // input
@@ -67,6 +68,12 @@ struct ConvGeom {
   int activation;         // 0 none, 1 relu
   // output
   int OH, OW;
+  // Compact K (second-generation bf16 kernel, transposed convolution whose column groups are whole output
+  // phases): a phase only has the taps t = phi + d*s + k/2 inside the kernel, e.g. 3x3, 3x2, 2x3, 2x2 of the
+  // 3x3 taps of a 5x5 stride-2 kernel, so a group's K loop (and its packed weights) runs over the
+  // sub-rectangle [ty0, ty1) x [tx0, tx1) of taps only: 25 instead of 36 tap blocks in that example.
+  int compact;
+  int ty0[kMaxGroups], ty1[kMaxGroups], tx0[kMaxGroups], tx1[kMaxGroups];
 };
 
 template <typename T> struct ConvTraits;
@@ -98,6 +105,15 @@ __device__ inline float packed_weight(const float* w, const PackGeom& g, const C
     ux = o >> 2;
     ci = o & 3;
     if (ux >= c.Ux || ci >= g.Cin_real) return 0.f;
+  } else if (c.compact) {
+    const int grp = col / (c.tiles * 32);
+    const int cb = c.Cin / 16;
+    const int tap = ks / cb;
+    const int wx = c.tx1[grp] - c.tx0[grp];
+    uy = c.ty0[grp] + tap / wx;
+    ux = c.tx0[grp] + tap % wx;
+    if (uy >= c.ty1[grp]) return 0.f;
+    ci = (ks % cb) * 16 + koff;
   } else {
     const int cb = c.Cin / 16;
     const int tap = ks / cb;
@@ -250,8 +266,45 @@ __global__ void __launch_bounds__(64 * kConvWaves) conv_kernel(const T* x, const
   }
 
   // ---- epilogue: acc[t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel m ----
+#ifdef TFC_CONV_NOSTORE
+  if (!live || !bias || bias[0] != 12345.f) return;
+#else
   if (!live) return;
+#endif
   const int colbase = group * TILES * 32;
+  if constexpr (BF) {
+    if (c.su == 1 && (c.Cout & 7) == 0) {
+      // 16-byte stores: lanes l and l + 32 (one pixel) trade halves of a pair of column groups, see the
+      // second-generation kernel's epilogue
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          const int col0 = colbase + 32 * t + 16 * qp;
+          if (col0 >= c.cols) continue;
+          u32x4 o;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int colq = col0 + 8 * half + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float b = (bias && colq + r < c.cols) ? bias[colq + r] : 0.f;
+              v[r] = acc[t][4 * (2 * qp + half) + r] + b;
+              if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
+            }
+            o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+            o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          }
+          const auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+          const int colh = col0 + 8 * h;
+          if (colh < c.cols)
+            *reinterpret_cast<u32x4*>(y + mm * c.Cout + colh) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+      return;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -352,18 +405,22 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
   // incrementally: the per-step divisions by runtime Cin / kernel width were the single largest
   // block of non-MFMA instructions in the loop.
   struct KPos { int uy, ux, cbi; long long off; };      // off = (uy * W + ux) * Cin + 16 * cbi
-  const long long row_step = static_cast<long long>(c.W - c.Ux) * c.Cin + 16;   // last tap of a row -> next row
+  // taps of this column group: all of them, or the sub-rectangle of its output phase
+  const int uy0 = c.compact ? c.ty0[group] : 0, uy1 = c.compact ? c.ty1[group] : c.Uy;
+  const int ux0 = c.compact ? c.tx0[group] : 0, ux1 = c.compact ? c.tx1[group] : c.Ux;
+  const int ksteps = (uy1 - uy0) * (ux1 - ux0) * cb;
+  const long long row_step = static_cast<long long>(c.W - (ux1 - ux0)) * c.Cin + 16;   // last tap of a row -> next row
   auto advance = [&](KPos& k) {
     k.off += 16;                       // next channel block, or the next pixel of the row: contiguous
     if (++k.cbi == cb) {
       k.cbi = 0;
-      if (++k.ux == c.Ux) { k.ux = 0; ++k.uy; k.off += row_step - 16; }
+      if (++k.ux == ux1) { k.ux = ux0; ++k.uy; k.off += row_step - 16; }
     }
   };
   // B fragment of pixel tile p at K position k: 8 input values at K offset 8h, zero outside the image
   auto bload = [&](const KPos& k, int p) -> u32x4 {
     const bool ok = live[p] && static_cast<unsigned int>(iy0[p] + k.uy) < static_cast<unsigned int>(c.H) &&
-                    static_cast<unsigned int>(ix0[p] + k.ux) < static_cast<unsigned int>(c.W) && k.uy < c.Uy;
+                    static_cast<unsigned int>(ix0[p] + k.ux) < static_cast<unsigned int>(c.W) && k.uy < uy1;
     const __bf16* src = ok ? x + base_off[p] + k.off : zeros;
     return *reinterpret_cast<const u32x4*>(src);
   };
@@ -378,8 +435,8 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
 
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(
       static_cast<const unsigned char*>(packed) + static_cast<size_t>(group) * c.ksteps * TILES * 64 * 16);
-  const int nchunks = (c.ksteps + kChunk2 - 1) / kChunk2;
-  const long long wtotal = static_cast<long long>(c.ksteps) * TILES * 64;   // fragments of this group
+  const int nchunks = (ksteps + kChunk2 - 1) / kChunk2;
+  const long long wtotal = static_cast<long long>(ksteps) * TILES * 64;     // fragments of this group in use
 
   u32x4 stage[STAGE];
   auto wfetch = [&](int chunk) {
@@ -401,7 +458,7 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
   wfetch(0);
   wstore(0);
   u32x4 bq[kPF][MT];
-  KPos kpre{0, 0, 0, 0};               // position of the next B fragment to request
+  KPos kpre{uy0, ux0, 0, (static_cast<long long>(uy0) * c.W + ux0) * c.Cin};   // the next B fragment to request
 #pragma unroll
   for (int k = 0; k < kPF; ++k) {
 #pragma unroll
@@ -443,6 +500,55 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
   // ---- epilogue: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel mm[p] ----
   const int colbase = group * TILES * 32;
   const bool vec4 = (c.Cout & 3) == 0;       // 4 consecutive columns = 4 channels of one phase
+  if ((c.Cout & 7) == 0) {
+    // 8 consecutive columns = 8 channels of one pixel: lanes l and l + 32 (the same pixel, h = 0 / 1) trade
+    // halves of a pair of column groups (v_permlane32_swap, as in gdn_common.h) and each stores 16 bytes,
+    // 32 contiguous bytes per pixel and instruction.  With 8-byte stores the output traffic of the layers
+    // that write the most (the image-side analysis layer, the last 192 -> 192 synthesis layer) took 2.6 and
+    // 3.3 ms of their 4.4 and 14.8 ms at the C4 shapes.
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const int col0 = colbase + 32 * t + 16 * qp;          // the pair covers columns col0 .. col0 + 15
+        if (col0 >= c.cols) continue;                          // wave-uniform
+        const int co = col0 % c.Cout, phase = col0 / c.Cout;
+        f32x4 be = f32x4{0.f, 0.f, 0.f, 0.f}, bo = be;
+        if (bias) {
+          be = *reinterpret_cast<const f32x4*>(bias + co + 4 * h);
+          if (col0 + 8 < c.cols) bo = *reinterpret_cast<const f32x4*>(bias + (col0 + 8) % c.Cout + 4 * h);
+        }
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+          u32x4 o;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const f32x4& b4 = half ? bo : be;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[p][t][4 * (2 * qp + half) + r] + b4[r];
+              if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
+            }
+            o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+            o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          }
+          const auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+          // lane h stores columns col0 + 8h .. + 7 (h = 1: the odd group, possibly another phase / past the end)
+          const int colh = col0 + 8 * h;
+          if (!live[p] || colh >= c.cols) continue;
+          const int coh = colh % c.Cout, ph = colh / c.Cout;
+          const int oy = qy[p] * c.su + ph / c.su, ox = qx[p] * c.su + ph % c.su;
+          *reinterpret_cast<u32x4*>(y + ((nn[p] * c.OH + oy) * c.OW + ox) * c.Cout + coh) =
+              u32x4{s0[0], s1[0], s0[1], s1[1]};
+          (void)phase;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one column tile at a time (register pressure)
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
 #pragma unroll
@@ -460,7 +566,11 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
       }
 #pragma unroll
       for (int p = 0; p < MT; ++p) {
+#ifdef TFC_CONV_NOSTORE      // experiment: the kernel without its output traffic (stores only for an impossible bias)
+        if (!live[p] || col0 >= c.cols || b4[0] != 12345.f) continue;
+#else
         if (!live[p] || col0 >= c.cols) continue;
+#endif
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -501,6 +611,30 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
   c.kchunk = std::max(1, std::min(c.ksteps, (64 * 1024) / (c.tiles * 64 * FB)));
   const size_t lds = static_cast<size_t>(c.kchunk) * c.tiles * 64 * FB;
 
+  c.compact = 0;
+  if (std::is_same<T, __bf16>::value && !c.small_cin && g.up && c.groups <= kMaxGroups &&
+      c.Cout % (c.tiles * 32) == 0) {
+    // every column group lies inside one output phase: its taps are those with a kernel index in range
+    c.compact = 1;
+    int most = 0;
+    for (int grp = 0; grp < c.groups; ++grp) {
+      const int phase = grp * c.tiles * 32 / c.Cout;
+      const int phy = phase / g.su, phx = phase % g.su;
+      int y0 = c.Uy, y1 = 0, x0 = c.Ux, x1 = 0;
+      for (int u = 0; u < c.Uy; ++u) {
+        const int t = phy + (g.dmax_y - u) * g.su + g.kh / 2;
+        if (t >= 0 && t < g.kh) { y0 = std::min(y0, u); y1 = std::max(y1, u + 1); }
+      }
+      for (int u = 0; u < c.Ux; ++u) {
+        const int t = phx + (g.dmax_x - u) * g.su + g.kw / 2;
+        if (t >= 0 && t < g.kw) { x0 = std::min(x0, u); x1 = std::max(x1, u + 1); }
+      }
+      if (y1 <= y0 || x1 <= x0) { y0 = 0; y1 = 1; x0 = 0; x1 = 1; }   // a phase without taps: one (zero) block
+      c.ty0[grp] = y0; c.ty1[grp] = y1; c.tx0[grp] = x0; c.tx1[grp] = x1;
+      most = std::max(most, (y1 - y0) * (x1 - x0));
+    }
+    c.ksteps = most * (c.Cin / 16);          // packed K steps per group (the stride of the packed buffer)
+  }
   DevBuf packed, padded;
   const long long frags = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
   TFC_HIP(packed.alloc(static_cast<size_t>(frags) * FB + 16, st));
