@@ -360,6 +360,9 @@ __global__ void __launch_bounds__(64 * kConvWaves) conv_kernel(const T* x, const
 #ifndef TFC_CONV_CHUNK
 #define TFC_CONV_CHUNK 4
 #endif
+#ifndef TFC_CONV_INTERLEAVE
+#define TFC_CONV_INTERLEAVE 1
+#endif
 constexpr int kPF = TFC_CONV_PF;         // B fragments in flight per pixel tile
 constexpr int kChunk2 = TFC_CONV_CHUNK;  // K steps per LDS weight buffer (multiple of kPF)
 
@@ -410,19 +413,33 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
   const int ux0 = c.compact ? c.tx0[group] : 0, ux1 = c.compact ? c.tx1[group] : c.Ux;
   const int ksteps = (uy1 - uy0) * (ux1 - ux0) * cb;
   const long long row_step = static_cast<long long>(c.W - (ux1 - ux0)) * c.Cin + 16;   // last tap of a row -> next row
+  // (selects, not branches: the unrolled K steps of a chunk stay ONE basic block, which is what lets the
+  // scheduler put their address arithmetic, LDS reads and loads between the MFMAs)
   auto advance = [&](KPos& k) {
-    k.off += 16;                       // next channel block, or the next pixel of the row: contiguous
-    if (++k.cbi == cb) {
-      k.cbi = 0;
-      if (++k.ux == ux1) { k.ux = ux0; ++k.uy; k.off += row_step - 16; }
-    }
+    const int cbi1 = k.cbi + 1;
+    const bool wc = cbi1 == cb;                      // next channel block, or the next pixel of the row: contiguous
+    const int uxn = k.ux + (wc ? 1 : 0);
+    const bool wx = uxn == ux1;                      // last tap of a row -> next row
+    k.cbi = wc ? 0 : cbi1;
+    k.ux = wx ? ux0 : uxn;
+    k.uy += wx ? 1 : 0;
+    k.off += wx ? row_step : 16;
   };
   // B fragment of pixel tile p at K position k: 8 input values at K offset 8h, zero outside the image
   auto bload = [&](const KPos& k, int p) -> u32x4 {
-    const bool ok = live[p] && static_cast<unsigned int>(iy0[p] + k.uy) < static_cast<unsigned int>(c.H) &&
-                    static_cast<unsigned int>(ix0[p] + k.ux) < static_cast<unsigned int>(c.W) && k.uy < uy1;
-    const __bf16* src = ok ? x + base_off[p] + k.off : zeros;
-    return *reinterpret_cast<const u32x4*>(src);
+    // (& on purpose: && is control flow, an EXEC-masked block per term)
+    const bool ok = live[p] & (static_cast<unsigned int>(iy0[p] + k.uy) < static_cast<unsigned int>(c.H)) &
+                    (static_cast<unsigned int>(ix0[p] + k.ux) < static_cast<unsigned int>(c.W)) & (k.uy < uy1);
+    // address as an integer select (a pointer select became an EXEC-masked block per load)
+    unsigned long long a_in = reinterpret_cast<unsigned long long>(x) +
+                              2ull * static_cast<unsigned long long>(base_off[p] + k.off);
+    asm volatile("" : "+v"(a_in));     // computed for every lane: the select below stays two v_cndmask
+#ifdef TFC_CONV_NOBLOAD     // experiment: the K loop without its input traffic
+    const unsigned long long a = ok && k.uy > 1000 ? a_in : reinterpret_cast<unsigned long long>(zeros);
+#else
+    const unsigned long long a = ok ? a_in : reinterpret_cast<unsigned long long>(zeros);
+#endif
+    return *reinterpret_cast<__attribute__((address_space(1))) const u32x4*>(a);     // a global, not a flat, load
   };
 
   f32x16 acc[MT][TILES];
@@ -439,12 +456,16 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
   const long long wtotal = static_cast<long long>(ksteps) * TILES * 64;     // fragments of this group in use
 
   u32x4 stage[STAGE];
+  // Unconditional loads from a clamped index (fragments past the chunk / the group's K steps are never
+  // read by an MFMA that counts: their B operand is zero).  A load under a condition is a path WITHOUT
+  // the load for the compiler's s_waitcnt bookkeeping: it then allows fewer loads in flight at the first
+  // MFMA of a chunk than really are, and the wave waits there for the weights it has just requested
+  // (SQ_WAIT_ANY was 30 % of the wave cycles of the 192 -> 192 layers).
   auto wfetch = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < STAGE; ++i) {
       const long long f = static_cast<long long>(chunk) * CHUNK_FRAGS + i * 256 + threadIdx.x;
-      stage[i] = (i * 256 + static_cast<int>(threadIdx.x) < CHUNK_FRAGS && f < wtotal) ? wsrc[f]
-                                                                                       : u32x4{0u, 0u, 0u, 0u};
+      stage[i] = wsrc[f < wtotal ? f : wtotal - 1];
     }
   };
   auto wstore = [&](int buf) {
@@ -469,17 +490,24 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf = chunk & 1;
-    if (chunk + 1 < nchunks) wfetch(chunk + 1);
+#ifndef TFC_CONV_BARE       // (experiment: MFMAs only -- no weight staging, no barrier, with NOAREAD / NOBLOAD)
+    wfetch(chunk + 1);          // past the last chunk: the clamped fragment, not used
+#endif
     const bf16x8* abase = reinterpret_cast<const bf16x8*>(smem) + buf * CHUNK_FRAGS + lane;
     bf16x8 af[2][TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) af[0][t] = abase[t * 64];
 #pragma unroll
     for (int kk = 0; kk < kChunk2; ++kk) {
+#ifndef TFC_CONV_NOAREAD    // (experiment: without the A fragment reads of the steps after a chunk's first)
       if (kk + 1 < kChunk2) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) af[(kk + 1) & 1][t] = abase[((kk + 1) * TILES + t) * 64];
       }
+#else
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) af[(kk + 1) & 1][t] = af[kk & 1][t];
+#endif
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -488,13 +516,30 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const v
               af[kk & 1][t], __builtin_bit_cast(bf16x8, bq[kk % kPF][p]), acc[p][t], 0, 0, 0);
       // refill the ring slot with K step ks + PF (past the last tap row: zeros); after the MFMAs
       // that read it so that no copy of the slot is needed
+#ifndef TFC_CONV_BARE
 #pragma unroll
       for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = bload(kpre, p);
       advance(kpre);
+#endif
+#if TFC_CONV_INTERLEAVE
+      // One wave per SIMD: an MFMA occupies the matrix pipe for 32 cycles = 8 issue slots, about five other
+      // instructions fit in its shadow, and this K step has ~4.5 of them per MFMA (address arithmetic of
+      // the two B loads, the six A reads of the next step) -- but only if they sit BETWEEN the MFMAs;
+      // left to itself the scheduler issues the 12 MFMAs in a row and everything else behind them.
+#pragma unroll
+      for (int i = 0; i < TILES * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA
+        if (i < TILES) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one A fragment read
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                    // two VALU
+        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);                    // three SALU
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifndef TFC_CONV_BARE
     if (chunk + 1 < nchunks) wstore(buf ^ 1);
     __syncthreads();
+#endif
   }
 
   // ---- epilogue: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel mm[p] ----

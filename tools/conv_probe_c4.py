@@ -13,6 +13,11 @@ if __name__ == "__main__":
     C_, dt = 192, torch.bfloat16
     H, W = 512, 768
     k5 = lambda ci, co: torch.randn(5, 5, ci, co) / 70
+    only = os.environ.get("LAYERS")           # e.g. LAYERS=L1,S2: substrings of the labels to run
+    _run = run
+    def run(label, *a):
+        if only is None or any(tag in label for tag in only.split(",")):
+            _run(label, *a)
     run("analysis L0 5x5 3->C /2", conv2d_down, torch.rand(B, H, W, 3, device=dev), k5(3, C_), torch.zeros(C_), 2, False, dt)
     run("analysis L1 5x5 C->C /2", conv2d_down, torch.randn(B, H // 2, W // 2, C_, device=dev, dtype=dt), k5(C_, C_), torch.zeros(C_), 2, False, dt)
     run("analysis L2 5x5 C->C /2", conv2d_down, torch.randn(B, H // 4, W // 4, C_, device=dev, dtype=dt), k5(C_, C_), torch.zeros(C_), 2, False, dt)
