@@ -200,7 +200,7 @@ def source_hashes(paths):
     return out
 
 
-def load_profile(name, sources):
+def load_profile(name, sources, steps_per_launch=None):
     """A committed rocprofv3 --pmc summary (tools/pmc_summary.py / sq_summary.py stamp it with the git
     blob hashes of the kernel sources it was measured on), or None when the sources have changed since:
     a counter figure of other code is not a measurement of this run."""
@@ -212,20 +212,22 @@ def load_profile(name, sources):
     now = source_hashes(sources)
     if not stamp or any(stamp.get(k) != v for k, v in now.items()):
         return None
+    if steps_per_launch is not None and stamp.get("_steps_per_launch") != steps_per_launch:
+        return None            # per-launch counters of a command that launched another number of steps
     return table
 
 
-def pmc_traffic(kernel_substring, profile, sources):
+def pmc_traffic(kernel_substring, profile, sources, steps_per_launch=None):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes
     (tools/pmc_on_box.sh; same bench command).  Counter unit is KiB.  Corrections as
     MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-B read requests as 64 B
     (x2; calibrated in the same passes on torch's fp32->bf16 copy of a 201 MB tensor: reported
     98322 KiB, true 196608 KiB), WRITE_SIZE is exact on that kernel's 98304 KiB output."""
-    table = load_profile(profile, sources)
+    table = load_profile(profile, sources, steps_per_launch)
     if table is None:
         return None
     for name, ctrs in table.items():
-        if kernel_substring in name and "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs:
+        if kernel_substring in name and isinstance(ctrs, dict) and "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs:
             return int((2.0 * ctrs["FETCH_SIZE"]["mean"] + ctrs["WRITE_SIZE"]["mean"]) * 1024)
     return None
 
@@ -234,19 +236,19 @@ PMC_PROFILE = "r02_pmc_traffic.json"
 SQ_PROFILE = "r02_sq_inflight.json"
 
 
-def valu_issue_floor(ms_per_step, kernels):
+def valu_issue_floor(ms_per_step, kernels, steps_per_launch):
     """Vector-issue floor of a step: SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves; committed
     rocprofv3 --pmc pass of this command, tools/sq_on_box.sh) of the encoder + decoder launches of one
     step, spread over all SIMDs = the time a step needs if every SIMD issued vector instructions without
     a gap.  None when the profile was taken on other sources."""
-    table = load_profile(SQ_PROFILE, CODER_SOURCES)
+    table = load_profile(SQ_PROFILE, CODER_SOURCES, steps_per_launch)
     if table is None:
         return None
     quads = {}
     for name, row in table.items():
         for key in kernels:
             if key in name and key not in quads and isinstance(row, dict) and row.get("SQ_ACTIVE_INST_VALU"):
-                quads[key] = row["SQ_ACTIVE_INST_VALU"]
+                quads[key] = row["SQ_ACTIVE_INST_VALU"] / steps_per_launch      # the launch codes that many steps
     if len(quads) != len(kernels):
         return None
     simds, clock_hz = 256 * 4, 2.4e9
@@ -660,7 +662,7 @@ def main():
                 "bound": "hbm", "kernel": dom_symbol, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic(dom_symbol, PMC_PROFILE, CODER_SOURCES),
+                "traffic": pmc_traffic(dom_symbol, PMC_PROFILE, CODER_SOURCES, jobs_per_launch),
                 "traffic_source": f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   "this command; 2*FETCH + WRITE, KiB -> bytes); null = taken on other sources",
                 "algorithmic_bytes": int(dom_bytes),
@@ -673,7 +675,8 @@ def main():
             },
         }
         out["valu_issue_bound"] = valu_issue_floor(
-            1e3 * elapsed / args.steps, ("enc_lanes_kernel", "dec_lanes_kernel") if lanes else ("enc_fast_kernel", "dec_fast_kernel"))
+            1e3 * elapsed / args.steps, ("enc_lanes_kernel", "dec_lanes_kernel") if lanes else ("enc_fast_kernel", "dec_fast_kernel"),
+            jobs_per_launch)
         if world == 1:
             out["gdn_fwd"] = gdn_forward_bandwidth(device)
         if not args.no_cpu_baseline and world == 1:

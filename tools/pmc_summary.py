@@ -25,6 +25,10 @@ def source_stamp():
         except OSError:
             continue
         out[rel] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    # coding steps per lane-kernel launch of the profiled command (per-launch counters only compare with a run
+    # that launches the same number): exported by the profile script
+    if os.environ.get("TFC_PROFILE_STEPS_PER_LAUNCH"):
+        out["_steps_per_launch"] = int(os.environ["TFC_PROFILE_STEPS_PER_LAUNCH"])
     return out
 
 

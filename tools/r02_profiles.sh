@@ -5,18 +5,20 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 OUT=$R/gpurun_out/profiles; mkdir -p $OUT
-ARGS="--steps 64 --warmup 1 --no-cpu-baseline"
-rm -rf /tmp/st; timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d /tmp/st -- python $R/bench.py $ARGS > /tmp/st.log 2>&1
+# the driver's command (python bench.py --gpus 1 --steps 20 --warmup 5): 20 coding steps per lane-kernel launch
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline"
+export TFC_PROFILE_STEPS_PER_LAUNCH=20
+rm -rf /tmp/st; timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d /tmp/st -- python $R/bench.py $ARGS > /tmp/st.log 2>&1
 tail -1 /tmp/st.log | cut -c1-300
-python $R/tools/rocprof_summary.py /tmp/st $OUT/r02_bench_stats.md "Round 2: python bench.py --steps 64 --warmup 1 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)" | head -14 || true
+python $R/tools/rocprof_summary.py /tmp/st $OUT/r02_bench_stats.md "Round 2: python bench.py --steps 20 --warmup 5 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)" | head -14 || true
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
-  timeout -s KILL 240 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python $R/bench.py $ARGS > /tmp/pmc_$ctr.log 2>&1
+  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python $R/bench.py $ARGS > /tmp/pmc_$ctr.log 2>&1
   tail -1 /tmp/pmc_$ctr.log | cut -c1-200
 done
 python $R/tools/pmc_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/r02_pmc_traffic | head -12
 CTRS="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
 rm -rf /tmp/sq
-timeout -s KILL 240 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d /tmp/sq -- python $R/bench.py $ARGS > /tmp/sq.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d /tmp/sq -- python $R/bench.py $ARGS > /tmp/sq.log 2>&1
 tail -1 /tmp/sq.log | cut -c1-200
 python $R/tools/sq_summary.py /tmp/sq $OUT/r02_sq_inflight | head -8
