@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(512) factorized_backward_kernel(BitsParams p) 
 #pragma unroll
   for (int i = 0; i < L::kParams; ++i) { prm[i] = src[i]; dprm[i] = 0.f; }
   const T* yh = static_cast<const T*>(p.y_hat) + unit * p.elems;
+  const T* yin = p.y ? static_cast<const T*>(p.y) + unit * p.elems : nullptr;   // expected gradients: the input
   T* dy = static_cast<T*>(p.dy) + unit * p.elems;
   const float g = p.gbits[unit] * -1.4426950408889634f;     // dL/d(sum log p) of this unit
   for (long long e = static_cast<long long>(blk) * p.threads + t; e < p.elems;
@@ -249,7 +250,17 @@ __global__ void __launch_bounds__(512) factorized_backward_kernel(BitsParams p) 
     const float lo = mlp_forward<K, W, false>(prm, v - 0.5f, nullptr, nullptr);
     float gu, gl;
     log_interval_grad(up, lo, &gu, &gl);
-    const float dz = mlp_backward<K, W>(prm, v + 0.5f, g * gu, dprm) + mlp_backward<K, W>(prm, v - 0.5f, g * gl, dprm);
+    float dz = mlp_backward<K, W>(prm, v + 0.5f, g * gu, dprm) + mlp_backward<K, W>(prm, v - 0.5f, g * gl, dprm);
+    if (yin) {
+      // expected gradients (math_ops.py:157-216, perturb_and_apply(expected_grads=True)): the derivative
+      // w.r.t. the input is E_u[d log p / dx] = log p(x + .5) - log p(x - .5) at the UNPERTURBED x, i.e.
+      // the cumulative at x + 1, x, x - 1; the parameter gradients above stay those of log p(x + u).
+      const float x = load_as_float(yin, e);
+      const float c1 = mlp_forward<K, W, false>(prm, x + 1.f, nullptr, nullptr);
+      const float c0 = mlp_forward<K, W, false>(prm, x, nullptr, nullptr);
+      const float cm = mlp_forward<K, W, false>(prm, x - 1.f, nullptr, nullptr);
+      dz = g * (log_interval(c1, c0) - log_interval(c0, cm));
+    }
     store_from_float(dy, e, dz);
   }
   // threads t, t + C, t + 2C, ... of the block share a channel: fold them through LDS in a fixed
@@ -363,6 +374,23 @@ extern "C" int tfc_factorized_bits_backward(const void* y_hat, int dtype, int64_
   p.channels = static_cast<int>(channels); p.params = params; p.gbits = gbits; p.dy = dy;
   if (int rc = plan_blocks(units, elems, p.channels, &p.threads, &p.blocks_per_unit)) return rc;
   return dispatch(dtype, layers, width, "tfc_factorized_bits_backward",
+                  [&] { using TT = float; return TFC_FB_SWITCH(run_backward, p, dparams, st); },
+                  [&] { using TT = __hip_bfloat16; return TFC_FB_SWITCH(run_backward, p, dparams, st); });
+}
+
+extern "C" int tfc_factorized_bits_backward_expected(const void* y, const void* y_hat, int dtype, int64_t units,
+                                                     int64_t elems, int64_t channels, const float* params,
+                                                     int layers, int width, const float* gbits, void* dy,
+                                                     float* dparams, void* stream) {
+  using namespace tfc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (units == 0 || elems == 0) return 0;
+  if (y == nullptr) return fail("tfc_factorized_bits_backward_expected: the unperturbed input is required");
+  BitsParams p{};
+  p.y = y; p.y_hat = const_cast<void*>(y_hat); p.units = units; p.elems = elems;
+  p.channels = static_cast<int>(channels); p.params = params; p.gbits = gbits; p.dy = dy;
+  if (int rc = plan_blocks(units, elems, p.channels, &p.threads, &p.blocks_per_unit)) return rc;
+  return dispatch(dtype, layers, width, "tfc_factorized_bits_backward_expected",
                   [&] { using TT = float; return TFC_FB_SWITCH(run_backward, p, dparams, st); },
                   [&] { using TT = __hip_bfloat16; return TFC_FB_SWITCH(run_backward, p, dparams, st); });
 }

@@ -44,7 +44,7 @@ def pack_factorized_params(base) -> torch.Tensor:
 
 class _FactorizedBits(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, noise, params, layers, width, units, elems):
+    def forward(ctx, y, noise, params, layers, width, units, elems, expected_grads=False):
         _lib.require_device()
         y = y.contiguous()
         y_hat = torch.empty_like(y)
@@ -54,28 +54,41 @@ class _FactorizedBits(torch.autograd.Function):
             y.data_ptr(), noise.data_ptr() if noise is not None else None, y_hat.data_ptr(),
             _DTYPE_CODE[y.dtype], units, elems, channels, params.data_ptr(), layers, width, None,
             bits.data_ptr(), _lib.stream_ptr()))
-        ctx.save_for_backward(y_hat, params)
+        if expected_grads:
+            ctx.save_for_backward(y_hat, params, y)
+        else:
+            ctx.save_for_backward(y_hat, params)
         ctx.meta = (layers, width, units, elems)
         return y_hat, bits
 
     @staticmethod
     def backward(ctx, g_yhat, g_bits):
-        y_hat, params = ctx.saved_tensors
+        y_hat, params = ctx.saved_tensors[:2]
         layers, width, units, elems = ctx.meta
         dy = torch.empty_like(y_hat)
         dparams = torch.zeros_like(params)
         gb = (g_bits if g_bits is not None else torch.zeros(units, device=y_hat.device)).to(torch.float32).contiguous()
-        _lib.check(_lib.lib().tfc_factorized_bits_backward(
-            y_hat.data_ptr(), _DTYPE_CODE[y_hat.dtype], units, elems, params.shape[0], params.data_ptr(),
-            layers, width, gb.data_ptr(), dy.data_ptr(), dparams.data_ptr(), _lib.stream_ptr()))
+        if len(ctx.saved_tensors) == 3:
+            # expected gradients (math_ops.py:157-216): d/dy through the likelihood is the finite difference
+            # of log p at y +- .5, evaluated at the unperturbed input
+            y = ctx.saved_tensors[2]
+            _lib.check(_lib.lib().tfc_factorized_bits_backward_expected(
+                y.data_ptr(), y_hat.data_ptr(), _DTYPE_CODE[y_hat.dtype], units, elems, params.shape[0],
+                params.data_ptr(), layers, width, gb.data_ptr(), dy.data_ptr(), dparams.data_ptr(),
+                _lib.stream_ptr()))
+        else:
+            _lib.check(_lib.lib().tfc_factorized_bits_backward(
+                y_hat.data_ptr(), _DTYPE_CODE[y_hat.dtype], units, elems, params.shape[0], params.data_ptr(),
+                layers, width, gb.data_ptr(), dy.data_ptr(), dparams.data_ptr(), _lib.stream_ptr()))
         if g_yhat is not None:
             dy = dy + g_yhat
-        return dy, None, dparams, None, None, None, None
+        return dy, None, dparams, None, None, None, None, None
 
 
-def factorized_bits(bottleneck, base, coding_rank, noise=None):
+def factorized_bits(bottleneck, base, coding_rank, noise=None, expected_grads=False):
     """(y_hat, bits): y_hat = bottleneck + noise (noise None: bottleneck itself), bits summed over
-    the last `coding_rank` dimensions, shape = the leading dimensions."""
+    the last `coding_rank` dimensions, shape = the leading dimensions.  expected_grads: the gradient of
+    bits w.r.t. the bottleneck is the expectation over the noise (math_ops.py:157-216)."""
     lead = bottleneck.shape[:bottleneck.dim() - coding_rank]
     units = 1
     for s in lead:
@@ -85,5 +98,5 @@ def factorized_bits(bottleneck, base, coding_rank, noise=None):
     if noise is not None:
         noise = noise.to(bottleneck.dtype).contiguous()
     y_hat, bits = _FactorizedBits.apply(bottleneck, noise, params, len(base.num_filters) + 1,
-                                        int(base.num_filters[0]), units, elems)
+                                        int(base.num_filters[0]), units, elems, bool(expected_grads))
     return y_hat, bits.reshape(lead)

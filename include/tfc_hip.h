@@ -383,6 +383,14 @@ int tfc_factorized_bits_backward(const void* y_hat, int dtype, int64_t units, in
                                  int64_t channels, const float* params, int layers, int width,
                                  const float* gbits, void* dy, float* dparams, void* stream);
 
+/* The same with expected gradients — python/ops/math_ops.py:157-216, perturb_and_apply(expected_grads=True),
+ * as continuous_batched.py:291-322 calls it when the entropy model was built with expected_grads=True:
+ * dy = gbits * (log p(y + .5) - log p(y - .5)) / -ln 2 at the UNPERTURBED input y DEV [units, elems] dtype
+ * (the expectation of the derivative over the uniform noise); dparams through log p(y_hat) as above. */
+int tfc_factorized_bits_backward_expected(const void* y, const void* y_hat, int dtype, int64_t units,
+                                          int64_t elems, int64_t channels, const float* params, int layers,
+                                          int width, const float* gbits, void* dy, float* dparams, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
