@@ -76,6 +76,8 @@ SIGNATURES = {
                                            _vp, _vp, _vp]),
     "tfc_factorized_bits_backward": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp,
                                             _vp, _vp]),
+    "tfc_noisy_normal_bits_forward": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp]),
+    "tfc_noisy_normal_bits_backward": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "tfc_factorized_bits_backward_expected": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp,
                                                      _vp, _vp]),
 }

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..ops import gen_ops, math_ops, round_ops
+from ..ops import bottleneck_ops, gen_ops, math_ops, round_ops
 from . import continuous_base
 
 __all__ = ["ContinuousIndexedEntropyModel", "LocationScaleIndexedEntropyModel"]
@@ -89,6 +89,21 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
     def forward(self, bottleneck, indexes, training=True):
         bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
         indexes = self._normalize_indexes(torch.as_tensor(indexes))
+        ltm = self.laplace_tail_mass
+        if (training and not torch.is_tensor(ltm) and ltm == 0 and bottleneck_ops.fused_noisy_normal_supported(
+                self.prior_fn, self.parameter_fns, bottleneck, self.coding_rank)):
+            # NoisyNormal(loc, scale_fn(indexes)): one fused HIP kernel each way (csrc/noisy_normal_bits.hip);
+            # the parameter functions stay differentiable tensor ops, their gradients flow through `scale`
+            idx = indexes.to(self.prior_dtype)
+            loc = self.parameter_fns["loc"](idx)
+            scale = torch.as_tensor(self.parameter_fns["scale"](idx), dtype=self.prior_dtype, device=bottleneck.device)
+            shifted = bottleneck - loc if (torch.is_tensor(loc) or loc != 0) else bottleneck
+            noise = torch.rand_like(bottleneck) - 0.5
+            perturbed, bits = bottleneck_ops.noisy_normal_bits(shifted, scale, self.coding_rank, noise,
+                                                               expected_grads=self.expected_grads)
+            if torch.is_tensor(loc) or loc != 0:
+                perturbed = perturbed + loc
+            return perturbed, bits
         if training:
             def log_prob_fn(perturbed, idx):
                 return self._log_prob(self._make_prior(idx), perturbed)

@@ -100,3 +100,58 @@ def factorized_bits(bottleneck, base, coding_rank, noise=None, expected_grads=Fa
     y_hat, bits = _FactorizedBits.apply(bottleneck, noise, params, len(base.num_filters) + 1,
                                         int(base.num_filters[0]), units, elems, bool(expected_grads))
     return y_hat, bits.reshape(lead)
+
+
+class _NoisyNormalBits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, noise, scale, units, elems, expected_grads):
+        _lib.require_device()
+        y = y.contiguous()
+        scale = scale.to(torch.float32).contiguous()
+        y_hat = torch.empty_like(y)
+        bits = torch.empty(units, dtype=torch.float32, device=y.device)
+        _lib.check(_lib.lib().tfc_noisy_normal_bits_forward(
+            y.data_ptr(), noise.data_ptr() if noise is not None else None, scale.data_ptr(), y_hat.data_ptr(),
+            _DTYPE_CODE[y.dtype], units, elems, bits.data_ptr(), _lib.stream_ptr()))
+        ctx.save_for_backward(*((y_hat, scale, y) if expected_grads else (y_hat, scale)))
+        ctx.meta = (units, elems)
+        return y_hat, bits
+
+    @staticmethod
+    def backward(ctx, g_yhat, g_bits):
+        y_hat, scale = ctx.saved_tensors[:2]
+        y_in = ctx.saved_tensors[2] if len(ctx.saved_tensors) == 3 else None
+        units, elems = ctx.meta
+        dy = torch.empty_like(y_hat)
+        dscale = torch.empty_like(scale)
+        gb = (g_bits if g_bits is not None else torch.zeros(units, device=y_hat.device)).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().tfc_noisy_normal_bits_backward(
+            y_in.data_ptr() if y_in is not None else None, y_hat.data_ptr(), scale.data_ptr(),
+            _DTYPE_CODE[y_hat.dtype], units, elems, gb.data_ptr(), dy.data_ptr(), dscale.data_ptr(),
+            _lib.stream_ptr()))
+        if g_yhat is not None:
+            dy = dy + g_yhat
+        return dy, None, dscale, None, None, None
+
+
+def noisy_normal_bits(bottleneck, scale, coding_rank, noise=None, expected_grads=False):
+    """(y_hat, bits) of a NoisyNormal(0, scale) prior, fused (csrc/noisy_normal_bits.hip): y_hat = bottleneck +
+    noise, bits summed over the last `coding_rank` dimensions; `scale` broadcastable to the bottleneck's shape
+    and differentiable (gradients flow to whatever produced it, e.g. the hyper-synthesis transform)."""
+    lead = bottleneck.shape[:bottleneck.dim() - coding_rank]
+    units = 1
+    for s in lead:
+        units *= int(s)
+    elems = bottleneck.numel() // max(units, 1)
+    scale = torch.broadcast_to(scale.to(bottleneck.device), bottleneck.shape)
+    if noise is not None:
+        noise = noise.to(bottleneck.dtype).contiguous()
+    y_hat, bits = _NoisyNormalBits.apply(bottleneck, noise, scale, units, elems, bool(expected_grads))
+    return y_hat, bits.reshape(lead)
+
+
+def fused_noisy_normal_supported(prior_fn, parameter_fns, bottleneck, coding_rank):
+    from ..distributions import uniform_noise
+    return (prior_fn is uniform_noise.NoisyNormal and set(parameter_fns) == {"loc", "scale"}
+            and bottleneck.is_cuda and bottleneck.dtype in _DTYPE_CODE and coding_rank >= 1
+            and bottleneck.numel() > 0)

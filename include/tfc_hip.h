@@ -391,6 +391,24 @@ int tfc_factorized_bits_backward_expected(const void* y, const void* y_hat, int 
                                           int64_t elems, int64_t channels, const float* params, int layers,
                                           int width, const float* gbits, void* dy, float* dparams, void* stream);
 
+/* Training-time call of the indexed entropy model with a NoisyNormal prior, fused —
+ * python/entropy_models/continuous_indexed.py:313-353 (`__call__(training=True)`: perturb_and_apply of
+ * `_log_prob`), python/distributions/uniform_noise.py:117-156 over a Normal base:
+ *   y_hat = y + noise (noise NULL: y itself);  log p = log(Phi((y_hat + .5) / scale) - Phi((y_hat - .5) / scale));
+ *   bits[unit] = -sum log p / ln 2.
+ * y, noise, y_hat DEV [units, elems] dtype (0 f32, 1 bf16); scale DEV f32 [units, elems] (> 0; the location is
+ * the caller's: it shifts y); bits DEV f32 [units]. */
+int tfc_noisy_normal_bits_forward(const void* y, const void* noise, const float* scale, void* y_hat, int dtype,
+                                  int64_t units, int64_t elems, float* bits, void* stream);
+
+/* Gradients of the above: dy DEV [units, elems] dtype = dL/dy_hat through the likelihood (the caller adds the
+ * straight path), dscale DEV f32 [units, elems] = dL/dscale (overwritten).  y_in non-NULL selects expected
+ * gradients (math_ops.py:157-216): dy = gbits * (log p(y_in + .5) - log p(y_in - .5)) / -ln 2 at the
+ * unperturbed input. */
+int tfc_noisy_normal_bits_backward(const void* y_in, const void* y_hat, const float* scale, int dtype,
+                                   int64_t units, int64_t elems, const float* gbits, void* dy, float* dscale,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

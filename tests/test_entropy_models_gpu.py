@@ -300,3 +300,65 @@ def test_fused_training_bottleneck_expected_grads(num_filters, dtype):
     _, bits2 = em(y2, training=True)
     bits2.sum().backward()
     assert torch.isfinite(y2.grad.float()).all()
+
+
+@pytest.mark.parametrize("dtype,expected", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, False)])
+def test_fused_noisy_normal_bits_matches_torch_path(dtype, expected):
+    """csrc/noisy_normal_bits.hip against the op-by-op evaluation (uniform_noise.py:117-156 over a Normal base,
+    math_ops.py:157-216): same perturbed tensor, bits, gradients w.r.t. the input and the scale — including
+    far tails (|y| up to 40 sigma), where the difference of cumulatives is taken in log space."""
+    from compression_amd.distributions import uniform_noise
+    from compression_amd.ops import bottleneck_ops, math_ops
+    torch.manual_seed(21)
+    shape = (3, 6, 5, 32)
+    log_scale = torch.empty(shape, device="cuda").uniform_(-2.0, 3.0).requires_grad_(True)
+    y = (torch.randn(shape, device="cuda") * torch.exp(log_scale.detach()) * 1.5).to(dtype)
+    y.view(-1)[::97] *= 20.0                       # far tails
+    y.requires_grad_(True)
+    noise = (torch.rand(shape, device="cuda") - 0.5).to(dtype)
+    w = torch.tensor([1.0, -0.5, 2.0], device="cuda")
+
+    def reference():
+        scale = torch.exp(log_scale)
+        f = lambda v: uniform_noise.NoisyNormal(loc=0.0, scale=scale).log_prob(v.to(torch.float32))
+        lp, y_hat = math_ops.perturb_and_apply(f, y, u=noise, expected_grads=expected)
+        return y_hat, lp.sum(dim=(1, 2, 3)) / -float(np.log(2.0))
+
+    def fused():
+        return bottleneck_ops.noisy_normal_bits(y, torch.exp(log_scale), 3, noise, expected_grads=expected)
+
+    outs = []
+    for fn in (reference, fused):
+        y.grad = None
+        log_scale.grad = None
+        y_hat, bits = fn()
+        ((bits * w).sum() + (y_hat.float() ** 2).sum() * 1e-3).backward()
+        outs.append((y_hat.detach(), bits.detach(), y.grad.detach().float().clone(), log_scale.grad.detach().clone()))
+    (yr, br, gr, sr), (yf, bf, gf, sf) = outs
+    assert torch.equal(yr, yf)
+    assert torch.isfinite(bf).all() and torch.isfinite(gf).all() and torch.isfinite(sf).all()
+    assert torch.allclose(br, bf, rtol=2e-5, atol=1e-2)
+    gtol = 5e-4 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(gr, gf, rtol=gtol, atol=gtol * gr.abs().max().item())
+    assert torch.allclose(sr, sf, rtol=5e-4, atol=5e-4 * sr.abs().max().item())
+
+
+def test_location_scale_model_training_call_uses_fused_path():
+    """LocationScaleIndexedEntropyModel(training=True) with NoisyNormal: bits equal the torch evaluation of
+    the same perturbed tensor, gradients reach the bottleneck, the indexes (through scale_fn) and loc."""
+    from compression_amd.distributions import uniform_noise
+    torch.manual_seed(22)
+    scale_fn = lambda i: torch.exp(-2.0 + 0.1 * i)
+    em = tfc.LocationScaleIndexedEntropyModel(uniform_noise.NoisyNormal, 64, scale_fn, coding_rank=3)
+    y = torch.randn(2, 5, 5, 16, device="cuda", requires_grad=True)
+    idx = torch.empty(2, 5, 5, 16, device="cuda").uniform_(0, 63).requires_grad_(True)
+    loc = torch.randn(2, 5, 5, 16, device="cuda", requires_grad=True)
+    y_hat, bits = em(y, idx, loc=loc, training=True)
+    assert y_hat.shape == y.shape and bits.shape == (2,)
+    assert (y_hat - y).abs().max() <= 0.5 + 1e-6
+    prior = uniform_noise.NoisyNormal(loc=0.0, scale=scale_fn(idx.detach()))
+    want = prior.log_prob((y_hat - loc).detach()).sum(dim=(1, 2, 3)) / -float(np.log(2.0))
+    assert torch.allclose(bits.detach(), want, rtol=1e-5, atol=1e-3)
+    bits.sum().backward()
+    for t in (y, idx, loc):
+        assert t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0
