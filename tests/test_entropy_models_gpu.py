@@ -362,3 +362,47 @@ def test_location_scale_model_training_call_uses_fused_path():
     bits.sum().backward()
     for t in (y, idx, loc):
         assert t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0
+
+
+def _fused_normal_prob(x, loc, scale):
+    """Per-element probabilities out of the fused NoisyNormal kernel (one coding unit per element)."""
+    from compression_amd.ops import bottleneck_ops
+    v = (torch.as_tensor(x, dtype=torch.float32, device="cuda") - loc).reshape(-1, 1)
+    s = torch.full_like(v, float(scale))
+    _, bits = bottleneck_ops.noisy_normal_bits(v, s, 1, None)
+    return torch.exp2(-bits).cpu()
+
+
+def test_fused_noisy_normal_closed_form_checks():
+    """The checks of uniform_noise_test.py:46-61 (NoisyNormal) on the FUSED kernel: with the scale going to
+    zero the density is a unit-width box, and on an integer grid it is a PMF."""
+    mean = 10.0
+    x = torch.linspace(mean - 1, mean + 1, 10)
+    assert torch.allclose(_fused_normal_prob(x, mean, 1e-7), torch.tensor([0, 0, 0, 1, 1, 1, 1, 0, 0, 0.]), atol=1e-6)
+    grid = 0.05 + torch.arange(-100, 100, dtype=torch.float32)
+    assert abs(float(_fused_normal_prob(grid, 0.1, 0.3).sum()) - 1.0) < 1e-5
+    # and against the closed form itself, in float64
+    xs = torch.linspace(-6, 6, 49)
+    want = (torch.special.ndtr((xs.double() - 0.1 + 0.5) / 0.7) - torch.special.ndtr((xs.double() - 0.1 - 0.5) / 0.7))
+    assert torch.allclose(_fused_normal_prob(xs, 0.1, 0.7).double(), want, rtol=1e-5, atol=1e-9)
+
+
+def test_fused_deep_factorized_closed_form_checks():
+    """deep_factorized_test.py:119-124 (`test_uniform_is_special_case`) and the PMF property of
+    uniform_noise_test.py:56-61 on the FUSED kernel (one channel, one coding unit per element)."""
+    from compression_amd.ops import bottleneck_ops
+    torch.manual_seed(0)
+
+    def probs(prior, x):
+        v = torch.as_tensor(x, dtype=torch.float32, device="cuda").reshape(-1, 1)
+        _, bits = bottleneck_ops.factorized_bits(v, prior.base, 1, None)
+        return torch.exp2(-bits.detach()).cpu()
+
+    df = tfc.NoisyDeepFactorized(batch_shape=(1,), init_scale=1e-3).cuda()
+    assert torch.allclose(probs(df, torch.linspace(-1, 1, 10)), torch.tensor([0, 0, 0, 1, 1, 1, 1, 0, 0, 0.]), atol=1e-5)
+    df = tfc.NoisyDeepFactorized(batch_shape=(1,), init_scale=3.0).cuda()
+    with torch.no_grad():
+        for prm in df.parameters():
+            prm.add_(0.2 * torch.randn_like(prm))
+    grid = 0.3 + torch.arange(-200, 200, dtype=torch.float32)
+    assert abs(float(probs(df, grid).sum()) - 1.0) < 1e-4
