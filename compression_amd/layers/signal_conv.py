@@ -90,7 +90,21 @@ class SignalConv2D(torch.nn.Module):
             return self.kernel_variable
         if self.kernel_real is None:
             raise RuntimeError("Kernel is not initialized yet. Call build().")
-        return parameters.kernel_from_rdft(self.kernel_real, self.kernel_imag, self.kernel_support)
+        if torch.is_grad_enabled():
+            return parameters.kernel_from_rdft(self.kernel_real, self.kernel_imag, self.kernel_support)
+        # inference (compress / decompress run under no_grad): the inverse RDFT once per parameter version
+        # instead of once per call — 11 small FFTs per bmshj2018 step, and an FFT plan shared by host
+        # threads that code batch slices on different streams is not safe to execute concurrently
+        key = (self.kernel_real.data_ptr(), self.kernel_real._version, self.kernel_imag.data_ptr(),
+               self.kernel_imag._version, str(self.kernel_real.device))
+        cached = getattr(self, "_kernel_cache", None)
+        if cached is None or cached[0] != key:
+            k = parameters.kernel_from_rdft(self.kernel_real, self.kernel_imag, self.kernel_support).contiguous()
+            if k.is_cuda:
+                torch.cuda.current_stream().synchronize()      # complete before another stream reads it
+            object.__setattr__(self, "_kernel_cache", (key, k))
+            cached = self._kernel_cache
+        return cached[1]
 
     def forward(self, inputs):
         if inputs.dim() != 4:
