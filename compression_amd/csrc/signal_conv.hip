@@ -42,7 +42,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int kConvWaves = 4;          // pixel tiles (32 px) per workgroup
-constexpr int kMaxTiles = 6;           // 32-column tiles per column group (192 columns)
+#ifndef TFC_CONV_MAX_TILES
+#define TFC_CONV_MAX_TILES 6
+#endif
+constexpr int kMaxTiles = TFC_CONV_MAX_TILES;   // 32-column tiles per column group (6: 192 columns)
 constexpr int kMaxGroups = 16;         // column groups that can carry their own tap sub-rectangle
 
 struct ConvGeom {
@@ -366,8 +369,11 @@ __global__ void __launch_bounds__(64 * kConvWaves) conv_kernel(const T* x, const
 constexpr int kPF = TFC_CONV_PF;         // B fragments in flight per pixel tile
 constexpr int kChunk2 = TFC_CONV_CHUNK;  // K steps per LDS weight buffer (multiple of kPF)
 
+#ifndef TFC_CONV_WGS
+#define TFC_CONV_WGS 1
+#endif
 template <int TILES, int MT>
-__global__ void __launch_bounds__(256) conv_bf16_kernel(const __bf16* x, const void* packed,
+__global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf16* x, const void* packed,
                                                         const float* bias, __bf16* y, ConvGeom c) {
   extern __shared__ unsigned char smem[];          // 2 x kChunk2 * TILES * 64 fragments of 16 B
   constexpr int CHUNK_FRAGS = kChunk2 * TILES * 64;
@@ -650,7 +656,10 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
              hipStream_t st) {
   constexpr int FB = ConvTraits<T>::kFragBytes;
   const int tiles_total = (c.cols + 31) / 32;
-  c.tiles = std::min(tiles_total, kMaxTiles);
+  // image-side layers (first kernel): 3 column tiles per group — half the accumulators, twice the waves per
+  // CU; measured 3.39 -> 2.98 ms on the 5x5 3 -> 192 /2 layer of bmshj2018 at 128 x 768x512 (for the 192 -> 192
+  // layers of the second kernel the same split costs 45 %: every B gather is then issued twice)
+  c.tiles = std::min(tiles_total, (c.small_cin && std::is_same<T, __bf16>::value) ? std::min(3, kMaxTiles) : kMaxTiles);
   c.groups = (tiles_total + c.tiles - 1) / c.tiles;
   // 64 KiB of LDS per workgroup (two workgroups per CU)
   c.kchunk = std::max(1, std::min(c.ksteps, (64 * 1024) / (c.tiles * 64 * FB)));
