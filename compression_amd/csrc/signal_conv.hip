@@ -768,6 +768,85 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Transposed convolution into a few channels (the last synthesis layer, C -> 3), bf16: as an implicit
+// GEMM over output pixels it gathers every input pixel once per low-resolution tap (9 times for a 5x5
+// stride-2 kernel) for 12 useful of 32 MFMA columns, and those gathers are all its time (6.8 ms at the
+// C4 shape, 1.9 ms without them).  Instead: ONE 1x1 product per INPUT pixel with all kh*kw taps as output
+// columns, z[i][(ty, tx, c)] = sum_ci x[i][ci] w[ty][tx][ci][c] (the same kernel, 12 K steps per pixel
+// tile instead of 108), then every output pixel sums the <= ceil(k/s)^2 entries that land on it:
+// o = i*s + t - k/2 (signal_conv.py:778-847; the alignment test_identity_kernel_alignment pins).
+// z is bf16 (fp32 accumulation inside the product, one rounding per tap), 4 columns per tap so that a
+// tap's channels are one aligned 8-byte read.
+// ---------------------------------------------------------------------------
+__global__ void conv_up_weights_kernel(const float* w, int kh, int kw, int cin, int cout, float* w1) {
+  const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  const long long total = static_cast<long long>(cin) * kh * kw * 4;
+  if (idx >= total) return;
+  const int c = idx & 3;
+  const int tap = static_cast<int>((idx >> 2) % (kh * kw));
+  const int ci = static_cast<int>(idx / (4ll * kh * kw));
+  w1[idx] = c < cout ? w[(static_cast<long long>(tap) * cin + ci) * cout + c] : 0.f;     // [ci][tap][4]
+}
+
+__global__ void __launch_bounds__(256) conv_up_gather_kernel(const __bf16* z, const float* bias, __bf16* y,
+                                                             long long N, int H, int W, int kh, int kw, int s,
+                                                             int cout, int activation) {
+  const int OH = H * s, OW = W * s;
+  const long long o = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  if (o >= N * OH * OW) return;
+  const int ox = static_cast<int>(o % OW);
+  const int oy = static_cast<int>((o / OW) % OH);
+  const long long n = o / (static_cast<long long>(OW) * OH);
+  const int zc = kh * kw * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // o = i*s + t - k/2  =>  t = (o + k/2) mod s, + s, ... ;  i = (o + k/2 - t) / s
+  for (int ty = (oy + kh / 2) % s; ty < kh; ty += s) {
+    const int iy = (oy + kh / 2 - ty) / s;
+    if (iy < 0 || iy >= H) continue;
+    for (int tx = (ox + kw / 2) % s; tx < kw; tx += s) {
+      const int ix = (ox + kw / 2 - tx) / s;
+      if (ix < 0 || ix >= W) continue;
+      const u32x2 v = *reinterpret_cast<const u32x2*>(z + ((n * H + iy) * W + ix) * zc + (ty * kw + tx) * 4);
+      acc[0] += __uint_as_float(v.x << 16);
+      acc[1] += __uint_as_float(v.x & 0xFFFF0000u);
+      acc[2] += __uint_as_float(v.y << 16);
+      acc[3] += __uint_as_float(v.y & 0xFFFF0000u);
+    }
+  }
+  for (int c = 0; c < cout; ++c) {
+    float v = acc[c] + (bias ? bias[c] : 0.f);
+    if (activation == 1) v = fmaxf(v, 0.f);
+    y[o * cout + c] = static_cast<__bf16>(v);
+  }
+}
+
+int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
+               int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
+               int activation, int up, void* stream);
+
+int conv_up_small_cout(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h,
+                       int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride, int activation,
+                       hipStream_t st) {
+  const int zc = kh * kw * 4;
+  DevBuf w1, z;
+  TFC_HIP(w1.alloc(sizeof(float) * cin * zc, st));
+  TFC_HIP(z.alloc(sizeof(__bf16) * static_cast<size_t>(n) * h * wd * zc, st));
+  const long long wtotal = static_cast<long long>(cin) * zc;
+  hipLaunchKernelGGL(conv_up_weights_kernel, dim3(static_cast<unsigned>(ceil_div(wtotal, 256))), dim3(256), 0, st, w,
+                     kh, kw, static_cast<int>(cin), static_cast<int>(cout), w1.as<float>());
+  // the 1x1 product: a "down" convolution with a 1x1 kernel, stride 1, no bias, no activation
+  if (int rc = conv_entry(x, w1.p, nullptr, z.p, 1, n, h, wd, cin, zc, 1, 1, 1, 0, 0, st)) return rc;
+  const long long outs = n * h * stride * wd * stride;
+  if (ceil_div(outs, 256) >= (1ll << 31)) return fail("tfc_conv2d_up: problem too large for one launch");
+  KernelTimer timer("conv2d", st);
+  hipLaunchKernelGGL(conv_up_gather_kernel, dim3(static_cast<unsigned>(ceil_div(outs, 256))), dim3(256), 0, st,
+                     z.as<__bf16>(), bias, static_cast<__bf16*>(y), static_cast<long long>(n), static_cast<int>(h),
+                     static_cast<int>(wd), kh, kw, stride, static_cast<int>(cout), activation);
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
                int activation, int up, void* stream) {
@@ -778,6 +857,13 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
                 static_cast<long long>(cin));
   if (activation != 0 && activation != 1) return fail("tfc_conv2d: activation must be 0 (none) or 1 (relu)");
   if (n == 0 || h == 0 || wd == 0) return 0;
+#ifndef TFC_CONV_NO_UP_GATHER
+  // (up to 128 product columns, i.e. one column group: a 9x9 stride-4 kernel has 324 and measured the same
+  // or slower this way — 0.19 against 0.16 ms at batch 64 — so it keeps the implicit GEMM over output pixels)
+  if (up && dtype == 1 && cout <= 4 && cin % 16 == 0 && stride >= 2 && kh * kw * 4 <= 128)
+    return conv_up_small_cout(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, activation,
+                              static_cast<hipStream_t>(stream));
+#endif
   ConvGeom c{};
   PackGeom g{};
   g.kh = kh; g.kw = kw; g.Cin_real = static_cast<int>(cin); g.Cout = static_cast<int>(cout);

@@ -101,6 +101,25 @@ def test_bf16_paths():
     assert (y - want).abs().max() <= 2 ** -7 * max(1.0, want.abs().max())
 
 
+@pytest.mark.parametrize("k,s,cin,cout,hw", [(5, 2, 192, 3, (13, 9)), (9, 4, 64, 3, (7, 10)), (5, 2, 32, 1, (6, 6)),
+                                             (4, 2, 48, 4, (5, 8)), (5, 3, 32, 2, (4, 7))])
+def test_up_into_few_channels_bf16(k, s, cin, cout, hw):
+    """The last synthesis layer (C -> 3 and the like, bf16; kernels up to 5x5) runs as one 1x1 product per input
+    pixel plus a gather over the taps that land on an output pixel (signal_conv.hip, conv_up_small_cout), larger
+    kernels as the implicit GEMM over output pixels: same result as the definition (signal_conv.py:778-847),
+    with bias and with ReLU."""
+    from compression_amd.layers import conv2d_up
+    torch.manual_seed(k * 10 + s)
+    x = torch.randn(3, hw[0], hw[1], cin).bfloat16()
+    ker = (torch.randn(k, k, cin, cout) / (k * cin ** 0.5)).bfloat16().float()
+    bias = torch.randn(cout)
+    for act in (None, "relu"):
+        want = ref_up(x.float(), ker, bias, s, act == "relu")
+        y = conv2d_up(x.cuda(), ker, bias, s, act).float().cpu()
+        assert y.shape == want.shape
+        assert (y - want).abs().max() <= 2 ** -7 * max(1.0, want.abs().max())
+
+
 def test_identity_kernel_alignment():
     """signal_conv_test.py:266-314: with a centred delta kernel, `same_zeros` output
     sample 0 is aligned with input sample 0 (down: subsampling; up: zero-stuffing)."""
