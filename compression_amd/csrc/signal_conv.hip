@@ -69,6 +69,7 @@ struct ConvGeom {
   int small_cin;          // 1: packed-image mode (K runs along kernel rows)
   int kw4;                // small_cin: K steps per kernel row
   int activation;         // 0 none, 1 relu
+  int out_f32;            // bf16 kernels: write the fp32 accumulators (the tap products of conv_up_small_cout)
   // output
   int OH, OW;
   // Compact K (second-generation bf16 kernel, transposed convolution whose column groups are whole output
@@ -551,7 +552,7 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
   // ---- epilogue: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel mm[p] ----
   const int colbase = group * TILES * 32;
   const bool vec4 = (c.Cout & 3) == 0;       // 4 consecutive columns = 4 channels of one phase
-  if ((c.Cout & 7) == 0) {
+  if ((c.Cout & 7) == 0 && !c.out_f32) {
     // 8 consecutive columns = 8 channels of one pixel: lanes l and l + 32 (the same pixel, h = 0 / 1) trade
     // halves of a pair of column groups (v_permlane32_swap, as in gdn_common.h) and each stores 16 bytes,
     // 32 contiguous bytes per pixel and instruction.  With 8-byte stores the output traffic of the layers
@@ -628,7 +629,11 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
           v[r] = acc[p][t][4 * q + r] + b4[r];
           if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
         }
-        if (vec4) {
+        if (vec4 && c.out_f32) {
+          const int oy = qy[p] * c.su + phase / c.su, ox = qx[p] * c.su + phase % c.su;
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + ((nn[p] * c.OH + oy) * c.OW + ox) * c.Cout + co) =
+              f32x4{v[0], v[1], v[2], v[3]};
+        } else if (vec4) {
           // su == 1: phase 0, (oy, ox) = (qy, qx); else depth-to-space of the column's phase
           const int oy = qy[p] * c.su + phase / c.su, ox = qx[p] * c.su + phase % c.su;
           u32x2 o;
@@ -776,8 +781,9 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
 // columns, z[i][(ty, tx, c)] = sum_ci x[i][ci] w[ty][tx][ci][c] (the same kernel, 12 K steps per pixel
 // tile instead of 108), then every output pixel sums the <= ceil(k/s)^2 entries that land on it:
 // o = i*s + t - k/2 (signal_conv.py:778-847; the alignment test_identity_kernel_alignment pins).
-// z is bf16 (fp32 accumulation inside the product, one rounding per tap), 4 columns per tap so that a
-// tap's channels are one aligned 8-byte read.
+// z holds the products' fp32 accumulators (a bf16 z would round once per tap: with cancelling taps the error
+// is relative to the taps, not to the output), 4 columns per tap so that a tap's channels are one aligned
+// 16-byte read; the output is rounded once, like the implicit GEMM's.
 // ---------------------------------------------------------------------------
 __global__ void conv_up_weights_kernel(const float* w, int kh, int kw, int cin, int cout, float* w1) {
   const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
@@ -789,7 +795,7 @@ __global__ void conv_up_weights_kernel(const float* w, int kh, int kw, int cin, 
   w1[idx] = c < cout ? w[(static_cast<long long>(tap) * cin + ci) * cout + c] : 0.f;     // [ci][tap][4]
 }
 
-__global__ void __launch_bounds__(256) conv_up_gather_kernel(const __bf16* z, const float* bias, __bf16* y,
+__global__ void __launch_bounds__(256) conv_up_gather_kernel(const float* z, const float* bias, __bf16* y,
                                                              long long N, int H, int W, int kh, int kw, int s,
                                                              int cout, int activation) {
   const int OH = H * s, OW = W * s;
@@ -807,11 +813,11 @@ __global__ void __launch_bounds__(256) conv_up_gather_kernel(const __bf16* z, co
     for (int tx = (ox + kw / 2) % s; tx < kw; tx += s) {
       const int ix = (ox + kw / 2 - tx) / s;
       if (ix < 0 || ix >= W) continue;
-      const u32x2 v = *reinterpret_cast<const u32x2*>(z + ((n * H + iy) * W + ix) * zc + (ty * kw + tx) * 4);
-      acc[0] += __uint_as_float(v.x << 16);
-      acc[1] += __uint_as_float(v.x & 0xFFFF0000u);
-      acc[2] += __uint_as_float(v.y << 16);
-      acc[3] += __uint_as_float(v.y & 0xFFFF0000u);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(z + ((n * H + iy) * W + ix) * zc + (ty * kw + tx) * 4);
+      acc[0] += v[0];
+      acc[1] += v[1];
+      acc[2] += v[2];
+      acc[3] += v[3];
     }
   }
   for (int c = 0; c < cout; ++c) {
@@ -823,7 +829,7 @@ __global__ void __launch_bounds__(256) conv_up_gather_kernel(const __bf16* z, co
 
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
-               int activation, int up, void* stream);
+               int activation, int up, void* stream, bool out_f32 = false);
 
 int conv_up_small_cout(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h,
                        int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride, int activation,
@@ -831,17 +837,17 @@ int conv_up_small_cout(const void* x, const float* w, const float* bias, void* y
   const int zc = kh * kw * 4;
   DevBuf w1, z;
   TFC_HIP(w1.alloc(sizeof(float) * cin * zc, st));
-  TFC_HIP(z.alloc(sizeof(__bf16) * static_cast<size_t>(n) * h * wd * zc, st));
+  TFC_HIP(z.alloc(sizeof(float) * static_cast<size_t>(n) * h * wd * zc, st));
   const long long wtotal = static_cast<long long>(cin) * zc;
   hipLaunchKernelGGL(conv_up_weights_kernel, dim3(static_cast<unsigned>(ceil_div(wtotal, 256))), dim3(256), 0, st, w,
                      kh, kw, static_cast<int>(cin), static_cast<int>(cout), w1.as<float>());
   // the 1x1 product: a "down" convolution with a 1x1 kernel, stride 1, no bias, no activation
-  if (int rc = conv_entry(x, w1.p, nullptr, z.p, 1, n, h, wd, cin, zc, 1, 1, 1, 0, 0, st)) return rc;
+  if (int rc = conv_entry(x, w1.p, nullptr, z.p, 1, n, h, wd, cin, zc, 1, 1, 1, 0, 0, st, true)) return rc;
   const long long outs = n * h * stride * wd * stride;
   if (ceil_div(outs, 256) >= (1ll << 31)) return fail("tfc_conv2d_up: problem too large for one launch");
   KernelTimer timer("conv2d", st);
   hipLaunchKernelGGL(conv_up_gather_kernel, dim3(static_cast<unsigned>(ceil_div(outs, 256))), dim3(256), 0, st,
-                     z.as<__bf16>(), bias, static_cast<__bf16*>(y), static_cast<long long>(n), static_cast<int>(h),
+                     z.as<float>(), bias, static_cast<__bf16*>(y), static_cast<long long>(n), static_cast<int>(h),
                      static_cast<int>(wd), kh, kw, stride, static_cast<int>(cout), activation);
   TFC_HIP(hipGetLastError());
   return 0;
@@ -849,7 +855,7 @@ int conv_up_small_cout(const void* x, const float* w, const float* bias, void* y
 
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
-               int activation, int up, void* stream) {
+               int activation, int up, void* stream, bool out_f32) {
   if (dtype != 0 && dtype != 1) return fail("tfc_conv2d: dtype must be 0 (float32) or 1 (bfloat16)");
   if (kh < 1 || kw < 1 || stride < 1 || cin < 1 || cout < 1) return fail("tfc_conv2d: bad geometry");
   if (!(cin % 16 == 0 || cin <= 4))
@@ -871,6 +877,7 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
   c.N = n; c.H = static_cast<int>(h); c.W = static_cast<int>(wd);
   c.Cout = static_cast<int>(cout);
   c.activation = activation;
+  c.out_f32 = out_f32 ? 1 : 0;        // only reached with the second-generation bf16 kernel (Cin % 16 == 0, Cout % 4 == 0)
   if (!up) {
     c.sd = stride; c.su = 1;
     c.Uy = kh; c.Ux = kw;
