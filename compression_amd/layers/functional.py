@@ -66,8 +66,28 @@ def conv2d_wgrad(a, b, kernel_support, stride, transpose):
     """Weight gradient kernel: G[t][ca][cb] = sum A[n, q*s + t - k/2, ca] B[n, q, cb] as a float32
     [kh, kw, Cin, Cout] tensor (transpose=True: A carries Cout, B carries Cin)."""
     _lib.require_device()
-    a, b = a.contiguous(), b.contiguous()
     kh, kw = kernel_support
+    ca, cb = a.shape[-1], b.shape[-1]
+    built = (256, 192, 128, 64, 32)
+    if any(c > 4 and c not in built for c in (ca, cb)) and ca % 32 == 0 and cb % 32 == 0:
+        # the kernel is built for 32, 64, 128, 192 or 256 channels on either side; the gradient of a channel
+        # block pair only needs those channels, so other widths (ms2020: 224, 320 .. 512) go in blocks
+        def blocks(c):
+            if c <= 4 or c in built:
+                return [(0, c)]
+            out, i = [], 0
+            while i < c:
+                w = next(w for w in built if w <= c - i)
+                out.append((i, i + w))
+                i += w
+            return out
+        rows = []
+        for a0, a1 in blocks(ca):
+            cols = [conv2d_wgrad(a[..., a0:a1], b[..., b0:b1], kernel_support, stride, transpose)
+                    for b0, b1 in blocks(cb)]
+            rows.append(torch.cat(cols, dim=2 if transpose else 3))
+        return torch.cat(rows, dim=3 if transpose else 2)
+    a, b = a.contiguous(), b.contiguous()
     n, ha, wa, ca = a.shape
     _, hb, wb, cb = b.shape
     shape = (kh, kw, cb, ca) if transpose else (kh, kw, ca, cb)

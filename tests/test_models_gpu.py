@@ -144,3 +144,58 @@ def test_bls2017_training_steps_reduce_the_loss():
     missing = [n for n, p in model.named_parameters() if p.grad is None]
     assert not missing, f"parameters without gradient: {missing}"
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < np.mean(losses[:3])
+
+
+def test_ms2020_roundtrip_and_slice_order():
+    """ms2020.py:334-420: z string + one string per channel slice; decompress reproduces exactly what the
+    encoder's own reconstruction path gives (synthesis of the LRP-corrected slices), and decoding is
+    insensitive to nothing but the strings (a wrong slice string changes the output)."""
+    torch.manual_seed(4)
+    model = tfc.models.MS2020Model(num_filters=64, latent_depth=64, hyperprior_depth=32, num_slices=4,
+                                   max_support_slices=2).cuda().init_compression()
+    x = torch.from_numpy(synthetic.lowpass_images(2, 96, 80, seed=5)).cuda()       # 80 is not a multiple of 64
+    out = model.compress(x)
+    x_shape, y_shape, z_shape = out[:3]
+    assert x_shape == (96, 80) and y_shape == (6, 5) and z_shape == (2, 2)
+    assert len(out) == 4 + 4 and all(s.shape == (2,) for s in out[3:])
+    x_hat = model.decompress(*out)
+    assert x_hat.shape == (2, 96, 80, 3) and x_hat.dtype == torch.uint8
+    # the encoder's view of the reconstruction: quantised slices with the same parameters
+    with torch.no_grad():
+        y = model.analysis_transform(x.float())
+        z = model.hyper_analysis_transform(y)
+        z_hat = model.em_z.quantize(z)
+        ls, lm = model._hyper_features(z_hat, y_shape)
+        slices = []
+        for k, ys in enumerate(torch.chunk(y, 4, dim=-1)):
+            ms, mu, sigma = model._slice_params(k, lm, ls, slices, y_shape)
+            slices.append(model._lrp(k, ms, model.em_y.quantize(ys, loc=mu)))
+        ref = model.synthesis_transform(torch.cat(slices, dim=-1))[:, :96, :80, :]
+        ref = torch.clamp(torch.round(ref), 0, 255).to(torch.uint8)
+    assert torch.equal(x_hat, ref)
+    # a second call gives the same strings; swapping two slice strings does not decode to the same image
+    again = model.compress(x)
+    assert all(bytes(a) == bytes(b) for sa, sb in zip(out[3:], again[3:]) for a, b in zip(sa, sb))
+    swapped = list(out)
+    swapped[4], swapped[5] = swapped[5], swapped[4]
+    try:
+        other = model.decompress(*swapped)
+        assert not torch.equal(other, x_hat)
+    except RuntimeError:
+        pass                                          # the decoder's sanity check may already reject it
+
+
+def test_ms2020_training_forward_and_backward():
+    torch.manual_seed(6)
+    # slice depth 32 like the full model (latent_depth 320 / 10 slices); the support tensors are 320 + 32 k
+    # channels wide, so the weight gradients of the slice transforms go through the > 256-channel blocking
+    model = tfc.models.MS2020Model(num_filters=32, latent_depth=64, hyperprior_depth=32, num_slices=2,
+                                   max_support_slices=1).cuda()
+    x = torch.from_numpy(synthetic.lowpass_images(2, 64, 64, seed=7)).cuda()
+    loss, bpp, mse = model(x, training=True)
+    assert torch.isfinite(loss) and bpp > 0 and mse > 0
+    loss.backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 20 and all(torch.isfinite(g).all() for g in grads)
+    loss_eval, _, _ = model(x, training=False)
+    assert torch.isfinite(loss_eval)

@@ -157,6 +157,8 @@ GRAD_CASES = [
     (True, 1, 6, 5, 192, 192, 5, 2, False),       # C -> C synthesis
     (True, 1, 5, 6, 192, 3, 9, 4, False),         # last synthesis layer: narrow Cout
     (True, 1, 9, 8, 64, 64, 3, 1, True),
+    (True, 1, 6, 7, 352, 224, 5, 1, True),        # ms2020 slice transform widths: weight gradient in channel blocks
+    (False, 1, 8, 6, 320, 256, 5, 2, False),      # ms2020 hyper-analysis layer 1
 ]
 
 
