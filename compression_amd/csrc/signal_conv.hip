@@ -367,15 +367,24 @@ __global__ void __launch_bounds__(64 * kConvWaves) conv_kernel(const T* x, const
 #ifndef TFC_CONV_INTERLEAVE
 #define TFC_CONV_INTERLEAVE 1
 #endif
+#ifndef TFC_CONV_NO_FASTK
+#define TFC_CONV_NO_FASTK 0
+#endif
 constexpr int kPF = TFC_CONV_PF;         // B fragments in flight per pixel tile
 constexpr int kChunk2 = TFC_CONV_CHUNK;  // K steps per LDS weight buffer (multiple of kPF)
 
 #ifndef TFC_CONV_WGS
 #define TFC_CONV_WGS 1
 #endif
-template <int TILES, int MT>
+// FASTK (the host sets it when the channel blocks of a tap are a whole number of weight chunks, Cin % 64 == 0,
+// and B fragments are requested exactly one chunk ahead): all K steps of a chunk then belong to ONE tap, so
+// the tap's coordinates, the bounds test and the per-lane pointer (the zero page for lanes outside the image)
+// are set up once per chunk and the K steps' loads are that pointer plus an immediate offset — no address
+// arithmetic, no tap walk and no selects inside the K step.
+template <int TILES, int MT, bool FASTK, bool OUTF32 = false>
 __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf16* x, const void* packed,
                                                         const float* bias, __bf16* y, ConvGeom c) {
+  static_assert(!FASTK || kPF == kChunk2, "FASTK requests the B fragments of the next chunk during this one");
   extern __shared__ unsigned char smem[];          // 2 x kChunk2 * TILES * 64 fragments of 16 B
   constexpr int CHUNK_FRAGS = kChunk2 * TILES * 64;
   constexpr int STAGE = (CHUNK_FRAGS + 255) / 256;  // 16-byte pieces each thread moves per chunk
@@ -487,11 +496,45 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
   wstore(0);
   u32x4 bq[kPF][MT];
   KPos kpre{uy0, ux0, 0, (static_cast<long long>(uy0) * c.W + ux0) * c.Cin};   // the next B fragment to request
+  // FASTK: per-lane source of the chunk being requested (K step kk of it at + 32 kk bytes), and its tap
+  unsigned long long bsrc[MT];
+  int fuy = uy0, fux = ux0, fcbi = 0;
+  auto chunk_sources = [&]() __attribute__((always_inline)) {
+    const long long off = (static_cast<long long>(fuy) * c.W + fux) * c.Cin + 16 * fcbi;
 #pragma unroll
-  for (int k = 0; k < kPF; ++k) {
+    for (int p = 0; p < MT; ++p) {
+      const bool ok = live[p] & (static_cast<unsigned int>(iy0[p] + fuy) < static_cast<unsigned int>(c.H)) &
+                      (static_cast<unsigned int>(ix0[p] + fux) < static_cast<unsigned int>(c.W)) & (fuy < uy1);
+      unsigned long long a_in = reinterpret_cast<unsigned long long>(x) +
+                                2ull * static_cast<unsigned long long>(base_off[p] + off);
+      asm volatile("" : "+v"(a_in));
+      bsrc[p] = ok ? a_in : reinterpret_cast<unsigned long long>(zeros);
+    }
+    // on to the next chunk's position: kChunk2 channel blocks further, by selects
+    const int cbn = fcbi + kChunk2;
+    const bool wc = cbn == cb;
+    const int uxn = fux + (wc ? 1 : 0);
+    const bool wx = uxn == ux1;
+    fcbi = wc ? 0 : cbn;
+    fux = wx ? ux0 : uxn;
+    fuy += wx ? 1 : 0;
+  };
+  auto fast_load = [&](int kk, int p) __attribute__((always_inline)) -> u32x4 {
+    return *reinterpret_cast<__attribute__((address_space(1))) const u32x4*>(bsrc[p] + 32ull * kk);
+  };
+  if constexpr (FASTK) {
+    chunk_sources();
 #pragma unroll
-    for (int p = 0; p < MT; ++p) bq[k][p] = bload(kpre, p);
-    advance(kpre);
+    for (int k = 0; k < kPF; ++k)
+#pragma unroll
+      for (int p = 0; p < MT; ++p) bq[k][p] = fast_load(k, p);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) {
+#pragma unroll
+      for (int p = 0; p < MT; ++p) bq[k][p] = bload(kpre, p);
+      advance(kpre);
+    }
   }
   __syncthreads();
 
@@ -500,6 +543,7 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
 #ifndef TFC_CONV_BARE       // (experiment: MFMAs only -- no weight staging, no barrier, with NOAREAD / NOBLOAD)
     wfetch(chunk + 1);          // past the last chunk: the clamped fragment, not used
 #endif
+    if constexpr (FASTK) chunk_sources();     // of chunk + 1, whose fragments this chunk's K steps request
     const bf16x8* abase = reinterpret_cast<const bf16x8*>(smem) + buf * CHUNK_FRAGS + lane;
     bf16x8 af[2][TILES];
 #pragma unroll
@@ -524,9 +568,14 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
       // refill the ring slot with K step ks + PF (past the last tap row: zeros); after the MFMAs
       // that read it so that no copy of the slot is needed
 #ifndef TFC_CONV_BARE
+      if constexpr (FASTK) {
 #pragma unroll
-      for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = bload(kpre, p);
-      advance(kpre);
+        for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = fast_load(kk, p);
+      } else {
+#pragma unroll
+        for (int p = 0; p < MT; ++p) bq[kk % kPF][p] = bload(kpre, p);
+        advance(kpre);
+      }
 #endif
 #if TFC_CONV_INTERLEAVE
       // One wave per SIMD: an MFMA occupies the matrix pipe for 32 cycles = 8 issue slots, about five other
@@ -552,7 +601,7 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
   // ---- epilogue: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel mm[p] ----
   const int colbase = group * TILES * 32;
   const bool vec4 = (c.Cout & 3) == 0;       // 4 consecutive columns = 4 channels of one phase
-  if ((c.Cout & 7) == 0 && !c.out_f32) {
+  if ((c.Cout & 7) == 0 && !OUTF32) {
     // 8 consecutive columns = 8 channels of one pixel: lanes l and l + 32 (the same pixel, h = 0 / 1) trade
     // halves of a pair of column groups (v_permlane32_swap, as in gdn_common.h) and each stores 16 bytes,
     // 32 contiguous bytes per pixel and instruction.  With 8-byte stores the output traffic of the layers
@@ -629,7 +678,7 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
           v[r] = acc[p][t][4 * q + r] + b4[r];
           if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
         }
-        if (vec4 && c.out_f32) {
+        if (OUTF32 && vec4) {
           const int oy = qy[p] * c.su + phase / c.su, ox = qx[p] * c.su + phase % c.su;
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + ((nn[p] * c.OH + oy) * c.OW + ox) * c.Cout + co) =
               f32x4{v[0], v[1], v[2], v[3]};
@@ -696,8 +745,10 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
   }
   DevBuf packed, padded;
   const long long frags = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
-  TFC_HIP(packed.alloc(static_cast<size_t>(frags) * FB + 16, st));
-  TFC_HIP(hipMemsetAsync(static_cast<unsigned char*>(packed.p) + static_cast<size_t>(frags) * FB, 0, 16, st));
+  // + a zero page behind the fragments: what lanes outside the image read (16 bytes; the per-chunk pointers of
+  // the FASTK kernel read it at + 32 (kChunk2 - 1))
+  TFC_HIP(packed.alloc(static_cast<size_t>(frags) * FB + 32 * kChunk2, st));
+  TFC_HIP(hipMemsetAsync(static_cast<unsigned char*>(packed.p) + static_cast<size_t>(frags) * FB, 0, 32 * kChunk2, st));
   hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(static_cast<unsigned>(ceil_div(frags, 256))),
                      dim3(256), 0, st, w, g, c, packed.p);
   const T* xin = static_cast<const T*>(x);
@@ -725,15 +776,32 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
     const dim3 grid2(static_cast<unsigned>(pb * c.groups));
     const size_t lds2 = static_cast<size_t>(2) * kChunk2 * c.tiles * 64 * 16;
     KernelTimer timer("conv2d", st);
-#define TFC_CONV2_LAUNCH(NT, MTV)                                                                  \
+#define TFC_CONV2_LAUNCH(NT, MTV, FK)                                                              \
     do {                                                                                           \
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<NT, MTV>),       \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<NT, MTV, FK>),   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2))); \
-      hipLaunchKernelGGL((conv_bf16_kernel<NT, MTV>), grid2, dim3(256), lds2, st,                  \
+      hipLaunchKernelGGL((conv_bf16_kernel<NT, MTV, FK>), grid2, dim3(256), lds2, st,              \
                          static_cast<const __bf16*>(static_cast<const void*>(xin)), packed.p, bias,  \
                          static_cast<__bf16*>(y), c);                                              \
     } while (0)
-#define TFC_CONV2_CASE(NT) case NT: if (mt == 2) TFC_CONV2_LAUNCH(NT, 2); else TFC_CONV2_LAUNCH(NT, 1); break
+    // one tap per weight chunk (see the kernel): channel blocks per tap a multiple of the chunk
+    const bool fastk = kPF == kChunk2 && (c.Cin / 16) % kChunk2 == 0 && !TFC_CONV_NO_FASTK;
+    // (the fp32-output variant is a compile-time property: as a run-time flag in the epilogue it cost the
+    // 6-tile kernel 832 bytes of scratch per lane, accumulators spilled inside the K loop)
+#define TFC_CONV2_LAUNCH_F32(NT, MTV)                                                              \
+    do {                                                                                           \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<NT, MTV, false, true>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2))); \
+      hipLaunchKernelGGL((conv_bf16_kernel<NT, MTV, false, true>), grid2, dim3(256), lds2, st,     \
+                         static_cast<const __bf16*>(static_cast<const void*>(xin)), packed.p, bias,  \
+                         static_cast<__bf16*>(y), c);                                              \
+    } while (0)
+#define TFC_CONV2_CASE(NT)                                                                         \
+    case NT:                                                                                       \
+      if (c.out_f32) { if (mt == 2) TFC_CONV2_LAUNCH_F32(NT, 2); else TFC_CONV2_LAUNCH_F32(NT, 1); } \
+      else if (mt == 2) { if (fastk) TFC_CONV2_LAUNCH(NT, 2, true); else TFC_CONV2_LAUNCH(NT, 2, false); } \
+      else { if (fastk) TFC_CONV2_LAUNCH(NT, 1, true); else TFC_CONV2_LAUNCH(NT, 1, false); }      \
+      break
     switch (c.tiles) {
       TFC_CONV2_CASE(1);
       TFC_CONV2_CASE(2);
@@ -745,6 +813,7 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
     }
 #undef TFC_CONV2_CASE
 #undef TFC_CONV2_LAUNCH
+#undef TFC_CONV2_LAUNCH_F32
     TFC_HIP(hipGetLastError());
     return 0;
   }
