@@ -197,7 +197,11 @@ class MS2020Model(torch.nn.Module):
             mean_support, mu, sigma = self._slice_params(k, latent_means, latent_scales, y_hat_slices, y_shape)
             s = self.em_y.compress(y_slice.contiguous(), sigma.contiguous(), mu.contiguous())
             y_strings.append(s)
-            y_hat_slice = self.em_y.decompress(s, sigma.contiguous(), mu.contiguous()).to(self.compute_dtype)
+            # What the decoder will see.  The reference decodes the string it has just written
+            # (ms2020.py:366); decode(encode(y)) is round(y - mu) + mu, which quantize() computes without the
+            # slice's serial decode (half of compress()'s coder time); the round-trip test checks that the two
+            # sides reconstruct the same image bit for bit.
+            y_hat_slice = self.em_y.quantize(y_slice, loc=mu).to(self.compute_dtype)
             y_hat_slices.append(self._lrp(k, mean_support, y_hat_slice))
         return (x_shape, y_shape, z_shape, z_string) + tuple(y_strings)
 
