@@ -1,8 +1,9 @@
-"""File-level compress / decompress of the two models and their command line
-(models/bls2017.py:273-323, models/bmshj2018.py:348-398): PNG in, `.tfci` out and back.
-The container is the reference's PackedTensors layout — bls2017: [string, x_shape,
-y_shape]; bmshj2018: [string, side_string, x_shape, y_shape, z_shape] — so files are
-interchangeable with ones a reference model of the same weights would write."""
+"""File-level compress / decompress of the models and their command line
+(models/bls2017.py:273-323, models/bmshj2018.py:348-398, models/ms2020.py:520-568): PNG in, `.tfci` out and
+back.  The container is the reference's PackedTensors layout, in the order the model's compress() returns —
+bls2017: [string, x_shape, y_shape]; bmshj2018: [string, side_string, x_shape, y_shape, z_shape]; ms2020:
+[x_shape, y_shape, z_shape, z_string, y_string_0 ...] — so files are interchangeable with ones a reference
+model of the same weights would write."""
 from __future__ import annotations
 
 import argparse
@@ -12,7 +13,8 @@ import torch
 
 from ..util import PackedTensors
 
-__all__ = ["read_png", "write_png", "compress_file", "decompress_file", "load_checkpoint", "main"]
+__all__ = ["read_png", "write_png", "compress_file", "decompress_file", "container_dtypes", "load_checkpoint",
+           "main"]
 
 
 def read_png(filename) -> torch.Tensor:
@@ -34,6 +36,16 @@ def _pack(tensors) -> PackedTensors:
     packed.pack([np.asarray(t, dtype=object) if isinstance(t, np.ndarray) and t.dtype == object
                  else np.asarray(t, dtype=np.int32) for t in tensors])
     return packed
+
+
+def container_dtypes(model):
+    """The dtypes of decompress()'s arguments, in order (the reference reads them off
+    `model.decompress.input_signature`, bls2017.py:314, ms2020.py:560): a model either names them itself
+    (`container_dtypes`, ms2020) or has its strings first and its shapes after them."""
+    own = getattr(model, "container_dtypes", None)
+    if own is not None:
+        return list(own)
+    return [bytes] * model.num_strings + [np.int32] * (model.num_packed - model.num_strings)
 
 
 def compress_file(model, input_file, output_file, verbose=False):
@@ -59,12 +71,10 @@ def decompress_file(model, input_file, output_file=None):
     """bls2017.py:310-323: .tfci -> uint8 [H, W, 3] (and a PNG if output_file is given)."""
     with open(input_file, "rb") as f:
         packed = PackedTensors(f.read())
-    nstrings = model.num_strings
-    dtypes = [bytes] * nstrings + [np.int32] * (model.num_packed - nstrings)
+    dtypes = container_dtypes(model)
     tensors = packed.unpack(dtypes)
-    strings = tensors[:nstrings]
-    shapes = [tuple(int(v) for v in t) for t in tensors[nstrings:]]
-    x_hat = model.decompress(*strings, *shapes)[0]
+    tensors = [t if d is bytes else tuple(int(v) for v in t) for t, d in zip(tensors, dtypes)]
+    x_hat = model.decompress(*tensors)[0]
     if output_file is not None:
         write_png(output_file, x_hat)
     return x_hat

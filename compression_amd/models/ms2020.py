@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 
 from .. import distributions, entropy_models, layers
@@ -123,6 +124,11 @@ class MS2020Model(torch.nn.Module):
         self.hyperprior = distributions.NoisyDeepFactorized(batch_shape=(hyperprior_depth,))
         self.em_y = self.em_z = None
 
+    @property
+    def container_dtypes(self):
+        """.tfci layout = decompress()'s signature (ms2020.py:390, :560): three shapes, then the strings."""
+        return [np.int32] * 3 + [bytes] * (1 + self.num_slices)
+
     def _models(self, compression):
         em_z = entropy_models.ContinuousBatchedEntropyModel(
             self.hyperprior, coding_rank=3, compression=compression, offset_heuristic=False,
@@ -218,3 +224,10 @@ class MS2020Model(torch.nn.Module):
             y_hat_slices.append(self._lrp(k, mean_support, y_hat_slice))
         x_hat = self.synthesis_transform(torch.cat(y_hat_slices, dim=-1))[:, :x_shape[0], :x_shape[1], :]
         return torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+
+
+if __name__ == "__main__":      # python -m compression_amd.models.ms2020 compress in.png out.tfci
+    import sys
+
+    from .codec_io import main
+    sys.exit(main(MS2020Model))

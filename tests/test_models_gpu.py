@@ -99,25 +99,33 @@ def test_training_forward_runs():
     assert torch.isfinite(loss) and bpp > 0 and mse >= 0
 
 
-@pytest.mark.parametrize("which", ["bls2017", "bmshj2018"])
+@pytest.mark.parametrize("which", ["bls2017", "bmshj2018", "ms2020"])
 def test_tfci_file_round_trip(which, tmp_path):
-    """PNG -> .tfci -> PNG through the file helpers (bls2017.py:273-323): the container parses
-    back to exactly the tensors compress() produced and decodes to the same image."""
+    """PNG -> .tfci -> PNG through the file helpers (bls2017.py:273-323, ms2020.py:520-568): the container
+    parses back to exactly the tensors compress() produced, in compress()'s order, and decodes to the same
+    image."""
     from compression_amd import PackedTensors, models, synthetic
+    from compression_amd.models import codec_io
     torch.manual_seed(0)
-    model = (models.BLS2017Model(num_filters=64) if which == "bls2017"
-             else models.BMSHJ2018Model(num_filters=64)).cuda().init_compression()
+    model = {"bls2017": lambda: models.BLS2017Model(num_filters=64),
+             "bmshj2018": lambda: models.BMSHJ2018Model(num_filters=64),
+             "ms2020": lambda: models.MS2020Model(num_filters=64, latent_depth=64, hyperprior_depth=32,
+                                                  num_slices=2, max_support_slices=1)}[which]()
+    model = model.cuda().init_compression()
     img = torch.from_numpy(synthetic.lowpass_images(1, 96, 80, seed=5)[0])
     models.write_png(tmp_path / "in.png", img)
     assert torch.equal(models.read_png(tmp_path / "in.png"), img)
     data = models.compress_file(model, tmp_path / "in.png", tmp_path / "out.tfci")
     direct = model.compress(img.cuda())
-    ns = model.num_strings
-    unpacked = PackedTensors(data).unpack([bytes] * ns + [np.int32] * (model.num_packed - ns))
-    for got, want in zip(unpacked[:ns], direct[:ns]):
-        assert [bytes(b) for b in got] == [bytes(b) for b in np.asarray(want, dtype=object).reshape(-1)]
-    for got, want in zip(unpacked[ns:], direct[ns:]):
-        assert tuple(got.tolist()) == tuple(want)
+    dtypes = codec_io.container_dtypes(model)
+    assert len(dtypes) == len(direct)
+    if which == "ms2020":
+        assert dtypes == [np.int32] * 3 + [bytes] * 3
+    for got, want, dtype in zip(PackedTensors(data).unpack(dtypes), direct, dtypes):
+        if dtype is bytes:
+            assert [bytes(b) for b in got] == [bytes(b) for b in np.asarray(want, dtype=object).reshape(-1)]
+        else:
+            assert tuple(got.tolist()) == tuple(want)
     x_hat = models.decompress_file(model, tmp_path / "out.tfci", tmp_path / "rec.png")
     assert torch.equal(x_hat.cpu(), model.decompress(*direct)[0].cpu())
     assert torch.equal(models.read_png(tmp_path / "rec.png"), x_hat.cpu())
