@@ -80,6 +80,12 @@ SIGNATURES = {
     "tfc_noisy_normal_bits_backward": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "tfc_factorized_bits_backward_expected": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp,
                                                      _vp, _vp]),
+    "tfc_factorized_bits_forward_tail": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _int, _int, C.c_float,
+                                                _vp, _vp, _vp]),
+    "tfc_factorized_bits_backward_tail": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _int, _int, C.c_float, _vp,
+                                                 _vp, _vp, _vp]),
+    "tfc_noisy_normal_bits_forward_tail": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, C.c_float, _vp, _vp]),
+    "tfc_noisy_normal_bits_backward_tail": (_int, [_vp, _vp, _vp, _int, _i64, _i64, C.c_float, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

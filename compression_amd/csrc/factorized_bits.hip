@@ -4,6 +4,7 @@
 //   c = sigmoid(logits), logits = the deep factorized per-channel monotone MLP
 //                                                        (python/distributions/deep_factorized.py:166-194)
 //   bits[unit] = - sum_unit log p / ln 2                 (python/entropy_models/continuous_batched.py:291-322)
+// optionally with the Laplace-mixture tail of continuous_base.py:298-334 (the *_tail entry points, laplace_tail.h).
 // The reference runs this as a few dozen TF kernels over the whole latent tensor; here it is one
 // forward kernel (y, u -> y_hat, per-block partial sums of log p) and one backward kernel
 // (y_hat, dL/dbits -> dL/dy_hat and per-channel gradients of the reparameterised MLP weights,
@@ -22,6 +23,7 @@
 
 #include "../../include/tfc_hip.h"
 #include "common.h"
+#include "laplace_tail.h"
 #include "reduce_rows.h"
 
 namespace tfc {
@@ -117,6 +119,7 @@ struct BitsParams {
   const float* gbits;           // [units]
   void* dy;
   float* dpartial;              // [total blocks][channels][P]
+  float tail_mass;              // Laplace-mixture tail (laplace_tail.h); 0 = none
 };
 
 // A block owns a strided set of `threads`-element rows of one unit: thread t always sees channel
@@ -143,7 +146,8 @@ __global__ void __launch_bounds__(512) factorized_forward_kernel(BitsParams p) {
     v = load_as_float(yh, e);                       // the value later passes see (dtype-rounded)
     const float up = mlp_forward<K, W, false>(prm, v + 0.5f, nullptr, nullptr);
     const float lo = mlp_forward<K, W, false>(prm, v - 0.5f, nullptr, nullptr);
-    const float lp = log_interval(up, lo);
+    float lp = log_interval(up, lo);
+    if (p.tail_mass > 0.f) lp = tail_mix(lp, v, p.tail_mass);
     if (p.log_prob) p.log_prob[unit * p.elems + e] = lp;
     acc += lp;
   }
@@ -169,11 +173,13 @@ __global__ void factorized_bits_reduce_kernel(const float* partial, int blocks_p
   bits[u] = s * -1.4426950408889634f;          // / -ln 2
 }
 
-// d log_interval / d(upper, lower):  sigma'(u) / prob,  -sigma'(l) / prob
-__device__ inline void log_interval_grad(float upper, float lower, float* gu, float* gl) {
-  const bool right = upper > 0.f;
-  const float prob = right ? sigmoid(-lower) - sigmoid(-upper) : sigmoid(upper) - sigmoid(lower);
-  const float inv = 1.f / prob;
+// c(upper) - c(lower), on the side of the median where it does not cancel
+__device__ inline float interval_prob(float upper, float lower) {
+  return upper > 0.f ? sigmoid(-lower) - sigmoid(-upper) : sigmoid(upper) - sigmoid(lower);
+}
+// d log_interval / d(upper, lower) = sigma'(u) * inv, -sigma'(l) * inv with inv = 1 / prob
+// (with a Laplace tail: inv = (1 - m) / mixture, laplace_tail.h)
+__device__ inline void log_interval_grad(float upper, float lower, float inv, float* gu, float* gl) {
   *gu = sigmoid(upper) * sigmoid(-upper) * inv;
   *gl = -sigmoid(lower) * sigmoid(-lower) * inv;
 }
@@ -229,8 +235,11 @@ __device__ inline float mlp_backward(const float* p, float z, float gout, float*
   return dz;
 }
 
-template <typename T, int K, int W>
-__global__ void __launch_bounds__(512) factorized_backward_kernel(BitsParams p) {
+// MAXT: the block-size bound the kernel is compiled for.  The wider MLPs keep ~2 x 56 parameter registers plus
+// the activations of two cumulatives: within the 256 registers a 512-thread block allows they spill (300 / 650
+// bytes per lane), within the 512 of a <= 256-thread block they do not.
+template <typename T, int K, int W, int MAXT>
+__global__ void __launch_bounds__(MAXT) factorized_backward_kernel(BitsParams p) {
   using L = MlpLayout<K, W>;
   const int t = threadIdx.x;
   const long long unit = blockIdx.x / p.blocks_per_unit;
@@ -248,9 +257,17 @@ __global__ void __launch_bounds__(512) factorized_backward_kernel(BitsParams p) 
     const float v = load_as_float(yh, e);
     const float up = mlp_forward<K, W, false>(prm, v + 0.5f, nullptr, nullptr);
     const float lo = mlp_forward<K, W, false>(prm, v - 0.5f, nullptr, nullptr);
+    const float prob = interval_prob(up, lo);
+    float inv = 1.f / prob, direct = 0.f;
+    if (p.tail_mass > 0.f) {
+      const TailGrad tg = tail_mix_grad(prob, v, p.tail_mass);
+      inv = tg.prior;
+      direct = tg.direct;
+    }
     float gu, gl;
-    log_interval_grad(up, lo, &gu, &gl);
+    log_interval_grad(up, lo, inv, &gu, &gl);
     float dz = mlp_backward<K, W>(prm, v + 0.5f, g * gu, dprm) + mlp_backward<K, W>(prm, v - 0.5f, g * gl, dprm);
+    dz = fmaf(g, direct, dz);
     if (yin) {
       // expected gradients (math_ops.py:157-216, perturb_and_apply(expected_grads=True)): the derivative
       // w.r.t. the input is E_u[d log p / dx] = log p(x + .5) - log p(x - .5) at the UNPERTURBED x, i.e.
@@ -259,7 +276,12 @@ __global__ void __launch_bounds__(512) factorized_backward_kernel(BitsParams p) 
       const float c1 = mlp_forward<K, W, false>(prm, x + 1.f, nullptr, nullptr);
       const float c0 = mlp_forward<K, W, false>(prm, x, nullptr, nullptr);
       const float cm = mlp_forward<K, W, false>(prm, x - 1.f, nullptr, nullptr);
-      dz = g * (log_interval(c1, c0) - log_interval(c0, cm));
+      float hi = log_interval(c1, c0), low = log_interval(c0, cm);
+      if (p.tail_mass > 0.f) {
+        hi = tail_mix(hi, x + 0.5f, p.tail_mass);
+        low = tail_mix(low, x - 0.5f, p.tail_mass);
+      }
+      dz = g * (hi - low);
     }
     store_from_float(dy, e, dz);
   }
@@ -321,10 +343,17 @@ int run_backward(BitsParams p, float* dparams, hipStream_t st) {
   const size_t lds = sizeof(float) * p.threads * L::kParams;
   {
     KernelTimer timer("factorized_backward", st);
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&factorized_backward_kernel<T, K, W>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((factorized_backward_kernel<T, K, W>), dim3(static_cast<unsigned>(blocks)), dim3(p.threads),
-                       lds, st, p);
+    if (p.threads <= 256) {
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&factorized_backward_kernel<T, K, W, 256>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL((factorized_backward_kernel<T, K, W, 256>), dim3(static_cast<unsigned>(blocks)),
+                         dim3(p.threads), lds, st, p);
+    } else {
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&factorized_backward_kernel<T, K, W, 512>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL((factorized_backward_kernel<T, K, W, 512>), dim3(static_cast<unsigned>(blocks)),
+                         dim3(p.threads), lds, st, p);
+    }
   }
   launch_sum_rows(p.dpartial, blocks, n, n, dparams, st);   // dparams += block partials, fixed order
   TFC_HIP(hipGetLastError());
@@ -347,50 +376,83 @@ int dispatch(int dtype, int layers, int width, const char* who, F32 f32, BF16 bf
   : (layers == 4 && width == 3) ? FN<TT, 4, 3>(__VA_ARGS__)                                       \
                                 : FN<TT, 3, 5>(__VA_ARGS__)
 
-extern "C" int tfc_factorized_bits_forward(const void* y, const void* noise, void* y_hat, int dtype,
-                                           int64_t units, int64_t elems, int64_t channels,
-                                           const float* params, int layers, int width, float* log_prob,
-                                           float* bits, void* stream) {
+namespace {
+int fb_forward(const char* who, const void* y, const void* noise, void* y_hat, int dtype, int64_t units, int64_t elems,
+               int64_t channels, const float* params, int layers, int width, float tail_mass, float* log_prob,
+               float* bits, void* stream) {
   using namespace tfc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (units == 0 || elems == 0) return 0;
   BitsParams p{};
   p.y = y; p.noise = noise; p.y_hat = y_hat; p.units = units; p.elems = elems;
-  p.channels = static_cast<int>(channels); p.params = params; p.log_prob = log_prob;
+  p.channels = static_cast<int>(channels); p.params = params; p.log_prob = log_prob; p.tail_mass = tail_mass;
   if (int rc = plan_blocks(units, elems, p.channels, &p.threads, &p.blocks_per_unit)) return rc;
-  return dispatch(dtype, layers, width, "tfc_factorized_bits_forward",
+  return dispatch(dtype, layers, width, who,
                   [&] { using TT = float; return TFC_FB_SWITCH(run_forward, p, bits, st); },
                   [&] { using TT = __hip_bfloat16; return TFC_FB_SWITCH(run_forward, p, bits, st); });
+}
+
+// y non-null: expected gradients (the unperturbed input)
+int fb_backward(const char* who, const void* y, const void* y_hat, int dtype, int64_t units, int64_t elems,
+                int64_t channels, const float* params, int layers, int width, float tail_mass, const float* gbits,
+                void* dy, float* dparams, void* stream) {
+  using namespace tfc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (units == 0 || elems == 0) return 0;
+  BitsParams p{};
+  p.y = y; p.y_hat = const_cast<void*>(y_hat); p.units = units; p.elems = elems;
+  p.channels = static_cast<int>(channels); p.params = params; p.gbits = gbits; p.dy = dy; p.tail_mass = tail_mass;
+  if (int rc = plan_blocks(units, elems, p.channels, &p.threads, &p.blocks_per_unit)) return rc;
+  return dispatch(dtype, layers, width, who,
+                  [&] { using TT = float; return TFC_FB_SWITCH(run_backward, p, dparams, st); },
+                  [&] { using TT = __hip_bfloat16; return TFC_FB_SWITCH(run_backward, p, dparams, st); });
+}
+}  // namespace
+
+extern "C" int tfc_factorized_bits_forward(const void* y, const void* noise, void* y_hat, int dtype,
+                                           int64_t units, int64_t elems, int64_t channels,
+                                           const float* params, int layers, int width, float* log_prob,
+                                           float* bits, void* stream) {
+  return fb_forward("tfc_factorized_bits_forward", y, noise, y_hat, dtype, units, elems, channels, params, layers,
+                    width, 0.f, log_prob, bits, stream);
 }
 
 extern "C" int tfc_factorized_bits_backward(const void* y_hat, int dtype, int64_t units, int64_t elems,
                                             int64_t channels, const float* params, int layers, int width,
                                             const float* gbits, void* dy, float* dparams, void* stream) {
-  using namespace tfc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (units == 0 || elems == 0) return 0;
-  BitsParams p{};
-  p.y_hat = const_cast<void*>(y_hat); p.units = units; p.elems = elems;
-  p.channels = static_cast<int>(channels); p.params = params; p.gbits = gbits; p.dy = dy;
-  if (int rc = plan_blocks(units, elems, p.channels, &p.threads, &p.blocks_per_unit)) return rc;
-  return dispatch(dtype, layers, width, "tfc_factorized_bits_backward",
-                  [&] { using TT = float; return TFC_FB_SWITCH(run_backward, p, dparams, st); },
-                  [&] { using TT = __hip_bfloat16; return TFC_FB_SWITCH(run_backward, p, dparams, st); });
+  return fb_backward("tfc_factorized_bits_backward", nullptr, y_hat, dtype, units, elems, channels, params, layers,
+                     width, 0.f, gbits, dy, dparams, stream);
 }
 
 extern "C" int tfc_factorized_bits_backward_expected(const void* y, const void* y_hat, int dtype, int64_t units,
                                                      int64_t elems, int64_t channels, const float* params,
                                                      int layers, int width, const float* gbits, void* dy,
                                                      float* dparams, void* stream) {
-  using namespace tfc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (units == 0 || elems == 0) return 0;
-  if (y == nullptr) return fail("tfc_factorized_bits_backward_expected: the unperturbed input is required");
-  BitsParams p{};
-  p.y = y; p.y_hat = const_cast<void*>(y_hat); p.units = units; p.elems = elems;
-  p.channels = static_cast<int>(channels); p.params = params; p.gbits = gbits; p.dy = dy;
-  if (int rc = plan_blocks(units, elems, p.channels, &p.threads, &p.blocks_per_unit)) return rc;
-  return dispatch(dtype, layers, width, "tfc_factorized_bits_backward_expected",
-                  [&] { using TT = float; return TFC_FB_SWITCH(run_backward, p, dparams, st); },
-                  [&] { using TT = __hip_bfloat16; return TFC_FB_SWITCH(run_backward, p, dparams, st); });
+  if (y == nullptr && units != 0 && elems != 0)
+    return tfc::fail("tfc_factorized_bits_backward_expected: the unperturbed input is required");
+  return fb_backward("tfc_factorized_bits_backward_expected", y, y_hat, dtype, units, elems, channels, params,
+                     layers, width, 0.f, gbits, dy, dparams, stream);
+}
+
+extern "C" int tfc_factorized_bits_forward_tail(const void* y, const void* noise, void* y_hat, int dtype,
+                                                int64_t units, int64_t elems, int64_t channels,
+                                                const float* params, int layers, int width,
+                                                float laplace_tail_mass, float* log_prob, float* bits,
+                                                void* stream) {
+  if (!tfc::tail_mass_ok(laplace_tail_mass))
+    return tfc::fail("tfc_factorized_bits_forward_tail: laplace_tail_mass must be in (0, 1) (got %g)",
+                     static_cast<double>(laplace_tail_mass));
+  return fb_forward("tfc_factorized_bits_forward_tail", y, noise, y_hat, dtype, units, elems, channels, params,
+                    layers, width, laplace_tail_mass, log_prob, bits, stream);
+}
+
+extern "C" int tfc_factorized_bits_backward_tail(const void* y, const void* y_hat, int dtype, int64_t units,
+                                                 int64_t elems, int64_t channels, const float* params, int layers,
+                                                 int width, float laplace_tail_mass, const float* gbits, void* dy,
+                                                 float* dparams, void* stream) {
+  if (!tfc::tail_mass_ok(laplace_tail_mass))
+    return tfc::fail("tfc_factorized_bits_backward_tail: laplace_tail_mass must be in (0, 1) (got %g)",
+                     static_cast<double>(laplace_tail_mass));
+  return fb_backward("tfc_factorized_bits_backward_tail", y, y_hat, dtype, units, elems, channels, params, layers,
+                     width, laplace_tail_mass, gbits, dy, dparams, stream);
 }

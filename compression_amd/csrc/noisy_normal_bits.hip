@@ -13,11 +13,14 @@
 // Numerics follow the reference's op order: the difference of the two cumulatives is taken on the side of
 // the median where it does not cancel (survival functions right of it), in log space; log Phi as torch /
 // TF do it: log(erfcx(-z / sqrt 2) / 2) - z^2 / 2 for z < -1, log1p(-erfc(z / sqrt 2) / 2) otherwise.
+// The *_tail entry points add the Laplace-mixture tail of continuous_base.py:298-334 (laplace_tail.h); the
+// Laplace component sits at 0, so they are for priors whose location the caller has already subtracted.
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 
 #include "../../include/tfc_hip.h"
 #include "common.h"
+#include "laplace_tail.h"
 
 namespace tfc {
 namespace {
@@ -57,6 +60,7 @@ struct NnParams {
   void* dy;
   float* dscale;
   const void* y_in;          // expected gradients: the unperturbed input (else null)
+  float tail_mass;           // Laplace-mixture tail; 0 = none
 };
 
 constexpr int kThreads = 256;
@@ -78,7 +82,9 @@ __global__ void __launch_bounds__(kThreads) noisy_normal_forward_kernel(NnParams
     st(yh, e, v);
     v = ld(yh, e);                                    // the value later passes see (dtype-rounded)
     const float inv = 1.f / sc[e];
-    acc += log_interval_normal((v + 0.5f) * inv, (v - 0.5f) * inv);
+    float lp = log_interval_normal((v + 0.5f) * inv, (v - 0.5f) * inv);
+    if (p.tail_mass > 0.f) lp = tail_mix(lp, v, p.tail_mass);
+    acc += lp;
   }
   __shared__ float wsum[kThreads / 64];
 #pragma unroll
@@ -117,14 +123,28 @@ __global__ void __launch_bounds__(kThreads) noisy_normal_backward_kernel(NnParam
     const float zu = (v + 0.5f) * inv, zl = (v - 0.5f) * inv;
     const float lp = log_interval_normal(zu, zl);
     // d lp / d zu = phi(zu) / P, d lp / d zl = -phi(zl) / P, with P = exp(lp): ratios in log space
-    const float gu = __expf(-0.5f * zu * zu - kLogSqrt2Pi - lp);
-    const float gl = -__expf(-0.5f * zl * zl - kLogSqrt2Pi - lp);
-    float dv = g * (gu + gl) * inv;
+    float gu, gl, direct = 0.f;
+    if (p.tail_mass > 0.f) {
+      // d log(mixture) = (1 - m) dP / mixture + m dQ / mixture  (or d log Q where the mixture is below 1e-10)
+      const TailGrad tg = tail_mix_grad(__expf(lp), v, p.tail_mass);
+      gu = __expf(-0.5f * zu * zu - kLogSqrt2Pi) * tg.prior;
+      gl = -__expf(-0.5f * zl * zl - kLogSqrt2Pi) * tg.prior;
+      direct = tg.direct;
+    } else {
+      gu = __expf(-0.5f * zu * zu - kLogSqrt2Pi - lp);
+      gl = -__expf(-0.5f * zl * zl - kLogSqrt2Pi - lp);
+    }
+    float dv = g * fmaf(gu + gl, inv, direct);
     ds[e] = -g * (gu * zu + gl * zl) * inv;
     if (yin) {
       // expected gradients (math_ops.py:157-216): log p(x + .5) - log p(x - .5) at the unperturbed x
       const float x = ld(yin, e);
-      dv = g * (log_interval_normal((x + 1.f) * inv, x * inv) - log_interval_normal(x * inv, (x - 1.f) * inv));
+      float hi = log_interval_normal((x + 1.f) * inv, x * inv), low = log_interval_normal(x * inv, (x - 1.f) * inv);
+      if (p.tail_mass > 0.f) {
+        hi = tail_mix(hi, x + 0.5f, p.tail_mass);
+        low = tail_mix(low, x - 0.5f, p.tail_mass);
+      }
+      dv = g * (hi - low);
     }
     st(dy, e, dv);
   }
@@ -144,14 +164,16 @@ int plan(long long units, long long elems, int* blocks_per_unit) {
 }  // namespace
 }  // namespace tfc
 
-extern "C" int tfc_noisy_normal_bits_forward(const void* y, const void* noise, const float* scale, void* y_hat,
-                                             int dtype, int64_t units, int64_t elems, float* bits, void* stream) {
+namespace {
+int nn_forward(const char* who, const void* y, const void* noise, const float* scale, void* y_hat, int dtype,
+               int64_t units, int64_t elems, float tail_mass, float* bits, void* stream) {
   using namespace tfc;
-  if (dtype != 0 && dtype != 1) return fail("tfc_noisy_normal_bits_forward: dtype must be 0 (float32) or 1 (bfloat16)");
+  if (dtype != 0 && dtype != 1) return fail("%s: dtype must be 0 (float32) or 1 (bfloat16)", who);
   if (units == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   NnParams p{};
   p.y = y; p.noise = noise; p.scale = scale; p.y_hat = y_hat; p.units = units; p.elems = elems;
+  p.tail_mass = tail_mass;
   if (int rc = plan(units, elems, &p.blocks_per_unit)) return rc;
   DevBuf partial;
   TFC_HIP(partial.alloc(sizeof(float) * units * p.blocks_per_unit, st));
@@ -168,16 +190,15 @@ extern "C" int tfc_noisy_normal_bits_forward(const void* y, const void* noise, c
   return 0;
 }
 
-extern "C" int tfc_noisy_normal_bits_backward(const void* y_in, const void* y_hat, const float* scale, int dtype,
-                                              int64_t units, int64_t elems, const float* gbits, void* dy,
-                                              float* dscale, void* stream) {
+int nn_backward(const char* who, const void* y_in, const void* y_hat, const float* scale, int dtype, int64_t units,
+                int64_t elems, float tail_mass, const float* gbits, void* dy, float* dscale, void* stream) {
   using namespace tfc;
-  if (dtype != 0 && dtype != 1) return fail("tfc_noisy_normal_bits_backward: dtype must be 0 (float32) or 1 (bfloat16)");
+  if (dtype != 0 && dtype != 1) return fail("%s: dtype must be 0 (float32) or 1 (bfloat16)", who);
   if (units == 0 || elems == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   NnParams p{};
   p.y_in = y_in; p.y_hat = const_cast<void*>(y_hat); p.scale = scale; p.units = units; p.elems = elems;
-  p.gbits = gbits; p.dy = dy; p.dscale = dscale;
+  p.gbits = gbits; p.dy = dy; p.dscale = dscale; p.tail_mass = tail_mass;
   if (int rc = plan(units, elems, &p.blocks_per_unit)) return rc;
   KernelTimer timer("noisy_normal_backward", st);
   const dim3 grid(static_cast<unsigned>(units * p.blocks_per_unit));
@@ -185,4 +206,37 @@ extern "C" int tfc_noisy_normal_bits_backward(const void* y_in, const void* y_ha
   else hipLaunchKernelGGL(noisy_normal_backward_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st, p);
   TFC_HIP(hipGetLastError());
   return 0;
+}
+}  // namespace
+
+extern "C" int tfc_noisy_normal_bits_forward(const void* y, const void* noise, const float* scale, void* y_hat,
+                                             int dtype, int64_t units, int64_t elems, float* bits, void* stream) {
+  return nn_forward("tfc_noisy_normal_bits_forward", y, noise, scale, y_hat, dtype, units, elems, 0.f, bits, stream);
+}
+
+extern "C" int tfc_noisy_normal_bits_backward(const void* y_in, const void* y_hat, const float* scale, int dtype,
+                                              int64_t units, int64_t elems, const float* gbits, void* dy,
+                                              float* dscale, void* stream) {
+  return nn_backward("tfc_noisy_normal_bits_backward", y_in, y_hat, scale, dtype, units, elems, 0.f, gbits, dy,
+                     dscale, stream);
+}
+
+extern "C" int tfc_noisy_normal_bits_forward_tail(const void* y, const void* noise, const float* scale, void* y_hat,
+                                                  int dtype, int64_t units, int64_t elems, float laplace_tail_mass,
+                                                  float* bits, void* stream) {
+  if (!tfc::tail_mass_ok(laplace_tail_mass))
+    return tfc::fail("tfc_noisy_normal_bits_forward_tail: laplace_tail_mass must be in (0, 1) (got %g)",
+                     static_cast<double>(laplace_tail_mass));
+  return nn_forward("tfc_noisy_normal_bits_forward_tail", y, noise, scale, y_hat, dtype, units, elems,
+                    laplace_tail_mass, bits, stream);
+}
+
+extern "C" int tfc_noisy_normal_bits_backward_tail(const void* y_in, const void* y_hat, const float* scale, int dtype,
+                                                   int64_t units, int64_t elems, float laplace_tail_mass,
+                                                   const float* gbits, void* dy, float* dscale, void* stream) {
+  if (!tfc::tail_mass_ok(laplace_tail_mass))
+    return tfc::fail("tfc_noisy_normal_bits_backward_tail: laplace_tail_mass must be in (0, 1) (got %g)",
+                     static_cast<double>(laplace_tail_mass));
+  return nn_backward("tfc_noisy_normal_bits_backward_tail", y_in, y_hat, scale, dtype, units, elems,
+                     laplace_tail_mass, gbits, dy, dscale, stream);
 }

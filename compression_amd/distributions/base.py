@@ -116,9 +116,17 @@ class Laplace(_LocScale):
         z = self._z(x)
         return 0.5 - 0.5 * torch.sign(z) * torch.expm1(-torch.abs(z))
 
-    def _survival_function(self, x):
-        z = self._z(x)
-        return 0.5 + 0.5 * torch.sign(z) * torch.expm1(-torch.abs(z))
+    # log cdf / log survival function without cancellation, as the reference's Laplace (tfp) has them:
+    # z < 0: log(exp(z) / 2) = z - log 2 exactly; z >= 0: log1p(-exp(-z) / 2).  The survival function is the
+    # exponential of its log (tfp derives it that way), so the right tail keeps its relative accuracy; the
+    # Laplace-mixture tail of continuous_base.py:298-334 is evaluated out there.
+    @staticmethod
+    def _log_cdf_z(z):
+        return torch.where(z < 0, z - math.log(2.0), torch.log1p(-0.5 * torch.exp(-torch.abs(z))))
+
+    def _log_cdf(self, x): return self._log_cdf_z(self._z(x))
+    def _log_survival_function(self, x): return self._log_cdf_z(-self._z(x))
+    def _survival_function(self, x): return torch.exp(self._log_survival_function(x))
 
     def _quantile(self, q):
         return self.loc.to(q.device) - self.scale.to(q.device) * torch.sign(q - 0.5) * torch.log1p(

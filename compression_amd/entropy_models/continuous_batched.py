@@ -89,14 +89,15 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         """(bottleneck_perturbed, bits) — continuous_batched.py:291-322."""
         bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
         base = getattr(self.prior, "base", None)
-        ltm = self.laplace_tail_mass
-        if (training and not torch.is_tensor(ltm) and ltm == 0
+        ltm = bottleneck_ops.fused_tail_mass(self.laplace_tail_mass)
+        if (training and ltm is not None
                 and bottleneck_ops.fused_factorized_supported(base, bottleneck, self.coding_rank)):
-            # one fused HIP kernel each way: noise add + likelihood + bits (csrc/factorized_bits.hip);
-            # expected_grads selects the backward kernel's finite-difference input gradient
+            # one fused HIP kernel each way: noise add + likelihood (with the Laplace-mixture tail if the model
+            # has one) + bits (csrc/factorized_bits.hip); expected_grads selects the backward kernel's
+            # finite-difference input gradient
             noise = torch.rand_like(bottleneck) - 0.5
             return bottleneck_ops.factorized_bits(bottleneck, base, self.coding_rank, noise,
-                                                  expected_grads=self.expected_grads)
+                                                  expected_grads=self.expected_grads, laplace_tail_mass=ltm)
         log_prob_fn = functools.partial(self._log_prob, self.prior)
         if training:
             log_probs, perturbed = math_ops.perturb_and_apply(

@@ -89,18 +89,24 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
     def forward(self, bottleneck, indexes, training=True):
         bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
         indexes = self._normalize_indexes(torch.as_tensor(indexes))
-        ltm = self.laplace_tail_mass
-        if (training and not torch.is_tensor(ltm) and ltm == 0 and bottleneck_ops.fused_noisy_normal_supported(
-                self.prior_fn, self.parameter_fns, bottleneck, self.coding_rank)):
-            # NoisyNormal(loc, scale_fn(indexes)): one fused HIP kernel each way (csrc/noisy_normal_bits.hip);
-            # the parameter functions stay differentiable tensor ops, their gradients flow through `scale`
+        ltm = bottleneck_ops.fused_tail_mass(self.laplace_tail_mass)
+        fused = training and ltm is not None and bottleneck_ops.fused_noisy_normal_supported(
+            self.prior_fn, self.parameter_fns, bottleneck, self.coding_rank)
+        if fused:
             idx = indexes.to(self.prior_dtype)
             loc = self.parameter_fns["loc"](idx)
+            # the Laplace component of the tail mixture sits at 0 of the UNSHIFTED bottleneck
+            # (continuous_base.py:298-334): the kernel, which sees the shifted one, takes it only for loc == 0
+            fused = ltm == 0 or not (torch.is_tensor(loc) or loc != 0)
+        if fused:
+            # NoisyNormal(loc, scale_fn(indexes)): one fused HIP kernel each way (csrc/noisy_normal_bits.hip);
+            # the parameter functions stay differentiable tensor ops, their gradients flow through `scale`
             scale = torch.as_tensor(self.parameter_fns["scale"](idx), dtype=self.prior_dtype, device=bottleneck.device)
             shifted = bottleneck - loc if (torch.is_tensor(loc) or loc != 0) else bottleneck
             noise = torch.rand_like(bottleneck) - 0.5
             perturbed, bits = bottleneck_ops.noisy_normal_bits(shifted, scale, self.coding_rank, noise,
-                                                               expected_grads=self.expected_grads)
+                                                               expected_grads=self.expected_grads,
+                                                               laplace_tail_mass=ltm)
             if torch.is_tensor(loc) or loc != 0:
                 perturbed = perturbed + loc
             return perturbed, bits

@@ -7,7 +7,7 @@ import torch
 
 from .. import _lib
 
-__all__ = ["factorized_bits", "pack_factorized_params", "fused_factorized_supported"]
+__all__ = ["factorized_bits", "pack_factorized_params", "fused_factorized_supported", "fused_tail_mass"]
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 _BUILT = {(3, 3), (4, 3), (3, 5)}          # (layers, width) the library instantiates
@@ -44,31 +44,43 @@ def pack_factorized_params(base) -> torch.Tensor:
 
 class _FactorizedBits(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, noise, params, layers, width, units, elems, expected_grads=False):
+    def forward(ctx, y, noise, params, layers, width, units, elems, expected_grads=False, tail_mass=0.0):
         _lib.require_device()
         y = y.contiguous()
         y_hat = torch.empty_like(y)
         bits = torch.empty(units, dtype=torch.float32, device=y.device)
         channels = params.shape[0]
-        _lib.check(_lib.lib().tfc_factorized_bits_forward(
-            y.data_ptr(), noise.data_ptr() if noise is not None else None, y_hat.data_ptr(),
-            _DTYPE_CODE[y.dtype], units, elems, channels, params.data_ptr(), layers, width, None,
-            bits.data_ptr(), _lib.stream_ptr()))
+        noise_ptr = noise.data_ptr() if noise is not None else None
+        if tail_mass:
+            _lib.check(_lib.lib().tfc_factorized_bits_forward_tail(
+                y.data_ptr(), noise_ptr, y_hat.data_ptr(), _DTYPE_CODE[y.dtype], units, elems, channels,
+                params.data_ptr(), layers, width, tail_mass, None, bits.data_ptr(), _lib.stream_ptr()))
+        else:
+            _lib.check(_lib.lib().tfc_factorized_bits_forward(
+                y.data_ptr(), noise_ptr, y_hat.data_ptr(), _DTYPE_CODE[y.dtype], units, elems, channels,
+                params.data_ptr(), layers, width, None, bits.data_ptr(), _lib.stream_ptr()))
         if expected_grads:
             ctx.save_for_backward(y_hat, params, y)
         else:
             ctx.save_for_backward(y_hat, params)
-        ctx.meta = (layers, width, units, elems)
+        ctx.meta = (layers, width, units, elems, tail_mass)
         return y_hat, bits
 
     @staticmethod
     def backward(ctx, g_yhat, g_bits):
         y_hat, params = ctx.saved_tensors[:2]
-        layers, width, units, elems = ctx.meta
+        layers, width, units, elems, tail_mass = ctx.meta
         dy = torch.empty_like(y_hat)
         dparams = torch.zeros_like(params)
         gb = (g_bits if g_bits is not None else torch.zeros(units, device=y_hat.device)).to(torch.float32).contiguous()
-        if len(ctx.saved_tensors) == 3:
+        if tail_mass:
+            # Laplace-mixture tail (continuous_base.py:298-334); the unperturbed input selects expected gradients
+            y = ctx.saved_tensors[2] if len(ctx.saved_tensors) == 3 else None
+            _lib.check(_lib.lib().tfc_factorized_bits_backward_tail(
+                y.data_ptr() if y is not None else None, y_hat.data_ptr(), _DTYPE_CODE[y_hat.dtype], units, elems,
+                params.shape[0], params.data_ptr(), layers, width, tail_mass, gb.data_ptr(), dy.data_ptr(),
+                dparams.data_ptr(), _lib.stream_ptr()))
+        elif len(ctx.saved_tensors) == 3:
             # expected gradients (math_ops.py:157-216): d/dy through the likelihood is the finite difference
             # of log p at y +- .5, evaluated at the unperturbed input
             y = ctx.saved_tensors[2]
@@ -82,13 +94,23 @@ class _FactorizedBits(torch.autograd.Function):
                 layers, width, gb.data_ptr(), dy.data_ptr(), dparams.data_ptr(), _lib.stream_ptr()))
         if g_yhat is not None:
             dy = dy + g_yhat
-        return dy, None, dparams, None, None, None, None, None
+        return dy, None, dparams, None, None, None, None, None, None
 
 
-def factorized_bits(bottleneck, base, coding_rank, noise=None, expected_grads=False):
+def fused_tail_mass(laplace_tail_mass):
+    """The entropy models' `laplace_tail_mass` as the kernels take it: 0.0 (none) or a float in (0, 1); None if
+    the fused kernels cannot take it (a tensor — possibly learned — or out of range)."""
+    if torch.is_tensor(laplace_tail_mass):
+        return None
+    m = float(laplace_tail_mass)
+    return m if 0.0 <= m < 1.0 else None
+
+
+def factorized_bits(bottleneck, base, coding_rank, noise=None, expected_grads=False, laplace_tail_mass=0.0):
     """(y_hat, bits): y_hat = bottleneck + noise (noise None: bottleneck itself), bits summed over
     the last `coding_rank` dimensions, shape = the leading dimensions.  expected_grads: the gradient of
-    bits w.r.t. the bottleneck is the expectation over the noise (math_ops.py:157-216)."""
+    bits w.r.t. the bottleneck is the expectation over the noise (math_ops.py:157-216).  laplace_tail_mass:
+    the likelihood is the mixture with a NoisyLaplace(0, 1) of continuous_base.py:298-334."""
     lead = bottleneck.shape[:bottleneck.dim() - coding_rank]
     units = 1
     for s in lead:
@@ -98,46 +120,59 @@ def factorized_bits(bottleneck, base, coding_rank, noise=None, expected_grads=Fa
     if noise is not None:
         noise = noise.to(bottleneck.dtype).contiguous()
     y_hat, bits = _FactorizedBits.apply(bottleneck, noise, params, len(base.num_filters) + 1,
-                                        int(base.num_filters[0]), units, elems, bool(expected_grads))
+                                        int(base.num_filters[0]), units, elems, bool(expected_grads),
+                                        float(laplace_tail_mass))
     return y_hat, bits.reshape(lead)
 
 
 class _NoisyNormalBits(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, noise, scale, units, elems, expected_grads):
+    def forward(ctx, y, noise, scale, units, elems, expected_grads, tail_mass=0.0):
         _lib.require_device()
         y = y.contiguous()
         scale = scale.to(torch.float32).contiguous()
         y_hat = torch.empty_like(y)
         bits = torch.empty(units, dtype=torch.float32, device=y.device)
-        _lib.check(_lib.lib().tfc_noisy_normal_bits_forward(
-            y.data_ptr(), noise.data_ptr() if noise is not None else None, scale.data_ptr(), y_hat.data_ptr(),
-            _DTYPE_CODE[y.dtype], units, elems, bits.data_ptr(), _lib.stream_ptr()))
+        noise_ptr = noise.data_ptr() if noise is not None else None
+        if tail_mass:
+            _lib.check(_lib.lib().tfc_noisy_normal_bits_forward_tail(
+                y.data_ptr(), noise_ptr, scale.data_ptr(), y_hat.data_ptr(), _DTYPE_CODE[y.dtype], units, elems,
+                tail_mass, bits.data_ptr(), _lib.stream_ptr()))
+        else:
+            _lib.check(_lib.lib().tfc_noisy_normal_bits_forward(
+                y.data_ptr(), noise_ptr, scale.data_ptr(), y_hat.data_ptr(), _DTYPE_CODE[y.dtype], units, elems,
+                bits.data_ptr(), _lib.stream_ptr()))
         ctx.save_for_backward(*((y_hat, scale, y) if expected_grads else (y_hat, scale)))
-        ctx.meta = (units, elems)
+        ctx.meta = (units, elems, tail_mass)
         return y_hat, bits
 
     @staticmethod
     def backward(ctx, g_yhat, g_bits):
         y_hat, scale = ctx.saved_tensors[:2]
         y_in = ctx.saved_tensors[2] if len(ctx.saved_tensors) == 3 else None
-        units, elems = ctx.meta
+        units, elems, tail_mass = ctx.meta
         dy = torch.empty_like(y_hat)
         dscale = torch.empty_like(scale)
         gb = (g_bits if g_bits is not None else torch.zeros(units, device=y_hat.device)).to(torch.float32).contiguous()
-        _lib.check(_lib.lib().tfc_noisy_normal_bits_backward(
-            y_in.data_ptr() if y_in is not None else None, y_hat.data_ptr(), scale.data_ptr(),
-            _DTYPE_CODE[y_hat.dtype], units, elems, gb.data_ptr(), dy.data_ptr(), dscale.data_ptr(),
-            _lib.stream_ptr()))
+        y_in_ptr = y_in.data_ptr() if y_in is not None else None
+        if tail_mass:
+            _lib.check(_lib.lib().tfc_noisy_normal_bits_backward_tail(
+                y_in_ptr, y_hat.data_ptr(), scale.data_ptr(), _DTYPE_CODE[y_hat.dtype], units, elems, tail_mass,
+                gb.data_ptr(), dy.data_ptr(), dscale.data_ptr(), _lib.stream_ptr()))
+        else:
+            _lib.check(_lib.lib().tfc_noisy_normal_bits_backward(
+                y_in_ptr, y_hat.data_ptr(), scale.data_ptr(), _DTYPE_CODE[y_hat.dtype], units, elems,
+                gb.data_ptr(), dy.data_ptr(), dscale.data_ptr(), _lib.stream_ptr()))
         if g_yhat is not None:
             dy = dy + g_yhat
-        return dy, None, dscale, None, None, None
+        return dy, None, dscale, None, None, None, None
 
 
-def noisy_normal_bits(bottleneck, scale, coding_rank, noise=None, expected_grads=False):
+def noisy_normal_bits(bottleneck, scale, coding_rank, noise=None, expected_grads=False, laplace_tail_mass=0.0):
     """(y_hat, bits) of a NoisyNormal(0, scale) prior, fused (csrc/noisy_normal_bits.hip): y_hat = bottleneck +
     noise, bits summed over the last `coding_rank` dimensions; `scale` broadcastable to the bottleneck's shape
-    and differentiable (gradients flow to whatever produced it, e.g. the hyper-synthesis transform)."""
+    and differentiable (gradients flow to whatever produced it, e.g. the hyper-synthesis transform).
+    laplace_tail_mass: mixture with a NoisyLaplace(0, 1) at the (shifted) bottleneck, continuous_base.py:298-334."""
     lead = bottleneck.shape[:bottleneck.dim() - coding_rank]
     units = 1
     for s in lead:
@@ -146,7 +181,8 @@ def noisy_normal_bits(bottleneck, scale, coding_rank, noise=None, expected_grads
     scale = torch.broadcast_to(scale.to(bottleneck.device), bottleneck.shape)
     if noise is not None:
         noise = noise.to(bottleneck.dtype).contiguous()
-    y_hat, bits = _NoisyNormalBits.apply(bottleneck, noise, scale, units, elems, bool(expected_grads))
+    y_hat, bits = _NoisyNormalBits.apply(bottleneck, noise, scale, units, elems, bool(expected_grads),
+                                         float(laplace_tail_mass))
     return y_hat, bits.reshape(lead)
 
 

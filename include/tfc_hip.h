@@ -409,6 +409,30 @@ int tfc_noisy_normal_bits_backward(const void* y_in, const void* y_hat, const fl
                                    int64_t units, int64_t elems, const float* gbits, void* dy, float* dscale,
                                    void* stream);
 
+/* The four calls above with the Laplace-mixture tail the entropy models take as `laplace_tail_mass`
+ * (python/entropy_models/continuous_base.py:298-334, `_log_prob`): with m = laplace_tail_mass in (0, 1) and
+ * Q = NoisyLaplace(0, 1),
+ *   probs = (1 - m) p(y_hat) + m Q(y_hat);   log p := probs < 1e-10 ? log m + log Q(y_hat) : log probs,
+ * in the likelihood, in its gradients (only the branch the reference's tf.where selects carries one) and in the
+ * finite difference of expected gradients.  Q is evaluated in closed form (csrc/laplace_tail.h): the
+ * reference's float32 difference of Laplace cumulatives loses all its digits beyond |y_hat| ~ 15, exactly where
+ * this branch matters.  The backward calls take the unperturbed input y (y_in) or NULL like
+ * tfc_noisy_normal_bits_backward: non-NULL selects expected gradients.  The Laplace component sits at 0: the
+ * NoisyNormal calls are for a prior whose location the caller has subtracted from y. */
+int tfc_factorized_bits_forward_tail(const void* y, const void* noise, void* y_hat, int dtype, int64_t units,
+                                     int64_t elems, int64_t channels, const float* params, int layers, int width,
+                                     float laplace_tail_mass, float* log_prob, float* bits, void* stream);
+int tfc_factorized_bits_backward_tail(const void* y, const void* y_hat, int dtype, int64_t units, int64_t elems,
+                                      int64_t channels, const float* params, int layers, int width,
+                                      float laplace_tail_mass, const float* gbits, void* dy, float* dparams,
+                                      void* stream);
+int tfc_noisy_normal_bits_forward_tail(const void* y, const void* noise, const float* scale, void* y_hat, int dtype,
+                                       int64_t units, int64_t elems, float laplace_tail_mass, float* bits,
+                                       void* stream);
+int tfc_noisy_normal_bits_backward_tail(const void* y_in, const void* y_hat, const float* scale, int dtype,
+                                        int64_t units, int64_t elems, float laplace_tail_mass, const float* gbits,
+                                        void* dy, float* dscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

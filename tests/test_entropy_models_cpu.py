@@ -148,6 +148,28 @@ def test_noisy_normal_prob_matches_cdf_difference():
     assert torch.allclose(d.log_prob(x).exp(), want, atol=1e-6)
 
 
+def test_noisy_laplace_log_prob_keeps_its_digits_in_the_tails():
+    """The Laplace log cdf / log survival function are evaluated without cancellation (as tfp's, which the
+    reference uses): the unit-interval log mass equals its closed form log(sinh(.5)) - |v| at any distance,
+    in float32 — this is the branch the Laplace-mixture tail (continuous_base.py:298-334) takes far out."""
+    d = tfc.NoisyLaplace(loc=0.0, scale=1.0)
+    v = torch.tensor([-80.0, -30.0, -17.0, -3.0, -0.75, 3.0, 17.0, 30.0, 80.0], requires_grad=True)
+    lp = d.log_prob(v)
+    want = math.log(math.sinh(0.5)) - v.detach().abs()
+    assert torch.allclose(lp, want, rtol=1e-6, atol=1e-6)
+    lp.sum().backward()
+    assert torch.equal(v.grad, -torch.sign(v.detach()))
+    near = torch.linspace(-0.45, 0.45, 7)
+    assert torch.allclose(d.log_prob(near), torch.log(1 - math.exp(-0.5) * torch.cosh(near)), atol=1e-6)
+    # a scaled, shifted one against the float64 cdf difference
+    e = tfc.NoisyLaplace(loc=0.7, scale=torch.tensor([0.3, 2.5]))
+    x = torch.linspace(-12, 12, 25)[:, None]
+    e64 = tfc.NoisyLaplace(loc=0.7, scale=torch.tensor([0.3, 2.5], dtype=torch.float64), dtype=torch.float64)
+    want = torch.log(e64.base.cdf(x.double() + 0.5) - e64.base.cdf(x.double() - 0.5))
+    ok = torch.isfinite(want) & (want > -30)
+    assert torch.allclose(e.log_prob(x).double()[ok], want[ok], rtol=1e-5, atol=1e-5)
+
+
 def test_indexed_model_host_logic():
     em = tfc.LocationScaleIndexedEntropyModel(
         tfc.NoisyNormal, num_scales=8, scale_fn=lambda i: torch.exp(math.log(0.5) + 0.4 * i), coding_rank=1)

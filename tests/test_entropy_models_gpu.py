@@ -406,3 +406,168 @@ def test_fused_deep_factorized_closed_form_checks():
             prm.add_(0.2 * torch.randn_like(prm))
     grid = 0.3 + torch.arange(-200, 200, dtype=torch.float32)
     assert abs(float(probs(df, grid).sum()) - 1.0) < 1e-4
+
+
+def _run_both(reference, fused, leaves, params):
+    """(y_hat, bits, d/dleaves, d/dparams) of the two evaluations under the same scalar loss."""
+    w = torch.tensor([1.0, -2.0, 0.5], device="cuda")
+    outs = []
+    for fn, prm in ((reference, params[0]), (fused, params[1])):
+        for t in list(leaves) + list(prm):
+            t.grad = None
+        y_hat, bits = fn()
+        ((bits * w).sum() + (y_hat.float() ** 2).sum() * 1e-3).backward()
+        outs.append((y_hat.detach(), bits.detach().float(), [t.grad.detach().float().clone() for t in leaves],
+                     [p.grad.detach().float().clone() for p in prm]))
+    return outs
+
+
+@pytest.mark.parametrize("expected", [False, True])
+def test_fused_laplace_tail_deep_factorized(expected):
+    """The *_tail entry points of csrc/factorized_bits.hip against the reference's `_log_prob`
+    (continuous_base.py:298-334) evaluated op by op in FLOAT64 (a float32 evaluation of the mixture has no
+    digits left where the tail matters), through math_ops.perturb_and_apply: bits, d/dy and the gradients of
+    every prior parameter, with inputs on both sides of the 1e-10 switch and where the two components are of
+    the same size."""
+    from compression_amd.ops import bottleneck_ops, math_ops
+    torch.manual_seed(31)
+    C, m = 48, 1e-3
+    prior = tfc.NoisyDeepFactorized(batch_shape=(C,), init_scale=0.5).cuda()
+    with torch.no_grad():
+        for prm in prior.parameters():
+            prm.add_(0.2 * torch.randn_like(prm))
+    prior64 = tfc.NoisyDeepFactorized(batch_shape=(C,), init_scale=0.5, dtype=torch.float64).cuda()
+    prior64.load_state_dict(prior.state_dict())
+    em = tfc.ContinuousBatchedEntropyModel(prior, coding_rank=3, laplace_tail_mass=m, expected_grads=expected)
+    y = 3.0 * torch.randn(3, 5, 7, C, device="cuda")
+    far = y.view(-1)[::53]
+    far.copy_(torch.sign(far) * torch.empty_like(far).uniform_(4.0, 32.0))
+    y.requires_grad_(True)
+    noise = torch.rand(3, 5, 7, C, device="cuda") - 0.5
+
+    with torch.no_grad():
+        v = (y + noise).double()
+        p_prior = prior64.prob(v)
+        p_tail = m * tfc.NoisyLaplace(loc=0.0, scale=1.0, dtype=torch.float64).prob(v)
+        mix = (1 - m) * p_prior + p_tail
+        assert (mix < 1e-10).sum() >= 10                                    # the log m + log Q branch
+        assert ((mix >= 1e-10) & (p_tail > 0.05 * p_prior)).sum() >= 10     # the tail is material, mixture branch
+
+    def reference():
+        lp, y_hat = math_ops.perturb_and_apply(lambda t: em._log_prob(prior64, t.double()), y, u=noise,
+                                               expected_grads=expected)
+        return y_hat, lp.sum(dim=(1, 2, 3)) / -float(np.log(2.0))
+
+    def fused():
+        return bottleneck_ops.factorized_bits(y, prior.base, 3, noise, expected_grads=expected, laplace_tail_mass=m)
+
+    (yr, br, (gr,), pr), (yf, bf, (gf,), pf) = _run_both(
+        reference, fused, [y], (list(prior64.parameters()), list(prior.parameters())))
+    assert torch.equal(yr, yf)
+    assert torch.isfinite(bf).all() and torch.isfinite(gf).all()
+    assert torch.allclose(br, bf, rtol=1e-5, atol=1e-3)
+    assert torch.allclose(gr, gf, rtol=2e-4, atol=2e-4 * gr.abs().max().item())
+    for a, b in zip(pr, pf):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3 * max(a.abs().max().item(), 1e-3))
+    # without the tail the result differs (the far inputs cost more bits): the option is not a no-op
+    _, plain = bottleneck_ops.factorized_bits(y.detach(), prior.base, 3, noise)
+    assert (plain - bf > 1.0).all()
+    # the entropy model's training call takes the fused kernels
+    calls = []
+    orig = bottleneck_ops.factorized_bits
+    try:
+        bottleneck_ops.factorized_bits = lambda *a, **k: (calls.append(k), orig(*a, **k))[1]
+        y2 = y.detach().clone().requires_grad_(True)
+        y_hat2, bits2 = em(y2, training=True)
+    finally:
+        bottleneck_ops.factorized_bits = orig
+    assert len(calls) == 1 and calls[0]["laplace_tail_mass"] == m
+    want = em._log_prob(prior64, y_hat2.detach().double()).sum(dim=(1, 2, 3)) / -float(np.log(2.0))
+    assert torch.allclose(bits2.detach(), want.float(), rtol=1e-5, atol=1e-3)
+    bits2.sum().backward()
+    assert torch.isfinite(y2.grad).all()
+
+
+@pytest.mark.parametrize("dtype,expected", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, False)])
+def test_fused_laplace_tail_noisy_normal(dtype, expected):
+    """The *_tail entry points of csrc/noisy_normal_bits.hip against `_log_prob` (continuous_base.py:298-334)
+    in float64 over a NoisyNormal(0, scale): bits, d/dy, d/dscale, inputs out to where the normal's mass
+    underflows and only the log m + log Q branch is left."""
+    from compression_amd.distributions import uniform_noise
+    from compression_amd.ops import bottleneck_ops, math_ops
+    torch.manual_seed(32)
+    m = 1e-3
+    shape = (3, 6, 5, 32)
+    log_scale = torch.empty(shape, device="cuda").uniform_(-2.0, 1.5).requires_grad_(True)
+    y = (torch.randn(shape, device="cuda") * torch.exp(log_scale.detach()) * 1.5).to(dtype)
+    y.view(-1)[::37] *= 12.0
+    y.requires_grad_(True)
+    noise = (torch.rand(shape, device="cuda") - 0.5).to(dtype)
+    em = tfc.LocationScaleIndexedEntropyModel(uniform_noise.NoisyNormal, 64, lambda i: torch.exp(-2.0 + 0.1 * i),
+                                              coding_rank=3, laplace_tail_mass=m, expected_grads=expected,
+                                              bottleneck_dtype=dtype)
+
+    def reference():
+        prior = uniform_noise.NoisyNormal(loc=0.0, scale=torch.exp(log_scale).double(), dtype=torch.float64)
+        lp, y_hat = math_ops.perturb_and_apply(lambda t: em._log_prob(prior, t.double()), y, u=noise,
+                                               expected_grads=expected)
+        return y_hat, lp.sum(dim=(1, 2, 3)) / -float(np.log(2.0))
+
+    def fused():
+        return bottleneck_ops.noisy_normal_bits(y, torch.exp(log_scale), 3, noise, expected_grads=expected,
+                                                laplace_tail_mass=m)
+
+    with torch.no_grad():
+        v = (y + noise).double()
+        prior = uniform_noise.NoisyNormal(loc=0.0, scale=torch.exp(log_scale).double(), dtype=torch.float64)
+        p_tail = m * uniform_noise.NoisyLaplace(loc=0.0, scale=1.0, dtype=torch.float64).prob(v)
+        mix = (1 - m) * prior.prob(v) + p_tail
+        assert (mix < 1e-10).sum() >= 10 and ((mix >= 1e-10) & (p_tail > 0.05 * prior.prob(v))).sum() >= 10
+
+    (yr, br, (gr, sr), _), (yf, bf, (gf, sf), _) = _run_both(reference, fused, [y, log_scale], ([], []))
+    assert torch.equal(yr, yf)
+    assert torch.isfinite(bf).all() and torch.isfinite(gf).all() and torch.isfinite(sf).all()
+    assert torch.allclose(br, bf, rtol=2e-5, atol=1e-2)
+    gtol = 5e-4 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(gr, gf, rtol=gtol, atol=gtol * gr.abs().max().item())
+    assert torch.allclose(sr, sf, rtol=5e-4, atol=5e-4 * sr.abs().max().item())
+    # the model's training call (loc given: the model shifts the bottleneck, the prior's own loc is 0)
+    calls = []
+    orig = bottleneck_ops.noisy_normal_bits
+    try:
+        bottleneck_ops.noisy_normal_bits = lambda *a, **k: (calls.append(k), orig(*a, **k))[1]
+        idx = torch.empty(shape, device="cuda").uniform_(0, 63)
+        loc = torch.randn(shape, device="cuda").to(dtype)
+        y_hat2, bits2 = em(y.detach(), idx, loc=loc, training=True)
+    finally:
+        bottleneck_ops.noisy_normal_bits = orig
+    assert len(calls) == 1 and calls[0]["laplace_tail_mass"] == m
+    assert torch.isfinite(bits2).all() and (bits2 > 0).all()
+    if dtype == torch.float32:          # (in bfloat16, y_hat - loc is not the value the kernel saw)
+        prior2 = uniform_noise.NoisyNormal(loc=0.0, scale=torch.exp(-2.0 + 0.1 * idx).double(), dtype=torch.float64)
+        want = em._log_prob(prior2, (y_hat2 - loc).double()).sum(dim=(1, 2, 3)) / -float(np.log(2.0))
+        assert torch.allclose(bits2.float(), want.float(), rtol=1e-4, atol=1e-2)
+
+
+def test_indexed_model_with_a_prior_location_keeps_the_tail_unfused():
+    """A NoisyNormal whose location comes from the indexes: the Laplace component of the tail sits at 0 of the
+    unshifted bottleneck (continuous_base.py:298-334), which the shifted kernel cannot see — that
+    configuration must stay on the op-by-op path, and agree with `_log_prob`."""
+    from compression_amd.distributions import uniform_noise
+    from compression_amd.ops import bottleneck_ops
+    torch.manual_seed(33)
+    em = tfc.ContinuousIndexedEntropyModel(
+        uniform_noise.NoisyNormal, (8,), dict(loc=lambda i: 0.5 * i - 2.0, scale=lambda i: torch.exp(0.2 * i - 1.0)),
+        coding_rank=1, channel_axis=None, laplace_tail_mass=1e-3)
+    y = 4.0 * torch.randn(5, 40, device="cuda")
+    idx = torch.randint(0, 8, (5, 40), device="cuda").float()
+    calls = []
+    orig = bottleneck_ops.noisy_normal_bits
+    try:
+        bottleneck_ops.noisy_normal_bits = lambda *a, **k: (calls.append(k), orig(*a, **k))[1]
+        y_hat, bits = em(y, idx, training=True)
+    finally:
+        bottleneck_ops.noisy_normal_bits = orig
+    assert not calls
+    want = em._log_prob(em._make_prior(idx), y_hat).sum(dim=1) / -float(np.log(2.0))
+    assert torch.allclose(bits, want, rtol=1e-5, atol=1e-4)

@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HOT = ["conv_bf16_kernel", "enc_lanes_kernel", "dec_lanes_kernel", "enc_fast_kernel", "dec_fast_kernel",
        "gdn_fwd_bf16_kernelILi6E", "gdn_bwd_fused_bf16_kernelILi6E", "gdn_param_grad_kernelItLi6E",
-       "noisy_normal_forward_kernel", "noisy_normal_backward_kernel", "factorized_forward_kernel"]
+       "noisy_normal_forward_kernel", "noisy_normal_backward_kernel", "factorized_forward_kernel",
+       "ELi256EEEvNS_10BitsParamsE"]        # factorized_backward_kernel<..., MAXT = 256>: every MLP shape
 
 
 def test_hot_kernels_do_not_spill():
