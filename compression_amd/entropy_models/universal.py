@@ -6,8 +6,9 @@ as one more index dimension.
 
 The shared randomness.  The reference draws the offset levels with
 `tf.random.stateless_uniform(shape, seed=(1234, 1234), minval=0, maxval=num_noise_levels, dtype=int32)`
-(universal.py:30-41).  `stateless_offset_indexes` below restates that op — Philox-4x32-10, key and counter
-scrambled from the seed as TensorFlow's stateless ops do, one 32-bit draw per element in flat order, reduced
+(universal.py:30-41).  `stateless_offset_indexes` below restates that op — Philox-4x32-10; key and counter
+scrambled from the seed as TensorFlow's stateless ops do (one Philox block under the fixed key
+0x3ec8f720, 0x02461e29 with the seed words as counter); one 32-bit draw per element in flat order, reduced
 modulo the range — from TensorFlow's published algorithm.  TensorFlow is not available here, so this stream
 is UNPINNED against the reference: encoder and decoder of this package agree with each other (that is what
 the tests check); interoperability of the strings with the reference's additionally needs the stream to be
@@ -42,21 +43,28 @@ def _philox4x32(counter, key, rounds=10):
     return c.astype(np.uint32)
 
 
+# TensorFlow's seed scrambling for stateless ops (core/kernels/stateless_random_ops.cc, GenerateKey): ONE
+# Philox block under a fixed key with the two seed words as the counter; its first two output words become
+# the key, its last two the upper counter words, and the lower counter words count 4-draw blocks.
+_SCRAMBLE_KEY = (0x3EC8F720, 0x02461E29)
+
+
 @functools.lru_cache(maxsize=32)
 def _stateless_uniform_int(n, seed, maxval):
     """`n` draws of stateless_uniform(seed=seed, minval=0, maxval=maxval, dtype=int32) in flat order."""
-    # key / counter from the seed: one Philox block keyed by the seed with a zero counter
-    mix = _philox4x32(np.zeros((1, 4), np.uint32), (seed[0] & 0xFFFFFFFF, seed[1] & 0xFFFFFFFF))[0]
+    s0, s1 = int(seed[0]) & 0xFFFFFFFFFFFFFFFF, int(seed[1]) & 0xFFFFFFFFFFFFFFFF
+    seed_ctr = np.array([[s0 & 0xFFFFFFFF, s0 >> 32, s1 & 0xFFFFFFFF, s1 >> 32]], np.uint32)
+    mix = _philox4x32(seed_ctr, _SCRAMBLE_KEY)[0]
     key = (int(mix[0]), int(mix[1]))
-    base = (int(mix[3]) << 32 | int(mix[2])) << 64            # counter words 2, 3; words 0, 1 count blocks
     blocks = (n + 3) // 4
     idx = np.arange(blocks, dtype=np.uint64)
     ctr = np.zeros((blocks, 4), np.uint32)
-    ctr[:, 0] = (idx & _M32).astype(np.uint32)
-    ctr[:, 1] = (idx >> np.uint64(32)).astype(np.uint32)
-    ctr[:, 2] = np.uint32((base >> 64) & 0xFFFFFFFF)
-    ctr[:, 3] = np.uint32((base >> 96) & 0xFFFFFFFF)
+    ctr[:, 0] = (idx & _M32).astype(np.uint32)          # Skip(block): 128-bit add to a counter whose low
+    ctr[:, 1] = (idx >> np.uint64(32)).astype(np.uint32)  # 64 bits start at zero
+    ctr[:, 2] = mix[2]
+    ctr[:, 3] = mix[3]
     draws = _philox4x32(ctr, key).reshape(-1)[:n]
+    # UniformDistribution<PhiloxRandom, int32>: lo + draw % range, one 32-bit draw per element
     return (draws % np.uint32(maxval)).astype(np.int32)
 
 
