@@ -52,3 +52,20 @@ def test_ops_fail_loudly_without_device():
     import compression_amd as tfc
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         tfc.create_range_encoder([2], torch.tensor([12, 0, 4096], dtype=torch.int32))
+
+
+def test_argument_validation_of_the_transform_and_bits_calls_is_host_side():
+    """Bad scalar arguments are rejected before anything is launched (null tensors, no device needed)."""
+    from compression_amd import _lib
+    lib = _lib.lib()
+    for m in (0.0, 1.0, -0.5, float("nan")):
+        rc = lib.tfc_factorized_bits_forward_tail(None, None, None, 0, 1, 3, 3, None, 3, 3, m, None, None, None)
+        assert rc != 0 and "laplace_tail_mass must be in (0, 1)" in _lib.last_error()
+        rc = lib.tfc_noisy_normal_bits_backward_tail(None, None, None, 0, 1, 3, m, None, None, None, None)
+        assert rc != 0 and "laplace_tail_mass must be in (0, 1)" in _lib.last_error()
+    rc = lib.tfc_gdn_forward_general(None, None, 0, 32, 32, None, None, 0, 0, -1.0, 1.0, None)
+    assert rc != 0 and "alpha and epsilon must be positive" in _lib.last_error()
+    rc = lib.tfc_gdn_forward(None, None, 0, 32, 48, None, None, 0, 0, 1, 0, None)
+    assert rc != 0 and "multiple of 32" in _lib.last_error()
+    rc = lib.tfc_gdn_forward(None, None, 7, 32, 32, None, None, 0, 0, 1, 0, None)
+    assert rc != 0 and "dtype" in _lib.last_error()
