@@ -1,6 +1,7 @@
 """Probability models feeding the range-coding tables (the reference's
-`python/distributions`, minus the round adapters and mixtures it marks optional)."""
+`python/distributions`, minus the round adapters)."""
 from .base import Distribution, Laplace, Logistic, Normal
 from .deep_factorized import DeepFactorized, NoisyDeepFactorized
 from .helpers import estimate_tails, lower_tail, quantization_offset, upper_tail
-from .uniform_noise import NoisyLaplace, NoisyLogistic, NoisyNormal, UniformNoiseAdapter
+from .uniform_noise import (MixtureSameFamily, NoisyLaplace, NoisyLogistic, NoisyLogisticMixture,
+                            NoisyMixtureSameFamily, NoisyNormal, NoisyNormalMixture, UniformNoiseAdapter)
