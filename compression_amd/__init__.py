@@ -9,7 +9,7 @@ from .ops import gen_ops
 from .ops.gen_ops import *  # noqa: F401,F403
 from .ops.math_ops import lower_bound, perturb_and_apply, upper_bound  # noqa: F401
 from .ops.padding_ops import same_padding_for_kernel  # noqa: F401
-from .ops.round_ops import round_st  # noqa: F401
+from .ops.round_ops import round_st, soft_round, soft_round_conditional_mean, soft_round_inverse  # noqa: F401
 from .distributions import *  # noqa: F401,F403
 from .entropy_models import *  # noqa: F401,F403
 from .layers import *  # noqa: F401,F403

@@ -71,3 +71,20 @@ def test_indexed_roundtrip_and_rate():
     _, bt = em(yg, ig, training=True)
     bt.sum().backward()
     assert torch.isfinite(yg.grad).all() and torch.isfinite(ig.grad).all() and ig.grad.abs().sum() > 0
+
+
+def test_batched_roundtrip_with_a_soft_rounded_prior():
+    """The universal models' usual prior (round_adapters.py:253-290: soft-rounded normal + uniform noise): table
+    building through the monotonic adapter's tails, exact round trip, coded size near the estimate."""
+    torch.manual_seed(4)
+    C = 8
+    prior = tfc.NoisySoftRoundedNormal(loc=torch.linspace(-1, 1, C), scale=torch.linspace(0.7, 5.0, C), alpha=3.0)
+    em = tfc.UniversalBatchedEntropyModel(prior, coding_rank=2, compression=True, num_noise_levels=15)
+    y = tfc.soft_round(torch.randn(3, 1500, C) * torch.linspace(0.7, 5.0, C) + torch.linspace(-1, 1, C), 3.0).cuda()
+    strings = em.compress(y)
+    y_hat = em.decompress(strings, (1500,))
+    _, offset = em._compute_indexes_and_offset((1500,))
+    assert torch.equal(y_hat, torch.round(y - offset.cuda()) + offset.cuda())
+    _, bits = em(y, training=False)
+    coded = np.array([8 * len(bytes(s)) for s in strings], dtype=np.float64)
+    assert np.all(coded >= bits.cpu().numpy() * 0.97) and np.all(coded <= bits.cpu().numpy() * 1.06 + 64)
