@@ -40,9 +40,14 @@ class SignalConv2D(torch.nn.Module):
         self.activation = activation
         self.use_bias = bool(use_bias)
         self.use_explicit = bool(use_explicit)
-        if kernel_parameter not in ("rdft", "variable"):
-            raise ValueError("kernel_parameter must be 'rdft' or 'variable'")
-        self.kernel_parameter = kernel_parameter
+        # a tensor, a callable (e.g. a `parameters.Parameter`) or one of the strings (signal_conv.py:222-236)
+        if isinstance(kernel_parameter, str) and kernel_parameter not in ("rdft", "variable"):
+            raise ValueError("kernel_parameter must be a tensor, a callable, 'rdft' or 'variable'")
+        if isinstance(bias_parameter, str) and bias_parameter != "variable":
+            raise ValueError("bias_parameter must be a tensor, a callable or 'variable'")
+        self.kernel_parameter = kernel_parameter if isinstance(kernel_parameter, str) else "given"
+        self._kernel_given = None if isinstance(kernel_parameter, str) else kernel_parameter
+        self._bias_given = None if isinstance(bias_parameter, str) else bias_parameter
         self._kernel_init, self._bias_init = kernel_initializer, bias_initializer
         self.kernel_real = self.kernel_imag = self.kernel_variable = self.bias = None
         self._check_implemented()
@@ -65,6 +70,11 @@ class SignalConv2D(torch.nn.Module):
     def build(self, cin, device=None):
         if self.kernel_real is not None or self.kernel_variable is not None:
             return
+        if self.use_bias and self._bias_given is None and self.bias is None:
+            b = self._bias_init((self.filters,)) if self._bias_init else torch.zeros(self.filters)
+            self.bias = torch.nn.Parameter(b.float().to(device))
+        if self._kernel_given is not None:
+            return
         kh, kw = self.kernel_support
         if self._kernel_init is not None:
             k = self._kernel_init((kh, kw, cin, self.filters))
@@ -80,12 +90,19 @@ class SignalConv2D(torch.nn.Module):
             self.kernel_imag = torch.nn.Parameter(imag.to(device))
         else:
             self.kernel_variable = torch.nn.Parameter(k.to(device))
-        if self.use_bias:
-            b = self._bias_init((self.filters,)) if self._bias_init else torch.zeros(self.filters)
-            self.bias = torch.nn.Parameter(b.float().to(device))
+
+    def _bias_value(self):
+        """The bias in use: the layer's own variable `bias`, or the tensor / callable given as `bias_parameter`."""
+        if not self.use_bias:
+            return None
+        if self._bias_given is not None:
+            return torch.as_tensor(self._bias_given() if callable(self._bias_given) else self._bias_given)
+        return self.bias
 
     @property
     def kernel(self):
+        if self._kernel_given is not None:
+            return torch.as_tensor(self._kernel_given() if callable(self._kernel_given) else self._kernel_given)
         if self.kernel_variable is not None:
             return self.kernel_variable
         if self.kernel_real is None:
@@ -122,9 +139,9 @@ class SignalConv2D(torch.nn.Module):
                 self._check_implemented_fail()
             corr, kernel = False, kernel.flip(0, 1)            # signal_conv.py:875-880
         if corr:
-            y = functional.conv2d_down(x, kernel, self.bias, down, fused)
+            y = functional.conv2d_down(x, kernel, self._bias_value(), down, fused)
         else:
-            y = functional.conv2d_up(x, kernel, self.bias, up, fused)
+            y = functional.conv2d_up(x, kernel, self._bias_value(), up, fused)
             if down != 1:
                 y = y[:, ::down, ::down]
         if act is not None and fused is None:

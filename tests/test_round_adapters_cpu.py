@@ -88,7 +88,7 @@ def test_adapter_tails(name):
         right = dist.survival_function(upper)
     except NotImplementedError:
         right = dist.base.survival_function(upper)
-    assert float(left) <= 2 ** -8 and float(right) <= 2 ** -8 and float(upper) > float(lower)
+    assert float(left.detach()) <= 2 ** -8 and float(right.detach()) <= 2 ** -8 and float(upper) > float(lower)
 
 
 @pytest.mark.parametrize("base", ["Logistic", "Normal"])
