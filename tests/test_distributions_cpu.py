@@ -123,3 +123,74 @@ def test_laplace_tail_mass_for_large_and_small_inputs():
     torch.manual_seed(1)
     _, bits2 = em2(x[..., None])
     assert torch.allclose(bits1, bits2, rtol=0.01, atol=0.05)
+
+
+# ------------------------------------------------------------------ helpers_test.py
+def test_estimate_tails_terminates_on_nan_and_on_a_perfect_initial_guess():
+    helpers.estimate_tails(lambda x: torch.tanh(x) * float("nan"), target=0.5, shape=(), dtype=torch.float32)
+    # the initial guess is zero: no zero crossing would ever start the count
+    helpers.estimate_tails(torch.tanh, target=0.0, shape=(), dtype=torch.float32)
+
+
+@pytest.mark.parametrize("family,loc,scale", [("Laplace", -2.0, 5.0), ("Logistic", -3.0, 1.0), ("Normal", 3.0, 5.0)])
+def test_location_scale_offsets_and_tails(family, loc, scale):
+    dist = getattr(tfc.distributions, family)(loc=loc, scale=scale)
+    assert float(helpers.quantization_offset(dist)) == 0.0          # decimal part of the mode
+    assert float(helpers.upper_tail(dist, 2 ** -8)) > float(helpers.lower_tail(dist, 2 ** -8))
+    assert abs(float(dist.cdf(helpers.lower_tail(dist, 2 ** -8))) - 2 ** -9) < 1e-5
+    shifted = getattr(tfc.distributions, family)(loc=1.4, scale=3.0)
+    assert abs(float(helpers.quantization_offset(shifted)) - 0.4) < 1e-6
+
+
+@pytest.mark.parametrize("cls", ["DeepFactorized", "NoisyDeepFactorized"])
+def test_deep_factorized_tails_are_in_order(cls):
+    torch.manual_seed(0)
+    dist = getattr(tfc, cls)(batch_shape=[10])
+    assert (helpers.upper_tail(dist, 2 ** -8) - helpers.lower_tail(dist, 2 ** -8) > 0).all()
+
+
+# ------------------------------------------------------------------ deep_factorized_test.py
+def test_deep_factorized_shapes_and_defaults():
+    df = tfc.DeepFactorized()
+    assert tuple(df.batch_shape) == () and tuple(df.event_shape) == ()
+    assert df.num_filters == (3, 3) and df.init_scale == 10
+    df = tfc.DeepFactorized(batch_shape=(4, 3))
+    assert tuple(df.batch_shape) == (4, 3)
+    noisy = tfc.NoisyDeepFactorized(num_filters=(2, 3, 4))
+    assert noisy.base.num_filters == (2, 3, 4) and tuple(noisy.batch_shape) == ()
+    noisy.prob(torch.randn(10))
+    tfc.NoisyDeepFactorized(batch_shape=(4, 3)).prob(torch.randn(10, 4, 3))
+
+
+@pytest.mark.parametrize("method", ["prob", "log_prob", "cdf", "log_cdf", "survival_function",
+                                    "log_survival_function"])
+def test_deep_factorized_methods(method):
+    # without hidden units the density collapses to a logistic distribution
+    torch.manual_seed(0)
+    df = tfc.DeepFactorized(num_filters=(), init_scale=1)
+    logistic = tfc.distributions.Logistic(loc=-df.biases[0].detach().reshape(()), scale=1.0)
+    x = torch.linspace(-5.0, 5.0, 20)
+    assert torch.allclose(getattr(df, method)(x), getattr(logistic, method)(x), atol=1e-6, rtol=1e-5)
+    # broadcasting: [4, 5, 1, 1] against batch shape (2, 3)
+    df = tfc.DeepFactorized(batch_shape=(2, 3))
+    assert getattr(df, method)(torch.linspace(-5.0, 5.0, 20).reshape(4, 5, 1, 1)).shape == (4, 5, 2, 3)
+
+
+def test_noisy_deep_factorized_special_cases_and_gradients():
+    torch.manual_seed(0)
+    df = tfc.NoisyDeepFactorized()
+    loss = -df.log_prob(torch.randn(20)).mean()
+    grads = torch.autograd.grad(loss, list(df.parameters()))
+    assert len(grads) == 8 and all(g is not None for g in grads)
+    df = tfc.NoisyDeepFactorized(num_filters=(), init_scale=1)
+    logistic = tfc.distributions.Logistic(loc=-df.base.biases[0].detach().reshape(()), scale=1.0)
+    x = torch.linspace(-5.0, 5.0, 20)
+    assert torch.allclose(df.prob(x), logistic.cdf(x + 0.5) - logistic.cdf(x - 0.5), atol=1e-6)
+    df = tfc.NoisyDeepFactorized(init_scale=1e-3)
+    assert torch.allclose(df.prob(torch.linspace(-1.0, 1.0, 10)), torch.tensor([0, 0, 0, 1, 1, 1, 1, 0, 0, 0.0]),
+                          atol=1e-4)
+    df = tfc.NoisyDeepFactorized()
+    assert float(helpers.upper_tail(df, 2 ** -8)) > float(helpers.lower_tail(df, 2 ** -8))
+    for what in (df.mode, df.mean, lambda: df.quantile(0.5), lambda: df.survival_function(0.5)):
+        with pytest.raises(NotImplementedError):
+            what()
