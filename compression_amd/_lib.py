@@ -22,6 +22,10 @@ SIGNATURES = {
     "tfc_profile_enable": (None, [_int]),
     "tfc_set_default_mode": (_int, [_int]),
     "tfc_get_default_mode": (_int, []),
+    "tfc_device_compute_units": (_int, [C.POINTER(_int)]),
+    "tfc_stream_create_cu_mask": (_int, [_vp, _int, C.POINTER(_vp)]),
+    "tfc_stream_destroy": (_int, [_vp]),
+    "tfc_encoder_capacity": (_int, [_vp, C.POINTER(_i64)]),
     "tfc_profile_query": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "tfc_tables_create": (_int, [_vp, _int, _i64, _i64, _vp, C.POINTER(_vp)]),
     "tfc_tables_count": (_i64, [_vp]),
@@ -88,6 +92,8 @@ SIGNATURES = {
     "tfc_noisy_normal_bits_backward_tail": (_int, [_vp, _vp, _vp, _int, _i64, _i64, C.c_float, _vp, _vp, _vp, _vp]),
 }
 
+ABI_VERSION = 2          # include/tfc_hip.h TFC_ABI_VERSION this binding was written against
+
 _lib = None
 
 
@@ -104,6 +110,15 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         handle = C.CDLL(LIB_PATH)
+        try:
+            handle.tfc_abi_version.restype = _int
+            version = handle.tfc_abi_version()
+        except AttributeError:
+            version = None
+        if version != ABI_VERSION:
+            raise HipLibraryMissing(
+                f"{LIB_PATH} has ABI version {version}, this package needs {ABI_VERSION}: rebuild it with "
+                "`python -c 'import __graft_entry__ as g; g.build(force=True)'`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res

@@ -192,7 +192,7 @@ int scan_row(const std::vector<int32_t>& v, int64_t end, int64_t* cur, std::vect
 
 }  // namespace
 
-extern "C" int tfc_abi_version(void) { return 1; }
+extern "C" int tfc_abi_version(void) { return TFC_ABI_VERSION; }
 extern "C" const char* tfc_last_error(void) { return last_error().c_str(); }
 extern "C" void tfc_free(void* p) { std::free(p); }
 
@@ -442,7 +442,25 @@ struct EncParams {
   const long long* chunk_off;       // [streams + 1]
   unsigned int* chunk_len;          // [streams]
   unsigned int* overflow_flag;      // [1]
+  // deferred-error handles (no read-back between the counting and the coding pass): the coding pass
+  // itself looks at the counting pass's verdict — guard[0] = first range error (~0 = none), guard[1] =
+  // bytes the per-stream slabs need — and appends nothing if there was an error or the slab the host
+  // sized without knowing the data is too small (then it raises the overflow flag).  null: checked by the host.
+  const unsigned long long* guard;
+  unsigned long long cap_total;
 };
+
+// true: this call appends nothing (see EncParams::guard); the stream's piece gets length 0
+__device__ inline bool enc_guard_skips(const EncParams& p, int64_t s, int lane) {
+  if (!p.guard) return false;
+  const unsigned long long err = p.guard[0], need = p.guard[1];
+  if (err == ~0ull && need <= p.cap_total) return false;
+  if (lane == 0) {
+    p.chunk_len[s] = 0u;
+    if (need > p.cap_total) atomicOr(p.overflow_flag, 1u);
+  }
+  return true;
+}
 
 // Per-element classification shared by the counting and the coding pass.
 struct Call {
@@ -718,6 +736,7 @@ __global__ void __launch_bounds__(kBlock) enc_kernel(EncParams p, Src src) {
   const int64_t s = __builtin_amdgcn_readfirstlane(
       static_cast<int>(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
   if (s >= p.streams) return;
+  if (enc_guard_skips(p, s, lane)) return;
 
   const uint4 st0 = p.state[s];
   EncoderState st;
@@ -1305,6 +1324,17 @@ struct tfc_encoder {
   std::shared_ptr<DevBuf> result_group;   // finalize_device_many: blob / offsets are slices of one allocation
   DevView blob, offsets;
   int64_t total = 0;
+  int64_t blob_capacity = 0;    // bytes behind `blob`
+  // Every entry point that takes a stream retargets the handle's buffers to it: they are released in the
+  // order of the stream that used them LAST, not of the one they were allocated under.
+  void touch(hipStream_t s) {
+    ctl.touch(s);
+    if (ctl_group) ctl_group->touch(s);
+    for (auto& c : chunks) { c.data.touch(s); c.off.touch(s); c.len.touch(s); }
+    blob_own.touch(s);
+    offsets_own.touch(s);
+    if (result_group) result_group->touch(s);
+  }
 };
 
 namespace {
@@ -1540,6 +1570,23 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   return 0;
 }
 
+// Deferred-error handles, wave-per-stream families: the counting pass's first error goes to the handle's
+// status word on the device (the value / index behind it are recorded by enc_error_kernel).
+__global__ void enc_defer_kernel(const unsigned long long* count_status, unsigned long long* status) {
+  if (count_status[0] != ~0ull && status[0] == ~0ull) status[0] = count_status[0];
+}
+
+// Slab bytes for a wave-per-stream call sized WITHOUT the counting pass's result: what the call needs
+// when no symbol takes an escape code (2 bytes per coder call + 4, rounded per stream), a quarter more
+// when the tables have escape rows (an escape adds 2 log2|overflow| + 3 calls; the tables' own tail mass
+// is 2^-8 ... 2^-7 of the symbols), and room for digits earlier calls held back.
+size_t speculative_slab_bytes(const tfc_tables* t, int64_t streams, int64_t elems) {
+  const size_t per = ((2 * static_cast<size_t>(elems) + 4 + 15) / 16) * 16 + 32;
+  size_t bytes = per * static_cast<size_t>(streams);
+  if (t->any_escape) bytes += bytes / 4;
+  return bytes + (64u << 10);
+}
+
 int encode_precheck(tfc_encoder* e, int64_t elems) {
   if (e->finalized) return fail("encoder handle was already finalized");
   if (e->poisoned) return fail("encoder handle met a range error in an earlier call");
@@ -1550,6 +1597,7 @@ int encode_precheck(tfc_encoder* e, int64_t elems) {
 template <typename Src>
 int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& src, hipStream_t st) {
   if (encode_precheck(e, elems)) return 1;
+  e->touch(st);
   if (e->streams == 0 || elems == 0) return 0;
   const tfc_tables* t = e->tables;
   if (t->rows.empty()) return fail("index=0 not in range [0, 0)");
@@ -1574,6 +1622,8 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   p.chunk_off = nullptr;
   p.chunk_len = ch.len.as<unsigned int>();
   p.overflow_flag = e->oflag.as<unsigned int>();
+  p.guard = nullptr;
+  p.cap_total = 0;
   unsigned long long host_status[4] = {~0ull, 0ull, 0ull, 0ull};
 
   // wave-per-stream families: validation + exact output bound first (one read-back)
@@ -1582,8 +1632,8 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   TFC_HIP(cstat.alloc(sizeof(unsigned long long) * 3, st));
   TFC_HIP(hipMemsetAsync(calls.p, 0, sizeof(unsigned long long) * e->streams, st));
   // cstat[0] = first error position, [1] = total capacity, [2] = coder calls of all streams
-  const unsigned long long init[3] = {~0ull, 0ull, 0ull};
-  TFC_HIP(hipMemcpyAsync(cstat.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  TFC_HIP(hipMemsetAsync(cstat.p, 0xFF, sizeof(unsigned long long), st));
+  TFC_HIP(hipMemsetAsync(cstat.as<unsigned long long>() + 1, 0, 2 * sizeof(unsigned long long), st));
   TFC_HIP(ch.off.alloc(sizeof(long long) * (e->streams + 1), st));
   p.calls = calls.as<unsigned long long>();
   p.first_error = cstat.as<unsigned long long>();
@@ -1597,7 +1647,25 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   hipLaunchKernelGGL(enc_offsets_kernel, dim3(1), dim3(1024), 0, st, p.calls, p.state,
                      e->family == kFast ? 1 : 0, e->streams, ch.off.as<long long>(),
                      cstat.as<unsigned long long>() + 1);
-  unsigned long long count_status[3];
+  unsigned long long count_status[3] = {~0ull, 0ull, 0ull};
+  if (e->deferred) {
+    // no read-back: the slab is sized from the geometry alone and the coding pass checks the counting
+    // pass's verdict on the device (EncParams::guard); an error or an outgrown slab surfaces at
+    // tfc_encoder_status / tfc_encoder_finalize, as for the lane kernels
+    count_status[1] = speculative_slab_bytes(t, e->streams, elems);
+    p.guard = cstat.as<unsigned long long>();
+    p.cap_total = count_status[1];
+    hipLaunchKernelGGL(enc_defer_kernel, dim3(1), dim3(1), 0, st, cstat.as<unsigned long long>(),
+                       e->status.as<unsigned long long>());
+    EncErrJobs<Src> errs;
+    errs.elems = elems;
+    errs.ntab = p.tab.ntab;
+    errs.n = 1;
+    errs.job[0].status = e->status.as<unsigned long long>();
+    errs.job[0].src = src;
+    errs.job[0].index = index;
+    hipLaunchKernelGGL((enc_error_kernel<Src>), dim3(1), dim3(64), 0, st, errs);
+  } else {
   TFC_HIP(hipMemcpyAsync(count_status, cstat.p, sizeof(count_status), hipMemcpyDeviceToHost, st));
   TFC_HIP(hipStreamSynchronize(st));
   if (count_status[0] != ~0ull) {
@@ -1621,6 +1689,7 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
     return rc;
   }
 
+  }
   TFC_HIP(ch.data.alloc(count_status[1], st));
   ch.data_bytes = count_status[1];
   p.chunk = ch.data.as<uint8_t>();
@@ -1732,6 +1801,7 @@ extern "C" int tfc_encoder_finalize_device_many(int n, tfc_encoder* const* es, v
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n <= 0) return 0;
   bool batch = n <= kMaxFinalizeJobs;
+  for (int k = 0; k < n; ++k) es[k]->touch(st);
   for (int k = 0; k < n && batch; ++k) {
     const tfc_encoder* e = es[k];
     if (e->finalized || e->family != kLanes || e->chunks.size() != 1 || e->streams != es[0]->streams ||
@@ -1772,6 +1842,7 @@ extern "C" int tfc_encoder_finalize_device_many(int n, tfc_encoder* const* es, v
     e->result_group = group;
     e->offsets.p = f.base + k * f.job_bytes + f.offsets_off;
     e->blob.p = f.base + k * f.job_bytes + f.blob_off;
+    e->blob_capacity = static_cast<int64_t>(cap);
     e->chunks.clear();       // stream-ordered frees behind the pack launch
     e->finalized = true;
   }
@@ -1804,6 +1875,7 @@ extern "C" int tfc_encoder_encode_many(int n, tfc_encoder* const* es, const int3
   for (int k = 0; k < n; ++k) {
     tfc_encoder* e = es[k];
     if (encode_precheck(e, elems)) return 1;
+    e->touch(st);
     if (e->tables != es[0]->tables || e->streams != es[0]->streams)
       return fail("tfc_encoder_encode_many: handles must share tables and stream count");
     if ((indexes && indexes[k]) != (indexes && indexes[0]))
@@ -1861,6 +1933,7 @@ namespace {
 // Tail + lengths + offsets on the device; `exact` = synchronise to size the blob exactly, otherwise
 // the blob gets the slabs' total capacity and nothing is read back.
 int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
+  e->touch(st);
   if (e->finalized) return 0;
   const int64_t n = e->streams;
   TFC_HIP(e->offsets_own.alloc(sizeof(long long) * (n + 1), st));
@@ -1869,6 +1942,7 @@ int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
     TFC_HIP(hipMemsetAsync(e->offsets.p, 0, sizeof(long long), st));
     TFC_HIP(e->blob_own.alloc(0, st));
     e->blob.p = e->blob_own.p;
+    e->blob_capacity = 0;
     e->total = 0;
     e->total_known = true;
     e->finalized = true;
@@ -1918,6 +1992,7 @@ int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
   }
   TFC_HIP(e->blob_own.alloc(capacity, st));
   e->blob.p = e->blob_own.p;
+  e->blob_capacity = static_cast<int64_t>(capacity);
   hipLaunchKernelGGL(enc_pack_kernel, dim3(static_cast<unsigned>(ceil_div(n, kWavesPerBlock))),
                      dim3(kBlock), 0, st, n, list, static_cast<int>(refs.size()),
                      tail.as<Tail>(), e->offsets.as<long long>(), e->blob.as<uint8_t>());
@@ -1946,6 +2021,7 @@ extern "C" int tfc_encoder_finalize_device(tfc_encoder* e, void* stream) {
 
 extern "C" int tfc_encoder_status(tfc_encoder* e, void* stream, int64_t* total_bytes) {
   hipStream_t st = static_cast<hipStream_t>(stream);
+  e->touch(st);
   unsigned int oflag = 0;
   unsigned long long host_status[4];
   long long total = 0;
@@ -1970,6 +2046,12 @@ extern "C" int tfc_encoder_result(const tfc_encoder* e, const uint8_t** blob, co
   if (!e->finalized) return fail("encoder handle is not finalized");
   *blob = e->blob.as<uint8_t>();
   *offsets = e->offsets.as<int64_t>();
+  return 0;
+}
+
+extern "C" int tfc_encoder_capacity(const tfc_encoder* e, int64_t* bytes) {
+  if (!e->finalized) return fail("encoder handle is not finalized");
+  *bytes = e->blob_capacity;
   return 0;
 }
 
@@ -2003,6 +2085,12 @@ struct tfc_decoder {
   DevView state, status;                   // uint4 [streams]; u64 first index error (views of ctl)
   const uint8_t* blob_p = nullptr;         // device bytes the kernels read (owned or borrowed)
   const long long* off_p = nullptr;
+  void touch(hipStream_t s) {              // released in the order of the stream that used the handle last
+    blob.touch(s);
+    offsets.touch(s);
+    ctl.touch(s);
+    if (ctl_group) ctl_group->touch(s);
+  }
 };
 
 extern "C" int tfc_decoder_create(const tfc_tables* tables, const uint8_t* blob,
@@ -2090,6 +2178,7 @@ extern "C" int tfc_decoder_create_many(const tfc_tables* tables, int n, tfc_enco
 extern "C" int tfc_decoder_finalize_device_many(int n, tfc_decoder* const* ds, uint8_t* ok, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n <= 0) return 0;
+  for (int k = 0; k < n; ++k) ds[k]->touch(st);
   const int64_t streams = ds[0]->streams;
   for (int g0 = 0; g0 < n; g0 += kMaxDecoderJobs) {
     const int gn = std::min(kMaxDecoderJobs, n - g0);
@@ -2197,6 +2286,7 @@ template <typename Dst>
 int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& dst,
                hipStream_t st) {
   if (elems < 0) return fail("negative element count");
+  d->touch(st);
   if (d->streams == 0 || elems == 0) return 0;
   const tfc_tables* t = d->tables;
   if (t->rows.empty()) return fail("index=0 not in range [0, 0)");
@@ -2249,6 +2339,7 @@ extern "C" int tfc_decoder_decode_many(int n, tfc_decoder* const* ds, const int3
   if (n <= 0) return 0;
   if (elems < 0) return fail("negative element count");
   bool batch = elems > 0 && elems < (int64_t{1} << 29);
+  for (int k = 0; k < n; ++k) ds[k]->touch(st);
   for (int k = 0; k < n; ++k) {
     const tfc_decoder* d = ds[k];
     if (d->tables != ds[0]->tables || d->streams != ds[0]->streams)
@@ -2292,6 +2383,7 @@ extern "C" int tfc_decoder_decode_dequantized(tfc_decoder* d, const int32_t* ind
 
 extern "C" int tfc_decoder_finalize_device(tfc_decoder* d, uint8_t* ok_dev, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
+  d->touch(st);
   const int64_t n = d->streams;
   if (n)
     hipLaunchKernelGGL(dec_close_kernel, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256),
@@ -2302,6 +2394,7 @@ extern "C" int tfc_decoder_finalize_device(tfc_decoder* d, uint8_t* ok_dev, void
 
 extern "C" int tfc_decoder_status(tfc_decoder* d, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
+  d->touch(st);
   unsigned long long first_error = ~0ull;
   TFC_HIP(hipMemcpyAsync(&first_error, d->status.p, sizeof(first_error), hipMemcpyDeviceToHost, st));
   TFC_HIP(hipStreamSynchronize(st));

@@ -211,6 +211,7 @@ __global__ void enc_fast_kernel(EncParams p, Src src) {
   const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int64_t s = static_cast<int64_t>(blockIdx.x) * waves + wid;
   if (s >= p.streams) return;
+  if (enc_guard_skips(p, s, lane)) return;
   unsigned int* ring = rings + wid * kRingWords;
 
   const uint4 st0 = p.state[s];

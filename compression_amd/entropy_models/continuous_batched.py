@@ -113,35 +113,46 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         bottleneck = torch.as_tensor(bottleneck).to(self.bottleneck_dtype)
         offset = self.quantization_offset
         if offset is not None:
-            offset = offset.to(bottleneck.device)
+            if self.compression and bottleneck.is_cuda:
+                offset = self._device_tables(bottleneck.device)[2]     # cached: no copy (and no sync) per call
+            else:
+                offset = offset.to(bottleneck.device)
         return round_ops.round_st(bottleneck, offset)
 
     # ------------------------------------------------------------------ coding
     def _device_tables(self, device):
+        """(cdf_offset, quantization offset as float32 [C], quantization offset as stored) on the device,
+        uploaded once per table version."""
         cache = getattr(self, "_dev_cache", None)
-        key = (self.cdf.data_ptr(), self.cdf._version, str(device))
+        key = (self.cdf.data_ptr(), getattr(self.cdf, "_version", 0), str(device))
         if cache is None or cache[0] != key:
             off = self.cdf_offset.to(device).contiguous()
             q = self._quantization_offset
             qf = None if q is None else q.to(device, torch.float32).reshape(-1).contiguous()
-            object.__setattr__(self, "_dev_cache", (key, off, qf))
+            qn = None if q is None else q.to(device)
+            object.__setattr__(self, "_dev_cache", (key, off, qf, qn))
             cache = self._dev_cache
-        return cache[1], cache[2]
+        return cache[1], cache[2], cache[3]
 
-    def compress(self, bottleneck):
+    def compress(self, bottleneck, device_result=False):
         """continuous_batched.py:347-383.  Returns a numpy object array of `bytes`
-        shaped like `bottleneck` minus the `coding_rank` innermost dimensions."""
+        shaped like `bottleneck` minus the `coding_rank` innermost dimensions.
+
+        `device_result=True`: nothing is read back — the call is enqueued on the current HIP stream and
+        returns the finalized encoder handle, whose strings stay in HBM (`gen_ops.device_strings`,
+        `gen_ops.fetch_strings`; `decompress` takes the handle in place of the strings).  Range errors are
+        then reported by `fetch_strings` / `gen_ops.entropy_encode_status`."""
         self._check_compression()
         device = _lib.require_device()
         bottleneck = torch.as_tensor(bottleneck).to(device, self.bottleneck_dtype).contiguous()
         shape = tuple(bottleneck.shape)
         batch_shape = shape[:len(shape) - self.coding_rank] if self.coding_rank else shape
-        handle = gen_ops.create_range_encoder(batch_shape, self.cdf)
+        handle = gen_ops.create_range_encoder(batch_shape, self.cdf, deferred_errors=device_result)
         if handle.streams == 0:
             raise ValueError(f"`handle` is empty: handle.shape={list(batch_shape)}")
         channels = int(self.prior_shape.numel())
         elems = bottleneck.numel() // handle.streams
-        cdf_offset, qoff = self._device_tables(device)
+        cdf_offset, qoff, _ = self._device_tables(device)
         if self.fused and bottleneck.dtype in _DTYPE_CODE:
             handle._keep += [bottleneck, cdf_offset, qoff]
             _lib.check(_lib.lib().tfc_encoder_encode_quantized(
@@ -156,11 +167,17 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             iid = shape[:len(shape) - len(self.prior_shape)] if len(self.prior_shape) else shape
             symbols = symbols.reshape(tuple(iid) + (-1,)) - cdf_offset
             handle = gen_ops.entropy_encode_channel(handle, symbols.contiguous())
+        if device_result:
+            return gen_ops.entropy_encode_finalize_device(handle)
         return gen_ops.entropy_encode_finalize(handle)
 
-    def decompress(self, strings, broadcast_shape):
+    def decompress(self, strings, broadcast_shape, defer_sanity=False):
         """continuous_batched.py:385-422: output shape = strings.shape + broadcast_shape +
-        prior_shape."""
+        prior_shape.  `strings`: bytes container, or a handle from `compress(device_result=True)`.
+
+        `defer_sanity=True`: nothing is read back; returns (values, ok) with `ok` the device-resident
+        uint8 result of EntropyDecodeFinalize (1 = the end-of-stream check passed) for the caller to test
+        once the stream has run."""
         self._check_compression()
         device = _lib.require_device()
         broadcast_shape = tuple(int(s) for s in broadcast_shape)
@@ -168,22 +185,26 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         channels = int(self.prior_shape.numel())
         out_shape = tuple(handle.shape) + broadcast_shape + tuple(self.prior_shape)
         elems = int(np.prod(broadcast_shape, dtype=np.int64)) * channels
-        cdf_offset, qoff = self._device_tables(device)
+        cdf_offset, qoff, _ = self._device_tables(device)
         if self.fused and self.bottleneck_dtype in _DTYPE_CODE:
             out = torch.empty(out_shape, dtype=self.bottleneck_dtype, device=device)
             _lib.check(_lib.lib().tfc_decoder_decode_dequantized(
                 handle.ptr, None, out.data_ptr(), _DTYPE_CODE[self.bottleneck_dtype],
                 None if qoff is None else qoff.data_ptr(), cdf_offset.data_ptr(), channels, elems,
                 _lib.stream_ptr()))
-            sanity = gen_ops.entropy_decode_finalize(handle)
+            handle._keep.append(out)
         else:
             handle, symbols = gen_ops.entropy_decode_channel(
                 handle, broadcast_shape + (channels,), torch.int32)
-            sanity = gen_ops.entropy_decode_finalize(handle)
             out = (symbols + cdf_offset).reshape(out_shape).to(self.bottleneck_dtype)
             offset = self.quantization_offset
             if offset is not None:
                 out = out + offset.to(device)
+        if defer_sanity:
+            ok = gen_ops.entropy_decode_finalize_device(handle)
+            ok._tfc_handle = handle          # the decoder (and what it borrows) lives as long as its verdict
+            return out, ok
+        sanity = gen_ops.entropy_decode_finalize(handle)
         if self.decode_sanity_check and not bool(sanity.all()):
             raise RuntimeError("Sanity check failed.")
         return out

@@ -69,7 +69,7 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
     def _normalize_indexes(self, indexes):
         indexes = math_ops.lower_bound(indexes, 0)
         if self.channel_axis is None:
-            bounds = torch.tensor(self.index_ranges[0] - 1, dtype=indexes.dtype, device=indexes.device)
+            bounds = self.index_ranges[0] - 1       # a number: a device tensor would cost a synchronising copy per call
         else:
             axes = [1] * indexes.dim()
             axes[self.channel_axis] = len(self.index_ranges)
@@ -127,8 +127,19 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
     def quantize(self, bottleneck):
         return round_ops.round_st(torch.as_tensor(bottleneck).to(self.bottleneck_dtype))
 
-    def compress(self, bottleneck, indexes):
-        """continuous_indexed.py:355-386."""
+    def _device_offsets(self, device):
+        """cdf_offset on the device, uploaded once per table version (a pageable H->D copy in every call
+        would put a host synchronisation into the coding path)."""
+        key = (self.cdf_offset.data_ptr(), getattr(self.cdf_offset, "_version", 0), str(device))
+        cache = getattr(self, "_dev_offsets", None)
+        if cache is None or cache[0] != key:
+            object.__setattr__(self, "_dev_offsets", (key, self.cdf_offset.to(device).contiguous()))
+            cache = self._dev_offsets
+        return cache[1]
+
+    def compress(self, bottleneck, indexes, device_result=False):
+        """continuous_indexed.py:355-386.  `device_result=True`: see
+        `ContinuousBatchedEntropyModel.compress` (nothing read back, returns the finalized handle)."""
         self._check_compression()
         device = _lib.require_device()
         bottleneck = torch.as_tensor(bottleneck).to(device, self.bottleneck_dtype).contiguous()
@@ -136,8 +147,8 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         flat = self._flatten_indexes(indexes).contiguous()
         shape = tuple(flat.shape)
         batch_shape = shape[:len(shape) - self.coding_rank] if self.coding_rank else shape
-        cdf_offset = self.cdf_offset.to(device)
-        handle = gen_ops.create_range_encoder(batch_shape, self.cdf)
+        cdf_offset = self._device_offsets(device)
+        handle = gen_ops.create_range_encoder(batch_shape, self.cdf, deferred_errors=device_result)
         if handle.streams == 0:
             raise ValueError(f"`handle` is empty: handle.shape={list(batch_shape)}")
         if self.fused and bottleneck.dtype in _DTYPE_CODE:
@@ -149,17 +160,21 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         else:
             symbols = torch.round(bottleneck).to(torch.int32) - cdf_offset[flat.long()]
             handle = gen_ops.entropy_encode_index(handle, flat, symbols.contiguous())
+        if device_result:
+            return gen_ops.entropy_encode_finalize_device(handle)
         return gen_ops.entropy_encode_finalize(handle)
 
-    def decompress(self, strings, indexes):
-        """continuous_indexed.py:388-417."""
+    def decompress(self, strings, indexes, defer_sanity=False):
+        """continuous_indexed.py:388-417.  `strings` may be a handle from `compress(device_result=True)`;
+        `defer_sanity=True` returns (values, ok) without reading anything back (see
+        `ContinuousBatchedEntropyModel.decompress`)."""
         self._check_compression()
         device = _lib.require_device()
         indexes = self._normalize_indexes(torch.as_tensor(indexes).to(device))
         flat = self._flatten_indexes(indexes).contiguous()
         shape = tuple(flat.shape)
         decode_shape = shape[len(shape) - self.coding_rank:] if self.coding_rank else ()
-        cdf_offset = self.cdf_offset.to(device)
+        cdf_offset = self._device_offsets(device)
         handle = gen_ops.create_range_decoder(strings, self.cdf)
         if tuple(handle.shape) + tuple(decode_shape) != shape:
             raise ValueError(
@@ -168,15 +183,18 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         if self.fused and self.bottleneck_dtype in _DTYPE_CODE:
             out = torch.empty(shape, dtype=self.bottleneck_dtype, device=device)
             elems = flat.numel() // handle.streams
-            handle._keep.append(flat)
+            handle._keep += [flat, out, cdf_offset]
             _lib.check(_lib.lib().tfc_decoder_decode_dequantized(
                 handle.ptr, flat.data_ptr(), out.data_ptr(), _DTYPE_CODE[self.bottleneck_dtype],
                 None, cdf_offset.data_ptr(), 0, elems, _lib.stream_ptr()))
-            sanity = gen_ops.entropy_decode_finalize(handle)
         else:
             handle, symbols = gen_ops.entropy_decode_index(handle, flat, decode_shape, torch.int32)
-            sanity = gen_ops.entropy_decode_finalize(handle)
             out = (symbols + cdf_offset[flat.long()]).to(self.bottleneck_dtype)
+        if defer_sanity:
+            ok = gen_ops.entropy_decode_finalize_device(handle)
+            ok._tfc_handle = handle
+            return out, ok
+        sanity = gen_ops.entropy_decode_finalize(handle)
         if self.decode_sanity_check and not bool(sanity.all()):
             raise RuntimeError("Sanity check failed.")
         return out
@@ -210,13 +228,16 @@ class LocationScaleIndexedEntropyModel(ContinuousIndexedEntropyModel):
     def quantize(self, bottleneck, loc=None):
         return round_ops.round_st(torch.as_tensor(bottleneck).to(self.bottleneck_dtype), loc)
 
-    def compress(self, bottleneck, scale_indexes, loc=None):
+    def compress(self, bottleneck, scale_indexes, loc=None, device_result=False):
         if loc is not None:
             bottleneck = bottleneck - loc
-        return super().compress(bottleneck, scale_indexes)
+        return super().compress(bottleneck, scale_indexes, device_result=device_result)
 
-    def decompress(self, strings, scale_indexes, loc=None):
-        values = super().decompress(strings, scale_indexes)
+    def decompress(self, strings, scale_indexes, loc=None, defer_sanity=False):
+        values = super().decompress(strings, scale_indexes, defer_sanity=defer_sanity)
+        ok = None
+        if defer_sanity:
+            values, ok = values
         if loc is not None:
             values = values + loc
-        return values
+        return (values, ok) if defer_sanity else values

@@ -83,16 +83,53 @@ class GDN(torch.nn.Module):
             self.reparam_gamma = torch.nn.Parameter(
                 parameters.gdn_reparam_init(self._gamma_init(c).float()).to(device))
 
+    def _cached_value(self, name, variable, minimum):
+        """Under no_grad (compress / decompress) the reparameterised value is computed once per version
+        of its variable instead of once per call (three small kernels per parameter and call otherwise).
+        Keyed on storage and version counter like SignalConv2D's kernel cache: `invalidate_kernel_cache()`
+        after a write through `.data`."""
+        try:
+            key = (variable.data_ptr(), variable._version, str(variable.device))
+        except RuntimeError:                      # inference tensor: no version counter, no cache
+            return parameters.gdn_reparam_value(variable, minimum=minimum)
+        cache = self.__dict__.setdefault("_value_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            v = parameters.gdn_reparam_value(variable, minimum=minimum).contiguous()
+            if v.is_cuda:
+                torch.cuda.current_stream().synchronize()      # complete before another stream reads it
+            cache[name] = hit = (key, v)
+        return hit[1]
+
+    def invalidate_kernel_cache(self):
+        self.__dict__["_value_cache"] = {}
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_kernel_cache()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_kernel_cache()
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode=True):
+        self.invalidate_kernel_cache()
+        return super().train(mode)
+
     @property
     def beta(self):
         if self._beta_fixed is not None:
             return torch.as_tensor(self._beta_fixed() if callable(self._beta_fixed) else self._beta_fixed)
+        if not torch.is_grad_enabled():
+            return self._cached_value("beta", self.reparam_beta, 1e-6)
         return parameters.gdn_reparam_value(self.reparam_beta, minimum=1e-6)
 
     @property
     def gamma(self):
         if self._gamma_fixed is not None:
             return torch.as_tensor(self._gamma_fixed() if callable(self._gamma_fixed) else self._gamma_fixed)
+        if not torch.is_grad_enabled():
+            return self._cached_value("gamma", self.reparam_gamma, 0.0)
         return parameters.gdn_reparam_value(self.reparam_gamma, minimum=0.0)
 
     def forward(self, inputs):

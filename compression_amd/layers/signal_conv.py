@@ -12,6 +12,15 @@ from .gdn import GDN
 __all__ = ["SignalConv2D"]
 
 
+def _version_of(t):
+    """The tensor's version counter, or None where it has none (tensors created under
+    torch.inference_mode raise on `_version`)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def _pair(v):
     return (int(v), int(v)) if isinstance(v, int) else tuple(int(s) for s in v)
 
@@ -112,9 +121,11 @@ class SignalConv2D(torch.nn.Module):
         # inference (compress / decompress run under no_grad): the inverse RDFT once per parameter version
         # instead of once per call — 11 small FFTs per bmshj2018 step, and an FFT plan shared by host
         # threads that code batch slices on different streams is not safe to execute concurrently
-        key = (self.kernel_real.data_ptr(), self.kernel_real._version, self.kernel_imag.data_ptr(),
-               self.kernel_imag._version, str(self.kernel_real.device))
+        key = (self.kernel_real.data_ptr(), _version_of(self.kernel_real), self.kernel_imag.data_ptr(),
+               _version_of(self.kernel_imag), str(self.kernel_real.device))
         cached = getattr(self, "_kernel_cache", None)
+        if key[1] is None or key[3] is None:
+            cached = None                                     # inference tensors carry no version counter: recompute
         if cached is None or cached[0] != key:
             k = parameters.kernel_from_rdft(self.kernel_real, self.kernel_imag, self.kernel_support).contiguous()
             if k.is_cuda:
@@ -122,6 +133,25 @@ class SignalConv2D(torch.nn.Module):
             object.__setattr__(self, "_kernel_cache", (key, k))
             cached = self._kernel_cache
         return cached[1]
+
+    def invalidate_kernel_cache(self):
+        """Drops the cached inference kernel.  The cache is keyed on the parameters' storage and version
+        counters, which in-place writes through `.data` (`p.data.copy_()`: EMA weight swaps, manual weight
+        loading) do NOT advance — call this after such an update.  Loading a state dict, `.to()` / `.cuda()` /
+        `.half()` and `train()` invalidate it themselves."""
+        object.__setattr__(self, "_kernel_cache", None)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_kernel_cache()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_kernel_cache()
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode=True):
+        self.invalidate_kernel_cache()
+        return super().train(mode)
 
     def forward(self, inputs):
         if inputs.dim() != 4:

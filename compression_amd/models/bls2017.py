@@ -7,6 +7,7 @@ from __future__ import annotations
 import torch
 
 from .. import distributions, entropy_models, layers
+from ..pipeline import inline_lane
 
 __all__ = ["AnalysisTransform", "SynthesisTransform", "BLS2017Model"]
 
@@ -74,21 +75,40 @@ class BLS2017Model(torch.nn.Module):
         return self
 
     @torch.no_grad()
-    def compress(self, x):
-        """x: uint8 [B, H, W, 3] (or [H, W, 3]) -> (strings[B], x_shape, y_shape) — bls2017.py:164-176."""
+    def compress(self, x, device_result=False, lane=None):
+        """x: uint8 [B, H, W, 3] (or [H, W, 3]) -> (strings[B], x_shape, y_shape) — bls2017.py:164-176.
+        `device_result` / `lane`: see BMSHJ2018Model.compress (strings stay in HBM, nothing read back;
+        transforms and coder on the lane's two streams)."""
+        lane = lane or inline_lane()
         if x.dim() == 3:
             x = x[None]
-        x = x.to(self.compute_dtype)
-        y = self.analysis_transform(x)
-        return self.entropy_model.compress(y), tuple(x.shape[1:-1]), tuple(y.shape[1:-1])
+        with lane.on("transform"):
+            x = x.to(self.compute_dtype)
+            y = self.analysis_transform(x)
+        with lane.on("coder"):
+            string = self.entropy_model.compress(y, device_result=device_result)
+        if device_result:
+            string._keep.append(y)          # produced on the transform stream, read by the coder stream
+        return string, tuple(x.shape[1:-1]), tuple(y.shape[1:-1])
 
     @torch.no_grad()
-    def decompress(self, string, x_shape, y_shape):
-        """-> uint8 [B, H, W, 3] — bls2017.py:178-190."""
-        y_hat = self.entropy_model.decompress(string, y_shape)
-        x_hat = self.synthesis_transform(y_hat)
-        x_hat = x_hat[:, :x_shape[0], :x_shape[1], :]
-        return torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+    def decompress(self, string, x_shape, y_shape, defer_sanity=False, lane=None):
+        """-> uint8 [B, H, W, 3] — bls2017.py:178-190.  `defer_sanity=True`: (x_hat, [ok]) with the
+        device-resident EntropyDecodeFinalize flags, nothing read back."""
+        lane = lane or inline_lane()
+        with lane.on("coder"):
+            y_hat = self.entropy_model.decompress(string, y_shape, defer_sanity=defer_sanity)
+        ok = []
+        if defer_sanity:
+            y_hat, oky = y_hat
+            ok.append(oky)
+        with lane.on("transform"):
+            x_hat = self.synthesis_transform(y_hat)
+            x_hat = x_hat[:, :x_shape[0], :x_shape[1], :]
+            x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            if defer_sanity:
+                x_hat._tfc_keep = (y_hat,)
+        return (x_hat, ok) if defer_sanity else x_hat
 
 
 if __name__ == "__main__":      # python -m compression_amd.models.bls2017 compress in.png out.tfci

@@ -7,6 +7,7 @@ import math
 import torch
 
 from .. import distributions, entropy_models, layers
+from ..pipeline import inline_lane
 
 __all__ = ["AnalysisTransform", "SynthesisTransform", "HyperAnalysisTransform",
            "HyperSynthesisTransform", "BMSHJ2018Model"]
@@ -115,29 +116,59 @@ class BMSHJ2018Model(torch.nn.Module):
         return self
 
     @torch.no_grad()
-    def compress(self, x):
+    def compress(self, x, device_result=False, lane=None):
         """uint8 [B, H, W, 3] -> (string[B], side_string[B], x_shape, y_shape, z_shape) —
-        bmshj2018.py:219-240."""
+        bmshj2018.py:219-240.
+
+        `device_result=True`: the two string entries are finalized encoder handles whose bytes stay in
+        HBM (`gen_ops.fetch_strings` / `gen_ops.device_strings`), nothing is read back and the call only
+        enqueues work; `lane` (compression_amd.pipeline.Lane) puts the transforms and the coder on their
+        own streams / compute units."""
+        lane = lane or inline_lane()
         if x.dim() == 3:
             x = x[None]
-        x = x.to(self.compute_dtype)
-        y = self.analysis_transform(x)
-        z = self.hyper_analysis_transform(torch.abs(y))
-        x_shape, y_shape, z_shape = tuple(x.shape[1:-1]), tuple(y.shape[1:-1]), tuple(z.shape[1:-1])
-        z_hat = self.side_entropy_model.quantize(z)
-        indexes = self.hyper_synthesis_transform(z_hat)[:, :y_shape[0], :y_shape[1], :]
-        side_string = self.side_entropy_model.compress(z)
-        string = self.entropy_model.compress(y, indexes)
+        with lane.on("transform"):
+            x = x.to(self.compute_dtype)
+            y = self.analysis_transform(x)
+            z = self.hyper_analysis_transform(torch.abs(y))
+            x_shape, y_shape, z_shape = tuple(x.shape[1:-1]), tuple(y.shape[1:-1]), tuple(z.shape[1:-1])
+            z_hat = self.side_entropy_model.quantize(z)
+            indexes = self.hyper_synthesis_transform(z_hat)[:, :y_shape[0], :y_shape[1], :]
+        with lane.on("coder"):
+            side_string = self.side_entropy_model.compress(z, device_result=device_result)
+            string = self.entropy_model.compress(y, indexes, device_result=device_result)
+        if device_result:
+            # produced on the transform stream, read by the coder stream: alive as long as the strings
+            string._keep += [y, indexes]
+            side_string._keep += [z]
         return string, side_string, x_shape, y_shape, z_shape
 
     @torch.no_grad()
-    def decompress(self, string, side_string, x_shape, y_shape, z_shape):
-        """bmshj2018.py:242-264: the y stream can only be decoded after z (strict two-phase order)."""
-        z_hat = self.side_entropy_model.decompress(side_string, z_shape)
-        indexes = self.hyper_synthesis_transform(z_hat)[:, :y_shape[0], :y_shape[1], :]
-        y_hat = self.entropy_model.decompress(string, indexes)
-        x_hat = self.synthesis_transform(y_hat)[:, :x_shape[0], :x_shape[1], :]
-        return torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+    def decompress(self, string, side_string, x_shape, y_shape, z_shape, defer_sanity=False, lane=None):
+        """bmshj2018.py:242-264: the y stream can only be decoded after z (strict two-phase order).
+        The strings may be the handles `compress(device_result=True)` returned; `defer_sanity=True`
+        returns (x_hat, [ok_z, ok_y]) with the device-resident EntropyDecodeFinalize flags instead of
+        reading them back."""
+        lane = lane or inline_lane()
+        with lane.on("coder"):
+            z_hat = self.side_entropy_model.decompress(side_string, z_shape, defer_sanity=defer_sanity)
+        ok = []
+        if defer_sanity:
+            z_hat, okz = z_hat
+            ok.append(okz)
+        with lane.on("transform"):
+            indexes = self.hyper_synthesis_transform(z_hat)[:, :y_shape[0], :y_shape[1], :]
+        with lane.on("coder"):
+            y_hat = self.entropy_model.decompress(string, indexes, defer_sanity=defer_sanity)
+        if defer_sanity:
+            y_hat, oky = y_hat
+            ok.append(oky)
+        with lane.on("transform"):
+            x_hat = self.synthesis_transform(y_hat)[:, :x_shape[0], :x_shape[1], :]
+            x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            if defer_sanity:
+                x_hat._tfc_keep = (z_hat, indexes, y_hat)     # produced on one stream, read on the other
+        return (x_hat, ok) if defer_sanity else x_hat
 
 
 if __name__ == "__main__":      # python -m compression_amd.models.bmshj2018 compress in.png out.tfci

@@ -32,6 +32,7 @@ __all__ = [
     "entropy_encode_channel_many", "entropy_decode_channel_many",
     "create_range_encoders", "create_range_decoders",
     "entropy_encode_finalize_device_many", "entropy_decode_finalize_device_many",
+    "device_strings", "fetch_strings", "invalidate_table_cache",
 ]
 
 _MODES = {None: 0, "auto": 0, "latency": 1, "throughput": 2}
@@ -81,11 +82,22 @@ _TABLE_CACHE_SIZE = 32
 _TABLE_CACHE_LOCK = threading.Lock()      # handles may be created from several host threads
 
 
+def invalidate_table_cache() -> None:
+    """Drops every cached device copy of range-coding tables.  The cache is keyed on the lookup tensor's
+    storage and version counter; a write through `.data` does not advance the counter — call this after one."""
+    with _TABLE_CACHE_LOCK:
+        _TABLE_CACHE.clear()
+
+
 def _tables_for(lookup) -> _Tables:
     lookup = torch.as_tensor(lookup)
     if lookup.dtype != torch.int32:
         raise TypeError(f"`lookup` must be int32, got {lookup.dtype}")
-    key = (lookup.data_ptr(), lookup._version, tuple(lookup.shape), str(lookup.device))
+    try:
+        version = lookup._version
+    except RuntimeError:            # inference tensors carry no version counter: never cached
+        return _Tables(lookup)
+    key = (lookup.data_ptr(), version, tuple(lookup.shape), str(lookup.device))
     with _TABLE_CACHE_LOCK:
         hit = _TABLE_CACHE.get(key)
         if hit is not None and hit[0] is lookup:
@@ -274,6 +286,50 @@ def entropy_encode_finalize_device_many(handles):
         hp = (C.c_void_p * n)(*[h.ptr for h in handles])
         _lib.check(_lib.lib().tfc_encoder_finalize_device_many(n, hp, _lib.stream_ptr()))
     return handles
+
+
+class _DeviceSpan:
+    """A span of device memory owned by a handle, exposed through __cuda_array_interface__ so that torch can
+    view it without a copy (`owner` keeps the handle alive as long as the view is)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_strings(handle: EncoderHandle):
+    """Zero-copy torch views of a finalized handle's packed strings in HBM: (blob uint8 [capacity],
+    offsets int64 [streams + 1]); stream s is blob[offsets[s]:offsets[s + 1]].  After
+    entropy_encode_finalize_device the blob has the slabs' capacity — the total is offsets[-1], on the
+    device.  The views are valid in the order of the stream the handle was finalized on."""
+    blob_p, off_p = C.c_void_p(), C.c_void_p()
+    _lib.check(_lib.lib().tfc_encoder_result(handle.ptr, C.byref(blob_p), C.byref(off_p)))
+    cap = C.c_int64()
+    _lib.check(_lib.lib().tfc_encoder_capacity(handle.ptr, C.byref(cap)))
+    offsets = torch.as_tensor(_DeviceSpan(off_p.value, (handle.streams + 1,), "<i8", handle), device=handle.device)
+    if cap.value <= 0 or not blob_p.value:
+        return torch.empty(0, dtype=torch.uint8, device=handle.device), offsets
+    blob = torch.as_tensor(_DeviceSpan(blob_p.value, (cap.value,), "|u1", handle), device=handle.device)
+    return blob, offsets
+
+
+def fetch_strings(handle: EncoderHandle):
+    """The strings of a handle finalized with entropy_encode_finalize_device, on the host (numpy object
+    array of bytes shaped like the handle).  Synchronises the current stream; raises a deferred range
+    error.  Same result as entropy_encode_finalize on a handle that was not finalized yet."""
+    total = entropy_encode_status(handle)
+    if total < 0:
+        return entropy_encode_finalize(handle)
+    blob = np.empty(max(total, 1), np.uint8)
+    off = np.empty(handle.streams + 1, np.int64)
+    _lib.check(_lib.lib().tfc_encoder_read(handle.ptr, blob.ctypes.data, off.ctypes.data, 0, _lib.stream_ptr()))
+    handle._keep.clear()
+    data = blob.tobytes()
+    out = np.empty(handle.streams, dtype=object)
+    for i in range(handle.streams):
+        out[i] = data[off[i]:off[i + 1]]
+    return out.reshape(handle.shape)
 
 
 def entropy_encode_status(handle: EncoderHandle) -> int:

@@ -29,7 +29,10 @@ typedef struct tfc_tables tfc_tables;
 typedef struct tfc_encoder tfc_encoder;
 typedef struct tfc_decoder tfc_decoder;
 
-/* Library identity; bumps when the ABI changes. */
+/* Library identity; bumps when the ABI changes (compression_amd/_lib.py refuses a library whose
+ * version is not the one it was written against).  2: round-3 ABI (per-handle modes, *_many entry
+ * points, stream-ordered finalize, CU-masked streams). */
+#define TFC_ABI_VERSION 2
 int tfc_abi_version(void);
 /* Text of the last failure on this thread ("" if none). */
 const char* tfc_last_error(void);
@@ -58,6 +61,17 @@ int tfc_profile_query(const char* kernel, double* total_ms, int64_t* launches);
 #define TFC_MODE_THROUGHPUT 2
 int tfc_set_default_mode(int mode);
 int tfc_get_default_mode(void);
+
+/* HIP streams restricted to a subset of the compute units (hipExtStreamCreateWithCUMask).  No
+ * reference counterpart: the reference's coder ops and its transforms share TensorFlow's intra-op thread
+ * pool (range_coder_kernels.cc:212-215, ParallelFor over the streams); here the coder's serial chains
+ * need one wave per SIMD on a few CUs for a long time while the transforms want every remaining CU, so a
+ * model pipeline gives the two disjoint CU sets and lets them overlap (compression_amd/parallel.py,
+ * CoderPartition).  `mask`: one bit per CU, `words` 32-bit words, bit i of word i/32 = CU i in the
+ * driver's numbering (consecutive bits alternate over the XCDs).  The stream is a plain hipStream_t. */
+int tfc_device_compute_units(int* cus);
+int tfc_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
+int tfc_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* CDF tables                                                               */
@@ -158,6 +172,9 @@ int tfc_encoder_status(tfc_encoder* e, void* stream, int64_t* total_bytes);
 /* After finalize: device views of the packed result (owned by the handle):
  * blob DEV uint8 [total_bytes], offsets DEV int64 [streams + 1]. */
 int tfc_encoder_result(const tfc_encoder* e, const uint8_t** blob, const int64_t** offsets);
+/* Bytes the device blob was allocated with (>= offsets[streams]): what a caller may map before it
+ * knows the total (after tfc_encoder_finalize_device). */
+int tfc_encoder_capacity(const tfc_encoder* e, int64_t* bytes);
 /* After finalize: copies the result out.  dst_on_device selects hipMemcpy
  * direction.  Synchronises when copying to the host. */
 int tfc_encoder_read(const tfc_encoder* e, uint8_t* blob_dst, int64_t* offsets_dst,

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in tfc_hip.h but not exported"
     assert set(_lib.SIGNATURES) == declared
-    assert lib.tfc_abi_version() == 1
+    assert lib.tfc_abi_version() == 2
 
 
 def test_every_entry_point_cites_reference():
