@@ -25,6 +25,16 @@ streams).
 Multi-GPU: the batch dimension shards (independent code streams), so every rank
 codes its own 512-stream shard (weak scaling); no data-path collective, only the
 barrier + max-reduce of the timing.
+
+The same line carries, as sub-objects (N = 1 only; `--no-extras` drops them):
+  single_batch  ONE 512-stream batch at a time (BASELINE config 2 as literally written), both families;
+  escapes       the same --steps command with 0.4 % (the tables' own tail mass) and 1 % of
+                the symbols replaced by out-of-range values, slot 0's bytes compared with the CPU reference;
+  models        BASELINE config 1 (bls2017, 512 x 256x256) and config 4 (bmshj2018, 128 x 768x512) full
+                compress + decompress, batches pipelined over a CU partition (compression_amd/pipeline.py),
+                every image's strings compared with the CPU reference coder on the model's own symbols;
+  conv          SignalConv2D TFLOP/s per layer shape of config 4;
+  gdn_fwd       BASELINE config 3.
 """
 from __future__ import annotations
 
@@ -61,10 +71,15 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec
 def build_tables(device):
     """192 Gaussian tables through the PRODUCT table builder (HIP pmf_to_quantized_cdf)."""
     pmfs, _ = synthetic.gaussian_pmfs(num_tables=CHANNELS)
-    cdfs = []
-    for p in pmfs:
-        c = tfc.pmf_to_quantized_cdf(torch.from_numpy(p).to(device), PRECISION)
-        cdfs.append(c.cpu().numpy())
+    # PmfToQuantizedCdf takes a rectangular [rows, n] tensor: one call per distinct row length
+    by_len = {}
+    for i, p in enumerate(pmfs):
+        by_len.setdefault(len(p), []).append(i)
+    cdfs = [None] * len(pmfs)
+    for n, rows in by_len.items():
+        c = tfc.pmf_to_quantized_cdf(torch.from_numpy(np.stack([pmfs[i] for i in rows])).to(device), PRECISION)
+        for i, row in zip(rows, c.cpu().numpy()):
+            cdfs[i] = row
     return synthetic.assemble_lookup(cdfs, PRECISION, overflow=True)
 
 
@@ -339,180 +354,319 @@ def model_conv_flops(workload, batch, hw):
     return batch * (2 * per + 3 * hyper)
 
 
-def model_workload(args, world, rank, device, distributed):
-    """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5).
-    Multi-GPU (config 5): the batch is sharded, rank 0's weights and range-coding tables are broadcast
-    once (tables are shared, never rebuilt per rank: continuous_base.py:175-184), and every step ends with
-    the variable-length gather of the coded strings."""
-    import torch.distributed as dist
-    from compression_amd import parallel
-    from compression_amd.ops import gen_ops
-    dtype = torch.bfloat16 if args.model_dtype == "bf16" else torch.float32
-    torch.manual_seed(0)
-    if args.workload == "bls2017":
-        model = tfc.models.BLS2017Model(num_filters=192, compute_dtype=dtype)
-        batch, hw = args.batch or 512, (256, 256)
-    else:
-        model = tfc.models.BMSHJ2018Model(num_filters=192, compute_dtype=dtype)
-        batch, hw = args.batch or 128, (512, 768)
-    model = model.to(device).init_compression()
-    if distributed:
-        parallel.broadcast_tables(model)
-    base = torch.from_numpy(synthetic.lowpass_images(8, hw[0], hw[1], seed=2 + rank)).to(device)
-    x = base.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
-
-    def step():
-        out = model.compress(x)
-        gathered = None
-        if distributed:
-            # the coded strings of the whole batch on every rank: lengths, then padded bytes (two all-gathers)
-            gathered = []
-            for arr in out:
-                if isinstance(arr, np.ndarray) and arr.dtype == object:
-                    blob, off, _ = gen_ops.blob_from_strings(arr)
-                    gathered.append(parallel.gather_encoded(torch.from_numpy(blob).to(device),
-                                                            torch.from_numpy(off).to(device)))
-        return out, model.decompress(*out), gathered
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    _lib.lib().tfc_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, x_hat, gathered = step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kern = {name: profile_query(name) for name in ("enc_kernel", "dec_kernel", "conv2d", "gdn_forward")}
-    _lib.lib().tfc_profile_enable(0)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert x_hat.shape == x.shape
-    strings = [arr for arr in out if isinstance(arr, np.ndarray) and arr.dtype == object]
-    nbytes = sum(len(bytes(s)) for arr in strings for s in arr.reshape(-1))
-    if gathered:
-        assert int(gathered[0][1][-1]) >= sum(len(bytes(s)) for s in strings[0].reshape(-1))
-    if rank == 0:
-        pixels = world * batch * hw[0] * hw[1]
-        ms = {k: (v[0] / max(v[1], 1), v[1] // max(args.steps, 1)) for k, v in kern.items()}
-        conv_ms_step = kern["conv2d"][0] / max(args.steps, 1)
-        flops = model_conv_flops(args.workload, batch, hw)
-        conv_tflops = flops / 1e12 / (conv_ms_step / 1e3) if conv_ms_step > 0 else 0.0
-        coder_ms_step = (kern["enc_kernel"][0] + kern["dec_kernel"][0]) / max(args.steps, 1)
-        symbols = sum(int(np.prod(a.shape)) for a in strings)      # streams; symbols per stream from the model
-        line = {
-            "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
-            "value": round(pixels / 1e6 / (elapsed / args.steps), 2), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.model_dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload} compress+decompress, {batch} images of "
-                                   f"{hw[1]}x{hw[0]} per GPU, 192 filters, random-init weights",
-                       "parallelism": f"batch-sharded x{world}",
-                       "collectives": "broadcast of weights + tables at setup; per step all-gather of string "
-                                      "lengths and padded bytes (RCCL)" if distributed else "none"},
-            "bits_per_pixel": round(8.0 * nbytes / (batch * hw[0] * hw[1]), 4),
-            "kernels_ms_per_step": {"conv2d": round(conv_ms_step, 3), "coder": round(coder_ms_step, 3),
-                                    "gdn_forward": round(kern["gdn_forward"][0] / max(args.steps, 1), 3)},
-            "roofline": {"bound": "mfma", "kernel": "conv2d (all SignalConv2D launches of a step)",
-                         "achieved": round(conv_tflops, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(conv_tflops / 2500.0, 4), "traffic": None,
-                         "algorithmic_flops": int(flops),
-                         "note": "dominant GPU kernel family of the step; the step itself is bounded by the host "
-                                 "glue between launches and by the coder's serial chains (kernels_ms_per_step)"},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = model_cpu_baseline(model, x, out, hw, batch)
-        print(json.dumps(line))
-    if distributed:
-        dist.destroy_process_group()
-
-
-def model_cpu_baseline(model, x, out, hw, batch):
-    """The reference's coder (oracle/_ref, or its restatement) on the host cores, on the SAME symbols
-    the model coded: the main latent stream of a bounded sample of the batch.  The transforms have no
-    CPU leg here (the reference's are TensorFlow/Eigen, not installable): the figure is Mpixels/s of the
-    entropy-coding part only.  This and cpu_baseline() are the only places bench.py touches oracle/."""
-    from oracle import oracle
-    lib = oracle.best()
-    _, cores, _ = usable_cores()
-    sample = min(batch, 16)
+def calibrate_hyperprior(model, x, index_mean=20.0, index_std=12.0, latent_std=1.0, side_std=3.0):
+    """Random-init weights leave bmshj2018's scale indexes all 0 (one 4-symbol table): not the workload
+    the indexed coder is for.  Rescales three linear layers so that, on the bench images, the main latent has
+    standard deviation `latent_std`, the side latent `side_std`, and the hyper-synthesis output (the scale
+    index field) mean `index_mean` / standard deviation `index_std` before clipping to [0, 63] — a field
+    that varies in space, covers the 64 tables and puts most of its mass on the narrow ones, as a trained
+    model's does.  Returns the histogram of the indexes actually coded."""
     with torch.no_grad():
-        y = model.analysis_transform(x[:sample].to(model.compute_dtype))
+        xs = x[:8].to(model.compute_dtype)
+        def scale_layer(layer, f):
+            for name in ("kernel_real", "kernel_imag", "kernel_variable", "bias"):
+                t = getattr(layer, name, None)
+                if t is not None:
+                    t.mul_(f)
+        y = model.analysis_transform(xs)
+        scale_layer(model.analysis_transform.layer_3, latent_std / float(y.float().std()))
+        y = model.analysis_transform(xs)
+        z = model.hyper_analysis_transform(torch.abs(y))
+        scale_layer(model.hyper_analysis_transform.layer_2, side_std / float(z.float().std()))
+        z = model.hyper_analysis_transform(torch.abs(y))
+        z_hat = model.side_entropy_model.quantize(z)
+        out = model.hyper_synthesis_transform(z_hat).float()
+        last = model.hyper_synthesis_transform.layer_2
+        g = index_std / float(out.std())
+        m = float(out.mean())
+        last.kernel_variable.mul_(g)
+        last.bias.mul_(g).add_(index_mean - m * g)
+        idx = model.hyper_synthesis_transform(z_hat)[:, :y.shape[1], :y.shape[2], :]
+        flat = model.entropy_model._flatten_indexes(model.entropy_model._normalize_indexes(idx))
+        hist = torch.bincount(flat.reshape(-1).long(), minlength=model.num_scales).cpu().numpy()
+    return hist
+
+
+def model_symbols(model, x):
+    """The symbols (and table indexes) the model's coder sees for images `x`, on the host: inputs of the CPU
+    reference coder."""
+    with torch.no_grad():
+        y = model.analysis_transform(x.to(model.compute_dtype))
+        n = x.shape[0]
         if hasattr(model, "side_entropy_model"):
             z = model.hyper_analysis_transform(torch.abs(y))
             z_hat = model.side_entropy_model.quantize(z)
             idx = model.hyper_synthesis_transform(z_hat)[:, :y.shape[1], :y.shape[2], :]
             em = model.entropy_model
-            flat = em._flatten_indexes(em._normalize_indexes(idx)).reshape(sample, -1).cpu().numpy()
-            sym = (torch.round(y.float()).to(torch.int32).reshape(sample, -1).cpu().numpy()
-                   - em.cdf_offset.numpy()[flat])
-            lookup = em.cdf.numpy()
-        else:
-            em = model.entropy_model
-            off = em.quantization_offset
-            yq = torch.round(y.float() - off.to(y.device).float() if off is not None else y.float()).to(torch.int32)
-            sym = yq.reshape(sample, -1).cpu().numpy() - np.tile(em.cdf_offset.numpy(), yq[0].numel() // em.cdf_offset.numel())
-            flat = None
-            lookup = em.cdf.numpy()
-    t0 = time.perf_counter()
-    strings, _, _ = lib.encode(lookup, sym, index=flat, threads=cores)
-    t1 = time.perf_counter()
-    dec, ok = lib.decode(lookup, strings, sym.shape[1], index=flat, threads=cores)
-    t2 = time.perf_counter()
-    assert ok.all() and (dec == sym).all()
-    mine = out[0].reshape(-1)[:sample]
-    return {"value": round(sample * hw[0] * hw[1] / 1e6 / (t2 - t0), 2), "unit": "Mpixels/s", "cores": cores,
+            flat = em._flatten_indexes(em._normalize_indexes(idx)).reshape(n, -1)
+            sym = torch.round(y.float()).to(torch.int32).reshape(n, -1) - em.cdf_offset.to(y.device)[flat.long()]
+            return em.cdf.cpu().numpy(), sym.cpu().numpy(), flat.cpu().numpy()
+        em = model.entropy_model
+        off = em.quantization_offset
+        yq = torch.round(y.float() - off.to(y.device).float() if off is not None else y.float()).to(torch.int32)
+        sym = yq.reshape(n, -1) - em.cdf_offset.to(y.device).repeat(yq[0].numel() // em.cdf_offset.numel())
+        return em.cdf.cpu().numpy(), sym.cpu().numpy(), None
+
+
+def model_cpu_baseline(model, x, strings, hw, chunk=32):
+    """The reference's coder (oracle/_ref, or its restatement) on the host cores, on the SAME symbols the
+    model coded — the main latent stream of EVERY image of the batch, byte-compared with the GPU's strings.
+    The transforms have no CPU leg here (the reference's are TensorFlow/Eigen, not installable): the figure
+    is Mpixels/s of the entropy-coding part only.  This and cpu_baseline() are the only places bench.py
+    touches oracle/."""
+    from oracle import oracle
+    lib = oracle.best()
+    _, cores, _ = usable_cores()
+    batch = x.shape[0]
+    enc_s = dec_s = 0.0
+    same = True
+    escapes = total = 0
+    mine = [bytes(s) for s in strings.reshape(-1)]
+    for b0 in range(0, batch, chunk):
+        lookup, sym, flat = model_symbols(model, x[b0:b0 + chunk])
+        t0 = time.perf_counter()
+        cpu_strings, _, _ = lib.encode(lookup, sym, index=flat, threads=cores)
+        t1 = time.perf_counter()
+        dec, ok = lib.decode(lookup, cpu_strings, sym.shape[1], index=flat, threads=cores)
+        t2 = time.perf_counter()
+        assert ok.all() and (dec == sym).all()
+        enc_s += t1 - t0
+        dec_s += t2 - t1
+        same &= mine[b0:b0 + len(cpu_strings)] == cpu_strings
+        total += sym.size
+    return {"value": round(batch * hw[0] * hw[1] / 1e6 / (enc_s + dec_s), 2), "unit": "Mpixels/s", "cores": cores,
             "kind": lib.kind,
-            "sample": f"main latent stream of {sample} of the {batch} images (the symbols the model coded), "
-                      "range encode + decode only, one call each",
-            "encode_ms": round(1e3 * (t1 - t0), 2), "decode_ms": round(1e3 * (t2 - t1), 2),
-            "bytes_identical_to_gpu": bool([bytes(s) for s in mine] == strings)}
+            "sample": f"main latent stream of all {batch} images (the symbols the model coded), range encode + "
+                      f"decode only, {chunk} images per call",
+            "encode_ms": round(1e3 * enc_s, 2), "decode_ms": round(1e3 * dec_s, 2),
+            "symbols": int(total),
+            "bytes_identical_to_gpu": bool(same), "images_compared": batch}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=64,
-                    help="independent steps per launch group (one host thread); 1 = serial")
-    ap.add_argument("--escape-fraction", type=float, default=0.0)
-    ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
-                    help="c2 (default, the headline): coder round trip; bls2017 / bmshj2018: "
-                         "full model compress+decompress (informational)")
-    ap.add_argument("--batch", type=int, default=0, help="images per GPU for the model workloads")
-    ap.add_argument("--model-dtype", default="bf16", choices=["bf16", "f32"])
-    args = ap.parse_args()
+def make_model(workload, dtype, device, batch, rank=0, calibrate=True):
+    torch.manual_seed(0)
+    if workload == "bls2017":
+        model = tfc.models.BLS2017Model(num_filters=192, compute_dtype=dtype)
+        batch, hw = batch or 512, (256, 256)
+    else:
+        model = tfc.models.BMSHJ2018Model(num_filters=192, compute_dtype=dtype)
+        batch, hw = batch or 128, (512, 768)
+    model = model.to(device).init_compression()
+    base = torch.from_numpy(synthetic.lowpass_images(8, hw[0], hw[1], seed=2 + rank)).to(device)
+    x = base.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
+    hist = None
+    if workload == "bmshj2018" and calibrate:
+        hist = calibrate_hyperprior(model, x)
+    return model, x, batch, hw, hist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+
+class StepRecord:
+    """What one model step in flight keeps alive until it is retired."""
+    def __init__(self, out, x_hat, oks, end):
+        self.out, self.x_hat, self.oks, self.end = out, x_hat, oks, end
+        self.strings = None
+
+
+def run_model_steps(model, x, steps, lanes, fetch=True):
+    """`steps` compress + decompress passes over `x`, step k on lanes[k % len(lanes)], all enqueued by this
+    one thread with nothing read back inside a step; a lane's previous step is retired (host waits for its
+    end event, fetches its strings and sanity flags) before the lane is reused — while the other lanes'
+    steps keep the GPU busy.  Returns (seconds, last record)."""
+    main = torch.cuda.current_stream()
+    pending = [None] * len(lanes)
+    last = None
+
+    def retire(rec):
+        if rec.end is not None:
+            rec.end.synchronize()
+        if fetch:
+            rec.strings = [tfc.fetch_strings(h) for h in rec.out if isinstance(h, tfc.gen_ops.EncoderHandle)]
+            for ok in rec.oks:
+                assert bool(ok.cpu().all()), "EntropyDecodeFinalize reported a failed stream"
+        return rec
+
+    t0 = time.perf_counter()
+    for k in range(steps):
+        slot = k % len(lanes)
+        if pending[slot] is not None:
+            last = retire(pending[slot])
+        lane = lanes[slot].begin(main)
+        out = model.compress(x, device_result=True, lane=lane)
+        x_hat, oks = model.decompress(*out, defer_sanity=True, lane=lane)
+        pending[slot] = StepRecord(out, x_hat, oks, lane.end_event())
+    order = [(k % len(lanes)) for k in range(max(0, steps - len(lanes)), steps)]
+    for slot in order:
+        if pending[slot] is not None:
+            last = retire(pending[slot])
+            pending[slot] = None
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, last
+
+
+def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=2, coder_cus=32,
+                cpu=True, rank=0, world=1, distributed=False):
+    """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5)."""
+    import torch.distributed as dist
+    from compression_amd import parallel, pipeline
+    from compression_amd.ops import gen_ops
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    model, x, batch, hw, hist = make_model(workload, dtype, device, batch, rank)
+    if distributed:
+        parallel.broadcast_tables(model)
+    side = torch.cuda.Stream(device=device)          # never the null stream: it would serialise the masked streams
+    with torch.cuda.stream(side):
+        # (a) a lone step at a time on the whole chip, per-kernel split (nothing else resident)
+        inline = [pipeline.inline_lane()]
+        run_model_steps(model, x, max(warmup, 1), inline)
+        _lib.lib().tfc_profile_enable(1)
+        lone_steps = 2
+        lone_s, rec = run_model_steps(model, x, lone_steps, inline)
+        kern = {name: profile_query(name) for name in ("enc_kernel", "dec_kernel", "conv2d", "gdn_forward")}
+        _lib.lib().tfc_profile_enable(0)
+        # (b) the timed region: `depth` steps in flight over the CU partition
+        part = pipeline.CoderPartition(coder_cus=coder_cus, depth=depth, device=device) if depth > 1 else None
+        lanes = part.lanes if part else inline
+        run_model_steps(model, x, max(warmup, len(lanes)), lanes)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed, rec = run_model_steps(model, x, steps, lanes)
+        gathered = None
+        if distributed:
+            # the coded strings of the whole batch on every rank: lengths, then padded bytes (two all-gathers)
+            gathered = []
+            for h in rec.out:
+                if isinstance(h, gen_ops.EncoderHandle):
+                    blob, off = gen_ops.device_strings(h)
+                    gathered.append(parallel.gather_encoded(blob[:int(off[-1])], off))
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert rec.x_hat.shape == x.shape
+        strings = rec.strings
+        nbytes = sum(len(bytes(s)) for arr in strings for s in arr.reshape(-1))
+        if gathered:
+            assert int(gathered[0][1][-1]) >= sum(len(bytes(s)) for s in strings[0].reshape(-1))
+        res = None
+        if rank == 0:
+            pixels = world * batch * hw[0] * hw[1]
+            conv_ms = kern["conv2d"][0] / lone_steps
+            flops = model_conv_flops(workload, batch, hw)
+            conv_tflops = flops / 1e12 / (conv_ms / 1e3) if conv_ms > 0 else 0.0
+            res = {
+                "value": round(pixels / 1e6 / (elapsed / steps), 2), "unit": "Mpixels/s",
+                "ms_per_step": round(1e3 * elapsed / steps, 3), "steps": steps, "warmup": warmup,
+                "workload": f"{workload} compress+decompress, {batch} images of {hw[1]}x{hw[0]} per GPU, 192 filters, "
+                            f"random-init weights" + (", hyperprior calibrated (scale_index_histogram)" if hist is not None else ""),
+                "dtype": dtype_name,
+                "steps_in_flight": len(lanes),
+                "cu_partition": ({"coder_cus": part.coder_cus, "transform_cus": part.total_cus - part.coder_cus}
+                                 if part else None),
+                "strings_fetched_to_host_in_timed_region": True,
+                "lone_step": {"ms_per_step": round(1e3 * lone_s / lone_steps, 3),
+                              "mpixels_s": round(batch * hw[0] * hw[1] / 1e6 / (lone_s / lone_steps), 2),
+                              "kernels_ms": {"conv2d": round(conv_ms, 3),
+                                             "coder_encode": round(kern["enc_kernel"][0] / lone_steps, 3),
+                                             "coder_decode": round(kern["dec_kernel"][0] / lone_steps, 3),
+                                             "gdn_forward": round(kern["gdn_forward"][0] / lone_steps, 3)},
+                              "note": "one step at a time, whole chip, nothing else resident: where the kernel split is measured"},
+                "bits_per_pixel": round(8.0 * nbytes / (batch * hw[0] * hw[1]), 4),
+                "roofline": {"bound": "mfma", "kernel": "conv2d (all SignalConv2D launches of a step)",
+                             "achieved": round(conv_tflops, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                             "frac": round(conv_tflops / 2500.0, 4), "traffic": None,
+                             "algorithmic_flops": int(flops)},
+            }
+            if hist is not None:
+                res["scale_index_histogram"] = [int(v) for v in hist]
+            if cpu and world == 1:
+                res["cpu_baseline"] = model_cpu_baseline(model, x, strings[0], hw)
+                assert res["cpu_baseline"]["bytes_identical_to_gpu"], "GPU strings differ from the CPU reference's"
+        del rec
+        if part:
+            part.close()
+    return res
+
+
+def conv_layer_table(device, batch=128):
+    """SignalConv2D per layer shape of BASELINE config 4 (bmshj2018, `batch` images of 768x512, bf16): kernel
+    time between HIP events, 2 M K N FLOP (synthesis on its output grid), fraction of the 2.5 PFLOP/s dense
+    bf16 MFMA peak."""
+    from compression_amd.layers import conv2d_down, conv2d_up
+    C_, dt, H, W = 192, torch.bfloat16, 512, 768
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    k = lambda kh, ci, co: (torch.randn(kh, kh, ci, co, generator=gen) / (kh * kh * ci) ** 0.5).to(device)
+    layers = [
+        ("analysis 5x5 3->192 /2", conv2d_down, (H, W, 3), 5, 3, C_, 2, False),
+        ("analysis 5x5 192->192 /2 @384x256", conv2d_down, (H // 2, W // 2, C_), 5, C_, C_, 2, False),
+        ("analysis 5x5 192->192 /2 @192x128", conv2d_down, (H // 4, W // 4, C_), 5, C_, C_, 2, False),
+        ("analysis 5x5 192->192 /2 @96x64", conv2d_down, (H // 8, W // 8, C_), 5, C_, C_, 2, False),
+        ("synthesis 5x5 192->192 x2 @48x32", conv2d_up, (H // 16, W // 16, C_), 5, C_, C_, 2, True),
+        ("synthesis 5x5 192->192 x2 @96x64", conv2d_up, (H // 8, W // 8, C_), 5, C_, C_, 2, True),
+        ("synthesis 5x5 192->192 x2 @192x128", conv2d_up, (H // 4, W // 4, C_), 5, C_, C_, 2, True),
+        ("synthesis 5x5 192->3 x2 @384x256", conv2d_up, (H // 2, W // 2, C_), 5, C_, 3, 2, True),
+    ]
+    rows = []
+    for name, fn, shp, kh, ci, co, stride, up in layers:
+        x = torch.randn((batch,) + shp, device=device).to(dt)
+        w = k(kh, ci, co)
+        b = torch.zeros(co, device=device)
+        for _ in range(2):
+            fn(x, w, b, stride)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record()
+        for _ in range(reps):
+            fn(x, w, b, stride)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out_pix = batch * shp[0] * shp[1] * (stride * stride if up else 1.0 / (stride * stride))
+        flops = 2.0 * out_pix * kh * kh * ci * co / (stride * stride if up else 1)
+        tf = flops / 1e12 / (ms / 1e3)
+        rows.append({"layer": name, "ms": round(ms, 3), "tflops": round(tf, 1), "frac_of_2500": round(tf / 2500.0, 4)})
+        del x
+    return {"workload": f"SignalConv2D layer shapes of bmshj2018 at {batch} x 768x512, bf16", "layers": rows}
+
+
+def model_workload(args, world, rank, device, distributed):
+    """`--workload bls2017|bmshj2018`: the model step as the headline line (BASELINE configs 1/4/5)."""
+    import torch.distributed as dist
+    res = model_bench(args.workload, args.model_dtype, device, batch=args.batch, steps=args.steps,
+                      warmup=args.warmup, depth=max(1, args.model_depth), coder_cus=args.coder_cus,
+                      cpu=not args.no_cpu_baseline, rank=rank, world=world, distributed=distributed)
+    if rank == 0:
+        line = {
+            "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
+            "value": res["value"], "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.model_dtype, "data": "synthetic",
+            "config": {"workload": res["workload"], "parallelism": f"batch-sharded x{world}",
+                       "steps_in_flight": res["steps_in_flight"], "cu_partition": res["cu_partition"],
+                       "collectives": "broadcast of weights + tables at setup; per step all-gather of string "
+                                      "lengths and padded bytes (RCCL)" if distributed else "none"},
+        }
+        for key in ("bits_per_pixel", "lone_step", "roofline", "scale_index_histogram", "cpu_baseline"):
+            if key in res:
+                line[key] = res[key]
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_fraction, steps, inflight,
+           serial=True):
+    """The coder round trip at BASELINE config 2 with `escape_fraction` of the symbols out of range: exactly
+    `steps` steps, `inflight` per launch group.  Returns the measurements (every rank) — rank 0 formats."""
+    import hashlib
     if distributed:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
-    if args.workload != "c2":
-        return model_workload(args, world, rank, device, distributed)
-
-    lookup = build_tables(device)
-    lookup_t = torch.from_numpy(lookup)            # tables are uploaded once (cached per tensor)
-    inflight = max(1, min(args.inflight, args.steps))
+    inflight = max(1, min(inflight, steps))
     # every slot in flight codes its own tensor (inputs resident in HBM)
-    slots = [sample_symbols_device(lookup, 1000 * rank + k, device, args.escape_fraction) for k in range(inflight)]
+    slots = [sample_symbols_device(lookup, 1000 * rank + k, device, escape_fraction) for k in range(inflight)]
     # one stream: the launches of a group fill the chip on their own (a decoder workgroup takes a whole
     # CU's LDS), groups on different streams would only queue behind each other's workgroups
     side_streams = [torch.cuda.Stream(device=device)]
@@ -555,58 +709,145 @@ def main():
             assert torch.equal(dec_r.reshape(STREAMS, ELEMS), slots[slot]), "decode(encode(x)) != x"
 
     flight_mode = "throughput" if inflight > 1 else "latency"
-    _, res, _ = run_steps(max(args.warmup, 1), 1, "latency")
+    _, res, _ = run_steps(max(min(args.warmup, 3), 1), 1, "latency")
     verify(res)
     if inflight > 1:
         # the timed pattern once, untimed: primes both streams and the stream-ordered memory pool with
         # exactly the buffers the timed region asks for (a fresh 50-100 MB driver allocation per buffer
         # would otherwise be timed instead of the coder)
-        _, res, _ = run_steps(args.steps, inflight, flight_mode)
+        _, res, _ = run_steps(steps, inflight, flight_mode)
         verify(res)
     del res
     torch.cuda.synchronize()
 
-    # serial pass: one step at a time, latency-mode handles; per-kernel durations with the GPU to one launch
+    m = {"inflight": inflight, "steps": steps, "escape_fraction": escape_fraction}
+    if serial:
+        # one batch at a time (config 2 as literally written), per-kernel durations with the GPU to one launch
+        for mode, key in (("latency", "serial"), ("throughput", "serial_lanes")):
+            _lib.lib().tfc_profile_enable(1)
+            n = min(steps, 5 if mode == "latency" else 2)
+            sec, results, _ = run_steps(n, 1, mode)
+            enc_ms, enc_n = profile_query("enc_kernel")
+            dec_ms, dec_n = profile_query("dec_kernel")
+            _lib.lib().tfc_profile_enable(0)
+            verify(results)
+            del results
+            m[key] = {"seconds": sec, "steps": n, "enc_ms": enc_ms / max(enc_n, 1), "dec_ms": dec_ms / max(dec_n, 1)}
+    # the timed region: exactly `steps` steps
     _lib.lib().tfc_profile_enable(1)
-    serial_steps = min(args.steps, 5) if inflight > 1 else args.steps
-    serial_elapsed, results, _ = run_steps(serial_steps, 1, "latency")
-    enc_ms, enc_n = profile_query("enc_kernel")
-    dec_ms, dec_n = profile_query("dec_kernel")
+    elapsed, results, t_enqueued = run_steps(steps, inflight, flight_mode)
+    cenc_ms, cenc_n = profile_query("enc_kernel")
+    cdec_ms, cdec_n = profile_query("dec_kernel")
     _lib.lib().tfc_profile_enable(0)
     verify(results)
-    # the timed region: exactly --steps steps
-    if inflight > 1:
-        del results
-        _lib.lib().tfc_profile_enable(1)
-        elapsed, results, t_enqueued = run_steps(args.steps, inflight, flight_mode)
-        cenc_ms, cenc_n = profile_query("enc_kernel")
-        cdec_ms, cdec_n = profile_query("dec_kernel")
-        _lib.lib().tfc_profile_enable(0)
-        verify(results)
-    else:
-        elapsed, cenc_ms, cenc_n, cdec_ms, cdec_n, t_enqueued = serial_elapsed, enc_ms, enc_n, dec_ms, dec_n, 0.0
+    elapsed_local = elapsed
     if distributed:
-        t = torch.tensor([elapsed, serial_elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, serial_elapsed = float(t[0].item()), float(t[1].item())
+        elapsed = float(t[0].item())
     # slot 0's bytes, for the comparison with the CPU reference
-    import hashlib
     h0 = next(r[0] for r in results if r[4] == 0)
     strings = tfc.entropy_encode_finalize(h0)
     blob0 = h0.blob.cpu().numpy()
     offs0 = h0.offsets.cpu().numpy().astype(np.int64)
-    total_bytes = int(offs0[-1])
     del strings, results
+    m.update(elapsed=elapsed, elapsed_local=elapsed_local, t_enqueued=t_enqueued, enc_tr=cenc_ms / max(cenc_n, 1), dec_tr=cdec_ms / max(cdec_n, 1),
+             total_bytes=int(offs0[-1]), blob_sha=hashlib.sha256(blob0.tobytes()).hexdigest(),
+             offs_sha=hashlib.sha256(offs0.tobytes()).hexdigest(), slot0=slots[0])
+    return m
+
+
+def escape_object(args, lookup, lookup_t, device, fraction, cpu_value):
+    """The --steps command again with `fraction` of the symbols out of range (Elias-gamma escape codes):
+    throughput, and slot 0's bytes against the CPU reference coder's."""
+    m = c2_run(args, lookup, lookup_t, device, 1, 0, False, fraction, args.steps, args.inflight, serial=False)
+    value = STREAMS * PIXELS_PER_STREAM / 1e6 / (m["elapsed"] / args.steps)
+    obj = {"escape_fraction": fraction, "value": round(value, 2), "unit": "Mpixels/s",
+           "ms_per_step": round(1e3 * m["elapsed"] / args.steps, 4), "steps": args.steps,
+           "steps_in_flight": m["inflight"],
+           "bits_per_symbol": round(8.0 * m["total_bytes"] / (STREAMS * ELEMS), 4),
+           "kernels_ms_in_flight": {"enc_kernel": round(m["enc_tr"], 4), "dec_kernel": round(m["dec_tr"], 4)}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        import hashlib
+        lib = oracle.best()
+        _, cores, _ = usable_cores()
+        value_h = m["slot0"].cpu().numpy()
+        enc, dec, total, ok = lib.bench_roundtrip(lookup, value_h, threads=cores, reps=4)
+        assert ok
+        rt = float(np.median((enc + dec)[1:]))
+        _, cpu_blob, cpu_offs = lib.encode(lookup, value_h, threads=cores)
+        same = (hashlib.sha256(np.ascontiguousarray(cpu_blob).tobytes()).hexdigest() == m["blob_sha"] and
+                hashlib.sha256(np.ascontiguousarray(cpu_offs, np.int64).tobytes()).hexdigest() == m["offs_sha"])
+        cpu_mpix = STREAMS * PIXELS_PER_STREAM / 1e6 / rt
+        obj["cpu_baseline"] = {"value": round(cpu_mpix, 2), "unit": "Mpixels/s", "cores": cores, "kind": lib.kind,
+                               "sample": "the same 512-stream batch (slot 0), 4 repetitions (first discarded)"}
+        obj["speedup_vs_cpu_baseline"] = round(value / cpu_mpix, 2)
+        obj["bytes_identical_to_gpu"] = bool(same)
+        assert same, "GPU bytes differ from the CPU reference's (escape run)"
+    return obj
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline measurement (no single_batch / escapes / models / conv sub-objects)")
+    ap.add_argument("--inflight", type=int, default=64,
+                    help="independent steps per launch group (one host thread); 1 = serial")
+    ap.add_argument("--escape-fraction", type=float, default=0.0)
+    ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
+                    help="c2 (default, the headline): coder round trip; bls2017 / bmshj2018: "
+                         "full model compress+decompress as the headline line (configs 1/4/5)")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU for the model workloads")
+    ap.add_argument("--model-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model-depth", type=int, default=2, help="model steps in flight (1: one at a time, no CU partition)")
+    ap.add_argument("--coder-cus", type=int, default=32, help="compute units reserved for the coder streams of a model pipeline")
+    ap.add_argument("--model-steps", type=int, default=6, help="timed steps of the `models` sub-objects")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    if args.workload != "c2":
+        return model_workload(args, world, rank, device, distributed)
+
+    lookup = build_tables(device)
+    lookup_t = torch.from_numpy(lookup)            # tables are uploaded once (cached per tensor)
+    extras = not args.no_extras and world == 1
+    m = c2_run(args, lookup, lookup_t, device, world, rank, distributed, args.escape_fraction, args.steps,
+               args.inflight, serial=True)
+    inflight, elapsed, total_bytes = m["inflight"], m["elapsed"], m["total_bytes"]
+    per_rank = None
+    if distributed:
+        # every rank's own rate and byte total, so that the N = 1 SCALE value can be checked against BENCH
+        mine = torch.tensor([STREAMS * PIXELS_PER_STREAM / 1e6 / (m["elapsed_local"] / args.steps), float(total_bytes)],
+                            dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"mpixels_s": [round(float(t[0]), 2) for t in allr],
+                    "slot0_bytes": [int(t[1]) for t in allr],
+                    "note": "each rank's own rate over its own clock (value uses the slowest rank's) and the byte total "
+                            "of its slot-0 batch; ranks code differently seeded batches"}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         pixels_all = world * STREAMS * PIXELS_PER_STREAM
         value_mpix = pixels_all / 1e6 / (elapsed / args.steps)
         symbols = STREAMS * ELEMS
-        enc_avg = enc_ms / max(enc_n, 1)          # serial pass: a launch has the GPU to itself
-        dec_avg = dec_ms / max(dec_n, 1)
-        enc_tr = cenc_ms / max(cenc_n, 1)         # timed region (launches of other steps co-resident)
-        dec_tr = cdec_ms / max(cdec_n, 1)
+        enc_avg, dec_avg = m["serial"]["enc_ms"], m["serial"]["dec_ms"]     # a launch has the GPU to itself
+        enc_tr, dec_tr = m["enc_tr"], m["dec_tr"]                           # timed region
         # algorithmic bytes per launch (SURVEY.md §8d): encode reads 4 B/symbol and
         # writes the code bytes; decode reads the code bytes and writes 4 B/symbol.
         alg_dec = 4 * symbols + total_bytes
@@ -619,6 +860,7 @@ def main():
         achieved = dom_bytes / 1e9 / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         dom_symbol = {("dec_kernel", True): "dec_lanes_kernel", ("enc_kernel", True): "enc_lanes_kernel",
                       ("dec_kernel", False): "dec_fast_kernel", ("enc_kernel", False): "enc_fast_kernel"}[(dom, lanes)]
+        ser, ser_l = m["serial"], m["serial_lanes"]
         out = {
             "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
             "value": round(value_mpix, 2),
@@ -646,18 +888,30 @@ def main():
                 "distinct_inputs": inflight,
                 "library_mode": "TFC_MODE_THROUGHPUT handles (one code stream per lane), deferred errors, "
                                 "device finalize" if lanes else "TFC_MODE_LATENCY handles (one wave per stream)",
+                "value_depends_on_steps": "a launch takes the same time for 1 ... ~128 batches (one wave per SIMD), so "
+                                          "`value` grows with --steps; `single_batch` is one batch at a time",
             },
             "bits_per_pixel": round(8.0 * total_bytes / (STREAMS * PIXELS_PER_STREAM), 5),
             "bits_per_symbol": round(8.0 * total_bytes / symbols, 4),
             "gsymbols_per_s_roundtrip": round(world * symbols / 1e9 / (elapsed / args.steps), 3),
-            "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 4),
+            "host_enqueue_ms_per_step": round(1e3 * m["t_enqueued"] / args.steps, 4),
             "kernels_ms": {"enc_kernel": round(enc_avg, 4), "dec_kernel": round(dec_avg, 4),
                            "note": "latency-mode kernels, one launch at a time"},
-            "kernels_ms_in_flight": {"enc_kernel": round(cenc_ms / max(cenc_n, 1), 4),
-                                     "dec_kernel": round(cdec_ms / max(cdec_n, 1), 4)},
-            "serial": {"ms_per_step": round(1e3 * serial_elapsed / serial_steps, 4),
-                       "mpixels_s": round(pixels_all / 1e6 / (serial_elapsed / serial_steps), 2),
-                       "steps": serial_steps, "library_mode": "TFC_MODE_LATENCY"},
+            "kernels_ms_in_flight": {"enc_kernel": round(enc_tr, 4), "dec_kernel": round(dec_tr, 4)},
+            "single_batch": {
+                "note": "BASELINE config 2 as literally written: ONE 512-stream batch at a time, host waits for every step",
+                "latency_mode": {"ms_per_step": round(1e3 * ser["seconds"] / ser["steps"], 4),
+                                 "mpixels_s": round(pixels_all / 1e6 / (ser["seconds"] / ser["steps"]), 2),
+                                 "enc_kernel_ms": round(ser["enc_ms"], 4), "dec_kernel_ms": round(ser["dec_ms"], 4),
+                                 "kernels": "one wave per stream"},
+                "throughput_mode": {"ms_per_step": round(1e3 * ser_l["seconds"] / ser_l["steps"], 4),
+                                    "mpixels_s": round(pixels_all / 1e6 / (ser_l["seconds"] / ser_l["steps"]), 2),
+                                    "enc_kernel_ms": round(ser_l["enc_ms"], 4), "dec_kernel_ms": round(ser_l["dec_ms"], 4),
+                                    "kernels": "one lane per stream"},
+            },
+            "serial": {"ms_per_step": round(1e3 * ser["seconds"] / ser["steps"], 4),
+                       "mpixels_s": round(pixels_all / 1e6 / (ser["seconds"] / ser["steps"]), 2),
+                       "steps": ser["steps"], "library_mode": "TFC_MODE_LATENCY"},
             "roofline": {
                 "bound": "hbm", "kernel": dom_symbol, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -674,17 +928,37 @@ def main():
                 "path_gbytes_s_in_flight": round((alg_enc + alg_dec) * args.steps / 1e9 / elapsed, 2),
             },
         }
+        if per_rank:
+            out["per_rank"] = per_rank
         out["valu_issue_bound"] = valu_issue_floor(
             1e3 * elapsed / args.steps, ("enc_lanes_kernel", "dec_lanes_kernel") if lanes else ("enc_fast_kernel", "dec_fast_kernel"),
             jobs_per_launch)
         if world == 1:
             out["gdn_fwd"] = gdn_forward_bandwidth(device)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(lookup, slots[0].cpu().numpy(),
-                                               hashlib.sha256(blob0.tobytes()).hexdigest(),
-                                               hashlib.sha256(offs0.tobytes()).hexdigest())
+            out["cpu_baseline"] = cpu_baseline(lookup, m["slot0"].cpu().numpy(), m["blob_sha"], m["offs_sha"])
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+            out["single_batch"]["latency_mode"]["speedup_vs_cpu_baseline"] = round(
+                out["single_batch"]["latency_mode"]["mpixels_s"] / out["cpu_baseline"]["value"], 2)
+            out["single_batch"]["throughput_mode"]["speedup_vs_cpu_baseline"] = round(
+                out["single_batch"]["throughput_mode"]["mpixels_s"] / out["cpu_baseline"]["value"], 2)
             assert out["cpu_baseline"]["bytes_identical_to_gpu"], "GPU bytes differ from the CPU reference's"
+        del m
+        if extras:
+            torch.set_num_threads(1)
+            if args.escape_fraction == 0.0:
+                out["escapes"] = {}
+                for frac in (0.004, 0.01):
+                    out["escapes"][str(frac)] = escape_object(args, lookup, lookup_t, device, frac,
+                                                              out.get("cpu_baseline", {}).get("value"))
+            torch.cuda.empty_cache()
+            out["conv"] = conv_layer_table(device)
+            out["models"] = {}
+            for name, key in (("bls2017", "c1"), ("bmshj2018", "c4")):
+                torch.cuda.empty_cache()
+                out["models"][key] = model_bench(name, args.model_dtype, device, steps=args.model_steps, warmup=2,
+                                                 depth=max(1, args.model_depth), coder_cus=args.coder_cus,
+                                                 cpu=not args.no_cpu_baseline)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -75,13 +75,18 @@ def stateless_offset_indexes(shape, num_noise_levels):
 
 
 def _offset_indexes_to_offset(offset_indexes, num_noise_levels, dtype):
-    """(k + 1) / (L + 1) - 1/2 (universal.py:44-46)."""
-    return ((offset_indexes.to(torch.float64) + 1) / (num_noise_levels + 1) - 0.5).to(dtype)
+    """(k + 1) / (L + 1) - 1/2 (universal.py:44-46), in the arithmetic type the reference's expression
+    has: float64 for integer offset indexes (TensorFlow's `/` on int32 is a float64 true division), the
+    tensor's own type for floating-point ones (the indexed model casts the drawn levels to the dtype of the
+    caller's indexes, universal.py:40), then cast to `dtype`."""
+    k = offset_indexes if offset_indexes.is_floating_point() else offset_indexes.to(torch.float64)
+    return ((k + 1) / (num_noise_levels + 1) - 0.5).to(dtype)
 
 
 def _range_coding_offsets(num_noise_levels, prior_rank, dtype):
-    """Offsets the tables are built for, shaped [L, 1, ..., 1] (universal.py:54-61)."""
-    k = torch.arange(num_noise_levels, dtype=torch.float64).reshape((-1,) + (1,) * prior_rank)
+    """Offsets the tables are built for, shaped [L, 1, ..., 1] (universal.py:54-61: `tf.range(L, dtype=dtype)`,
+    i.e. the levels AND the arithmetic are in `dtype`, the bottleneck's)."""
+    k = torch.arange(num_noise_levels, dtype=dtype).reshape((-1,) + (1,) * prior_rank)
     return _offset_indexes_to_offset(k, num_noise_levels, dtype)
 
 
@@ -102,7 +107,7 @@ class UniversalBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             raise ValueError("`coding_rank` can't be smaller than `prior_shape`.")
         self.decode_sanity_check = decode_sanity_check
         if self.compression:
-            offset = _range_coding_offsets(self._num_noise_levels, len(self.prior_shape), prior.dtype)
+            offset = _range_coding_offsets(self._num_noise_levels, len(self.prior_shape), self.bottleneck_dtype)
             cdf, cdf_offset = self._build_tables(self.prior, range_coder_precision, offset=offset)
             self._init_compression(cdf, cdf_offset, None)
 
@@ -146,20 +151,28 @@ class UniversalBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         bits = (log_probs.sum(dim=axes) if axes else log_probs) / (-float(np.log(2.0)))
         return perturbed, bits
 
+    def _coder_inputs(self, bottleneck):
+        """(symbols, table indexes) handed to EntropyEncodeIndex for `bottleneck` — universal.py:251-262:
+        symbols = int32(round(bottleneck - offset)) - cdf_offset[indexes]; both int32, shaped like
+        `bottleneck`, on its device."""
+        device = bottleneck.device
+        _, _, broadcast_shape = self._split(bottleneck.shape)
+        indexes, offset = self._compute_indexes_and_offset(broadcast_shape)
+        indexes, offset = indexes.to(device), offset.to(device)
+        symbols = torch.round(bottleneck - offset).to(torch.int32) - self.cdf_offset.to(device)[indexes.long()]
+        return symbols.contiguous(), torch.broadcast_to(indexes, symbols.shape).contiguous()
+
     def compress(self, bottleneck):
         """universal.py:229-266."""
         self._check_compression()
         device = _lib.require_device()
         bottleneck = torch.as_tensor(bottleneck).to(device, self.bottleneck_dtype)
-        batch_shape, _, broadcast_shape = self._split(bottleneck.shape)
-        indexes, offset = self._compute_indexes_and_offset(broadcast_shape)
-        indexes, offset = indexes.to(device), offset.to(device)
-        symbols = torch.round(bottleneck - offset).to(torch.int32) - self.cdf_offset.to(device)[indexes.long()]
+        batch_shape, _, _ = self._split(bottleneck.shape)
+        symbols, indexes = self._coder_inputs(bottleneck)
         handle = gen_ops.create_range_encoder(batch_shape, self.cdf)
         if handle.streams == 0:
             raise ValueError(f"`handle` is empty: handle.shape={list(batch_shape)}")
-        handle = gen_ops.entropy_encode_index(handle, torch.broadcast_to(indexes, symbols.shape).contiguous(),
-                                              symbols.contiguous())
+        handle = gen_ops.entropy_encode_index(handle, indexes, symbols)
         return gen_ops.entropy_encode_finalize(handle)
 
     def decompress(self, strings, broadcast_shape):
@@ -219,7 +232,7 @@ class UniversalIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
                                    indexing="ij")
             indexes = torch.stack(grids, dim=-1)
             self._prior = self._make_prior(indexes)
-            offset = _range_coding_offsets(self._num_noise_levels, len(self.prior.batch_shape), self.prior_dtype)
+            offset = _range_coding_offsets(self._num_noise_levels, len(self.prior.batch_shape), self.bottleneck_dtype)
             cdf, cdf_offset = self._build_tables(self.prior, range_coder_precision, offset=offset)
             self._init_compression(cdf, cdf_offset, None)
 
@@ -276,20 +289,28 @@ class UniversalIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         bits = log_probs.sum(dim=axes) / (-float(np.log(2.0)))
         return perturbed, bits
 
+    def _coder_inputs(self, bottleneck, indexes):
+        """(symbols, flat table indexes) handed to EntropyEncodeIndex — universal.py:557-565: offset level
+        prepended to `indexes`, normalised, flattened; symbols = int32(round(bottleneck - offset)) -
+        cdf_offset[flat]."""
+        device = bottleneck.device
+        indexes = self._normalize_indexes(self._add_offset_indexes(torch.as_tensor(indexes).to(device)))
+        flat = self._flatten_indexes(indexes).contiguous()
+        offset = self._offset_from_indexes(indexes)
+        symbols = torch.round(bottleneck - offset).to(torch.int32) - self.cdf_offset.to(device)[flat.long()]
+        return symbols.contiguous(), flat
+
     def compress(self, bottleneck, indexes):
         """universal.py:534-568."""
         self._check_compression()
         device = _lib.require_device()
         bottleneck = torch.as_tensor(bottleneck).to(device, self.bottleneck_dtype)
-        indexes = self._normalize_indexes(self._add_offset_indexes(torch.as_tensor(indexes).to(device)))
-        flat = self._flatten_indexes(indexes).contiguous()
+        symbols, flat = self._coder_inputs(bottleneck, indexes)
         batch_shape = tuple(flat.shape[:flat.dim() - self.coding_rank])
-        offset = self._offset_from_indexes(indexes)
-        symbols = torch.round(bottleneck - offset).to(torch.int32) - self.cdf_offset.to(device)[flat.long()]
         handle = gen_ops.create_range_encoder(batch_shape, self.cdf)
         if handle.streams == 0:
             raise ValueError(f"`handle` is empty: handle.shape={list(batch_shape)}")
-        handle = gen_ops.entropy_encode_index(handle, flat, symbols.contiguous())
+        handle = gen_ops.entropy_encode_index(handle, flat, symbols)
         return gen_ops.entropy_encode_finalize(handle)
 
     def decompress(self, strings, indexes):

@@ -47,7 +47,8 @@ def _bound(inputs, bound, upper, gradient):
     if isinstance(bound, torch.Tensor):
         bound = bound.to(dtype=inputs.dtype, device=inputs.device)
     else:
-        bound = float(bound)
+        # integer inputs stay integers (tf.maximum(int32, 0) in the reference's _normalize_indexes)
+        bound = float(bound) if inputs.is_floating_point() else int(bound)
     return _Bound.apply(inputs, bound, upper, gradient)
 
 

@@ -51,5 +51,21 @@ def gather_encoded(blob: torch.Tensor, offsets: torch.Tensor, group=None):
 def broadcast_tables(module: torch.nn.Module, src: int = 0, group=None):
     """Replicates weights and range-coding tables from `src` (tables must be shared, never
     rebuilt per rank: continuous_base.py:175-184)."""
+    backend = dist.get_backend(group)
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if backend == "nccl" and not t.is_cuda:
+            # the range-coding tables live on the host (the coder library keeps its own device copy):
+            # through the device for RCCL, back into the same storage
+            staged = t.data.to(torch.device("cuda", torch.cuda.current_device()))
+            dist.broadcast(staged, src=src, group=group)
+            t.data.copy_(staged.cpu())
+        else:
+            dist.broadcast(t.data, src=src, group=group)
+    from .ops import gen_ops
+    gen_ops.invalidate_table_cache()        # `.data` writes do not advance the version counters the caches key on
+    for m in module.modules():
+        if hasattr(m, "invalidate_kernel_cache"):
+            m.invalidate_kernel_cache()
+        for name in ("_dev_cache", "_dev_offsets"):
+            if name in m.__dict__:
+                object.__setattr__(m, name, None)

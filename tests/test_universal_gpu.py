@@ -88,3 +88,77 @@ def test_batched_roundtrip_with_a_soft_rounded_prior():
     _, bits = em(y, training=False)
     coded = np.array([8 * len(bytes(s)) for s in strings], dtype=np.float64)
     assert np.all(coded >= bits.cpu().numpy() * 0.97) and np.all(coded <= bits.cpu().numpy() * 1.06 + 64)
+
+
+def _oracle_strings(em, symbols, flat, streams):
+    """The CPU oracle's EntropyEncodeIndex + Finalize on the symbols / table indexes the model derived, and its
+    decode of those strings (the oracle is pinned to the reference's compiled op kernels, tests/test_oracle.py)."""
+    from oracle import oracle
+    port = oracle.best()
+    lookup = em.cdf.cpu().numpy()
+    sym = symbols.reshape(streams, -1).cpu().numpy()
+    idx = flat.reshape(streams, -1).cpu().numpy()
+    strings, _, _ = port.encode(lookup, sym, index=idx)
+    dec, ok = port.decode(lookup, strings, sym.shape[1], index=idx)
+    assert ok.all() and (dec == sym).all()
+    return strings, sym, idx
+
+
+def test_batched_strings_equal_the_oracles():
+    """Row f4 pinned to something other than itself: the strings UniversalBatchedEntropyModel.compress
+    returns are, byte for byte, what the reference's index-mode coder produces for the symbols and
+    (offset level, channel) table indexes the model hands to it (universal.py:229-266) — and the values
+    decompress() returns are the oracle-decoded symbols put back through cdf_offset and the dither.
+    (What stays unpinned is only WHICH offset level each element draws: the TensorFlow stateless_uniform
+    stream, see entropy_models/universal.py.)"""
+    torch.manual_seed(11)
+    C = 12
+    scale = torch.linspace(0.4, 9.0, C)
+    prior = tfc.NoisyNormal(loc=torch.linspace(-2, 2, C), scale=scale)
+    em = tfc.UniversalBatchedEntropyModel(prior, coding_rank=3, compression=True, num_noise_levels=15)
+    y = (torch.randn(5, 13, 7, C) * scale * 1.5 + torch.linspace(-2, 2, C)).cuda()   # 1.5 sigma: some escapes
+    strings = em.compress(y)
+    symbols, flat = em._coder_inputs(y)
+    assert flat.min() >= 0 and flat.max() < 15 * C and len(torch.unique(flat // C)) == 15     # every offset level in use
+    want, sym, idx = _oracle_strings(em, symbols, flat, 5)
+    assert [bytes(s) for s in strings] == want
+    # escapes were exercised: some symbols lie outside their table
+    from compression_amd import synthetic
+    rows = synthetic.lookup_rows(em.cdf.numpy())
+    width = np.array([len(c) - 2 for _, c in rows])
+    assert ((sym < 0) | (sym >= width[idx])).any()
+    y_hat = em.decompress(strings, (13, 7))
+    _, offset = em._compute_indexes_and_offset((13, 7))
+    back = (torch.from_numpy(sym).cuda().reshape(y.shape) + em.cdf_offset.cuda()[flat.long()]).float() + offset.cuda()
+    assert torch.equal(y_hat, back)
+
+
+@pytest.mark.parametrize("index_dtype", [torch.float32, torch.int32])
+def test_indexed_strings_equal_the_oracles(index_dtype):
+    """The same for UniversalIndexedEntropyModel (universal.py:534-603), with float and integer index tensors
+    (the offset arithmetic follows the index dtype, as the reference's does)."""
+    torch.manual_seed(12)
+    em = tfc.UniversalIndexedEntropyModel(
+        tfc.NoisyNormal, index_ranges=(24,),
+        parameter_fns=dict(loc=lambda i: 0.0, scale=lambda i: torch.exp(-1.0 + 0.15 * i[..., 0])),
+        coding_rank=2, compression=True, num_noise_levels=12)
+    idx = torch.randint(0, 24, (6, 211, 3, 1)).cuda()
+    y = torch.randn(6, 211, 3, device="cuda") * torch.exp(-1.0 + 0.15 * idx[..., 0].float()) * 1.4
+    idx = idx.to(index_dtype)
+    strings = em.compress(y, idx)
+    symbols, flat = em._coder_inputs(y, idx)
+    assert flat.max() < 12 * 24 and len(torch.unique(flat // 24)) == 12
+    want, sym, fidx = _oracle_strings(em, symbols, flat, 6)
+    assert [bytes(s) for s in strings] == want
+    y_hat = em.decompress(strings, idx)
+    full = em._normalize_indexes(em._add_offset_indexes(idx))
+    back = (torch.from_numpy(sym).cuda().reshape(y.shape) + em.cdf_offset.cuda()[flat.long()]).float() \
+        + em._offset_from_indexes(full)
+    assert torch.equal(y_hat, back)
+
+
+def test_table_offsets_follow_the_bottleneck_dtype():
+    """universal.py:54-61: the offsets the tables are built for come from tf.range(L, dtype=bottleneck_dtype)."""
+    off = universal._range_coding_offsets(11, 1, torch.float32)
+    k = torch.arange(11, dtype=torch.float32)
+    assert off.dtype == torch.float32 and torch.equal(off.reshape(-1), (k + 1) / 12 - 0.5)
