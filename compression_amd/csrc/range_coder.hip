@@ -1584,7 +1584,14 @@ size_t speculative_slab_bytes(const tfc_tables* t, int64_t streams, int64_t elem
   const size_t per = ((2 * static_cast<size_t>(elems) + 4 + 15) / 16) * 16 + 32;
   size_t bytes = per * static_cast<size_t>(streams);
   if (t->any_escape) bytes += bytes / 4;
-  return bytes + (64u << 10);
+  bytes += 64u << 10;
+  // test hook (tests/test_pipeline_gpu.py): TFC_SPECULATIVE_SLAB_DIV=n shrinks the slab so that the
+  // "outgrown" path can be exercised with ordinary data
+  if (const char* e = std::getenv("TFC_SPECULATIVE_SLAB_DIV")) {
+    const long n = std::strtol(e, nullptr, 10);
+    if (n > 1) bytes = std::max<size_t>(bytes / static_cast<size_t>(n), 256);
+  }
+  return bytes;
 }
 
 int encode_precheck(tfc_encoder* e, int64_t elems) {

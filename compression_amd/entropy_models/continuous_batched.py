@@ -168,6 +168,7 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             symbols = symbols.reshape(tuple(iid) + (-1,)) - cdf_offset
             handle = gen_ops.entropy_encode_channel(handle, symbols.contiguous())
         if device_result:
+            handle.coder_inputs = (bottleneck, None)     # what the coder read (values, table indexes): for checkers
             return gen_ops.entropy_encode_finalize_device(handle)
         return gen_ops.entropy_encode_finalize(handle)
 

@@ -161,6 +161,7 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             symbols = torch.round(bottleneck).to(torch.int32) - cdf_offset[flat.long()]
             handle = gen_ops.entropy_encode_index(handle, flat, symbols.contiguous())
         if device_result:
+            handle.coder_inputs = (bottleneck, flat)     # what the coder read (values, table indexes): for checkers
             return gen_ops.entropy_encode_finalize_device(handle)
         return gen_ops.entropy_encode_finalize(handle)
 

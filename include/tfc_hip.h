@@ -68,7 +68,10 @@ int tfc_get_default_mode(void);
  * need one wave per SIMD on a few CUs for a long time while the transforms want every remaining CU, so a
  * model pipeline gives the two disjoint CU sets and lets them overlap (compression_amd/parallel.py,
  * CoderPartition).  `mask`: one bit per CU, `words` 32-bit words, bit i of word i/32 = CU i in the
- * driver's numbering (consecutive bits alternate over the XCDs).  The stream is a plain hipStream_t. */
+ * driver's numbering (consecutive bits alternate over the XCDs).  The stream is a plain hipStream_t.
+ * tfc_stream_destroy synchronises the stream and parks it for the next request with the same mask instead
+ * of destroying it: coder handles free their buffers in the order of the stream that used them last and
+ * may outlive the pipeline that created the stream. */
 int tfc_device_compute_units(int* cus);
 int tfc_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
 int tfc_stream_destroy(void* stream);

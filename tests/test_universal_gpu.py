@@ -60,7 +60,10 @@ def test_indexed_roundtrip_and_rate():
     strings = em.compress(y, idx)
     assert strings.shape == (4,)
     y_hat = em.decompress(strings, idx)
-    off = universal._offset_indexes_to_offset(universal.stateless_offset_indexes((4, 300, 5), 11), 11, torch.float32).cuda()
+    # float indexes: the drawn levels are cast to the indexes' dtype and the offset arithmetic is float32
+    # (universal.py:40-46)
+    off = universal._offset_indexes_to_offset(universal.stateless_offset_indexes((4, 300, 5), 11).float(), 11,
+                                              torch.float32).cuda()
     assert torch.equal(y_hat, torch.round(y - off) + off)
     _, bits = em(y, idx, training=False)
     coded = np.array([8 * len(bytes(s)) for s in strings], dtype=np.float64)
