@@ -531,7 +531,7 @@ def run_model_steps(model, x, steps, lanes, fetch=True):
 
 
 def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=2, coder_cus=32,
-                cpu=True, rank=0, world=1, distributed=False):
+                cpu=True, rank=0, world=1, distributed=False, partition="masked"):
     """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5)."""
     import torch.distributed as dist
     from compression_amd import parallel, pipeline
@@ -553,7 +553,7 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
         # (b) the timed region: `depth` steps in flight over the CU partition
         # the wave-per-stream coder wants one wave per SIMD: a quarter of a CU per image, at most half the chip
         cus = coder_cus if coder_cus > 0 else min(128, max(16, (batch + 3) // 4))
-        part = pipeline.CoderPartition(coder_cus=cus, depth=depth, device=device) if depth > 1 else None
+        part = pipeline.CoderPartition(coder_cus=cus, depth=depth, device=device, mode=partition) if depth > 1 else None
         lanes = part.lanes if part else inline
         run_model_steps(model, x, max(warmup, len(lanes)), lanes)
         torch.cuda.synchronize()
@@ -575,6 +575,11 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert rec.x_hat.shape == x.shape
+        # decode parity: what the decoder returned IS the quantised latent the encoder coded (every image)
+        y_coded = rec.out[0].coder_inputs[0]
+        y_decoded = rec.x_hat._tfc_keep[-1]
+        want = model.entropy_model.quantize(y_coded) if workload == "bls2017" else torch.round(y_coded.float()).to(y_coded.dtype)
+        assert torch.equal(y_decoded, want), "decompress did not return the quantised latents"
         strings = rec.strings
         nbytes = sum(len(bytes(s)) for arr in strings for s in arr.reshape(-1))
         if gathered:
@@ -592,7 +597,7 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
                             f"random-init weights" + (", hyperprior calibrated (scale_index_histogram)" if hist is not None else ""),
                 "dtype": dtype_name,
                 "steps_in_flight": len(lanes),
-                "cu_partition": ({"coder_cus": part.coder_cus, "transform_cus": part.total_cus - part.coder_cus}
+                "cu_partition": ({"mode": part.mode, "coder_cus": part.coder_cus, "transform_cus": part.total_cus - part.coder_cus}
                                  if part else None),
                 "strings_fetched_to_host_in_timed_region": True,
                 "lone_step": {"ms_per_step": round(1e3 * lone_s / lone_steps, 3),
@@ -666,7 +671,8 @@ def model_workload(args, world, rank, device, distributed):
     import torch.distributed as dist
     res = model_bench(args.workload, args.model_dtype, device, batch=args.batch, steps=args.steps,
                       warmup=args.warmup, depth=max(1, args.model_depth), coder_cus=args.coder_cus,
-                      cpu=not args.no_cpu_baseline, rank=rank, world=world, distributed=distributed)
+                      cpu=not args.no_cpu_baseline, rank=rank, world=world, distributed=distributed,
+                      partition=args.partition)
     if rank == 0:
         line = {
             "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
@@ -838,6 +844,8 @@ def main():
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="compute units reserved for the coder streams of a model pipeline (0: one SIMD per image, "
                          "at most half the chip)")
+    ap.add_argument("--partition", default="masked", choices=["masked", "plain", "single", "coder-masked", "transform-masked"],
+                    help="streams of a model pipeline lane: CU-masked pair, ordinary pair, or one ordinary stream")
     ap.add_argument("--model-steps", type=int, default=6, help="timed steps of the `models` sub-objects")
     args = ap.parse_args()
 
@@ -990,7 +998,7 @@ def main():
                 torch.cuda.empty_cache()
                 out["models"][key] = model_bench(name, args.model_dtype, device, steps=args.model_steps, warmup=2,
                                                  depth=max(1, args.model_depth), coder_cus=args.coder_cus,
-                                                 cpu=not args.no_cpu_baseline)
+                                                 cpu=not args.no_cpu_baseline, partition=args.partition)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

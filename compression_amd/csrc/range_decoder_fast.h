@@ -322,15 +322,49 @@ __device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned in
   TFC_DEC_WSTEP8(TFC_OUT(39), 40, 41, 42, 43, 44, 45, 46, 47, 48, 49) \
   TFC_DEC_WSTEP8(TFC_OUT(47), 48, 49, 50, 51, 52, 53, 54, 55, 56, 57) \
   TFC_DEC_WSTEP8(TFC_OUT(55), 56, 57, 58, 59, 60, 61, 62, 63, 0, 1)
+// ---- mixed batches: the step of every symbol chosen by its own row ------------------------------
+// A batch that contains ANY row wider than 64 symbols used to run all 64 symbols through the two-stage
+// step (52 slots against 27): with bmshj2018's scale tables ~7 % of the symbols have wide rows but 99 % of
+// the batches contain one, so the whole stream decoded at the wide rate.  Here bit N of the scalar mask
+// `wm` (ballot of "row N is wide") picks the step: narrow rows fall through an untaken branch (~12
+// cycles) into the 27-slot step; wide rows jump to an out-of-line copy of the two-stage step behind the
+// batch and come back.  Both steps keep the same register protocol (v40/v42 stage-1 bounds of the current /
+// next symbol, sx = next-but-one row), so they can follow each other in any order.
+#define TFC_DEC_MSTEP_IN(N, N2, CUR, NXT, OUTPREV)                                             \
+  "s_bitcmp1_b64 %[wm], " #N "\n\t"                                                           \
+  "s_cbranch_scc1 .Ltfcw%=_" #N "\n\t"                                                        \
+  TFC_DEC_STEP(N2, CUR, NXT, OUTPREV)                                                         \
+  ".Ltfcb%=_" #N ":\n\t"
+#define TFC_DEC_MSTEP_OUT(N, N2, CUR, NXT, OUTPREV)                                            \
+  ".Ltfcw%=_" #N ":\n\t"                                                                      \
+  TFC_DEC_WSTEP(N, N2, CUR, NXT, OUTPREV)                                                     \
+  "s_branch .Ltfcb%=_" #N "\n\t"
+#define TFC_DEC_MSTEP8(M, FIRST, a, b, c, d, e, f, g, h, i, j)                                 \
+  M(a, c, 40, 42, FIRST) M(b, d, 42, 40, TFC_OUT(a))                                           \
+  M(c, e, 40, 42, TFC_OUT(b)) M(d, f, 42, 40, TFC_OUT(c))                                      \
+  M(e, g, 40, 42, TFC_OUT(d)) M(f, h, 42, 40, TFC_OUT(e))                                      \
+  M(g, i, 40, 42, TFC_OUT(f)) M(h, j, 42, 40, TFC_OUT(g))
+#define TFC_DEC_MSTEP64(M) \
+  TFC_DEC_MSTEP8(M, TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9) \
+  TFC_DEC_MSTEP8(M, TFC_OUT(7), 8, 9, 10, 11, 12, 13, 14, 15, 16, 17) \
+  TFC_DEC_MSTEP8(M, TFC_OUT(15), 16, 17, 18, 19, 20, 21, 22, 23, 24, 25) \
+  TFC_DEC_MSTEP8(M, TFC_OUT(23), 24, 25, 26, 27, 28, 29, 30, 31, 32, 33) \
+  TFC_DEC_MSTEP8(M, TFC_OUT(31), 32, 33, 34, 35, 36, 37, 38, 39, 40, 41) \
+  TFC_DEC_MSTEP8(M, TFC_OUT(39), 40, 41, 42, 43, 44, 45, 46, 47, 48, 49) \
+  TFC_DEC_MSTEP8(M, TFC_OUT(47), 48, 49, 50, 51, 52, 53, 54, 55, 56, 57) \
+  TFC_DEC_MSTEP8(M, TFC_OUT(55), 56, 57, 58, 59, 60, 61, 62, 63, 0, 1)
+// a run = prologue, inline steps, epilogue, jump over the out-of-line steps
+#define TFC_DEC_MRUN(FIRSTROW, LAST, IN, OUT) \
+  TFC_DEC_WPROLOGUE(FIRSTROW) IN TFC_DEC_EPILOGUE(LAST) "\n\ts_branch .Ltfce%=\n\t" OUT ".Ltfce%=:"
 #define TFC_DEC_WPROLOGUE(FIRSTROW) TFC_DEC_PROLOGUE(FIRSTROW) "v_mov_b32 v61, 0\n\t"
 #define TFC_DEC_WOPERANDS(P_st, P_hi, P_out, P_rowx, P_wreg, P_lane4, P_lanev, P_c0, P_c16, P_sx, P_dig, P_L, \
-                          P_chunkv, P_firstv, P_chunk, P_first, P_a0, P_cc)                               \
+                          P_chunkv, P_firstv, P_chunk, P_first, P_a0, P_cc, P_wm)                         \
   : [t] "+s"(P_st.t), [D] "+s"(P_st.D), [pos] "+s"(P_st.pos), [sh] "+s"(P_st.sh), [out] "+v"(P_out),      \
     [hi] "+v"(P_hi), [sx] "=&s"(P_sx), [dig] "=&s"(P_dig), [L] "=&s"(P_L), [chunk] "=&s"(P_chunk),        \
     [first] "=&s"(P_first), [a0] "=&s"(P_a0), [c0] "=&s"(P_cc)                                            \
   : [rowx] "v"(P_rowx), [wreg] "v"(P_wreg), [lane4] "v"(P_lane4), [lanev] "v"(P_lanev), [zero] "v"(P_c0), \
-    [c16] "v"(P_c16), [k64] "s"(65536u), [chunkv] "v"(P_chunkv), [firstv] "v"(P_firstv)                   \
-  : "vcc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",         \
+    [c16] "v"(P_c16), [k64] "s"(65536u), [chunkv] "v"(P_chunkv), [firstv] "v"(P_firstv), [wm] "s"(P_wm)   \
+  : "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",  \
     "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v61", "v62"
 // FIRSTROW = index of the run's second symbol (its row is read ahead of the first step)
 #define TFC_DEC_PROLOGUE(FIRSTROW) \
@@ -459,7 +493,8 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
     ch0 = static_cast<int>((static_cast<unsigned int>(ch0) + 64u) % static_cast<unsigned int>(ntab));
     const DecRow row = dir[t];
     const int cnt = static_cast<int>(min<int64_t>(64, p.elems - j0));
-    const bool anywide = __ballot(valid && (row.z >> 16) > 1) != 0;
+    const unsigned long long widemask = __ballot(valid && (row.z >> 16) > 1);    // bit n: symbol n's row is wide
+    const bool anywide = widemask != 0;
 
     if (j0 == 0) fast_window_load(w, lane); else fast_window_advance(w, st.pos, lane);
     st.pos = 0;
@@ -518,7 +553,7 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
           st.pos = 0;
         }
         const int escsym = __builtin_amdgcn_readlane(row.w, n);
-        int sym = anywide ? wide_step(n) : narrow_step(n);
+        int sym = ((widemask >> n) & 1ull) ? wide_step(n) : narrow_step(n);
         if (sym == escsym) {
           // Elias-gamma escape (range_coder_kernels.cc:449-471); the unary prefix
           // is bounded so that damaged input cannot spin.
@@ -565,9 +600,9 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
         unsigned int sx, dg, ck, fs, a0, cc;
         int L;
         reassert_uniform(st);
-        asm volatile(TFC_DEC_WPROLOGUE(1) TFC_DEC_WSTEP64 TFC_DEC_EPILOGUE(63)
+        asm volatile(TFC_DEC_MRUN(1, 63, TFC_DEC_MSTEP64(TFC_DEC_MSTEP_IN), TFC_DEC_MSTEP64(TFC_DEC_MSTEP_OUT))
                      TFC_DEC_WOPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L,
-                                       chunkv, first1v, ck, fs, a0, cc));
+                                       chunkv, first1v, ck, fs, a0, cc, widemask));
         reassert_uniform(st);
       }
       if (!blocks && __ballot(outv == row.w) != 0) {
@@ -612,17 +647,25 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
             int L;
             reassert_uniform(st);
             switch (blk) {
-#define TFC_WBLK(B, FIRSTROW, LAST, S) case B: asm volatile(TFC_DEC_WPROLOGUE(FIRSTROW) S TFC_DEC_EPILOGUE(LAST) \
+#define TFC_WBLK(B, FIRSTROW, LAST, S) case B: asm volatile(TFC_DEC_MRUN(FIRSTROW, LAST, S(TFC_DEC_MSTEP_IN), S(TFC_DEC_MSTEP_OUT)) \
                      TFC_DEC_WOPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L, \
-                                       chunkv, first1v, ck, fs, a0, cc)); break;
-              TFC_WBLK(0, 1, 7, TFC_DEC_WSTEP8(TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9))
-              TFC_WBLK(1, 9, 15, TFC_DEC_WSTEP8(TFC_NOOUT, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17))
-              TFC_WBLK(2, 17, 23, TFC_DEC_WSTEP8(TFC_NOOUT, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25))
-              TFC_WBLK(3, 25, 31, TFC_DEC_WSTEP8(TFC_NOOUT, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33))
-              TFC_WBLK(4, 33, 39, TFC_DEC_WSTEP8(TFC_NOOUT, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41))
-              TFC_WBLK(5, 41, 47, TFC_DEC_WSTEP8(TFC_NOOUT, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49))
-              TFC_WBLK(6, 49, 55, TFC_DEC_WSTEP8(TFC_NOOUT, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57))
-              TFC_WBLK(7, 57, 63, TFC_DEC_WSTEP8(TFC_NOOUT, 56, 57, 58, 59, 60, 61, 62, 63, 0, 1))
+                                       chunkv, first1v, ck, fs, a0, cc, widemask)); break;
+#define TFC_MB0(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9)
+              TFC_WBLK(0, 1, 7, TFC_MB0)
+#define TFC_MB1(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)
+              TFC_WBLK(1, 9, 15, TFC_MB1)
+#define TFC_MB2(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25)
+              TFC_WBLK(2, 17, 23, TFC_MB2)
+#define TFC_MB3(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33)
+              TFC_WBLK(3, 25, 31, TFC_MB3)
+#define TFC_MB4(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41)
+              TFC_WBLK(4, 33, 39, TFC_MB4)
+#define TFC_MB5(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49)
+              TFC_WBLK(5, 41, 47, TFC_MB5)
+#define TFC_MB6(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57)
+              TFC_WBLK(6, 49, 55, TFC_MB6)
+#define TFC_MB7(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 56, 57, 58, 59, 60, 61, 62, 63, 0, 1)
+              TFC_WBLK(7, 57, 63, TFC_MB7)
 #undef TFC_WBLK
             }
             reassert_uniform(st);

@@ -81,8 +81,11 @@ class CoderPartition:
     transform streams get the others.  Consecutive bits of a HIP CU mask alternate over the XCDs, so
     the coder's share is spread evenly over the eight dies (and their L2s)."""
 
-    def __init__(self, coder_cus=32, depth=2, device=None):
+    def __init__(self, coder_cus=32, depth=2, device=None, mode="masked"):
+        """mode: "masked" (disjoint CU sets), "plain" (two ordinary streams per lane: the hardware shares
+        the CUs), "single" (one ordinary stream per lane: only whole steps overlap)."""
         _lib.require_device()
+        self.mode = mode
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         n = C.c_int()
         with torch.cuda.device(self.device):
@@ -93,15 +96,17 @@ class CoderPartition:
             self._raw = []
             self.lanes = []
             for _ in range(int(depth)):
-                if self.coder_cus == 0:
+                if self.coder_cus == 0 or mode == "single":
                     t = c = torch.cuda.Stream(device=self.device)
+                elif mode == "plain":
+                    t, c = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device, priority=-1)
                 else:
                     coder_bits = (1 << self.coder_cus) - 1
                     rest_bits = ((1 << self.total_cus) - 1) & ~coder_bits
                     coder_mask = [(coder_bits >> (32 * w)) & 0xFFFFFFFF for w in range(words)]
                     rest_mask = [(rest_bits >> (32 * w)) & 0xFFFFFFFF for w in range(words)]
-                    c = self._masked(coder_mask)
-                    t = self._masked(rest_mask)
+                    c = torch.cuda.Stream(device=self.device) if mode == "transform-masked" else self._masked(coder_mask)
+                    t = torch.cuda.Stream(device=self.device) if mode == "coder-masked" else self._masked(rest_mask)
                 self.lanes.append(Lane(t, c))
 
     def _masked(self, mask):
