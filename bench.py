@@ -531,7 +531,7 @@ def run_model_steps(model, x, steps, lanes, fetch=True):
 
 
 def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=2, coder_cus=32,
-                cpu=True, rank=0, world=1, distributed=False, partition="masked"):
+                cpu=True, rank=0, world=1, distributed=False, partition="single"):
     """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5)."""
     import torch.distributed as dist
     from compression_amd import parallel, pipeline
@@ -844,7 +844,7 @@ def main():
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="compute units reserved for the coder streams of a model pipeline (0: one SIMD per image, "
                          "at most half the chip)")
-    ap.add_argument("--partition", default="masked", choices=["masked", "plain", "single", "coder-masked", "transform-masked"],
+    ap.add_argument("--partition", default="single", choices=["masked", "plain", "single", "coder-masked", "transform-masked"],
                     help="streams of a model pipeline lane: CU-masked pair, ordinary pair, or one ordinary stream")
     ap.add_argument("--model-steps", type=int, default=6, help="timed steps of the `models` sub-objects")
     args = ap.parse_args()

@@ -999,6 +999,7 @@ struct DecParams {
   uint4* state;                    // base, span_m1, window, pulls
   unsigned long long* first_error; // index range error
   const unsigned int* only_flagged; // dec_fast_kernel: if set, decode only streams with a nonzero flag
+  int blocks_after_escape;         // dec_fast_kernel: batches decoded as checked 8-symbol blocks after an escape
 };
 
 // 64 upcoming big-endian digits of the stream, one per lane.
@@ -2307,6 +2308,11 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   p.state = d->state.as<uint4>();
   p.first_error = d->status.as<unsigned long long>();
   p.only_flagged = nullptr;
+  p.blocks_after_escape = [] {
+    const char* e = std::getenv("TFC_BLOCKS_AFTER_ESCAPE");
+    const long n = e ? std::strtol(e, nullptr, 10) : 64;
+    return static_cast<int>(n >= 0 && n <= 1024 ? n : 64);
+  }();
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
   const size_t fast_lds = sizeof(int32_t) * ((t->dec_words + 3) & ~3) + sizeof(int4) * t->rows.size();

@@ -356,6 +356,83 @@ __device__ inline int select_step(FastDecState& st, unsigned int hi, unsigned in
 // a run = prologue, inline steps, epilogue, jump over the out-of-line steps
 #define TFC_DEC_MRUN(FIRSTROW, LAST, IN, OUT) \
   TFC_DEC_WPROLOGUE(FIRSTROW) IN TFC_DEC_EPILOGUE(LAST) "\n\ts_branch .Ltfce%=\n\t" OUT ".Ltfce%=:"
+// ---- re-entrant checked runs: a batch in eight blocks of eight symbols inside ONE asm statement -------
+// Used once a stream has met an escape code.  Each block saves the state it starts from (four s_mov, the
+// current bounds register and its own number) and, after its eighth symbol, compares the block's eight
+// decoded symbols with their rows' escape symbols; a hit leaves the statement at once — the caller
+// decodes that block from the saved state with the checked loop (which reads the Elias-gamma bits) and
+// re-enters the statement at the following block through the dispatch at its top.  Against separate
+// 8-symbol asm statements (the previous form: ~75 cycles per symbol for prologues, re-declaring the
+// state uniform, the switch and a cold row pipeline per block) this costs ~6 cycles per symbol, and
+// nothing behind the block with the escape is decoded in vain.
+// STEPS = the eight steps of block K (first one with TFC_NOOUT), L7 = 8 K + 7, SH = 8 K.
+#define TFC_DEC_RBLOCK(K, STEPS, L7, SH)                                                      \
+  ".Ltfcr%=_" #K ":\n\t"                                                                      \
+  "s_mov_b32 %[sD], %[D]\n\t"                                                                 \
+  "s_mov_b32 %[sT], %[t]\n\t"                                                                 \
+  "s_mov_b32 %[sSh], %[sh]\n\t"                                                               \
+  "s_mov_b32 %[sPos], %[pos]\n\t"                                                             \
+  "v_mov_b32 %[sHi], v40\n\t"                                                                 \
+  "s_mov_b32 %[blk], " #K "\n\t"                                                              \
+  STEPS                                                                                       \
+  "v_writelane_b32 %[out], %[L], " #L7 "\n\t"                                                 \
+  "v_cmp_eq_u32 vcc, %[out], %[escv]\n\t"                                                     \
+  "s_lshr_b64 vcc, vcc, " #SH "\n\t"                                                          \
+  "s_and_b32 vcc_lo, vcc_lo, 0xff\n\t"                                                        \
+  "s_cmp_lg_u32 vcc_lo, 0\n\t"                                                                \
+  "s_cbranch_scc1 .Ltfcx%=\n\t"
+#define TFC_DEC_RDISPATCH                                                                     \
+  "s_cmp_eq_u32 %[entry], 1\n\ts_cbranch_scc1 .Ltfcr%=_1\n\t"                                 \
+  "s_cmp_eq_u32 %[entry], 2\n\ts_cbranch_scc1 .Ltfcr%=_2\n\t"                                 \
+  "s_cmp_eq_u32 %[entry], 3\n\ts_cbranch_scc1 .Ltfcr%=_3\n\t"                                 \
+  "s_cmp_eq_u32 %[entry], 4\n\ts_cbranch_scc1 .Ltfcr%=_4\n\t"                                 \
+  "s_cmp_eq_u32 %[entry], 5\n\ts_cbranch_scc1 .Ltfcr%=_5\n\t"                                 \
+  "s_cmp_eq_u32 %[entry], 6\n\ts_cbranch_scc1 .Ltfcr%=_6\n\t"                                 \
+  "s_cmp_eq_u32 %[entry], 7\n\ts_cbranch_scc1 .Ltfcr%=_7\n\t"
+// prologue with the row to read ahead given at run time (frow = 8 entry + 1)
+#define TFC_DEC_RPROLOGUE \
+  "v_readlane_b32 %[sx], %[rowx], %[frow]\n\tv_mov_b32 v40, %[hi]\n\tv_mov_b32 v41, 0\n\tv_mov_b32 v43, 0\n\tv_mov_b32 v61, 0\n\t"
+// the eight blocks with step macro family S8(FIRST, a .. j)
+#define TFC_DEC_RBLOCKS(S8)                                                                   \
+  TFC_DEC_RBLOCK(0, S8(TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9), 7, 0)                          \
+  TFC_DEC_RBLOCK(1, S8(TFC_NOOUT, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17), 15, 8)                 \
+  TFC_DEC_RBLOCK(2, S8(TFC_NOOUT, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25), 23, 16)              \
+  TFC_DEC_RBLOCK(3, S8(TFC_NOOUT, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33), 31, 24)              \
+  TFC_DEC_RBLOCK(4, S8(TFC_NOOUT, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41), 39, 32)              \
+  TFC_DEC_RBLOCK(5, S8(TFC_NOOUT, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49), 47, 40)              \
+  TFC_DEC_RBLOCK(6, S8(TFC_NOOUT, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57), 55, 48)              \
+  TFC_DEC_RBLOCK(7, S8(TFC_NOOUT, 56, 57, 58, 59, 60, 61, 62, 63, 0, 1), 63, 56)
+#define TFC_DEC_MIN8(FIRST, a, b, c, d, e, f, g, h, i, j) TFC_DEC_MSTEP8(TFC_DEC_MSTEP_IN, FIRST, a, b, c, d, e, f, g, h, i, j)
+#define TFC_DEC_MOUT8(FIRST, a, b, c, d, e, f, g, h, i, j) TFC_DEC_MSTEP8(TFC_DEC_MSTEP_OUT, FIRST, a, b, c, d, e, f, g, h, i, j)
+// the out-of-line two-stage steps of all eight blocks (mixed variant only)
+#define TFC_DEC_ROUTS                                                                         \
+  TFC_DEC_MOUT8(TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9)                                       \
+  TFC_DEC_MOUT8(TFC_NOOUT, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)                               \
+  TFC_DEC_MOUT8(TFC_NOOUT, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25)                             \
+  TFC_DEC_MOUT8(TFC_NOOUT, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33)                             \
+  TFC_DEC_MOUT8(TFC_NOOUT, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41)                             \
+  TFC_DEC_MOUT8(TFC_NOOUT, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49)                             \
+  TFC_DEC_MOUT8(TFC_NOOUT, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57)                             \
+  TFC_DEC_MOUT8(TFC_NOOUT, 56, 57, 58, 59, 60, 61, 62, 63, 0, 1)
+// narrow rows only / any mix of rows
+#define TFC_DEC_RRUN_NARROW \
+  TFC_DEC_RPROLOGUE TFC_DEC_RDISPATCH TFC_DEC_RBLOCKS(TFC_DEC_STEP8) \
+  "s_mov_b32 %[blk], 8\n\t.Ltfcx%=:\n\tv_mov_b32 %[hi], v40"
+#define TFC_DEC_RRUN_MIXED \
+  TFC_DEC_RPROLOGUE TFC_DEC_RDISPATCH TFC_DEC_RBLOCKS(TFC_DEC_MIN8) \
+  "s_mov_b32 %[blk], 8\n\t.Ltfcx%=:\n\tv_mov_b32 %[hi], v40\n\ts_branch .Ltfce%=\n\t" TFC_DEC_ROUTS ".Ltfce%=:"
+#define TFC_DEC_ROPERANDS(P_st, P_hi, P_out, P_rowx, P_wreg, P_lane4, P_lanev, P_c0, P_c16, P_sx, P_dig, P_L, \
+                          P_chunkv, P_firstv, P_chunk, P_first, P_a0, P_cc, P_wm, P_escv, P_entry, P_frow,    \
+                          P_sD, P_sT, P_sSh, P_sPos, P_sHi, P_blk)                                            \
+  : [t] "+s"(P_st.t), [D] "+s"(P_st.D), [pos] "+s"(P_st.pos), [sh] "+s"(P_st.sh), [out] "+v"(P_out),      \
+    [hi] "+v"(P_hi), [sx] "=&s"(P_sx), [dig] "=&s"(P_dig), [L] "=&s"(P_L), [chunk] "=&s"(P_chunk),        \
+    [first] "=&s"(P_first), [a0] "=&s"(P_a0), [c0] "=&s"(P_cc), [sD] "=&s"(P_sD), [sT] "=&s"(P_sT),       \
+    [sSh] "=&s"(P_sSh), [sPos] "=&s"(P_sPos), [sHi] "=&v"(P_sHi), [blk] "=&s"(P_blk)                      \
+  : [rowx] "v"(P_rowx), [wreg] "v"(P_wreg), [lane4] "v"(P_lane4), [lanev] "v"(P_lanev), [zero] "v"(P_c0), \
+    [c16] "v"(P_c16), [k64] "s"(65536u), [chunkv] "v"(P_chunkv), [firstv] "v"(P_firstv), [wm] "s"(P_wm),  \
+    [escv] "v"(P_escv), [entry] "s"(P_entry), [frow] "s"(P_frow)                                          \
+  : "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",  \
+    "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v61", "v62"
 #define TFC_DEC_WPROLOGUE(FIRSTROW) TFC_DEC_PROLOGUE(FIRSTROW) "v_mov_b32 v61, 0\n\t"
 #define TFC_DEC_WOPERANDS(P_st, P_hi, P_out, P_rowx, P_wreg, P_lane4, P_lanev, P_c0, P_c16, P_sx, P_dig, P_L, \
                           P_chunkv, P_firstv, P_chunk, P_first, P_a0, P_cc, P_wm)                         \
@@ -465,7 +542,20 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
   w.wbase = __builtin_amdgcn_readfirstlane(st0.w);
   const int ntab = p.tab.ntab;
   int ch0 = 0;
-  bool escape_in_last_batch = false;
+  // Batches left in "blocks mode": a stream that met an escape code decodes its next kBlocksAfterEscape
+  // batches as eight checked 8-symbol blocks straight away instead of speculating on the whole batch first.
+  // Escapes cluster per stream, and at the tables' own tail mass (2^-8 of the symbols) a third of the
+  // batches contain one: the speculative pass would be wasted on most of them (one check per block costs
+  // ~5 cycles per symbol, a wasted pass ~190).
+  const int kBlocksAfterEscape = p.blocks_after_escape;
+  int blocks_mode = 0;
+  // index mode: the table indexes of the NEXT batch are requested a batch ahead (one HBM round trip per
+  // 64 symbols is ~50 cycles per symbol on this chain when it is waited for on the spot)
+  int t_ahead = 0;
+  if (p.index && p.elems > 0) {
+    const int64_t j = lane;
+    t_ahead = j < p.elems ? p.index[s * p.elems + j] : 0;
+  }
 
 #ifdef TFC_PHASE_TIMING
   const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -478,9 +568,13 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
     const int64_t j = j0 + lane;
     const bool valid = j < p.elems;
     int t = 0;
+    if (p.index) {
+      t = t_ahead;
+      const int64_t jn = j + 64;
+      t_ahead = jn < p.elems ? p.index[s * p.elems + jn] : 0;      // consumed by the next batch
+    }
     if (valid) {
       if (p.index) {
-        t = p.index[s * p.elems + j];
         if (t < 0 || t >= ntab) {
           atomicMin(p.first_error, static_cast<unsigned long long>(s * p.elems + j));
           t = 0;
@@ -585,7 +679,8 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
       // the symbols escaping, 47 % of the batches contain one and the speculative run is wasted).
       const FastDecState saved64 = st;
       const unsigned int hi_saved64 = hi_cur;
-      bool blocks = escape_in_last_batch;
+      bool blocks = blocks_mode > 0;
+      if (blocks_mode > 0) --blocks_mode;
       if (blocks) {
         // straight to level 2
       } else if (!anywide) {
@@ -596,6 +691,15 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
                      TFC_DEC_OPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L));
         reassert_uniform(st);
         outv &= 63;   // no-op for symbols of narrow rows; keeps damaged input inside the row range
+      } else if (widemask == ~0ull) {
+        // every row of the batch is wide (e.g. one wide prior for all channels): the branch-free two-stage run
+        unsigned int sx, dg, ck, fs, a0, cc;
+        int L;
+        reassert_uniform(st);
+        asm volatile(TFC_DEC_WPROLOGUE(1) TFC_DEC_WSTEP64 TFC_DEC_EPILOGUE(63)
+                     TFC_DEC_WOPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L,
+                                       chunkv, first1v, ck, fs, a0, cc, widemask));
+        reassert_uniform(st);
       } else {
         unsigned int sx, dg, ck, fs, a0, cc;
         int L;
@@ -611,72 +715,43 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
         blocks = true;
       }
       if (blocks) {
-        escape_in_last_batch = false;
-        for (int blk = 0; blk < 8; ++blk) {
-          const int n0 = blk * 8;
-          // With escape codes in the batch its 64 symbols can take more than the 64 digits of the window
-          // register (one digit per symbol only happens with symbols of probability <= 2^-16, plus up to
-          // five per escape code): a block starts with at least 16 digits ahead.
-          if (st.pos > 48u) {
+        // the batch as eight checked blocks inside one re-entrant asm run (TFC_DEC_RBLOCK): out at the first
+        // block whose symbols contain an escape, that block again from its saved state in the checked loop,
+        // back in at the next block
+        int entry = 0;
+        while (entry < 8) {
+          // the rest of the batch takes at most one digit per symbol (a further escape leaves the run again)
+          if (st.pos + static_cast<unsigned int>(64 - 8 * entry) > 64u) {
             fast_window_advance(w, st.pos, lane);
             st.pos = 0;
           }
-          const FastDecState saved = st;
-          const unsigned int hi_saved = hi_cur;
+          unsigned int sx, dg, ck, fs, a0, cc, sD, sT, sSh, sPos, sHi;
+          int L, blk;
+          const int frow = 8 * entry + 1;
+          reassert_uniform(st);
           if (!anywide) {
-            // eight hand-scheduled steps; the block index selects the output lanes
-            unsigned int sx, dg;
-            int L;
-            reassert_uniform(st);
-            switch (blk) {
-#define TFC_BLK(B, FIRSTROW, LAST, S) case B: asm volatile(TFC_DEC_PROLOGUE(FIRSTROW) S TFC_DEC_EPILOGUE(LAST) \
-                     TFC_DEC_OPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L)); break;
-              TFC_BLK(0, 1, 7, TFC_DEC_STEP8(TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9))
-              TFC_BLK(1, 9, 15, TFC_DEC_STEP8(TFC_NOOUT, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17))
-              TFC_BLK(2, 17, 23, TFC_DEC_STEP8(TFC_NOOUT, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25))
-              TFC_BLK(3, 25, 31, TFC_DEC_STEP8(TFC_NOOUT, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33))
-              TFC_BLK(4, 33, 39, TFC_DEC_STEP8(TFC_NOOUT, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41))
-              TFC_BLK(5, 41, 47, TFC_DEC_STEP8(TFC_NOOUT, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49))
-              TFC_BLK(6, 49, 55, TFC_DEC_STEP8(TFC_NOOUT, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57))
-              TFC_BLK(7, 57, 63, TFC_DEC_STEP8(TFC_NOOUT, 56, 57, 58, 59, 60, 61, 62, 63, 0, 1))
-#undef TFC_BLK
-            }
-            reassert_uniform(st);
+            asm volatile(TFC_DEC_RRUN_NARROW
+                         TFC_DEC_ROPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L,
+                                           chunkv, first1v, ck, fs, a0, cc, widemask, row.w, entry, frow,
+                                           sD, sT, sSh, sPos, sHi, blk));
           } else {
-            unsigned int sx, dg, ck, fs, a0, cc;
-            int L;
-            reassert_uniform(st);
-            switch (blk) {
-#define TFC_WBLK(B, FIRSTROW, LAST, S) case B: asm volatile(TFC_DEC_MRUN(FIRSTROW, LAST, S(TFC_DEC_MSTEP_IN), S(TFC_DEC_MSTEP_OUT)) \
-                     TFC_DEC_WOPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L, \
-                                       chunkv, first1v, ck, fs, a0, cc, widemask)); break;
-#define TFC_MB0(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9)
-              TFC_WBLK(0, 1, 7, TFC_MB0)
-#define TFC_MB1(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)
-              TFC_WBLK(1, 9, 15, TFC_MB1)
-#define TFC_MB2(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25)
-              TFC_WBLK(2, 17, 23, TFC_MB2)
-#define TFC_MB3(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33)
-              TFC_WBLK(3, 25, 31, TFC_MB3)
-#define TFC_MB4(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41)
-              TFC_WBLK(4, 33, 39, TFC_MB4)
-#define TFC_MB5(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49)
-              TFC_WBLK(5, 41, 47, TFC_MB5)
-#define TFC_MB6(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57)
-              TFC_WBLK(6, 49, 55, TFC_MB6)
-#define TFC_MB7(M) TFC_DEC_MSTEP8(M, TFC_NOOUT, 56, 57, 58, 59, 60, 61, 62, 63, 0, 1)
-              TFC_WBLK(7, 57, 63, TFC_MB7)
-#undef TFC_WBLK
-            }
-            reassert_uniform(st);
+            asm volatile(TFC_DEC_RRUN_MIXED
+                         TFC_DEC_ROPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L,
+                                           chunkv, first1v, ck, fs, a0, cc, widemask, row.w, entry, frow,
+                                           sD, sT, sSh, sPos, sHi, blk));
           }
-          const unsigned long long hits = __ballot(outv == row.w) & (0xFFull << n0);
-          if (hits != 0) {
-            st = saved;
-            hi_cur = hi_saved;
-            checked(n0, n0 + 8);
-            escape_in_last_batch = true;
-          }
+          reassert_uniform(st);
+          blk = __builtin_amdgcn_readfirstlane(blk);
+          if (blk >= 8) break;
+          // block `blk` decoded an escape symbol: again from where it started, bit by bit
+          st.D = __builtin_amdgcn_readfirstlane(sD);
+          st.t = __builtin_amdgcn_readfirstlane(sT);
+          st.sh = __builtin_amdgcn_readfirstlane(sSh);
+          st.pos = __builtin_amdgcn_readfirstlane(sPos);
+          hi_cur = sHi;
+          checked(8 * blk, 8 * blk + 8);
+          blocks_mode = kBlocksAfterEscape;
+          entry = blk + 1;
         }
       }
     } else {

@@ -74,13 +74,28 @@ def stateless_offset_indexes(shape, num_noise_levels):
     return torch.from_numpy(_stateless_uniform_int(n, (1234, 1234), int(num_noise_levels)).copy()).reshape(tuple(shape))
 
 
+_NP_DTYPE = {torch.float32: np.float32, torch.float64: np.float64, torch.float16: np.float16}
+
+
 def _offset_indexes_to_offset(offset_indexes, num_noise_levels, dtype):
     """(k + 1) / (L + 1) - 1/2 (universal.py:44-46), in the arithmetic type the reference's expression
     has: float64 for integer offset indexes (TensorFlow's `/` on int32 is a float64 true division), the
     tensor's own type for floating-point ones (the indexed model casts the drawn levels to the dtype of the
-    caller's indexes, universal.py:40), then cast to `dtype`."""
-    k = offset_indexes if offset_indexes.is_floating_point() else offset_indexes.to(torch.float64)
-    return ((k + 1) / (num_noise_levels + 1) - 0.5).to(dtype)
+    caller's indexes, universal.py:40), then cast to `dtype`.
+
+    There are only L distinct values: they are computed ONCE on the host with IEEE true division and
+    gathered by level, so that encoder and decoder get bit-identical dithers whatever device each runs on
+    (a device kernel may turn `x / c` into `x * (1 / c)`, one ulp off — enough to flip a rounding)."""
+    arith = offset_indexes.dtype if offset_indexes.is_floating_point() else torch.float64
+    if arith in _NP_DTYPE:
+        k = np.arange(num_noise_levels, dtype=_NP_DTYPE[arith])
+        one, half = k.dtype.type(1), k.dtype.type(0.5)
+        table = torch.from_numpy((k + one) / k.dtype.type(num_noise_levels + 1) - half)
+    else:                                   # bfloat16 levels: torch's CPU arithmetic (true division as well)
+        k = torch.arange(num_noise_levels, dtype=arith)
+        table = (k + 1) / (num_noise_levels + 1) - 0.5
+    table = table.to(dtype).to(offset_indexes.device)
+    return table[offset_indexes.long().clamp(0, num_noise_levels - 1)]
 
 
 def _range_coding_offsets(num_noise_levels, prior_rank, dtype):
