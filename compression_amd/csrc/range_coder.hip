@@ -308,9 +308,10 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       cdf_entries += static_cast<size_t>(nsym + 1);
       words += std::max<size_t>(1, (size_t{1} << prec) / 64);
     }
-    // the directory repeats its first entries behind its end: a block of 8 steps reads 8 consecutive
-    // entries without a wrap test per step
-    constexpr size_t kDirRepeat = 8;
+    // the directory repeats its first entries behind its end: a block of kEncCadence / kDecCadence steps
+    // reads that many consecutive entries without a wrap test per step
+    constexpr size_t kDirRepeat = 16;
+    // (>= kEncCadence and kDecCadence of range_lanes.h, which asserts it)
     const size_t dir_bytes = sizeof(tfc::LaneRow) * (ntab + kDirRepeat);
     const size_t cdf_bytes = (2 * cdf_entries + 15) & ~size_t{15};
     const size_t enc_bytes = dir_bytes + cdf_bytes;
@@ -824,8 +825,8 @@ struct ChunkList {
 // Tail of every stream per RangeEncoder::Finalize (range_coder.cc:266-307); one
 // thread per stream.  tail[s] = {head bytes (<= 2), 0xFFFF digits to insert,
 // end bytes (<= 2)}; also sums the stream's total length.
-//   generic kernels: state = (base, span-1, delay digit + 1, delayed bytes)
-//   fast kernels:    state = (base, span-1, valid<<31 | held digit, held 0xFFFF run)
+//   generic kernels:        state = (base, span-1, delay digit + 1, delayed bytes)
+//   fast and lane kernels:  state = (base, span-1, valid<<31 | held digit, held 0xFFFF run)
 struct Tail {
   unsigned char head[2];
   unsigned char end[2];
@@ -900,7 +901,7 @@ __global__ void enc_tail_many_kernel(const FinalizeJobs f) {
   one.inline_refs[0] = f.job[k].chunk;
   one.more = nullptr;
   one.n = 1;
-  enc_tail_one(f.job[k].state, f.streams, one, 1, 0, fin_tail(f, k), fin_length(f, k));
+  enc_tail_one(f.job[k].state, f.streams, one, 1, 1, fin_tail(f, k), fin_length(f, k));     // lane family: held-digit state
 }
 
 __device__ inline void scan_lengths_one(const long long* length, int64_t streams, long long* off) {
@@ -1978,7 +1979,7 @@ int finalize_impl(tfc_encoder* e, hipStream_t st, bool exact) {
   long long* const length_p = reinterpret_cast<long long*>(tail.as<uint8_t>() + ((sizeof(Tail) * n + 15) & ~size_t{15}));
   const unsigned tb = static_cast<unsigned>(ceil_div(n, 256));
   hipLaunchKernelGGL(enc_tail_kernel, dim3(tb), dim3(256), 0, st, e->state.as<uint4>(), n,
-                     list, static_cast<int>(refs.size()), e->family == kFast ? 1 : 0,
+                     list, static_cast<int>(refs.size()), e->family != kGeneric ? 1 : 0,
                      tail.as<Tail>(), length_p);
   hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, length_p, n,
                      e->offsets.as<long long>());

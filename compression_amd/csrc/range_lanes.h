@@ -23,9 +23,14 @@
 //   per-lane mode machine, so a lane that meets an escape falls behind its neighbours instead of
 //   stalling them (lanes run their streams at their own pace; the wave ends with its slowest lane).
 //
-// Encoder: the reference's state machine (base, span - 1, delay) per lane; a call emits 0, 1 or 2
-// digits (a resolved delayed digit and/or the renormalisation digit; longer delayed runs take a rare
-// loop), each a 2-byte store at the lane's own cursor.  The slab of a stream is sized on the host from
+// Encoder: base and span - 1 per lane as in the reference; its delayed-carry bookkeeping (delay_,
+// range_coder.cc:167-263) is kept in the form the wave-per-stream encoder uses — the last digit is HELD
+// back (plus a count of 0xFFFF digits behind it), because a carry can only ever reach those — which makes
+// the common step "add the carry to the held digit, and if the call renormalises, store the held digit
+// and hold the new one": one digit per call at most, 26 vector instructions instead of the 40 the delay_
+// arithmetic took (profiles/r02_d_sq_lanes.md -> r03).  The finalize kernel maps (held digit, run) to the
+// reference's Finalize bytes (enc_tail_one, fast_state); the bytes are identical, tests/ check them
+// against the compiled reference for every golden vector.  A 2-byte store at the lane's own cursor per digit.  The slab of a stream is sized on the host from
 // a bound that needs no counting pass (lanes_slab_bytes() in range_coder.hip).
 //
 // Memory: a lane's accesses are 64 different cache lines per wave instruction, and anything a step
@@ -221,7 +226,8 @@ __host__ __device__ constexpr int lane_stride(int payload) {
 // Encoder
 // ---------------------------------------------------------------------------------------------
 
-constexpr unsigned int kEncCadence = 8;         // steps between memory phases
+constexpr unsigned int kLaneDirRepeat = 16;     // directory entries repeated behind its end (tfc_tables_create, kDirRepeat)
+constexpr unsigned int kEncCadence = 16;        // steps between memory phases (= steps of the hand-scheduled block)
 constexpr unsigned int kEncDigitBytes = 32;     // digit bytes staged per lane between two phases (<= 2 digits per step)
 
 // LDS of one encoder wave: per lane digits, value window (2 cadences of elements), index window
@@ -241,14 +247,18 @@ struct EncWaveLds {
 // ---- kEncCadence encoder steps, hand-scheduled ------------------------------------------------
 // The common case only: every lane codes a plain int32 symbol of a channel-mode row in every step.  Step
 // k + 1's table lookups (row -> cdf entries) are issued before step k's interval arithmetic, so the chain
-// never waits for LDS.  The interval update keeps the reference's state machine but as arithmetic on
-// 0/1 values (st = carry undecided, r = renormalise ...) instead of branches:
-//   base1 = base + a, d = pd - 1 + carry(base1)           the delayed digit, resolved if !st && pd != 0
-//   e = r & !st; em = e & !st' (emit top), sp = e & st' (delay top + 1), pb += 2 (r & st)
-// Both digits are written to the staging area speculatively; the cursor NA only moves when they count.
-// Escapes, values out of range and delayed runs (pb != 0 at a resolve) bump FLAG: the caller restores
-// the lane state and repeats the block with the generic steps.  Fixed temporaries v140-v175:
-// v[140:147] the block's values, v[148:149] / v[150:151] rows (cdf - 2, info), v[152:153] v[154:155] /
+// never waits for LDS.  Interval update and digit bookkeeping per call, all selects (c, r = 0/1):
+//   a = (span lo) >> 16, b = ((span hi) >> 16) - 1, bs = base + a (carry c), t1 = b - a, r = t1 < 2^16
+//   X = H + c                          the held digit with the carry applied
+//   emit X  iff  had & (c | r)         a carry settles the held digit for good; a renormalisation pushes it out
+//   r: H = bs >> 16, had = 1 (the new digit is held), base = bs << 16, span - 1 = (t1 << 16) | 0xFFFF
+//   !r: had &= !c, base = bs, span - 1 = t1
+// The digit is written to the staging area speculatively; the cursor NA only moves when it counts.
+// Not covered, FLAG is bumped and the caller repeats the block from the saved lane state with the generic
+// steps: escapes and values out of range, a new digit 0xFFFF (it opens a run a later carry may have to
+// ripple through) and lanes that come in with such a run (RN != 0, tested by the caller).
+// Fixed temporaries v140-v175:
+// v[124:139] the block's values, v[148:149] / v[150:151] rows (cdf - 2, info), v[152:153] v[154:155] /
 // v[156:157] v[158:159] (lo, 0) (hi, 0) of even / odd steps.
 #define TFC_LENC_A(VAL, R0, R1, LO, HI, NEXTROW, NP)                                        \
   NEXTROW                                                                                 \
@@ -263,41 +273,30 @@ struct EncWaveLds {
   "v_mad_u64_u32 v[160:161], s[52:53], v" #LO ", %[S], v[" #LO ":" #LOH "]\n\t"             \
   "v_mad_u64_u32 v[162:163], s[52:53], v" #HI ", %[S], v[" #HI ":" #HIH "]\n\t"             \
   "v_alignbit_b32 v160, v161, v160, 16\n\t"                                               \
-  "v_add_co_u32 v164, vcc, %[BASE], v160\n\t"                                             \
-  "v_addc_co_u32 v167, vcc, -1, %[PD], vcc\n\t"                                           \
   "v_alignbit_b32 v162, v163, v162, 16\n\t"                                               \
   "v_add_u32 v162, -1, v162\n\t"                                                          \
   "v_min_u32 v162, v162, %[S]\n\t"                                                        \
+  "v_add_co_u32 v164, vcc, %[BASE], v160\n\t"                                             \
+  "v_addc_co_u32 v167, vcc, 0, %[H], vcc\n\t"                                             \
   "v_sub_u32 v165, v162, v160\n\t"                                                        \
-  "v_add_co_u32 v166, vcc, v164, v165\n\t"                                                \
-  "v_cndmask_b32 v168, %[PD], %[DIR0], vcc\n\t"                                           \
-  "v_cndmask_b32 v173, 1, 0, vcc\n\t"                                                     \
-  "v_perm_b32 v167, 0, v167, %[PERM]\n\t"                                                 \
-  "ds_write_b16 %[NA], v167\n\t"                                                          \
-  "v_min_u32 v169, 1, v168\n\t"                                                           \
-  "v_lshl_add_u32 %[NA], v169, 1, %[NA]\n\t"                                              \
-  "v_sub_u32 %[PD], %[PD], v168\n\t"                                                      \
-  "v_mul_u32_u24 v169, v169, %[PB]\n\t"                                                   \
-  "v_or_b32 %[FLAG], %[FLAG], v169\n\t"                                                   \
+  "v_sub_u32 v173, v167, %[H]\n\t"                                                        \
   "v_cmp_gt_u32 vcc, %[K64K], v165\n\t"                                                   \
-  "v_lshlrev_b32 v168, 16, v164\n\t"                                                      \
-  "v_lshl_or_b32 v169, v165, 16, %[KFFFF]\n\t"                                            \
-  "v_cndmask_b32 %[BASE], v164, v168, vcc\n\t"                                            \
-  "v_cndmask_b32 %[S], v165, v169, vcc\n\t"                                               \
   "v_cndmask_b32 v174, 0, 1, vcc\n\t"                                                     \
-  "v_add_co_u32 v166, vcc, %[BASE], %[S]\n\t"                                             \
-  "v_lshrrev_b32 v169, 16, v164\n\t"                                                      \
-  "v_and_b32 v168, v174, v173\n\t"                                                        \
-  "v_cndmask_b32 v175, 1, 0, vcc\n\t"                                                     \
-  "v_sub_u32 v174, v174, v168\n\t"                                                        \
-  "v_lshl_add_u32 %[PB], v174, 1, %[PB]\n\t"                                              \
-  "v_perm_b32 v166, 0, v169, %[PERM]\n\t"                                                 \
+  "v_perm_b32 v166, 0, v167, %[PERM]\n\t"                                                 \
   "ds_write_b16 %[NA], v166\n\t"                                                          \
-  "v_and_b32 v175, v168, v175\n\t"                                                        \
-  "v_lshl_add_u32 %[NA], v175, 1, %[NA]\n\t"                                              \
-  "v_sub_u32 v168, v168, v175\n\t"                                                        \
-  "v_add_u32 v169, 1, v169\n\t"                                                           \
-  "v_mad_u32_u24 %[PD], v168, v169, %[PD]\n\t"
+  "v_or_b32 v168, v173, v174\n\t"                                                         \
+  "v_and_b32 v168, v168, %[HAD]\n\t"                                                      \
+  "v_lshl_add_u32 %[NA], v168, 1, %[NA]\n\t"                                              \
+  "v_lshrrev_b32 v169, 16, v164\n\t"                                                      \
+  "v_lshlrev_b32 v170, 16, v164\n\t"                                                      \
+  "v_lshl_or_b32 v171, v165, 16, %[KFFFF]\n\t"                                            \
+  "v_cndmask_b32 %[BASE], v164, v170, vcc\n\t"                                            \
+  "v_cndmask_b32 %[S], v165, v171, vcc\n\t"                                               \
+  "v_cndmask_b32 %[H], %[H], v169, vcc\n\t"                                               \
+  "v_or_b32 v175, %[HAD], v174\n\t"                                                       \
+  "v_bfi_b32 %[HAD], v173, v174, v175\n\t"                                                \
+  "v_cmp_eq_u32 vcc, %[KFFFF], %[H]\n\t"                                                  \
+  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"
 #define TFC_LENC_ROW_A(OFF) "ds_read_b64 v[148:149], %[DIRP] offset:" #OFF "\n\t"
 #define TFC_LENC_ROW_B(OFF) "ds_read_b64 v[150:151], %[DIRP] offset:" #OFF "\n\t"
 // A value that is not a plain symbol: (plain variant) bump FLAG, the block is repeated generically /
@@ -306,49 +305,90 @@ struct EncWaveLds {
 #define TFC_LENC_PRE_PLAIN ""
 #define TFC_LENC_NP_FREEZE0(VAL) "s[58:59], v" #VAL ", v171\n\t"
 #define TFC_LENC_NP_FREEZE1(VAL) "s[60:61], v" #VAL ", v171\n\t"
+#define TFC_LENC_NP_FREEZE2(VAL) "s[62:63], v" #VAL ", v171\n\t"
 #define TFC_LENC_PRE_FREEZE0 "s_andn2_b64 exec, exec, s[58:59]\n\tv_add_u32 %[CNT], 1, %[CNT]\n\t"
 #define TFC_LENC_PRE_FREEZE1 "s_andn2_b64 exec, exec, s[60:61]\n\tv_add_u32 %[CNT], 1, %[CNT]\n\t"
-#define TFC_LENC_BLOCK(NP0, NP1, PRE0, PRE1)                                                                  \
-  "s_mov_b64 s[56:57], exec\n\t"                                                          \
-  "ds_read2_b32 v[140:141], %[VP] offset1:1\n\t"                                          \
-  "ds_read2_b32 v[142:143], %[VP] offset0:2 offset1:3\n\t"                                \
-  "ds_read2_b32 v[144:145], %[VP] offset0:4 offset1:5\n\t"                                \
-  "ds_read2_b32 v[146:147], %[VP] offset0:6 offset1:7\n\t"                                \
-  TFC_LENC_ROW_A(0)                                                                       \
-  "v_mov_b32 v153, 0\n\tv_mov_b32 v155, 0\n\tv_mov_b32 v157, 0\n\tv_mov_b32 v159, 0\n\t"  \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                              \
-  TFC_LENC_A(140, 148, 149, 152, 154, TFC_LENC_ROW_B(16), NP0)                                     \
-  "s_waitcnt lgkmcnt(2)\n\t"                                                              \
-  TFC_LENC_A(141, 150, 151, 156, 158, TFC_LENC_ROW_A(32), NP1)                                     \
-  "s_waitcnt lgkmcnt(3)\n\t"                                                              \
-  TFC_LENC_B(152, 153, 154, 155, PRE0)                                                          \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(142, 148, 149, 152, 154, TFC_LENC_ROW_B(48), NP0)                                     \
-  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(156, 157, 158, 159, PRE1)                                                          \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(143, 150, 151, 156, 158, TFC_LENC_ROW_A(64), NP1)                                     \
-  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(152, 153, 154, 155, PRE0)                                                          \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(144, 148, 149, 152, 154, TFC_LENC_ROW_B(80), NP0)                                     \
-  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(156, 157, 158, 159, PRE1)                                                          \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(145, 150, 151, 156, 158, TFC_LENC_ROW_A(96), NP1)                                     \
-  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(152, 153, 154, 155, PRE0)                                                          \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(146, 148, 149, 152, 154, TFC_LENC_ROW_B(112), NP0)                                     \
-  "s_waitcnt lgkmcnt(5)\n\t"                                                              \
-  TFC_LENC_B(156, 157, 158, 159, PRE1)                                                          \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_A(147, 150, 151, 156, 158, "", NP1)                                                 \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                              \
-  TFC_LENC_B(152, 153, 154, 155, PRE0)                                                          \
-  "s_waitcnt lgkmcnt(2)\n\t"                                                              \
-  TFC_LENC_B(156, 157, 158, 159, PRE1)                                                          \
-  "s_mov_b64 exec, s[56:57]\n\t"                                                          \
+#define TFC_LENC_PRE_FREEZE2 "s_andn2_b64 exec, exec, s[62:63]\n\tv_add_u32 %[CNT], 1, %[CNT]\n\t"
+// generated by tools/gen_lenc_block.py 16: part A of a step two steps ahead of its part B, three (lo, hi) sets;
+// the block's kEncCadence values in v[124:139]
+#define TFC_LENC_BLOCK(NP0, NP1, NP2, PRE0, PRE1, PRE2)                                        \
+  "s_mov_b64 s[56:57], exec\n\t" \
+  "ds_read2_b32 v[124:125], %[VP] offset0:0 offset1:1\n\t" \
+  "ds_read2_b32 v[126:127], %[VP] offset0:2 offset1:3\n\t" \
+  "ds_read2_b32 v[128:129], %[VP] offset0:4 offset1:5\n\t" \
+  "ds_read2_b32 v[130:131], %[VP] offset0:6 offset1:7\n\t" \
+  "ds_read2_b32 v[132:133], %[VP] offset0:8 offset1:9\n\t" \
+  "ds_read2_b32 v[134:135], %[VP] offset0:10 offset1:11\n\t" \
+  "ds_read2_b32 v[136:137], %[VP] offset0:12 offset1:13\n\t" \
+  "ds_read2_b32 v[138:139], %[VP] offset0:14 offset1:15\n\t" \
+  TFC_LENC_ROW_A(0) \
+  "v_mov_b32 v153, 0\n\tv_mov_b32 v155, 0\n\tv_mov_b32 v157, 0\n\tv_mov_b32 v159, 0\n\t" \
+  "v_mov_b32 v177, 0\n\tv_mov_b32 v179, 0\n\t" \
+  "s_waitcnt lgkmcnt(0)\n\t" \
+  TFC_LENC_A(124, 148, 149, 152, 154, TFC_LENC_ROW_B(16), NP0) \
+  "s_waitcnt lgkmcnt(2)\n\t" \
+  TFC_LENC_A(125, 150, 151, 156, 158, TFC_LENC_ROW_A(32), NP1) \
+  "s_waitcnt lgkmcnt(2)\n\t" \
+  TFC_LENC_A(126, 148, 149, 176, 178, TFC_LENC_ROW_B(48), NP2) \
+  "s_waitcnt lgkmcnt(6)\n\t" \
+  TFC_LENC_B(152, 153, 154, 155, PRE0) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(127, 150, 151, 152, 154, TFC_LENC_ROW_A(64), NP0) \
+  "s_waitcnt lgkmcnt(7)\n\t" \
+  TFC_LENC_B(156, 157, 158, 159, PRE1) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(128, 148, 149, 156, 158, TFC_LENC_ROW_B(80), NP1) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(176, 177, 178, 179, PRE2) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(129, 150, 151, 176, 178, TFC_LENC_ROW_A(96), NP2) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(152, 153, 154, 155, PRE0) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(130, 148, 149, 152, 154, TFC_LENC_ROW_B(112), NP0) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(156, 157, 158, 159, PRE1) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(131, 150, 151, 156, 158, TFC_LENC_ROW_A(128), NP1) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(176, 177, 178, 179, PRE2) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(132, 148, 149, 176, 178, TFC_LENC_ROW_B(144), NP2) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(152, 153, 154, 155, PRE0) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(133, 150, 151, 152, 154, TFC_LENC_ROW_A(160), NP0) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(156, 157, 158, 159, PRE1) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(134, 148, 149, 156, 158, TFC_LENC_ROW_B(176), NP1) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(176, 177, 178, 179, PRE2) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(135, 150, 151, 176, 178, TFC_LENC_ROW_A(192), NP2) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(152, 153, 154, 155, PRE0) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(136, 148, 149, 152, 154, TFC_LENC_ROW_B(208), NP0) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(156, 157, 158, 159, PRE1) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(137, 150, 151, 156, 158, TFC_LENC_ROW_A(224), NP1) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(176, 177, 178, 179, PRE2) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(138, 148, 149, 176, 178, TFC_LENC_ROW_B(240), NP2) \
+  "s_waitcnt lgkmcnt(8)\n\t" \
+  TFC_LENC_B(152, 153, 154, 155, PRE0) \
+  "s_waitcnt lgkmcnt(3)\n\t" \
+  TFC_LENC_A(139, 150, 151, 152, 154, "", NP0) \
+  "s_waitcnt lgkmcnt(7)\n\t" \
+  TFC_LENC_B(156, 157, 158, 159, PRE1) \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  TFC_LENC_B(176, 177, 178, 179, PRE2) \
+  "s_waitcnt lgkmcnt(2)\n\t" \
+  TFC_LENC_B(152, 153, 154, 155, PRE0) \
+  "s_mov_b64 exec, s[56:57]\n\t" \
   "s_waitcnt lgkmcnt(0)\n\t"
 
 template <bool INDEXED, typename Src>
@@ -370,8 +410,10 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
   const int64_t pos0 = (live ? s : 0) * jobs.elems;
 
   uint4 st = live ? J.state[s] : make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
-  unsigned int base = st.x, s1 = st.y, pd = st.z, pb = st.w;
-  lanes_pin(base, s1, pd, pb);
+  // (base, span - 1, held digit | valid << 31, 0xFFFF digits held behind it): the wave-per-stream fast
+  // encoder's state form (range_encoder_fast.h, FastEncState)
+  unsigned int base = st.x, s1 = st.y, hd = st.z & 0xFFFFu, had = st.z >> 31, rn = st.w;
+  lanes_pin(base, s1, hd, rn);
 
   // the kernel's dynamic LDS starts at LDS address lds0 (0 unless static LDS ever gets added)
   const unsigned int lds0 = static_cast<unsigned int>(reinterpret_cast<size_t>(
@@ -437,33 +479,42 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
 
   // one coder call on [lo, hi) / 2^16 for the lanes with `act`
   auto call = [&](unsigned int lo, unsigned int hi, bool act) __attribute__((always_inline)) {
-    // ---- RangeEncoder::Encode (range_coder.cc:37-264) on [lo, hi) / 2^16; pd = delay_ & 0xFFFF
-    // (0: state 0), pb = delay_ >> 16; every update is a select on `act` --------------------------------
+    // ---- RangeEncoder::Encode (range_coder.cc:37-264) on [lo, hi) / 2^16 with the delayed digits kept as
+    // (held digit hd, had, run rn of 0xFFFF digits behind it) — the single-call case of consume_calls() in
+    // range_encoder_fast.h, every update a select on `act` --------------------------------------------
     const unsigned int a = scale16(s1, lo);
     const unsigned int b = scale16(s1, hi) - 1u;
-    const unsigned int base1 = base + a;
-    const unsigned int s11 = b - a;
-    const bool wrapped = base1 < a;
-    const bool st1 = static_cast<unsigned int>(base1 + s11) < base1;      // the carry is (still) undecided
-    const bool ren = act && (s11 >> 16) == 0u;
-    // state 1 -> 0: the delayed digit is decided (and the run of 0x0000 / 0xFFFF digits behind it)
-    const bool resolve = act && !st1 && pd != 0u;
-    put(wrapped ? pd : pd - 1u, resolve);
-    if (__any(resolve && pb != 0u)) {
-      if (resolve && pb != 0u) put_run(wrapped ? 0u : 0xFFFFu, pb);
+    const unsigned int bs = base + a;
+    const unsigned int t1 = b - a;
+    const bool carry = act && bs < a;                   // base + a left 32 bits: +1 into the held digits
+    const bool ren = act && (t1 >> 16) == 0u;
+    const unsigned int e = bs >> 16;                    // the digit a renormalisation shifts out
+    const bool solid = ren && e != 0xFFFFu;
+    const bool ffff = ren && e == 0xFFFFu;
+    const bool held = had != 0u;
+    const unsigned int X = (hd + (carry ? 1u : 0u)) & 0xFFFFu;
+    // X leaves when a digit that cannot pass a carry on arrives behind it, or when the carry has arrived
+    // (a new 0xFFFF digit directly behind a held digit without a run only joins it: [X][FFFF])
+    const bool emit = held && (solid || (carry && (!ffff || rn != 0u)));
+    put(X, emit);
+    // ... followed by the run behind it: 0xFFFF digits as they are, or 0x0000 if the carry went through
+    // them (with a new 0xFFFF digit arriving, the last of them stays held as 0x0000)
+    const unsigned int run_out = !held ? 0u : solid ? rn : (carry && rn != 0u) ? (ffff ? rn - 1u : rn) : 0u;
+    if (__any(run_out != 0u)) {
+      if (run_out != 0u) put_run(carry ? 0u : 0xFFFFu, 2u * run_out);
     }
-    pd = resolve ? 0u : pd;
-    pb = resolve ? 0u : pb;
-    // renormalisation
-    const unsigned int top = base1 >> 16;
-    const unsigned int base2 = ren ? base1 << 16 : base1;
-    const unsigned int s12 = ren ? (s11 << 16) | 0xFFFFu : s11;
-    const bool st1r = static_cast<unsigned int>(base2 + s12) < base2;     // state after the shift
-    put(top, ren && !st1 && !st1r);
-    pd = (ren && !st1 && st1r) ? top + 1u : pd;
-    pb = (ren && st1) ? pb + 2u : pb;
-    base = act ? base2 : base;
-    s1 = act ? s12 : s1;
+    if (solid) {
+      hd = e; had = 1u; rn = 0u;
+    } else if (ffff) {
+      if (!held) { hd = 0xFFFFu; had = 1u; rn = 0u; }
+      else if (!carry) { rn += 1u; }
+      else if (rn == 0u) { hd = X; rn = 1u; }
+      else { hd = 0u; rn = 1u; }
+    } else if (carry && held) {
+      had = 0u; rn = 0u;
+    }
+    base = act ? (ren ? bs << 16 : bs) : base;
+    s1 = act ? (ren ? (t1 << 16) | 0xFFFFu : t1) : s1;
   };
 
   // one generic step: any lane state
@@ -547,25 +598,29 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
     }
     const bool busy = j < elems || qn != 0u;
     if (__builtin_expect(kFastBlock && lds0 == 0u && !__any(busy && (j + kEncCadence > elems || qn != 0u)), 1)) {
-      const unsigned int base0 = base, s10 = s1, pd0 = pd, pb0 = pb;
-      unsigned int flag = 0u, na = ds_off, cnt = 0u;
+      const unsigned int base0 = base, s10 = s1, hd0 = hd, had0 = had;
+      unsigned int flag = rn, na = ds_off, cnt = 0u;           // a lane inside a 0xFFFF run: generic steps
       if (busy) {
         const unsigned int vp = vw_off + (j * 4u - vw.base);
         // the plain block until this wave has met its first exception, the freezing one afterwards
 #define TFC_LENC_OPERANDS                                                                                          \
-                     : [BASE] "+v"(base), [S] "+v"(s1), [PD] "+v"(pd), [PB] "+v"(pb), [NA] "+v"(na), [FLAG] "+v"(flag), \
+                     : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na), [FLAG] "+v"(flag), \
                        [CNT] "+v"(cnt)                                                                                \
                      : [VP] "v"(vp), [DIRP] "v"(dirp), [DIR0] "v"(0u), [K64K] "s"(0x10000u),                          \
                        [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)                                                  \
-                     : "vcc", "memory", "s52", "s53", "s56", "s57", "s58", "s59", "s60", "s61", "v140", "v141", "v142", \
+                     : "vcc", "memory", "s52", "s53", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v176", "v177", \
+                       "v178", "v179", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", \
+                       "v136", "v137", "v138", "v139", "v140", "v141", "v142", \
                        "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", \
                        "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", \
                        "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175"
         if constexpr (kFreeze) {
-          asm volatile(TFC_LENC_BLOCK(TFC_LENC_NP_FREEZE0, TFC_LENC_NP_FREEZE1, TFC_LENC_PRE_FREEZE0, TFC_LENC_PRE_FREEZE1)
+          asm volatile(TFC_LENC_BLOCK(TFC_LENC_NP_FREEZE0, TFC_LENC_NP_FREEZE1, TFC_LENC_NP_FREEZE2,
+                                      TFC_LENC_PRE_FREEZE0, TFC_LENC_PRE_FREEZE1, TFC_LENC_PRE_FREEZE2)
                        TFC_LENC_OPERANDS);
         } else {
-          asm volatile(TFC_LENC_BLOCK(TFC_LENC_NP_PLAIN, TFC_LENC_NP_PLAIN, TFC_LENC_PRE_PLAIN, TFC_LENC_PRE_PLAIN)
+          asm volatile(TFC_LENC_BLOCK(TFC_LENC_NP_PLAIN, TFC_LENC_NP_PLAIN, TFC_LENC_NP_PLAIN,
+                                      TFC_LENC_PRE_PLAIN, TFC_LENC_PRE_PLAIN, TFC_LENC_PRE_PLAIN)
                        TFC_LENC_OPERANDS);
           cnt = kEncCadence;
         }
@@ -615,21 +670,22 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
         call(lo, hi, stopped);
         // The bits: one call per round on [0, 2^15) or [2^15, 2^16), i.e. a = 0 / half, b = half - 1 / s1 with
         // half = (s1 + 1) >> 1; the interval update is the block's (TFC_LENC_B).  Hand-written: the compiler's
-        // version of this loop takes about twice the instructions.  EXEC drops a lane when its code is
-        // complete or its digit area has no room for two more digits; a lane with a carry run pending
-        // (pb != 0: its resolution may need put_run) does not enter / leaves and goes on in the generic steps.
-        if (qn != 0u && n + 4u <= kEncDigitBytes && pb == 0u) {
+        // version of this loop takes about twice the instructions.  A round is computed into temporaries and
+        // committed under EXEC: a lane whose round would shift out a 0xFFFF digit (it opens a run) drops out
+        // BEFORE the commit and takes that bit in the generic steps; EXEC also drops a lane when its code is
+        // complete or its digit area has no room for another digit.  A lane inside a run does not enter.
+        if (qn != 0u && n + 4u <= kEncDigitBytes && rn == 0u) {
           unsigned int na2 = ds_off + n;
           asm volatile(
               "s_mov_b64 s[56:57], exec\n\t"
               "v_mov_b32 v108, %[G]\n\t"
               "v_mov_b32 v109, 0\n\t"
               "1:\n\t"
-              "v_add_u32 %[QN], -1, %[QN]\n\t"
-              "v_add_u32 v110, -1, %[QN]\n\t"
-              "v_lshrrev_b64 v[110:111], v110, v[108:109]\n\t"       // bit qn - 1 of g (0 from bit 32 on)
+              "v_add_u32 v106, -1, %[QN]\n\t"                        // qn - 1 (committed below)
+              "v_add_u32 v110, -1, v106\n\t"
+              "v_lshrrev_b64 v[110:111], v110, v[108:109]\n\t"       // bit qn - 2 of g (0 from bit 32 on)
               "v_and_b32 v110, 1, v110\n\t"
-              "v_cmp_eq_u32 vcc, 0, %[QN]\n\t"
+              "v_cmp_eq_u32 vcc, 0, v106\n\t"
               "v_cndmask_b32 v110, v110, %[NEG], vcc\n\t"            // ... the sign at the end
               "v_lshrrev_b32 v101, 1, %[S]\n\t"
               "v_and_b32 v102, 1, %[S]\n\t"
@@ -638,56 +694,48 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
               "v_cndmask_b32 v160, 0, v101, vcc\n\t"                 // a
               "v_add_u32 v162, -1, v101\n\t"
               "v_cndmask_b32 v162, v162, %[S], vcc\n\t"              // b
-              "v_add_co_u32 v164, vcc, %[BASE], v160\n\t"
-              "v_addc_co_u32 v167, vcc, -1, %[PD], vcc\n\t"
-              "v_sub_u32 v165, v162, v160\n\t"
-              "v_add_co_u32 v166, vcc, v164, v165\n\t"
-              "v_cndmask_b32 v168, %[PD], %[DIR0], vcc\n\t"
-              "v_cndmask_b32 v173, 1, 0, vcc\n\t"
-              "v_perm_b32 v167, 0, v167, %[PERM]\n\t"
-              "ds_write_b16 %[NA], v167\n\t"
-              "v_min_u32 v169, 1, v168\n\t"
-              "v_lshl_add_u32 %[NA], v169, 1, %[NA]\n\t"
-              "v_sub_u32 %[PD], %[PD], v168\n\t"
-              "v_cmp_gt_u32 vcc, %[K64K], v165\n\t"
-              "v_lshlrev_b32 v168, 16, v164\n\t"
-              "v_lshl_or_b32 v169, v165, 16, %[KFFFF]\n\t"
-              "v_cndmask_b32 %[BASE], v164, v168, vcc\n\t"
-              "v_cndmask_b32 %[S], v165, v169, vcc\n\t"
+              "v_add_co_u32 v164, vcc, %[BASE], v160\n\t"            // bs, carry
+              "v_addc_co_u32 v167, vcc, 0, %[H], vcc\n\t"            // X = H + c
+              "v_sub_u32 v165, v162, v160\n\t"                       // t1
+              "v_sub_u32 v173, v167, %[H]\n\t"                       // c
+              "v_lshrrev_b32 v169, 16, v164\n\t"                     // e
+              "v_cmp_gt_u32 vcc, %[K64K], v165\n\t"                  // r
+              "v_cmp_eq_u32 s[54:55], %[KFFFF], v169\n\t"
+              "s_and_b64 s[54:55], s[54:55], vcc\n\t"                // r & e == 0xFFFF: not in here
+              "s_andn2_b64 exec, exec, s[54:55]\n\t"
               "v_cndmask_b32 v174, 0, 1, vcc\n\t"
-              "v_add_co_u32 v166, vcc, %[BASE], %[S]\n\t"
-              "v_lshrrev_b32 v169, 16, v164\n\t"
-              "v_and_b32 v168, v174, v173\n\t"
-              "v_cndmask_b32 v175, 1, 0, vcc\n\t"
-              "v_sub_u32 v174, v174, v168\n\t"
-              "v_lshl_add_u32 %[PB], v174, 1, %[PB]\n\t"
-              "v_perm_b32 v166, 0, v169, %[PERM]\n\t"
+              "v_perm_b32 v166, 0, v167, %[PERM]\n\t"
               "ds_write_b16 %[NA], v166\n\t"
-              "v_and_b32 v175, v168, v175\n\t"
-              "v_lshl_add_u32 %[NA], v175, 1, %[NA]\n\t"
-              "v_sub_u32 v168, v168, v175\n\t"
-              "v_add_u32 v169, 1, v169\n\t"
-              "v_mad_u32_u24 %[PD], v168, v169, %[PD]\n\t"
+              "v_or_b32 v168, v173, v174\n\t"
+              "v_and_b32 v168, v168, %[HAD]\n\t"
+              "v_lshl_add_u32 %[NA], v168, 1, %[NA]\n\t"
+              "v_lshlrev_b32 v170, 16, v164\n\t"
+              "v_lshl_or_b32 v171, v165, 16, %[KFFFF]\n\t"
+              "v_cndmask_b32 %[BASE], v164, v170, vcc\n\t"
+              "v_cndmask_b32 %[S], v165, v171, vcc\n\t"
+              "v_cndmask_b32 %[H], %[H], v169, vcc\n\t"
+              "v_or_b32 v175, %[HAD], v174\n\t"
+              "v_bfi_b32 %[HAD], v173, v174, v175\n\t"
+              "v_mov_b32 %[QN], v106\n\t"
               "v_cmp_ne_u32 s[54:55], 0, %[QN]\n\t"
               "v_sub_u32 v107, %[NA], %[DSOFF]\n\t"
               "v_cmp_ge_u32 vcc, %[ROOM], v107\n\t"
-              "s_and_b64 s[54:55], s[54:55], vcc\n\t"
-              "v_cmp_eq_u32 vcc, 0, %[PB]\n\t"
               "s_and_b64 s[54:55], s[54:55], vcc\n\t"
               "s_and_b64 exec, exec, s[54:55]\n\t"
               "s_cbranch_execnz 1b\n\t"
               "s_mov_b64 exec, s[56:57]\n\t"
               "s_waitcnt lgkmcnt(0)\n\t"
-              : [BASE] "+v"(base), [S] "+v"(s1), [PD] "+v"(pd), [PB] "+v"(pb), [NA] "+v"(na2), [QN] "+v"(qn)
-              : [G] "v"(g), [NEG] "v"(neg), [DSOFF] "v"(ds_off), [DIR0] "v"(0u), [ROOM] "s"(kEncDigitBytes - 4u),
+              : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na2), [QN] "+v"(qn)
+              : [G] "v"(g), [NEG] "v"(neg), [DSOFF] "v"(ds_off), [ROOM] "s"(kEncDigitBytes - 4u),
                 [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)
-              : "vcc", "memory", "s54", "s55", "s56", "s57", "v101", "v102", "v107", "v108", "v109", "v110", "v111",
-                "v160", "v162", "v164", "v165", "v166", "v167", "v168", "v169", "v173", "v174", "v175");
+              : "vcc", "memory", "s54", "s55", "s56", "s57", "v101", "v102", "v106", "v107", "v108", "v109", "v110",
+                "v111", "v160", "v162", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v173", "v174",
+                "v175");
           n = na2 - ds_off;
         }
         continue;
       }
-      base = base0; s1 = s10; pd = pd0; pb = pb0;                   // an exception somewhere in the wave
+      base = base0; s1 = s10; hd = hd0; had = had0;                 // an exception somewhere in the wave (rn is not touched by the block)
     }
 #pragma nounroll
     for (unsigned int k = 0; k < kEncCadence; ++k) step();
@@ -698,7 +746,7 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
   if constexpr (kFastBlock) run(std::true_type{});
   flush();
   if (live) {
-    J.state[s] = make_uint4(base, s1, pd, pb);
+    J.state[s] = make_uint4(base, s1, (hd & 0xFFFFu) | (had << 31), rn);
     J.chunk_len[s] = wpos;
     if (overflow) atomicOr(J.overflow_flag, 1u);
   }
@@ -708,7 +756,8 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
 // Decoder
 // ---------------------------------------------------------------------------------------------
 
-constexpr unsigned int kDecCadence = 8;
+constexpr unsigned int kDecCadence = 16;
+static_assert(kEncCadence <= kLaneDirRepeat && kDecCadence <= kLaneDirRepeat, "a block reads cadence consecutive directory entries");
 
 // LDS of one decoder wave: per lane the code-byte window (a step consumes <= 2 bytes), the decoded
 // elements of one cadence, and the index window.
@@ -799,6 +848,7 @@ struct DecWaveLds {
 #define TFC_LDEC_ESC2_FREEZE "s_andn2_b64 exec, exec, s[54:55]\n\tv_add_u32 %[CNT], 1, %[CNT]\n\t"
 #define TFC_LDEC_READ_A(OFF) "ds_read_b128 v[100:103], %[DIRP] offset:" #OFF "\n\t"
 #define TFC_LDEC_READ_B(OFF) "ds_read_b128 v[104:107], %[DIRP] offset:" #OFF "\n\t"
+// kDecCadence steps (rows alternate between the two 4-register buffers, the next row is requested a step ahead)
 #define TFC_LDEC_BLOCK(ESC1, ESC2)                                                        \
   "s_mov_b64 s[56:57], exec\n\t"                                                          \
   "v_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t"                                           \
@@ -810,7 +860,15 @@ struct DecWaveLds {
   TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(80), 16, ESC1, ESC2)                  \
   TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(96), 20, ESC1, ESC2)                  \
   TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(112), 24, ESC1, ESC2)                 \
-  TFC_LDEC_STEP(104, 105, 106, 107, "", 28, ESC1, ESC2)                                   \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(128), 28, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(144), 32, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(160), 36, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(176), 40, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(192), 44, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(208), 48, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(104, 105, 106, 107, TFC_LDEC_READ_A(224), 52, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(240), 56, ESC1, ESC2)                 \
+  TFC_LDEC_STEP(104, 105, 106, 107, "", 60, ESC1, ESC2)                                   \
   "s_mov_b64 exec, s[56:57]\n\t"                                                          \
   "s_waitcnt lgkmcnt(0)\n\t"
 
