@@ -247,8 +247,8 @@ def pmc_traffic(kernel_substring, profile, sources, steps_per_launch=None):
     return None
 
 
-PMC_PROFILE = "r02_pmc_traffic.json"
-SQ_PROFILE = "r02_sq_inflight.json"
+PMC_PROFILE = "r03_pmc_traffic.json"
+SQ_PROFILE = "r03_sq_inflight.json"
 
 
 def valu_issue_floor(ms_per_step, kernels, steps_per_launch):

@@ -691,8 +691,10 @@ __global__ void dec_fast_kernel(DecParams p, Dst dst) {
                      TFC_DEC_OPERANDS(st, hi_cur, outv, row.x, w.reg, lane4, lane, vzero, vsixteen, sx, dg, L));
         reassert_uniform(st);
         outv &= 63;   // no-op for symbols of narrow rows; keeps damaged input inside the row range
-      } else if (widemask == ~0ull) {
-        // every row of the batch is wide (e.g. one wide prior for all channels): the branch-free two-stage run
+      } else if (__popcll(widemask) >= 24) {
+        // mostly wide rows (one wide prior for all channels, or the upper channels of the bench tables): the
+        // branch-free two-stage run for the whole batch — a narrow row goes through it as chunk size 1 —
+        // beats a taken branch out of line and back per wide symbol once a third of the batch is wide
         unsigned int sx, dg, ck, fs, a0, cc;
         int L;
         reassert_uniform(st);
