@@ -494,14 +494,19 @@ class StepRecord:
         self.strings = None
 
 
-def run_model_steps(model, x, steps, lanes, fetch=True):
+def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
     """`steps` compress + decompress passes over `x`, step k on lanes[k % len(lanes)], all enqueued by this
     one thread with nothing read back inside a step; a lane's previous step is retired (host waits for its
     end event, fetches its strings and sanity flags) before the lane is reused — while the other lanes'
-    steps keep the GPU busy.  Returns (seconds, last record)."""
+    steps keep the GPU busy.  group > 1: `group` steps (differently rolled copies of `x`) are enqueued as one
+    unit through the model's compress_many / decompress_many — one coder launch per direction for all of
+    them.  Returns (seconds, last record)."""
     main = torch.cuda.current_stream()
     pending = [None] * len(lanes)
     last = None
+    assert steps % group == 0
+    units = steps // group
+    xs = [x] if group == 1 else [torch.roll(x, k, 0) for k in range(group)]
 
     def retire(rec):
         if rec.end is not None:
@@ -513,15 +518,24 @@ def run_model_steps(model, x, steps, lanes, fetch=True):
         return rec
 
     t0 = time.perf_counter()
-    for k in range(steps):
+    for k in range(units):
         slot = k % len(lanes)
         if pending[slot] is not None:
             last = retire(pending[slot])
         lane = lanes[slot].begin(main)
-        out = model.compress(x, device_result=True, lane=lane)
-        x_hat, oks = model.decompress(*out, defer_sanity=True, lane=lane)
+        if group == 1:
+            out = model.compress(x, device_result=True, lane=lane)
+            x_hat, oks = model.decompress(*out, defer_sanity=True, lane=lane)
+        else:
+            with lane.on("transform"):
+                packed = model.compress_many(xs)
+                x_hats, ok = model.decompress_many(packed)
+            # the record of the unit: its first batch's handle first (the parity checks look at rec.out[0])
+            out = tuple(p[0] for p in packed)
+            x_hat, oks = x_hats[0], [ok]
+            x_hat._tfc_group = x_hats
         pending[slot] = StepRecord(out, x_hat, oks, lane.end_event())
-    order = [(k % len(lanes)) for k in range(max(0, steps - len(lanes)), steps)]
+    order = [(k % len(lanes)) for k in range(max(0, units - len(lanes)), units)]
     for slot in order:
         if pending[slot] is not None:
             last = retire(pending[slot])
@@ -531,7 +545,7 @@ def run_model_steps(model, x, steps, lanes, fetch=True):
 
 
 def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=2, coder_cus=32,
-                cpu=True, rank=0, world=1, distributed=False, partition="single"):
+                cpu=True, rank=0, world=1, distributed=False, partition="single", group=1):
     """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5)."""
     import torch.distributed as dist
     from compression_amd import parallel, pipeline
@@ -555,12 +569,14 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
         cus = coder_cus if coder_cus > 0 else min(128, max(16, (batch + 3) // 4))
         part = pipeline.CoderPartition(coder_cus=cus, depth=depth, device=device, mode=partition) if depth > 1 else None
         lanes = part.lanes if part else inline
-        run_model_steps(model, x, max(warmup, len(lanes)), lanes)
+        group = group if hasattr(model, "compress_many") else 1
+        steps = max(group, steps - steps % group)
+        run_model_steps(model, x, max(warmup, len(lanes)) * group, lanes, group=group)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
             torch.cuda.synchronize()
-        elapsed, rec = run_model_steps(model, x, steps, lanes)
+        elapsed, rec = run_model_steps(model, x, steps, lanes, group=group)
         gathered = None
         if distributed:
             # the coded strings of the whole batch on every rank: lengths, then padded bytes (two all-gathers)
@@ -581,7 +597,8 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
         want = model.entropy_model.quantize(y_coded) if workload == "bls2017" else torch.round(y_coded.float()).to(y_coded.dtype)
         assert torch.equal(y_decoded, want), "decompress did not return the quantised latents"
         strings = rec.strings
-        nbytes = sum(len(bytes(s)) for arr in strings for s in arr.reshape(-1))
+        counted = strings[:1] if group > 1 else strings          # a group's record holds one string array per batch
+        nbytes = sum(len(bytes(s)) for arr in counted for s in arr.reshape(-1))
         if gathered:
             assert int(gathered[0][1][-1]) >= sum(len(bytes(s)) for s in strings[0].reshape(-1))
         res = None
@@ -596,7 +613,8 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
                 "workload": f"{workload} compress+decompress, {batch} images of {hw[1]}x{hw[0]} per GPU, 192 filters, "
                             f"random-init weights" + (", hyperprior calibrated (scale_index_histogram)" if hist is not None else ""),
                 "dtype": dtype_name,
-                "steps_in_flight": len(lanes),
+                "steps_in_flight": len(lanes) * group,
+                "steps_per_coder_launch": group,
                 "cu_partition": ({"mode": part.mode, "coder_cus": part.coder_cus, "transform_cus": part.total_cus - part.coder_cus}
                                  if part else None),
                 "strings_fetched_to_host_in_timed_region": True,
@@ -672,7 +690,7 @@ def model_workload(args, world, rank, device, distributed):
     res = model_bench(args.workload, args.model_dtype, device, batch=args.batch, steps=args.steps,
                       warmup=args.warmup, depth=max(1, args.model_depth), coder_cus=args.coder_cus,
                       cpu=not args.no_cpu_baseline, rank=rank, world=world, distributed=distributed,
-                      partition=args.partition)
+                      partition=args.partition, group=max(1, args.model_group))
     if rank == 0:
         line = {
             "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
@@ -846,6 +864,10 @@ def main():
                          "at most half the chip)")
     ap.add_argument("--partition", default="single", choices=["masked", "plain", "single", "coder-masked", "transform-masked"],
                     help="streams of a model pipeline lane: CU-masked pair, ordinary pair, or one ordinary stream")
+    ap.add_argument("--model-group", type=int, default=1,
+                    help="batches per coder launch where the model has compress_many (bls2017): the lane-per-stream "
+                         "kernels code them in one launch per direction where the tables' image fits the LDS (the "
+                         "random-init bls2017 tables do not: 172 KB); 1 = every batch its own launch")
     ap.add_argument("--model-steps", type=int, default=6, help="timed steps of the `models` sub-objects")
     args = ap.parse_args()
 
@@ -996,9 +1018,11 @@ def main():
             out["models"] = {}
             for name, key in (("bls2017", "c1"), ("bmshj2018", "c4")):
                 torch.cuda.empty_cache()
-                out["models"][key] = model_bench(name, args.model_dtype, device, steps=args.model_steps, warmup=2,
-                                                 depth=max(1, args.model_depth), coder_cus=args.coder_cus,
-                                                 cpu=not args.no_cpu_baseline, partition=args.partition)
+                out["models"][key] = model_bench(name, args.model_dtype, device,
+                                                 steps=max(args.model_steps, 2 * max(1, args.model_group)),
+                                                 warmup=2, depth=max(1, args.model_depth), coder_cus=args.coder_cus,
+                                                 cpu=not args.no_cpu_baseline, partition=args.partition,
+                                                 group=max(1, args.model_group))
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -210,6 +210,67 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             raise RuntimeError("Sanity check failed.")
         return out
 
+    # ------------------------------------------------------------------ several batches per launch
+    def _symbols(self, bottleneck, cdf_offset, qoff_native):
+        """int32 symbols of continuous_batched.py:370-380 as tensor ops (the `*_many` path hands the coder
+        plain symbols: the lane-per-stream kernels' hand-scheduled blocks take int32 in channel mode)."""
+        if qoff_native is not None:
+            bottleneck = bottleneck - qoff_native
+        symbols = torch.round(bottleneck.float()).to(torch.int32)
+        iid = bottleneck.shape[:bottleneck.dim() - len(self.prior_shape)] if len(self.prior_shape) else bottleneck.shape
+        return (symbols.reshape(tuple(iid) + (-1,)) - cdf_offset).reshape(bottleneck.shape).contiguous()
+
+    def compress_many(self, bottlenecks):
+        """compress() of several independent batches (same shape) with ONE coder launch: the batches'
+        code streams share the lane-per-stream kernels' grid (tfc_encoder_encode_many), whose running time
+        is set by the symbols per stream, not by the number of streams, until every SIMD holds a wave — the
+        way a server that has several batches in flight fills the chip.  Nothing is read back: returns one
+        finalized encoder handle per batch (`gen_ops.fetch_strings`, `decompress_many`).  Same strings as
+        compress() batch by batch."""
+        self._check_compression()
+        device = _lib.require_device()
+        bottlenecks = [torch.as_tensor(b).to(device, self.bottleneck_dtype).contiguous() for b in bottlenecks]
+        if not bottlenecks:
+            return []
+        shape = tuple(bottlenecks[0].shape)
+        if any(tuple(b.shape) != shape for b in bottlenecks):
+            raise ValueError("compress_many: all bottlenecks must have the same shape")
+        batch_shape = shape[:len(shape) - self.coding_rank] if self.coding_rank else shape
+        cdf_offset, _, qn = self._device_tables(device)
+        symbols = [self._symbols(b, cdf_offset, qn) for b in bottlenecks]
+        handles = gen_ops.create_range_encoders(len(symbols), batch_shape, self.cdf, mode="throughput",
+                                                deferred_errors=True)
+        handles = gen_ops.entropy_encode_channel_many(handles, symbols)
+        handles = gen_ops.entropy_encode_finalize_device_many(handles)
+        for h, b, sym in zip(handles, bottlenecks, symbols):
+            h.coder_inputs = (b, None)
+            h._keep += [b, sym]
+        return handles
+
+    def decompress_many(self, handles, broadcast_shape):
+        """decompress() for the handles of compress_many (or any finalized encoder handles of one shape): one
+        decoder launch for all of them; returns ([values per batch], ok) with `ok` the device-resident
+        EntropyDecodeFinalize flags [len(handles), *batch_shape] — nothing is read back."""
+        self._check_compression()
+        device = _lib.require_device()
+        handles = list(handles)
+        if not handles:
+            return [], None
+        broadcast_shape = tuple(int(s) for s in broadcast_shape)
+        channels = int(self.prior_shape.numel())
+        cdf_offset, _, qn = self._device_tables(device)
+        decoders = gen_ops.create_range_decoders(handles, self.cdf, mode="throughput")
+        decoders, symbols = gen_ops.entropy_decode_channel_many(decoders, broadcast_shape + (channels,), torch.int32)
+        ok = gen_ops.entropy_decode_finalize_device_many(decoders)
+        ok._tfc_handle = decoders
+        outs = []
+        for h, sym in zip(handles, symbols):
+            out = (sym + cdf_offset).reshape(tuple(h.shape) + broadcast_shape + tuple(self.prior_shape)).to(self.bottleneck_dtype)
+            if qn is not None:
+                out = out + qn
+            outs.append(out)
+        return outs, ok
+
     def get_config(self):
         config = super().get_config()
         config.update(prior_shape=tuple(map(int, self.prior_shape)),

@@ -111,6 +111,29 @@ class BLS2017Model(torch.nn.Module):
         return (x_hat, ok) if defer_sanity else x_hat
 
 
+    @torch.no_grad()
+    def compress_many(self, xs):
+        """compress() of several batches with one coder launch (ContinuousBatchedEntropyModel.compress_many):
+        [(handle, x_shape, y_shape)] — the handles keep the strings in HBM."""
+        ys = [self.analysis_transform((x if x.dim() == 4 else x[None]).to(self.compute_dtype)) for x in xs]
+        handles = self.entropy_model.compress_many(ys)
+        return [(h, tuple(x.shape[-3:-1]), tuple(y.shape[1:-1])) for h, x, y in zip(handles, xs, ys)]
+
+    @torch.no_grad()
+    def decompress_many(self, packed):
+        """decompress() for the results of compress_many: ([x_hat per batch], ok flags on the device)."""
+        packed = list(packed)
+        handles = [p[0] for p in packed]
+        y_hats, ok = self.entropy_model.decompress_many(handles, packed[0][2])
+        outs = []
+        for (h, x_shape, y_shape), y_hat in zip(packed, y_hats):
+            x_hat = self.synthesis_transform(y_hat)[:, :x_shape[0], :x_shape[1], :]
+            x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            x_hat._tfc_keep = (y_hat,)
+            outs.append(x_hat)
+        return outs, ok
+
+
 if __name__ == "__main__":      # python -m compression_amd.models.bls2017 compress in.png out.tfci
     import sys
 

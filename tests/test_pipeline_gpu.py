@@ -149,3 +149,20 @@ def test_cu_partition_masks():
     lane.join()
     assert float(a.sum()) == 2.0 * (1 << 20)
     part.close()
+
+
+def test_compress_many_equals_batch_by_batch():
+    """Several batches through ONE coder launch per direction (lane-per-stream kernels): the strings and the
+    reconstructions of compress() / decompress() batch by batch."""
+    torch.manual_seed(0)
+    model = tfc.models.BLS2017Model(num_filters=64, compute_dtype=torch.bfloat16).cuda().init_compression()
+    xs = [torch.from_numpy(synthetic.lowpass_images(6, 64, 96, seed=20 + k)).cuda() for k in range(5)]
+    plain = [model.compress(x) for x in xs]
+    want = [model.decompress(*p) for p in plain]
+    packed = model.compress_many(xs)
+    x_hats, ok = model.decompress_many(packed)
+    assert bool(ok.cpu().all()) and tuple(ok.shape) == (5, 6)
+    for k in range(5):
+        assert [bytes(s) for s in tfc.fetch_strings(packed[k][0])] == [bytes(s) for s in plain[k][0]]
+        assert packed[k][1:] == plain[k][1:]
+        assert torch.equal(x_hats[k], want[k])
