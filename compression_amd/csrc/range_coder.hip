@@ -337,9 +337,11 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
         d.info = static_cast<unsigned int>(esc ? nsym - 1 : nsym) | (esc ? 0x80000000u : 0u);
         for (int k = 0; k <= nsym; ++k) cdf16[ce + k] = static_cast<uint16_t>(cdf[k] << (16 - prec));
         for (int k = 0; k < nsym; ++k) bits[wo + (cdf[k] >> 6)] |= uint64_t{1} << (cdf[k] & 63);
+        // per word: the boundaries before it MINUS ONE, as int16 (rank - 1 = symbol: the decoder adds the
+        // popcount inside the word and has the symbol; -1 for the first word)
         unsigned int run = 0;
         for (size_t w = 0; w < nw; ++w) {
-          cum[wo + w] = static_cast<uint16_t>(run);
+          cum[wo + w] = static_cast<uint16_t>(static_cast<int16_t>(static_cast<int>(run) - 1));
           run += static_cast<unsigned int>(__builtin_popcountll(bits[wo + w]));
         }
         ce += static_cast<size_t>(nsym + 1);

@@ -797,27 +797,25 @@ struct DecWaveLds {
   "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
   "v_cvt_f32_u32 v111, %[S]\n\t"                                                          \
   "v_rcp_f32 v111, v111\n\t"                                                              \
-  "v_add_f32 v110, 0.5, v110\n\t"                                                         \
+  "v_fma_f32 v110, v110, %[SCALE], %[HSCALE]\n\t"                                         \
   "s_nop 0\n\t"                                                                           \
   "v_mul_f32 v110, v110, v111\n\t"                                                        \
-  "v_mul_f32 v110, %[SCALE], v110\n\t"                                                    \
   "v_cvt_u32_f32 v110, v110\n\t"                                                          \
   "v_min_u32 v110, %[QMAX], v110\n\t"                                                     \
   "v_lshrrev_b32 v111, 6, v110\n\t"                                                       \
   "v_lshl_add_u32 v112, v111, 3, v" #ROW2 "\n\t"                                          \
   "v_lshl_add_u32 v113, v111, 1, v" #ROW3 "\n\t"                                          \
   "ds_read_b64 v[114:115], v112\n\t"                                                      \
-  "ds_read_u16 v116, v113\n\t"                                                            \
+  "ds_read_i16 v116, v113\n\t"                                                            \
   "v_not_b32 v110, v110\n\t"                                                              \
   "s_waitcnt lgkmcnt(0)\n\t"                                                              \
   "v_lshlrev_b64 v[118:119], v110, v[114:115]\n\t"                                        \
   "v_bcnt_u32_b32 v116, v118, v116\n\t"                                                   \
-  "v_bcnt_u32_b32 v116, v119, v116\n\t"                                                   \
-  "v_lshl_add_u32 v112, v116, 1, v" #ROW0 "\n\t"                                          \
-  "ds_read_u16 v122, v112\n\t"                                                            \
-  "ds_read_u16 v124, v112 offset:2\n\t"                                                   \
-  "v_xor_b32 v113, 0x80000000, v" #ROW1 "\n\t"                                            \
-  "v_add_u32 v117, -1, v116\n\t"                                                          \
+  "v_bcnt_u32_b32 v117, v119, v116\n\t"                                                   \
+  "v_lshl_add_u32 v112, v117, 1, v" #ROW0 "\n\t"                                          \
+  "ds_read_u16 v122, v112 offset:2\n\t"                                                   \
+  "ds_read_u16 v124, v112 offset:4\n\t"                                                   \
+  "v_xad_u32 v113, v117, v" #ROW1 ", %[K31]\n\t"                                          \
   ESC1                                                                                    \
   "ds_write_b32 %[OQ], v117 offset:" #OUTOFF "\n\t"                                       \
   "v_perm_b32 v109, 0, v109, %[PERM]\n\t"                                                 \
@@ -842,9 +840,9 @@ struct DecWaveLds {
   ESC2
 // an escape symbol: (plain variant) bump FLAG, the whole block is repeated generically / (freezing variant)
 // remember the lanes, let them finish this step, then take them out of the rest of the block
-#define TFC_LDEC_ESC1_PLAIN "v_cmp_eq_u32 vcc, v117, v113\n\tv_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"
+#define TFC_LDEC_ESC1_PLAIN "v_min_u32 %[ACC], %[ACC], v113\n\t"
 #define TFC_LDEC_ESC2_PLAIN ""
-#define TFC_LDEC_ESC1_FREEZE "v_cmp_eq_u32 s[54:55], v117, v113\n\t"
+#define TFC_LDEC_ESC1_FREEZE "v_cmp_eq_u32 s[54:55], 0, v113\n\t"
 #define TFC_LDEC_ESC2_FREEZE "s_andn2_b64 exec, exec, s[54:55]\n\tv_add_u32 %[CNT], 1, %[CNT]\n\t"
 #define TFC_LDEC_READ_A(OFF) "ds_read_b128 v[100:103], %[DIRP] offset:" #OFF "\n\t"
 #define TFC_LDEC_READ_B(OFF) "ds_read_b128 v[104:107], %[DIRP] offset:" #OFF "\n\t"
@@ -922,6 +920,9 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
   }
 
   const float scale = static_cast<float>(1u << la.precision);     // quotient scale: 2^precision
+  float hscale = 0.5f * scale;                                    // ... and half of it, in vector registers for the block
+  unsigned int k31 = 0x80000000u;
+  asm volatile("" : "+v"(hscale), "+v"(k31));
   const unsigned int cp_max = (1u << la.precision) - 1u;
   const unsigned int dir_end = 16u * static_cast<unsigned int>(la.ntab);
   const unsigned int dir_step = (16u * kDecCadence) % dir_end;
@@ -1013,9 +1014,10 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         const unsigned int q = min(static_cast<unsigned int>(fq), cp_max);
         const unsigned int w = q >> 6;
         const unsigned long long word = *reinterpret_cast<const unsigned long long*>(lanes_lds + row.z + 8u * w);
-        const unsigned int cum = lds_u16(lanes_lds, row.w + 2u * w);
+        // boundaries before word w, minus one (int16): symbol = that + the boundaries up to q in the word
+        const int cum_m1 = *reinterpret_cast<const short*>(lanes_lds + row.w + 2u * w);
         const unsigned long long below = ~0ull >> (63u - (q & 63u));
-        unsigned int sym = cum + static_cast<unsigned int>(__popcll(word & below)) - 1u;
+        unsigned int sym = static_cast<unsigned int>(cum_m1 + __popcll(word & below));
         // ---- exact bounds; the reference's search condition A <= D < B verifies the estimate ----
         unsigned int lo = lds_u16(lanes_lds, row.x + 2u * sym + 2u);
         unsigned int hi = lds_u16(lanes_lds, row.x + 2u * sym + 4u);
@@ -1085,12 +1087,14 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
     if (__builtin_expect(kFastBlock && lds0 == 0u && !__any(j < elems && (j + kDecCadence > elems || mode != 0u)), 1)) {
       const unsigned int D0 = D, s10 = s1, cp0 = cp;
       unsigned int flag = 0u, cnt = 0u;
+      unsigned int acc = 0xFFFFFFFFu;      // plain block: min over the steps of (symbol ^ row info) + 2^31, 0 = an escape symbol
       if (j < elems) {
         // the plain block until this wave has met its first escape symbol, the freezing one afterwards
         // (the freeze costs ~10 % per step: a scalar EXEC update behind a vector compare, and the count)
 #define TFC_LDEC_OPERANDS                                                                                       \
-                     : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [FLAG] "+v"(flag), [CNT] "+v"(cnt)              \
-                     : [DIRP] "v"(dirp), [OQ] "v"(oq_off), [SCALE] "s"(scale), [QMAX] "s"(cp_max),               \
+                     : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [FLAG] "+v"(flag), [CNT] "+v"(cnt), [ACC] "+v"(acc) \
+                     : [DIRP] "v"(dirp), [OQ] "v"(oq_off), [SCALE] "s"(scale), [HSCALE] "v"(hscale), [QMAX] "s"(cp_max), \
+                       [K31] "v"(k31),                                                                             \
                        [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)                       \
                      : "vcc", "memory", "s54", "s55", "s56", "s57", "v100", "v101", "v102", "v103", "v104", "v105", \
                        "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", \
@@ -1101,6 +1105,7 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         } else {
           asm volatile(TFC_LDEC_BLOCK(TFC_LDEC_ESC1_PLAIN, TFC_LDEC_ESC2_PLAIN) TFC_LDEC_OPERANDS);
           cnt = kDecCadence;
+          flag += acc == 0u ? 1u : 0u;
         }
 #undef TFC_LDEC_OPERANDS
       }
