@@ -38,6 +38,8 @@ SIGNATURES = {
     "tfc_encoder_encode_many": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
     "tfc_encoder_encode_quantized": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
     "tfc_encoder_encode_quantized_indexed": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _vp]),
+    "tfc_encoder_encode_quantized_many": (_int, [_int, _vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
+    "tfc_decoder_decode_dequantized_many": (_int, [_int, _vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
     "tfc_encoder_finalize": (_int, [_vp, _vp, C.POINTER(_i64)]),
     "tfc_encoder_finalize_device": (_int, [_vp, _vp]),
     "tfc_encoder_finalize_device_many": (_int, [_int, _vp, _vp]),

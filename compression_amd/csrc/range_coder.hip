@@ -1405,6 +1405,17 @@ int select_family(const tfc_tables* t, int mode, int64_t streams, int64_t elems,
   return fast_ok ? kFast : kGeneric;
 }
 
+// Blocks a wave of the lane kernels lets lanes wait in front of an escape code before it takes the codes of all
+// waiting lanes together (LaneArgs::defer; 1 = after every block).
+inline int lanes_escape_defer() {
+  static const int v = [] {
+    const char* e = std::getenv("TFC_ESCAPE_DEFER");
+    const long n = e ? std::strtol(e, nullptr, 10) : 3;
+    return static_cast<int>(n >= 1 && n <= 64 ? n : 3);
+  }();
+  return v;
+}
+
 // Streams per workgroup of the lane kernels: one wave (64 streams) until the launch fills the chip,
 // so that a 512-stream call spreads over eight CUs (and XCDs), then more waves behind each LDS image.
 inline int lanes_block(int64_t streams) {
@@ -1480,7 +1491,7 @@ int encoder_error(tfc_encoder* e, const unsigned long long* host_status) {
 // kMaxLaneJobs of them; no counting pass, no read-back unless a handle wants its range errors now.
 template <typename Src>
 int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int32_t* const* indexes,
-                      int64_t elems, hipStream_t st, bool worst_case_slab = false) {
+                      int64_t elems, hipStream_t st, bool worst_case_slab) {
   constexpr int kMaxLaneJobs = EncLaneJobs<Src>::kMax;
   const tfc_tables* t = es[0]->tables;
   const int64_t streams = es[0]->streams;
@@ -1491,6 +1502,7 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   la.ntab = static_cast<int>(t->rows.size());
   la.precision = t->lane_precision;
   la.cap = lanes_slab_bytes(t, elems, worst_case_slab);
+  la.defer = lanes_escape_defer();
   const bool speculative = t->any_escape && !worst_case_slab;
   std::vector<DevBuf> backups(speculative ? n : 0);     // pre-call coder states of the handles that can retry
   la.lds_image = (t->lane_enc_bytes + 1023) & ~1023;
@@ -1598,6 +1610,69 @@ size_t speculative_slab_bytes(const tfc_tables* t, int64_t streams, int64_t elem
   return bytes;
 }
 
+// ---- fused quantise / dequantise for the lane family ----------------------------------------------
+// The lane kernels' hand-scheduled blocks take plain int32 symbols in channel mode; their generic steps (which
+// convert per element) are ~2.3x slower.  For bottleneck values the conversion therefore runs as its own
+// elementwise pass — HBM-bound, ~25 us for the 25 M elements of config 2 against milliseconds of coding — into a
+// stream-ordered temporary, and the blocks code int32: continuous_batched.py:370-380 / :416-422 at the speed of
+// int32 channel mode (+ the pass).
+// grid = (ceil(elems / 1024), streams): four elements per thread, 256 apart (every access of a wave is one
+// contiguous run); 32-bit index arithmetic — the table of an element is its position in the stream modulo the
+// table count, stepped by 256 mod ntab instead of divided per element
+template <typename T>
+__global__ void __launch_bounds__(256) lanes_quantize_kernel(tfc::SymQuant<T> src, unsigned int elems, unsigned int ntab,
+                                                             int32_t* out) {
+  const unsigned int j0 = blockIdx.x * 1024u + threadIdx.x;
+  const long long base = static_cast<long long>(blockIdx.y) * elems;
+  const unsigned int step = 256u % ntab;
+  unsigned int t = j0 % ntab;
+#pragma unroll
+  for (unsigned int k = 0; k < 4u; ++k) {
+    const unsigned int j = j0 + 256u * k;
+    if (j < elems) out[base + j] = src.quant(src.y[base + j], static_cast<int>(t));
+    t += step;
+    t -= t >= ntab ? ntab : 0u;
+  }
+}
+template <typename Dst>
+__global__ void __launch_bounds__(256) lanes_dequantize_kernel(Dst dst, const int32_t* sym, unsigned int elems,
+                                                               unsigned int ntab) {
+  const unsigned int j0 = blockIdx.x * 1024u + threadIdx.x;
+  const long long base = static_cast<long long>(blockIdx.y) * elems;
+  const unsigned int step = 256u % ntab;
+  unsigned int t = j0 % ntab;
+#pragma unroll
+  for (unsigned int k = 0; k < 4u; ++k) {
+    const unsigned int j = j0 + 256u * k;
+    if (j < elems) dst.store(base + j, static_cast<int>(t), sym[base + j]);
+    t += step;
+    t -= t >= ntab ? ntab : 0u;
+  }
+}
+
+template <typename Src> struct is_plain_symbols : std::false_type {};
+template <> struct is_plain_symbols<tfc::SymInt32> : std::true_type {};
+
+// channel mode, bottleneck values: quantise pass, then the int32 blocks
+template <typename Src>
+int encode_lanes_prequantized(tfc_encoder* const* es, int n, const Src* srcs, int64_t elems, hipStream_t st) {
+  const long long per = static_cast<long long>(es[0]->streams) * elems;
+  const int ntab = static_cast<int>(es[0]->tables->rows.size());
+  DevBuf tmp;
+  TFC_HIP(tmp.alloc(sizeof(int32_t) * static_cast<size_t>(per) * n, st));
+  std::vector<tfc::SymInt32> q(n);
+  for (int k = 0; k < n; ++k) {
+    int32_t* out = tmp.as<int32_t>() + static_cast<long long>(k) * per;
+    hipLaunchKernelGGL((lanes_quantize_kernel<typename Src::raw_type>),
+                       dim3(static_cast<unsigned>(ceil_div(elems, 1024)), static_cast<unsigned>(es[0]->streams)),
+                       dim3(256), 0, st, srcs[k], static_cast<unsigned int>(elems), static_cast<unsigned int>(ntab), out);
+    q[k] = tfc::SymInt32{out};
+  }
+  TFC_HIP(hipGetLastError());
+  return encode_lanes_many(es, n, q.data(), static_cast<const int32_t* const*>(nullptr), elems, st, false);
+  // `tmp` goes back to the pool in stream order, behind the coding launch
+}
+
 int encode_precheck(tfc_encoder* e, int64_t elems) {
   if (e->finalized) return fail("encoder handle was already finalized");
   if (e->poisoned) return fail("encoder handle met a range error in an earlier call");
@@ -1614,7 +1689,12 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   if (t->rows.empty()) return fail("index=0 not in range [0, 0)");
   if (e->family < 0) e->family = select_family(t, e->mode, e->streams, elems, e->fast);
   if (e->family == kLanes && elems >= (int64_t{1} << 29)) return fail("encode call too large for this handle");
-  if (e->family == kLanes) return encode_lanes_many(&e, 1, &src, &index, elems, st);
+  if (e->family == kLanes) {
+    if constexpr (!is_plain_symbols<Src>::value) {
+      if (!index) return encode_lanes_prequantized(&e, 1, &src, elems, st);
+    }
+    return encode_lanes_many(&e, 1, &src, &index, elems, st, false);
+  }
   e->elems_last = elems;
   e->indexed_last = index != nullptr;
 
@@ -1902,7 +1982,7 @@ extern "C" int tfc_encoder_encode_many(int n, tfc_encoder* const* es, const int3
   }
   std::vector<SymInt32> srcs(n);
   for (int k = 0; k < n; ++k) srcs[k] = SymInt32{values[k]};
-  return encode_lanes_many(es, n, srcs.data(), indexes, elems, st);
+  return encode_lanes_many(es, n, srcs.data(), indexes, elems, st, false);
 }
 
 namespace {
@@ -1937,6 +2017,58 @@ extern "C" int tfc_encoder_encode_quantized_indexed(tfc_encoder* e, const void* 
   if (!index) return fail("index is null");
   return dispatch_quantized(e, y, dtype, nullptr, index, cdf_offset, elems,
                             static_cast<hipStream_t>(stream));
+}
+
+namespace {
+template <typename T>
+int encode_quantized_many(int n, tfc_encoder* const* es, const void* const* ys, const float* qoffset,
+                          const int32_t* cdf_offset, int64_t elems, hipStream_t st) {
+  bool batch = elems > 0 && elems < (int64_t{1} << 29);
+  for (int k = 0; k < n; ++k) {
+    tfc_encoder* e = es[k];
+    if (encode_precheck(e, elems)) return 1;
+    e->touch(st);
+    if (e->tables != es[0]->tables || e->streams != es[0]->streams)
+      return fail("tfc_encoder_encode_quantized_many: handles must share tables and stream count");
+    if (e->streams == 0 || e->tables->rows.empty()) batch = false;
+    if (batch && e->family < 0) e->family = select_family(e->tables, e->mode, e->streams * n, elems, e->fast);
+    if (e->family != kLanes) batch = false;
+  }
+  std::vector<tfc::SymQuant<T>> srcs(n);
+  for (int k = 0; k < n; ++k) srcs[k] = tfc::SymQuant<T>{static_cast<const T*>(ys[k]), qoffset, cdf_offset};
+  if (!batch) {
+    for (int k = 0; k < n; ++k)
+      if (run_encode(es[k], nullptr, elems, srcs[k], st)) return 1;
+    return 0;
+  }
+  for (int g0 = 0; g0 < n; g0 += kMaxFinalizeJobs) {      // bounded temporaries: <= 64 batches of symbols at a time
+    const int gn = std::min(kMaxFinalizeJobs, n - g0);
+    for (int k = 0; k < gn; ++k) {
+      es[g0 + k]->elems_last = elems;
+      es[g0 + k]->indexed_last = false;
+    }
+    if (encode_lanes_prequantized(es + g0, gn, srcs.data() + g0, elems, st)) return 1;
+  }
+  return 0;
+}
+}  // namespace
+
+// EntropyEncodeChannel with the quantise prologue for n independent handles (same tables, same geometry) as one
+// coding launch — tfc_encoder_encode_quantized x tfc_encoder_encode_many.
+extern "C" int tfc_encoder_encode_quantized_many(int n, tfc_encoder* const* es, const void* const* ys, int dtype,
+                                                 const float* qoffset, const int32_t* cdf_offset,
+                                                 int64_t channels, int64_t elems, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return 0;
+  if (channels != static_cast<int64_t>(es[0]->tables->rows.size()))
+    return fail("channel count %lld does not match table count %lld",
+                static_cast<long long>(channels), static_cast<long long>(es[0]->tables->rows.size()));
+  switch (dtype) {
+    case 0: return encode_quantized_many<float>(n, es, ys, qoffset, cdf_offset, elems, st);
+    case 1: return encode_quantized_many<__hip_bfloat16>(n, es, ys, qoffset, cdf_offset, elems, st);
+    case 2: return encode_quantized_many<__half>(n, es, ys, qoffset, cdf_offset, elems, st);
+    default: return fail("unsupported dtype code %d", dtype);
+  }
 }
 
 namespace {
@@ -2247,6 +2379,7 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   la.ntab = static_cast<int>(t->rows.size());
   la.precision = t->lane_precision;
   la.cap = 0;
+  la.defer = lanes_escape_defer();
   la.lds_image = (t->lane_dec_bytes + 1023) & ~1023;
   using WaveLds = DecWaveLds<typename Dst::elem>;
   la.lds_wave = indexed ? WaveLds::kBytes : WaveLds::kIndex;
@@ -2278,6 +2411,24 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
     if (indexed) hipLaunchKernelGGL((dec_lanes_kernel<true, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
     else hipLaunchKernelGGL((dec_lanes_kernel<false, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
   }
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+// channel mode, bottleneck outputs: the int32 blocks into a stream-ordered temporary, then the dequantise pass
+template <typename Dst>
+int decode_lanes_dequantized(tfc_decoder* const* ds, int n, const Dst* dsts, int64_t elems, hipStream_t st) {
+  const long long per = static_cast<long long>(ds[0]->streams) * elems;
+  const int ntab = static_cast<int>(ds[0]->tables->rows.size());
+  DevBuf tmp;
+  TFC_HIP(tmp.alloc(sizeof(int32_t) * static_cast<size_t>(per) * n, st));
+  std::vector<OutInt32> outs(n);
+  for (int k = 0; k < n; ++k) outs[k] = OutInt32{tmp.as<int32_t>() + static_cast<long long>(k) * per};
+  if (decode_lanes_many(ds, n, outs.data(), static_cast<const int32_t* const*>(nullptr), elems, st)) return 1;
+  for (int k = 0; k < n; ++k)
+    hipLaunchKernelGGL((lanes_dequantize_kernel<Dst>),
+                       dim3(static_cast<unsigned>(ceil_div(elems, 1024)), static_cast<unsigned>(ds[0]->streams)), dim3(256), 0,
+                       st, dsts[k], outs[k].out, static_cast<unsigned int>(elems), static_cast<unsigned int>(ntab));
   TFC_HIP(hipGetLastError());
   return 0;
 }
@@ -2323,6 +2474,9 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   const int family = decoder_family<typename Dst::elem>(d, d->streams, elems, index != nullptr, fast_ok);
   d->family = family;
   if (family == kLanes) {
+    if constexpr (!std::is_same<Dst, OutInt32>::value) {
+      if (!index) return decode_lanes_dequantized(&d, 1, &dst, elems, st);
+    }
     return decode_lanes_many(&d, 1, &dst, &index, elems, st);
   } else if (family == kFast) {
     KernelTimer timer("dec_kernel", st);
@@ -2393,6 +2547,52 @@ extern "C" int tfc_decoder_decode_dequantized(tfc_decoder* d, const int32_t* ind
     case 0: return run_decode(d, index, elems, OutDequant<float>{static_cast<float*>(y), qoffset, cdf_offset}, st);
     case 1: return run_decode(d, index, elems, OutDequant<__hip_bfloat16>{static_cast<__hip_bfloat16*>(y), qoffset, cdf_offset}, st);
     case 2: return run_decode(d, index, elems, OutDequant<__half>{static_cast<__half*>(y), qoffset, cdf_offset}, st);
+    default: return fail("unsupported dtype code %d", dtype);
+  }
+}
+
+namespace {
+template <typename T>
+int decode_dequantized_many(int n, tfc_decoder* const* ds, void* const* ys, const float* qoffset,
+                            const int32_t* cdf_offset, int64_t elems, hipStream_t st) {
+  bool batch = elems > 0 && elems < (int64_t{1} << 29);
+  for (int k = 0; k < n; ++k) ds[k]->touch(st);
+  for (int k = 0; k < n; ++k) {
+    const tfc_decoder* d = ds[k];
+    if (d->tables != ds[0]->tables || d->streams != ds[0]->streams)
+      return fail("tfc_decoder_decode_dequantized_many: handles must share tables and stream count");
+    if (d->streams == 0 || d->tables->rows.empty()) batch = false;
+    if (batch && decoder_family<int32_t>(d, d->streams * n, elems, false, true) != kLanes) batch = false;
+  }
+  std::vector<OutDequant<T>> dsts(n);
+  for (int k = 0; k < n; ++k) dsts[k] = OutDequant<T>{static_cast<T*>(ys[k]), qoffset, cdf_offset};
+  if (!batch) {
+    for (int k = 0; k < n; ++k)
+      if (run_decode(ds[k], nullptr, elems, dsts[k], st)) return 1;
+    return 0;
+  }
+  for (int g0 = 0; g0 < n; g0 += kMaxFinalizeJobs) {
+    const int gn = std::min(kMaxFinalizeJobs, n - g0);
+    if (decode_lanes_dequantized(ds + g0, gn, dsts.data() + g0, elems, st)) return 1;
+  }
+  return 0;
+}
+}  // namespace
+
+// EntropyDecodeChannel with the dequantise epilogue for n independent handles as one coding launch.
+extern "C" int tfc_decoder_decode_dequantized_many(int n, tfc_decoder* const* ds, void* const* ys, int dtype,
+                                                   const float* qoffset, const int32_t* cdf_offset,
+                                                   int64_t channels, int64_t elems, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return 0;
+  if (elems < 0) return fail("negative element count");
+  if (channels != static_cast<int64_t>(ds[0]->tables->rows.size()))
+    return fail("channel count %lld does not match table count %lld",
+                static_cast<long long>(channels), static_cast<long long>(ds[0]->tables->rows.size()));
+  switch (dtype) {
+    case 0: return decode_dequantized_many<float>(n, ds, ys, qoffset, cdf_offset, elems, st);
+    case 1: return decode_dequantized_many<__hip_bfloat16>(n, ds, ys, qoffset, cdf_offset, elems, st);
+    case 2: return decode_dequantized_many<__half>(n, ds, ys, qoffset, cdf_offset, elems, st);
     default: return fail("unsupported dtype code %d", dtype);
   }
 }

@@ -68,6 +68,7 @@ struct LaneArgs {
   unsigned int cap;            // encoder: slab bytes per stream
   int lds_image;               // LDS bytes reserved for the image (multiple of 1024)
   int lds_wave;                // LDS bytes of every wave's private area behind it
+  int defer;                   // blocks a wave may run with lanes parked in front of an escape before it codes them
 };
 
 __device__ inline void lanes_load_image(unsigned char* lds, const LaneArgs& a) {
@@ -584,6 +585,7 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
   constexpr bool kFastBlock = !INDEXED && std::is_same<Src, SymInt32>::value;
   auto run = [&](auto freeze_tag) __attribute__((always_inline)) {
   constexpr bool kFreeze = decltype(freeze_tag)::value;
+  int deferred = 0;                 // blocks since the stopped lanes' escape codes were last taken
   while (__any(j < elems || qn != 0u)) {
     {
       // memory phase: park what the previous phase requested, request from the current position, store
@@ -646,6 +648,14 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
           dirp += 16u * cnt;
         }
         while (__any(busy && dirp >= dir_end)) dirp -= dirp >= dir_end ? dir_end : 0u;
+        // The escape codes of the stopped lanes cost the whole wave a loop of ~10 rounds; a stopped lane simply
+        // stops again at step 0 of the next block (its value is still not a plain symbol).  So the codes are
+        // taken together, every la.defer-th block, as long as somebody still gets a whole block done.
+        if (deferred + 1 < la.defer && __any(busy && cnt == kEncCadence)) {
+          ++deferred;
+          continue;
+        }
+        deferred = 0;
         const bool stopped = busy && cnt != kEncCadence;
         unsigned int lo = 0u, hi = 0u;
         if (stopped) {
@@ -847,8 +857,10 @@ struct DecWaveLds {
 #define TFC_LDEC_READ_A(OFF) "ds_read_b128 v[100:103], %[DIRP] offset:" #OFF "\n\t"
 #define TFC_LDEC_READ_B(OFF) "ds_read_b128 v[104:107], %[DIRP] offset:" #OFF "\n\t"
 // kDecCadence steps (rows alternate between the two 4-register buffers, the next row is requested a step ahead)
-#define TFC_LDEC_BLOCK(ESC1, ESC2)                                                        \
+#define TFC_LDEC_PARK_FREEZE "s_andn2_b64 exec, exec, %[PARK]\n\t"
+#define TFC_LDEC_BLOCK(ESC1, ESC2, PARKPRE)                                               \
   "s_mov_b64 s[56:57], exec\n\t"                                                          \
+  PARKPRE                                                                                 \
   "v_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t"                                           \
   TFC_LDEC_READ_A(0) "s_waitcnt lgkmcnt(0)\n\t"                                           \
   TFC_LDEC_STEP(100, 101, 102, 103, TFC_LDEC_READ_B(16), 0, ESC1, ESC2)                   \
@@ -1070,6 +1082,7 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
   constexpr bool kFastBlock = !INDEXED && std::is_same<Dst, OutInt32>::value;
   auto run = [&](auto freeze_tag) __attribute__((always_inline)) {
   constexpr bool kFreeze = decltype(freeze_tag)::value;
+  int deferred = 0;                 // blocks since the parked lanes' escape codes were last read
   while (__any(j < elems)) {
     {
       // memory phase: park the code bytes requested at the previous phase, request from the current
@@ -1084,7 +1097,13 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
       }
       flush();
     }
-    if (__builtin_expect(kFastBlock && lds0 == 0u && !__any(j < elems && (j + kDecCadence > elems || mode != 0u)), 1)) {
+    // A lane that has decoded an escape symbol and not yet a bit of its code (mode 1, no zeros seen) may sit
+    // out blocks ("parked": the freezing block takes it out of EXEC at its top); any other lane inside a
+    // code goes through the generic steps.
+    if (__builtin_expect(kFastBlock && lds0 == 0u &&
+                         !__any(j < elems && (j + kDecCadence > elems ||
+                                              (mode != 0u && (!kFreeze || mode != 1u || nb != 0u)))), 1)) {
+      const unsigned long long park = __ballot(j < elems && mode != 0u);
       const unsigned int D0 = D, s10 = s1, cp0 = cp;
       unsigned int flag = 0u, cnt = 0u;
       unsigned int acc = 0xFFFFFFFFu;      // plain block: min over the steps of (symbol ^ row info) + 2^31, 0 = an escape symbol
@@ -1094,16 +1113,16 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
 #define TFC_LDEC_OPERANDS                                                                                       \
                      : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [FLAG] "+v"(flag), [CNT] "+v"(cnt), [ACC] "+v"(acc) \
                      : [DIRP] "v"(dirp), [OQ] "v"(oq_off), [SCALE] "s"(scale), [HSCALE] "v"(hscale), [QMAX] "s"(cp_max), \
-                       [K31] "v"(k31),                                                                             \
+                       [K31] "v"(k31), [PARK] "s"(park),                                                           \
                        [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)                       \
                      : "vcc", "memory", "s54", "s55", "s56", "s57", "v100", "v101", "v102", "v103", "v104", "v105", \
                        "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", \
                        "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", \
                        "v130", "v131", "v132"
         if constexpr (kFreeze) {
-          asm volatile(TFC_LDEC_BLOCK(TFC_LDEC_ESC1_FREEZE, TFC_LDEC_ESC2_FREEZE) TFC_LDEC_OPERANDS);
+          asm volatile(TFC_LDEC_BLOCK(TFC_LDEC_ESC1_FREEZE, TFC_LDEC_ESC2_FREEZE, TFC_LDEC_PARK_FREEZE) TFC_LDEC_OPERANDS);
         } else {
-          asm volatile(TFC_LDEC_BLOCK(TFC_LDEC_ESC1_PLAIN, TFC_LDEC_ESC2_PLAIN) TFC_LDEC_OPERANDS);
+          asm volatile(TFC_LDEC_BLOCK(TFC_LDEC_ESC1_PLAIN, TFC_LDEC_ESC2_PLAIN, "") TFC_LDEC_OPERANDS);
           cnt = kDecCadence;
           flag += acc == 0u ? 1u : 0u;
         }
@@ -1125,13 +1144,20 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
           j += cnt;
           ko = cnt * kEs;
           dirp += 16u * cnt;
-          if (cnt != kDecCadence) {
+          if (cnt != kDecCadence && mode == 0u) {        // (a parked lane keeps the code it is waiting to read)
             mode = 1u;
             nb = 0u;
             esc_limit = *reinterpret_cast<const unsigned int*>(lanes_lds + dirp + 4u) & 0x7FFFFFFFu;
           }
         }
         while (__any(j < elems && dirp >= dir_end)) dirp -= dirp >= dir_end ? dir_end : 0u;
+        // the codes are read together every la.defer-th block (the loop below costs the whole wave ~10 rounds),
+        // as long as somebody still gets a whole block done
+        if (deferred + 1 < la.defer && __any(j < elems && cnt == kDecCadence)) {
+          ++deferred;
+          continue;
+        }
+        deferred = 0;
         // The code as a bit string: z zeros, the z + 1 bits of the magnitude, the sign.  acc collects the
         // bits behind the zeros, k counts all of them; the code is complete at k = 2 z + 2.  A lane stays
         // in the loop (hand-written: the compiler's version of it takes twice the instructions) while the

@@ -236,15 +236,27 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         if any(tuple(b.shape) != shape for b in bottlenecks):
             raise ValueError("compress_many: all bottlenecks must have the same shape")
         batch_shape = shape[:len(shape) - self.coding_rank] if self.coding_rank else shape
-        cdf_offset, _, qn = self._device_tables(device)
-        symbols = [self._symbols(b, cdf_offset, qn) for b in bottlenecks]
-        handles = gen_ops.create_range_encoders(len(symbols), batch_shape, self.cdf, mode="throughput",
-                                                deferred_errors=True)
-        handles = gen_ops.entropy_encode_channel_many(handles, symbols)
+        cdf_offset, qoff, qn = self._device_tables(device)
+        n = len(bottlenecks)
+        handles = gen_ops.create_range_encoders(n, batch_shape, self.cdf, mode="throughput", deferred_errors=True)
+        if self.fused and bottlenecks[0].dtype in _DTYPE_CODE:
+            # quantise prologue inside the library: one elementwise pass per batch, then ONE coding launch
+            channels = int(self.prior_shape.numel())
+            elems = bottlenecks[0].numel() // handles[0].streams
+            hp = (C.c_void_p * n)(*[h.ptr for h in handles])
+            yp = (C.c_void_p * n)(*[b.data_ptr() for b in bottlenecks])
+            _lib.check(_lib.lib().tfc_encoder_encode_quantized_many(
+                n, hp, yp, _DTYPE_CODE[bottlenecks[0].dtype], None if qoff is None else qoff.data_ptr(),
+                cdf_offset.data_ptr(), channels, elems, _lib.stream_ptr()))
+            keep = [[b, cdf_offset, qoff] for b in bottlenecks]
+        else:
+            symbols = [self._symbols(b, cdf_offset, qn) for b in bottlenecks]
+            handles = gen_ops.entropy_encode_channel_many(handles, symbols)
+            keep = [[b, s] for b, s in zip(bottlenecks, symbols)]
         handles = gen_ops.entropy_encode_finalize_device_many(handles)
-        for h, b, sym in zip(handles, bottlenecks, symbols):
+        for h, b, k in zip(handles, bottlenecks, keep):
             h.coder_inputs = (b, None)
-            h._keep += [b, sym]
+            h._keep += k
         return handles
 
     def decompress_many(self, handles, broadcast_shape):
@@ -258,17 +270,30 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             return [], None
         broadcast_shape = tuple(int(s) for s in broadcast_shape)
         channels = int(self.prior_shape.numel())
-        cdf_offset, _, qn = self._device_tables(device)
+        cdf_offset, qoff, qn = self._device_tables(device)
         decoders = gen_ops.create_range_decoders(handles, self.cdf, mode="throughput")
-        decoders, symbols = gen_ops.entropy_decode_channel_many(decoders, broadcast_shape + (channels,), torch.int32)
+        n = len(decoders)
+        out_shape = tuple(handles[0].shape) + broadcast_shape + tuple(self.prior_shape)
+        if self.fused and self.bottleneck_dtype in _DTYPE_CODE:
+            outs = [torch.empty(out_shape, dtype=self.bottleneck_dtype, device=device) for _ in range(n)]
+            elems = int(np.prod(broadcast_shape, dtype=np.int64)) * channels
+            dp = (C.c_void_p * n)(*[d.ptr for d in decoders])
+            yp = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+            _lib.check(_lib.lib().tfc_decoder_decode_dequantized_many(
+                n, dp, yp, _DTYPE_CODE[self.bottleneck_dtype], None if qoff is None else qoff.data_ptr(),
+                cdf_offset.data_ptr(), channels, elems, _lib.stream_ptr()))
+            for d, o in zip(decoders, outs):
+                d._keep += [o, cdf_offset, qoff]
+        else:
+            decoders, symbols = gen_ops.entropy_decode_channel_many(decoders, broadcast_shape + (channels,), torch.int32)
+            outs = []
+            for sym in symbols:
+                out = (sym + cdf_offset).reshape(out_shape).to(self.bottleneck_dtype)
+                if qn is not None:
+                    out = out + qn
+                outs.append(out)
         ok = gen_ops.entropy_decode_finalize_device_many(decoders)
         ok._tfc_handle = decoders
-        outs = []
-        for h, sym in zip(handles, symbols):
-            out = (sym + cdf_offset).reshape(tuple(h.shape) + broadcast_shape + tuple(self.prior_shape)).to(self.bottleneck_dtype)
-            if qn is not None:
-                out = out + qn
-            outs.append(out)
         return outs, ok
 
     def get_config(self):

@@ -156,6 +156,14 @@ int tfc_encoder_encode_quantized_indexed(tfc_encoder* e, const void* y, int dtyp
                                          const int32_t* index, const int32_t* cdf_offset,
                                          int64_t elems, void* stream);
 
+/* ... for n independent handles (same tables, same geometry) as ONE coding launch: tfc_encoder_encode_quantized
+ * x tfc_encoder_encode_many.  y: HOST array of n DEV pointers.  Handles of the throughput family quantise in
+ * an elementwise pass of their own (HBM-bound) and code int32 symbols with the hand-scheduled blocks — the
+ * fused call costs what int32 channel mode costs; other handles go one by one. */
+int tfc_encoder_encode_quantized_many(int n, tfc_encoder* const* e, const void* const* y, int dtype,
+                                      const float* qoffset, const int32_t* cdf_offset,
+                                      int64_t channels, int64_t elems, void* stream);
+
 /* EntropyEncodeFinalize — cc/ops/range_coder_ops.cc:129-135,
  * cc/kernels/range_coder_kernels.cc:274-287 + cc/lib/range_coder.cc:266-307.
  * Flushes every stream, packs the streams back to back and returns the total
@@ -226,6 +234,12 @@ int tfc_decoder_decode_many(int n, tfc_decoder* const* d, const int32_t* const* 
 int tfc_decoder_decode_dequantized(tfc_decoder* d, const int32_t* index, void* y, int dtype,
                                    const float* qoffset, const int32_t* cdf_offset,
                                    int64_t channels, int64_t elems, void* stream);
+
+/* ... for n independent handles as ONE coding launch (channel mode; see tfc_encoder_encode_quantized_many).
+ * y: HOST array of n DEV pointers. */
+int tfc_decoder_decode_dequantized_many(int n, tfc_decoder* const* d, void* const* y, int dtype,
+                                        const float* qoffset, const int32_t* cdf_offset,
+                                        int64_t channels, int64_t elems, void* stream);
 
 /* EntropyDecodeFinalize — cc/ops/range_coder_ops.cc:239-246,
  * cc/lib/range_coder.h:144-169.  ok: HOST uint8 [streams] (1 = the weak

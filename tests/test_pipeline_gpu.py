@@ -166,3 +166,33 @@ def test_compress_many_equals_batch_by_batch():
         assert [bytes(s) for s in tfc.fetch_strings(packed[k][0])] == [bytes(s) for s in plain[k][0]]
         assert packed[k][1:] == plain[k][1:]
         assert torch.equal(x_hats[k], want[k])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_quantise_on_the_lane_kernels(dtype):
+    """Throughput-mode handles take bottleneck values through an elementwise quantise pass and the int32 blocks
+    (tfc_encoder_encode_quantized[_many], tfc_decoder_decode_dequantized[_many]): same strings and values as the
+    wave-per-stream kernels' fused load / store, with a quantisation offset in play."""
+    torch.manual_seed(3)
+    C = 24
+    prior = tfc.NoisyNormal(loc=torch.linspace(-0.7, 0.7, C), scale=torch.linspace(0.3, 7.0, C))
+    em = tfc.ContinuousBatchedEntropyModel(prior, coding_rank=3, compression=True, bottleneck_dtype=dtype,
+                                           quantization_offset=torch.linspace(-0.4, 0.4, C))
+    ys = [(torch.randn(70, 9, 13, C) * torch.linspace(0.3, 7.0, C) * 1.3).to(dtype).cuda() for _ in range(3)]
+    tfc.set_default_mode("latency")
+    try:
+        want = [em.compress(y) for y in ys]
+        want_hat = [em.decompress(s, (9, 13)) for s in want]
+        tfc.set_default_mode("throughput")
+        got = [em.compress(y) for y in ys]
+        got_hat = [em.decompress(s, (9, 13)) for s in got]
+    finally:
+        tfc.set_default_mode("auto")
+    handles = em.compress_many(ys)
+    many_hat, ok = em.decompress_many(handles, (9, 13))
+    assert bool(ok.cpu().all())
+    for k in range(3):
+        assert [bytes(s) for s in got[k]] == [bytes(s) for s in want[k]]
+        assert [bytes(s) for s in tfc.fetch_strings(handles[k])] == [bytes(s) for s in want[k]]
+        assert torch.equal(got_hat[k], want_hat[k]) and torch.equal(many_hat[k], want_hat[k])
+        assert torch.equal(want_hat[k], em.quantize(ys[k]))
