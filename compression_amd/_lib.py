@@ -69,6 +69,9 @@ SIGNATURES = {
     "tfc_free": (None, [_vp]),
     "tfc_pmf_to_quantized_cdf": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
     "tfc_gdn_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "tfc_gdn_params_create": (_int, [_vp, _vp, _i64, _int, _vp, C.POINTER(_vp)]),
+    "tfc_gdn_params_destroy": (None, [_vp]),
+    "tfc_gdn_forward_prepared": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp]),
     "tfc_gdn_forward_general": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _int, _int, C.c_float, C.c_float, _vp]),
     "tfc_gdn_backward": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _int, _int, _int,
                                 _int, _vp, _vp, _vp]),

@@ -59,6 +59,7 @@ struct GdnParams {
   float negf_e;         // the same for n^epsilon
   long long tiles;      // ceil(pixels / 32)
   const void* image;    // fragment-ordered Gamma^T (+ beta) built by gdn_prep_*_kernel
+  const void* prepared; // != null: the caller's image of these parameters (tfc_gdn_params): no prep launch
   // backward passes (see the mode table above the kernels)
   const void* g;        // dL/dy                      (MODE_BWD_T)
   const void* r;        // g * n^s from pass 1        (MODE_BWD_DX)
@@ -508,11 +509,15 @@ int launch_gdn_variant(GdnParams p, int dtype, hipStream_t st) {
   if (dtype == 1) {
    if constexpr ((DTYPES & 2) != 0) {
     const size_t lds = sizeof(bf16x8) * KT * (KT * 2) * 64 + sizeof(float) * KT * 32;
-    TFC_HIP(image.alloc(lds, st));
-    const int n = KT * KT * 2 * 64;
-    hipLaunchKernelGGL(gdn_prep_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.gamma, p.beta,
-                       KT * 32, transposed, image.as<bf16x8>());
-    p.image = image.p;
+    if (p.prepared) {
+      p.image = p.prepared;
+    } else {
+      TFC_HIP(image.alloc(lds, st));
+      const int n = KT * KT * 2 * 64;
+      hipLaunchKernelGGL(gdn_prep_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.gamma, p.beta,
+                         KT * 32, transposed, image.as<bf16x8>());
+      p.image = image.p;
+    }
     KernelTimer timer(label, st);
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -524,11 +529,15 @@ int launch_gdn_variant(GdnParams p, int dtype, hipStream_t st) {
   } else {
     if constexpr (KT <= 6 && (DTYPES & 1) != 0) {
       const size_t lds = sizeof(f32x4) * KT * KT * 4 * 64 + sizeof(float) * KT * 32;
-      TFC_HIP(image.alloc(lds, st));
-      const int n = KT * KT * 4 * 64;
-      hipLaunchKernelGGL(gdn_prep_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.gamma, p.beta,
-                         KT * 32, transposed, image.as<f32x4>());
-      p.image = image.p;
+      if (p.prepared) {
+        p.image = p.prepared;
+      } else {
+        TFC_HIP(image.alloc(lds, st));
+        const int n = KT * KT * 4 * 64;
+        hipLaunchKernelGGL(gdn_prep_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.gamma, p.beta,
+                           KT * 32, transposed, image.as<f32x4>());
+        p.image = image.p;
+      }
       KernelTimer timer(label, st);
       TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_f32_kernel<KT, MODE, PLAIN, GEN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

@@ -8,16 +8,53 @@ from .. import _lib
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 
+class GDNPrepared:
+    """The forward kernels' LDS image of one (beta, gamma) pair, built once (include/tfc_hip.h
+    tfc_gdn_params_create): the per-call preparation launch drops out of inference calls."""
+
+    def __init__(self, beta: torch.Tensor, gamma: torch.Tensor, dtype: torch.dtype):
+        device = _lib.require_device()
+        if dtype not in _DTYPE_CODE:
+            raise TypeError(f"GDN kernel supports float32 and bfloat16, got {dtype}")
+        beta = beta.detach().to(device, torch.float32).contiguous()
+        gamma = gamma.detach().to(device, torch.float32).contiguous()
+        C = beta.shape[0]
+        if gamma.shape != (C, C):
+            raise ValueError(f"beta/gamma shapes {tuple(beta.shape)}/{tuple(gamma.shape)} do not match")
+        import ctypes
+        out = ctypes.c_void_p()
+        _lib.check(_lib.lib().tfc_gdn_params_create(beta.data_ptr(), gamma.data_ptr(), C, _DTYPE_CODE[dtype],
+                                                    _lib.stream_ptr(), ctypes.byref(out)))
+        self.ptr, self.channels, self.dtype = out, C, dtype
+        self._keep = (beta, gamma)        # read by the preparation kernel in stream order
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                _lib.lib().tfc_gdn_params_destroy(self.ptr)
+        except Exception:
+            pass
+
+
 def gdn_forward(x: torch.Tensor, beta: torch.Tensor, gamma: torch.Tensor, inverse: bool = False,
-                rectify: bool = False, alpha: float = 1, epsilon: float = 1) -> torch.Tensor:
+                rectify: bool = False, alpha: float = 1, epsilon: float = 1, prepared: GDNPrepared = None) -> torch.Tensor:
     """Fused GDN/IGDN forward, channels-last: x [..., C], beta [C], gamma [C(in), C(out)]
-    (the layout of `GDN.gamma`, python/layers/gdn.py:394-398)."""
+    (the layout of `GDN.gamma`, python/layers/gdn.py:394-398).  `prepared` (GDNPrepared of the same beta /
+    gamma / dtype): skips the per-call parameter preparation (fixed alpha in {1, 2}, epsilon in {1, .5})."""
     _lib.require_device()
     if x.dtype not in _DTYPE_CODE:
         raise TypeError(f"GDN kernel supports float32 and bfloat16, got {x.dtype}")
     alpha, epsilon = float(alpha), float(epsilon)
     x = x.contiguous()
     C = x.shape[-1]
+    if prepared is not None and alpha in (1, 2) and epsilon in (1, 0.5):
+        if prepared.channels != C or prepared.dtype != x.dtype:
+            raise ValueError("prepared GDN parameters do not match the input")
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().tfc_gdn_forward_prepared(
+            prepared.ptr, x.data_ptr(), y.data_ptr(), x.numel() // C, int(bool(inverse)), int(bool(rectify)),
+            int(alpha), 1 if epsilon == 0.5 else 0, _lib.stream_ptr()))
+        return y
     beta = beta.detach().to(x.device, torch.float32).contiguous()
     gamma = gamma.detach().to(x.device, torch.float32).contiguous()
     if beta.shape != (C,) or gamma.shape != (C, C):

@@ -101,6 +101,15 @@ class GDN(torch.nn.Module):
             cache[name] = hit = (key, v)
         return hit[1]
 
+    def _prepared_params(self, beta, gamma, dtype):
+        """functional.GDNPrepared of the cached beta / gamma values (rebuilt when they are)."""
+        cache = self.__dict__.setdefault("_value_cache", {})
+        key = (beta.data_ptr(), gamma.data_ptr(), str(dtype), str(beta.device))
+        hit = cache.get("prepared")
+        if hit is None or hit[0] != key:
+            cache["prepared"] = hit = (key, functional.GDNPrepared(beta, gamma, dtype), beta, gamma)
+        return hit[1]
+
     def invalidate_kernel_cache(self):
         self.__dict__["_value_cache"] = {}
 
@@ -145,7 +154,14 @@ class GDN(torch.nn.Module):
                 and float(alpha) in (1.0, 2.0) and float(epsilon) in (1.0, 0.5))
         needs_grad = torch.is_grad_enabled() and any(
             torch.is_tensor(t) and t.requires_grad for t in (x, beta, gamma, alpha, epsilon))
-        if fast:
+        if fast and not needs_grad and self._beta_fixed is None and self._gamma_fixed is None \
+                and x.is_cuda and x.dtype in functional._DTYPE_CODE \
+                and (x.dtype != torch.float32 or x.shape[-1] <= 192):
+            # inference on the layer's own variables: the kernels' parameter image is prepared once per
+            # parameter version (same cache key as the reparameterised values)
+            y = functional.gdn_forward(x.contiguous(), beta, gamma, self.inverse, self.rectify, float(alpha),
+                                       float(epsilon), prepared=self._prepared_params(beta, gamma, x.dtype))
+        elif fast:
             y = _GDNFunction.apply(x.contiguous(), beta, gamma, self.inverse, self.rectify,
                                    int(alpha) if float(alpha) in (1.0, 2.0) else alpha,
                                    1 if float(epsilon) == 1.0 else 0.5)

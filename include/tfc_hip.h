@@ -333,6 +333,17 @@ int tfc_gdn_forward(const void* x, void* y, int dtype, int64_t pixels, int64_t c
                     const float* beta, const float* gamma, int inverse, int rectify,
                     int alpha_mode, int eps_mode, void* stream);
 
+/* Inference form: the kernels' LDS image of (beta, gamma) built ONCE (tfc_gdn_params_create launches the small
+ * preparation kernel the plain entry point launches per call) and reused by every tfc_gdn_forward_prepared call
+ * while the parameters do not change — python/layers/gdn.py holds beta / gamma as variables, constant outside
+ * training.  channels / dtype as for tfc_gdn_forward. */
+typedef struct tfc_gdn_params tfc_gdn_params;
+int tfc_gdn_params_create(const float* beta, const float* gamma, int64_t channels, int dtype, void* stream,
+                          tfc_gdn_params** out);
+void tfc_gdn_params_destroy(tfc_gdn_params* p);
+int tfc_gdn_forward_prepared(const tfc_gdn_params* params, const void* x, void* y, int64_t pixels,
+                             int inverse, int rectify, int alpha_mode, int eps_mode, void* stream);
+
 /* The same layer with general (e.g. learned) exponents — python/layers/gdn.py:345-369 creates alpha
  * (>= 1) and epsilon (>= 1e-6) as scalar parameters when the constructor gets None, and :386-387 /
  * :411-412 then take `inputs ** alpha` and `norm_pool ** epsilon` with tf.pow:

@@ -240,3 +240,30 @@ def test_gdn_layer_learned_alpha_epsilon():
     with torch.no_grad():
         y_kernel = layer(x.detach())
     assert torch.allclose(y_kernel, y.detach(), atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_prepared_parameters_give_the_same_outputs(dtype, inverse):
+    """tfc_gdn_params_create + tfc_gdn_forward_prepared (the parameter image built once) == tfc_gdn_forward, bit for
+    bit; the layer takes that path under no_grad and rebuilds the image when its variables change."""
+    from compression_amd.layers import functional
+    torch.manual_seed(7)
+    C = 96
+    x = torch.randn(3, 17, 19, C, device="cuda").to(dtype)
+    beta = 1 + 0.1 * torch.rand(C, device="cuda")
+    gamma = 0.1 * torch.eye(C, device="cuda") + 0.01 * torch.rand(C, C, device="cuda")
+    want = functional.gdn_forward(x, beta, gamma, inverse=inverse)
+    prep = functional.GDNPrepared(beta, gamma, dtype)
+    assert torch.equal(functional.gdn_forward(x, beta, gamma, inverse=inverse, prepared=prep), want)
+    import compression_amd as tfc
+    layer = tfc.GDN(inverse=inverse).cuda()
+    y_grad = layer(x)                                   # builds the variables; autograd path
+    with torch.no_grad():
+        y0 = layer(x)
+        assert torch.equal(y0, y_grad.detach())
+        assert "prepared" in layer.__dict__["_value_cache"]
+        layer.reparam_beta.mul_(1.5)                    # version bump: values and image are rebuilt
+        y1 = layer(x)
+    assert not torch.equal(y1, y0)
+    assert torch.equal(y1, functional.gdn_forward(x, layer.beta, layer.gamma, inverse=inverse))
