@@ -559,6 +559,42 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
     return time.perf_counter() - t0, last
 
 
+def run_model_pipeline(model, x, steps, sp, fetch=True):
+    """`steps` compress + decompress passes through a `pipeline.SoftwarePipeline` (one transform and one coder
+    stream on disjoint CUs; step k's synthesis and step k + 2's analysis... see its docstring).  The host never
+    waits inside a step: step k - 2 is retired (end event, strings and sanity flags fetched) after step k has been
+    enqueued.  Returns (seconds, last record)."""
+    main = torch.cuda.current_stream()
+    states, last = [], None
+
+    def retire(state, ev):
+        ev.synchronize()
+        rec = StepRecord(state["packed"], state["x_hat"], state["ok"], None)
+        rec.x_hat._tfc_keep = (state["y_hat"],)
+        if fetch:
+            rec.strings = [tfc.fetch_strings(h) for h in rec.out if isinstance(h, tfc.gen_ops.EncoderHandle)]
+            for ok in rec.oks:
+                assert bool(ok.cpu().all()), "EntropyDecodeFinalize reported a failed stream"
+        return rec
+
+    t0 = time.perf_counter()
+    ready = []                                   # (state, end event) of steps whose last stage is enqueued
+    for k in range(steps):
+        stages, state = model.codec_stages(x)
+        states.append(state)
+        _, ev = sp.submit(stages, after=main)
+        if ev is not None:
+            ready.append((states[k - 1], ev))
+        while len(ready) > 1:
+            last = retire(*ready.pop(0))
+    _, ev = sp.drain()
+    ready.append((states[-1], ev))
+    for item in ready:
+        last = retire(*item)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, last
+
+
 def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=2, coder_cus=32,
                 cpu=True, rank=0, world=1, distributed=False, partition="single", group=1):
     """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5)."""
@@ -566,6 +602,8 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
     from compression_amd import parallel, pipeline
     from compression_amd.ops import gen_ops
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    if depth <= 0:
+        depth = 4 if workload == "bls2017" else 3
     model, x, batch, hw, hist = make_model(workload, dtype, device, batch, rank)
     if distributed:
         parallel.broadcast_tables(model)
@@ -582,16 +620,25 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
         # (b) the timed region: `depth` steps in flight over the CU partition
         # the wave-per-stream coder wants one wave per SIMD: a quarter of a CU per image, at most half the chip
         cus = coder_cus if coder_cus > 0 else min(128, max(16, (batch + 3) // 4))
-        part = pipeline.CoderPartition(coder_cus=cus, depth=depth, device=device, mode=partition) if depth > 1 else None
-        lanes = part.lanes if part else inline
-        group = group if hasattr(model, "compress_many") else 1
+        software = partition.startswith("pipelined")
+        if software:
+            # ONE transform stream and ONE coder stream on complementary CU sets ("pipelined-plain": ordinary streams)
+            part = pipeline.CoderPartition(coder_cus=cus, depth=1, device=device,
+                                           mode="plain" if partition.endswith("plain") else "masked")
+            lanes, group = part.lanes, 1
+            run = lambda n: run_model_pipeline(model, x, n, pipeline.SoftwarePipeline(part.lanes[0]))
+        else:
+            part = pipeline.CoderPartition(coder_cus=cus, depth=depth, device=device, mode=partition) if depth > 1 else None
+            lanes = part.lanes if part else inline
+            group = group if hasattr(model, "compress_many") else 1
+            run = lambda n: run_model_steps(model, x, n, lanes, group=group)
         steps = max(group, steps - steps % group)
-        run_model_steps(model, x, max(warmup, len(lanes)) * group, lanes, group=group)
+        run(max(warmup, len(lanes), 2) * group)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
             torch.cuda.synchronize()
-        elapsed, rec = run_model_steps(model, x, steps, lanes, group=group)
+        elapsed, rec = run(steps)
         gathered = None
         if distributed:
             # the coded strings of the whole batch on every rank: lengths, then padded bytes (two all-gathers)
@@ -628,7 +675,7 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
                 "workload": f"{workload} compress+decompress, {batch} images of {hw[1]}x{hw[0]} per GPU, 192 filters, "
                             f"random-init weights" + (", hyperprior calibrated (scale_index_histogram)" if hist is not None else ""),
                 "dtype": dtype_name,
-                "steps_in_flight": len(lanes) * group,
+                "steps_in_flight": 3 if software else len(lanes) * group,
                 "steps_per_coder_launch": group,
                 "cu_partition": ({"mode": part.mode, "coder_cus": part.coder_cus, "transform_cus": part.total_cus - part.coder_cus}
                                  if part else None),
@@ -703,7 +750,7 @@ def model_workload(args, world, rank, device, distributed):
     """`--workload bls2017|bmshj2018`: the model step as the headline line (BASELINE configs 1/4/5)."""
     import torch.distributed as dist
     res = model_bench(args.workload, args.model_dtype, device, batch=args.batch, steps=args.steps,
-                      warmup=args.warmup, depth=max(1, args.model_depth), coder_cus=args.coder_cus,
+                      warmup=args.warmup, depth=args.model_depth, coder_cus=args.coder_cus,
                       cpu=not args.no_cpu_baseline, rank=rank, world=world, distributed=distributed,
                       partition=args.partition, group=max(1, args.model_group))
     if rank == 0:
@@ -879,17 +926,21 @@ def main():
                          "full model compress+decompress as the headline line (configs 1/4/5)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU for the model workloads")
     ap.add_argument("--model-dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--model-depth", type=int, default=2, help="model steps in flight (1: one at a time, no CU partition)")
+    ap.add_argument("--model-depth", type=int, default=0,
+                    help="model steps in flight (1: one at a time; 0: 3 for bmshj2018, 4 for bls2017 — measured, "
+                         "profiles/r03_notes.md)")
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="compute units reserved for the coder streams of a model pipeline (0: one SIMD per image, "
                          "at most half the chip)")
-    ap.add_argument("--partition", default="single", choices=["masked", "plain", "single", "coder-masked", "transform-masked"],
-                    help="streams of a model pipeline lane: CU-masked pair, ordinary pair, or one ordinary stream")
+    ap.add_argument("--partition", default="single", choices=["pipelined", "pipelined-plain", "masked", "plain", "single", "coder-masked", "transform-masked"],
+                    help="model steps: software-pipelined over ONE transform + ONE coder stream on disjoint CUs (pipelined; "
+                         "-plain: ordinary streams), or --model-depth whole steps in flight on CU-masked pairs, ordinary "
+                         "pairs, or one ordinary stream each")
     ap.add_argument("--model-group", type=int, default=1,
                     help="batches per coder launch where the model has compress_many (bls2017): the lane-per-stream "
                          "kernels code them in one launch per direction where the tables' image fits the LDS (the "
                          "random-init bls2017 tables do not: 172 KB); 1 = every batch its own launch")
-    ap.add_argument("--model-steps", type=int, default=6, help="timed steps of the `models` sub-objects")
+    ap.add_argument("--model-steps", type=int, default=12, help="timed steps of the `models` sub-objects")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1043,7 +1094,7 @@ def main():
                 torch.cuda.empty_cache()
                 out["models"][key] = model_bench(name, args.model_dtype, device,
                                                  steps=max(args.model_steps, 2 * max(1, args.model_group)),
-                                                 warmup=2, depth=max(1, args.model_depth), coder_cus=args.coder_cus,
+                                                 warmup=2, depth=args.model_depth, coder_cus=args.coder_cus,
                                                  cpu=not args.no_cpu_baseline, partition=args.partition,
                                                  group=max(1, args.model_group))
         print(json.dumps(out))

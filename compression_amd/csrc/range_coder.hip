@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <type_traits>
@@ -41,6 +42,30 @@ namespace tfc {
 std::string& last_error() {
   static thread_local std::string e;
   return e;
+}
+
+double slow_call_threshold_ms() {
+  static const double ms = [] {
+    const char* e = std::getenv("TFC_SLOW_CALL_MS");
+    return e ? std::atof(e) : 0.0;
+  }();
+  return ms;
+}
+
+namespace {
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+SlowCall::SlowCall(const char* w, const char* f, int l)
+    : what(w), file(f), line(l), t0(slow_call_threshold_ms() > 0.0 ? now_ms() : 0.0) {}
+
+SlowCall::~SlowCall() {
+  if (t0 == 0.0) return;
+  const double dt = now_ms() - t0;
+  if (dt >= slow_call_threshold_ms())
+    std::fprintf(stderr, "[tfc slow call] %8.2f ms  %s:%d  %s  (%llu)\n", dt, file, line, what, detail);
 }
 
 int fail(const char* fmt, ...) {
@@ -77,7 +102,18 @@ ProfileEntry& profile_entry(const char* name) {
 
 bool profiling_enabled() { return g_profile_on; }
 
-KernelTimer::KernelTimer(const char* n, hipStream_t s) : name(n), st(s), on(g_profile_on) {
+// The caller's "coder gate" (tfc_set_coder_gate): recorded ONCE on the launch stream, immediately in front of the
+// next long coding kernel — a launch that carries the "enc_kernel" / "dec_kernel" timer — of this host thread.
+namespace {
+thread_local hipEvent_t g_coder_gate = nullptr;
+}
+
+KernelTimer::KernelTimer(const char* n, hipStream_t s) : name(n), st(s), on(g_profile_on), slow(n, "launch scope", 0) {
+  if (g_coder_gate && (std::strcmp(n, "enc_kernel") == 0 || std::strcmp(n, "dec_kernel") == 0))
+  {
+    (void)hipEventRecord(g_coder_gate, st);
+    g_coder_gate = nullptr;                     // one shot: the FIRST long coding kernel after tfc_set_coder_gate
+  }
   if (!on) return;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
@@ -94,6 +130,11 @@ KernelTimer::~KernelTimer() {
 }  // namespace tfc
 
 using namespace tfc;
+
+extern "C" int tfc_set_coder_gate(void* event) {
+  tfc::g_coder_gate = static_cast<hipEvent_t>(event);
+  return 0;
+}
 
 namespace {
 std::atomic<int>& default_mode() {

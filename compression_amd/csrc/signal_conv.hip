@@ -749,8 +749,11 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
   // the FASTK kernel read it at + 32 (kChunk2 - 1))
   TFC_HIP(packed.alloc(static_cast<size_t>(frags) * FB + 32 * kChunk2, st));
   TFC_HIP(hipMemsetAsync(static_cast<unsigned char*>(packed.p) + static_cast<size_t>(frags) * FB, 0, 32 * kChunk2, st));
-  hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(static_cast<unsigned>(ceil_div(frags, 256))),
-                     dim3(256), 0, st, w, g, c, packed.p);
+  {
+    SlowCall slow("conv_pack_kernel launch", __FILE__, __LINE__);
+    hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(static_cast<unsigned>(ceil_div(frags, 256))),
+                       dim3(256), 0, st, w, g, c, packed.p);
+  }
   const T* xin = static_cast<const T*>(x);
   if (c.small_cin) {
     // right margin: a K run may read up to kw4*16 values past the last window start

@@ -110,6 +110,33 @@ class BLS2017Model(torch.nn.Module):
                 x_hat._tfc_keep = (y_hat,)
         return (x_hat, ok) if defer_sanity else x_hat
 
+    @torch.no_grad()
+    def codec_stages(self, x):
+        """One compress() + decompress() of `x` as ([(kind, fn)], state) for
+        `compression_amd.pipeline.SoftwarePipeline` (see BMSHJ2018Model.codec_stages)."""
+        s = {}
+        if x.dim() == 3:
+            x = x[None]
+
+        def analysis():
+            xc = x.to(self.compute_dtype)
+            s["y"] = y = self.analysis_transform(xc)
+            s["shapes"] = tuple(xc.shape[1:-1]), tuple(y.shape[1:-1])
+
+        def code():
+            string = self.entropy_model.compress(s["y"], device_result=True)
+            s["packed"] = (string,) + s["shapes"]
+            s["y_hat"], ok = self.entropy_model.decompress(string, s["shapes"][1], defer_sanity=True)
+            s["ok"] = [ok]
+
+        def synthesis():
+            x_shape = s["shapes"][0]
+            x_hat = self.synthesis_transform(s["y_hat"])[:, :x_shape[0], :x_shape[1], :]
+            s["x_hat"] = x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            return x_hat
+
+        stages = [("transform", analysis), ("coder", code), ("transform", synthesis)]
+        return [(kind, torch.no_grad()(fn)) for kind, fn in stages], s      # the stages run after this call returns
 
     @torch.no_grad()
     def compress_many(self, xs):

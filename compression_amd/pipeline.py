@@ -21,11 +21,13 @@ import contextlib
 import ctypes as C
 
 import numpy as np
+import time
+
 import torch
 
 from . import _lib
 
-__all__ = ["CoderPartition", "Lane", "inline_lane"]
+__all__ = ["CoderPartition", "Lane", "inline_lane", "SoftwarePipeline"]
 
 
 class Lane:
@@ -137,3 +139,102 @@ class CoderPartition:
                 _lib.lib().tfc_stream_destroy(p)
         except Exception:
             pass
+
+
+class SoftwarePipeline:
+    """Steps whose stages alternate between transform work and coding, software-pipelined over ONE transform
+    stream and ONE coder stream (a `CoderPartition(depth=1)` lane: disjoint CU sets).
+
+    A step is a list of (kind, fn) stages, kind "transform" or "coder" (models' `codec_stages`): `head`
+    transform stages, then coder stages with transform stages in between, then `tail` transform stages.  The
+    coder stream runs the coding stages of consecutive steps back to back.  The transform stream runs, beside
+    step k's LAST coding stage, the tail of step k - 1 and the head of step k + 1; if a step has two coding
+    stages and a tail of several stages, the first tail stage of step k - 1 runs beside step k's FIRST coding stage
+    instead (it has to be shorter than that stage: the transform stage between the two coding stages queues up
+    behind it).  Each stream's FIFO order is the schedule; nothing here synchronises with the host.
+
+    Transform stages that run beside a coding stage are released by the library's coder gate
+    (tfc_set_coder_gate: an event recorded immediately in front of the stage's first long coding kernel), i.e.
+    together with the coding kernel they run beside, never ahead of it: a coding kernel that becomes ready while
+    the transform queue is running large grids back to back is not dispatched until that queue drains
+    (tools/queue_pair_probe.py, profiles/r03_notes.md).
+    """
+
+    def __init__(self, lane: Lane):
+        self.lane = lane
+        self.T, self.C = lane.transform, lane.coder
+        self._deferred = None                # (tail stages of the previous step, event behind its last coder stage)
+        self._last_gate = None               # gate of the previous step's last coding stage
+        self.host_log = None                 # a list: (stage name, host time entering, leaving) per enqueued stage
+
+    def _run(self, stream, waits, fn, gate=None):
+        for ev in waits:
+            if ev is not None:
+                stream.wait_event(ev)
+        t0 = time.perf_counter() if self.host_log is not None else 0.0
+        with torch.cuda.stream(stream):
+            if gate is not None:
+                gate.record(stream)          # creates the HIP event; re-recorded by the library further down the stream
+                _lib.check(_lib.lib().tfc_set_coder_gate(gate.cuda_event))
+            try:
+                out = fn()
+            finally:
+                if gate is not None:
+                    _lib.lib().tfc_set_coder_gate(None)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        if self.host_log is not None:
+            self.host_log.append((getattr(fn, "__name__", "?"), t0, time.perf_counter()))
+        return out, ev
+
+    def _tail(self, stages, dep, gate):
+        """Runs deferred tail stages on the transform stream: behind their own step's coding (`dep`), beside the
+        coding kernel `gate` stands in front of."""
+        out = ev = None
+        for _, fn in stages:
+            out, ev = self._run(self.T, [dep, gate], fn)
+            dep = gate = None
+        return out, ev
+
+    def submit(self, stages, after=None):
+        """Enqueues one step up to and including its last coding stage, and the tail of the previous step.
+        Returns (what the previous step's last stage returned, its end event) — (None, None) for the first."""
+        stages = list(stages)
+        kinds = [k for k, _ in stages]
+        assert kinds[0] == "transform" and kinds[-1] == "transform" and "coder" in kinds
+        first_c = kinds.index("coder")
+        last_c = len(kinds) - 1 - kinds[::-1].index("coder")
+        start = None
+        if after is not None:
+            start = torch.cuda.Event()
+            start.record(after)
+        ev = None
+        for _, fn in stages[:first_c]:
+            # head: released with the previous step's last coding kernel, not ahead of it
+            _, ev = self._run(self.T, [start, self._last_gate], fn)
+            start = None
+        prev, done = self._deferred, (None, None)
+        split = prev is not None and last_c > first_c and len(prev[0]) > 1
+        for i in range(first_c, last_c + 1):
+            kind, fn = stages[i]
+            if kind == "coder" and i in (first_c, last_c):
+                gate = torch.cuda.Event()
+                _, ev = self._run(self.C, [ev], fn, gate=gate)
+                if i == first_c and split:
+                    self._tail(prev[0][:1], prev[1], gate)
+                    prev = (prev[0][1:], None)
+                if i == last_c:
+                    if prev is not None:
+                        done = self._tail(prev[0], prev[1], gate)
+                    self._last_gate = gate
+            else:
+                _, ev = self._run(self.C if kind == "coder" else self.T, [ev], fn)
+        self._deferred = (stages[last_c + 1:], ev)
+        return done
+
+    def drain(self):
+        """Enqueues the last step's tail; returns (its result, its end event)."""
+        if self._deferred is None:
+            return None, None
+        prev, self._deferred = self._deferred, None
+        return self._tail(prev[0], prev[1], None)

@@ -72,6 +72,14 @@ int tfc_get_default_mode(void);
  * tfc_stream_destroy synchronises the stream and parks it for the next request with the same mask instead
  * of destroying it: coder handles free their buffers in the order of the stream that used them last and
  * may outlive the pipeline that created the stream. */
+/* "Coder gate" of the calling host thread: a hipEvent_t (NULL to clear) that the library records ONCE, on the launch
+ * stream, immediately in front of the next long coding kernel (the per-symbol encode / decode kernel, not the
+ * preparation kernels ahead of it) it launches from this thread, and then forgets.  A model pipeline lets the
+ * transform work of OTHER batches wait for it, so that those kernels are released together with the coding
+ * kernel instead of ahead of it: on this hardware a small-grid kernel that becomes ready while another queue is
+ * running large grids back to back is not dispatched until that queue drains, whereas kernels released together
+ * (or coder first) run side by side (tools/queue_pair_probe.py). */
+int tfc_set_coder_gate(void* event);
 int tfc_device_compute_units(int* cus);
 int tfc_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
 int tfc_stream_destroy(void* stream);

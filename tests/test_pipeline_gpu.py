@@ -132,6 +132,68 @@ def test_model_device_path_equals_plain_calls(which):
     part.close()
 
 
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("mode", ["masked", "plain"])
+def test_software_pipeline_equals_plain_calls(which, mode):
+    """Model steps software-pipelined over one transform and one coder stream (synthesis of step k - 1 and analysis
+    of step k + 1 beside the coding of step k, released by the library's coder gate): every step's strings and
+    reconstruction are those of compress() / decompress() one call at a time — on DIFFERENT images per step, so
+    a stage reading a neighbouring step's tensors would show."""
+    model, hw, batch = _models()[which]
+    xs = [torch.from_numpy(synthetic.lowpass_images(batch, hw[0], hw[1], seed=30 + k)).cuda() for k in range(5)]
+    plain = [model.compress(x) for x in xs]
+    want = [model.decompress(*p) for p in plain]
+    nstr = model.num_strings
+    part = pipeline.CoderPartition(coder_cus=16, depth=1, mode=mode)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        sp = pipeline.SoftwarePipeline(part.lane(0))
+        states, ends = [], []
+        for x in xs:
+            stages, state = model.codec_stages(x)
+            states.append(state)
+            out, ev = sp.submit(stages, after=side)
+            if ev is not None:
+                ends.append(ev)
+                assert out is states[len(ends) - 1]["x_hat"]
+        ends.append(sp.drain()[1])
+        for k, (state, ev) in enumerate(zip(states, ends)):
+            ev.synchronize()
+            for j in range(nstr):
+                assert [bytes(s) for s in tfc.fetch_strings(state["packed"][j])] == [bytes(s) for s in plain[k][j]]
+            assert state["packed"][nstr:] == plain[k][nstr:]
+            assert torch.equal(state["x_hat"], want[k]) and all(bool(f.cpu().all()) for f in state["ok"])
+    part.close()
+
+
+def test_coder_gate_is_recorded_once_in_front_of_the_next_coding_kernel():
+    """tfc_set_coder_gate: recorded in front of the next long coding kernel of this thread, then forgotten (a
+    second encode behind ~10 ms of other work does not move it)."""
+    from compression_amd import _lib
+    L = _lib.lib()
+    _, lookup = _tables()
+    lt = torch.from_numpy(lookup)
+    v = torch.from_numpy(synthetic.sample_symbols(lookup, 24, 5000, seed=3)).cuda()
+    spin = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    start, gate, end = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    gate.record()                                    # creates the HIP event
+    for _ in range(2):                               # first pass: warm-up (table upload, allocations)
+        torch.cuda.synchronize()
+        start.record()
+        _lib.check(L.tfc_set_coder_gate(gate.cuda_event))
+        h1 = tfc.entropy_encode_channel(tfc.create_range_encoder([24], lt, deferred_errors=True), v)
+        for _ in range(100):
+            spin.add_(1)
+        h2 = tfc.entropy_encode_channel(tfc.create_range_encoder([24], lt, deferred_errors=True), v)
+        _lib.check(L.tfc_set_coder_gate(None))
+        end.record()
+        torch.cuda.synchronize()
+    total = start.elapsed_time(end)
+    assert total > 4.0 and start.elapsed_time(gate) < 0.25 * total
+    assert [bytes(s) for s in tfc.fetch_strings(tfc.entropy_encode_finalize_device(h1))] == \
+        [bytes(s) for s in tfc.fetch_strings(tfc.entropy_encode_finalize_device(h2))]
+
+
 def test_cu_partition_masks():
     part = pipeline.CoderPartition(coder_cus=32, depth=1)
     assert part.total_cus >= 64 and part.coder_cus == 32

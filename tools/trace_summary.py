@@ -26,13 +26,15 @@ def main():
     ap.add_argument("csv")
     ap.add_argument("--bin", type=float, default=500.0)
     ap.add_argument("--last-ms", type=float, default=400.0, help="only the last N milliseconds of the trace")
+    ap.add_argument("--skip-last-ms", type=float, default=0.0, help="... ending this long before the last kernel")
     args = ap.parse_args()
     rows = []
     with open(args.csv) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]))
     rows.sort()
-    t_end = max(r[1] for r in rows)
+    t_end = max(r[1] for r in rows) - int(args.skip_last_ms * 1e6)
+    rows = [r for r in rows if r[0] <= t_end]
     t0 = max(min(r[0] for r in rows), t_end - int(args.last_ms * 1e6))
     rows = [r for r in rows if r[1] >= t0]
     queues = collections.OrderedDict()
