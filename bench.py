@@ -596,14 +596,14 @@ def run_model_pipeline(model, x, steps, sp, fetch=True):
 
 
 def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=2, coder_cus=32,
-                cpu=True, rank=0, world=1, distributed=False, partition="single", group=1):
+                cpu=True, rank=0, world=1, distributed=False, partition="single", group=1, queue=2):
     """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5)."""
     import torch.distributed as dist
     from compression_amd import parallel, pipeline
     from compression_amd.ops import gen_ops
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     if depth <= 0:
-        depth = 4 if workload == "bls2017" else 3
+        depth = 4
     model, x, batch, hw, hist = make_model(workload, dtype, device, batch, rank)
     if distributed:
         parallel.broadcast_tables(model)
@@ -629,7 +629,9 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
             run = lambda n: run_model_pipeline(model, x, n, pipeline.SoftwarePipeline(part.lanes[0]))
         else:
             part = pipeline.CoderPartition(coder_cus=cus, depth=depth, device=device, mode=partition) if depth > 1 else None
-            lanes = part.lanes if part else inline
+            # `queue` steps enqueued per stream: a stream whose step has finished still has work while the host
+            # retires that step (waits for its end event, fetches strings and flags) and enqueues the next
+            lanes = list(part.lanes) * max(1, queue) if part else inline
             group = group if hasattr(model, "compress_many") else 1
             run = lambda n: run_model_steps(model, x, n, lanes, group=group)
         steps = max(group, steps - steps % group)
@@ -676,6 +678,7 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
                             f"random-init weights" + (", hyperprior calibrated (scale_index_histogram)" if hist is not None else ""),
                 "dtype": dtype_name,
                 "steps_in_flight": 3 if software else len(lanes) * group,
+                "streams": 2 if software else (len(part.lanes) if part else 1),
                 "steps_per_coder_launch": group,
                 "cu_partition": ({"mode": part.mode, "coder_cus": part.coder_cus, "transform_cus": part.total_cus - part.coder_cus}
                                  if part else None),
@@ -752,7 +755,7 @@ def model_workload(args, world, rank, device, distributed):
     res = model_bench(args.workload, args.model_dtype, device, batch=args.batch, steps=args.steps,
                       warmup=args.warmup, depth=args.model_depth, coder_cus=args.coder_cus,
                       cpu=not args.no_cpu_baseline, rank=rank, world=world, distributed=distributed,
-                      partition=args.partition, group=max(1, args.model_group))
+                      partition=args.partition, group=max(1, args.model_group), queue=args.model_queue)
     if rank == 0:
         line = {
             "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
@@ -927,8 +930,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU for the model workloads")
     ap.add_argument("--model-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model-depth", type=int, default=0,
-                    help="model steps in flight (1: one at a time; 0: 3 for bmshj2018, 4 for bls2017 — measured, "
-                         "profiles/r03_notes.md)")
+                    help="streams that carry model steps (1: one step at a time; 0: 4 — measured, profiles/r03_notes.md)")
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="compute units reserved for the coder streams of a model pipeline (0: one SIMD per image, "
                          "at most half the chip)")
@@ -940,6 +942,7 @@ def main():
                     help="batches per coder launch where the model has compress_many (bls2017): the lane-per-stream "
                          "kernels code them in one launch per direction where the tables' image fits the LDS (the "
                          "random-init bls2017 tables do not: 172 KB); 1 = every batch its own launch")
+    ap.add_argument("--model-queue", type=int, default=2, help="model steps enqueued per stream (--model-depth streams)")
     ap.add_argument("--model-steps", type=int, default=12, help="timed steps of the `models` sub-objects")
     args = ap.parse_args()
 
@@ -1096,7 +1099,7 @@ def main():
                                                  steps=max(args.model_steps, 2 * max(1, args.model_group)),
                                                  warmup=2, depth=args.model_depth, coder_cus=args.coder_cus,
                                                  cpu=not args.no_cpu_baseline, partition=args.partition,
-                                                 group=max(1, args.model_group))
+                                                 group=max(1, args.model_group), queue=args.model_queue)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
