@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -78,6 +79,21 @@ struct ConvGeom {
   // sub-rectangle [ty0, ty1) x [tx0, tx1) of taps only: 25 instead of 36 tap blocks in that example.
   int compact;
   int ty0[kMaxGroups], ty1[kMaxGroups], tx0[kMaxGroups], tx1[kMaxGroups];
+  // Third-generation kernel: K runs channel block by channel block, a group's taps inside each
+  // (K step = cbi * taps + tap); with `compact` tap rectangles for every group.
+  int cbmajor;
+};
+
+// Third-generation kernel: a workgroup computes an 8 x 32 block of low-resolution output pixels of ONE image
+// from an input patch staged in LDS one 16-channel block at a time.
+struct Conv3Geom {
+  int BXn, BYn;            // blocks per image row / column
+  int PW, PWh;             // patch columns; columns per x-parity plane (ceil(PW / sd))
+  int lg;                  // log2(sd), sd in {1, 2}
+  int granules;            // 16-byte granules of a patch: PH * sd * 2 * PWh, order [row][x parity][h][x / sd]
+  int pixels;              // PH * PW
+  int gcount;              // column groups this launch covers ...
+  int glist[kMaxGroups];   // ... and which
 };
 
 template <typename T> struct ConvTraits;
@@ -109,6 +125,15 @@ __device__ inline float packed_weight(const float* w, const PackGeom& g, const C
     ux = o >> 2;
     ci = o & 3;
     if (ux >= c.Ux || ci >= g.Cin_real) return 0.f;
+  } else if (c.cbmajor) {
+    const int grp = col / (c.tiles * 32);
+    const int wx = c.tx1[grp] - c.tx0[grp];
+    const int nt = (c.ty1[grp] - c.ty0[grp]) * wx;
+    const int cbi = ks / nt, tap = ks % nt;
+    if (cbi >= c.Cin / 16) return 0.f;
+    uy = c.ty0[grp] + tap / wx;
+    ux = c.tx0[grp] + tap % wx;
+    ci = cbi * 16 + koff;
   } else if (c.compact) {
     const int grp = col / (c.tiles * 32);
     const int cb = c.Cin / 16;
@@ -705,10 +730,412 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
   }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 main kernel, third generation (5x5 / 3x3 layers between wide feature maps: Cin % 16 == 0,
+// Cout = 128 or 192 per group).  What the second generation spends beside its MFMAs is the B operand: a
+// 16-byte gather per lane, tap and K step straight from the NHWC tensor (every input value requested kh*kw/sd^2
+// times), each with its bounds test, address select and tap walk.  Here a workgroup owns an 8 x 32 block of
+// low-resolution output pixels of one image and
+//   * stages the input PATCH of that block in LDS, one 16-channel block at a time, double-buffered: every input
+//     value is requested once per workgroup (+ the halo), bounds are tested once per granule and channel block
+//     by the loader, and out-of-image positions are zeros in LDS;
+//   * runs K channel block by channel block, the taps inside: a tap is a wave-uniform LDS offset, so a B
+//     fragment is one ds_read_b128 at (per-lane base) + (scalar tap offset) — no per-lane arithmetic;
+//   * lays the patch out as [row][x parity][h][x / sd] granules of 16 bytes (h = which 8 of the 16 channels):
+//     the 32 pixels of a tile (one output row segment, input stride sd) are consecutive granules of one
+//     parity / h plane, i.e. all 64 banks once per 16-lane group of the ds_read_b128;
+//   * keeps the rest of the second generation: weights as packed A fragments through a double-buffered LDS
+//     chunk (here CH K steps = CH taps of one channel block, CH | taps), A / B fragments double-buffered in
+//     registers, 2 pixel tiles x TILES column tiles per wave, 16-byte output stores.
+// NPG = 16-byte patch pieces per thread (granules / 256, rounded up).
+// TFC_CONV3_EXP (build switch, timing experiments only — results are wrong): 1 no barriers, 2 no weight staging,
+// 4 no patch staging, 8 / 16 B / A fragments read once per chunk, 32 no output stores (tools/conv3_variants.sh).
+// ---------------------------------------------------------------------------
+#ifndef TFC_CONV3_EXP
+#define TFC_CONV3_EXP 0
+#endif
+template <int TILES, int CH, int NPG>
+__global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, const void* packed,
+                                                            const float* bias, __bf16* y, ConvGeom c,
+                                                            Conv3Geom d) {
+  extern __shared__ unsigned char smem[];          // 2 patches of PATCH_BYTES | 2 weight chunks of STAGE * 4 KB
+  constexpr int MT = 2;
+  constexpr int CHUNK_FRAGS = CH * TILES * 64;
+  constexpr int STAGE = (CHUNK_FRAGS + 255) / 256;          // 16-byte pieces per thread and weight chunk
+  // a patch buffer: the granules + room for the (unread) granules of threads past the patch's last pixel
+  constexpr unsigned int PATCH_BYTES = NPG * 4096u + (NPG > 4 ? 2048u : 0u);
+  constexpr unsigned int WBUF_BYTES = STAGE * 4096u;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6, h = lane >> 5, l = lane & 31;
+  long long b = blockIdx.x;
+  const int group = d.glist[b % d.gcount]; b /= d.gcount;
+  const int bx = static_cast<int>(b % d.BXn); b /= d.BXn;
+  const int by = static_cast<int>(b % d.BYn);
+  const long long n = b / d.BYn;
+  const int qx0 = bx * 32, qy0 = by * 8;
+  const int lg = d.lg, sd = 1 << lg, PWh = d.PWh;
+  const int uy0 = c.ty0[group], uy1 = c.ty1[group], ux0 = c.tx0[group], ux1 = c.tx1[group];
+  const int nt = (uy1 - uy0) * (ux1 - ux0);
+  const int cb = c.Cin / 16;
+  const int nch = nt / CH;
+  const int total_chunks = cb * nch;
+  unsigned char* wl = smem + 2 * PATCH_BYTES;
+
+  // ---- loader: this thread's granules of a patch (the same for every channel block).  Buffer loads: a granule
+  // outside the image has an offset outside the image's buffer and reads as zeros — no select, no address
+  // arithmetic (offset register + the channel block as the scalar offset) ----
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x + n * c.H * c.W * c.Cin), 0, c.H * c.W * c.Cin * 2, 0x00020000);
+  // piece 2j + hh of a thread = half hh (8 of the 16 channels) of patch pixel j * 256 + tid: the two halves of a pixel
+  // are requested back to back (one 32-byte run of the tensor), consecutive lanes take consecutive pixels
+  static_assert(NPG % 2 == 0, "two pieces per patch pixel");
+  unsigned int poff[NPG / 2];             // byte offset of the pixel's channel block 0 in the image; outside: zeros
+  unsigned int pdst[NPG / 2];             // its granule in the patch (h = 0; h = 1 at + PWh granules)
+#pragma unroll
+  for (int j = 0; j < NPG / 2; ++j) {
+    const int q = j * 256 + tid;
+    const int py = q / d.PW, px = q - py * d.PW;
+    const int iy = qy0 * sd - c.py0 + py, ix = qx0 * sd - c.px0 + px;
+    const bool ok = (q < d.pixels) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(c.H)) &
+                    (static_cast<unsigned int>(ix) < static_cast<unsigned int>(c.W));
+    poff[j] = ok ? static_cast<unsigned int>((iy * c.W + ix) * c.Cin * 2) : 0x80000000u;
+    // (pixels past the patch: a granule behind it, inside the padded buffer, that nobody reads)
+    pdst[j] = q < d.pixels ? static_cast<unsigned int>((((py << lg) + (px & (sd - 1))) * 2 * PWh + (px >> lg)) * 16)
+                           : PATCH_BYTES - 16u * PWh - 16u;
+  }
+  u32x4 pst[NPG];
+  auto pfetch = [&](int cbi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NPG / 2; ++j) {
+      pst[2 * j] = __builtin_amdgcn_raw_buffer_load_b128(xr, poff[j], cbi * 32, 0);
+      pst[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b128(xr, poff[j] + 16u, cbi * 32, 0);
+    }
+  };
+  auto pstore = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* dst = smem + buf * PATCH_BYTES;
+#pragma unroll
+    for (int j = 0; j < NPG / 2; ++j) {
+      *reinterpret_cast<u32x4*>(dst + pdst[j]) = pst[2 * j];
+      *reinterpret_cast<u32x4*>(dst + pdst[j] + 16u * PWh) = pst[2 * j + 1];
+    }
+  };
+
+  // ---- weights: packed A fragments of this group, chunk by chunk (past the end: zeros) ----
+  const long long wtotal = static_cast<long long>(nt) * cb * TILES * 64;
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(static_cast<const unsigned char*>(packed)) +
+          static_cast<size_t>(group) * c.ksteps * TILES * 64 * 16,
+      0, static_cast<int>(wtotal * 16), 0x00020000);
+  u32x4 stage[STAGE];
+  auto wfetch = [&](int chunk) __attribute__((always_inline)) {
+    const unsigned int v0 = static_cast<unsigned int>(chunk) * (CHUNK_FRAGS * 16u) + tid * 16u;
+#pragma unroll
+    for (int i = 0; i < STAGE; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, v0 + i * 4096u, 0, 0);
+  };
+  auto wstore = [&](int buf) __attribute__((always_inline)) {
+    u32x4* dst = reinterpret_cast<u32x4*>(wl + buf * WBUF_BYTES) + tid;
+#pragma unroll
+    for (int i = 0; i < STAGE; ++i) dst[i * 256] = stage[i];
+  };
+
+  // ---- B: per-lane granule of (tile p, tap (0, 0)); a tap adds a wave-uniform offset ----
+  unsigned int lb[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) {
+    const int row = 2 * wid + p;
+    lb[p] = static_cast<unsigned int>(((row * sd * sd * 2 + h) * PWh + l) * 16);
+  }
+  auto tap_offset = [&](int uy, int ux) -> unsigned int {
+    return static_cast<unsigned int>(((((uy << lg) + (ux & (sd - 1))) * 2) * PWh + (ux >> lg)) * 16);
+  };
+
+  f32x16 acc[MT][TILES];
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.f;
+
+  // Schedule of a chunk c (CH K steps, weights in LDS buffer c & 1):
+  //   start        chunk c + 1 (requested during chunk c - 1) registers -> LDS buffer (c + 1) & 1, whose last readers
+  //                finished before the barrier of chunk c - 1; request chunk c + 2; first chunk of a channel block:
+  //                request the next channel block's patch
+  //   K step kk    reads the fragments of K step kk + 1 under its MFMAs
+  //   end of kk = CH - 2   (the patch registers -> the other patch buffer;) wait for this wave's LDS traffic, barrier
+  //   kk = CH - 1  the fragments it reads ahead are those of chunk c + 1's first K step: from the buffer published
+  //                before the barrier, so no K step ever waits for a read it has just issued behind a barrier
+  // (no __syncthreads: its fence would also wait for the global prefetches in flight).
+  pfetch(0);
+  wfetch(0);
+  pstore(0);
+  wstore(0);
+  wfetch(1);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  bf16x8 af[2][TILES];
+  u32x4 bq[2][MT];
+  int uy = uy0, ux = ux0;                 // tap of the K step whose fragments were read last
+  {
+    const unsigned int toff = tap_offset(uy, ux);
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) af[0][t] = (reinterpret_cast<const bf16x8*>(wl) + lane)[t * 64];
+#pragma unroll
+    for (int p = 0; p < MT; ++p) bq[0][p] = *reinterpret_cast<const u32x4*>(smem + lb[p] + toff);
+  }
+  int chunk = 0, cbi = 0, ch = 0;
+  // PAR = register set that holds the chunk's first K step (alternates between chunks when CH is odd)
+  auto body = [&](auto PAR, const int chunk, const int cbi, const int ch) __attribute__((always_inline)) {
+    constexpr int P0 = decltype(PAR)::value;
+    const int buf = chunk & 1;
+    const bool more = cbi + 1 < cb;
+    const bool first = ch == 0, last = ch + 1 == nch;
+#if !(TFC_CONV3_EXP & 2)
+    wstore(buf ^ 1);                      // (behind the last chunk: zeros into a buffer nobody reads again)
+    wfetch(chunk + 2);                    // past the last chunk: zeros, not used
+#endif
+#if !(TFC_CONV3_EXP & 4)
+    if (first) pfetch(more ? cbi + 1 : cbi);
+#endif
+    const bf16x8* abase = reinterpret_cast<const bf16x8*>(wl + buf * WBUF_BYTES) + lane;
+    const bf16x8* anext = reinterpret_cast<const bf16x8*>(wl + (buf ^ 1) * WBUF_BYTES) + lane;
+    const unsigned char* pbase = smem + (cbi & 1) * PATCH_BYTES;
+    const unsigned char* pnext = smem + ((cbi + (last ? 1 : 0)) & 1) * PATCH_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk) {
+      const int cur = (P0 + kk) & 1, nxt = cur ^ 1;
+      // the next K step's tap (wave-uniform)
+      ++ux;
+      if (ux == ux1) { ux = ux0; ++uy; }
+      if (uy == uy1) uy = uy0;            // past the rectangle: the next channel block starts over
+      const unsigned int toff = tap_offset(uy, ux);
+      if (kk + 1 < CH) {
+#if !(TFC_CONV3_EXP & 16)
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) af[nxt][t] = abase[((kk + 1) * TILES + t) * 64];
+#else
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) af[nxt][t] = af[cur][t];
+#endif
+#if !(TFC_CONV3_EXP & 8)
+#pragma unroll
+        for (int p = 0; p < MT; ++p) bq[nxt][p] = *reinterpret_cast<const u32x4*>(pbase + lb[p] + toff);
+#else
+#pragma unroll
+        for (int p = 0; p < MT; ++p) bq[nxt][p] = bq[cur][p];
+#endif
+      } else {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) af[nxt][t] = anext[t * 64];
+#pragma unroll
+        for (int p = 0; p < MT; ++p) bq[nxt][p] = *reinterpret_cast<const u32x4*>(pnext + lb[p] + toff);
+      }
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int p = 0; p < MT; ++p)
+          acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              af[cur][t], __builtin_bit_cast(bf16x8, bq[cur][p]), acc[p][t], 0, 0, 0);
+#if TFC_CONV_INTERLEAVE
+#pragma unroll
+      for (int i = 0; i < TILES * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+        if (i < TILES + MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one A / B fragment read
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                        // VALU
+        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                        // SALU
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        // a global load of the prefetches
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        // an LDS write of the staging
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == CH - 2) {
+#if !(TFC_CONV3_EXP & 4)
+        // requested in the channel block's first chunk, stored in its last: the gather has all the block's K steps
+        // to arrive (last channel block: its own patch again, into the idle buffer)
+        if (last) pstore((cbi + 1) & 1);
+#endif
+#if !(TFC_CONV3_EXP & 1)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+      }
+    }
+  };
+#define TFC_CONV3_CHUNK(PARV)                                   \
+  do {                                                          \
+    body(std::integral_constant<int, PARV>{}, chunk, cbi, ch);  \
+    ++chunk;                                                    \
+    if (++ch == nch) { ch = 0; ++cbi; }                         \
+  } while (0)
+  if constexpr (CH & 1) {
+    while (chunk + 1 < total_chunks) {
+      TFC_CONV3_CHUNK(0);
+      TFC_CONV3_CHUNK(1);
+    }
+    if (chunk < total_chunks) TFC_CONV3_CHUNK(0);
+  } else {
+    while (chunk < total_chunks) TFC_CONV3_CHUNK(0);
+  }
+#undef TFC_CONV3_CHUNK
+
+  // ---- epilogue: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel (qy0 + 2 wid + p, qx0 + l);
+  // 16-byte stores as in the second generation (Cout % 8 == 0) ----
+  const int colbase = group * TILES * 32;
+  const int qx = qx0 + l;
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      const int col0 = colbase + 32 * t + 16 * qp;
+      if (col0 >= c.cols) continue;
+      const int co = col0 % c.Cout;
+      f32x4 be = f32x4{0.f, 0.f, 0.f, 0.f}, bo = be;
+      if (bias) {
+        be = *reinterpret_cast<const f32x4*>(bias + co + 4 * h);
+        if (col0 + 8 < c.cols) bo = *reinterpret_cast<const f32x4*>(bias + (col0 + 8) % c.Cout + 4 * h);
+      }
+#pragma unroll
+      for (int p = 0; p < MT; ++p) {
+        u32x4 o;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const f32x4& b4 = half ? bo : be;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[p][t][4 * (2 * qp + half) + r] + b4[r];
+            if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
+          }
+          o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+        }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+        const int colh = col0 + 8 * h;
+        const int qy = qy0 + 2 * wid + p;
+#if TFC_CONV3_EXP & 32
+        if (qy >= c.OHq || qx >= c.OWq || colh >= c.cols || be[0] != 12345.f) continue;     // (no stores)
+#else
+        if (qy >= c.OHq || qx >= c.OWq || colh >= c.cols) continue;
+#endif
+        const int coh = colh % c.Cout, ph = colh / c.Cout;
+        const int oy = qy * c.su + ph / c.su, ox = qx * c.su + ph % c.su;
+        *reinterpret_cast<u32x4*>(y + ((n * c.OH + oy) * c.OW + ox) * c.Cout + coh) =
+            u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Host side of the third-generation kernel: 0 = launched, -1 = not this shape (the caller goes on with the second
+// generation), > 0 = error.
+int conv3_gen() {
+  const char* e = std::getenv("TFC_CONV_GEN");     // read per call: tests compare the generations in one process
+  return e ? std::atoi(e) : 3;
+}
+
+int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, ConvGeom c, PackGeom g,
+              hipStream_t st) {
+  if (conv3_gen() < 3 || c.small_cin || c.out_f32 || c.Cin % 16 || (c.sd != 1 && c.sd != 2)) return -1;
+  if (c.Cout != 128 && c.Cout != 192) return -1;
+  // measured (tools/conv3_check.py, profiles/r03_notes.md): ahead of the second generation on the transposed
+  // layers and the stride-1 layers, level with it or behind on the stride-2 analysis layers (their patch is 4x the
+  // pixels per block); and only where the 8 x 32 blocks are mostly inside the map
+  if (!g.up && c.sd == 2 && conv3_gen() < 4) return -1;
+  {
+    const double inside = static_cast<double>(c.OWq) * c.OHq / (((c.OWq + 31) / 32) * 32.0 * (((c.OHq + 7) / 8) * 8.0));
+    if (inside < 0.85) return -1;
+  }
+  c.tiles = c.Cout / 32;
+  c.groups = c.su * c.su;                              // one output phase per group
+  if (c.groups > kMaxGroups) return -1;
+  c.compact = 1;
+  c.cbmajor = 1;
+  const int cb = c.Cin / 16;
+  int most = 0;
+  for (int grp = 0; grp < c.groups; ++grp) {
+    int y0 = 0, y1 = c.Uy, x0 = 0, x1 = c.Ux;
+    if (g.up) {
+      const int phy = grp / g.su, phx = grp % g.su;
+      y0 = c.Uy; y1 = 0; x0 = c.Ux; x1 = 0;
+      for (int u = 0; u < c.Uy; ++u) {
+        const int t = phy + (g.dmax_y - u) * g.su + g.kh / 2;
+        if (t >= 0 && t < g.kh) { y0 = std::min(y0, u); y1 = std::max(y1, u + 1); }
+      }
+      for (int u = 0; u < c.Ux; ++u) {
+        const int t = phx + (g.dmax_x - u) * g.su + g.kw / 2;
+        if (t >= 0 && t < g.kw) { x0 = std::min(x0, u); x1 = std::max(x1, u + 1); }
+      }
+      if (y1 <= y0 || x1 <= x0) return -1;
+    }
+    c.ty0[grp] = y0; c.ty1[grp] = y1; c.tx0[grp] = x0; c.tx1[grp] = x1;
+    most = std::max(most, (y1 - y0) * (x1 - x0));
+  }
+  c.ksteps = most * cb;
+  Conv3Geom d{};
+  d.lg = c.sd == 2 ? 1 : 0;
+  d.BXn = (c.OWq + 31) / 32;
+  d.BYn = (c.OHq + 7) / 8;
+  const int PH = 7 * c.sd + c.Uy;
+  d.PW = 31 * c.sd + c.Ux;
+  d.PWh = (d.PW + c.sd - 1) / c.sd;
+  d.granules = PH * c.sd * 2 * d.PWh;
+  d.pixels = PH * d.PW;
+  const int npg = 2 * ((d.pixels + 255) / 256);        // 16-byte pieces per thread: two per patch pixel
+  const int npgt = npg <= 4 ? 4 : 10;                  // the built loader widths
+  const size_t patch_bytes = static_cast<size_t>(npgt) * 4096 + (npgt > 4 ? 2048 : 0);
+  if (npg > npgt || static_cast<size_t>(d.granules) * 16 + 16 * d.PWh + 16 > patch_bytes) return -1;
+  // launches by chunk length (K steps per weight chunk = taps per chunk): 5 | taps, else 4, else 3
+  int chs[kMaxGroups];
+  for (int grp = 0; grp < c.groups; ++grp) {
+    const int nt = (c.ty1[grp] - c.ty0[grp]) * (c.tx1[grp] - c.tx0[grp]);
+    chs[grp] = nt % 5 == 0 ? 5 : nt % 4 == 0 ? 4 : nt % 3 == 0 ? 3 : 0;
+    if (!chs[grp]) return -1;
+    if (chs[grp] == 5 && npgt != 10) return -1;         // built: (5, 10), (4, 4), (3, 4)
+    if (chs[grp] != 5 && npgt != 4) return -1;
+  }
+  if (c.N * d.BXn * d.BYn * c.groups >= (1ll << 31)) return -1;
+  DevBuf packed;
+  const long long frags = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
+  TFC_HIP(packed.alloc(static_cast<size_t>(frags) * 16 + 64, st));
+  {
+    SlowCall slow("conv_pack_kernel launch", __FILE__, __LINE__);
+    hipLaunchKernelGGL((conv_pack_kernel<__bf16>), dim3(static_cast<unsigned>(ceil_div(frags, 256))), dim3(256), 0, st,
+                       w, g, c, packed.p);
+  }
+  KernelTimer timer("conv2d", st);
+  for (int chv = 3; chv <= 5; ++chv) {
+    d.gcount = 0;
+    for (int grp = 0; grp < c.groups; ++grp)
+      if (chs[grp] == chv) d.glist[d.gcount++] = grp;
+    if (!d.gcount) continue;
+    const size_t lds = 2 * patch_bytes + 2 * static_cast<size_t>((chv * c.tiles * 64 + 255) / 256) * 4096;
+    const dim3 grid(static_cast<unsigned>(c.N * d.BXn * d.BYn * d.gcount));
+#define TFC_CONV3_LAUNCH(NT, CHV, NPGV)                                                                    \
+    do {                                                                                                   \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NPGV>),        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
+      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NPGV>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
+    } while (0)
+    if (c.tiles == 6) {
+      if (chv == 5) TFC_CONV3_LAUNCH(6, 5, 10); else if (chv == 4) TFC_CONV3_LAUNCH(6, 4, 4); else TFC_CONV3_LAUNCH(6, 3, 4);
+    } else {
+      if (chv == 5) TFC_CONV3_LAUNCH(4, 5, 10); else if (chv == 4) TFC_CONV3_LAUNCH(4, 4, 4); else TFC_CONV3_LAUNCH(4, 3, 4);
+    }
+#undef TFC_CONV3_LAUNCH
+  }
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T>
 int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom c, PackGeom g,
              hipStream_t st) {
   constexpr int FB = ConvTraits<T>::kFragBytes;
+  if constexpr (std::is_same<T, __bf16>::value) {
+    const int rc = run_conv3(static_cast<const __bf16*>(x), w, bias, static_cast<__bf16*>(y), c, g, st);
+    if (rc >= 0) return rc;
+  }
   const int tiles_total = (c.cols + 31) / 32;
   // image-side layers (first kernel): 3 column tiles per group — half the accumulators, twice the waves per
   // CU; measured 3.39 -> 2.98 ms on the 5x5 3 -> 192 /2 layer of bmshj2018 at 128 x 768x512 (for the 192 -> 192

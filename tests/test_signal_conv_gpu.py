@@ -82,6 +82,45 @@ def test_up_f32(case):
     assert (y - want).abs().max() <= 2e-5 * max(1.0, want.abs().max())
 
 
+GEN3_CASES = [  # up, n, h, w, cin, cout, k, s  — shapes the third-generation bf16 kernel takes (maps >= 24 wide)
+    (False, 2, 64, 64, 192, 192, 5, 2),      # analysis 5x5 /2 (TFC_CONV_GEN=4 below: built, not the default there)
+    (False, 1, 62, 186, 192, 192, 5, 2),     # blocks hanging over the right and lower edge
+    (False, 2, 32, 48, 192, 192, 3, 1),      # hyper-analysis 3x3
+    (False, 1, 64, 64, 128, 128, 5, 2),      # bls2017 width
+    (True, 2, 32, 48, 192, 192, 5, 2),       # synthesis 5x5 x2: four phase groups of 9 / 6 / 6 / 4 taps
+    (True, 1, 31, 93, 192, 192, 5, 2),
+    (True, 1, 32, 32, 128, 128, 5, 2),
+    (True, 1, 24, 40, 192, 192, 3, 1),
+    (False, 1, 48, 64, 64, 192, 5, 2),       # 4 channel blocks only
+]
+
+
+@pytest.mark.parametrize("case", GEN3_CASES)
+def test_bf16_third_generation(case, monkeypatch):
+    """conv3_bf16_kernel (input patch staged in LDS per 16-channel block, K = channel block x taps) against the
+    float32 definition, and against the second-generation kernel on the same inputs (their K order differs: equal
+    up to the rounding of the bf16 result)."""
+    from compression_amd.layers import conv2d_down, conv2d_up
+    up, n, h, w, cin, cout, k, s = case
+    torch.manual_seed(5)
+    x = torch.randn(n, h, w, cin).bfloat16()
+    ker = (torch.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).bfloat16().float()
+    bias = torch.randn(cout)
+    fn, ref = (conv2d_up, ref_up) if up else (conv2d_down, ref_down)
+    want = ref(x.float(), ker, bias, s, True)
+    got = {}
+    for gen in ("4", "2"):
+        monkeypatch.setenv("TFC_CONV_GEN", gen)
+        got[gen] = fn(x.cuda(), ker, bias, s, "relu").float().cpu()
+        assert got[gen].shape == want.shape
+        assert (got[gen] - want).abs().max() <= 2 ** -7 * max(1.0, want.abs().max())
+    assert (got["4"] - got["2"]).abs().max() <= 2 ** -6 * max(1.0, want.abs().max())
+    # and image by image the same whatever the batch around it
+    monkeypatch.setenv("TFC_CONV_GEN", "4")
+    one = fn(x[:1].cuda(), ker, bias, s, "relu").float().cpu()
+    assert torch.equal(one, got["4"][:1])
+
+
 def test_bf16_paths():
     from compression_amd.layers import conv2d_down, conv2d_up
     torch.manual_seed(2)

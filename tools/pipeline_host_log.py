@@ -1,12 +1,13 @@
 #!/usr/bin/env python
 """Host-side timing of the model software pipeline: how long each stage's enqueue call takes and when, to find
 where the enqueuing thread blocks.  Usage (GPU box): python tools/pipeline_host_log.py [bmshj2018|bls2017] [steps]"""
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from compression_amd import pipeline
 
