@@ -748,13 +748,24 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
 //     chunk (here CH K steps = CH taps of one channel block, CH | taps), A / B fragments double-buffered in
 //     registers, 2 pixel tiles x TILES column tiles per wave, 16-byte output stores.
 // NPG = 16-byte patch pieces per thread (granules / 256, rounded up).
+//   * persistent workgroups (one per CU): a workgroup takes every W-th block and, for each, the launch's groups; the
+//     requests for an item's first patch and weight chunks run under the previous item's last K steps;
+//   * the K steps of a channel block are unrolled into ONE basic block (template NCH chunks x CH K steps): taps are
+//     compile-time indexes into a table of scalar offsets, and the staging of a chunk boundary sits between the MFMAs.
 // TFC_CONV3_EXP (build switch, timing experiments only — results are wrong): 1 no barriers, 2 no weight staging,
-// 4 no patch staging, 8 / 16 B / A fragments read once per chunk, 32 no output stores (tools/conv3_variants.sh).
+// 4 no patch staging, 32 no output stores (tools/conv3_variants.sh).
 // ---------------------------------------------------------------------------
 #ifndef TFC_CONV3_EXP
 #define TFC_CONV3_EXP 0
 #endif
-template <int TILES, int CH, int NPG>
+// workgroup barrier that orders LDS traffic only (a __syncthreads also waits for the global loads in flight)
+#define TFC_LDS_BARRIER()                                                \
+  do {                                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      \
+    __builtin_amdgcn_s_barrier();                                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      \
+  } while (0)
+template <int TILES, int CH, int NCH, int NPG>
 __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, const void* packed,
                                                             const float* bias, __bf16* y, ConvGeom c,
                                                             Conv3Geom d) {
@@ -765,46 +776,67 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   // a patch buffer: the granules + room for the (unread) granules of threads past the patch's last pixel
   constexpr unsigned int PATCH_BYTES = NPG * 4096u + (NPG > 4 ? 2048u : 0u);
   constexpr unsigned int WBUF_BYTES = STAGE * 4096u;
+  static_assert(NPG % 2 == 0, "two pieces per patch pixel");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6, h = lane >> 5, l = lane & 31;
-  long long b = blockIdx.x;
-  const int group = d.glist[b % d.gcount]; b /= d.gcount;
-  const int bx = static_cast<int>(b % d.BXn); b /= d.BXn;
-  const int by = static_cast<int>(b % d.BYn);
-  const long long n = b / d.BYn;
-  const int qx0 = bx * 32, qy0 = by * 8;
   const int lg = d.lg, sd = 1 << lg, PWh = d.PWh;
-  const int uy0 = c.ty0[group], uy1 = c.ty1[group], ux0 = c.tx0[group], ux1 = c.tx1[group];
-  const int nt = (uy1 - uy0) * (ux1 - ux0);
   const int cb = c.Cin / 16;
-  const int nch = nt / CH;
-  const int total_chunks = cb * nch;
   unsigned char* wl = smem + 2 * PATCH_BYTES;
 
-  // ---- loader: this thread's granules of a patch (the same for every channel block).  Buffer loads: a granule
-  // outside the image has an offset outside the image's buffer and reads as zeros — no select, no address
-  // arithmetic (offset register + the channel block as the scalar offset) ----
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__bf16*>(x + n * c.H * c.W * c.Cin), 0, c.H * c.W * c.Cin * 2, 0x00020000);
-  // piece 2j + hh of a thread = half hh (8 of the 16 channels) of patch pixel j * 256 + tid: the two halves of a pixel
-  // are requested back to back (one 32-byte run of the tensor), consecutive lanes take consecutive pixels
-  static_assert(NPG % 2 == 0, "two pieces per patch pixel");
-  unsigned int poff[NPG / 2];             // byte offset of the pixel's channel block 0 in the image; outside: zeros
-  unsigned int pdst[NPG / 2];             // its granule in the patch (h = 0; h = 1 at + PWh granules)
+  // ---- the workgroup's ITEMS: item t = (block w + (t / gcount) * W, group glist[t % gcount]) for workgroup w of W:
+  // persistent, so that the loads of an item's first patch and weight chunks fly under the previous item's last K
+  // steps and its output stores drain under the next item's first ones (a workgroup per block paid ~6 us of
+  // exposed prologue + epilogue per 25-50 us of K loop, with every CU in that phase at the same time) ----
+  const long long nblk = c.N * d.BYn * d.BXn;
+  const int W = gridDim.x, w = blockIdx.x;
+  const long long nitems = w < nblk ? ((nblk - w + W - 1) / W) * d.gcount : 0;
+  if (nitems == 0) return;
+
+  struct Item {                  // wave-uniform
+    long long n;
+    int qx0, qy0, group;
+    int uy0, uy1, ux0, ux1;
+  };
+  auto item_at = [&](long long t) -> Item {
+    Item it;
+    const long long blk = w + (t / d.gcount) * W;
+    it.group = d.glist[t % d.gcount];
+    it.qx0 = static_cast<int>(blk % d.BXn) * 32;
+    it.qy0 = static_cast<int>((blk / d.BXn) % d.BYn) * 8;
+    it.n = blk / (static_cast<long long>(d.BXn) * d.BYn);
+    it.uy0 = c.ty0[it.group]; it.uy1 = c.ty1[it.group]; it.ux0 = c.tx0[it.group]; it.ux1 = c.tx1[it.group];
+    return it;
+  };
+
+  // ---- patch loader.  Piece 2j + hh of a thread = half hh (8 of the 16 channels) of patch pixel j * 256 + tid; the
+  // granule it goes to is the same for every item, the place it comes from (poff) is per item.  Buffer loads: a pixel
+  // outside the image has an offset outside the image's buffer and reads as zeros ----
+  unsigned int pdst[NPG / 2];             // granule of (pixel, h = 0); h = 1 at + PWh granules
 #pragma unroll
   for (int j = 0; j < NPG / 2; ++j) {
     const int q = j * 256 + tid;
     const int py = q / d.PW, px = q - py * d.PW;
-    const int iy = qy0 * sd - c.py0 + py, ix = qx0 * sd - c.px0 + px;
-    const bool ok = (q < d.pixels) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(c.H)) &
-                    (static_cast<unsigned int>(ix) < static_cast<unsigned int>(c.W));
-    poff[j] = ok ? static_cast<unsigned int>((iy * c.W + ix) * c.Cin * 2) : 0x80000000u;
     // (pixels past the patch: a granule behind it, inside the padded buffer, that nobody reads)
     pdst[j] = q < d.pixels ? static_cast<unsigned int>((((py << lg) + (px & (sd - 1))) * 2 * PWh + (px >> lg)) * 16)
                            : PATCH_BYTES - 16u * PWh - 16u;
   }
+  auto patch_offsets = [&](int qx0, int qy0, unsigned int* poff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NPG / 2; ++j) {
+      const int q = j * 256 + tid;
+      const int py = q / d.PW, px = q - py * d.PW;
+      const int iy = qy0 * sd - c.py0 + py, ix = qx0 * sd - c.px0 + px;
+      const bool ok = (q < d.pixels) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(c.H)) &
+                      (static_cast<unsigned int>(ix) < static_cast<unsigned int>(c.W));
+      poff[j] = ok ? static_cast<unsigned int>((iy * c.W + ix) * c.Cin * 2) : 0x80000000u;
+    }
+  };
+  auto image_rsrc = [&](long long n) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x + n * c.H * c.W * c.Cin), 0,
+                                             c.H * c.W * c.Cin * 2, 0x00020000);
+  };
   u32x4 pst[NPG];
-  auto pfetch = [&](int cbi) __attribute__((always_inline)) {
+  auto pfetch = [&](__amdgpu_buffer_rsrc_t xr, const unsigned int* poff, int cbi) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NPG / 2; ++j) {
       pst[2 * j] = __builtin_amdgcn_raw_buffer_load_b128(xr, poff[j], cbi * 32, 0);
@@ -820,17 +852,19 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     }
   };
 
-  // ---- weights: packed A fragments of this group, chunk by chunk (past the end: zeros) ----
-  const long long wtotal = static_cast<long long>(nt) * cb * TILES * 64;
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(static_cast<const unsigned char*>(packed)) +
-          static_cast<size_t>(group) * c.ksteps * TILES * 64 * 16,
-      0, static_cast<int>(wtotal * 16), 0x00020000);
+  // ---- weights: the packed A fragments of a group, chunk by chunk; the request runs two chunks ahead of the K loop
+  // and on into the next item's group (chunks past a group's end read as zeros) ----
+  auto weight_rsrc = [&](const Item& it) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(static_cast<const unsigned char*>(packed)) +
+            static_cast<size_t>(it.group) * c.ksteps * TILES * 64 * 16,
+        0, NCH * cb * (CHUNK_FRAGS * 16), 0x00020000);
+  };
   u32x4 stage[STAGE];
-  auto wfetch = [&](int chunk) __attribute__((always_inline)) {
+  auto wfetch = [&](__amdgpu_buffer_rsrc_t r, int chunk) __attribute__((always_inline)) {
     const unsigned int v0 = static_cast<unsigned int>(chunk) * (CHUNK_FRAGS * 16u) + tid * 16u;
 #pragma unroll
-    for (int i = 0; i < STAGE; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, v0 + i * 4096u, 0, 0);
+    for (int i = 0; i < STAGE; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(r, v0 + i * 4096u, 0, 0);
   };
   auto wstore = [&](int buf) __attribute__((always_inline)) {
     u32x4* dst = reinterpret_cast<u32x4*>(wl + buf * WBUF_BYTES) + tid;
@@ -850,201 +884,247 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   };
 
   f32x16 acc[MT][TILES];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int p = 0; p < MT; ++p)
+    for (int p = 0; p < MT; ++p)
 #pragma unroll
-    for (int t = 0; t < TILES; ++t)
+      for (int t = 0; t < TILES; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.f;
+  };
+  zero_acc();
+
+  // ---- epilogue of an item: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel
+  // (qy0 + 2 wid + p, qx0 + l); 16-byte stores as in the second generation (Cout % 8 == 0) ----
+  auto epilogue = [&](const Item& it) __attribute__((always_inline)) {
+    const int colbase = it.group * TILES * 32;
+    const int qx = it.qx0 + l;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const int col0 = colbase + 32 * t + 16 * qp;
+        if (col0 >= c.cols) continue;
+        const int co = col0 % c.Cout;
+        f32x4 be = f32x4{0.f, 0.f, 0.f, 0.f}, bo = be;
+        if (bias) {
+          be = *reinterpret_cast<const f32x4*>(bias + co + 4 * h);
+          if (col0 + 8 < c.cols) bo = *reinterpret_cast<const f32x4*>(bias + (col0 + 8) % c.Cout + 4 * h);
+        }
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+          u32x4 o;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const f32x4& b4 = half ? bo : be;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[p][t][4 * (2 * qp + half) + r] + b4[r];
+              if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
+            }
+            o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+            o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          }
+          const auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+          const int colh = col0 + 8 * h;
+          const int qy = it.qy0 + 2 * wid + p;
+#if TFC_CONV3_EXP & 32
+          if (qy >= c.OHq || qx >= c.OWq || colh >= c.cols || be[0] != 12345.f) continue;     // (no stores)
+#else
+          if (qy >= c.OHq || qx >= c.OWq || colh >= c.cols) continue;
+#endif
+          const int coh = colh % c.Cout, ph = colh / c.Cout;
+          const int oy = qy * c.su + ph / c.su, ox = qx * c.su + ph % c.su;
+          *reinterpret_cast<u32x4*>(y + ((it.n * c.OH + oy) * c.OW + ox) * c.Cout + coh) =
+              u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
   // Schedule of a chunk c (CH K steps, weights in LDS buffer c & 1):
   //   start        chunk c + 1 (requested during chunk c - 1) registers -> LDS buffer (c + 1) & 1, whose last readers
   //                finished before the barrier of chunk c - 1; request chunk c + 2; first chunk of a channel block:
-  //                request the next channel block's patch
+  //                request the next channel block's patch (the next ITEM's first, behind an item's last)
   //   K step kk    reads the fragments of K step kk + 1 under its MFMAs
-  //   end of kk = CH - 2   (the patch registers -> the other patch buffer;) wait for this wave's LDS traffic, barrier
-  //   kk = CH - 1  the fragments it reads ahead are those of chunk c + 1's first K step: from the buffer published
+  //   end of kk = CH - 2   (last chunk of a channel block: the patch registers -> the other patch buffer;) wait for
+  //                this wave's LDS traffic, barrier
+  //   kk = CH - 1  the fragments it reads ahead are those of chunk c + 1's first K step: from the buffers published
   //                before the barrier, so no K step ever waits for a read it has just issued behind a barrier
   // (no __syncthreads: its fence would also wait for the global prefetches in flight).
-  pfetch(0);
-  wfetch(0);
+  constexpr int NT = CH * NCH;            // taps of a group = K steps of a channel block
+  Item cur = item_at(0);
+  Item nxt = item_at(nitems > 1 ? 1 : 0);
+  unsigned int poff[NPG / 2], poffn[NPG / 2];
+  patch_offsets(cur.qx0, cur.qy0, poff);
+  patch_offsets(nxt.qx0, nxt.qy0, poffn);
+  __amdgpu_buffer_rsrc_t xr = image_rsrc(cur.n), xrn = image_rsrc(nxt.n);
+  __amdgpu_buffer_rsrc_t wr = weight_rsrc(cur), wrn = weight_rsrc(nxt);
+  // the taps' patch offsets (wave-uniform, one SGPR each: the K steps below are unrolled over a whole channel block)
+  unsigned int toff[NT], toffn0;
+  auto tap_table = [&](const Item& it) __attribute__((always_inline)) {
+    const int wx = it.ux1 - it.ux0;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) toff[k] = tap_offset(it.uy0 + k / wx, it.ux0 + k % wx);
+  };
+  tap_table(cur);
+  toffn0 = tap_offset(nxt.uy0, nxt.ux0);
+  pfetch(xr, poff, 0);
+  wfetch(wr, 0);
   pstore(0);
   wstore(0);
-  wfetch(1);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  wfetch(wr, 1);                          // (the host takes items of >= 2 chunks only)
+  TFC_LDS_BARRIER();
 
   bf16x8 af[2][TILES];
   u32x4 bq[2][MT];
-  int uy = uy0, ux = ux0;                 // tap of the K step whose fragments were read last
-  {
-    const unsigned int toff = tap_offset(uy, ux);
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) af[0][t] = (reinterpret_cast<const bf16x8*>(wl) + lane)[t * 64];
+  for (int t = 0; t < TILES; ++t) af[0][t] = (reinterpret_cast<const bf16x8*>(wl) + lane)[t * 64];
 #pragma unroll
-    for (int p = 0; p < MT; ++p) bq[0][p] = *reinterpret_cast<const u32x4*>(smem + lb[p] + toff);
-  }
-  int chunk = 0, cbi = 0, ch = 0;
-  // PAR = register set that holds the chunk's first K step (alternates between chunks when CH is odd)
-  auto body = [&](auto PAR, const int chunk, const int cbi, const int ch) __attribute__((always_inline)) {
-    constexpr int P0 = decltype(PAR)::value;
-    const int buf = chunk & 1;
-    const bool more = cbi + 1 < cb;
-    const bool first = ch == 0, last = ch + 1 == nch;
+  for (int p = 0; p < MT; ++p) bq[0][p] = *reinterpret_cast<const u32x4*>(smem + lb[p] + toff[0]);
+  int gchunk = 0;                         // chunks so far: weight buffer gchunk & 1
+  int pcb = 0;                            // channel blocks so far: patch buffer pcb & 1
+
+  // ONE CHANNEL BLOCK: NT K steps in NCH weight chunks, fully unrolled — one basic block, so that the staging of a
+  // chunk boundary (registers -> LDS, the next requests) and of the patch sits between the MFMAs of the K steps
+  // around it, and a tap is a compile-time index into the offset table.  Schedule of chunk c (weights in LDS buffer
+  // c & 1):
+  //   first K step   chunk c + 1 (requested during chunk c - 1) registers -> LDS buffer (c + 1) & 1, whose last readers
+  //                  finished before the barrier of chunk c - 1; request chunk c + 2; first chunk of the block: request
+  //                  the next channel block's patch (the next ITEM's first, behind an item's last)
+  //   K step kk      reads the fragments of K step kk + 1 under its MFMAs
+  //   end of kk = CH - 2   (last chunk: the patch registers -> the other patch buffer;) LDS barrier
+  //   kk = CH - 1    the fragments it reads ahead are those of chunk c + 1's first K step, from the buffers published
+  //                  before the barrier: no K step waits for a read it has just issued behind a barrier
+  // Fragment register sets alternate per K step; a block of an odd number of K steps ends with a copy so that every
+  // block starts from set 0.
+  auto channel_block = [&](const int cbi, const int chunk0, const int total_chunks, const int wpar, const int pb)
+                           __attribute__((always_inline)) {
+    const bool more = cbi + 1 < cb;       // else: the next channel block is the next item's first
+    const unsigned char* pbase = smem + pb * PATCH_BYTES;
+    const unsigned char* pnext = smem + (pb ^ 1) * PATCH_BYTES;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int buf = wpar ^ (ch & 1);
+      const bf16x8* abase = reinterpret_cast<const bf16x8*>(wl + buf * WBUF_BYTES) + lane;
+      const bf16x8* anext = reinterpret_cast<const bf16x8*>(wl + (buf ^ 1) * WBUF_BYTES) + lane;
 #if !(TFC_CONV3_EXP & 2)
-    wstore(buf ^ 1);                      // (behind the last chunk: zeros into a buffer nobody reads again)
-    wfetch(chunk + 2);                    // past the last chunk: zeros, not used
+      wstore(buf ^ 1);
+      {
+        const int f = chunk0 + ch + 2;
+        const bool here = f < total_chunks;
+        wfetch(here ? wr : wrn, here ? f : f - total_chunks);
+      }
 #endif
 #if !(TFC_CONV3_EXP & 4)
-    if (first) pfetch(more ? cbi + 1 : cbi);
+      if (ch == 0) pfetch(more ? xr : xrn, more ? poff : poffn, more ? cbi + 1 : 0);
 #endif
-    const bf16x8* abase = reinterpret_cast<const bf16x8*>(wl + buf * WBUF_BYTES) + lane;
-    const bf16x8* anext = reinterpret_cast<const bf16x8*>(wl + (buf ^ 1) * WBUF_BYTES) + lane;
-    const unsigned char* pbase = smem + (cbi & 1) * PATCH_BYTES;
-    const unsigned char* pnext = smem + ((cbi + (last ? 1 : 0)) & 1) * PATCH_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < CH; ++kk) {
-      const int cur = (P0 + kk) & 1, nxt = cur ^ 1;
-      // the next K step's tap (wave-uniform)
-      ++ux;
-      if (ux == ux1) { ux = ux0; ++uy; }
-      if (uy == uy1) uy = uy0;            // past the rectangle: the next channel block starts over
-      const unsigned int toff = tap_offset(uy, ux);
-      if (kk + 1 < CH) {
-#if !(TFC_CONV3_EXP & 16)
+      for (int kk = 0; kk < CH; ++kk) {
+        const int k = ch * CH + kk;
+        const int cur_set = k & 1, nxt_set = cur_set ^ 1;
+        if (kk + 1 < CH) {
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) af[nxt][t] = abase[((kk + 1) * TILES + t) * 64];
-#else
+          for (int t = 0; t < TILES; ++t) af[nxt_set][t] = abase[((kk + 1) * TILES + t) * 64];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) af[nxt][t] = af[cur][t];
-#endif
-#if !(TFC_CONV3_EXP & 8)
+          for (int p = 0; p < MT; ++p) bq[nxt_set][p] = *reinterpret_cast<const u32x4*>(pbase + lb[p] + toff[k + 1 < NT ? k + 1 : 0]);
+        } else {
+          const bool block_end = ch + 1 == NCH;
+          const unsigned int tn = !block_end ? toff[k + 1 < NT ? k + 1 : 0] : (more ? toff[0] : toffn0);
 #pragma unroll
-        for (int p = 0; p < MT; ++p) bq[nxt][p] = *reinterpret_cast<const u32x4*>(pbase + lb[p] + toff);
-#else
+          for (int t = 0; t < TILES; ++t) af[nxt_set][t] = anext[t * 64];
 #pragma unroll
-        for (int p = 0; p < MT; ++p) bq[nxt][p] = bq[cur][p];
-#endif
-      } else {
+          for (int p = 0; p < MT; ++p)
+            bq[nxt_set][p] = *reinterpret_cast<const u32x4*>((block_end ? pnext : pbase) + lb[p] + tn);
+        }
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) af[nxt][t] = anext[t * 64];
+        for (int t = 0; t < TILES; ++t)
 #pragma unroll
-        for (int p = 0; p < MT; ++p) bq[nxt][p] = *reinterpret_cast<const u32x4*>(pnext + lb[p] + toff);
-      }
-#pragma unroll
-      for (int t = 0; t < TILES; ++t)
-#pragma unroll
-        for (int p = 0; p < MT; ++p)
-          acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              af[cur][t], __builtin_bit_cast(bf16x8, bq[cur][p]), acc[p][t], 0, 0, 0);
+          for (int p = 0; p < MT; ++p)
+            acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                af[cur_set][t], __builtin_bit_cast(bf16x8, bq[cur_set][p]), acc[p][t], 0, 0, 0);
 #if TFC_CONV_INTERLEAVE
 #pragma unroll
-      for (int i = 0; i < TILES * MT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
-        if (i < TILES + MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one A / B fragment read
-        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                        // VALU
-        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                        // SALU
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        // a global load of the prefetches
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        // an LDS write of the staging
-      }
+        for (int i = 0; i < TILES * MT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+          if (i < TILES + MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one A / B fragment read
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        // an LDS write of the staging
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                        // global loads of the prefetches
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                        // VALU
+          __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                        // SALU
+        }
 #endif
-      __builtin_amdgcn_sched_barrier(0);
-      if (kk == CH - 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk == CH - 2) {
 #if !(TFC_CONV3_EXP & 4)
-        // requested in the channel block's first chunk, stored in its last: the gather has all the block's K steps
-        // to arrive (last channel block: its own patch again, into the idle buffer)
-        if (last) pstore((cbi + 1) & 1);
+          // requested in the block's first chunk, stored in its last: the gather has the whole block to arrive
+          if (ch + 1 == NCH) pstore(pb ^ 1);
 #endif
 #if !(TFC_CONV3_EXP & 1)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          TFC_LDS_BARRIER();
 #endif
+        }
       }
+    }
+    if constexpr (NT & 1) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) af[0][t] = af[1][t];
+#pragma unroll
+      for (int p = 0; p < MT; ++p) bq[0][p] = bq[1][p];
     }
   };
-#define TFC_CONV3_CHUNK(PARV)                                   \
-  do {                                                          \
-    body(std::integral_constant<int, PARV>{}, chunk, cbi, ch);  \
-    ++chunk;                                                    \
-    if (++ch == nch) { ch = 0; ++cbi; }                         \
-  } while (0)
-  if constexpr (CH & 1) {
-    while (chunk + 1 < total_chunks) {
-      TFC_CONV3_CHUNK(0);
-      TFC_CONV3_CHUNK(1);
+  for (long long t_item = 0; t_item < nitems; ++t_item) {
+    const int total_chunks = cb * NCH;
+    for (int cbi = 0; cbi < cb; ++cbi) {
+      channel_block(cbi, cbi * NCH, total_chunks, gchunk & 1, pcb & 1);
+      gchunk += NCH;
+      ++pcb;
     }
-    if (chunk < total_chunks) TFC_CONV3_CHUNK(0);
-  } else {
-    while (chunk < total_chunks) TFC_CONV3_CHUNK(0);
-  }
-#undef TFC_CONV3_CHUNK
-
-  // ---- epilogue: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel (qy0 + 2 wid + p, qx0 + l);
-  // 16-byte stores as in the second generation (Cout % 8 == 0) ----
-  const int colbase = group * TILES * 32;
-  const int qx = qx0 + l;
+    epilogue(cur);
+    zero_acc();
+    cur = nxt;
+    xr = xrn;
+    wr = wrn;
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) {
-#pragma unroll
-    for (int qp = 0; qp < 2; ++qp) {
-      const int col0 = colbase + 32 * t + 16 * qp;
-      if (col0 >= c.cols) continue;
-      const int co = col0 % c.Cout;
-      f32x4 be = f32x4{0.f, 0.f, 0.f, 0.f}, bo = be;
-      if (bias) {
-        be = *reinterpret_cast<const f32x4*>(bias + co + 4 * h);
-        if (col0 + 8 < c.cols) bo = *reinterpret_cast<const f32x4*>(bias + (col0 + 8) % c.Cout + 4 * h);
-      }
-#pragma unroll
-      for (int p = 0; p < MT; ++p) {
-        u32x4 o;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const f32x4& b4 = half ? bo : be;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[p][t][4 * (2 * qp + half) + r] + b4[r];
-            if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
-          }
-          o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
-          o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
-        }
-        const auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
-        const auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
-        const int colh = col0 + 8 * h;
-        const int qy = qy0 + 2 * wid + p;
-#if TFC_CONV3_EXP & 32
-        if (qy >= c.OHq || qx >= c.OWq || colh >= c.cols || be[0] != 12345.f) continue;     // (no stores)
-#else
-        if (qy >= c.OHq || qx >= c.OWq || colh >= c.cols) continue;
-#endif
-        const int coh = colh % c.Cout, ph = colh / c.Cout;
-        const int oy = qy * c.su + ph / c.su, ox = qx * c.su + ph % c.su;
-        *reinterpret_cast<u32x4*>(y + ((n * c.OH + oy) * c.OW + ox) * c.Cout + coh) =
-            u32x4{s0[0], s1[0], s0[1], s1[1]};
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < NPG / 2; ++j) poff[j] = poffn[j];
+    nxt = item_at(t_item + 2 < nitems ? t_item + 2 : nitems - 1);
+    xrn = image_rsrc(nxt.n);
+    wrn = weight_rsrc(nxt);
+    patch_offsets(nxt.qx0, nxt.qy0, poffn);
+    tap_table(cur);
+    toffn0 = tap_offset(nxt.uy0, nxt.ux0);
   }
 }
 
 // Host side of the third-generation kernel: 0 = launched, -1 = not this shape (the caller goes on with the second
 // generation), > 0 = error.
+// TFC_CONV_GEN: 2 (default) the second generation everywhere; 3 the third on the transposed 5x5 layers of wide maps;
+// 4 the third wherever it is built.  Why 2: alone on the chip the third generation takes 31.0 instead of 34.0 ms of a
+// C4 step's convolutions, but with 8 steps in flight (bench.py's model line) the step is 48.8 instead of 47.0 ms — its
+// workgroups hold 152 KB of LDS and gather their patches from HBM / the infinity cache beside the other steps' kernels
+// (profiles/r03_notes.md).  Read per call: tests compare the generations in one process.
 int conv3_gen() {
-  const char* e = std::getenv("TFC_CONV_GEN");     // read per call: tests compare the generations in one process
-  return e ? std::atoi(e) : 3;
+  const char* e = std::getenv("TFC_CONV_GEN");
+  return e ? std::atoi(e) : 2;
 }
 
 int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, ConvGeom c, PackGeom g,
               hipStream_t st) {
   if (conv3_gen() < 3 || c.small_cin || c.out_f32 || c.Cin % 16 || (c.sd != 1 && c.sd != 2)) return -1;
   if (c.Cout != 128 && c.Cout != 192) return -1;
-  // measured (tools/conv3_check.py, profiles/r03_notes.md): ahead of the second generation on the transposed
-  // layers and the stride-1 layers, level with it or behind on the stride-2 analysis layers (their patch is 4x the
-  // pixels per block); and only where the 8 x 32 blocks are mostly inside the map
-  if (!g.up && c.sd == 2 && conv3_gen() < 4) return -1;
+  // Where it is used (measured, tools/conv3_check.py and profiles/r03_notes.md): the transposed 5x5 layers, where it is
+  // 18-25 % ahead of the second generation.  On the stride-2 analysis layers it is level with it (TFC_CONV_GEN=4 runs
+  // it there): their patch is 4x the pixels per block and its 32-byte gathers re-fetch every 128-byte line of the input
+  // once per channel block.  The rule looks at the map only, never at the batch: an image's result must not depend on
+  // the batch it is coded in.
+  if (conv3_gen() < 4 && !(g.up && c.su == 2)) return -1;
   {
-    const double inside = static_cast<double>(c.OWq) * c.OHq / (((c.OWq + 31) / 32) * 32.0 * (((c.OHq + 7) / 8) * 8.0));
-    if (inside < 0.85) return -1;
+    const int bxn = (c.OWq + 31) / 32, byn = (c.OHq + 7) / 8;
+    if (static_cast<double>(c.OWq) * c.OHq < 0.85 * (bxn * 32.0 * byn * 8.0)) return -1;   // blocks mostly outside the map
+    if (bxn * byn < 8 && conv3_gen() < 4) return -1;                                       // a handful of blocks per image
   }
   c.tiles = c.Cout / 32;
   c.groups = c.su * c.su;                              // one output phase per group
@@ -1085,16 +1165,15 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
   const int npgt = npg <= 4 ? 4 : 10;                  // the built loader widths
   const size_t patch_bytes = static_cast<size_t>(npgt) * 4096 + (npgt > 4 ? 2048 : 0);
   if (npg > npgt || static_cast<size_t>(d.granules) * 16 + 16 * d.PWh + 16 > patch_bytes) return -1;
-  // launches by chunk length (K steps per weight chunk = taps per chunk): 5 | taps, else 4, else 3
-  int chs[kMaxGroups];
+  // a launch per tap count: the kernel is built for 25 taps (5 chunks of 5 K steps; the big patch loader), and 9
+  // (3 x 3), 6 (2 x 3), 4 (1 x 4) taps with the small one
+  int nts[kMaxGroups];
   for (int grp = 0; grp < c.groups; ++grp) {
-    const int nt = (c.ty1[grp] - c.ty0[grp]) * (c.tx1[grp] - c.tx0[grp]);
-    chs[grp] = nt % 5 == 0 ? 5 : nt % 4 == 0 ? 4 : nt % 3 == 0 ? 3 : 0;
-    if (!chs[grp]) return -1;
-    if (chs[grp] == 5 && npgt != 10) return -1;         // built: (5, 10), (4, 4), (3, 4)
-    if (chs[grp] != 5 && npgt != 4) return -1;
+    nts[grp] = (c.ty1[grp] - c.ty0[grp]) * (c.tx1[grp] - c.tx0[grp]);
+    const bool built = (nts[grp] == 25 && npgt == 10) || ((nts[grp] == 9 || nts[grp] == 6 || nts[grp] == 4) && npgt == 4);
+    if (!built) return -1;
+    if (cb * (nts[grp] == 25 ? 5 : nts[grp] == 9 ? 3 : nts[grp] == 6 ? 2 : 1) < 2) return -1;   // (weights are requested two chunks ahead)
   }
-  if (c.N * d.BXn * d.BYn * c.groups >= (1ll << 31)) return -1;
   DevBuf packed;
   const long long frags = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
   TFC_HIP(packed.alloc(static_cast<size_t>(frags) * 16 + 64, st));
@@ -1103,25 +1182,44 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     hipLaunchKernelGGL((conv_pack_kernel<__bf16>), dim3(static_cast<unsigned>(ceil_div(frags, 256))), dim3(256), 0, st,
                        w, g, c, packed.p);
   }
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   KernelTimer timer("conv2d", st);
-  for (int chv = 3; chv <= 5; ++chv) {
+  const int tap_counts[4] = {25, 9, 6, 4};
+  for (int ntv : tap_counts) {
     d.gcount = 0;
     for (int grp = 0; grp < c.groups; ++grp)
-      if (chs[grp] == chv) d.glist[d.gcount++] = grp;
+      if (nts[grp] == ntv) d.glist[d.gcount++] = grp;
     if (!d.gcount) continue;
+    const int chv = ntv == 25 ? 5 : ntv == 4 ? 4 : 3;
     const size_t lds = 2 * patch_bytes + 2 * static_cast<size_t>((chv * c.tiles * 64 + 255) / 256) * 4096;
-    const dim3 grid(static_cast<unsigned>(c.N * d.BXn * d.BYn * d.gcount));
-#define TFC_CONV3_LAUNCH(NT, CHV, NPGV)                                                                    \
+    // One workgroup per block (its items = the launch's groups).  The kernel can run persistently — any smaller grid
+    // makes a workgroup take every W-th block, TFC_CONV3_PERSISTENT=1 launches one per CU — and alone on the chip that is
+    // the same speed; but a model step shares the chip with the other steps in flight, and workgroups that hold their
+    // CU for the whole launch keep those kernels out: C4 51.6 instead of 47.6 ms per step (profiles/r03_notes.md).
+    static const bool persistent = [] {
+      const char* e = std::getenv("TFC_CONV3_PERSISTENT");
+      return e && std::atoi(e) != 0;
+    }();
+    const long long nblk = c.N * d.BXn * d.BYn;
+    if (nblk >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
+    const dim3 grid(static_cast<unsigned>(persistent ? std::min<long long>(nblk, cus) : nblk));
+#define TFC_CONV3_LAUNCH(NT, CHV, NCHV, NPGV)                                                              \
     do {                                                                                                   \
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NPGV>),        \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV>),  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
-      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NPGV>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
+      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
     } while (0)
-    if (c.tiles == 6) {
-      if (chv == 5) TFC_CONV3_LAUNCH(6, 5, 10); else if (chv == 4) TFC_CONV3_LAUNCH(6, 4, 4); else TFC_CONV3_LAUNCH(6, 3, 4);
-    } else {
-      if (chv == 5) TFC_CONV3_LAUNCH(4, 5, 10); else if (chv == 4) TFC_CONV3_LAUNCH(4, 4, 4); else TFC_CONV3_LAUNCH(4, 3, 4);
-    }
+#define TFC_CONV3_TAPS(NT)                                                   \
+    do {                                                                     \
+      if (ntv == 25) TFC_CONV3_LAUNCH(NT, 5, 5, 10);                         \
+      else if (ntv == 9) TFC_CONV3_LAUNCH(NT, 3, 3, 4);                      \
+      else if (ntv == 6) TFC_CONV3_LAUNCH(NT, 3, 2, 4);                      \
+      else TFC_CONV3_LAUNCH(NT, 4, 1, 4);                                    \
+    } while (0)
+    if (c.tiles == 6) TFC_CONV3_TAPS(6); else TFC_CONV3_TAPS(4);
+#undef TFC_CONV3_TAPS
 #undef TFC_CONV3_LAUNCH
   }
   TFC_HIP(hipGetLastError());
