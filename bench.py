@@ -943,7 +943,7 @@ def main():
                          "kernels code them in one launch per direction where the tables' image fits the LDS (the "
                          "random-init bls2017 tables do not: 172 KB); 1 = every batch its own launch")
     ap.add_argument("--model-queue", type=int, default=2, help="model steps enqueued per stream (--model-depth streams)")
-    ap.add_argument("--model-steps", type=int, default=12, help="timed steps of the `models` sub-objects")
+    ap.add_argument("--model-steps", type=int, default=32, help="timed steps of the `models` sub-objects")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -1419,6 +1419,20 @@ inline size_t lds_request(size_t need) {
 // Waves (= code streams) that share one LDS copy of the tables.  4 keeps a lone 512-stream
 // launch at one wave per SIMD; TFC_WAVES_PER_BLOCK=8 puts 8 streams behind one table copy (measured
 // slower, also with many launches in flight).
+// Waves a workgroup of `streams` code streams gets: the limit (one wave per SIMD of a CU) whenever there are that many
+// streams.  Fewer, fuller workgroups: a CU that hosts even one coder wave is lost to a convolution workgroup — which
+// wants all four SIMDs' registers — for as long as that wave runs, so with model steps in flight 128 streams as 64
+// workgroups of 2 waves cost the transforms twice the CUs of 32 workgroups of 4 (C4: 47.2 -> 45.2 ms per step; 8 or 16
+// waves per workgroup, two or four per SIMD: 51.2 / 63.5).  TFC_PACK_WAVES=0: the old spread (a wave per 64 streams).
+inline int64_t waves_per_block_limit();
+inline int64_t waves_wanted(int64_t streams) {
+  static const bool pack = [] {
+    const char* e = std::getenv("TFC_PACK_WAVES");
+    return !e || std::atoi(e) != 0;
+  }();
+  const int64_t spread = std::max<int64_t>(1, pack ? streams : ceil_div(streams, 64));
+  return std::min<int64_t>(waves_per_block_limit(), spread);
+}
 inline int64_t waves_per_block_limit() {
   static const int64_t v = [] {
     const char* e = std::getenv("TFC_WAVES_PER_BLOCK");
@@ -1869,7 +1883,7 @@ extern "C" int tfc_encoder_create(const tfc_tables* tables, int64_t streams, voi
     if (!tables->rows.empty() && fixed + ring <= 160 * 1024) {
       e->fast = true;
       const size_t fit = (160 * 1024 - fixed) / ring;
-      const size_t want = static_cast<size_t>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(streams, 64))));
+      const size_t want = static_cast<size_t>(waves_wanted(streams));
       e->fast_waves = static_cast<int>(std::min(fit, want));
       e->fast_lds = fixed + ring * e->fast_waves;
     }
@@ -1907,7 +1921,7 @@ extern "C" int tfc_encoder_create_many(const tfc_tables* tables, int64_t streams
     if (!tables->rows.empty() && fixed + ring <= 160 * 1024) {
       e->fast = true;
       const size_t fit = (160 * 1024 - fixed) / ring;
-      const size_t want = static_cast<size_t>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(streams, 64))));
+      const size_t want = static_cast<size_t>(waves_wanted(streams));
       e->fast_waves = static_cast<int>(std::min(fit, want));
       e->fast_lds = fixed + ring * e->fast_waves;
     }
@@ -2521,7 +2535,7 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
     return decode_lanes_many(&d, 1, &dst, &index, elems, st);
   } else if (family == kFast) {
     KernelTimer timer("dec_kernel", st);
-    const int waves = static_cast<int>(std::min<int64_t>(waves_per_block_limit(), std::max<int64_t>(1, ceil_div(d->streams, 64))));
+    const int waves = static_cast<int>(waves_wanted(d->streams));
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds_request(fast_lds))));
