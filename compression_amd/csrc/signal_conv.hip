@@ -1101,14 +1101,15 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
 
 // Host side of the third-generation kernel: 0 = launched, -1 = not this shape (the caller goes on with the second
 // generation), > 0 = error.
-// TFC_CONV_GEN: 2 (default) the second generation everywhere; 3 the third on the transposed 5x5 layers of wide maps;
-// 4 the third wherever it is built.  Why 2: alone on the chip the third generation takes 31.0 instead of 34.0 ms of a
-// C4 step's convolutions, but with 8 steps in flight (bench.py's model line) the step is 48.8 instead of 47.0 ms — its
-// workgroups hold 152 KB of LDS and gather their patches from HBM / the infinity cache beside the other steps' kernels
-// (profiles/r03_notes.md).  Read per call: tests compare the generations in one process.
+// TFC_CONV_GEN: 2 the second generation everywhere; 3 (default) the third on the transposed 5x5 layers of wide maps;
+// 4 the third wherever it is built.  Measured on C4 (profiles/r03_notes.md): a step's convolutions take 31.0 instead of
+// 34.0 ms alone on the chip, and with 8 steps in flight the step 40.8 instead of 43.0 ms (before the coder's workgroups
+// were packed four waves to a CU it was the other way round, 48.8 against 47.0: the third generation's workgroups hold
+// 152 KB of LDS and found even fewer CUs free of coder waves).  Read per call: tests compare the generations in one
+// process.
 int conv3_gen() {
   const char* e = std::getenv("TFC_CONV_GEN");
-  return e ? std::atoi(e) : 2;
+  return e ? std::atoi(e) : 3;
 }
 
 int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, ConvGeom c, PackGeom g,
