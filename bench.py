@@ -635,12 +635,14 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
             group = group if hasattr(model, "compress_many") else 1
             run = lambda n: run_model_steps(model, x, n, lanes, group=group)
         steps = max(group, steps - steps % group)
+        _lib.check(_lib.lib().tfc_set_chip_shared(1))      # several steps in flight: pipeline.chip_shared()
         run(max(warmup, len(lanes), 2) * group)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
             torch.cuda.synchronize()
         elapsed, rec = run(steps)
+        _lib.lib().tfc_set_chip_shared(0)
         gathered = None
         if distributed:
             # the coded strings of the whole batch on every rank: lengths, then padded bytes (two all-gathers)

@@ -23,6 +23,7 @@ SIGNATURES = {
     "tfc_set_default_mode": (_int, [_int]),
     "tfc_get_default_mode": (_int, []),
     "tfc_set_coder_gate": (_int, [_vp]),
+    "tfc_set_chip_shared": (_int, [_int]),
     "tfc_device_compute_units": (_int, [C.POINTER(_int)]),
     "tfc_stream_create_cu_mask": (_int, [_vp, _int, C.POINTER(_vp)]),
     "tfc_stream_destroy": (_int, [_vp]),

@@ -131,6 +131,15 @@ KernelTimer::~KernelTimer() {
 
 using namespace tfc;
 
+namespace {
+std::atomic<int> g_chip_shared{0};      // tfc_set_chip_shared
+}
+
+extern "C" int tfc_set_chip_shared(int shared) {
+  g_chip_shared.store(shared ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+
 extern "C" int tfc_set_coder_gate(void* event) {
   tfc::g_coder_gate = static_cast<hipEvent_t>(event);
   return 0;
@@ -1425,13 +1434,21 @@ inline size_t lds_request(size_t need) {
 // workgroups of 2 waves cost the transforms twice the CUs of 32 workgroups of 4 (C4: 47.2 -> 45.2 ms per step; 8 or 16
 // waves per workgroup, two or four per SIMD: 51.2 / 63.5).  TFC_PACK_WAVES=0: the old spread (a wave per 64 streams).
 inline int64_t waves_per_block_limit();
+inline bool waves_per_block_given() { return std::getenv("TFC_WAVES_PER_BLOCK") != nullptr; }
 inline int64_t waves_wanted(int64_t streams) {
   static const bool pack = [] {
     const char* e = std::getenv("TFC_PACK_WAVES");
     return !e || std::atoi(e) != 0;
   }();
+  static const bool given = waves_per_block_given();
+  // tfc_set_chip_shared(1) — the caller keeps other kernels in flight beside the coder's: 512 streams and more get two
+  // waves per SIMD, i.e. 64 instead of 128 CUs under a bls2017 batch (C1: 12.0 -> 11.1 ms per step with 8 steps in
+  // flight; a lone 512-stream call is 1.4x slower that way, 6.5 -> 8.8 ms, hence not the default); for 128 streams the
+  // same packing costs more than it frees (profiles/r03_notes.md)
+  const bool shared = g_chip_shared.load(std::memory_order_relaxed) != 0;
+  const int64_t limit = given ? waves_per_block_limit() : (pack && shared && streams >= 512 ? 8 : waves_per_block_limit());
   const int64_t spread = std::max<int64_t>(1, pack ? streams : ceil_div(streams, 64));
-  return std::min<int64_t>(waves_per_block_limit(), spread);
+  return std::min<int64_t>(limit, spread);
 }
 inline int64_t waves_per_block_limit() {
   static const int64_t v = [] {

@@ -27,7 +27,18 @@ import torch
 
 from . import _lib
 
-__all__ = ["CoderPartition", "Lane", "inline_lane", "SoftwarePipeline"]
+__all__ = ["CoderPartition", "Lane", "inline_lane", "SoftwarePipeline", "chip_shared"]
+
+
+@contextlib.contextmanager
+def chip_shared(shared=True):
+    """Coder handles created inside know that other kernels run beside theirs (tfc_set_chip_shared): batches of 512
+    streams and more are packed two waves per SIMD, on half the CUs."""
+    _lib.check(_lib.lib().tfc_set_chip_shared(1 if shared else 0))
+    try:
+        yield
+    finally:
+        _lib.lib().tfc_set_chip_shared(0)
 
 
 class Lane:

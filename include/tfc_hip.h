@@ -80,6 +80,11 @@ int tfc_get_default_mode(void);
  * running large grids back to back is not dispatched until that queue drains, whereas kernels released together
  * (or coder first) run side by side (tools/queue_pair_probe.py). */
 int tfc_set_coder_gate(void* event);
+/* Process-wide hint: 1 = the caller keeps other kernels (the transforms of other batches) in flight beside the coder's,
+ * 0 (default) = a coder call has the chip to itself.  Shared: handles of 512 streams and more are created with two
+ * waves per SIMD (half the CUs; a convolution workgroup cannot use a CU that hosts a coder wave).  Takes effect for
+ * handles created afterwards.  No reference counterpart (TensorFlow's executor owns such placement). */
+int tfc_set_chip_shared(int shared);
 int tfc_device_compute_units(int* cus);
 int tfc_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
 int tfc_stream_destroy(void* stream);

@@ -194,6 +194,25 @@ def test_coder_gate_is_recorded_once_in_front_of_the_next_coding_kernel():
         [bytes(s) for s in tfc.fetch_strings(tfc.entropy_encode_finalize_device(h2))]
 
 
+def test_chip_shared_hint_changes_only_the_launch_shape():
+    """pipeline.chip_shared(): handles of >= 512 streams are created with two waves per SIMD (tfc_set_chip_shared);
+    the strings and the decoded symbols are those of the default layout."""
+    _, lookup = _tables()
+    lt = torch.from_numpy(lookup)
+    value = synthetic.sample_symbols(lookup, 640, 3000, seed=8, escape_fraction=0.004)
+    v = torch.from_numpy(value).cuda()
+    out = []
+    for shared in (False, True):
+        with pipeline.chip_shared(shared):
+            h = tfc.entropy_encode_finalize_device(
+                tfc.entropy_encode_channel(tfc.create_range_encoder([640], lt, mode="latency", deferred_errors=True), v))
+            d, dec = tfc.entropy_decode_channel(tfc.create_range_decoder(h, lt, mode="latency"), [3000], torch.int32)
+            ok = tfc.entropy_decode_finalize_device(d)
+        out.append(([bytes(s) for s in tfc.fetch_strings(h)], dec.cpu(), ok.cpu()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[1][1], torch.from_numpy(value)) and bool(out[1][2].all())
+
+
 def test_cu_partition_masks():
     part = pipeline.CoderPartition(coder_cus=32, depth=1)
     assert part.total_cus >= 64 and part.coder_cus == 32
