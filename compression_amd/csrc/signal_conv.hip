@@ -1425,6 +1425,359 @@ __global__ void __launch_bounds__(256) conv_up_gather_kernel(const float* z, con
   }
 }
 
+// ---------------------------------------------------------------------------
+// Image-side analysis layer (Cin <= 4 -> 128 / 192 channels, stride 2 or 4, bf16): all of its time is the output
+// (4.8 GB at the C4 shape) — K is a few dozen steps.  A workgroup takes an 8 x 32 block of output pixels, stages the
+// image patch under it in LDS as rows of interleaved (x, c) values (19 x 67 pixels x 3 channels = 8 KB for 5x5 / 2),
+// and runs K kernel row by kernel row: the kw * Cin values of a row are CONTIGUOUS in the patch, so a row is
+// ceil(kw * Cin / 16) K steps (one for 5x5 x 3, against two with the 4-channel padding of the first kernel), and a
+// B fragment is 16 bytes at (row, 2-byte-aligned column): four ds_read_b32.  Two workgroups per CU (LDS 40 KB, 256
+// registers per wave): one's output stores drain under the other's MFMAs.
+// ---------------------------------------------------------------------------
+struct ImageConvGeom {
+  long long N;
+  int H, W, Cin, Cout;
+  int kh, kw, sd;
+  int py0, px0;
+  int OH, OW;
+  int BXn, BYn;
+  int PH, RL, RS;           // patch rows; values per row in use; row stride (values)
+  int ksr;                  // K steps per kernel row
+  int activation;
+};
+
+__global__ void conv_image_weights_kernel(const float* w, ImageConvGeom g, int tiles, bf16x8* packed) {
+  // packed[((ty * ksr + ks) * tiles + t) * 64 + lane], lane (i, h): row values 16 ks + 8h .. + 7, output column 32t + i
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = g.kh * g.ksr * tiles * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  int r = idx >> 6;
+  const int t = r % tiles; r /= tiles;
+  const int ks = r % g.ksr, ty = r / g.ksr;
+  const int co = 32 * t + (lane & 31), h = lane >> 5;
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * ks + 8 * h + e;
+    const int tx = k / g.Cin, c = k % g.Cin;
+    v[e] = static_cast<__bf16>(tx < g.kw && co < g.Cout
+                                   ? w[((static_cast<long long>(ty) * g.kw + tx) * g.Cin + c) * g.Cout + co] : 0.f);
+  }
+  packed[idx] = v;
+}
+
+template <int TILES>
+__global__ void __launch_bounds__(256, 2) conv_image_kernel(const __bf16* x, const bf16x8* wpk, const float* bias,
+                                                            __bf16* y, ImageConvGeom g) {
+  extern __shared__ unsigned char smem[];            // patch: PH rows of RS values | weight fragments
+  constexpr int MT = 2;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5, l = lane & 31;
+  long long b = blockIdx.x;
+  const int bx = static_cast<int>(b % g.BXn); b /= g.BXn;
+  const int by = static_cast<int>(b % g.BYn);
+  const long long n = b / g.BYn;
+  const int qx0 = bx * 32, qy0 = by * 8;
+  unsigned short* patch = reinterpret_cast<unsigned short*>(smem);
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smem + static_cast<size_t>(g.PH) * g.RS * 2);
+  const int nfr = g.kh * g.ksr * TILES * 64;
+  for (int i = tid; i < nfr; i += 256) wl[i] = wpk[i];
+  // patch: value j of row py = x[n][iy][ix0 + j / Cin][j % Cin]: contiguous in the image row
+  const unsigned short* xn = reinterpret_cast<const unsigned short*>(x) + n * g.H * g.W * g.Cin;
+  const int ix0 = qx0 * g.sd - g.px0;
+  constexpr int PB = 8;                                // loads in flight per thread (the patch is 16-60 values each)
+  const int pvals = g.PH * g.RS;
+  for (int i0 = tid; i0 < pvals; i0 += 256 * PB) {
+    unsigned short v[PB];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      const int i = i0 + 256 * k;
+      const int py = i / g.RS, j = i - py * g.RS;
+      const int iy = qy0 * g.sd - g.py0 + py;
+      const int ix = ix0 + j / g.Cin;                  // (j >= RL: pixels nobody multiplies with a weight)
+      const bool ok = (i < pvals) & (j < g.RL) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H)) &
+                      (static_cast<unsigned int>(ix) < static_cast<unsigned int>(g.W));
+      // clamped address, value selected afterwards: the loads of a batch are issued together
+      const long long a = ok ? (static_cast<long long>(iy) * g.W + ix0) * g.Cin + j : 0;
+      const unsigned short t = xn[a];
+      v[k] = ok ? t : static_cast<unsigned short>(0);
+    }
+#pragma unroll
+    for (int k = 0; k < PB; ++k)
+      if (i0 + 256 * k < pvals) patch[i0 + 256 * k] = v[k];
+  }
+  __syncthreads();
+  f32x16 acc[MT][TILES];
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.f;
+  // per-lane patch position of (tile p, kernel row 0, K step 0), in values
+  int lb[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) lb[p] = ((2 * wid + p) * g.sd) * g.RS + l * g.sd * g.Cin + 8 * h;
+  const int steps = g.kh * g.ksr;
+  for (int st = 0; st < steps; ++st) {
+    const int ty = st / g.ksr, ks = st - ty * g.ksr;
+    const int o = ty * g.RS + 16 * ks;
+    u32x4 bq[MT];
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      const unsigned int* src = reinterpret_cast<const unsigned int*>(patch + lb[p] + o);     // 4-byte aligned
+      bq[p] = u32x4{src[0], src[1], src[2], src[3]};
+    }
+    const bf16x8* abase = wl + st * TILES * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const bf16x8 a = abase[t * 64];
+#pragma unroll
+      for (int p = 0; p < MT; ++p)
+        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bq[p]), acc[p][t], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: acc[p][t][4q + r] = column 32t + 8q + 4h + r of pixel (qy0 + 2 wid + p, qx0 + l); 16-byte stores ----
+  const int qx = qx0 + l;
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      const int col0 = 32 * t + 16 * qp;
+      if (col0 >= g.Cout) continue;
+      f32x4 be = f32x4{0.f, 0.f, 0.f, 0.f}, bo = be;
+      if (bias) {
+        be = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * h);
+        if (col0 + 8 < g.Cout) bo = *reinterpret_cast<const f32x4*>(bias + col0 + 8 + 4 * h);
+      }
+#pragma unroll
+      for (int p = 0; p < MT; ++p) {
+        u32x4 o;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const f32x4& b4 = half ? bo : be;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[p][t][4 * (2 * qp + half) + r] + b4[r];
+            if (g.activation == 1) v[r] = fmaxf(v[r], 0.f);
+          }
+          o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+        }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+        const int colh = col0 + 8 * h;
+        const int qy = qy0 + 2 * wid + p;
+        if (qy >= g.OH || qx >= g.OW || colh >= g.Cout) continue;
+        *reinterpret_cast<u32x4*>(y + ((n * g.OH + qy) * g.OW + qx) * g.Cout + colh) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// 0 = launched, -1 = not this shape, > 0 = error
+int run_conv_image(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
+                   int64_t cin, int64_t cout, int kh, int kw, int stride, int activation, hipStream_t st) {
+  static const bool off = [] { const char* e = std::getenv("TFC_CONV_IMAGE_KERNEL"); return e && std::atoi(e) == 0; }();
+  if (off || cin > 4 || (cout != 128 && cout != 192) || (stride != 2 && stride != 4) || (stride * cin) % 2) return -1;
+  ImageConvGeom g{};
+  g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin); g.Cout = static_cast<int>(cout);
+  g.kh = kh; g.kw = kw; g.sd = stride; g.py0 = kh / 2; g.px0 = kw / 2; g.activation = activation;
+  g.OH = static_cast<int>((h + stride - 1) / stride); g.OW = static_cast<int>((wd + stride - 1) / stride);
+  g.BXn = (g.OW + 31) / 32; g.BYn = (g.OH + 7) / 8;
+  g.PH = 7 * stride + kh;
+  g.ksr = (kw * g.Cin + 15) / 16;
+  g.RL = (31 * stride + kw) * g.Cin;
+  g.RS = ((31 * stride * g.Cin + 16 * g.ksr + 8) + 7) & ~7;       // the last lane's last K step stays inside its row
+  const int tiles = static_cast<int>(cout / 32);
+  const size_t lds = static_cast<size_t>(g.PH) * g.RS * 2 + static_cast<size_t>(kh) * g.ksr * tiles * 64 * 16;
+  if (lds > 64 * 1024 || n * g.BXn * g.BYn >= (1ll << 31)) return -1;
+  if (g.OW < 24) return -1;
+  DevBuf wpk;
+  const int frags = kh * g.ksr * tiles * 64;
+  TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
+  hipLaunchKernelGGL(conv_image_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, g, tiles, wpk.as<bf16x8>());
+  KernelTimer timer("conv2d", st);
+  const dim3 grid(static_cast<unsigned>(n * g.BXn * g.BYn));
+  if (tiles == 6) {
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_kernel<6>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((conv_image_kernel<6>), grid, dim3(256), lds, st, static_cast<const __bf16*>(x), wpk.as<bf16x8>(),
+                       bias, static_cast<__bf16*>(y), g);
+  } else {
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_kernel<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((conv_image_kernel<4>), grid, dim3(256), lds, st, static_cast<const __bf16*>(x), wpk.as<bf16x8>(),
+                       bias, static_cast<__bf16*>(y), g);
+  }
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// The same, fused: the tap products of a block never leave the CU.  A workgroup takes an 8 x 32 block of INPUT pixels
+// plus the halo the block's output pixels reach into ((8 + Uy - 1) x (32 + Ux - 1) patch pixels, 340 for a 5x5
+// stride-2 kernel), computes z[patch pixel][(tap, c)] for them with the MFMA (fp32, into LDS: <= 80 columns, row
+// stride 84 floats so that the 16-byte accumulator writes of 8 lanes cover all banks), and then every thread sums, for
+// 4 consecutive output pixels of the block's (8s) x (32s) output tile, the <= ceil(k/s)^2 products that land on each.
+// HBM traffic: the input once (+ 33 % halo, mostly L2 hits) and the output, instead of + 2 x 400 bytes of z per input
+// pixel (5 GB each way at the C4 shape).  K and tap order as in the unfused pair.
+// ---------------------------------------------------------------------------
+struct UpFusedGeom {
+  long long N;
+  int H, W, Cin, Cout;
+  int kh, kw, s;
+  int dmax_y, dmax_x;       // halo before: patch origin = block origin - dmax
+  int PH, PW;               // patch rows, columns
+  int BXn, BYn;
+  int NC;                   // kh * kw * Cout product columns
+  int activation;
+};
+constexpr int kUpZStride = 84;      // floats per patch pixel in LDS
+constexpr int kUpColTiles = 3;      // 96 >= NC columns
+
+__global__ void conv_up_fused_weights_kernel(const float* w, int kh, int kw, int cin, int cout, bf16x8* packed) {
+  // A fragments: packed[(ks * kUpColTiles + t) * 64 + lane], lane (i, h): K offsets 8h .. 8h + 7 of step ks, column 32t + i
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = (cin / 16) * kUpColTiles * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63, t = (idx >> 6) % kUpColTiles, ks = (idx >> 6) / kUpColTiles;
+  const int col = 32 * t + (lane & 31), h = lane >> 5;
+  const int tap = col / cout, c = col % cout;
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = ks * 16 + 8 * h + e;
+    v[e] = static_cast<__bf16>(tap < kh * kw ? w[(static_cast<long long>(tap) * cin + ci) * cout + c] : 0.f);
+  }
+  packed[idx] = v;
+}
+
+constexpr int kUpThreads = 512;     // 8 waves: the block's 11 pixel tiles and 1024 output pixels over more waves
+// KH, KW, S, COUT > 0: the gather is unrolled for that kernel (5, 5, 2, 3: bmshj2018's last layer); 0: any.
+template <int KH, int KW, int S, int COUT>
+__global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16* x, const bf16x8* wpk,
+                                                                    const float* bias, __bf16* y, UpFusedGeom g) {
+  extern __shared__ unsigned char smem[];            // z: tiles * 32 rows of kUpZStride floats | weight fragments
+  constexpr int WAVES = kUpThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5, l = lane & 31;
+  long long b = blockIdx.x;
+  const int bx = static_cast<int>(b % g.BXn); b /= g.BXn;
+  const int by = static_cast<int>(b % g.BYn);
+  const long long n = b / g.BYn;
+  const int npix = g.PH * g.PW;
+  const int tiles = (npix + 31) / 32;
+  float* z = reinterpret_cast<float*>(smem);
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smem + static_cast<size_t>(tiles) * 32 * kUpZStride * 4);
+  const int cb = g.Cin / 16;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x + n * g.H * g.W * g.Cin), 0, g.H * g.W * g.Cin * 2, 0x00020000);
+  // this wave's first pixel tile: its first four K steps are requested before the weights are staged
+  auto tile_offset = [&](int tile) -> unsigned int {
+    const int pi = tile * 32 + l;
+    const int py = pi / g.PW, px = pi - py * g.PW;
+    const int iy = by * 8 - g.dmax_y + py, ix = bx * 32 - g.dmax_x + px;
+    const bool ok = (pi < npix) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H)) &
+                    (static_cast<unsigned int>(ix) < static_cast<unsigned int>(g.W));
+    return ok ? static_cast<unsigned int>(((iy * g.W + ix) * g.Cin + 8 * h) * 2) : 0x80000000u;
+  };
+  constexpr int PF = 4;                              // K steps in flight per pixel tile
+  u32x4 bq[PF];
+  unsigned int off = tile_offset(wid);
+#pragma unroll
+  for (int k = 0; k < PF; ++k) bq[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, (k < cb ? k : cb - 1) * 32, 0);
+  for (int i = tid; i < cb * kUpColTiles * 64; i += kUpThreads) wl[i] = wpk[i];
+  __syncthreads();
+  // ---- z of the patch, a pixel tile (32 patch pixels) per wave at a time ----
+  for (int tile = wid; tile < tiles; tile += WAVES) {
+    const int pi = tile * 32 + l;
+    f32x16 acc[kUpColTiles];
+#pragma unroll
+    for (int t = 0; t < kUpColTiles; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const unsigned int offn = tile_offset(tile + WAVES < tiles ? tile + WAVES : tile);
+    for (int ks = 0; ks < cb; ks += PF) {            // (Cin % 64 == 0: PF K steps per turn, a ring of PF fragments)
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+#pragma unroll
+        for (int t = 0; t < kUpColTiles; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[((ks + k) * kUpColTiles + t) * 64 + lane],
+                                                          __builtin_bit_cast(bf16x8, bq[k]), acc[t], 0, 0, 0);
+        // refill the slot: K step ks + k + PF of this tile, or the next tile's first ones
+        const int kn = ks + k + PF;
+        bq[k] = kn < cb ? __builtin_amdgcn_raw_buffer_load_b128(xr, off, kn * 32, 0)
+                        : __builtin_amdgcn_raw_buffer_load_b128(xr, offn, (kn - cb) * 32, 0);
+      }
+    }
+    off = offn;
+    // acc[t][4q + r] = column 32t + 8q + 4h + r of patch pixel pi; columns < 80 go to LDS
+    float* zrow = z + static_cast<size_t>(pi) * kUpZStride;
+#pragma unroll
+    for (int t = 0; t < kUpColTiles; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (32 * t + 8 * q >= 80) continue;
+        *reinterpret_cast<f32x4*>(zrow + 32 * t + 8 * q + 4 * h) =
+            f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+      }
+  }
+  __syncthreads();
+  // ---- gather: thread -> 4 consecutive output pixels of the (8 s) x (32 s) output tile ----
+  const int kh = KH ? KH : g.kh, kw = KW ? KW : g.kw, s = S ? S : g.s, cout = COUT ? COUT : g.Cout;
+  const int OH = g.H * s, OW = g.W * s;
+  const int tw = 32 * s, th = 8 * s;
+  float bc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias)
+    for (int c = 0; c < cout; ++c) bc[c] = bias[c];
+  for (int grp = tid; grp < th * (tw / 4); grp += kUpThreads) {
+    const int ry = grp / (tw / 4), rx = (grp % (tw / 4)) * 4;
+    const int oy = by * th + ry;
+    if (oy >= OH) continue;
+    // o = i*s + t - k/2  =>  t = (o + k/2) mod s, + s, ... ;  i = (o + k/2 - t) / s
+    const int ty0 = (oy + kh / 2) % s;
+    const int py0 = (oy + kh / 2 - ty0) / s - (by * 8 - g.dmax_y);       // patch row of tap ty0; ty0 + s: one row up
+    unsigned short outv[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ox = bx * tw + rx + k;
+      const int tx0 = (ox + kw / 2) % s;
+      const int px0 = (ox + kw / 2 - tx0) / s - (bx * 32 - g.dmax_x);
+      float a[4] = {bc[0], bc[1], bc[2], bc[3]};
+#pragma unroll
+      for (int jy = 0; jy < (KH ? (KH + S - 1) / S : 8); ++jy) {
+        const int ty = ty0 + jy * s;
+        if (ty >= kh) break;
+#pragma unroll
+        for (int jx = 0; jx < (KW ? (KW + S - 1) / S : 8); ++jx) {
+          const int tx = tx0 + jx * s;
+          if (tx >= kw) break;
+          const float* zp = z + static_cast<size_t>((py0 - jy) * g.PW + (px0 - jx)) * kUpZStride + (ty * kw + tx) * cout;
+#pragma unroll
+          for (int c = 0; c < (COUT ? COUT : 4); ++c)
+            if (c < cout) a[c] += zp[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < (COUT ? COUT : 4); ++c) {
+        float v = a[c];
+        if (g.activation == 1) v = fmaxf(v, 0.f);
+        outv[k * 4 + c] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+      }
+    }
+    __bf16* dst = y + ((n * OH + oy) * OW + bx * tw + rx) * cout;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (bx * tw + rx + k >= OW) continue;
+#pragma unroll
+      for (int c = 0; c < (COUT ? COUT : 4); ++c)
+        if (c < cout) dst[k * cout + c] = __builtin_bit_cast(__bf16, outv[k * 4 + c]);
+    }
+  }
+}
+
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
                int activation, int up, void* stream, bool out_f32 = false);
@@ -1432,6 +1785,43 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
 int conv_up_small_cout(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h,
                        int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride, int activation,
                        hipStream_t st) {
+  {
+    // fused variant: the products of a block stay in LDS (<= 80 product columns, Cin a multiple of 32)
+    auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    UpFusedGeom g{};
+    g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin);
+    g.Cout = static_cast<int>(cout); g.kh = kh; g.kw = kw; g.s = stride; g.activation = activation;
+    g.dmax_y = fdiv(kh - 1 - kh / 2, stride);
+    g.dmax_x = fdiv(kw - 1 - kw / 2, stride);
+    const int dmin_y = -fdiv((stride - 1) + kh / 2, stride), dmin_x = -fdiv((stride - 1) + kw / 2, stride);
+    g.PH = 8 + g.dmax_y - dmin_y; g.PW = 32 + g.dmax_x - dmin_x;
+    g.BXn = (g.W + 31) / 32; g.BYn = (g.H + 7) / 8;
+    g.NC = kh * kw * g.Cout;
+    const int tiles = (g.PH * g.PW + 31) / 32;
+    const size_t lds = static_cast<size_t>(tiles) * 32 * kUpZStride * 4 + static_cast<size_t>(cin / 16) * kUpColTiles * 64 * 16;
+    static const bool unfused = [] { const char* e = std::getenv("TFC_CONV_UP_UNFUSED"); return e && std::atoi(e) != 0; }();
+    if (!unfused && g.NC <= 80 && cin % 64 == 0 && lds <= 160 * 1024 && n * g.BXn * g.BYn < (1ll << 31)) {
+      DevBuf wpk;
+      const int frags = static_cast<int>(cin / 16) * kUpColTiles * 64;
+      TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
+      hipLaunchKernelGGL(conv_up_fused_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, kh, kw,
+                         static_cast<int>(cin), static_cast<int>(cout), wpk.as<bf16x8>());
+      KernelTimer timer("conv2d", st);
+#define TFC_UP_FUSED_LAUNCH(...)                                                                              \
+      do {                                                                                                     \
+        TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up_fused_kernel<__VA_ARGS__>),         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));       \
+        hipLaunchKernelGGL((conv_up_fused_kernel<__VA_ARGS__>), dim3(static_cast<unsigned>(n * g.BXn * g.BYn)), \
+                           dim3(kUpThreads), lds, st, static_cast<const __bf16*>(x), wpk.as<bf16x8>(), bias,   \
+                           static_cast<__bf16*>(y), g);                                                        \
+      } while (0)
+      if (kh == 5 && kw == 5 && stride == 2 && cout == 3) TFC_UP_FUSED_LAUNCH(5, 5, 2, 3);
+      else TFC_UP_FUSED_LAUNCH(0, 0, 0, 0);
+#undef TFC_UP_FUSED_LAUNCH
+      TFC_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   const int zc = kh * kw * 4;
   DevBuf w1, z;
   TFC_HIP(w1.alloc(sizeof(float) * cin * zc, st));
@@ -1468,6 +1858,11 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
     return conv_up_small_cout(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, activation,
                               static_cast<hipStream_t>(stream));
 #endif
+  if (!up && dtype == 1 && cin <= 4 && !out_f32) {
+    const int rc = run_conv_image(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, activation,
+                                  static_cast<hipStream_t>(stream));
+    if (rc >= 0) return rc;
+  }
   ConvGeom c{};
   PackGeom g{};
   g.kh = kh; g.kw = kw; g.Cin_real = static_cast<int>(cin); g.Cout = static_cast<int>(cout);

@@ -159,6 +159,47 @@ def test_up_into_few_channels_bf16(k, s, cin, cout, hw):
         assert (y - want).abs().max() <= 2 ** -7 * max(1.0, want.abs().max())
 
 
+@pytest.mark.parametrize("case", [(5, 2, 192, 3, (40, 70)), (5, 2, 64, 3, (9, 33)), (3, 2, 32, 4, (17, 50)),
+                                  (5, 2, 192, 2, (8, 32)), (4, 2, 64, 3, (11, 37))])
+def test_up_into_few_channels_fused_equals_unfused(case, monkeypatch):
+    """conv_up_fused_kernel (tap products of a block kept in LDS) against the unfused pair (TFC_CONV_UP_UNFUSED=1 is read
+    once per process, so the comparison is with the float32 definition, at the tolerance of one bf16 rounding) — blocks
+    hanging over every edge, several column tiles, even kernels."""
+    from compression_amd.layers import conv2d_up
+    k, s, cin, cout, hw = case
+    torch.manual_seed(k + cin)
+    x = torch.randn(2, hw[0], hw[1], cin).bfloat16()
+    ker = (torch.randn(k, k, cin, cout) / (k * cin ** 0.5)).bfloat16().float()
+    bias = torch.randn(cout)
+    want = ref_up(x.float(), ker, bias, s, False)
+    y = conv2d_up(x.cuda(), ker, bias, s).float().cpu()
+    assert y.shape == want.shape
+    assert (y - want).abs().max() <= 2 ** -8 * max(1.0, want.abs().max())
+    one = conv2d_up(x[1:].cuda(), ker, bias, s).float().cpu()
+    assert torch.equal(one, y[1:])
+
+
+@pytest.mark.parametrize("case", [(5, 2, 3, 192, (64, 96)), (5, 2, 3, 192, (37, 71)), (9, 4, 3, 128, (128, 128)),
+                                  (9, 4, 3, 128, (101, 190)), (5, 2, 1, 128, (48, 64)), (5, 2, 4, 192, (33, 50))])
+def test_image_side_analysis_layer_bf16(case):
+    """conv_image_kernel (image patch in LDS as interleaved (x, c) rows, a kernel row = ceil(kw * Cin / 16) K steps)
+    against the float32 definition — blocks over every edge, 1 / 3 / 4 input channels, both strides — and image by
+    image the same whatever the batch."""
+    from compression_amd.layers import conv2d_down
+    k, s, cin, cout, hw = case
+    torch.manual_seed(k + cout)
+    x = torch.rand(3, hw[0], hw[1], cin).bfloat16()
+    ker = (torch.randn(k, k, cin, cout) / (k * cin ** 0.5)).bfloat16().float()
+    bias = torch.randn(cout)
+    for act in (None, "relu"):
+        want = ref_down(x.float(), ker, bias, s, act == "relu")
+        y = conv2d_down(x.cuda(), ker, bias, s, act).float().cpu()
+        assert y.shape == want.shape
+        assert (y - want).abs().max() <= 2 ** -7 * max(1.0, want.abs().max())
+    one = conv2d_down(x[2:].cuda(), ker, bias, s, "relu").float().cpu()
+    assert torch.equal(one, y[2:])
+
+
 def test_identity_kernel_alignment():
     """signal_conv_test.py:266-314: with a centred delta kernel, `same_zeros` output
     sample 0 is aligned with input sample 0 (down: subsampling; up: zero-stuffing)."""
