@@ -1444,6 +1444,7 @@ struct ImageConvGeom {
   int PH, RL, RS;           // patch rows; values per row in use; row stride (values)
   int ksr;                  // K steps per kernel row
   int activation;
+  int pairs;                // 1: patch loaded two values at a time
 };
 
 __global__ void conv_image_weights_kernel(const float* w, ImageConvGeom g, int tiles, bf16x8* packed) {
@@ -1485,26 +1486,60 @@ __global__ void __launch_bounds__(256, 2) conv_image_kernel(const __bf16* x, con
   // patch: value j of row py = x[n][iy][ix0 + j / Cin][j % Cin]: contiguous in the image row
   const unsigned short* xn = reinterpret_cast<const unsigned short*>(x) + n * g.H * g.W * g.Cin;
   const int ix0 = qx0 * g.sd - g.px0;
-  constexpr int PB = 8;                                // loads in flight per thread (the patch is 16-60 values each)
-  const int pvals = g.PH * g.RS;
-  for (int i0 = tid; i0 < pvals; i0 += 256 * PB) {
-    unsigned short v[PB];
+  constexpr int PB = 8;                                // loads in flight per thread
+  if (g.pairs) {
+    // two values per load: every image row and every patch row start on a 4-byte boundary (host check).  A pair that
+    // straddles the image's edge is split by value, not by address: both halves are tested
+    const int pvals = g.PH * g.RS / 2;
+    unsigned int* patch2 = reinterpret_cast<unsigned int*>(patch);
+    const int rs2 = g.RS / 2;
+    for (int i0 = tid; i0 < pvals; i0 += 256 * PB) {
+      unsigned int v[PB];
 #pragma unroll
-    for (int k = 0; k < PB; ++k) {
-      const int i = i0 + 256 * k;
-      const int py = i / g.RS, j = i - py * g.RS;
-      const int iy = qy0 * g.sd - g.py0 + py;
-      const int ix = ix0 + j / g.Cin;                  // (j >= RL: pixels nobody multiplies with a weight)
-      const bool ok = (i < pvals) & (j < g.RL) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H)) &
-                      (static_cast<unsigned int>(ix) < static_cast<unsigned int>(g.W));
-      // clamped address, value selected afterwards: the loads of a batch are issued together
-      const long long a = ok ? (static_cast<long long>(iy) * g.W + ix0) * g.Cin + j : 0;
-      const unsigned short t = xn[a];
-      v[k] = ok ? t : static_cast<unsigned short>(0);
+      for (int k = 0; k < PB; ++k) {
+        const int i = i0 + 256 * k;
+        const int py = i / rs2, j = 2 * (i - py * rs2);
+        const int iy = qy0 * g.sd - g.py0 + py;
+        const int ixa = ix0 + j / g.Cin, ixb = ix0 + (j + 1) / g.Cin;
+        const bool row = (i < pvals) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H));
+        const bool oka = row & (j < g.RL) & (static_cast<unsigned int>(ixa) < static_cast<unsigned int>(g.W));
+        const bool okb = row & (j + 1 < g.RL) & (static_cast<unsigned int>(ixb) < static_cast<unsigned int>(g.W));
+        // the pair lies inside the image's allocation whenever one half is inside the image, except at the very first
+        // and last value of the tensor: those pairs are read half by half
+        const long long a = (static_cast<long long>(iy) * g.W + ix0) * g.Cin + j;
+        const long long last = static_cast<long long>(g.H) * g.W * g.Cin - 2;
+        unsigned int t = 0;
+        if (oka | okb) {
+          if (a >= 0 && a <= last) t = *reinterpret_cast<const unsigned int*>(xn + a);
+          else t = (oka ? xn[a] : 0u) | (okb ? static_cast<unsigned int>(xn[a + 1]) << 16 : 0u);
+        }
+        v[k] = (oka ? t & 0xFFFFu : 0u) | (okb ? t & 0xFFFF0000u : 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < PB; ++k)
+        if (i0 + 256 * k < pvals) patch2[i0 + 256 * k] = v[k];
     }
+  } else {
+    const int pvals = g.PH * g.RS;
+    for (int i0 = tid; i0 < pvals; i0 += 256 * PB) {
+      unsigned short v[PB];
 #pragma unroll
-    for (int k = 0; k < PB; ++k)
-      if (i0 + 256 * k < pvals) patch[i0 + 256 * k] = v[k];
+      for (int k = 0; k < PB; ++k) {
+        const int i = i0 + 256 * k;
+        const int py = i / g.RS, j = i - py * g.RS;
+        const int iy = qy0 * g.sd - g.py0 + py;
+        const int ix = ix0 + j / g.Cin;                  // (j >= RL: pixels nobody multiplies with a weight)
+        const bool ok = (i < pvals) & (j < g.RL) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H)) &
+                        (static_cast<unsigned int>(ix) < static_cast<unsigned int>(g.W));
+        // clamped address, value selected afterwards: the loads of a batch are issued together
+        const long long a = ok ? (static_cast<long long>(iy) * g.W + ix0) * g.Cin + j : 0;
+        const unsigned short t = xn[a];
+        v[k] = ok ? t : static_cast<unsigned short>(0);
+      }
+#pragma unroll
+      for (int k = 0; k < PB; ++k)
+        if (i0 + 256 * k < pvals) patch[i0 + 256 * k] = v[k];
+    }
   }
   __syncthreads();
   f32x16 acc[MT][TILES];
@@ -1593,7 +1628,11 @@ int run_conv_image(const void* x, const float* w, const float* bias, void* y, in
   g.RS = ((31 * stride * g.Cin + 16 * g.ksr + 8) + 7) & ~7;       // the last lane's last K step stays inside its row
   const int tiles = static_cast<int>(cout / 32);
   const size_t lds = static_cast<size_t>(g.PH) * g.RS * 2 + static_cast<size_t>(kh) * g.ksr * tiles * 64 * 16;
-  if (lds > 64 * 1024 || n * g.BXn * g.BYn >= (1ll << 31)) return -1;
+  if (lds > 160 * 1024 || n * g.BXn * g.BYn >= (1ll << 31)) return -1;
+  // image rows and patch rows on 4-byte boundaries (x itself is: torch allocations are 256-byte aligned, and a slice
+  // of a batch starts at a whole image)
+  g.pairs = (g.W * g.Cin) % 2 == 0 && (g.px0 * g.Cin) % 2 == 0 && (g.H * g.W * g.Cin) % 2 == 0 &&
+            reinterpret_cast<uintptr_t>(x) % 4 == 0;
   if (g.OW < 24) return -1;
   DevBuf wpk;
   const int frags = kh * g.ksr * tiles * 64;
