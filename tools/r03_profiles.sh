@@ -28,3 +28,11 @@ for wl in bls2017 bmshj2018; do
   tail -1 /tmp/st_$wl.log | cut -c1-200
   python $R/tools/rocprof_summary.py /tmp/st_$wl $OUT/r03_${wl}_stats.md "Round 3: python bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)" | head -8 || true
 done
+# kernel-trace timelines of the model steps in flight (one character per bin and queue)
+for cfg in "bmshj2018 1000 260 60 c4" "bls2017 250 70 15 c1"; do
+  set -- $cfg
+  rm -rf /tmp/tl_$1; timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$1 -- python $R/bench.py --workload $1 --steps 24 --warmup 2 --no-cpu-baseline > /tmp/tl_$1.log 2>&1
+  f=$(find /tmp/tl_$1 -name "*kernel_trace.csv" | head -1)
+  { grep "^{" /tmp/tl_$1.log | cut -c1-220; python $R/tools/trace_summary.py $f --bin $2 --last-ms $3 --skip-last-ms $4; } > $OUT/r03_$5_overlap_timeline.txt
+  head -3 $OUT/r03_$5_overlap_timeline.txt | cut -c1-200
+done
