@@ -25,12 +25,13 @@ def timed(fn, reps=5):
     return a.elapsed_time(b) / reps
 
 
-layers = [("analysis 9x9 3->128 /4 @256", conv2d_down, 256, 9, 3, 128, 4),
-          ("analysis 5x5 128->128 /2 @64", conv2d_down, 64, 5, 128, 128, 2),
-          ("analysis 5x5 128->128 /2 @32", conv2d_down, 32, 5, 128, 128, 2),
-          ("synthesis 5x5 128->128 x2 @16", conv2d_up, 16, 5, 128, 128, 2),
-          ("synthesis 5x5 128->128 x2 @32", conv2d_up, 32, 5, 128, 128, 2),
-          ("synthesis 9x9 128->3 x4 @64", conv2d_up, 64, 9, 128, 3, 4)]
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+layers = [(f"analysis 9x9 3->{F} /4 @256", conv2d_down, 256, 9, 3, F, 4),
+          ("analysis 5x5 F->F /2 @64", conv2d_down, 64, 5, F, F, 2),
+          ("analysis 5x5 F->F /2 @32", conv2d_down, 32, 5, F, F, 2),
+          ("synthesis 5x5 F->F x2 @16", conv2d_up, 16, 5, F, F, 2),
+          ("synthesis 5x5 F->F x2 @32", conv2d_up, 32, 5, F, F, 2),
+          ("synthesis 9x9 F->3 x4 @64", conv2d_up, 64, 9, F, 3, 4)]
 total = 0.0
 for name, fn, hw, k, ci, co, s in layers:
     x = (torch.rand if ci == 3 else torch.randn)(batch, hw, hw, ci, generator=gen).to(torch.bfloat16).cuda()
