@@ -366,7 +366,9 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
     const size_t cdf_bytes = (2 * cdf_entries + 15) & ~size_t{15};
     const size_t enc_bytes = dir_bytes + cdf_bytes;
     const size_t dec_bytes = enc_bytes + 8 * words + ((2 * words + 15) & ~size_t{15});
-    if (dec_bytes > 160 * 1024) ok = false;
+    // (the encoder needs directory + cdf entries only; a decoder image over the CU's LDS keeps the decoder on the
+    // wave-per-stream kernels — decoder_family checks — and the encoder may still run lane-per-stream)
+    if (enc_bytes > 128 * 1024) ok = false;
     if (ok) {
       std::vector<uint8_t> image(dec_bytes, 0);
       tfc::LaneRow* dir = reinterpret_cast<tfc::LaneRow*>(image.data());
@@ -1474,6 +1476,10 @@ int select_family(const tfc_tables* t, int mode, int64_t streams, int64_t elems,
   if (mode == TFC_MODE_AUTO) mode = tfc_get_default_mode();
   if (mode == TFC_MODE_THROUGHPUT && lanes_ok) return kLanes;
   if (mode == TFC_MODE_AUTO && lanes_ok && streams >= 4096) return kLanes;
+  // tfc_set_chip_shared(1): a batch of 256 streams and more goes to the lane kernels where they fit — a wave per 64
+  // streams on a handful of CUs instead of a wave per stream on 64-128 CUs that the convolutions then cannot use
+  if (mode == TFC_MODE_AUTO && lanes_ok && streams >= 256 && g_chip_shared.load(std::memory_order_relaxed) != 0)
+    return kLanes;
   return fast_ok ? kFast : kGeneric;
 }
 

@@ -202,15 +202,17 @@ def test_chip_shared_hint_changes_only_the_launch_shape():
     value = synthetic.sample_symbols(lookup, 640, 3000, seed=8, escape_fraction=0.004)
     v = torch.from_numpy(value).cuda()
     out = []
-    for shared in (False, True):
+    for shared, mode in ((False, "latency"), (True, "latency"), (True, None)):
+        # (mode None under the hint: 640 streams go to the lane-per-stream kernels)
         with pipeline.chip_shared(shared):
             h = tfc.entropy_encode_finalize_device(
-                tfc.entropy_encode_channel(tfc.create_range_encoder([640], lt, mode="latency", deferred_errors=True), v))
-            d, dec = tfc.entropy_decode_channel(tfc.create_range_decoder(h, lt, mode="latency"), [3000], torch.int32)
+                tfc.entropy_encode_channel(tfc.create_range_encoder([640], lt, mode=mode, deferred_errors=True), v))
+            d, dec = tfc.entropy_decode_channel(tfc.create_range_decoder(h, lt, mode=mode), [3000], torch.int32)
             ok = tfc.entropy_decode_finalize_device(d)
         out.append(([bytes(s) for s in tfc.fetch_strings(h)], dec.cpu(), ok.cpu()))
-    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
-    assert torch.equal(out[1][1], torch.from_numpy(value)) and bool(out[1][2].all())
+    for o in out[1:]:
+        assert o[0] == out[0][0] and torch.equal(o[1], out[0][1]) and bool(o[2].all())
+    assert torch.equal(out[0][1], torch.from_numpy(value))
 
 
 def test_cu_partition_masks():
