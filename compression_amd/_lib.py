@@ -24,6 +24,8 @@ SIGNATURES = {
     "tfc_get_default_mode": (_int, []),
     "tfc_set_coder_gate": (_int, [_vp]),
     "tfc_set_chip_shared": (_int, [_int]),
+    "tfc_cache_bytes": (_int, [C.POINTER(C.c_longlong)]),
+    "tfc_cache_trim": (_int, [C.POINTER(C.c_longlong)]),
     "tfc_device_compute_units": (_int, [C.POINTER(_int)]),
     "tfc_stream_create_cu_mask": (_int, [_vp, _int, C.POINTER(_vp)]),
     "tfc_stream_destroy": (_int, [_vp]),

@@ -111,6 +111,25 @@ struct BlockCache {
     cached -= cap;
     return p;
   }
+  // Returns every cached block whose last use has completed to the driver (hipFreeAsync on its last-use stream — behind
+  // completed work that call does not hold the thread); -> bytes released.
+  size_t trim() {
+    std::lock_guard<std::mutex> lock(mu);
+    size_t released = 0;
+    for (auto& kv : free) {
+      auto& v = kv.second;
+      for (size_t k = v.size(); k-- > 0;) {
+        if (hipEventQuery(v[k].ev) != hipSuccess) continue;
+        (void)hipFreeAsync(v[k].p, v[k].st);
+        events.push_back(v[k].ev);
+        released += kv.first.cap;
+        v.erase(v.begin() + static_cast<long>(k));
+      }
+    }
+    (void)hipGetLastError();
+    cached -= released;
+    return released;
+  }
   // false: over the limit, the caller frees the block
   bool give(int dev, hipStream_t st, size_t cap, void* p) {
     std::lock_guard<std::mutex> lock(mu);

@@ -71,3 +71,18 @@ extern "C" int tfc_stream_destroy(void* stream) {
     if (p.stream == static_cast<hipStream_t>(stream)) p.in_use = false;
   return 0;
 }
+
+// Bytes the library keeps cached for reuse (DevBuf's free lists, csrc/common.h), and a way to hand the idle ones back.
+extern "C" int tfc_cache_bytes(long long* bytes) {
+  if (!bytes) return tfc::fail("tfc_cache_bytes: null argument");
+  tfc::BlockCache& c = tfc::BlockCache::get();
+  std::lock_guard<std::mutex> lock(c.mu);
+  *bytes = static_cast<long long>(c.cached);
+  return 0;
+}
+
+extern "C" int tfc_cache_trim(long long* released) {
+  const size_t n = tfc::BlockCache::get().trim();
+  if (released) *released = static_cast<long long>(n);
+  return 0;
+}

@@ -27,7 +27,22 @@ import torch
 
 from . import _lib
 
-__all__ = ["CoderPartition", "Lane", "inline_lane", "SoftwarePipeline", "chip_shared"]
+__all__ = ["CoderPartition", "Lane", "inline_lane", "SoftwarePipeline", "chip_shared", "cached_bytes", "empty_cache"]
+
+
+def cached_bytes() -> int:
+    """Device memory the HIP library keeps for reuse (tfc_cache_bytes)."""
+    n = C.c_longlong()
+    _lib.check(_lib.lib().tfc_cache_bytes(C.byref(n)))
+    return int(n.value)
+
+
+def empty_cache() -> int:
+    """Hands the library's idle cached blocks back to the driver (tfc_cache_trim) -> bytes released; the library-side
+    counterpart of torch.cuda.empty_cache()."""
+    n = C.c_longlong()
+    _lib.check(_lib.lib().tfc_cache_trim(C.byref(n)))
+    return int(n.value)
 
 
 @contextlib.contextmanager

@@ -85,6 +85,13 @@ int tfc_set_coder_gate(void* event);
  * waves per SIMD (half the CUs; a convolution workgroup cannot use a CU that hosts a coder wave).  Takes effect for
  * handles created afterwards.  No reference counterpart (TensorFlow's executor owns such placement). */
 int tfc_set_chip_shared(int shared);
+/* Device memory the library keeps for reuse: every buffer a call or handle releases goes to per-size free lists instead
+ * of back to the driver (hipFreeAsync behind a running kernel holds the calling thread until that kernel ends).
+ * tfc_cache_bytes: bytes cached now; tfc_cache_trim: returns the blocks whose last use has completed to the driver
+ * (-> bytes released).  TFC_CACHE_LIMIT_MB bounds the cache (default 65536).  No reference counterpart (TensorFlow's
+ * allocator owns the ops' scratch memory). */
+int tfc_cache_bytes(long long* bytes);
+int tfc_cache_trim(long long* released);
 int tfc_device_compute_units(int* cus);
 int tfc_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
 int tfc_stream_destroy(void* stream);

@@ -215,6 +215,28 @@ def test_chip_shared_hint_changes_only_the_launch_shape():
     assert torch.equal(out[0][1], torch.from_numpy(value))
 
 
+def test_library_cache_trim():
+    """Released coder buffers stay with the library (no hipFreeAsync in steady state); pipeline.empty_cache() hands the
+    idle ones back, after which the same calls still work."""
+    _, lookup = _tables()
+    lt = torch.from_numpy(lookup)
+    v = torch.from_numpy(synthetic.sample_symbols(lookup, 24, 5000, seed=3)).cuda()
+
+    def once():
+        h = tfc.entropy_encode_finalize_device(tfc.entropy_encode_channel(tfc.create_range_encoder([24], lt, deferred_errors=True), v))
+        return [bytes(s) for s in tfc.fetch_strings(h)]
+
+    first = once()
+    torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    held = pipeline.cached_bytes()
+    assert held > 0
+    released = pipeline.empty_cache()
+    assert 0 < released <= held and pipeline.cached_bytes() == held - released
+    assert once() == first
+
+
 def test_cu_partition_masks():
     part = pipeline.CoderPartition(coder_cus=32, depth=1)
     assert part.total_cus >= 64 and part.coder_cus == 32
