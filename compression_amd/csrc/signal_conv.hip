@@ -1675,23 +1675,35 @@ struct UpFusedGeom {
   int BXn, BYn;
   int NC;                   // kh * kw * Cout product columns
   int activation;
+  // passes: 1 = all taps at once (NC <= 84 columns); s = one pass per residue r of the kernel ROW index modulo s — the taps
+  // ty = r, r + s, ... are exactly those of the output rows with (oy + kh/2) mod s = r — for kernels whose kh * kw * Cout
+  // products do not fit the LDS row (bls2017: 9 x 9 x 3 = 243; a pass has 3 or 2 kernel rows: 81 / 54 columns)
+  int passes;
 };
 constexpr int kUpZStride = 84;      // floats per patch pixel in LDS
 constexpr int kUpColTiles = 3;      // 96 >= NC columns
 
-__global__ void conv_up_fused_weights_kernel(const float* w, int kh, int kw, int cin, int cout, bf16x8* packed) {
-  // A fragments: packed[(ks * kUpColTiles + t) * 64 + lane], lane (i, h): K offsets 8h .. 8h + 7 of step ks, column 32t + i
+__global__ void conv_up_fused_weights_kernel(const float* w, int kh, int kw, int cin, int cout, int passes,
+                                             bf16x8* packed) {
+  // A fragments: packed[((pass * cb + ks) * kUpColTiles + t) * 64 + lane], lane (i, h): K offsets 8h .. 8h + 7 of step ks,
+  // column 32t + i = ((jy * kw + tx) * cout + c), kernel row ty = pass + jy * passes (one pass: ty = jy)
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = (cin / 16) * kUpColTiles * 64;
+  const int cb = cin / 16;
+  const int total = passes * cb * kUpColTiles * 64;
   if (idx >= total) return;
-  const int lane = idx & 63, t = (idx >> 6) % kUpColTiles, ks = (idx >> 6) / kUpColTiles;
+  const int lane = idx & 63;
+  int r = idx >> 6;
+  const int t = r % kUpColTiles; r /= kUpColTiles;
+  const int ks = r % cb, pass = r / cb;
   const int col = 32 * t + (lane & 31), h = lane >> 5;
-  const int tap = col / cout, c = col % cout;
+  const int jy = col / (kw * cout), rem = col % (kw * cout);
+  const int tx = rem / cout, c = rem % cout;
+  const int ty = passes == 1 ? jy : pass + jy * passes;
   bf16x8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ci = ks * 16 + 8 * h + e;
-    v[e] = static_cast<__bf16>(tap < kh * kw ? w[(static_cast<long long>(tap) * cin + ci) * cout + c] : 0.f);
+    v[e] = static_cast<__bf16>(ty < kh ? w[((static_cast<long long>(ty) * kw + tx) * cin + ci) * cout + c] : 0.f);
   }
   packed[idx] = v;
 }
@@ -1725,11 +1737,22 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
     return ok ? static_cast<unsigned int>(((iy * g.W + ix) * g.Cin + 8 * h) * 2) : 0x80000000u;
   };
   constexpr int PF = 4;                              // K steps in flight per pixel tile
+  const int kh = KH ? KH : g.kh, kw = KW ? KW : g.kw, s = S ? S : g.s, cout = COUT ? COUT : g.Cout;
+  const int OH = g.H * s, OW = g.W * s;
+  const int tw = 32 * s, th = 8 * s;
+  float bc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias)
+    for (int c = 0; c < cout; ++c) bc[c] = bias[c];
+  for (int pass = 0; pass < g.passes; ++pass) {
+  if (pass) __syncthreads();                         // the previous pass's gather is done with z
   u32x4 bq[PF];
   unsigned int off = tile_offset(wid);
 #pragma unroll
   for (int k = 0; k < PF; ++k) bq[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, (k < cb ? k : cb - 1) * 32, 0);
-  for (int i = tid; i < cb * kUpColTiles * 64; i += kUpThreads) wl[i] = wpk[i];
+  {
+    const bf16x8* src = wpk + static_cast<size_t>(pass) * cb * kUpColTiles * 64;
+    for (int i = tid; i < cb * kUpColTiles * 64; i += kUpThreads) wl[i] = src[i];
+  }
   __syncthreads();
   // ---- z of the patch, a pixel tile (32 patch pixels) per wave at a time ----
   for (int tile = wid; tile < tiles; tile += WAVES) {
@@ -1760,25 +1783,22 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
     for (int t = 0; t < kUpColTiles; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (32 * t + 8 * q >= 80) continue;
+        if (32 * t + 8 * q >= kUpZStride) continue;
+        if (32 * t + 8 * q + 4 * h + 4 > kUpZStride) continue;      // (columns 84 .. 87 of the h = 1 lanes: no room)
         *reinterpret_cast<f32x4*>(zrow + 32 * t + 8 * q + 4 * h) =
             f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
       }
   }
   __syncthreads();
-  // ---- gather: thread -> 4 consecutive output pixels of the (8 s) x (32 s) output tile ----
-  const int kh = KH ? KH : g.kh, kw = KW ? KW : g.kw, s = S ? S : g.s, cout = COUT ? COUT : g.Cout;
-  const int OH = g.H * s, OW = g.W * s;
-  const int tw = 32 * s, th = 8 * s;
-  float bc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias)
-    for (int c = 0; c < cout; ++c) bc[c] = bias[c];
+  // ---- gather: thread -> 4 consecutive output pixels of the (8 s) x (32 s) output tile (several passes: of its rows
+  // with this pass's residue) ----
   for (int grp = tid; grp < th * (tw / 4); grp += kUpThreads) {
     const int ry = grp / (tw / 4), rx = (grp % (tw / 4)) * 4;
     const int oy = by * th + ry;
     if (oy >= OH) continue;
     // o = i*s + t - k/2  =>  t = (o + k/2) mod s, + s, ... ;  i = (o + k/2 - t) / s
     const int ty0 = (oy + kh / 2) % s;
+    if (g.passes > 1 && ty0 != pass) continue;
     const int py0 = (oy + kh / 2 - ty0) / s - (by * 8 - g.dmax_y);       // patch row of tap ty0; ty0 + s: one row up
     unsigned short outv[16];
 #pragma unroll
@@ -1795,7 +1815,8 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
         for (int jx = 0; jx < (KW ? (KW + S - 1) / S : 8); ++jx) {
           const int tx = tx0 + jx * s;
           if (tx >= kw) break;
-          const float* zp = z + static_cast<size_t>((py0 - jy) * g.PW + (px0 - jx)) * kUpZStride + (ty * kw + tx) * cout;
+          const float* zp = z + static_cast<size_t>((py0 - jy) * g.PW + (px0 - jx)) * kUpZStride +
+                            ((g.passes > 1 ? jy : ty) * kw + tx) * cout;
 #pragma unroll
           for (int c = 0; c < (COUT ? COUT : 4); ++c)
             if (c < cout) a[c] += zp[c];
@@ -1817,51 +1838,70 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
         if (c < cout) dst[k * cout + c] = __builtin_bit_cast(__bf16, outv[k * 4 + c]);
     }
   }
+  }     // passes
 }
 
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
                int activation, int up, void* stream, bool out_f32 = false);
 
+// Fused variant of the transposed convolution into few channels: 0 = launched, -1 = not this shape, > 0 = error.
+int run_conv_up_fused(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
+                      int64_t cin, int64_t cout, int kh, int kw, int stride, int activation, hipStream_t st) {
+  static const bool unfused = [] { const char* e = std::getenv("TFC_CONV_UP_UNFUSED"); return e && std::atoi(e) != 0; }();
+  if (unfused || cout > 4 || cin % 64 || stride < 2) return -1;
+  auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+  UpFusedGeom g{};
+  g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin);
+  g.Cout = static_cast<int>(cout); g.kh = kh; g.kw = kw; g.s = stride; g.activation = activation;
+  g.dmax_y = fdiv(kh - 1 - kh / 2, stride);
+  g.dmax_x = fdiv(kw - 1 - kw / 2, stride);
+  const int dmin_y = -fdiv((stride - 1) + kh / 2, stride), dmin_x = -fdiv((stride - 1) + kw / 2, stride);
+  g.PH = 8 + g.dmax_y - dmin_y; g.PW = 32 + g.dmax_x - dmin_x;
+  g.BXn = (g.W + 31) / 32; g.BYn = (g.H + 7) / 8;
+  g.NC = kh * kw * g.Cout;
+  // all taps at once, or a pass per kernel-row residue (its (kh - r + s - 1) / s rows x kw x Cout columns)
+  g.passes = 1;
+  if (g.NC > kUpZStride) {
+    // measured level with the implicit GEMM over output pixels (bls2017's 9x9 x4 into 3 channels at 512 x 64x64: 1.22
+    // against 1.21 ms — four passes over the patch cost what the products' round trip through HBM saved), so it is
+    // opt-in: TFC_CONV_UP_PASSES=1
+    const char* e = std::getenv("TFC_CONV_UP_PASSES");
+    if (!e || std::atoi(e) == 0) return -1;
+    g.passes = stride;
+    if (((kh + stride - 1) / stride) * kw * g.Cout > kUpZStride) return -1;
+  }
+  const int tiles = (g.PH * g.PW + 31) / 32;
+  const size_t lds = static_cast<size_t>(tiles) * 32 * kUpZStride * 4 + static_cast<size_t>(cin / 16) * kUpColTiles * 64 * 16;
+  if (lds > 160 * 1024 || n * g.BXn * g.BYn >= (1ll << 31)) return -1;
+  DevBuf wpk;
+  const int frags = g.passes * static_cast<int>(cin / 16) * kUpColTiles * 64;
+  TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
+  hipLaunchKernelGGL(conv_up_fused_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, kh, kw,
+                     static_cast<int>(cin), static_cast<int>(cout), g.passes, wpk.as<bf16x8>());
+  KernelTimer timer("conv2d", st);
+#define TFC_UP_FUSED_LAUNCH(...)                                                                              \
+  do {                                                                                                       \
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up_fused_kernel<__VA_ARGS__>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));         \
+    hipLaunchKernelGGL((conv_up_fused_kernel<__VA_ARGS__>), dim3(static_cast<unsigned>(n * g.BXn * g.BYn)),   \
+                       dim3(kUpThreads), lds, st, static_cast<const __bf16*>(x), wpk.as<bf16x8>(), bias,     \
+                       static_cast<__bf16*>(y), g);                                                          \
+  } while (0)
+  if (kh == 5 && kw == 5 && stride == 2 && cout == 3) TFC_UP_FUSED_LAUNCH(5, 5, 2, 3);          // bmshj2018
+  else if (kh == 9 && kw == 9 && stride == 4 && cout == 3) TFC_UP_FUSED_LAUNCH(9, 9, 4, 3);     // bls2017
+  else TFC_UP_FUSED_LAUNCH(0, 0, 0, 0);
+#undef TFC_UP_FUSED_LAUNCH
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
 int conv_up_small_cout(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h,
                        int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride, int activation,
                        hipStream_t st) {
   {
-    // fused variant: the products of a block stay in LDS (<= 80 product columns, Cin a multiple of 32)
-    auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
-    UpFusedGeom g{};
-    g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin);
-    g.Cout = static_cast<int>(cout); g.kh = kh; g.kw = kw; g.s = stride; g.activation = activation;
-    g.dmax_y = fdiv(kh - 1 - kh / 2, stride);
-    g.dmax_x = fdiv(kw - 1 - kw / 2, stride);
-    const int dmin_y = -fdiv((stride - 1) + kh / 2, stride), dmin_x = -fdiv((stride - 1) + kw / 2, stride);
-    g.PH = 8 + g.dmax_y - dmin_y; g.PW = 32 + g.dmax_x - dmin_x;
-    g.BXn = (g.W + 31) / 32; g.BYn = (g.H + 7) / 8;
-    g.NC = kh * kw * g.Cout;
-    const int tiles = (g.PH * g.PW + 31) / 32;
-    const size_t lds = static_cast<size_t>(tiles) * 32 * kUpZStride * 4 + static_cast<size_t>(cin / 16) * kUpColTiles * 64 * 16;
-    static const bool unfused = [] { const char* e = std::getenv("TFC_CONV_UP_UNFUSED"); return e && std::atoi(e) != 0; }();
-    if (!unfused && g.NC <= 80 && cin % 64 == 0 && lds <= 160 * 1024 && n * g.BXn * g.BYn < (1ll << 31)) {
-      DevBuf wpk;
-      const int frags = static_cast<int>(cin / 16) * kUpColTiles * 64;
-      TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
-      hipLaunchKernelGGL(conv_up_fused_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, kh, kw,
-                         static_cast<int>(cin), static_cast<int>(cout), wpk.as<bf16x8>());
-      KernelTimer timer("conv2d", st);
-#define TFC_UP_FUSED_LAUNCH(...)                                                                              \
-      do {                                                                                                     \
-        TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up_fused_kernel<__VA_ARGS__>),         \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));       \
-        hipLaunchKernelGGL((conv_up_fused_kernel<__VA_ARGS__>), dim3(static_cast<unsigned>(n * g.BXn * g.BYn)), \
-                           dim3(kUpThreads), lds, st, static_cast<const __bf16*>(x), wpk.as<bf16x8>(), bias,   \
-                           static_cast<__bf16*>(y), g);                                                        \
-      } while (0)
-      if (kh == 5 && kw == 5 && stride == 2 && cout == 3) TFC_UP_FUSED_LAUNCH(5, 5, 2, 3);
-      else TFC_UP_FUSED_LAUNCH(0, 0, 0, 0);
-#undef TFC_UP_FUSED_LAUNCH
-      TFC_HIP(hipGetLastError());
-      return 0;
-    }
+    const int rc = run_conv_up_fused(x, w, bias, y, n, h, wd, cin, cout, kh, kw, stride, activation, st);
+    if (rc >= 0) return rc;
   }
   const int zc = kh * kw * 4;
   DevBuf w1, z;
@@ -1895,6 +1935,11 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
 #ifndef TFC_CONV_NO_UP_GATHER
   // (up to 128 product columns, i.e. one column group: a 9x9 stride-4 kernel has 324 and measured the same
   // or slower this way — 0.19 against 0.16 ms at batch 64 — so it keeps the implicit GEMM over output pixels)
+  if (up && dtype == 1 && cout <= 4 && cin % 64 == 0 && stride >= 2 && !out_f32) {
+    const int rc = run_conv_up_fused(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride,
+                                     activation, static_cast<hipStream_t>(stream));
+    if (rc >= 0) return rc;
+  }
   if (up && dtype == 1 && cout <= 4 && cin % 16 == 0 && stride >= 2 && kh * kw * 4 <= 128)
     return conv_up_small_cout(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, activation,
                               static_cast<hipStream_t>(stream));
