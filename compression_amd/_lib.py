@@ -24,6 +24,9 @@ SIGNATURES = {
     "tfc_get_default_mode": (_int, []),
     "tfc_set_coder_gate": (_int, [_vp]),
     "tfc_set_chip_shared": (_int, [_int]),
+    "tfc_image_to_unit": (_int, [_vp, _vp, _int, C.c_int64, _vp]),
+    "tfc_unit_to_image": (_int, [_vp, _int, _vp, C.c_int64, _vp]),
+    "tfc_index_prepare": (_int, [_vp, _int, _vp, C.c_int64, _int, _vp]),
     "tfc_cache_bytes": (_int, [C.POINTER(C.c_longlong)]),
     "tfc_cache_trim": (_int, [C.POINTER(C.c_longlong)]),
     "tfc_device_compute_units": (_int, [C.POINTER(_int)]),

@@ -77,6 +77,16 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
                                   device=indexes.device).reshape(axes)
         return math_ops.upper_bound(indexes, bounds)
 
+    def _table_indexes(self, indexes):
+        """The coder's int32 table indexes: `_normalize_indexes` + `_flatten_indexes` (continuous_indexed.py:272-296),
+        as one kernel for a single index range over floating-point indexes."""
+        if self.channel_axis is None:
+            from ..layers import functional
+            flat = functional.index_prepare(indexes, self.index_ranges[0])
+            if flat is not None:
+                return flat
+        return self._flatten_indexes(self._normalize_indexes(indexes)).contiguous()
+
     def _flatten_indexes(self, indexes):
         indexes = indexes.to(torch.int32)
         if self.channel_axis is None:
@@ -143,8 +153,7 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         self._check_compression()
         device = _lib.require_device()
         bottleneck = torch.as_tensor(bottleneck).to(device, self.bottleneck_dtype).contiguous()
-        indexes = self._normalize_indexes(torch.as_tensor(indexes).to(device))
-        flat = self._flatten_indexes(indexes).contiguous()
+        flat = self._table_indexes(torch.as_tensor(indexes).to(device))
         shape = tuple(flat.shape)
         batch_shape = shape[:len(shape) - self.coding_rank] if self.coding_rank else shape
         cdf_offset = self._device_offsets(device)
@@ -171,8 +180,7 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         `ContinuousBatchedEntropyModel.decompress`)."""
         self._check_compression()
         device = _lib.require_device()
-        indexes = self._normalize_indexes(torch.as_tensor(indexes).to(device))
-        flat = self._flatten_indexes(indexes).contiguous()
+        flat = self._table_indexes(torch.as_tensor(indexes).to(device))
         shape = tuple(flat.shape)
         decode_shape = shape[len(shape) - self.coding_rank:] if self.coding_rank else ()
         cdf_offset = self._device_offsets(device)

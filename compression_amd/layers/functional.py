@@ -223,3 +223,35 @@ def gdn_general_composite(x, beta, gamma, alpha, epsilon, inverse=False, rectify
     norm = torch.pow(norm, epsilon)
     y = xf * norm if inverse else xf / norm
     return y.to(x.dtype)
+
+
+def image_to_unit(x, dtype):
+    """uint8 image tensor -> dtype(x) / 255 in one pass (the input scaling of the models' analysis transforms:
+    bls2017.py:164-170, bmshj2018.py:219-224).  Other inputs take the torch expression."""
+    if x.dtype != torch.uint8 or dtype not in _DTYPE_CODE or not x.is_cuda or not x.is_contiguous():
+        return x.to(dtype) / 255.0
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.check(_lib.lib().tfc_image_to_unit(x.data_ptr(), y.data_ptr(), _DTYPE_CODE[dtype], x.numel(), _lib.stream_ptr()))
+    return y
+
+
+def unit_to_image(x):
+    """saturate_cast(round(x * 255), uint8) with the product rounded to x's dtype, in one pass (the output of the
+    models' synthesis transforms: bls2017.py:186-190, bmshj2018.py:262-264)."""
+    if x.dtype not in _DTYPE_CODE or not x.is_cuda or not x.is_contiguous():
+        return torch.clamp(torch.round((x * 255.0).float()), 0, 255).to(torch.uint8)
+    y = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().tfc_unit_to_image(x.data_ptr(), _DTYPE_CODE[x.dtype], y.data_ptr(), x.numel(), _lib.stream_ptr()))
+    return y
+
+
+def index_prepare(indexes, num_tables):
+    """int32(min(max(indexes, 0), num_tables - 1)) in one pass, or None where the torch ops have to do it (integer or
+    non-contiguous indexes, gradients wanted)."""
+    if (indexes.dtype not in _DTYPE_CODE or not indexes.is_cuda or not indexes.is_contiguous()
+            or (torch.is_grad_enabled() and indexes.requires_grad)):
+        return None
+    out = torch.empty(indexes.shape, dtype=torch.int32, device=indexes.device)
+    _lib.check(_lib.lib().tfc_index_prepare(indexes.data_ptr(), _DTYPE_CODE[indexes.dtype], out.data_ptr(),
+                                            indexes.numel(), int(num_tables), _lib.stream_ptr()))
+    return out

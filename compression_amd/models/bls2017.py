@@ -7,6 +7,7 @@ from __future__ import annotations
 import torch
 
 from .. import distributions, entropy_models, layers
+from ..layers import functional
 from ..pipeline import inline_lane
 
 __all__ = ["AnalysisTransform", "SynthesisTransform", "BLS2017Model"]
@@ -24,7 +25,11 @@ class AnalysisTransform(torch.nn.Module):
                                            use_bias=False, activation=None, in_channels=C)
 
     def forward(self, x):
-        return self.layer_2(self.layer_1(self.layer_0(x / 255.0)))
+        return self.unit(x / 255.0)
+
+    def unit(self, u):
+        """The layers, on an image already scaled to [0, 1] (`functional.image_to_unit`)."""
+        return self.layer_2(self.layer_1(self.layer_0(u)))
 
 
 class SynthesisTransform(torch.nn.Module):
@@ -39,7 +44,11 @@ class SynthesisTransform(torch.nn.Module):
                                            use_bias=True, activation=None, in_channels=C)
 
     def forward(self, y):
-        return self.layer_2(self.layer_1(self.layer_0(y))) * 255.0
+        return self.unit(y) * 255.0
+
+    def unit(self, y):
+        """The layers, without the scaling to [0, 255] (`functional.unit_to_image` takes it with the rounding)."""
+        return self.layer_2(self.layer_1(self.layer_0(y)))
 
 
 class BLS2017Model(torch.nn.Module):
@@ -83,8 +92,7 @@ class BLS2017Model(torch.nn.Module):
         if x.dim() == 3:
             x = x[None]
         with lane.on("transform"):
-            x = x.to(self.compute_dtype)
-            y = self.analysis_transform(x)
+            y = self.analysis_transform.unit(functional.image_to_unit(x, self.compute_dtype))
         with lane.on("coder"):
             string = self.entropy_model.compress(y, device_result=device_result)
         if device_result:
@@ -103,9 +111,7 @@ class BLS2017Model(torch.nn.Module):
             y_hat, oky = y_hat
             ok.append(oky)
         with lane.on("transform"):
-            x_hat = self.synthesis_transform(y_hat)
-            x_hat = x_hat[:, :x_shape[0], :x_shape[1], :]
-            x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            x_hat = functional.unit_to_image(self.synthesis_transform.unit(y_hat)[:, :x_shape[0], :x_shape[1], :])
             if defer_sanity:
                 x_hat._tfc_keep = (y_hat,)
         return (x_hat, ok) if defer_sanity else x_hat
@@ -119,9 +125,8 @@ class BLS2017Model(torch.nn.Module):
             x = x[None]
 
         def analysis():
-            xc = x.to(self.compute_dtype)
-            s["y"] = y = self.analysis_transform(xc)
-            s["shapes"] = tuple(xc.shape[1:-1]), tuple(y.shape[1:-1])
+            s["y"] = y = self.analysis_transform.unit(functional.image_to_unit(x, self.compute_dtype))
+            s["shapes"] = tuple(x.shape[1:-1]), tuple(y.shape[1:-1])
 
         def code():
             string = self.entropy_model.compress(s["y"], device_result=True)
@@ -131,8 +136,8 @@ class BLS2017Model(torch.nn.Module):
 
         def synthesis():
             x_shape = s["shapes"][0]
-            x_hat = self.synthesis_transform(s["y_hat"])[:, :x_shape[0], :x_shape[1], :]
-            s["x_hat"] = x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            s["x_hat"] = x_hat = functional.unit_to_image(
+                self.synthesis_transform.unit(s["y_hat"])[:, :x_shape[0], :x_shape[1], :])
             return x_hat
 
         stages = [("transform", analysis), ("coder", code), ("transform", synthesis)]
@@ -142,7 +147,8 @@ class BLS2017Model(torch.nn.Module):
     def compress_many(self, xs):
         """compress() of several batches with one coder launch (ContinuousBatchedEntropyModel.compress_many):
         [(handle, x_shape, y_shape)] — the handles keep the strings in HBM."""
-        ys = [self.analysis_transform((x if x.dim() == 4 else x[None]).to(self.compute_dtype)) for x in xs]
+        ys = [self.analysis_transform.unit(functional.image_to_unit(x if x.dim() == 4 else x[None], self.compute_dtype))
+              for x in xs]
         handles = self.entropy_model.compress_many(ys)
         return [(h, tuple(x.shape[-3:-1]), tuple(y.shape[1:-1])) for h, x, y in zip(handles, xs, ys)]
 
@@ -154,8 +160,7 @@ class BLS2017Model(torch.nn.Module):
         y_hats, ok = self.entropy_model.decompress_many(handles, packed[0][2])
         outs = []
         for (h, x_shape, y_shape), y_hat in zip(packed, y_hats):
-            x_hat = self.synthesis_transform(y_hat)[:, :x_shape[0], :x_shape[1], :]
-            x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            x_hat = functional.unit_to_image(self.synthesis_transform.unit(y_hat)[:, :x_shape[0], :x_shape[1], :])
             x_hat._tfc_keep = (y_hat,)
             outs.append(x_hat)
         return outs, ok

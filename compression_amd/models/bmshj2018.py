@@ -7,6 +7,7 @@ import math
 import torch
 
 from .. import distributions, entropy_models, layers
+from ..layers import functional
 from ..pipeline import inline_lane
 
 __all__ = ["AnalysisTransform", "SynthesisTransform", "HyperAnalysisTransform",
@@ -27,7 +28,11 @@ class AnalysisTransform(torch.nn.Module):
         self.layer_3 = _conv(C, 5, C, corr=True, strides_down=2, use_bias=True, activation=None)
 
     def forward(self, x):
-        return self.layer_3(self.layer_2(self.layer_1(self.layer_0(x / 255.0))))
+        return self.unit(x / 255.0)
+
+    def unit(self, u):
+        """The layers, on an image already scaled to [0, 1] (`functional.image_to_unit`)."""
+        return self.layer_3(self.layer_2(self.layer_1(self.layer_0(u))))
 
 
 class SynthesisTransform(torch.nn.Module):
@@ -41,7 +46,11 @@ class SynthesisTransform(torch.nn.Module):
         self.layer_3 = _conv(3, 5, C, corr=False, strides_up=2, use_bias=True, activation=None)
 
     def forward(self, y):
-        return self.layer_3(self.layer_2(self.layer_1(self.layer_0(y)))) * 255.0
+        return self.unit(y) * 255.0
+
+    def unit(self, y):
+        """The layers, without the scaling to [0, 255] (`functional.unit_to_image` takes it with the rounding)."""
+        return self.layer_3(self.layer_2(self.layer_1(self.layer_0(y))))
 
 
 class HyperAnalysisTransform(torch.nn.Module):
@@ -128,8 +137,7 @@ class BMSHJ2018Model(torch.nn.Module):
         if x.dim() == 3:
             x = x[None]
         with lane.on("transform"):
-            x = x.to(self.compute_dtype)
-            y = self.analysis_transform(x)
+            y = self.analysis_transform.unit(functional.image_to_unit(x, self.compute_dtype))
             z = self.hyper_analysis_transform(torch.abs(y))
             x_shape, y_shape, z_shape = tuple(x.shape[1:-1]), tuple(y.shape[1:-1]), tuple(z.shape[1:-1])
             z_hat = self.side_entropy_model.quantize(z)
@@ -164,8 +172,7 @@ class BMSHJ2018Model(torch.nn.Module):
             y_hat, oky = y_hat
             ok.append(oky)
         with lane.on("transform"):
-            x_hat = self.synthesis_transform(y_hat)[:, :x_shape[0], :x_shape[1], :]
-            x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            x_hat = functional.unit_to_image(self.synthesis_transform.unit(y_hat)[:, :x_shape[0], :x_shape[1], :])
             if defer_sanity:
                 x_hat._tfc_keep = (z_hat, indexes, y_hat)     # produced on one stream, read on the other
         return (x_hat, ok) if defer_sanity else x_hat
@@ -182,10 +189,9 @@ class BMSHJ2018Model(torch.nn.Module):
             x = x[None]
 
         def analysis():
-            xc = x.to(self.compute_dtype)
-            s["y"] = y = self.analysis_transform(xc)
+            s["y"] = y = self.analysis_transform.unit(functional.image_to_unit(x, self.compute_dtype))
             s["z"] = z = self.hyper_analysis_transform(torch.abs(y))
-            s["shapes"] = tuple(xc.shape[1:-1]), tuple(y.shape[1:-1]), tuple(z.shape[1:-1])
+            s["shapes"] = tuple(x.shape[1:-1]), tuple(y.shape[1:-1]), tuple(z.shape[1:-1])
             z_hat = self.side_entropy_model.quantize(z)
             s["indexes"] = self.hyper_synthesis_transform(z_hat)[:, :y.shape[1], :y.shape[2], :]
 
@@ -212,8 +218,8 @@ class BMSHJ2018Model(torch.nn.Module):
 
         def synthesis_rest():
             t, x_shape = self.synthesis_transform, s["shapes"][0]
-            x_hat = (t.layer_3(t.layer_2(s.pop("u"))) * 255.0)[:, :x_shape[0], :x_shape[1], :]
-            s["x_hat"] = x_hat = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+            s["x_hat"] = x_hat = functional.unit_to_image(
+                t.layer_3(t.layer_2(s.pop("u")))[:, :x_shape[0], :x_shape[1], :])
             return x_hat
 
         # the synthesis in two stages: its first two layers (a third of its time, shorter than the encode) can run

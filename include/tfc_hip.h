@@ -90,6 +90,14 @@ int tfc_set_chip_shared(int shared);
  * tfc_cache_bytes: bytes cached now; tfc_cache_trim: returns the blocks whose last use has completed to the driver
  * (-> bytes released).  TFC_CACHE_LIMIT_MB bounds the cache (default 65536).  No reference counterpart (TensorFlow's
  * allocator owns the ops' scratch memory). */
+/* Elementwise passes of the model pipelines (csrc/elementwise.hip), one kernel each; dtype 0 = float32, 1 = bfloat16.
+ * tfc_image_to_unit: y[i] = dtype(x[i]) / 255 for uint8 x (models/bls2017.py:164-170, bmshj2018.py:219-224).
+ * tfc_unit_to_image: y[i] = saturate_cast<uint8>(round_half_even(dtype(x[i] * 255))) (bls2017.py:186-190).
+ * tfc_index_prepare: out[i] = int32(min(max(indexes[i], 0), num_tables - 1)), cast toward zero
+ * (continuous_indexed.py:272-296: `_normalize_indexes` and the int32 cast of `_flatten_indexes`, one index range). */
+int tfc_image_to_unit(const void* x, void* y, int dtype, int64_t n, void* stream);
+int tfc_unit_to_image(const void* x, int dtype, void* y, int64_t n, void* stream);
+int tfc_index_prepare(const void* indexes, int dtype, int32_t* out, int64_t n, int num_tables, void* stream);
 int tfc_cache_bytes(long long* bytes);
 int tfc_cache_trim(long long* released);
 int tfc_device_compute_units(int* cus);
