@@ -603,7 +603,11 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
     from compression_amd.ops import gen_ops
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     if depth <= 0:
-        depth = 4
+        # 6 streams x `queue` steps.  4 measure the same in a fresh process (35-38 against 36-39 ms for C4), but where the
+        # process has a history (the default line: C2, the convolution table, C1 first) the step on 4 streams comes out
+        # bimodal — 35 or 44-53 ms, same binary, same box — as if two of the streams shared a hardware queue; with 6 the
+        # same line gives 39 (profiles/r03_notes.md)
+        depth = 6
     model, x, batch, hw, hist = make_model(workload, dtype, device, batch, rank)
     if distributed:
         parallel.broadcast_tables(model)
@@ -932,7 +936,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU for the model workloads")
     ap.add_argument("--model-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model-depth", type=int, default=0,
-                    help="streams that carry model steps (1: one step at a time; 0: 4 — measured, profiles/r03_notes.md)")
+                    help="streams that carry model steps (1: one step at a time; 0: 6 — measured, profiles/r03_notes.md)")
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="compute units reserved for the coder streams of a model pipeline (0: one SIMD per image, "
                          "at most half the chip)")
