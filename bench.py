@@ -561,9 +561,9 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
 
 def run_model_pipeline(model, x, steps, sp, fetch=True):
     """`steps` compress + decompress passes through a `pipeline.SoftwarePipeline` (one transform and one coder
-    stream on disjoint CUs; step k's synthesis and step k + 2's analysis... see its docstring).  The host never
-    waits inside a step: step k - 2 is retired (end event, strings and sanity flags fetched) after step k has been
-    enqueued.  Returns (seconds, last record)."""
+    stream; step k's coding beside step k - 1's synthesis and step k + 1's analysis — see its docstring).  The host
+    never waits inside a step: step k - 2 is retired (end event, strings and sanity flags fetched) after step k has
+    been enqueued.  Returns (seconds, last record)."""
     main = torch.cuda.current_stream()
     states, last = [], None
 

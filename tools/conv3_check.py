@@ -59,11 +59,6 @@ for name, fn, (H, W), k, ci, co, s in cases:
         os.environ["TFC_CONV_GEN"] = "4" if g == "3" else g       # 4: the third generation wherever it is built
         out[g] = fn(x, w, bias, s, "relu")
         ms[g] = timed(lambda: fn(x, w, bias, s, "relu"))
-    exps = []
-    for e in os.environ.get("CONV3_EXPS", "").split():
-        os.environ["TFC_CONV_GEN"], os.environ["TFC_CONV3_EXP"] = "4", e
-        exps.append(f"exp{e}={timed(lambda: fn(x, w, bias, s, 'relu')):.3f}")
-        os.environ["TFC_CONV3_EXP"] = "0"
     # torch fp32 on a slice of the batch
     xs = x[:2].float().permute(0, 3, 1, 2)
     wq = w.to(torch.bfloat16).float()
@@ -80,4 +75,4 @@ for name, fn, (H, W), k, ci, co, s in cases:
     dref2 = (out["2"][:2].float() - ref).abs().max().item()
     flops = 2.0 * out["3"].numel() / co * (k * k / (s * s) if fn is conv2d_up else k * k) * ci * co
     print(f"{name:32s} n={n:3d}  gen3 {ms['3']:7.3f} ms ({flops / ms['3'] / 1e9:6.0f} TF)  gen2 {ms['2']:7.3f} ms ({flops / ms['2'] / 1e9:6.0f} TF)"
-          f"  {' '.join(exps)}  |3-2| {d32:.4f}  |3-ref| {dref3:.4f}  |2-ref| {dref2:.4f}  max|ref| {ref.abs().max().item():.2f}")
+          f"  |3-2| {d32:.4f}  |3-ref| {dref3:.4f}  |2-ref| {dref2:.4f}  max|ref| {ref.abs().max().item():.2f}")
