@@ -110,10 +110,14 @@ def step_group(lookup_t, values, mode):
     return list(zip(hs, ds, decoded, oks))
 
 
-def sample_symbols_device(lookup, seed, device, escape_fraction=0.0):
-    """[STREAMS, ELEMS] int32 symbols on the device: uniform `precision`-bit draws inverted through each
-    channel's CDF (same law as synthetic.sample_symbols, drawn with torch's generator so that 32 slots
-    take milliseconds instead of minutes)."""
+def sample_symbols_device(lookup, seed, device, escape_fraction=0.0, fold=False):
+    """[STREAMS, ELEMS] int32 symbols on the device, the input law of SURVEY.md 8(d): uniform `precision`-bit draws
+    inverted through each channel's CDF (same law as synthetic.sample_symbols, drawn with torch's generator so that
+    32 slots take milliseconds instead of minutes).  A draw that lands in a row's overflow bucket IS the row's escape
+    symbol — a value just outside the table, coded with the shortest Elias-gamma code — so the tables' own tail mass
+    (2^-8 per row, ~0.4 % of the symbols) takes the escape path.  `escape_fraction` > 0 additionally replaces that
+    share of the symbols by +-(len + Geometric(0.2)) (8(d)'s second run); `fold=True` moves the overflow draws onto
+    the neighbouring plain symbol instead (an escape-free input, for comparison only)."""
     rows = synthetic.lookup_rows(lookup)
     ntab = len(rows)
     width = max(len(c) for _, c in rows)
@@ -131,7 +135,7 @@ def sample_symbols_device(lookup, seed, device, escape_fraction=0.0):
     reps = ELEMS // ntab
     uu = u.view(STREAMS, reps, ntab).permute(2, 0, 1).reshape(ntab, -1).contiguous()
     sym = torch.searchsorted(table_t, uu, right=True) - 1
-    top = torch.where(esc, nsym - 2, nsym - 1).clamp(min=0)[:, None]   # fold the escape symbol onto its neighbour
+    top = (torch.where(esc, nsym - 2, nsym - 1) if fold else nsym - 1).clamp(min=0)[:, None]
     sym = torch.minimum(sym, top).clamp(min=0)
     out = sym.view(ntab, STREAMS, reps).permute(1, 2, 0).reshape(STREAMS, ELEMS)
     if escape_fraction > 0:
@@ -142,6 +146,14 @@ def sample_symbols_device(lookup, seed, device, escape_fraction=0.0):
         neg = torch.randint(0, 2, (STREAMS, ELEMS), generator=gen, device=device).bool()
         out = torch.where(mask, torch.where(neg, -geo, lens + geo), out)
     return out.to(torch.int32).contiguous()
+
+
+def escape_share(lookup, value_t):
+    """Share of the symbols of `value_t` [STREAMS, ELEMS] that take the escape path of their row."""
+    rows = synthetic.lookup_rows(lookup)
+    limit = torch.tensor([len(c) - 2 if sp < 0 else 1 << 30 for sp, c in rows], device=value_t.device)
+    lim = limit[torch.arange(value_t.shape[1], device=value_t.device) % len(rows)][None, :]
+    return float(((value_t < 0) | (value_t >= lim)).float().mean().item())
 
 
 def gdn_forward_bandwidth(device, steps=20):
@@ -210,7 +222,7 @@ def gdn_forward_bandwidth(device, steps=20):
                          "unit": "GB/s"}}
 
 
-CODER_SOURCES = ["compression_amd/csrc/range_coder.hip", "compression_amd/csrc/range_lanes.h",
+CODER_SOURCES = ["compression_amd/csrc/range_coder.hip", "compression_amd/csrc/range_lanes.h", "compression_amd/csrc/range_pipe.h",
                  "compression_amd/csrc/range_encoder_fast.h", "compression_amd/csrc/range_decoder_fast.h"]
 GDN_SOURCES = ["compression_amd/csrc/gdn.hip", "compression_amd/csrc/gdn_common.h",
                "compression_amd/csrc/gdn_backward.hip"]
@@ -262,8 +274,8 @@ def pmc_traffic(kernel_substring, profile, sources, steps_per_launch=None):
     return None
 
 
-PMC_PROFILE = "r03_pmc_traffic.json"
-SQ_PROFILE = "r03_sq_inflight.json"
+PMC_PROFILE = "r04_pmc_traffic.json"
+SQ_PROFILE = "r04_sq_inflight.json"
 
 
 def valu_issue_floor(ms_per_step, kernels, steps_per_launch):
@@ -783,7 +795,7 @@ def model_workload(args, world, rank, device, distributed):
 
 
 def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_fraction, steps, inflight,
-           serial=True):
+           serial=True, fold=False):
     """The coder round trip at BASELINE config 2 with `escape_fraction` of the symbols out of range: exactly
     `steps` steps, `inflight` per launch group.  Returns the measurements (every rank) — rank 0 formats."""
     import hashlib
@@ -791,7 +803,7 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
         import torch.distributed as dist
     inflight = max(1, min(inflight, steps))
     # every slot in flight codes its own tensor (inputs resident in HBM)
-    slots = [sample_symbols_device(lookup, 1000 * rank + k, device, escape_fraction) for k in range(inflight)]
+    slots = [sample_symbols_device(lookup, 1000 * rank + k, device, escape_fraction, fold) for k in range(inflight)]
     # one stream: the launches of a group fill the chip on their own (a decoder workgroup takes a whole
     # CU's LDS), groups on different streams would only queue behind each other's workgroups
     side_streams = [torch.cuda.Stream(device=device)]
@@ -845,7 +857,7 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
     del res
     torch.cuda.synchronize()
 
-    m = {"inflight": inflight, "steps": steps, "escape_fraction": escape_fraction}
+    m = {"inflight": inflight, "steps": steps, "escape_fraction": escape_fraction, "escape_share": escape_share(lookup, slots[0])}
     if serial:
         # one batch at a time (config 2 as literally written), per-kernel durations with the GPU to one launch
         # (a counter-profiling run leaves the single-step lane launches out: per-launch counter averages of the
@@ -869,6 +881,12 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
     elapsed, results, t_enqueued = run_steps(steps, inflight, flight_mode)
     cenc_ms, cenc_n = profile_query("enc_kernel")
     cdec_ms, cdec_n = profile_query("dec_kernel")
+    # the pipelined lane kernels (csrc/range_pipe.h): the launches inside an encode / decode call, each timed on its own
+    stages = {}
+    for name in ("enc_expand", "enc_chain", "dec_chain", "dec_parse"):
+        ms, cnt = profile_query(name)
+        if cnt:
+            stages[name] = ms / cnt
     _lib.lib().tfc_profile_enable(0)
     verify(results)
     elapsed_local = elapsed
@@ -882,18 +900,21 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
     blob0 = h0.blob.cpu().numpy()
     offs0 = h0.offsets.cpu().numpy().astype(np.int64)
     del strings, results
-    m.update(elapsed=elapsed, elapsed_local=elapsed_local, t_enqueued=t_enqueued, enc_tr=cenc_ms / max(cenc_n, 1), dec_tr=cdec_ms / max(cdec_n, 1),
+    m.update(stages=stages, elapsed=elapsed, elapsed_local=elapsed_local, t_enqueued=t_enqueued, enc_tr=cenc_ms / max(cenc_n, 1), dec_tr=cdec_ms / max(cdec_n, 1),
              total_bytes=int(offs0[-1]), blob_sha=hashlib.sha256(blob0.tobytes()).hexdigest(),
              offs_sha=hashlib.sha256(offs0.tobytes()).hexdigest(), slot0=slots[0])
     return m
 
 
-def escape_object(args, lookup, lookup_t, device, fraction, cpu_value):
-    """The --steps command again with `fraction` of the symbols out of range (Elias-gamma escape codes):
-    throughput, and slot 0's bytes against the CPU reference coder's."""
-    m = c2_run(args, lookup, lookup_t, device, 1, 0, False, fraction, args.steps, args.inflight, serial=False)
+def escape_object(args, lookup, lookup_t, device, fraction, cpu_value, fold=False):
+    """The --steps command again on another input law — `fraction` of the symbols replaced by far-out values, or
+    (`fold`) the overflow draws folded away: throughput, and slot 0's bytes against the CPU reference coder's."""
+    m = c2_run(args, lookup, lookup_t, device, 1, 0, False, fraction, args.steps, args.inflight, serial=False, fold=fold)
     value = STREAMS * PIXELS_PER_STREAM / 1e6 / (m["elapsed"] / args.steps)
-    obj = {"escape_fraction": fraction, "value": round(value, 2), "unit": "Mpixels/s",
+    obj = {"law": "overflow draws folded onto the neighbouring symbol (no escape codes)" if fold else
+                  f"8(d) law + {fraction:g} of the symbols replaced by +-(len + Geometric(0.2))",
+           "symbols_on_the_escape_path": round(m["escape_share"], 5),
+           "value": round(value, 2), "unit": "Mpixels/s",
            "ms_per_step": round(1e3 * m["elapsed"] / args.steps, 4), "steps": args.steps,
            "steps_in_flight": m["inflight"],
            "bits_per_symbol": round(8.0 * m["total_bytes"] / (STREAMS * ELEMS), 4),
@@ -1003,6 +1024,13 @@ def main():
         achieved = dom_bytes / 1e9 / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         dom_symbol = {("dec_kernel", True): "dec_lanes_kernel", ("enc_kernel", True): "enc_lanes_kernel",
                       ("dec_kernel", False): "dec_fast_kernel", ("enc_kernel", False): "enc_fast_kernel"}[(dom, lanes)]
+        stages = m.get("stages") or {}
+        if lanes and stages:
+            # throughput-mode calls run the pipelined kernels of csrc/range_pipe.h: the dominant KERNEL is one stage
+            stage = max(stages, key=stages.get)
+            dom_symbol, dom_ms = stage + "_kernel", stages[stage]
+            dom_bytes = (alg_dec if stage.startswith("dec") else alg_enc) * jobs_per_launch
+            achieved = dom_bytes / 1e9 / (dom_ms / 1e3)
         ser, ser_l = m["serial"], m["serial_lanes"]
         out = {
             "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
@@ -1022,7 +1050,10 @@ def main():
                             "(192ch x 16 x 16 = one 256x256 image each), 192 Gaussian tables, "
                             "precision 12, escape coding enabled, per GPU",
                 "streams_per_gpu": STREAMS, "symbols_per_stream": ELEMS,
-                "escape_fraction": args.escape_fraction,
+                "input_law": "SURVEY 8(d): uniform 12-bit draws inverted through each row's CDF, overflow bucket included "
+                             "(the rows' tail mass 2^-8 takes the Elias-gamma escape path)" +
+                             (f"; {args.escape_fraction:g} of the symbols replaced by far-out values" if args.escape_fraction else ""),
+                "symbols_on_the_escape_path": round(m["escape_share"], 5),
                 "parallelism": f"batch-sharded x{world}",
                 "steps_in_flight": inflight,
                 "launch": "the coding calls of the steps in flight are one launch per direction "
@@ -1040,7 +1071,9 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * m["t_enqueued"] / args.steps, 4),
             "kernels_ms": {"enc_kernel": round(enc_avg, 4), "dec_kernel": round(dec_avg, 4),
                            "note": "latency-mode kernels, one launch at a time"},
-            "kernels_ms_in_flight": {"enc_kernel": round(enc_tr, 4), "dec_kernel": round(dec_tr, 4)},
+            "kernels_ms_in_flight": {"enc_kernel": round(enc_tr, 4), "dec_kernel": round(dec_tr, 4),
+                                     "stages": {k: round(v, 4) for k, v in stages.items()},
+                                     "note": "enc_kernel / dec_kernel: all launches of an encode / decode call of the group"},
             "single_batch": {
                 "note": "BASELINE config 2 as literally written: ONE 512-stream batch at a time, host waits for every step",
                 "latency_mode": {"ms_per_step": round(1e3 * ser["seconds"] / ser["steps"], 4),
@@ -1075,7 +1108,7 @@ def main():
         if per_rank:
             out["per_rank"] = per_rank
         out["valu_issue_bound"] = valu_issue_floor(
-            1e3 * elapsed / args.steps, ("enc_lanes_kernel", "dec_lanes_kernel") if lanes else ("enc_fast_kernel", "dec_fast_kernel"),
+            1e3 * elapsed / args.steps, ("enc_chain_kernel", "dec_chain_kernel") if lanes else ("enc_fast_kernel", "dec_fast_kernel"),
             jobs_per_launch)
         if world == 1:
             out["gdn_fwd"] = gdn_forward_bandwidth(device)
@@ -1092,10 +1125,10 @@ def main():
         if extras:
             torch.set_num_threads(1)
             if args.escape_fraction == 0.0:
-                out["escapes"] = {}
-                for frac in (0.004, 0.01):
-                    out["escapes"][str(frac)] = escape_object(args, lookup, lookup_t, device, frac,
-                                                              out.get("cpu_baseline", {}).get("value"))
+                out["escapes"] = {
+                    "0.01": escape_object(args, lookup, lookup_t, device, 0.01, out.get("cpu_baseline", {}).get("value")),
+                    "escape_free": escape_object(args, lookup, lookup_t, device, 0.0,
+                                                 out.get("cpu_baseline", {}).get("value"), fold=True)}
             torch.cuda.empty_cache()
             out["conv"] = conv_layer_table(device)
             out["models"] = {}

@@ -358,11 +358,15 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       cdf_entries += static_cast<size_t>(nsym + 1);
       words += std::max<size_t>(1, (size_t{1} << prec) / 64);
     }
+    // behind the tables' rows: the uniform binary row {0, 1/2, 1} the pipelined decoder (range_pipe.h) decodes the
+    // bits of an escape code from (range_coder_kernels.cc:449-471: DecodeLinearly on {0, 1, 2} at precision 1)
+    cdf_entries += 3;
+    words += std::max<size_t>(1, (size_t{1} << prec) / 64);
     // the directory repeats its first entries behind its end: a block of kEncCadence / kDecCadence steps
     // reads that many consecutive entries without a wrap test per step
     constexpr size_t kDirRepeat = 16;
     // (>= kEncCadence and kDecCadence of range_lanes.h, which asserts it)
-    const size_t dir_bytes = sizeof(tfc::LaneRow) * (ntab + kDirRepeat);
+    const size_t dir_bytes = sizeof(tfc::LaneRow) * (ntab + kDirRepeat + 1);
     const size_t cdf_bytes = (2 * cdf_entries + 15) & ~size_t{15};
     const size_t enc_bytes = dir_bytes + cdf_bytes;
     const size_t dec_bytes = enc_bytes + 8 * words + ((2 * words + 15) & ~size_t{15});
@@ -400,6 +404,24 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
         wo += nw;
       }
       for (size_t i = 0; i < kDirRepeat; ++i) dir[ntab + i] = dir[i % ntab];
+      {
+        // the binary row, at the table set's precision (the quotient scale is a kernel constant); at precision 0
+        // (no such tables: precision >= 1) its two boundaries would coincide
+        tfc::LaneRow& d = dir[ntab + kDirRepeat];
+        d.cdf = static_cast<unsigned int>(dir_bytes + 2 * ce) - 2u;
+        d.bits = static_cast<unsigned int>(enc_bytes + 8 * wo);
+        d.cum = static_cast<unsigned int>(enc_bytes + 8 * words + 2 * wo);
+        d.info = 2u;
+        cdf16[ce] = 0; cdf16[ce + 1] = 0x8000; cdf16[ce + 2] = 0;
+        const unsigned int mid = 1u << (prec - 1);
+        bits[wo] |= 1ull;
+        bits[wo + (mid >> 6)] |= uint64_t{1} << (mid & 63);
+        unsigned int run = 0;
+        for (size_t w = 0; w < nw; ++w) {
+          cum[wo + w] = static_cast<uint16_t>(static_cast<int16_t>(static_cast<int>(run) - 1));
+          run += static_cast<unsigned int>(__builtin_popcountll(bits[wo + w]));
+        }
+      }
       TFC_HIP(t->d_lane_image.alloc(image.size(), st));
       TFC_HIP(hipMemcpyAsync(t->d_lane_image.p, image.data(), image.size(), hipMemcpyHostToDevice, st));
       TFC_HIP(hipStreamSynchronize(st));
@@ -1248,6 +1270,7 @@ __global__ void __launch_bounds__(kBlock) dec_kernel(DecParams p, Dst dst) {
 }  // namespace tfc
 #include "range_decoder_fast.h"
 #include "range_lanes.h"
+#include "range_pipe.h"
 namespace tfc {
 
 // Reads the first four bytes of every stream (RangeDecoder ctor,
@@ -1565,8 +1588,31 @@ int encoder_error(tfc_encoder* e, const unsigned long long* host_status) {
                           ch, static_cast<int32_t>(static_cast<long long>(host_status[1])));
 }
 
+// The pipelined kernels of range_pipe.h in front of the lane-per-stream kernels (TFC_PIPE=0: the latter alone —
+// an A/B switch for measurements, not a product setting).
+inline bool pipe_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("TFC_PIPE");
+    return !e || std::atoi(e) != 0;
+  }();
+  return on;
+}
+// TFC_PIPE_NOFALLBACK=1 (tools/pipe_probe.py): the lane-per-stream kernel is NOT launched behind the pipelined ones, so
+// that a job they gave up on shows as wrong output instead of being covered up
+inline bool pipe_fallback_launch() {
+  static const bool on = [] {
+    const char* e = std::getenv("TFC_PIPE_NOFALLBACK");
+    return !e || std::atoi(e) == 0;
+  }();
+  return on;
+}
+// temporaries of one pipelined launch are bounded: more jobs than this go out as several launches
+constexpr size_t kPipeTempBytes = size_t{6} << 30;
+
 // Lane-per-stream family: n handles (same tables, same stream count) coded by one launch per
 // kMaxLaneJobs of them; no counting pass, no read-back unless a handle wants its range errors now.
+// Where the geometry allows, the pipelined kernels (range_pipe.h: parallel expansion into call words, then the
+// chain) take the launch and the lane-per-stream kernel behind them only codes the jobs they gave up on.
 template <typename Src>
 int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int32_t* const* indexes,
                       int64_t elems, hipStream_t st, bool worst_case_slab) {
@@ -1581,6 +1627,7 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   la.precision = t->lane_precision;
   la.cap = lanes_slab_bytes(t, elems, worst_case_slab);
   la.defer = lanes_escape_defer();
+  la.guard = nullptr;
   const bool speculative = t->any_escape && !worst_case_slab;
   std::vector<DevBuf> backups(speculative ? n : 0);     // pre-call coder states of the handles that can retry
   la.lds_image = (t->lane_enc_bytes + 1023) & ~1023;
@@ -1591,8 +1638,22 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   const void* fn = indexed ? reinterpret_cast<const void*>(&enc_lanes_kernel<true, Src>)
                            : reinterpret_cast<const void*>(&enc_lanes_kernel<false, Src>);
   TFC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-  for (int g0 = 0; g0 < n; g0 += kMaxLaneJobs) {
-    const int gn = std::min(kMaxLaneJobs, n - g0);
+  // pipelined launch plan: groups of 64 streams, tiles of kPipeTile symbols; rows (coder calls) per group: one per
+  // symbol, room for escape codes when the tables have escape rows, and the rounding of every tile to whole blocks
+  PipeEncArgs pa;
+  pa.nt = static_cast<int>(ceil_div(elems, kPipeTile));
+  // (a tile takes the rows of its LONGEST lane, so the budget for escape codes is generous: half more than the symbols)
+  const int64_t rows64 = elems + (t->any_escape ? elems / 2 + 64 : 0) + static_cast<int64_t>(kPipeBlock) * pa.nt;
+  pa.rows = static_cast<int>(std::min<int64_t>((rows64 + kPipeBlock - 1) / kPipeBlock * kPipeBlock, int64_t{1} << 30));
+  pa.groups_per_job = static_cast<int>(ceil_div(streams, 64));
+  const size_t group_bytes = static_cast<size_t>(pa.rows) * 256 + sizeof(unsigned int) * pa.nt;
+  const size_t job_bytes = group_bytes * pa.groups_per_job;
+  const bool pipe = pipe_enabled() && rows64 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
+                    static_cast<int64_t>(pa.nt) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
+  const int per_launch = !pipe ? kMaxLaneJobs
+                               : static_cast<int>(std::max<size_t>(1, std::min<size_t>(kMaxLaneJobs, kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
+  for (int g0 = 0; g0 < n; g0 += per_launch) {
+    const int gn = std::min(per_launch, n - g0);
     EncLaneJobs<Src> jobs;
     EncErrJobs<Src> errs;
     jobs.streams = streams;
@@ -1630,9 +1691,54 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
     }
     {
       KernelTimer timer("enc_kernel", st);
+      DevBuf temp;
+      if (pipe) {
+        const size_t groups = static_cast<size_t>(pa.groups_per_job) * gn;
+        // (one block of rows behind the last group: the chain requests a block ahead)
+        const size_t calls_bytes = (groups * pa.rows + kPipeBlock) * 64 * sizeof(unsigned int);
+        const size_t end_bytes = (groups * pa.nt * sizeof(unsigned int) + 255) & ~size_t{255};
+        TFC_HIP(temp.alloc(calls_bytes + end_bytes + 256, st));
+        uint8_t* base = temp.as<uint8_t>();
+        pa.calls = reinterpret_cast<unsigned int*>(base);
+        pa.tileend = reinterpret_cast<unsigned int*>(base + calls_bytes);
+        pa.fallback = reinterpret_cast<unsigned int*>(base + calls_bytes + end_bytes);
+        pa.groups = static_cast<int>(groups);
+        pa.fast16 = t->d_fast.as<uint16_t>();
+        pa.rows_fast = t->d_rows_fast.as<int2>();
+        pa.ntab = la.ntab;
+        pa.cap = la.cap;
+        TFC_HIP(hipMemsetAsync(pa.tileend, 0, end_bytes + 256, st));       // tile ends not yet known, no fallback
+        const dim3 xgrid(static_cast<unsigned>(groups * pa.nt));
+        {
+          KernelTimer t2("enc_expand", st);
+          if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src>), xgrid, dim3(256), 0, st, jobs, pa);
+          else hipLaunchKernelGGL((enc_expand_kernel<false, Src>), xgrid, dim3(256), 0, st, jobs, pa);
+        }
+        PipeChainJobs cj;
+        cj.streams = streams;
+        for (int k = 0; k < gn; ++k)
+          cj.job[k] = PipeChainJob{jobs.job[k].state, jobs.job[k].chunk, jobs.job[k].chunk_len, jobs.job[k].overflow_flag};
+        {
+          KernelTimer t2("enc_chain", st);
+          hipLaunchKernelGGL(enc_chain_kernel, dim3(static_cast<unsigned>(groups)), dim3(64), 0, st, cj, pa);
+        }
+        la.guard = pa.fallback;
+        if (std::getenv("TFC_PIPE_DEBUG")) {
+          TFC_HIP(hipStreamSynchronize(st));
+          std::vector<unsigned int> ends(groups * pa.nt), fb(64);
+          TFC_HIP(hipMemcpy(ends.data(), pa.tileend, sizeof(unsigned int) * ends.size(), hipMemcpyDeviceToHost));
+          TFC_HIP(hipMemcpy(fb.data(), pa.fallback, 256, hipMemcpyDeviceToHost));
+          std::fprintf(stderr, "[pipe enc] elems %lld streams %lld jobs %d rows %d nt %d fallback0 %u ends:", (long long)elems,
+                       (long long)streams, gn, pa.rows, pa.nt, fb[0]);
+          for (size_t i = 0; i < std::min<size_t>(ends.size(), 12); ++i) std::fprintf(stderr, " %x", ends[i]);
+          std::fprintf(stderr, "\n");
+        }
+      }
       const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
-      if (indexed) hipLaunchKernelGGL((enc_lanes_kernel<true, Src>), grid, dim3(block), lds_bytes, st, jobs, la);
+      if (pipe && !pipe_fallback_launch()) {}
+      else if (indexed) hipLaunchKernelGGL((enc_lanes_kernel<true, Src>), grid, dim3(block), lds_bytes, st, jobs, la);
       else hipLaunchKernelGGL((enc_lanes_kernel<false, Src>), grid, dim3(block), lds_bytes, st, jobs, la);
+      // `temp` goes back to the library's cache in stream order, behind these launches
     }
     hipLaunchKernelGGL((enc_error_kernel<Src>), dim3(1), dim3(64), 0, st, errs);
     TFC_HIP(hipGetLastError());
@@ -1769,7 +1875,8 @@ int run_encode(tfc_encoder* e, const int32_t* index, int64_t elems, const Src& s
   if (e->family == kLanes && elems >= (int64_t{1} << 29)) return fail("encode call too large for this handle");
   if (e->family == kLanes) {
     if constexpr (!is_plain_symbols<Src>::value) {
-      if (!index) return encode_lanes_prequantized(&e, 1, &src, elems, st);
+      // (the pipelined kernels quantise in their expansion pass)
+      if (!index && !pipe_enabled()) return encode_lanes_prequantized(&e, 1, &src, elems, st);
     }
     return encode_lanes_many(&e, 1, &src, &index, elems, st, false);
   }
@@ -2125,7 +2232,11 @@ int encode_quantized_many(int n, tfc_encoder* const* es, const void* const* ys, 
       es[g0 + k]->elems_last = elems;
       es[g0 + k]->indexed_last = false;
     }
-    if (encode_lanes_prequantized(es + g0, gn, srcs.data() + g0, elems, st)) return 1;
+    if (pipe_enabled()) {
+      if (encode_lanes_many(es + g0, gn, srcs.data() + g0, static_cast<const int32_t* const*>(nullptr), elems, st, false)) return 1;
+    } else if (encode_lanes_prequantized(es + g0, gn, srcs.data() + g0, elems, st)) {
+      return 1;
+    }
   }
   return 0;
 }
@@ -2443,7 +2554,9 @@ extern "C" int tfc_decoder_set_mode(tfc_decoder* d, int mode) {
 namespace {
 
 // Lane-per-stream family: n handles (same tables, same stream count) decoded by one launch per
-// kMaxLaneJobs of them.
+// kMaxLaneJobs of them.  Where the geometry allows, the pipelined kernels of range_pipe.h take the launch (chain into
+// raw rows, then the parallel parse into `dsts`) and the lane-per-stream kernel behind them only decodes the jobs
+// they gave up on.
 template <typename Dst>
 int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int32_t* const* indexes,
                       int64_t elems, hipStream_t st) {
@@ -2458,6 +2571,7 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   la.precision = t->lane_precision;
   la.cap = 0;
   la.defer = lanes_escape_defer();
+  la.guard = nullptr;
   la.lds_image = (t->lane_dec_bytes + 1023) & ~1023;
   using WaveLds = DecWaveLds<typename Dst::elem>;
   la.lds_wave = indexed ? WaveLds::kBytes : WaveLds::kIndex;
@@ -2466,8 +2580,31 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   const void* fn = indexed ? reinterpret_cast<const void*>(&dec_lanes_kernel<true, Dst>)
                            : reinterpret_cast<const void*>(&dec_lanes_kernel<false, Dst>);
   TFC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-  for (int g0 = 0; g0 < n; g0 += kMaxLaneJobs) {
-    const int gn = std::min(kMaxLaneJobs, n - g0);
+  // pipelined launch plan: groups of 64 streams; rows = steps of the chain (one per element, plus the bits of
+  // escape codes: a quarter more is planned for when the tables have escape rows)
+  PipeDecArgs pa;
+  LaneArgs pla = la;
+  pa.groups_per_job = static_cast<int>(ceil_div(streams, 64));
+  const int64_t rows64 = ((elems + (t->any_escape ? elems / 4 + 64 : 0)) + kPipeBlock - 1) / kPipeBlock * kPipeBlock;
+  pa.rows = static_cast<int>(std::min<int64_t>(rows64, (int64_t{1} << 30)));
+  const size_t raw_bytes = static_cast<size_t>(pa.rows) * 256;
+  const size_t rec_bytes = (static_cast<size_t>(pa.rows) / kPipeBlock + 1) * 256;
+  const size_t group_bytes = raw_bytes + rec_bytes + 64 * sizeof(uint4) + sizeof(unsigned int);
+  const size_t job_bytes = group_bytes * pa.groups_per_job + (indexed ? 2 * static_cast<size_t>(streams) * elems : 0);
+  pla.lds_wave = indexed ? PipeDecLds::kBytes : PipeDecLds::kRows;
+  const int pblock = std::min(lanes_block(streams * n), 64 * std::max(0, (160 * 1024 - pla.lds_image) / pla.lds_wave));
+  const bool pipe = pipe_enabled() && pblock >= 64 && rows64 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
+                    (!indexed || la.ntab < 4096) &&
+                    (static_cast<int64_t>(pa.rows) / kParseRows + 1) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
+  const int per_launch = !pipe ? kMaxLaneJobs
+                               : static_cast<int>(std::max<size_t>(1, std::min<size_t>(kMaxLaneJobs, kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
+  const int plds = pla.lds_image + (pblock / 64) * pla.lds_wave;
+  if (pipe) {
+    const void* pfn = indexed ? reinterpret_cast<const void*>(&dec_chain_kernel<true>) : reinterpret_cast<const void*>(&dec_chain_kernel<false>);
+    TFC_HIP(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+  }
+  for (int g0 = 0; g0 < n; g0 += per_launch) {
+    const int gn = std::min(per_launch, n - g0);
     DecLaneJobs<Dst> jobs;
     jobs.streams = streams;
     jobs.elems = elems;
@@ -2485,8 +2622,55 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
       J.first_error = d->status.as<unsigned long long>();
     }
     KernelTimer timer("dec_kernel", st);
+    DevBuf temp;
+    if (pipe) {
+      const size_t groups = static_cast<size_t>(pa.groups_per_job) * gn;
+      const size_t raw_all = raw_bytes * groups, rec_all = rec_bytes * groups, st_all = 64 * sizeof(uint4) * groups;
+      const size_t kend_all = (sizeof(unsigned int) * groups + 255) & ~size_t{255};
+      const size_t addr_all = indexed ? ((2 * static_cast<size_t>(streams) * elems * gn + 255) & ~size_t{255}) : 0;
+      TFC_HIP(temp.alloc(raw_all + rec_all + st_all + kend_all + addr_all + 256, st));
+      uint8_t* base = temp.as<uint8_t>();
+      pa.raw = reinterpret_cast<unsigned int*>(base);
+      pa.posrec = reinterpret_cast<unsigned int*>(base + raw_all);
+      pa.state_out = reinterpret_cast<uint4*>(base + raw_all + rec_all);
+      pa.kend = reinterpret_cast<unsigned int*>(base + raw_all + rec_all + st_all);
+      unsigned short* rowaddr = reinterpret_cast<unsigned short*>(base + raw_all + rec_all + st_all + kend_all);
+      pa.rowaddr = rowaddr;
+      pa.fallback = reinterpret_cast<unsigned int*>(base + raw_all + rec_all + st_all + kend_all + addr_all);
+      // (kend of a group the chain gave up on stays unset: the parse skips the whole job under its fallback flag)
+      TFC_HIP(hipMemsetAsync(pa.fallback, 0, 256, st));
+      PipeDecJobs cj;
+      cj.streams = streams;
+      cj.elems = elems;
+      cj.blocks_per_job = static_cast<int>(ceil_div(pa.groups_per_job, pblock / 64));
+      cj.n = gn;
+      for (int k = 0; k < gn; ++k) cj.job[k] = PipeDecJob{jobs.job[k].blob, jobs.job[k].off, jobs.job[k].state};
+      if (indexed) {
+        PipeRowJobs rj;
+        rj.per_job = streams * elems;
+        rj.ntab = la.ntab;
+        rj.n = gn;
+        for (int k = 0; k < gn; ++k) { rj.job[k].index = jobs.job[k].index; rj.job[k].first_error = jobs.job[k].first_error; }
+        hipLaunchKernelGGL(dec_rows_kernel, dim3(static_cast<unsigned>(ceil_div(rj.per_job, 1024)), static_cast<unsigned>(gn)),
+                           dim3(256), 0, st, rj, rowaddr);
+      }
+      const dim3 cgrid(static_cast<unsigned>(cj.blocks_per_job * gn));
+      const dim3 pgrid(static_cast<unsigned>(groups * (static_cast<size_t>(pa.rows) / kParseRows + 1)));
+      {
+        KernelTimer t2("dec_chain", st);
+        if (indexed) hipLaunchKernelGGL((dec_chain_kernel<true>), cgrid, dim3(pblock), plds, st, cj, pla, pa);
+        else hipLaunchKernelGGL((dec_chain_kernel<false>), cgrid, dim3(pblock), plds, st, cj, pla, pa);
+      }
+      {
+        KernelTimer t2("dec_parse", st);
+        if (indexed) hipLaunchKernelGGL((dec_parse_kernel<true, Dst>), pgrid, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
+        else hipLaunchKernelGGL((dec_parse_kernel<false, Dst>), pgrid, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
+      }
+      la.guard = pa.fallback;
+    }
     const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
-    if (indexed) hipLaunchKernelGGL((dec_lanes_kernel<true, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
+    if (pipe && !pipe_fallback_launch()) {}
+    else if (indexed) hipLaunchKernelGGL((dec_lanes_kernel<true, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
     else hipLaunchKernelGGL((dec_lanes_kernel<false, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
   }
   TFC_HIP(hipGetLastError());
@@ -2553,7 +2737,8 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   d->family = family;
   if (family == kLanes) {
     if constexpr (!std::is_same<Dst, OutInt32>::value) {
-      if (!index) return decode_lanes_dequantized(&d, 1, &dst, elems, st);
+      // (the pipelined kernels dequantise in their parse pass)
+      if (!index && !pipe_enabled()) return decode_lanes_dequantized(&d, 1, &dst, elems, st);
     }
     return decode_lanes_many(&d, 1, &dst, &index, elems, st);
   } else if (family == kFast) {
@@ -2651,7 +2836,11 @@ int decode_dequantized_many(int n, tfc_decoder* const* ds, void* const* ys, cons
   }
   for (int g0 = 0; g0 < n; g0 += kMaxFinalizeJobs) {
     const int gn = std::min(kMaxFinalizeJobs, n - g0);
-    if (decode_lanes_dequantized(ds + g0, gn, dsts.data() + g0, elems, st)) return 1;
+    if (pipe_enabled()) {
+      if (decode_lanes_many(ds + g0, gn, dsts.data() + g0, static_cast<const int32_t* const*>(nullptr), elems, st)) return 1;
+    } else if (decode_lanes_dequantized(ds + g0, gn, dsts.data() + g0, elems, st)) {
+      return 1;
+    }
   }
   return 0;
 }

@@ -69,6 +69,7 @@ struct LaneArgs {
   int lds_image;               // LDS bytes reserved for the image (multiple of 1024)
   int lds_wave;                // LDS bytes of every wave's private area behind it
   int defer;                   // blocks a wave may run with lanes parked in front of an escape before it codes them
+  const unsigned int* guard;   // null, or one flag per job: the job is coded only if its flag is set (fallback of range_pipe.h)
 };
 
 __device__ inline void lanes_load_image(unsigned char* lds, const LaneArgs& a) {
@@ -395,6 +396,7 @@ struct EncWaveLds {
 template <bool INDEXED, typename Src>
 __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> jobs, LaneArgs la) {
   extern __shared__ unsigned char lanes_lds[];
+  if (la.guard && la.guard[blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job)] == 0u) return;
   lanes_load_image(lanes_lds, la);
   using Raw = typename Src::raw_type;
   using L = EncWaveLds<Raw>;
@@ -885,6 +887,7 @@ struct DecWaveLds {
 template <bool INDEXED, typename Dst>
 __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> jobs, LaneArgs la) {
   extern __shared__ unsigned char lanes_lds[];
+  if (la.guard && la.guard[blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job)] == 0u) return;
   lanes_load_image(lanes_lds, la);
   using Elem = typename Dst::elem;
   using L = DecWaveLds<Elem>;

@@ -1,0 +1,871 @@
+// Pipelined lane-per-stream range coder for gfx950 — included by range_coder.hip behind range_lanes.h.
+//
+// range_lanes.h gives every LANE a stream, so the time of a launch is (symbols per stream) x (cycles of one
+// step of a lone wave) whatever the number of streams: everything a step does costs chain latency, and with
+// BASELINE config 2 (20 x 512 streams = 160 waves) 85 % of the chip's SIMDs hold no wave at all.  Here the
+// work of a step that is NOT on the chain leaves the chain wave and runs chip-wide in kernels of its own:
+//
+//   encode   enc_expand_kernel   parallel over symbols: quantise, table index, row lookup, range check, escape
+//                                codes expanded into their binary calls -> one 32-bit CALL WORD per coder call
+//                                (lo | hi << 16 on the 2^16 scale), laid out [tile][row][lane] so that the
+//                                chain wave reads row k of all its 64 streams with ONE coalesced load
+//            enc_chain_kernel    lane per stream: RangeEncoder::Encode (cc/lib/range_coder.cc:37-264) on the
+//                                call words — interval update + held-digit bookkeeping of range_lanes.h's block,
+//                                no table, no value window, no escape logic (an escape is just more rows)
+//   decode   dec_rows_kernel     (index mode) table index -> LDS address of its row, range-checked
+//            dec_chain_kernel    lane per stream: RangeDecoder::Decode (cc/lib/range_coder.h:224-271) with the
+//                                quotient-estimate / bitmap-rank step of range_lanes.h; the Elias-gamma bits of
+//                                an escape (cc/kernels/range_coder_kernels.cc:449-471) are ordinary steps on a
+//                                built-in binary row, selected per lane by a small mode counter M — a lane that
+//                                meets an escape falls a few steps behind its neighbours and nobody waits;
+//                                every step's raw result goes to [row][lane] with one coalesced store
+//            dec_parse_kernel    parallel over rows: transposes the raw results back to [stream][element],
+//                                assembles escape values from their bit rows, adds cdf_offset / dequantises
+//
+// The lanes of a wave advance in lockstep over ROWS (coder calls), not over symbols: a stream with an escape
+// simply has more rows.  The encoder re-aligns its 64 streams at every tile of kPipeTile symbols (the rows of
+// a tile start at row 0 for every lane; lanes with fewer calls sit out the tile's last rows under EXEC).
+//
+// Bytes and symbols are the reference's: the chain arithmetic is the one range_lanes.h already runs (tests
+// parametrise over both families), the expansion restates classify_fast() / escape_calls().
+// When the pipelined kernels cannot take a job (more escape codes in one tile than they plan for, a decoder
+// that runs out of rows) they raise the job's fallback flag and leave its state untouched; the lane-per-stream
+// kernel of range_lanes.h is launched behind them under that flag (LaneArgs::guard) and codes the job.
+#pragma once
+
+namespace tfc {
+
+constexpr int kPipeTile = 256;        // symbols of a stream per expansion workgroup
+constexpr int kPipeEscMax = 64;       // escape codes per stream and tile the expansion plans for
+constexpr unsigned int kPipeBlock = 16;          // rows per hand-scheduled block of the chain kernels
+// A call word that no table produces (lower bound 0xFFFF above upper bound 1): "this lane has no call in this row"
+constexpr unsigned int kPipeNoCall = 0x0001FFFFu;
+constexpr unsigned int kPipeReady = 0x80000000u;
+
+struct PipeEncArgs {
+  const uint16_t* fast16;       // tables scaled to 16 bits (tfc_tables::d_fast)
+  const int2* rows_fast;        // (offset, length | escape row << 31) per table
+  int ntab;
+  unsigned int* calls;          // [group][row][lane]; a lane without a call in a row holds kPipeNoCall there
+  unsigned int* tileend;        // [group][tile]: kPipeReady | first row behind the tile (0: not yet known)
+  unsigned int* fallback;       // [job]
+  int nt;                       // tiles per stream
+  int rows;                     // row capacity of a group
+  int groups_per_job;           // groups of 64 streams per job
+  int groups;                   // of the launch
+  unsigned int cap;             // slab bytes per stream (chain kernel)
+};
+
+// ---------------------------------------------------------------------------------------------
+// Encoder, stage 1: symbols -> call words
+// ---------------------------------------------------------------------------------------------
+
+// Number of extra (binary) calls of an escape code and its k-th call word, k = 1 ... extra
+// (range_coder_kernels.cc:304-321: floor(log2 g) zeros, the bits of g, the sign; each a call on the uniform
+// binary cdf at precision 1 = [0, 2^15) or [2^15, 2^16) on the 2^16 scale).
+__device__ inline unsigned int pipe_escape_extra(unsigned int g) { return 2u * static_cast<unsigned int>(31 - __clz(static_cast<int>(g))) + 2u; }
+__device__ inline unsigned int pipe_escape_word(unsigned int g, unsigned int neg, unsigned int extra, unsigned int k) {
+  const unsigned int left = extra - k;            // calls still to come behind this one
+  const unsigned int sft = left - 1u;
+  const unsigned int bit = left == 0u ? neg : (sft < 32u ? (g >> sft) & 1u : 0u);
+  return bit ? 0x00008000u : 0x80000000u;         // lo | hi << 16, hi = 2^16 stored as 0
+}
+
+// One workgroup per (tile of kPipeTile symbols, group of 64 streams); blockIdx = tile * groups + group, so that the
+// tiles of one group are dispatched in order and far apart.  The rows of a tile start at the same row for all 64
+// lanes (the chain wave reads row k of every lane with one load) and take as many rows as its longest lane has calls,
+// rounded up to whole blocks; where a tile starts is the sum over the tiles before it — a chained look-back over the
+// group's tiles (each workgroup publishes its end row once it has counted its calls, and needs its predecessor's
+// only when it starts writing).
+template <bool INDEXED, typename Src>
+__global__ void __launch_bounds__(256) enc_expand_kernel(const EncLaneJobs<Src> jobs, const PipeEncArgs pa) {
+  constexpr int kRow = kPipeTile + 1;                     // padded: the transposed reads of phase C hit 64 banks
+  __shared__ unsigned int W[64 * kRow];                   // call word of every (stream, symbol) of the tile
+  __shared__ unsigned int escmask[64][kPipeTile / 32];    // symbols that take an escape code
+  __shared__ unsigned short esc[64][kPipeEscMax];         // per stream, in order: position | neg << 8 | extra calls << 9
+  __shared__ unsigned int cnt[64], nesc[64], tmax, tstart;
+
+  const unsigned int gi = blockIdx.x % static_cast<unsigned int>(pa.groups);
+  const unsigned int T = blockIdx.x / static_cast<unsigned int>(pa.groups);
+  const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
+  const unsigned int gidx = gi % static_cast<unsigned int>(pa.groups_per_job);
+  const EncLaneJob<Src>& J = jobs.job[job];
+  const Src src = J.src;
+  const int32_t* const index = J.index;
+  const unsigned int tid = threadIdx.x;
+  const unsigned int elems = static_cast<unsigned int>(jobs.elems);
+  const int64_t s0 = static_cast<int64_t>(gidx) * 64;
+  const unsigned int j = T * kPipeTile + tid;             // this thread's symbol of every stream
+  const unsigned int ntab = static_cast<unsigned int>(pa.ntab);
+
+  for (unsigned int i = tid; i < 64u * (kPipeTile / 32); i += 256u) (&escmask[0][0])[i] = 0u;
+  if (tid == 0) tmax = 0u;
+  __syncthreads();
+
+  // table and value of symbol `at` of stream s (phases B and C look again at the few symbols with escape codes)
+  auto escape_of = [&](int64_t s, unsigned int at, unsigned int& g, unsigned int& neg) {
+    const int64_t pos = s * jobs.elems + at;
+    int t = static_cast<int>(at % ntab);
+    if (INDEXED) {
+      t = index[pos];
+      if (t < 0 || t >= pa.ntab) t = 0;
+    }
+    const int2 row = pa.rows_fast[t];
+    const int32_t v = src.load(pos, t);
+    const int32_t vmax = (row.y & 0x7FFFFFFF) - 3;
+    neg = v < 0 ? 1u : 0u;
+    g = v < 0 ? 0u - static_cast<unsigned int>(v) : static_cast<unsigned int>(v - vmax) + 1u;
+  };
+
+  // ---- phase A: one call word per symbol (an escape: the word of its row's escape symbol) -------------
+  const int tch = static_cast<int>(j % ntab);
+#pragma unroll 4
+  for (int sl = 0; sl < 64; ++sl) {
+    const int64_t s = s0 + sl;
+    unsigned int w = 0u;
+    if (s < jobs.streams && j < elems) {
+      const int64_t pos = s * jobs.elems + j;
+      int t = tch;
+      bool bad = false;
+      if (INDEXED) {
+        t = index[pos];
+        if (t < 0 || t >= pa.ntab) { bad = true; t = 0; }
+      }
+      const int2 row = pa.rows_fast[t];
+      const Call c = classify_fast(pa.fast16, row, src.load(pos, t));
+      if (bad || c.bad) atomicMin(J.first_error, static_cast<unsigned long long>(pos));
+      w = (static_cast<unsigned int>(c.lo16) & 0xFFFFu) | (static_cast<unsigned int>(c.hi16) << 16);
+      if (c.gamma) atomicOr(&escmask[sl][tid >> 5], 1u << (tid & 31u));
+    }
+    W[sl * kRow + tid] = w;
+  }
+  __syncthreads();
+
+  // ---- phase B: a thread per stream lists its escape codes in order ------------------------------------
+  if (tid < 64u) {
+    const int64_t s = s0 + tid;
+    unsigned int n = 0u, cum = 0u, valid = 0u;
+    bool over = false;
+    if (s < jobs.streams && T * kPipeTile < elems) {
+      valid = min(static_cast<unsigned int>(kPipeTile), elems - T * kPipeTile);
+      for (unsigned int wd = 0; wd < kPipeTile / 32; ++wd) {
+        unsigned int m = escmask[tid][wd];
+        while (m) {
+          const unsigned int e = 32u * wd + static_cast<unsigned int>(__ffs(static_cast<int>(m)) - 1);
+          m &= m - 1u;
+          unsigned int g, neg;
+          escape_of(s, T * kPipeTile + e, g, neg);
+          const unsigned int extra = pipe_escape_extra(g);
+          if (n < static_cast<unsigned int>(kPipeEscMax)) {
+            esc[tid][n] = static_cast<unsigned short>(e | (neg << 8) | (extra << 9));
+            cum += extra;
+            ++n;
+          } else {
+            over = true;
+          }
+        }
+      }
+    }
+    if (over) {
+      atomicOr(&pa.fallback[job], 1u);
+      n = 0u;
+      cum = 0u;
+    }
+    cnt[tid] = valid + cum;
+    nesc[tid] = n;
+    atomicMax(&tmax, valid + cum);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // first row of this tile = end of the tile before it (published by that workgroup; dispatched before this one)
+    unsigned int start = 0u;
+    unsigned int* const ends = pa.tileend + static_cast<size_t>(gi) * pa.nt;
+    if (T > 0u) {
+      unsigned int v;
+      do {
+        v = __hip_atomic_load(&ends[T - 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((v & kPipeReady) == 0u);
+      start = v & ~kPipeReady;
+    }
+    unsigned int end = start + ((tmax + kPipeBlock - 1u) & ~(kPipeBlock - 1u));
+    if (end > static_cast<unsigned int>(pa.rows)) {
+      // more rows than the launch planned for (escape codes far beyond the tables' tail mass): this job is left
+      // to the lane-per-stream kernel; the tiles behind still get a consistent (empty) position
+      atomicOr(&pa.fallback[job], 1u);
+      end = start;
+    }
+    __hip_atomic_store(&ends[T], end | kPipeReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    tstart = end == start ? 0xFFFFFFFFu : start;
+  }
+  __syncthreads();
+  if (tstart == 0xFFFFFFFFu) return;
+
+  // ---- phase C: rows out, transposed: thread (r, l) writes rows r, r + 4, ... of lane l; rows behind a lane's
+  // last call, up to the next whole block, hold "no call" --------------------------------------------------
+  {
+    const unsigned int l = tid & 63u;
+    const unsigned int mx = (tmax + kPipeBlock - 1u) & ~(kPipeBlock - 1u), mine = cnt[l], ne = nesc[l];
+    unsigned int* const out = pa.calls + (static_cast<size_t>(gi) * pa.rows + tstart) * 64 + l;
+    unsigned int i = 0u;                  // first escape code whose rows do not all lie before row r
+    unsigned int start = 0u, extra = 0u, cumi = 0u, epos = 0u, neg = 0u;
+    auto fetch = [&]() {
+      if (i < ne) {
+        const unsigned int e = esc[l][i];
+        epos = e & 0xFFu;
+        neg = (e >> 8) & 1u;
+        extra = e >> 9;
+        start = epos + cumi;              // row of the escape symbol's own call; its bits: the `extra` rows behind it
+      }
+    };
+    fetch();
+    for (unsigned int r = tid >> 6; r < mx; r += 4u) {
+      unsigned int w = kPipeNoCall;
+      if (r < mine) {
+        while (i < ne && r > start + extra) {
+          cumi += extra;
+          ++i;
+          fetch();
+        }
+        if (i < ne && r > start) {
+          unsigned int g, ng;
+          escape_of(s0 + l, T * kPipeTile + epos, g, ng);
+          w = pipe_escape_word(g, neg, extra, r - start);
+        } else {
+          w = W[l * kRow + (r - cumi)];
+        }
+      }
+      out[static_cast<size_t>(r) * 64] = w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder, stage 2: the chain
+// ---------------------------------------------------------------------------------------------
+
+// One row: a lane whose word is "no call" leaves EXEC for the rest of the block (tiles are whole blocks and a lane's
+// calls are the first rows of its tile, so nothing follows a "no call" inside a block); the call word is unpacked
+// into the (lo, 0) / (hi, 0) register pairs TFC_LENC_B multiplies from.
+#define TFC_PENC_STEP(W)                                                                   \
+  "v_cmpx_ne_u32 vcc, %[NOCALL], %[" #W "]\n\t"                                            \
+  "v_and_b32 v152, %[KFFFF], %[" #W "]\n\t"                                                \
+  "v_lshrrev_b32 v154, 16, %[" #W "]\n\t"                                                  \
+  TFC_LENC_B(152, 153, 154, 155, "")
+
+struct PipeChainJob { uint4* state; uint8_t* chunk; unsigned int* chunk_len; unsigned int* overflow_flag; };
+struct PipeChainJobs {
+  int64_t streams;
+  PipeChainJob job[64];
+};
+
+__global__ void __launch_bounds__(64) enc_chain_kernel(const PipeChainJobs jobs, const PipeEncArgs pa) {
+  constexpr int kStride = lane_stride(kEncDigitBytes + 8);
+  __shared__ __attribute__((aligned(16))) unsigned char stage[64 * kStride];
+
+  const unsigned int gi = blockIdx.x;
+  const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
+  const unsigned int gidx = gi % static_cast<unsigned int>(pa.groups_per_job);
+  if (pa.fallback[job] != 0u) return;
+  const PipeChainJob& J = jobs.job[job];
+  const unsigned int lane = threadIdx.x;
+  const int64_t s = static_cast<int64_t>(gidx) * 64 + lane;
+  const bool live = s < jobs.streams;
+
+  uint4 st = live ? J.state[s] : make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
+  unsigned int base = st.x, s1 = st.y, hd = st.z & 0xFFFFu, had = st.z >> 31, rn = st.w;
+  lanes_pin(base, s1, hd, rn);
+
+  const unsigned int ds_off = static_cast<unsigned int>(reinterpret_cast<size_t>(
+                                  (__attribute__((address_space(3))) unsigned char*)stage)) + kStride * lane;
+  unsigned char* const dstage = stage + kStride * lane;
+  unsigned char* const out = J.chunk + (live ? s : 0) * static_cast<int64_t>(pa.cap);
+  unsigned int wpos = 0u, n = 0u, overflow = 0u;
+
+  auto put = [&](unsigned int d, bool on) {
+    *reinterpret_cast<unsigned short*>(dstage + n) = __builtin_bswap16(static_cast<unsigned short>(d));
+    n += on ? 2u : 0u;
+  };
+  auto flush = [&]() {
+#pragma unroll
+    for (unsigned int c = 0; c < kEncDigitBytes / 16u; ++c) {
+      if (16u * c < n) {
+        uint2 v[2];
+        v[0] = reinterpret_cast<const uint2*>(dstage)[2 * c];
+        v[1] = reinterpret_cast<const uint2*>(dstage)[2 * c + 1];
+        if (wpos + 16u * c + 16u <= pa.cap) lanes_gstore16(out + wpos + 16u * c, v[0], v[1]);
+        else overflow = 1u;
+      }
+    }
+    wpos += n;
+    n = 0u;
+  };
+  auto put_run = [&](unsigned int fill, unsigned int bytes) {
+    flush();
+    for (unsigned int k = 0; k < bytes; k += 2u) {
+      const unsigned short be = static_cast<unsigned short>(fill);
+      if (wpos + 2u <= pa.cap) lanes_gstore_elem(reinterpret_cast<unsigned short*>(out + wpos), be);
+      else overflow = 1u;
+      wpos += 2u;
+    }
+  };
+  // one coder call on [lo, hi) / 2^16 for the lanes with `act` — the generic call of range_lanes.h
+  // (enc_lanes_kernel::call), every case of the held-digit bookkeeping
+  auto call = [&](unsigned int lo, unsigned int hi, bool act) __attribute__((always_inline)) {
+    const unsigned int a = scale16(s1, lo);
+    const unsigned int b = scale16(s1, hi) - 1u;
+    const unsigned int bs = base + a;
+    const unsigned int t1 = b - a;
+    const bool carry = act && bs < a;
+    const bool ren = act && (t1 >> 16) == 0u;
+    const unsigned int e = bs >> 16;
+    const bool solid = ren && e != 0xFFFFu;
+    const bool ffff = ren && e == 0xFFFFu;
+    const bool held = had != 0u;
+    const unsigned int X = (hd + (carry ? 1u : 0u)) & 0xFFFFu;
+    const bool emit = held && (solid || (carry && (!ffff || rn != 0u)));
+    put(X, emit);
+    const unsigned int run_out = !held ? 0u : solid ? rn : (carry && rn != 0u) ? (ffff ? rn - 1u : rn) : 0u;
+    if (__any(run_out != 0u)) {
+      if (run_out != 0u) put_run(carry ? 0u : 0xFFFFu, 2u * run_out);
+    }
+    if (solid) {
+      hd = e; had = 1u; rn = 0u;
+    } else if (ffff) {
+      if (!held) { hd = 0xFFFFu; had = 1u; rn = 0u; }
+      else if (!carry) { rn += 1u; }
+      else if (rn == 0u) { hd = X; rn = 1u; }
+      else { hd = 0u; rn = 1u; }
+    } else if (carry && held) {
+      had = 0u; rn = 0u;
+    }
+    base = act ? (ren ? bs << 16 : bs) : base;
+    s1 = act ? (ren ? (t1 << 16) | 0xFFFFu : t1) : s1;
+  };
+
+  const unsigned int* const calls = pa.calls + static_cast<size_t>(gi) * pa.rows * 64 + lane;
+  // rows of the group: the end of its last tile (whole blocks)
+  const unsigned int nb = (__builtin_amdgcn_readfirstlane(pa.tileend[static_cast<size_t>(gi) * pa.nt + pa.nt - 1]) & ~kPipeReady) / kPipeBlock;
+
+  // The rows of block b.  Requested a whole block before they are used, and taken over (`w = wn`) in front of the
+  // iteration's own loads and stores: hipcc turns any wait for a load into s_waitcnt vmcnt(0) while a store may be
+  // in flight (gfx9 counts both on vmcnt), so the one wait of an iteration has to sit where everything in flight
+  // is a block old.
+  unsigned int w[kPipeBlock] = {}, wn[kPipeBlock] = {};
+  auto load_block = [&](unsigned int b) {
+    const unsigned int* p = calls + static_cast<size_t>(b) * (kPipeBlock * 64u);
+#pragma unroll
+    for (unsigned int k = 0; k < kPipeBlock; ++k) wn[k] = p[k * 64u];
+  };
+
+  if (nb) load_block(0u);
+  // (waited for here: a value that may still be in flight when the loop is entered would put a wait in front of
+  // the block in every iteration)
+  asm volatile("" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(wn[4]), "+v"(wn[5]), "+v"(wn[6]), "+v"(wn[7]),
+                    "+v"(wn[8]), "+v"(wn[9]), "+v"(wn[10]), "+v"(wn[11]), "+v"(wn[12]), "+v"(wn[13]), "+v"(wn[14]), "+v"(wn[15]));
+  for (unsigned int b = 0; b < nb; ++b) {
+#pragma unroll
+    for (unsigned int k = 0; k < kPipeBlock; ++k) w[k] = wn[k];
+    load_block(b + 1u);           // (one block of rows is allocated behind the group's last)
+    flush();                      // the digits of the block before this one
+    const unsigned int base0 = base, s10 = s1, hd0 = hd, had0 = had;
+    unsigned int flag = rn, na = ds_off;
+    asm volatile(
+        "s_mov_b64 s[56:57], exec\n\t"
+        "v_mov_b32 v153, 0\n\tv_mov_b32 v155, 0\n\t"
+        TFC_PENC_STEP(W0) TFC_PENC_STEP(W1) TFC_PENC_STEP(W2) TFC_PENC_STEP(W3)
+        TFC_PENC_STEP(W4) TFC_PENC_STEP(W5) TFC_PENC_STEP(W6) TFC_PENC_STEP(W7)
+        TFC_PENC_STEP(W8) TFC_PENC_STEP(W9) TFC_PENC_STEP(W10) TFC_PENC_STEP(W11)
+        TFC_PENC_STEP(W12) TFC_PENC_STEP(W13) TFC_PENC_STEP(W14) TFC_PENC_STEP(W15)
+        "s_mov_b64 exec, s[56:57]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na), [FLAG] "+v"(flag)
+        : [NOCALL] "s"(kPipeNoCall), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u),
+          [W0] "v"(w[0]), [W1] "v"(w[1]), [W2] "v"(w[2]), [W3] "v"(w[3]), [W4] "v"(w[4]), [W5] "v"(w[5]),
+          [W6] "v"(w[6]), [W7] "v"(w[7]), [W8] "v"(w[8]), [W9] "v"(w[9]), [W10] "v"(w[10]), [W11] "v"(w[11]),
+          [W12] "v"(w[12]), [W13] "v"(w[13]), [W14] "v"(w[14]), [W15] "v"(w[15])
+        : "vcc", "memory", "s52", "s53", "s56", "s57", "v152", "v153", "v154", "v155", "v160", "v161", "v162", "v163",
+          "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v173", "v174", "v175");
+    if (__builtin_expect(!__any(flag != 0u), 1)) {
+      n = na - ds_off;
+    } else {
+      // a digit 0xFFFF was shifted out (it opens a run a later carry may ripple through), or a lane came
+      // in inside such a run: the block again from the saved state, call by call
+      base = base0; s1 = s10; hd = hd0; had = had0;
+#pragma nounroll
+      for (unsigned int k = 0; k < kPipeBlock; ++k) {
+        unsigned int word = w[0];
+#pragma unroll
+        for (unsigned int q = 1; q < kPipeBlock; ++q) word = k == q ? w[q] : word;
+        const unsigned int hi = word >> 16;
+        call(word & 0xFFFFu, hi == 0u ? 65536u : hi, word != kPipeNoCall);
+      }
+    }
+  }
+  flush();
+  if (live) {
+    J.state[s] = make_uint4(base, s1, (hd & 0xFFFFu) | (had << 31), rn);
+    J.chunk_len[s] = wpos;
+    if (overflow) atomicOr(J.overflow_flag, 1u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoder
+// ---------------------------------------------------------------------------------------------
+
+struct PipeDecArgs {
+  unsigned int* raw;             // [group][row][lane]: symbol | M << 16 of every step (M: see dec_chain_kernel)
+  unsigned int* posrec;          // [group][block + 1][lane]: elements started before the block
+  unsigned int* kend;            // [group]: rows written (a multiple of kPipeBlock)
+  uint4* state_out;              // [group][lane]: successor state, committed by dec_parse_kernel
+  const unsigned short* rowaddr; // index mode: [job][stream][element] LDS address of the element's directory entry
+  unsigned int* fallback;        // [job]
+  int rows;                      // row capacity of a group (multiple of kPipeBlock)
+  int groups_per_job;
+};
+struct PipeDecJob { const uint8_t* blob; const long long* off; const uint4* state; };
+struct PipeDecJobs {
+  int64_t streams, elems;
+  int blocks_per_job, n;
+  PipeDecJob job[64];
+};
+
+// Index mode, stage 0: table index -> LDS address of its directory entry (16 bytes per entry, directory at
+// LDS address 0), range-checked like EntropyDecodeIndex (range_coder_kernels.cc:388-393).
+struct PipeRowJobs {
+  int64_t per_job;               // streams * elems
+  int ntab, n;
+  struct { const int32_t* index; unsigned long long* first_error; } job[64];
+};
+__global__ void __launch_bounds__(256) dec_rows_kernel(const PipeRowJobs jobs, unsigned short* rowaddr) {
+  const int k = blockIdx.y;
+  const int32_t* index = jobs.job[k].index;
+  unsigned short* out = rowaddr + static_cast<size_t>(k) * jobs.per_job;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x, e = min(jobs.per_job, (static_cast<int64_t>(blockIdx.x) + 1) * 1024);
+       i < e; i += 256) {
+    int t = index[i];
+    if (t < 0 || t >= jobs.ntab) {
+      atomicMin(jobs.job[k].first_error, static_cast<unsigned long long>(i));
+      t = 0;
+    }
+    out[i] = static_cast<unsigned short>(16 * t);
+  }
+}
+
+// LDS of one decoder wave behind the tables' image: per lane a code-byte window and (index mode) a window of
+// row addresses, two blocks' worth each (a step consumes at most one 16-bit digit and one element)
+struct PipeDecLds {
+  // (two blocks of 2-byte entries and the one entry a step requests ahead, in whole 16-byte loads)
+  static constexpr int kWords = 2 * kPipeBlock * 2 / 8 + 2;
+  static constexpr int kStride = lane_stride(8 * kWords);
+  static constexpr int kCodes = 0;
+  static constexpr int kRows = kCodes + 64 * kStride;
+  static constexpr int kBytes = kRows + 64 * kStride;
+};
+
+// ---- one decoder step of every lane, hand-scheduled -------------------------------------------------
+// The step of range_lanes.h (TFC_LDEC_STEP: quotient estimate -> rank in the row's boundary bitmap -> exact
+// bounds = verification -> successor state) on the lane's CURRENT ROW R0..R3 (cdf - 2, info, bits, cum), plus
+// the per-lane mode counter M:
+//   M = 0   the step decodes an element of the lane's table row; an escape symbol sets M = -1
+//   M < 0   unary prefix of an Elias-gamma code, -M - 1 zeros seen: a zero decrements M, a one leaves
+//           M = -M calls to go (the magnitude's lower bits, then the sign)
+//   M > 0   M binary calls to go
+// in arithmetic:  t = M - (M != 0);  u = t + (symbol & (M >> 31)) (1 - 2 M);  M' = u - [escape symbol].
+// A lane with M' = 0 has completed an element: its row pointer PW moves on and the next step's row is the one
+// requested at the top of this step; with M' != 0 the next row is the built-in binary row B0..B3.  Both LDS
+// round trips of the step are covered by this bookkeeping.  Every step stores symbol | M << 16 (M before the
+// step) to row K of the raw plane.  FLAG: the verification failed (estimate one off, ~1e-5, or damaged input);
+// MACC: min of M (31 zeros in a prefix: damaged input, the reference stops counting there) — the caller then
+// repeats the block from its saved state with the generic steps.
+// Fixed temporaries v104-v140; v123 = v125 = 0.
+#define TFC_PDEC_STEP(KOFF, TOP, MID, SEL_EARLY, SEL_LATE, PWSTEP)                         \
+  TOP                                                                                     \
+  "ds_read_u16 v109, %[CP]\n\t"                                                           \
+  "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
+  "v_cvt_f32_u32 v111, %[S]\n\t"                                                          \
+  "v_rcp_f32 v111, v111\n\t"                                                              \
+  "v_fma_f32 v110, v110, %[SCALE], %[HSCALE]\n\t"                                         \
+  "s_nop 0\n\t"                                                                           \
+  "v_mul_f32 v110, v110, v111\n\t"                                                        \
+  "v_cvt_u32_f32 v110, v110\n\t"                                                          \
+  "v_min_u32 v110, %[QMAX], v110\n\t"                                                     \
+  "v_lshrrev_b32 v111, 6, v110\n\t"                                                       \
+  "v_lshl_add_u32 v112, v111, 3, %[R2]\n\t"                                               \
+  "v_lshl_add_u32 v113, v111, 1, %[R3]\n\t"                                               \
+  "ds_read_b64 v[114:115], v112\n\t"                                                      \
+  "ds_read_i16 v116, v113\n\t"                                                            \
+  "v_not_b32 v110, v110\n\t"                                                              \
+  "v_cmp_ne_u32 vcc, 0, %[M]\n\t"                                                         \
+  "v_subbrev_co_u32 v134, vcc, 0, %[M], vcc\n\t"                                          \
+  "v_ashrrev_i32 v135, 31, %[M]\n\t"                                                      \
+  "v_mad_i32_i24 v136, %[M], -2, 1\n\t"                                                   \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                              \
+  "v_perm_b32 v109, 0, v109, %[PERM]\n\t"                                                 \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                              \
+  MID                                                                                     \
+  "v_lshlrev_b64 v[118:119], v110, v[114:115]\n\t"                                        \
+  "v_bcnt_u32_b32 v116, v118, v116\n\t"                                                   \
+  "v_bcnt_u32_b32 v117, v119, v116\n\t"                                                   \
+  "v_lshl_add_u32 v112, v117, 1, %[R0]\n\t"                                               \
+  "ds_read_u16 v122, v112 offset:2\n\t"                                                   \
+  "ds_read_u16 v124, v112 offset:4\n\t"                                                   \
+  "v_xad_u32 v113, v117, %[R1], %[K31]\n\t"                                               \
+  "v_and_b32 v137, v117, v135\n\t"                                                        \
+  "v_mad_i32_i24 v138, v137, v136, v134\n\t"                                              \
+  "v_lshl_or_b32 v139, %[M], 16, v117\n\t"                                                \
+  "global_store_dword %[VOFF], v139, %[RAW] offset:" #KOFF "\n\t"                         \
+  "v_cmp_eq_u32 vcc, 0, v113\n\t"                                                         \
+  "v_subbrev_co_u32 %[M], vcc, 0, v138, vcc\n\t"                                          \
+  "v_min_i32 %[MACC], %[MACC], %[M]\n\t"                                                  \
+  "v_cmp_eq_u32 vcc, 0, %[M]\n\t"                                                         \
+  SEL_EARLY                                                                               \
+  "v_cndmask_b32 v140, 0, " #PWSTEP ", vcc\n\t"                                           \
+  "v_add_u32 %[PW], %[PW], v140\n\t"                                                      \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                              \
+  SEL_LATE                                                                                \
+  "v_mad_u64_u32 v[126:127], s[52:53], v122, %[S], v[122:123]\n\t"                        \
+  "v_mad_u64_u32 v[128:129], s[52:53], v124, %[S], v[124:125]\n\t"                        \
+  "v_alignbit_b32 v126, v127, v126, 16\n\t"                                               \
+  "v_alignbit_b32 v128, v129, v128, 16\n\t"                                               \
+  "v_add_u32 v128, -1, v128\n\t"                                                          \
+  "v_min_u32 v128, v128, %[S]\n\t"                                                        \
+  "v_sub_u32 v130, %[D], v126\n\t"                                                        \
+  "v_sub_u32 v131, v128, v126\n\t"                                                        \
+  "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
+  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
+  "v_cmp_gt_u32 vcc, %[K64K], v131\n\t"                                                   \
+  "v_lshl_or_b32 v132, v130, 16, v109\n\t"                                                \
+  "v_cndmask_b32 %[D], v130, v132, vcc\n\t"                                               \
+  "v_lshl_or_b32 v132, v131, 16, %[KFFFF]\n\t"                                            \
+  "v_cndmask_b32 %[S], v131, v132, vcc\n\t"                                               \
+  "v_cndmask_b32 v132, 0, 2, vcc\n\t"                                                     \
+  "v_add_u32 %[CP], %[CP], v132\n\t"
+#define TFC_PDEC_SELECT                                                                   \
+  "v_cndmask_b32 %[R0], %[B0], v104, vcc\n\t"                                             \
+  "v_cndmask_b32 %[R1], %[B1], v105, vcc\n\t"                                             \
+  "v_cndmask_b32 %[R2], %[B2], v106, vcc\n\t"                                             \
+  "v_cndmask_b32 %[R3], %[B3], v107, vcc\n\t"
+// channel mode: the next directory entry is requested at the top of the step; index mode: the next element's row
+// address there, the entry itself once the address has arrived, and the select waits for it
+#define TFC_PDEC_STEP_CH(KOFF) TFC_PDEC_STEP(KOFF, "ds_read_b128 v[104:107], %[PW] offset:16\n\t", "", TFC_PDEC_SELECT, "", 16)
+#define TFC_PDEC_STEP_IX(KOFF) TFC_PDEC_STEP(KOFF, "ds_read_u16 v108, %[PW] offset:2\n\t", "ds_read_b128 v[104:107], v108\n\t", "", TFC_PDEC_SELECT, 2)
+#define TFC_PDEC_BLOCK(STEP)                                                              \
+  "v_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t"                                           \
+  STEP(0) STEP(256) STEP(512) STEP(768) STEP(1024) STEP(1280) STEP(1536) STEP(1792)       \
+  STEP(2048) STEP(2304) STEP(2560) STEP(2816) STEP(3072) STEP(3328) STEP(3584) STEP(3840)
+
+template <bool INDEXED>
+__global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, const LaneArgs la, const PipeDecArgs pa) {
+  extern __shared__ unsigned char lanes_lds[];
+  lanes_load_image(lanes_lds, la);
+  using L = PipeDecLds;
+
+  const unsigned int job = blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job);
+  const unsigned int wv = (blockIdx.x % static_cast<unsigned int>(jobs.blocks_per_job)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wv >= static_cast<unsigned int>(pa.groups_per_job)) return;
+  const unsigned int gi = job * static_cast<unsigned int>(pa.groups_per_job) + wv;
+  const PipeDecJob& J = jobs.job[job];
+  const unsigned int lane = threadIdx.x & 63u;
+  const int64_t s = static_cast<int64_t>(wv) * 64 + lane;
+  const bool live = s < jobs.streams;
+  const unsigned int elems = live ? static_cast<unsigned int>(jobs.elems) : 0u;
+
+  const uint4 st = live ? J.state[s] : make_uint4(0u, 0xFFFFFFFFu, 0u, 2u);
+  unsigned int D = st.z - st.x;      // window - base
+  unsigned int s1 = st.y;            // span - 1
+  const long long o0 = live ? J.off[s] : 0;
+  unsigned int len = live ? static_cast<unsigned int>(J.off[s + 1] - o0) : 0u;
+  unsigned int pos_start = 2u * st.w;
+  lanes_pin(D, s1, len, pos_start);
+
+  const unsigned int lds0 = static_cast<unsigned int>(reinterpret_cast<size_t>(
+      (__attribute__((address_space(3))) unsigned char*)lanes_lds));
+  const unsigned int wave_off = static_cast<unsigned int>(la.lds_image) + (threadIdx.x >> 6) * static_cast<unsigned int>(la.lds_wave);
+  LaneWindow<L::kWords> cw;
+  const unsigned int cw_off = wave_off + L::kCodes + L::kStride * lane;
+  cw.lds = lanes_lds + cw_off;
+  cw.g = J.blob + o0;
+  cw.len = len;
+  cw.request(pos_start);
+  cw.base = pos_start;
+  unsigned int cp = cw_off;          // LDS offset of the next code digit: stream position cw.base + (cp - cw_off)
+  LaneWindow<L::kWords> iw;          // index mode: row addresses, 2 bytes per element
+  const unsigned int iw_off = wave_off + L::kRows + L::kStride * lane;
+  if (INDEXED) {
+    iw.lds = lanes_lds + iw_off;
+    iw.g = reinterpret_cast<const unsigned char*>(pa.rowaddr + (static_cast<size_t>(job) * jobs.streams + (live ? s : 0)) * jobs.elems);
+    iw.len = elems * 2u;
+    iw.request(0u);
+    iw.base = 0u;
+  }
+
+  const float scale = static_cast<float>(1u << la.precision);
+  float hscale = 0.5f * scale;
+  unsigned int k31 = 0x80000000u;
+  asm volatile("" : "+v"(hscale), "+v"(k31));
+  const unsigned int cp_max = (1u << la.precision) - 1u;
+  const unsigned int dir_end = 16u * static_cast<unsigned int>(la.ntab);
+  // the built-in binary row: directory entry behind the repeated ones
+  uint4 bin = *reinterpret_cast<const uint4*>(lanes_lds + dir_end + 16u * kLaneDirRepeat);
+  asm volatile("" : "+v"(bin.x), "+v"(bin.y), "+v"(bin.z), "+v"(bin.w));
+
+  unsigned int pos = 0u;             // elements completed
+  int M = 0;
+  // pw: channel mode, LDS offset of the directory entry of element `pos`; index mode, LDS offset of its row address
+  unsigned int pw = INDEXED ? iw_off : 0u;
+  uint4 R = make_uint4(0u, 0u, 0u, 0u);   // the row the next step decodes from (loaded behind the first memory phase)
+  bool row_loaded = false;
+
+  unsigned int* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
+  unsigned int* const posrec = pa.posrec + static_cast<size_t>(gi) * (pa.rows / kPipeBlock + 1) * 64 + lane;
+  const unsigned int voff = 4u * lane;
+  unsigned int k = 0u;               // rows written
+
+  // the row of element `pos` (channel mode: pw is kept inside the directory)
+  auto load_row = [&]() {
+    const unsigned int a = INDEXED ? static_cast<unsigned int>(*reinterpret_cast<const unsigned short*>(lanes_lds + pw)) : pw;
+    R = *reinterpret_cast<const uint4*>(lanes_lds + a);
+  };
+
+  // one generic step of the lanes with `act`: any mode, any exception
+  auto gstep = [&](bool act, unsigned int row) {
+    unsigned int entry = 0u;
+    if (act) {
+      const unsigned int dig = __builtin_bswap16(*reinterpret_cast<const unsigned short*>(lanes_lds + cp));
+      if (M == 0) {
+        // ---- symbol first: quotient estimate -> rank among the row's boundaries (range_lanes.h) ----
+        const float fq = (static_cast<float>(D) + 0.5f) * __builtin_amdgcn_rcpf(static_cast<float>(s1)) * scale;
+        const unsigned int q = min(static_cast<unsigned int>(fq), cp_max);
+        const unsigned int w = q >> 6;
+        const unsigned long long word = *reinterpret_cast<const unsigned long long*>(lanes_lds + R.z + 8u * w);
+        const int cum_m1 = *reinterpret_cast<const short*>(lanes_lds + R.w + 2u * w);
+        const unsigned long long below = ~0ull >> (63u - (q & 63u));
+        unsigned int sym = static_cast<unsigned int>(cum_m1 + __popcll(word & below));
+        unsigned int lo = lds_u16(lanes_lds, R.x + 2u * sym + 2u);
+        unsigned int hi = lds_u16(lanes_lds, R.x + 2u * sym + 4u);
+        unsigned int A = scale16(s1, lo);
+        unsigned int b = scale16(s1, hi) - 1u;
+        b = hi == 0u ? s1 : b;
+        const unsigned int nsym = (R.y & 0x7FFFFFFFu) + (R.y >> 31);
+        for (int fix = 0; fix < 4; ++fix) {
+          if (D - A > b - A) {
+            if (D < A) sym = sym > 0u ? sym - 1u : 0u;
+            else sym = sym + 1u < nsym ? sym + 1u : nsym - 1u;
+            lo = lds_u16(lanes_lds, R.x + 2u * sym + 2u);
+            hi = lds_u16(lanes_lds, R.x + 2u * sym + 4u);
+            A = scale16(s1, lo);
+            b = scale16(s1, hi) - 1u;
+            b = hi == 0u ? s1 : b;
+          }
+        }
+        D -= A;
+        s1 = b - A;
+        const bool ren = (s1 >> 16) == 0u;
+        D = ren ? (D << 16) | dig : D;
+        s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
+        cp += ren ? 2u : 0u;
+        entry = sym;
+        M = sym == (R.y ^ 0x80000000u) ? -1 : 0;
+      } else {
+        // ---- one bit of an Elias-gamma code (range_coder_kernels.cc:449-471): the uniform binary cdf at
+        // precision 1 needs no table ------------------------------------------------------------------
+        const unsigned int half = scale16(s1, 32768u);
+        const unsigned int bit = D >= half ? 1u : 0u;
+        const unsigned int A = bit ? half : 0u;
+        const unsigned int b = bit ? s1 : half - 1u;
+        D -= A;
+        s1 = b - A;
+        const bool ren = (s1 >> 16) == 0u;
+        D = ren ? (D << 16) | dig : D;
+        s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
+        cp += ren ? 2u : 0u;
+        entry = bit | (static_cast<unsigned int>(M) << 16);
+        if (M < 0) {
+          if (bit) M = -M;
+          else M = M == -31 ? 32 : M - 1;      // the 31st zero: the prefix ends here (range_lanes.h, bit_step)
+        } else {
+          --M;
+        }
+      }
+      if (M == 0) {
+        ++pos;
+        pw += INDEXED ? 2u : 16u;
+        if (!INDEXED && pw == dir_end) pw = 0u;
+        load_row();
+      } else {
+        R = bin;
+      }
+      raw[static_cast<size_t>(row) * 64 + lane] = entry;
+    }
+  };
+
+  bool gave_up = false;
+  while (__any(pos < elems)) {
+    if (k + kPipeBlock > static_cast<unsigned int>(pa.rows)) {
+      gave_up = true;                // more rows than planned for (escape codes far beyond the tables' tail mass)
+      break;
+    }
+    {
+      // memory phase: park the windows requested at the previous phase, request from the current positions
+      const unsigned int cpos = cw.base + (cp - cw_off);
+      cw.commit();
+      cp = cw_off + (cpos - cw.base);
+      cw.request(cpos);
+      if (INDEXED) {
+        iw.commit();
+        pw = iw_off + (2u * pos - iw.base);
+        iw.request(2u * pos);
+      }
+      // elements STARTED before row k (an escape code in progress has its first row behind us)
+      posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos + (M != 0 ? 1u : 0u);
+    }
+    if (!row_loaded) {
+      if (M == 0) load_row(); else R = bin;
+      row_loaded = true;
+    }
+    const bool busy = pos < elems;
+    if (__builtin_expect(lds0 == 0u && !__any(busy && pos + kPipeBlock > elems), 1)) {
+      const unsigned int D0 = D, s10 = s1, cp0 = cp, pw0 = pw;
+      const int M0 = M;
+      const uint4 R0 = R;
+      unsigned int flag = 0u;
+      int macc = 0;
+      if (busy) {
+        // (the plane's address is the same for every lane; hipcc cannot see that through threadIdx.x >> 6)
+        const unsigned long long rawa = reinterpret_cast<unsigned long long>(raw + static_cast<size_t>(k) * 64);
+        // (readfirstlane returns int: through unsigned, or a low half with bit 31 set smears into the high half)
+        const unsigned int rawlo = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned int>(rawa)));
+        const unsigned int rawhi = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned int>(rawa >> 32)));
+        const unsigned long long rawk = static_cast<unsigned long long>(rawlo) | (static_cast<unsigned long long>(rawhi) << 32);
+#define TFC_PDEC_OPERANDS                                                                                              \
+            : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [M] "+v"(M), [PW] "+v"(pw), [FLAG] "+v"(flag), [MACC] "+v"(macc), \
+              [R0] "+v"(R.x), [R1] "+v"(R.y), [R2] "+v"(R.z), [R3] "+v"(R.w)                                              \
+            : [VOFF] "v"(voff), [RAW] "s"(rawk), [B0] "v"(bin.x), [B1] "v"(bin.y), [B2] "v"(bin.z), [B3] "v"(bin.w),       \
+              [SCALE] "s"(scale), [HSCALE] "v"(hscale), [QMAX] "s"(cp_max), [K31] "v"(k31),                               \
+              [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)                                         \
+            : "vcc", "memory", "s52", "s53", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
+              "v114", "v115", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",      \
+              "v129", "v130", "v131", "v132", "v134", "v135", "v136", "v137", "v138", "v139", "v140"
+        if constexpr (INDEXED) asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
+        else asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_CH) TFC_PDEC_OPERANDS);
+#undef TFC_PDEC_OPERANDS
+      }
+      if (__builtin_expect(!__any(flag != 0u || macc <= -32), 1)) {
+        if (busy) {
+          pos += (pw - pw0) / (INDEXED ? 2u : 16u);
+        }
+        // (fewer tables than rows in a block: the directory cursor wraps more than once)
+        if (!INDEXED)
+          while (__any(busy && pw >= dir_end)) pw -= pw >= dir_end ? dir_end : 0u;
+        k += kPipeBlock;
+        continue;
+      }
+      D = D0; s1 = s10; cp = cp0; pw = pw0; M = M0; R = R0;      // an exception somewhere in the wave: the generic steps
+    }
+#pragma nounroll
+    for (unsigned int i = 0; i < kPipeBlock; ++i) gstep(pos < elems, k + i);
+    k += kPipeBlock;
+  }
+  posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos;
+  if (gave_up) {
+    if (lane == 0) atomicOr(&pa.fallback[job], 1u);
+    return;
+  }
+  if (lane == 0) pa.kend[gi] = k;
+  if (live) {
+    // back to the (base, span - 1, window, digits pulled) form shared with the other kernels
+    const unsigned int cpos = cw.base + (cp - cw_off);
+    const unsigned char* srcp = J.blob + o0;
+    unsigned int window = 0u;
+    for (int i = -4; i < 0; ++i) {
+      const long long q = static_cast<long long>(cpos) + i;
+      window = (window << 8) | ((q >= 0 && q < static_cast<long long>(len)) ? srcp[q] : 0u);
+    }
+    pa.state_out[static_cast<size_t>(gi) * 64 + lane] = make_uint4(window - D, s1, window, cpos >> 1);
+  }
+}
+
+// ---- stage 2: raw rows -> elements -------------------------------------------------------------------
+// A workgroup takes kParseRows rows of one group (64 streams): rows in (coalesced) -> LDS -> a wave walks one
+// stream's column 64 rows at a time; the rows that start an element (M = 0) are numbered by a ballot prefix from
+// the block records of the chain, an escape symbol collects its value from the bit rows behind it, and the
+// elements of a stream leave in order (coalesced along the stream).
+constexpr int kParseRows = 128;
+
+template <bool INDEXED, typename Dst>
+__global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> jobs, const PipeDecArgs pa, const DecRow* dir, int ntab) {
+  constexpr int kPitch = 65;
+  __shared__ unsigned int buf[kParseRows * kPitch];
+  const unsigned int tiles = static_cast<unsigned int>(pa.rows) / kParseRows + 1u;
+  const unsigned int gi = blockIdx.x / tiles, kt = blockIdx.x % tiles;
+  const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
+  const unsigned int wv = gi % static_cast<unsigned int>(pa.groups_per_job);
+  if (pa.fallback[job] != 0u) return;
+  const DecLaneJob<Dst>& J = jobs.job[job];
+  const unsigned int tid = threadIdx.x, lane = tid & 63u;
+  const unsigned int kend = pa.kend[gi];
+  const unsigned int k0 = kt * kParseRows;
+  if (kt == 0u && tid < 64u) {
+    // the chain's successor states become the handle's (nothing is committed when the job fell back)
+    const int64_t s = static_cast<int64_t>(wv) * 64 + tid;
+    if (s < jobs.streams) J.state[s] = pa.state_out[static_cast<size_t>(gi) * 64 + tid];
+  }
+  if (k0 >= kend) return;
+  const unsigned int* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
+  const unsigned int nrows = min(static_cast<unsigned int>(kParseRows), kend - k0);
+  for (unsigned int r = tid >> 6; r < nrows; r += 4u) buf[r * kPitch + lane] = raw[static_cast<size_t>(k0 + r) * 64 + lane];
+  __syncthreads();
+  const unsigned int* const posrec = pa.posrec + static_cast<size_t>(gi) * (pa.rows / kPipeBlock + 1) * 64;
+  const Dst dst = J.dst;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (unsigned int l = tid >> 6; l < 64u; l += 4u) {
+    const int64_t s = static_cast<int64_t>(wv) * 64 + l;
+    if (s >= jobs.streams) continue;
+    unsigned int p = posrec[static_cast<size_t>(k0 / kPipeBlock) * 64 + l];
+    const unsigned int p1 = posrec[static_cast<size_t>((k0 + nrows) / kPipeBlock) * 64 + l];
+    const int64_t base = s * jobs.elems;
+    for (unsigned int c = 0; c < nrows; c += 64u) {
+      const unsigned int i = c + lane;
+      const unsigned int e = i < nrows ? buf[i * kPitch + l] : 0xFFFF0000u;
+      const bool start = (e >> 16) == 0u;
+      const unsigned long long mask = __ballot(start);
+      const unsigned int ord = p + static_cast<unsigned int>(__popcll(mask & lt));
+      p += static_cast<unsigned int>(__popcll(mask));
+      if (start && ord < p1) {
+        const int64_t at = base + ord;
+        int t = static_cast<int>(ord % static_cast<unsigned int>(ntab));
+        if (INDEXED) {
+          t = J.index[at];
+          t = (t < 0 || t >= ntab) ? 0 : t;
+        }
+        int v = static_cast<int>(e);
+        const int es = dir[t].w;                       // escape symbol of the row, or -1
+        if (v == es) {
+          // the rows behind an escape symbol carry its Elias-gamma code: M < 0 the unary prefix (-M - 1 zeros
+          // before the row), M > 0 calls to go (M = 1: the sign; bit M - 2 of the magnitude otherwise)
+          unsigned int val = 0u;
+          bool neg = false;
+          for (unsigned int q = k0 + i + 1u; q < kend; ++q) {
+            const unsigned int x = q - k0 < nrows ? buf[(q - k0) * kPitch + l] : raw[static_cast<size_t>(q) * 64 + l];
+            const int m = static_cast<int>(x) >> 16;
+            const unsigned int bit = x & 1u;
+            if (m < 0) {
+              if (bit) val = 1u << (-m - 1);
+              else if (m == -31) val = 1u << 31;
+            } else if (m > 1) {
+              val |= bit << (m - 2);
+            } else {
+              neg = bit != 0u;
+              break;
+            }
+          }
+          v = neg ? -static_cast<int>(val) : static_cast<int>(val) + es - 1;
+        }
+        dst.store(at, t, v);
+      }
+    }
+  }
+}
+
+}  // namespace tfc

@@ -107,8 +107,29 @@ class GDN(torch.nn.Module):
         key = (beta.data_ptr(), gamma.data_ptr(), str(dtype), str(beta.device))
         hit = cache.get("prepared")
         if hit is None or hit[0] != key:
-            cache["prepared"] = hit = (key, functional.GDNPrepared(beta, gamma, dtype), beta, gamma)
+            prepared = functional.GDNPrepared(beta, gamma, dtype)
+            # the image is built by a kernel on the CURRENT stream and then read by whatever stream runs a later
+            # call (every pipeline lane has its own): complete before it is cached, like _cached_value
+            torch.cuda.current_stream().synchronize()
+            cache["prepared"] = hit = (key, prepared, beta, gamma)
         return hit[1]
+
+    # The cache holds native handles (functional.GDNPrepared): it is not copied or pickled with the module, the
+    # copy rebuilds its own on first use (copy.deepcopy for an EMA model, torch.save of the module object).
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_value_cache", None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_value_cache":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def invalidate_kernel_cache(self):
         self.__dict__["_value_cache"] = {}

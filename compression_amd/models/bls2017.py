@@ -112,8 +112,7 @@ class BLS2017Model(torch.nn.Module):
             ok.append(oky)
         with lane.on("transform"):
             x_hat = functional.unit_to_image(self.synthesis_transform.unit(y_hat)[:, :x_shape[0], :x_shape[1], :])
-            if defer_sanity:
-                x_hat._tfc_keep = (y_hat,)
+            x_hat._tfc_keep = (y_hat,)      # produced on the coder stream, read here on the transform stream
         return (x_hat, ok) if defer_sanity else x_hat
 
     @torch.no_grad()

@@ -173,8 +173,9 @@ class BMSHJ2018Model(torch.nn.Module):
             ok.append(oky)
         with lane.on("transform"):
             x_hat = functional.unit_to_image(self.synthesis_transform.unit(y_hat)[:, :x_shape[0], :x_shape[1], :])
-            if defer_sanity:
-                x_hat._tfc_keep = (z_hat, indexes, y_hat)     # produced on one stream, read on the other
+            # produced on one stream, read on the other: alive until the caller drops x_hat (a tensor freed behind a
+            # kernel of ANOTHER stream goes back to its own stream's pool while that kernel may still read it)
+            x_hat._tfc_keep = (z_hat, indexes, y_hat)
         return (x_hat, ok) if defer_sanity else x_hat
 
     @torch.no_grad()
