@@ -164,6 +164,8 @@ extern "C" int tfc_set_default_mode(int mode) {
 }
 extern "C" int tfc_get_default_mode(void) { return default_mode().load(); }
 
+extern "C" int tfc_pipe_counters(int64_t* launches, int64_t* fallback_blocks);
+
 extern "C" void tfc_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_profile_mutex);
   g_profile_on = on != 0;
@@ -1606,6 +1608,7 @@ inline bool pipe_fallback_launch() {
   }();
   return on;
 }
+std::atomic<long long> g_pipe_launches{0};
 // temporaries of one pipelined launch are bounded: more jobs than this go out as several launches
 constexpr size_t kPipeTempBytes = size_t{6} << 30;
 
@@ -1703,6 +1706,7 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         pa.tileend = reinterpret_cast<unsigned int*>(base + calls_bytes);
         pa.fallback = reinterpret_cast<unsigned int*>(base + calls_bytes + end_bytes);
         pa.groups = static_cast<int>(groups);
+        g_pipe_launches.fetch_add(1, std::memory_order_relaxed);
         pa.fast16 = t->d_fast.as<uint16_t>();
         pa.rows_fast = t->d_rows_fast.as<int2>();
         pa.ntab = la.ntab;
@@ -1711,8 +1715,8 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         const dim3 xgrid(static_cast<unsigned>(groups * pa.nt));
         {
           KernelTimer t2("enc_expand", st);
-          if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src>), xgrid, dim3(256), 0, st, jobs, pa);
-          else hipLaunchKernelGGL((enc_expand_kernel<false, Src>), xgrid, dim3(256), 0, st, jobs, pa);
+          if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
+          else hipLaunchKernelGGL((enc_expand_kernel<false, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
         }
         PipeChainJobs cj;
         cj.streams = streams;
@@ -2121,6 +2125,17 @@ extern "C" int tfc_encoder_finalize_device_many(int n, tfc_encoder* const* es, v
     e->blob_capacity = static_cast<int64_t>(cap);
     e->chunks.clear();       // stream-ordered frees behind the pack launch
     e->finalized = true;
+  }
+  return 0;
+}
+
+extern "C" int tfc_pipe_counters(int64_t* launches, int64_t* fallback_blocks) {
+  if (launches) *launches = g_pipe_launches.load();
+  if (fallback_blocks) {
+    unsigned long long v = 0;
+    TFC_HIP(hipDeviceSynchronize());
+    TFC_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(tfc::g_pipe_fallback_blocks), sizeof(v)));
+    *fallback_blocks = static_cast<int64_t>(v);
   }
   return 0;
 }
@@ -2639,6 +2654,7 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
       pa.fallback = reinterpret_cast<unsigned int*>(base + raw_all + rec_all + st_all + kend_all + addr_all);
       // (kend of a group the chain gave up on stays unset: the parse skips the whole job under its fallback flag)
       TFC_HIP(hipMemsetAsync(pa.fallback, 0, 256, st));
+      g_pipe_launches.fetch_add(1, std::memory_order_relaxed);
       PipeDecJobs cj;
       cj.streams = streams;
       cj.elems = elems;

@@ -60,6 +60,10 @@
 
 namespace tfc {
 
+// Workgroups of the lane-per-stream kernels that ran as the FALLBACK of the pipelined kernels (range_pipe.h): a job
+// the latter gave up on.  Read by tfc_pipe_counters (tests: the fast path really is the one that ran).
+__device__ unsigned long long g_pipe_fallback_blocks;
+
 struct LaneArgs {
   const uint32_t* image;       // device copy of the LDS image
   int bytes;                   // bytes of it this kernel needs (encoder: directory + cdf entries)
@@ -396,7 +400,10 @@ struct EncWaveLds {
 template <bool INDEXED, typename Src>
 __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> jobs, LaneArgs la) {
   extern __shared__ unsigned char lanes_lds[];
-  if (la.guard && la.guard[blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job)] == 0u) return;
+  if (la.guard) {
+    if (la.guard[blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job)] == 0u) return;
+    if (threadIdx.x == 0) atomicAdd(&g_pipe_fallback_blocks, 1ull);
+  }
   lanes_load_image(lanes_lds, la);
   using Raw = typename Src::raw_type;
   using L = EncWaveLds<Raw>;
@@ -887,7 +894,10 @@ struct DecWaveLds {
 template <bool INDEXED, typename Dst>
 __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> jobs, LaneArgs la) {
   extern __shared__ unsigned char lanes_lds[];
-  if (la.guard && la.guard[blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job)] == 0u) return;
+  if (la.guard) {
+    if (la.guard[blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job)] == 0u) return;
+    if (threadIdx.x == 0) atomicAdd(&g_pipe_fallback_blocks, 1ull);
+  }
   lanes_load_image(lanes_lds, la);
   using Elem = typename Dst::elem;
   using L = DecWaveLds<Elem>;

@@ -36,7 +36,7 @@
 namespace tfc {
 
 constexpr int kPipeTile = 256;        // symbols of a stream per expansion workgroup
-constexpr int kPipeEscMax = 64;       // escape codes per stream and tile the expansion plans for
+constexpr int kPipeEscMax = 32;       // escape codes per stream and tile the expansion plans for
 constexpr unsigned int kPipeBlock = 16;          // rows per hand-scheduled block of the chain kernels
 // A call word that no table produces (lower bound 0xFFFF above upper bound 1): "this lane has no call in this row"
 constexpr unsigned int kPipeNoCall = 0x0001FFFFu;
@@ -77,13 +77,16 @@ __device__ inline unsigned int pipe_escape_word(unsigned int g, unsigned int neg
 // rounded up to whole blocks; where a tile starts is the sum over the tiles before it — a chained look-back over the
 // group's tiles (each workgroup publishes its end row once it has counted its calls, and needs its predecessor's
 // only when it starts writing).
+constexpr int kExpandThreads = 512;
 template <bool INDEXED, typename Src>
-__global__ void __launch_bounds__(256) enc_expand_kernel(const EncLaneJobs<Src> jobs, const PipeEncArgs pa) {
+__global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const EncLaneJobs<Src> jobs, const PipeEncArgs pa) {
   constexpr int kRow = kPipeTile + 1;                     // padded: the transposed reads of phase C hit 64 banks
+  constexpr int kHalves = kExpandThreads / kPipeTile;     // thread = (half, symbol): half h takes streams h, h + kHalves, ...
   __shared__ unsigned int W[64 * kRow];                   // call word of every (stream, symbol) of the tile
-  __shared__ unsigned int escmask[64][kPipeTile / 32];    // symbols that take an escape code
-  __shared__ unsigned short esc[64][kPipeEscMax];         // per stream, in order: position | neg << 8 | extra calls << 9
-  __shared__ unsigned int cnt[64], nesc[64], tmax, tstart;
+  // escape codes per stream (appended in phase A, put in order in phase B):
+  // position | neg << 8 | extra calls << 9 | low 16 bits of gamma << 16 (all of gamma when extra < 34)
+  __shared__ unsigned int esc[64][kPipeEscMax];
+  __shared__ unsigned int ecount[64], cnt[64], nesc[64], tmax, tstart;
 
   const unsigned int gi = blockIdx.x % static_cast<unsigned int>(pa.groups);
   const unsigned int T = blockIdx.x / static_cast<unsigned int>(pa.groups);
@@ -92,17 +95,15 @@ __global__ void __launch_bounds__(256) enc_expand_kernel(const EncLaneJobs<Src> 
   const EncLaneJob<Src>& J = jobs.job[job];
   const Src src = J.src;
   const int32_t* const index = J.index;
-  const unsigned int tid = threadIdx.x;
+  const unsigned int tid = threadIdx.x, lane = tid & 63u;
   const unsigned int elems = static_cast<unsigned int>(jobs.elems);
   const int64_t s0 = static_cast<int64_t>(gidx) * 64;
-  const unsigned int j = T * kPipeTile + tid;             // this thread's symbol of every stream
   const unsigned int ntab = static_cast<unsigned int>(pa.ntab);
-
-  for (unsigned int i = tid; i < 64u * (kPipeTile / 32); i += 256u) (&escmask[0][0])[i] = 0u;
   if (tid == 0) tmax = 0u;
+  if (tid < 64u) ecount[tid] = 0u;
   __syncthreads();
 
-  // table and value of symbol `at` of stream s (phases B and C look again at the few symbols with escape codes)
+  // table and value of symbol `at` of stream s (phase C looks again at the rare escape code of 2^16 and more)
   auto escape_of = [&](int64_t s, unsigned int at, unsigned int& g, unsigned int& neg) {
     const int64_t pos = s * jobs.elems + at;
     int t = static_cast<int>(at % ntab);
@@ -117,60 +118,100 @@ __global__ void __launch_bounds__(256) enc_expand_kernel(const EncLaneJobs<Src> 
     g = v < 0 ? 0u - static_cast<unsigned int>(v) : static_cast<unsigned int>(v - vmax) + 1u;
   };
 
-  // ---- phase A: one call word per symbol (an escape: the word of its row's escape symbol) -------------
-  const int tch = static_cast<int>(j % ntab);
-#pragma unroll 4
-  for (int sl = 0; sl < 64; ++sl) {
-    const int64_t s = s0 + sl;
-    unsigned int w = 0u;
-    if (s < jobs.streams && j < elems) {
-      const int64_t pos = s * jobs.elems + j;
-      int t = tch;
-      bool bad = false;
+  // ---- phase A: one call word per symbol (an escape: the word of its row's escape symbol).  Written in stages
+  // over register arrays — all loads of a stage are in flight together (interleaved with the LDS stores, hipcc
+  // waits for every single load: a load through a pointer out of the kernel arguments is a flat load, which may
+  // alias LDS).  Which symbols take an escape code is collected by ballot: lane L of a wave keeps the mask of the
+  // wave's 64 symbols for the L-th stream it handles --------------------------------------------------------
+  {
+    constexpr int N = 64 / kHalves;       // streams per thread ...
+    constexpr int NB = 16;                // ... taken NB at a time (registers: two workgroups per CU)
+    const unsigned int p = tid % kPipeTile, half = tid / kPipeTile;
+    const unsigned int j = T * kPipeTile + p;             // this thread's symbol of every stream it handles
+    const bool inpos = j < elems;
+    const unsigned int jc = inpos ? j : 0u;
+    const int tch = static_cast<int>(jc % ntab);
+    const int2 rowc = pa.rows_fast[tch];
+    unsigned long long badpos = ~0ull;
+    auto position = [&](int i) {
+      const int64_t s = s0 + i * kHalves + static_cast<int>(half);
+      return (s < jobs.streams ? s : 0) * jobs.elems + jc;       // (a clamped address: loaded, not used)
+    };
+#pragma nounroll
+    for (int i0 = 0; i0 < N; i0 += NB) {
+      int32_t val[NB];
+      int tt[NB];
+      int2 rw[NB];
+      unsigned int word[NB];
       if (INDEXED) {
-        t = index[pos];
-        if (t < 0 || t >= pa.ntab) { bad = true; t = 0; }
-      }
-      const int2 row = pa.rows_fast[t];
-      const Call c = classify_fast(pa.fast16, row, src.load(pos, t));
-      if (bad || c.bad) atomicMin(J.first_error, static_cast<unsigned long long>(pos));
-      w = (static_cast<unsigned int>(c.lo16) & 0xFFFFu) | (static_cast<unsigned int>(c.hi16) << 16);
-      if (c.gamma) atomicOr(&escmask[sl][tid >> 5], 1u << (tid & 31u));
-    }
-    W[sl * kRow + tid] = w;
-  }
-  __syncthreads();
-
-  // ---- phase B: a thread per stream lists its escape codes in order ------------------------------------
-  if (tid < 64u) {
-    const int64_t s = s0 + tid;
-    unsigned int n = 0u, cum = 0u, valid = 0u;
-    bool over = false;
-    if (s < jobs.streams && T * kPipeTile < elems) {
-      valid = min(static_cast<unsigned int>(kPipeTile), elems - T * kPipeTile);
-      for (unsigned int wd = 0; wd < kPipeTile / 32; ++wd) {
-        unsigned int m = escmask[tid][wd];
-        while (m) {
-          const unsigned int e = 32u * wd + static_cast<unsigned int>(__ffs(static_cast<int>(m)) - 1);
-          m &= m - 1u;
-          unsigned int g, neg;
-          escape_of(s, T * kPipeTile + e, g, neg);
-          const unsigned int extra = pipe_escape_extra(g);
-          if (n < static_cast<unsigned int>(kPipeEscMax)) {
-            esc[tid][n] = static_cast<unsigned short>(e | (neg << 8) | (extra << 9));
-            cum += extra;
-            ++n;
-          } else {
-            over = true;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) tt[i] = index[position(i0 + i)];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          if (tt[i] < 0 || tt[i] >= pa.ntab) {
+            if (inpos && s0 + (i0 + i) * kHalves + static_cast<int>(half) < jobs.streams)
+              badpos = min(badpos, static_cast<unsigned long long>(position(i0 + i)));
+            tt[i] = 0;
           }
+          rw[i] = pa.rows_fast[tt[i]];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { tt[i] = tch; rw[i] = rowc; }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) val[i] = src.load(position(i0 + i), tt[i]);
+      // classify_fast() without branches: plain symbols are 0 ... nplain - 1; anything else is the row's escape
+      // symbol (rows that have one) or a range error; the call word is the 4 bytes lo | hi << 16 of the table image
+      unsigned int escbits = 0u;          // bit i: stream i0 + i of this thread takes an escape code
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int len = rw[i].y & 0x7FFFFFFF;
+        const bool hasesc = rw[i].y < 0;
+        const int nplain = hasesc ? len - 3 : len - 2;
+        const bool plain = static_cast<unsigned int>(val[i]) < static_cast<unsigned int>(nplain);
+        const int sym = plain ? val[i] : (hasesc ? len - 3 : 0);
+        const unsigned short* e = pa.fast16 + rw[i].x + 1 + sym;
+        word[i] = static_cast<unsigned int>(e[0]) | (static_cast<unsigned int>(e[1]) << 16);
+        const bool live = inpos && s0 + (i0 + i) * kHalves + static_cast<int>(half) < jobs.streams;
+        if (live && !plain && !hasesc) badpos = min(badpos, static_cast<unsigned long long>(position(i0 + i)));
+        escbits |= (live && !plain && hasesc) ? 1u << i : 0u;
+        word[i] = live ? word[i] : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int sl = (i0 + i) * kHalves + static_cast<int>(half);
+        W[sl * kRow + p] = word[i];
+        if ((escbits >> i) & 1u) {
+          // the code's magnitude (range_coder_kernels.cc:296-303) next to the symbol's position
+          const int32_t vmax = (rw[i].y & 0x7FFFFFFF) - 3;
+          const unsigned int neg = val[i] < 0 ? 1u : 0u;
+          const unsigned int g = val[i] < 0 ? 0u - static_cast<unsigned int>(val[i]) : static_cast<unsigned int>(val[i] - vmax) + 1u;
+          const unsigned int slot = atomicAdd(&ecount[sl], 1u);
+          if (slot < static_cast<unsigned int>(kPipeEscMax)) esc[sl][slot] = p | (neg << 8) | (pipe_escape_extra(g) << 9) | (g << 16);
         }
       }
     }
-    if (over) {
-      atomicOr(&pa.fallback[job], 1u);
+    if (badpos != ~0ull) atomicMin(J.first_error, badpos);
+  }
+  __syncthreads();
+
+  // ---- phase B: a thread per stream puts its escape codes in order and counts its rows ----------------
+  if (tid < 64u) {
+    const int64_t s = s0 + tid;
+    unsigned int n = ecount[tid], cum = 0u, valid = 0u;
+    if (s < jobs.streams && T * kPipeTile < elems) valid = min(static_cast<unsigned int>(kPipeTile), elems - T * kPipeTile);
+    if (n > static_cast<unsigned int>(kPipeEscMax)) {
+      atomicOr(&pa.fallback[job], 1u);      // more escape codes than planned for: the lane-per-stream kernel codes this job
       n = 0u;
-      cum = 0u;
     }
+    for (unsigned int a = 1; a < n; ++a) {      // insertion sort by position (a handful of entries)
+      const unsigned int x = esc[tid][a];
+      unsigned int b = a;
+      for (; b > 0u && (esc[tid][b - 1u] & 0xFFu) > (x & 0xFFu); --b) esc[tid][b] = esc[tid][b - 1u];
+      esc[tid][b] = x;
+    }
+    for (unsigned int a = 0; a < n; ++a) cum += (esc[tid][a] >> 9) & 0x7Fu;
     cnt[tid] = valid + cum;
     nesc[tid] = n;
     atomicMax(&tmax, valid + cum);
@@ -200,25 +241,27 @@ __global__ void __launch_bounds__(256) enc_expand_kernel(const EncLaneJobs<Src> 
   __syncthreads();
   if (tstart == 0xFFFFFFFFu) return;
 
-  // ---- phase C: rows out, transposed: thread (r, l) writes rows r, r + 4, ... of lane l; rows behind a lane's
+  // ---- phase C: rows out, transposed: thread (r, l) writes rows r, r + 8, ... of lane l; rows behind a lane's
   // last call, up to the next whole block, hold "no call" --------------------------------------------------
   {
-    const unsigned int l = tid & 63u;
+    constexpr unsigned int kRowsPerPass = kExpandThreads / 64;
+    const unsigned int l = lane;
     const unsigned int mx = (tmax + kPipeBlock - 1u) & ~(kPipeBlock - 1u), mine = cnt[l], ne = nesc[l];
     unsigned int* const out = pa.calls + (static_cast<size_t>(gi) * pa.rows + tstart) * 64 + l;
     unsigned int i = 0u;                  // first escape code whose rows do not all lie before row r
-    unsigned int start = 0u, extra = 0u, cumi = 0u, epos = 0u, neg = 0u;
+    unsigned int start = 0u, extra = 0u, cumi = 0u, epos = 0u, neg = 0u, glow = 0u;
     auto fetch = [&]() {
       if (i < ne) {
         const unsigned int e = esc[l][i];
         epos = e & 0xFFu;
         neg = (e >> 8) & 1u;
-        extra = e >> 9;
+        extra = (e >> 9) & 0x7Fu;
+        glow = e >> 16;
         start = epos + cumi;              // row of the escape symbol's own call; its bits: the `extra` rows behind it
       }
     };
     fetch();
-    for (unsigned int r = tid >> 6; r < mx; r += 4u) {
+    for (unsigned int r = tid >> 6; r < mx; r += kRowsPerPass) {
       unsigned int w = kPipeNoCall;
       if (r < mine) {
         while (i < ne && r > start + extra) {
@@ -227,8 +270,8 @@ __global__ void __launch_bounds__(256) enc_expand_kernel(const EncLaneJobs<Src> 
           fetch();
         }
         if (i < ne && r > start) {
-          unsigned int g, ng;
-          escape_of(s0 + l, T * kPipeTile + epos, g, ng);
+          unsigned int g = glow, ng;
+          if (extra >= 34u) escape_of(s0 + l, T * kPipeTile + epos, g, ng);      // 2^16 and more: the value again
           w = pipe_escape_word(g, neg, extra, r - start);
         } else {
           w = W[l * kRow + (r - cumi)];
@@ -793,10 +836,13 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
 // elements of a stream leave in order (coalesced along the stream).
 constexpr int kParseRows = 128;
 
+constexpr int kParseEscTables = 2048;     // escape symbols of up to this many tables are staged in LDS
+
 template <bool INDEXED, typename Dst>
 __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> jobs, const PipeDecArgs pa, const DecRow* dir, int ntab) {
   constexpr int kPitch = 65;
   __shared__ unsigned int buf[kParseRows * kPitch];
+  __shared__ int escsym[kParseEscTables];
   const unsigned int tiles = static_cast<unsigned int>(pa.rows) / kParseRows + 1u;
   const unsigned int gi = blockIdx.x / tiles, kt = blockIdx.x % tiles;
   const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
@@ -815,32 +861,43 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
   const unsigned int* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
   const unsigned int nrows = min(static_cast<unsigned int>(kParseRows), kend - k0);
   for (unsigned int r = tid >> 6; r < nrows; r += 4u) buf[r * kPitch + lane] = raw[static_cast<size_t>(k0 + r) * 64 + lane];
+  const bool esc_in_lds = ntab <= kParseEscTables;
+  if (esc_in_lds)
+    for (int i = tid; i < ntab; i += 256) escsym[i] = dir[i].w;
   __syncthreads();
   const unsigned int* const posrec = pa.posrec + static_cast<size_t>(gi) * (pa.rows / kPipeBlock + 1) * 64;
   const Dst dst = J.dst;
   const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned int untab = static_cast<unsigned int>(ntab);
   for (unsigned int l = tid >> 6; l < 64u; l += 4u) {
     const int64_t s = static_cast<int64_t>(wv) * 64 + l;
     if (s >= jobs.streams) continue;
     unsigned int p = posrec[static_cast<size_t>(k0 / kPipeBlock) * 64 + l];
     const unsigned int p1 = posrec[static_cast<size_t>((k0 + nrows) / kPipeBlock) * 64 + l];
     const int64_t base = s * jobs.elems;
+    unsigned int pmod = p % untab;                 // channel mode: table of element p
     for (unsigned int c = 0; c < nrows; c += 64u) {
       const unsigned int i = c + lane;
       const unsigned int e = i < nrows ? buf[i * kPitch + l] : 0xFFFF0000u;
       const bool start = (e >> 16) == 0u;
       const unsigned long long mask = __ballot(start);
-      const unsigned int ord = p + static_cast<unsigned int>(__popcll(mask & lt));
-      p += static_cast<unsigned int>(__popcll(mask));
+      const unsigned int before = static_cast<unsigned int>(__popcll(mask & lt));
+      const unsigned int ord = p + before;
+      const unsigned int total = static_cast<unsigned int>(__popcll(mask));
       if (start && ord < p1) {
         const int64_t at = base + ord;
-        int t = static_cast<int>(ord % static_cast<unsigned int>(ntab));
+        int t;
         if (INDEXED) {
           t = J.index[at];
           t = (t < 0 || t >= ntab) ? 0 : t;
+        } else {
+          unsigned int m = pmod + before;          // < ntab + 64
+          if (untab >= 64u) m -= m >= untab ? untab : 0u;
+          else m %= untab;
+          t = static_cast<int>(m);
         }
         int v = static_cast<int>(e);
-        const int es = dir[t].w;                       // escape symbol of the row, or -1
+        const int es = esc_in_lds ? escsym[t] : dir[t].w;      // escape symbol of the row, or -1
         if (v == es) {
           // the rows behind an escape symbol carry its Elias-gamma code: M < 0 the unary prefix (-M - 1 zeros
           // before the row), M > 0 calls to go (M = 1: the sign; bit M - 2 of the magnitude otherwise)
@@ -864,6 +921,8 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
         }
         dst.store(at, t, v);
       }
+      p += total;
+      pmod = (pmod + total) % untab;
     }
   }
 }

@@ -44,6 +44,10 @@ const char* tfc_last_error(void);
  * resets the counters. */
 void tfc_profile_enable(int on);
 int tfc_profile_query(const char* kernel, double* total_ms, int64_t* launches);
+/* Diagnostics for the tests: encode / decode launches of throughput-mode handles that went to the pipelined
+ * kernels (csrc/range_pipe.h) since the library was loaded, and workgroups of the lane-per-stream kernels that
+ * ran behind them as the fallback for a job they gave up on (synchronises the device).  Either may be null. */
+int tfc_pipe_counters(int64_t* launches, int64_t* fallback_blocks);
 
 /* Kernel family of a coder handle (no reference counterpart: the reference's ops shard streams over the
  * intra-op thread pool, range_coder_kernels.cc:212-267).  The bytes / symbols produced are identical.
