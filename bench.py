@@ -28,10 +28,12 @@ barrier + max-reduce of the timing.
 
 The same line carries, as sub-objects (N = 1 only; `--no-extras` drops them):
   single_batch  ONE 512-stream batch at a time (BASELINE config 2 as literally written), both families;
-  escapes       the same --steps command with 0.4 % (the tables' own tail mass) and 1 % of
-                the symbols replaced by out-of-range values, slot 0's bytes compared with the CPU reference;
+  escapes       the same --steps command on two other input laws: 1 % of the symbols replaced by far-out values
+                (SURVEY.md §8d's second run) and the overflow draws folded away (no escape codes at all);
+                slot 0's bytes compared with the CPU reference (the headline itself is on §8d's law:
+                draws inverted through the tables, overflow bucket included);
   models        BASELINE config 1 (bls2017, 512 x 256x256) and config 4 (bmshj2018, 128 x 768x512) full
-                compress + decompress, batches pipelined over a CU partition (compression_amd/pipeline.py),
+                compress + decompress, several steps in flight on ordinary streams (compression_amd/pipeline.py),
                 every image's strings compared with the CPU reference coder on the model's own symbols;
   conv          SignalConv2D TFLOP/s per layer shape of config 4;
   gdn_fwd       BASELINE config 3.
@@ -95,19 +97,48 @@ def one_step(lookup_t, value_t, mode):
     return step_group(lookup_t, [value_t], mode)[0]
 
 
-def step_group(lookup_t, values, mode):
+def step_group(lookup_t, values, mode, host=None):
     """len(values) independent steps on the current HIP stream, nothing read back.  Every step has its own
-    handles and strings; the coding calls of the group go to the GPU as one launch
+    handles and strings; the coding calls of the group go to the GPU as one launch per stage
     (entropy_encode_channel_many / entropy_decode_channel_many): the hardware overlaps only ~8 kernels
     however many streams carry them, and one 512-stream call is 8 waves.  Creation and finalisation of the
-    handles are batched the same way (one allocation and one small launch per group instead of per handle)."""
+    handles are batched the same way (one allocation and one small launch per group instead of per handle).
+    `host` (a HostSink): the strings are also copied to pinned host memory, on a second stream, while the
+    decoders run (the reference's ops return host strings)."""
     hs = tfc.create_range_encoders(len(values), [STREAMS], lookup_t, mode=mode, deferred_errors=True)
     hs = tfc.entropy_encode_channel_many(hs, values)
     hs = tfc.entropy_encode_finalize_device_many(hs)
+    encoded = torch.cuda.Event()
+    encoded.record()
     ds = tfc.create_range_decoders(hs, lookup_t, mode=mode)
     ds, decoded = tfc.entropy_decode_channel_many(ds, [ELEMS], torch.int32)
     oks = tfc.entropy_decode_finalize_device_many(ds)
+    if host is not None:
+        host.fetch(hs, encoded)
     return list(zip(hs, ds, decoded, oks))
+
+
+class HostSink:
+    """Pinned host buffers + a copy stream: the strings of a group of finalized encoder handles are copied out of
+    HBM asynchronously — offsets first (the host needs the byte counts), then exactly the bytes."""
+
+    def __init__(self, device, slots):
+        self.stream = torch.cuda.Stream(device=device)
+        self.offsets = [torch.empty(STREAMS + 1, dtype=torch.int64).pin_memory() for _ in range(slots)]
+        self.blobs = [torch.empty(3 * STREAMS * ELEMS // 2, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.bytes = 0
+
+    def fetch(self, handles, encoded):
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(encoded)
+            views = [tfc.device_strings(h) for h in handles]
+            for k, (_, off) in enumerate(views):
+                self.offsets[k].copy_(off, non_blocking=True)
+            self.stream.synchronize()          # the host waits for the ENCODER only; the decoders are already enqueued
+            for k, (blob, _) in enumerate(views):
+                n = int(self.offsets[k][-1])
+                self.blobs[k][:n].copy_(blob[:n], non_blocking=True)
+                self.bytes += n
 
 
 def sample_symbols_device(lookup, seed, device, escape_fraction=0.0, fold=False):
@@ -540,6 +571,10 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
             rec.end.synchronize()
         if fetch:
             rec.strings = [tfc.fetch_strings(h) for h in rec.out if isinstance(h, tfc.gen_ops.EncoderHandle)]
+            for other in getattr(rec.x_hat, "_tfc_group", (None, ()))[1]:
+                for h in other:
+                    if isinstance(h, tfc.gen_ops.EncoderHandle):
+                        tfc.fetch_strings(h)
             for ok in rec.oks:
                 assert bool(ok.cpu().all()), "EntropyDecodeFinalize reported a failed stream"
         return rec
@@ -557,10 +592,11 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
             with lane.on("transform"):
                 packed = model.compress_many(xs)
                 x_hats, ok = model.decompress_many(packed)
-            # the record of the unit: its first batch's handle first (the parity checks look at rec.out[0])
-            out = tuple(p[0] for p in packed)
-            x_hat, oks = x_hats[0], [ok]
-            x_hat._tfc_group = x_hats
+            # the record of the unit: its first batch's result (the parity checks look at rec.out), the handles of
+            # the other batches behind it (their strings are fetched with the record too)
+            out = tuple(packed[0])
+            x_hat, oks = x_hats[0], (ok if isinstance(ok, (list, tuple)) else [ok])
+            x_hat._tfc_group = (x_hats, packed[1:])
         pending[slot] = StepRecord(out, x_hat, oks, lane.end_event())
     order = [(k % len(lanes)) for k in range(max(0, units - len(lanes)), units)]
     for slot in order:
@@ -571,55 +607,17 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
     return time.perf_counter() - t0, last
 
 
-def run_model_pipeline(model, x, steps, sp, fetch=True):
-    """`steps` compress + decompress passes through a `pipeline.SoftwarePipeline` (one transform and one coder
-    stream; step k's coding beside step k - 1's synthesis and step k + 1's analysis — see its docstring).  The host
-    never waits inside a step: step k - 2 is retired (end event, strings and sanity flags fetched) after step k has
-    been enqueued.  Returns (seconds, last record)."""
-    main = torch.cuda.current_stream()
-    states, last = [], None
-
-    def retire(state, ev):
-        ev.synchronize()
-        rec = StepRecord(state["packed"], state["x_hat"], state["ok"], None)
-        rec.x_hat._tfc_keep = (state["y_hat"],)
-        if fetch:
-            rec.strings = [tfc.fetch_strings(h) for h in rec.out if isinstance(h, tfc.gen_ops.EncoderHandle)]
-            for ok in rec.oks:
-                assert bool(ok.cpu().all()), "EntropyDecodeFinalize reported a failed stream"
-        return rec
-
-    t0 = time.perf_counter()
-    ready = []                                   # (state, end event) of steps whose last stage is enqueued
-    for k in range(steps):
-        stages, state = model.codec_stages(x)
-        states.append(state)
-        _, ev = sp.submit(stages, after=main)
-        if ev is not None:
-            ready.append((states[k - 1], ev))
-        while len(ready) > 1:
-            last = retire(*ready.pop(0))
-    _, ev = sp.drain()
-    ready.append((states[-1], ev))
-    for item in ready:
-        last = retire(*item)
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0, last
-
-
-def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=2, coder_cus=32,
-                cpu=True, rank=0, world=1, distributed=False, partition="single", group=1, queue=2):
-    """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5)."""
+def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=None,
+                cpu=True, rank=0, world=1, distributed=False, group=1, queue=2):
+    """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5).  `lanes`: the
+    pipeline.StepLanes the steps are spread over (made first thing in the process: which hardware queue a stream gets
+    depends on what created streams before it, profiles/r03_notes.md); `queue` steps enqueued per lane; `group`
+    batches per coder launch (the models' compress_many / decompress_many)."""
     import torch.distributed as dist
     from compression_amd import parallel, pipeline
     from compression_amd.ops import gen_ops
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-    if depth <= 0:
-        # 6 streams x `queue` steps.  4 measure the same in a fresh process (35-38 against 36-39 ms for C4), but where the
-        # process has a history (the default line: C2, the convolution table, C1 first) the step on 4 streams comes out
-        # bimodal — 35 or 44-53 ms, same binary, same box — as if two of the streams shared a hardware queue; with 6 the
-        # same line gives 39 (profiles/r03_notes.md)
-        depth = 6
+    step_lanes = lanes if lanes is not None else pipeline.StepLanes(6, device)
     model, x, batch, hw, hist = make_model(workload, dtype, device, batch, rank)
     if distributed:
         parallel.broadcast_tables(model)
@@ -633,25 +631,13 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
         lone_s, rec = run_model_steps(model, x, lone_steps, inline)
         kern = {name: profile_query(name) for name in ("enc_kernel", "dec_kernel", "conv2d", "gdn_forward")}
         _lib.lib().tfc_profile_enable(0)
-        # (b) the timed region: `depth` steps in flight over the CU partition
-        # the wave-per-stream coder wants one wave per SIMD: a quarter of a CU per image, at most half the chip
-        cus = coder_cus if coder_cus > 0 else min(128, max(16, (batch + 3) // 4))
-        software = partition.startswith("pipelined")
-        if software:
-            # ONE transform stream and ONE coder stream on complementary CU sets ("pipelined-plain": ordinary streams)
-            part = pipeline.CoderPartition(coder_cus=cus, depth=1, device=device,
-                                           mode="plain" if partition.endswith("plain") else "masked")
-            lanes, group = part.lanes, 1
-            run = lambda n: run_model_pipeline(model, x, n, pipeline.SoftwarePipeline(part.lanes[0]))
-        else:
-            part = pipeline.CoderPartition(coder_cus=cus, depth=depth, device=device, mode=partition) if depth > 1 else None
-            # `queue` steps enqueued per stream: a stream whose step has finished still has work while the host
-            # retires that step (waits for its end event, fetches strings and flags) and enqueues the next
-            lanes = list(part.lanes) * max(1, queue) if part else inline
-            group = group if hasattr(model, "compress_many") else 1
-            run = lambda n: run_model_steps(model, x, n, lanes, group=group)
+        # (b) the timed region: `queue` steps enqueued per lane — a stream whose step has finished still has work while
+        # the host retires that step (waits for its end event, fetches strings and flags) and enqueues the next
+        lanes = list(step_lanes.lanes) * max(1, queue)
+        group = group if hasattr(model, "compress_many") else 1
+        run = lambda n: run_model_steps(model, x, n, lanes, group=group)
         steps = max(group, steps - steps % group)
-        _lib.check(_lib.lib().tfc_set_chip_shared(1))      # several steps in flight: pipeline.chip_shared()
+        _lib.lib().tfc_set_chip_shared(1)                   # several steps in flight: pipeline.chip_shared()
         run(max(warmup, len(lanes), 2) * group)
         torch.cuda.synchronize()
         if distributed:
@@ -679,8 +665,7 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
         want = model.entropy_model.quantize(y_coded) if workload == "bls2017" else torch.round(y_coded.float()).to(y_coded.dtype)
         assert torch.equal(y_decoded, want), "decompress did not return the quantised latents"
         strings = rec.strings
-        counted = strings[:1] if group > 1 else strings          # a group's record holds one string array per batch
-        nbytes = sum(len(bytes(s)) for arr in counted for s in arr.reshape(-1))
+        nbytes = sum(len(bytes(s)) for arr in strings for s in arr.reshape(-1))
         if gathered:
             assert int(gathered[0][1][-1]) >= sum(len(bytes(s)) for s in strings[0].reshape(-1))
         res = None
@@ -695,11 +680,9 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
                 "workload": f"{workload} compress+decompress, {batch} images of {hw[1]}x{hw[0]} per GPU, 192 filters, "
                             f"random-init weights" + (", hyperprior calibrated (scale_index_histogram)" if hist is not None else ""),
                 "dtype": dtype_name,
-                "steps_in_flight": 3 if software else len(lanes) * group,
-                "streams": 2 if software else (len(part.lanes) if part else 1),
+                "steps_in_flight": len(lanes) * group,
+                "streams": len(step_lanes.lanes),
                 "steps_per_coder_launch": group,
-                "cu_partition": ({"mode": part.mode, "coder_cus": part.coder_cus, "transform_cus": part.total_cus - part.coder_cus}
-                                 if part else None),
                 "strings_fetched_to_host_in_timed_region": True,
                 "lone_step": {"ms_per_step": round(1e3 * lone_s / lone_steps, 3),
                               "mpixels_s": round(batch * hw[0] * hw[1] / 1e6 / (lone_s / lone_steps), 2),
@@ -721,8 +704,6 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, depth=
                 assert res["cpu_baseline"]["bytes_identical_to_gpu"], (
                     "GPU strings differ from the CPU reference's: %s" % json.dumps(res["cpu_baseline"]))
         del rec
-        if part:
-            part.close()
     return res
 
 
@@ -767,13 +748,18 @@ def conv_layer_table(device, batch=128):
     return {"workload": f"SignalConv2D layer shapes of bmshj2018 at {batch} x 768x512, bf16", "layers": rows}
 
 
+def model_group(args, workload):
+    return args.model_group if args.model_group > 0 else (8 if workload == "bmshj2018" else 1)
+
+
 def model_workload(args, world, rank, device, distributed):
     """`--workload bls2017|bmshj2018`: the model step as the headline line (BASELINE configs 1/4/5)."""
     import torch.distributed as dist
+    from compression_amd import pipeline
     res = model_bench(args.workload, args.model_dtype, device, batch=args.batch, steps=args.steps,
-                      warmup=args.warmup, depth=args.model_depth, coder_cus=args.coder_cus,
+                      warmup=args.warmup, lanes=pipeline.StepLanes(args.model_depth or 6, device),
                       cpu=not args.no_cpu_baseline, rank=rank, world=world, distributed=distributed,
-                      partition=args.partition, group=max(1, args.model_group), queue=args.model_queue)
+                      group=model_group(args, args.workload), queue=args.model_queue)
     if rank == 0:
         line = {
             "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
@@ -782,7 +768,7 @@ def model_workload(args, world, rank, device, distributed):
             "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.model_dtype, "data": "synthetic",
             "config": {"workload": res["workload"], "parallelism": f"batch-sharded x{world}",
-                       "steps_in_flight": res["steps_in_flight"], "cu_partition": res["cu_partition"],
+                       "steps_in_flight": res["steps_in_flight"], "steps_per_coder_launch": res["steps_per_coder_launch"],
                        "collectives": "broadcast of weights + tables at setup; per step all-gather of string "
                                       "lengths and padded bytes (RCCL)" if distributed else "none"},
         }
@@ -795,7 +781,7 @@ def model_workload(args, world, rank, device, distributed):
 
 
 def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_fraction, steps, inflight,
-           serial=True, fold=False):
+           serial=True, fold=False, to_host=False):
     """The coder round trip at BASELINE config 2 with `escape_fraction` of the symbols out of range: exactly
     `steps` steps, `inflight` per launch group.  Returns the measurements (every rank) — rank 0 formats."""
     import hashlib
@@ -807,6 +793,7 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
     # one stream: the launches of a group fill the chip on their own (a decoder workgroup takes a whole
     # CU's LDS), groups on different streams would only queue behind each other's workgroups
     side_streams = [torch.cuda.Stream(device=device)]
+    sink = HostSink(device, inflight) if to_host else None
     torch.cuda.synchronize()
 
     def run_steps(total_steps, depth, mode):
@@ -827,7 +814,7 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
             for g, k0 in enumerate(range(0, total_steps, depth)):
                 idx = [k % depth for k in range(k0, min(k0 + depth, total_steps))]
                 with torch.cuda.stream(side_streams[g % len(side_streams)]):
-                    for r, slot in zip(step_group(lookup_t, [slots[i] for i in idx], mode), idx):
+                    for r, slot in zip(step_group(lookup_t, [slots[i] for i in idx], mode, sink), idx):
                         results.append(r + (slot,))
         t_enqueued = time.perf_counter() - t0
         torch.cuda.synchronize()
@@ -900,6 +887,8 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
     blob0 = h0.blob.cpu().numpy()
     offs0 = h0.offsets.cpu().numpy().astype(np.int64)
     del strings, results
+    if sink is not None:
+        m["host_bytes"] = sink.bytes
     m.update(stages=stages, elapsed=elapsed, elapsed_local=elapsed_local, t_enqueued=t_enqueued, enc_tr=cenc_ms / max(cenc_n, 1), dec_tr=cdec_ms / max(cdec_n, 1),
              total_bytes=int(offs0[-1]), blob_sha=hashlib.sha256(blob0.tobytes()).hexdigest(),
              offs_sha=hashlib.sha256(offs0.tobytes()).hexdigest(), slot0=slots[0])
@@ -958,19 +947,13 @@ def main():
     ap.add_argument("--model-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model-depth", type=int, default=0,
                     help="streams that carry model steps (1: one step at a time; 0: 6 — measured, profiles/r03_notes.md)")
-    ap.add_argument("--coder-cus", type=int, default=0,
-                    help="compute units reserved for the coder streams of a model pipeline (0: one SIMD per image, "
-                         "at most half the chip)")
-    ap.add_argument("--partition", default="single", choices=["pipelined", "pipelined-plain", "masked", "plain", "single", "coder-masked", "transform-masked"],
-                    help="model steps: software-pipelined over ONE transform + ONE coder stream on disjoint CUs (pipelined; "
-                         "-plain: ordinary streams), or --model-depth whole steps in flight on CU-masked pairs, ordinary "
-                         "pairs, or one ordinary stream each")
-    ap.add_argument("--model-group", type=int, default=1,
-                    help="batches per coder launch where the model has compress_many (bls2017): the lane-per-stream "
-                         "kernels code them in one launch per direction where the tables' image fits the LDS (the "
-                         "random-init bls2017 tables do not: 172 KB); 1 = every batch its own launch")
+    ap.add_argument("--model-group", type=int, default=0,
+                    help="batches per coder launch (the models' compress_many / decompress_many: one launch per stage "
+                         "of the pipelined lane kernels for all of them, a handful of waves whatever the group); "
+                         "0: 8 for bmshj2018, 1 for bls2017 (its random-init tables' decoder image does not fit the LDS)")
     ap.add_argument("--model-queue", type=int, default=2, help="model steps enqueued per stream (--model-depth streams)")
-    ap.add_argument("--model-steps", type=int, default=32, help="timed steps of the `models` sub-objects")
+    ap.add_argument("--model-steps", type=int, default=0,
+                    help="timed steps of the `models` sub-objects (0: 32, and 128 where 8 batches share a coder launch)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -986,6 +969,9 @@ def main():
 
     if args.workload != "c2":
         return model_workload(args, world, rank, device, distributed)
+    # the streams of the model sub-objects, before anything else creates streams in this process
+    from compression_amd import pipeline
+    step_lanes = pipeline.StepLanes(args.model_depth or 6, device) if (not args.no_extras and world == 1) else None
 
     lookup = build_tables(device)
     lookup_t = torch.from_numpy(lookup)            # tables are uploaded once (cached per tensor)
@@ -1059,6 +1045,9 @@ def main():
                 "launch": "the coding calls of the steps in flight are one launch per direction "
                           "(tfc_encoder_encode_many / tfc_decoder_decode_many); every step keeps its own handles and strings",
                 "host_threads": 1,
+                "strings": "stay in HBM inside their handles in the timed region (device finalize; the decoders read them "
+                           "in place); sub-object strings_to_host: the same command with every string copied to pinned "
+                           "host memory inside the timed region",
                 "distinct_inputs": inflight,
                 "library_mode": "TFC_MODE_THROUGHPUT handles (one code stream per lane), deferred errors, "
                                 "device finalize" if lanes else "TFC_MODE_LATENCY handles (one wave per stream)",
@@ -1124,6 +1113,15 @@ def main():
         del m
         if extras:
             torch.set_num_threads(1)
+            mh = c2_run(args, lookup, lookup_t, device, 1, 0, False, args.escape_fraction, args.steps, args.inflight,
+                        serial=False, to_host=True)
+            out["strings_to_host"] = {
+                "value": round(STREAMS * PIXELS_PER_STREAM / 1e6 / (mh["elapsed"] / args.steps), 2), "unit": "Mpixels/s",
+                "ms_per_step": round(1e3 * mh["elapsed"] / args.steps, 4),
+                "host_mbytes_per_step": round(mh["host_bytes"] / 1e6 / max(1, args.steps + args.steps), 3),
+                "note": "offsets, then exactly the bytes, device -> pinned host on a second stream while the decoders run; "
+                        "the host thread waits once per group, for the encoder"}
+            del mh
             if args.escape_fraction == 0.0:
                 out["escapes"] = {
                     "0.01": escape_object(args, lookup, lookup_t, device, 0.01, out.get("cpu_baseline", {}).get("value")),
@@ -1134,11 +1132,11 @@ def main():
             out["models"] = {}
             for name, key in (("bls2017", "c1"), ("bmshj2018", "c4")):
                 torch.cuda.empty_cache()
+                g = model_group(args, name)
                 out["models"][key] = model_bench(name, args.model_dtype, device,
-                                                 steps=max(args.model_steps, 2 * max(1, args.model_group)),
-                                                 warmup=2, depth=args.model_depth, coder_cus=args.coder_cus,
-                                                 cpu=not args.no_cpu_baseline, partition=args.partition,
-                                                 group=max(1, args.model_group), queue=args.model_queue)
+                                                 steps=args.model_steps or (32 if g == 1 else 16 * g),
+                                                 warmup=2, lanes=step_lanes, cpu=not args.no_cpu_baseline,
+                                                 group=g, queue=args.model_queue)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

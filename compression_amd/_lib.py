@@ -22,16 +22,12 @@ SIGNATURES = {
     "tfc_profile_enable": (None, [_int]),
     "tfc_set_default_mode": (_int, [_int]),
     "tfc_get_default_mode": (_int, []),
-    "tfc_set_coder_gate": (_int, [_vp]),
     "tfc_set_chip_shared": (_int, [_int]),
     "tfc_image_to_unit": (_int, [_vp, _vp, _int, C.c_int64, _vp]),
     "tfc_unit_to_image": (_int, [_vp, _int, _vp, C.c_int64, _vp]),
     "tfc_index_prepare": (_int, [_vp, _int, _vp, C.c_int64, _int, _vp]),
     "tfc_cache_bytes": (_int, [C.POINTER(C.c_longlong)]),
     "tfc_cache_trim": (_int, [C.POINTER(C.c_longlong)]),
-    "tfc_device_compute_units": (_int, [C.POINTER(_int)]),
-    "tfc_stream_create_cu_mask": (_int, [_vp, _int, C.POINTER(_vp)]),
-    "tfc_stream_destroy": (_int, [_vp]),
     "tfc_encoder_capacity": (_int, [_vp, C.POINTER(_i64)]),
     "tfc_profile_query": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "tfc_pipe_counters": (_int, [C.POINTER(_i64), C.POINTER(_i64)]),
@@ -48,6 +44,8 @@ SIGNATURES = {
     "tfc_encoder_encode_quantized_indexed": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _vp]),
     "tfc_encoder_encode_quantized_many": (_int, [_int, _vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
     "tfc_decoder_decode_dequantized_many": (_int, [_int, _vp, _vp, _int, _vp, _vp, _i64, _i64, _vp]),
+    "tfc_encoder_encode_quantized_indexed_many": (_int, [_int, _vp, _vp, _int, _vp, _vp, _i64, _vp]),
+    "tfc_decoder_decode_dequantized_indexed_many": (_int, [_int, _vp, _vp, _vp, _int, _vp, _i64, _vp]),
     "tfc_encoder_finalize": (_int, [_vp, _vp, C.POINTER(_i64)]),
     "tfc_encoder_finalize_device": (_int, [_vp, _vp]),
     "tfc_encoder_finalize_device_many": (_int, [_int, _vp, _vp]),

@@ -102,18 +102,7 @@ ProfileEntry& profile_entry(const char* name) {
 
 bool profiling_enabled() { return g_profile_on; }
 
-// The caller's "coder gate" (tfc_set_coder_gate): recorded ONCE on the launch stream, immediately in front of the
-// next long coding kernel — a launch that carries the "enc_kernel" / "dec_kernel" timer — of this host thread.
-namespace {
-thread_local hipEvent_t g_coder_gate = nullptr;
-}
-
 KernelTimer::KernelTimer(const char* n, hipStream_t s) : name(n), st(s), on(g_profile_on), slow(n, "launch scope", 0) {
-  if (g_coder_gate && (std::strcmp(n, "enc_kernel") == 0 || std::strcmp(n, "dec_kernel") == 0))
-  {
-    (void)hipEventRecord(g_coder_gate, st);
-    g_coder_gate = nullptr;                     // one shot: the FIRST long coding kernel after tfc_set_coder_gate
-  }
   if (!on) return;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
@@ -135,14 +124,9 @@ namespace {
 std::atomic<int> g_chip_shared{0};      // tfc_set_chip_shared
 }
 
+// -> the previous value, so that nested users can restore it
 extern "C" int tfc_set_chip_shared(int shared) {
-  g_chip_shared.store(shared ? 1 : 0, std::memory_order_relaxed);
-  return 0;
-}
-
-extern "C" int tfc_set_coder_gate(void* event) {
-  tfc::g_coder_gate = static_cast<hipEvent_t>(event);
-  return 0;
+  return g_chip_shared.exchange(shared ? 1 : 0, std::memory_order_relaxed);
 }
 
 namespace {
@@ -1439,51 +1423,21 @@ TableView view_of(const tfc_tables* t) {
   return v;
 }
 
-// LDS requested per workgroup of the fast kernels: what they need, or TFC_MIN_LDS_KB if that is more.
-// The dispatcher packs as many workgroups of a launch onto a CU as fit; asking for > 80 KB keeps a lone
-// launch at one workgroup (one wave per SIMD) per CU — lower latency for a single step, at the price of
-// half the residency when several steps are in flight.
-inline size_t lds_request(size_t need) {
-  static const size_t floor_bytes = [] {
-    const char* e = std::getenv("TFC_MIN_LDS_KB");
-    const long n = e ? std::strtol(e, nullptr, 10) : 0;
-    return static_cast<size_t>(n > 0 && n <= 160 ? n : 0) * 1024;
-  }();
-  return std::max(need, floor_bytes);
-}
+inline size_t lds_request(size_t need) { return need; }
 
-// Waves (= code streams) that share one LDS copy of the tables.  4 keeps a lone 512-stream
-// launch at one wave per SIMD; TFC_WAVES_PER_BLOCK=8 puts 8 streams behind one table copy (measured
-// slower, also with many launches in flight).
-// Waves a workgroup of `streams` code streams gets: the limit (one wave per SIMD of a CU) whenever there are that many
-// streams.  Fewer, fuller workgroups: a CU that hosts even one coder wave is lost to a convolution workgroup — which
-// wants all four SIMDs' registers — for as long as that wave runs, so with model steps in flight 128 streams as 64
-// workgroups of 2 waves cost the transforms twice the CUs of 32 workgroups of 4 (C4: 47.2 -> 45.2 ms per step; 8 or 16
-// waves per workgroup, two or four per SIMD: 51.2 / 63.5).  TFC_PACK_WAVES=0: the old spread (a wave per 64 streams).
-inline int64_t waves_per_block_limit();
-inline bool waves_per_block_given() { return std::getenv("TFC_WAVES_PER_BLOCK") != nullptr; }
+// Waves (= code streams) of a workgroup of the wave-per-stream kernels, sharing one LDS copy of the tables: one wave
+// per SIMD of a CU whenever there are that many streams.  Fewer, fuller workgroups: a CU that hosts even one coder wave
+// is lost to a convolution workgroup — which wants all four SIMDs' registers — for as long as that wave runs, so with
+// model steps in flight 128 streams as 64 workgroups of 2 waves cost the transforms twice the CUs of 32 workgroups of
+// 4 (C4: 47.2 -> 45.2 ms per step; 8 or 16 waves per workgroup, two or four per SIMD: 51.2 / 63.5; measured in round 3).
 inline int64_t waves_wanted(int64_t streams) {
-  static const bool pack = [] {
-    const char* e = std::getenv("TFC_PACK_WAVES");
-    return !e || std::atoi(e) != 0;
-  }();
-  static const bool given = waves_per_block_given();
   // tfc_set_chip_shared(1) — the caller keeps other kernels in flight beside the coder's: 512 streams and more get two
   // waves per SIMD, i.e. 64 instead of 128 CUs under a bls2017 batch (C1: 12.0 -> 11.1 ms per step with 8 steps in
   // flight; a lone 512-stream call is 1.4x slower that way, 6.5 -> 8.8 ms, hence not the default); for 128 streams the
   // same packing costs more than it frees (profiles/r03_notes.md)
   const bool shared = g_chip_shared.load(std::memory_order_relaxed) != 0;
-  const int64_t limit = given ? waves_per_block_limit() : (pack && shared && streams >= 512 ? 8 : waves_per_block_limit());
-  const int64_t spread = std::max<int64_t>(1, pack ? streams : ceil_div(streams, 64));
-  return std::min<int64_t>(limit, spread);
-}
-inline int64_t waves_per_block_limit() {
-  static const int64_t v = [] {
-    const char* e = std::getenv("TFC_WAVES_PER_BLOCK");
-    const long n = e ? std::strtol(e, nullptr, 10) : 4;
-    return static_cast<int64_t>(n >= 1 && n <= 16 ? n : 4);
-  }();
-  return v;
+  const int64_t limit = shared && streams >= 512 ? 8 : 4;
+  return std::min<int64_t>(limit, std::max<int64_t>(1, streams));
 }
 
 // Which kernels a handle uses.  The lane-per-stream kernels issue ~1 vector instruction per symbol
@@ -1492,8 +1446,6 @@ inline int64_t waves_per_block_limit() {
 // outnumber the chip's SIMDs several times.  AUTO decides on the stream count of the handle alone;
 // a caller that keeps many calls in flight asks for TFC_MODE_THROUGHPUT.
 int select_family(const tfc_tables* t, int mode, int64_t streams, int64_t elems, bool fast_ok) {
-  const char* force = std::getenv("TFC_FORCE_GENERIC");
-  if (force && force[0] == '1') return kGeneric;
   // the lane kernels address a stream's bytes with 32 bits, and their LDS plan (image + one wave's
   // staging planes, any variant of the encoder) has to fit the CU
   const bool lanes_ok = t->lanes_ok && elems < (int64_t{1} << 29) &&
@@ -1509,15 +1461,8 @@ int select_family(const tfc_tables* t, int mode, int64_t streams, int64_t elems,
 }
 
 // Blocks a wave of the lane kernels lets lanes wait in front of an escape code before it takes the codes of all
-// waiting lanes together (LaneArgs::defer; 1 = after every block).
-inline int lanes_escape_defer() {
-  static const int v = [] {
-    const char* e = std::getenv("TFC_ESCAPE_DEFER");
-    const long n = e ? std::strtol(e, nullptr, 10) : 3;
-    return static_cast<int>(n >= 1 && n <= 64 ? n : 3);
-  }();
-  return v;
-}
+// waiting lanes together (LaneArgs::defer; measured in round 3: 3).
+inline int lanes_escape_defer() { return 3; }
 
 // Streams per workgroup of the lane kernels: one wave (64 streams) until the launch fills the chip,
 // so that a 512-stream call spreads over eight CUs (and XCDs), then more waves behind each LDS image.
@@ -1727,16 +1672,6 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
           hipLaunchKernelGGL(enc_chain_kernel, dim3(static_cast<unsigned>(groups)), dim3(64), 0, st, cj, pa);
         }
         la.guard = pa.fallback;
-        if (std::getenv("TFC_PIPE_DEBUG")) {
-          TFC_HIP(hipStreamSynchronize(st));
-          std::vector<unsigned int> ends(groups * pa.nt), fb(64);
-          TFC_HIP(hipMemcpy(ends.data(), pa.tileend, sizeof(unsigned int) * ends.size(), hipMemcpyDeviceToHost));
-          TFC_HIP(hipMemcpy(fb.data(), pa.fallback, 256, hipMemcpyDeviceToHost));
-          std::fprintf(stderr, "[pipe enc] elems %lld streams %lld jobs %d rows %d nt %d fallback0 %u ends:", (long long)elems,
-                       (long long)streams, gn, pa.rows, pa.nt, fb[0]);
-          for (size_t i = 0; i < std::min<size_t>(ends.size(), 12); ++i) std::fprintf(stderr, " %x", ends[i]);
-          std::fprintf(stderr, "\n");
-        }
       }
       const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
       if (pipe && !pipe_fallback_launch()) {}
@@ -2276,6 +2211,50 @@ extern "C" int tfc_encoder_encode_quantized_many(int n, tfc_encoder* const* es, 
 }
 
 namespace {
+template <typename T>
+int encode_quantized_indexed_many(int n, tfc_encoder* const* es, const void* const* ys, const int32_t* const* indexes,
+                                  const int32_t* cdf_offset, int64_t elems, hipStream_t st) {
+  bool batch = elems > 0 && elems < (int64_t{1} << 29);
+  for (int k = 0; k < n; ++k) {
+    tfc_encoder* e = es[k];
+    if (!indexes[k]) return fail("index is null");
+    if (encode_precheck(e, elems)) return 1;
+    e->touch(st);
+    if (e->tables != es[0]->tables || e->streams != es[0]->streams)
+      return fail("tfc_encoder_encode_quantized_indexed_many: handles must share tables and stream count");
+    if (e->streams == 0 || e->tables->rows.empty()) batch = false;
+    if (batch && e->family < 0) e->family = select_family(e->tables, e->mode, e->streams * n, elems, e->fast);
+    if (e->family != kLanes) batch = false;
+  }
+  std::vector<tfc::SymQuant<T>> srcs(n);
+  for (int k = 0; k < n; ++k) srcs[k] = tfc::SymQuant<T>{static_cast<const T*>(ys[k]), nullptr, cdf_offset};
+  if (!batch) {
+    for (int k = 0; k < n; ++k)
+      if (run_encode(es[k], indexes[k], elems, srcs[k], st)) return 1;
+    return 0;
+  }
+  return encode_lanes_many(es, n, srcs.data(), indexes, elems, st, false);
+}
+}  // namespace
+
+// EntropyEncodeIndex with the quantise prologue for n independent handles (same tables, same geometry) as one
+// coding launch — tfc_encoder_encode_quantized_indexed x tfc_encoder_encode_many: the main latents of several
+// batches of a hyperprior model (continuous_indexed.py:355-386) behind one launch.
+extern "C" int tfc_encoder_encode_quantized_indexed_many(int n, tfc_encoder* const* es, const void* const* ys, int dtype,
+                                                         const int32_t* const* indexes, const int32_t* cdf_offset,
+                                                         int64_t elems, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return 0;
+  if (!indexes) return fail("index is null");
+  switch (dtype) {
+    case 0: return encode_quantized_indexed_many<float>(n, es, ys, indexes, cdf_offset, elems, st);
+    case 1: return encode_quantized_indexed_many<__hip_bfloat16>(n, es, ys, indexes, cdf_offset, elems, st);
+    case 2: return encode_quantized_indexed_many<__half>(n, es, ys, indexes, cdf_offset, elems, st);
+    default: return fail("unsupported dtype code %d", dtype);
+  }
+}
+
+namespace {
 
 // Tail + lengths + offsets on the device; `exact` = synchronise to size the blob exactly, otherwise
 // the blob gets the slabs' total capacity and nothing is read back.
@@ -2740,11 +2719,7 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   p.state = d->state.as<uint4>();
   p.first_error = d->status.as<unsigned long long>();
   p.only_flagged = nullptr;
-  p.blocks_after_escape = [] {
-    const char* e = std::getenv("TFC_BLOCKS_AFTER_ESCAPE");
-    const long n = e ? std::strtol(e, nullptr, 10) : 64;
-    return static_cast<int>(n >= 0 && n <= 1024 ? n : 64);
-  }();
+  p.blocks_after_escape = 64;
   const size_t lds = table_lds_bytes(t);
   const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
   const size_t fast_lds = sizeof(int32_t) * ((t->dec_words + 3) & ~3) + sizeof(int4) * t->rows.size();
@@ -2876,6 +2851,47 @@ extern "C" int tfc_decoder_decode_dequantized_many(int n, tfc_decoder* const* ds
     case 0: return decode_dequantized_many<float>(n, ds, ys, qoffset, cdf_offset, elems, st);
     case 1: return decode_dequantized_many<__hip_bfloat16>(n, ds, ys, qoffset, cdf_offset, elems, st);
     case 2: return decode_dequantized_many<__half>(n, ds, ys, qoffset, cdf_offset, elems, st);
+    default: return fail("unsupported dtype code %d", dtype);
+  }
+}
+
+namespace {
+template <typename T>
+int decode_dequantized_indexed_many(int n, tfc_decoder* const* ds, const int32_t* const* indexes, void* const* ys,
+                                    const int32_t* cdf_offset, int64_t elems, hipStream_t st) {
+  bool batch = elems > 0 && elems < (int64_t{1} << 29);
+  for (int k = 0; k < n; ++k) ds[k]->touch(st);
+  for (int k = 0; k < n; ++k) {
+    const tfc_decoder* d = ds[k];
+    if (!indexes[k]) return fail("index is null");
+    if (d->tables != ds[0]->tables || d->streams != ds[0]->streams)
+      return fail("tfc_decoder_decode_dequantized_indexed_many: handles must share tables and stream count");
+    if (d->streams == 0 || d->tables->rows.empty()) batch = false;
+    if (batch && decoder_family<int32_t>(d, d->streams * n, elems, true, true) != kLanes) batch = false;
+  }
+  std::vector<OutDequant<T>> dsts(n);
+  for (int k = 0; k < n; ++k) dsts[k] = OutDequant<T>{static_cast<T*>(ys[k]), nullptr, cdf_offset};
+  if (!batch) {
+    for (int k = 0; k < n; ++k)
+      if (run_decode(ds[k], indexes[k], elems, dsts[k], st)) return 1;
+    return 0;
+  }
+  return decode_lanes_many(ds, n, dsts.data(), indexes, elems, st);
+}
+}  // namespace
+
+// EntropyDecodeIndex with the dequantise epilogue for n independent handles as one coding launch.
+extern "C" int tfc_decoder_decode_dequantized_indexed_many(int n, tfc_decoder* const* ds, const int32_t* const* indexes,
+                                                           void* const* ys, int dtype, const int32_t* cdf_offset,
+                                                           int64_t elems, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return 0;
+  if (elems < 0) return fail("negative element count");
+  if (!indexes) return fail("index is null");
+  switch (dtype) {
+    case 0: return decode_dequantized_indexed_many<float>(n, ds, indexes, ys, cdf_offset, elems, st);
+    case 1: return decode_dequantized_indexed_many<__hip_bfloat16>(n, ds, indexes, ys, cdf_offset, elems, st);
+    case 2: return decode_dequantized_indexed_many<__half>(n, ds, indexes, ys, cdf_offset, elems, st);
     default: return fail("unsupported dtype code %d", dtype);
   }
 }

@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   // escape codes per stream (appended in phase A, put in order in phase B):
   // position | neg << 8 | extra calls << 9 | low 16 bits of gamma << 16 (all of gamma when extra < 34)
   __shared__ unsigned int esc[64][kPipeEscMax];
+  __shared__ unsigned short ecum[64][kPipeEscMax];        // extra calls of the stream's escape codes before this one
   __shared__ unsigned int ecount[64], cnt[64], nesc[64], tmax, tstart;
 
   const unsigned int gi = blockIdx.x % static_cast<unsigned int>(pa.groups);
@@ -211,7 +212,10 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
       for (; b > 0u && (esc[tid][b - 1u] & 0xFFu) > (x & 0xFFu); --b) esc[tid][b] = esc[tid][b - 1u];
       esc[tid][b] = x;
     }
-    for (unsigned int a = 0; a < n; ++a) cum += (esc[tid][a] >> 9) & 0x7Fu;
+    for (unsigned int a = 0; a < n; ++a) {
+      ecum[tid][a] = static_cast<unsigned short>(cum);
+      cum += (esc[tid][a] >> 9) & 0x7Fu;
+    }
     cnt[tid] = valid + cum;
     nesc[tid] = n;
     atomicMax(&tmax, valid + cum);
@@ -241,44 +245,39 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   __syncthreads();
   if (tstart == 0xFFFFFFFFu) return;
 
-  // ---- phase C: rows out, transposed: thread (r, l) writes rows r, r + 8, ... of lane l; rows behind a lane's
-  // last call, up to the next whole block, hold "no call" --------------------------------------------------
+  // ---- phase C: rows out, transposed (a wave = the 64 lanes of one row: one coalesced store).  Three passes, each
+  // with a thread (q, l) taking every 8th item of lane l: the plain call words from their symbol's position to its
+  // row (position + extra calls of the escape codes before it), the bit rows of the escape codes, and "no call" for
+  // the rows behind a lane's last call up to the next whole block ------------------------------------------
   {
-    constexpr unsigned int kRowsPerPass = kExpandThreads / 64;
-    const unsigned int l = lane;
+    constexpr unsigned int kPass = kExpandThreads / 64;
+    const unsigned int l = lane, q = tid >> 6;
     const unsigned int mx = (tmax + kPipeBlock - 1u) & ~(kPipeBlock - 1u), mine = cnt[l], ne = nesc[l];
-    unsigned int* const out = pa.calls + (static_cast<size_t>(gi) * pa.rows + tstart) * 64 + l;
-    unsigned int i = 0u;                  // first escape code whose rows do not all lie before row r
-    unsigned int start = 0u, extra = 0u, cumi = 0u, epos = 0u, neg = 0u, glow = 0u;
-    auto fetch = [&]() {
-      if (i < ne) {
-        const unsigned int e = esc[l][i];
-        epos = e & 0xFFu;
-        neg = (e >> 8) & 1u;
-        extra = (e >> 9) & 0x7Fu;
-        glow = e >> 16;
-        start = epos + cumi;              // row of the escape symbol's own call; its bits: the `extra` rows behind it
-      }
-    };
-    fetch();
-    for (unsigned int r = tid >> 6; r < mx; r += kRowsPerPass) {
-      unsigned int w = kPipeNoCall;
-      if (r < mine) {
-        while (i < ne && r > start + extra) {
-          cumi += extra;
+    const unsigned int first = __builtin_amdgcn_readfirstlane(tstart);
+    unsigned int* const out = pa.calls + (static_cast<size_t>(gi) * pa.rows + first) * 64;
+    const unsigned int valid = min(static_cast<unsigned int>(kPipeTile), elems > T * kPipeTile ? elems - T * kPipeTile : 0u);
+    const unsigned int nsym = s0 + l < jobs.streams ? valid : 0u;
+    {
+      unsigned int i = 0u, cum = 0u;
+      unsigned int nextpos = ne ? (esc[l][0] & 0xFFu) : 0xFFFFFFFFu;
+      for (unsigned int p = q; p < nsym; p += kPass) {
+        while (nextpos < p) {                 // escape codes in front of symbol p: their bits push it back
+          cum += (esc[l][i] >> 9) & 0x7Fu;
           ++i;
-          fetch();
+          nextpos = i < ne ? (esc[l][i] & 0xFFu) : 0xFFFFFFFFu;
         }
-        if (i < ne && r > start) {
-          unsigned int g = glow, ng;
-          if (extra >= 34u) escape_of(s0 + l, T * kPipeTile + epos, g, ng);      // 2^16 and more: the value again
-          w = pipe_escape_word(g, neg, extra, r - start);
-        } else {
-          w = W[l * kRow + (r - cumi)];
-        }
+        out[(p + cum) * 64u + l] = W[l * kRow + p];
       }
-      out[static_cast<size_t>(r) * 64] = w;
     }
+    for (unsigned int i = q; i < ne; i += kPass) {
+      const unsigned int e = esc[l][i];
+      const unsigned int epos = e & 0xFFu, neg = (e >> 8) & 1u, extra = (e >> 9) & 0x7Fu;
+      unsigned int g = e >> 16, ng;
+      if (extra >= 34u) escape_of(s0 + l, T * kPipeTile + epos, g, ng);      // 2^16 and more: the value again
+      const unsigned int row = epos + ecum[l][i];                              // the escape symbol's own call
+      for (unsigned int k = 1; k <= extra; ++k) out[(row + k) * 64u + l] = pipe_escape_word(g, neg, extra, k);
+    }
+    for (unsigned int r = mine + q; r < mx; r += kPass) out[r * 64u + l] = kPipeNoCall;
   }
 }
 

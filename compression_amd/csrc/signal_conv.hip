@@ -1197,17 +1197,12 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     if (!d.gcount) continue;
     const int chv = ntv == 25 ? 5 : ntv == 4 ? 4 : 3;
     const size_t lds = 2 * patch_bytes + 2 * static_cast<size_t>((chv * c.tiles * 64 + 255) / 256) * 4096;
-    // One workgroup per block (its items = the launch's groups).  The kernel can run persistently — any smaller grid
-    // makes a workgroup take every W-th block, TFC_CONV3_PERSISTENT=1 launches one per CU — and alone on the chip that is
-    // the same speed; but a model step shares the chip with the other steps in flight, and workgroups that hold their
-    // CU for the whole launch keep those kernels out: C4 51.6 instead of 47.6 ms per step (profiles/r03_notes.md).
-    static const bool persistent = [] {
-      const char* e = std::getenv("TFC_CONV3_PERSISTENT");
-      return e && std::atoi(e) != 0;
-    }();
+    // One workgroup per block (its items = the launch's groups).  (A grid of one workgroup per CU, each taking every
+    // W-th block, is the same speed alone on the chip but keeps the kernels of other steps in flight out of its CUs:
+    // C4 51.6 instead of 47.6 ms per step, profiles/r03_notes.md.)
     const long long nblk = c.N * d.BXn * d.BYn;
     if (nblk >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
-    const dim3 grid(static_cast<unsigned>(persistent ? std::min<long long>(nblk, cus) : nblk));
+    const dim3 grid(static_cast<unsigned>(nblk));
 #define TFC_CONV3_LAUNCH(NT, CHV, NCHV, NPGV)                                                              \
     do {                                                                                                   \
       TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV>),  \
@@ -1617,8 +1612,7 @@ __global__ void __launch_bounds__(256, 2) conv_image_kernel(const __bf16* x, con
 // 0 = launched, -1 = not this shape, > 0 = error
 int run_conv_image(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
                    int64_t cin, int64_t cout, int kh, int kw, int stride, int activation, hipStream_t st) {
-  static const bool off = [] { const char* e = std::getenv("TFC_CONV_IMAGE_KERNEL"); return e && std::atoi(e) == 0; }();
-  if (off || cin > 4 || (cout != 128 && cout != 192) || (stride != 2 && stride != 4) || (stride * cin) % 2) return -1;
+  if (cin > 4 || (cout != 128 && cout != 192) || (stride != 2 && stride != 4) || (stride * cin) % 2) return -1;
   ImageConvGeom g{};
   g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin); g.Cout = static_cast<int>(cout);
   g.kh = kh; g.kw = kw; g.sd = stride; g.py0 = kh / 2; g.px0 = kw / 2; g.activation = activation;
@@ -1675,30 +1669,25 @@ struct UpFusedGeom {
   int BXn, BYn;
   int NC;                   // kh * kw * Cout product columns
   int activation;
-  // passes: 1 = all taps at once (NC <= 84 columns); s = one pass per residue r of the kernel ROW index modulo s — the taps
-  // ty = r, r + s, ... are exactly those of the output rows with (oy + kh/2) mod s = r — for kernels whose kh * kw * Cout
-  // products do not fit the LDS row (bls2017: 9 x 9 x 3 = 243; a pass has 3 or 2 kernel rows: 81 / 54 columns)
-  int passes;
 };
 constexpr int kUpZStride = 84;      // floats per patch pixel in LDS
 constexpr int kUpColTiles = 3;      // 96 >= NC columns
 
-__global__ void conv_up_fused_weights_kernel(const float* w, int kh, int kw, int cin, int cout, int passes,
-                                             bf16x8* packed) {
-  // A fragments: packed[((pass * cb + ks) * kUpColTiles + t) * 64 + lane], lane (i, h): K offsets 8h .. 8h + 7 of step ks,
-  // column 32t + i = ((jy * kw + tx) * cout + c), kernel row ty = pass + jy * passes (one pass: ty = jy)
+__global__ void conv_up_fused_weights_kernel(const float* w, int kh, int kw, int cin, int cout, bf16x8* packed) {
+  // A fragments: packed[(ks * kUpColTiles + t) * 64 + lane], lane (i, h): K offsets 8h .. 8h + 7 of step ks,
+  // column 32t + i = ((ty * kw + tx) * cout + c)
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int cb = cin / 16;
-  const int total = passes * cb * kUpColTiles * 64;
+  const int total = cb * kUpColTiles * 64;
   if (idx >= total) return;
   const int lane = idx & 63;
   int r = idx >> 6;
   const int t = r % kUpColTiles; r /= kUpColTiles;
-  const int ks = r % cb, pass = r / cb;
+  const int ks = r % cb;
   const int col = 32 * t + (lane & 31), h = lane >> 5;
   const int jy = col / (kw * cout), rem = col % (kw * cout);
   const int tx = rem / cout, c = rem % cout;
-  const int ty = passes == 1 ? jy : pass + jy * passes;
+  const int ty = jy;
   bf16x8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -1743,14 +1732,12 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
   float bc[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias)
     for (int c = 0; c < cout; ++c) bc[c] = bias[c];
-  for (int pass = 0; pass < g.passes; ++pass) {
-  if (pass) __syncthreads();                         // the previous pass's gather is done with z
   u32x4 bq[PF];
   unsigned int off = tile_offset(wid);
 #pragma unroll
   for (int k = 0; k < PF; ++k) bq[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, (k < cb ? k : cb - 1) * 32, 0);
   {
-    const bf16x8* src = wpk + static_cast<size_t>(pass) * cb * kUpColTiles * 64;
+    const bf16x8* src = wpk;
     for (int i = tid; i < cb * kUpColTiles * 64; i += kUpThreads) wl[i] = src[i];
   }
   __syncthreads();
@@ -1790,15 +1777,13 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
       }
   }
   __syncthreads();
-  // ---- gather: thread -> 4 consecutive output pixels of the (8 s) x (32 s) output tile (several passes: of its rows
-  // with this pass's residue) ----
+  // ---- gather: thread -> 4 consecutive output pixels of the (8 s) x (32 s) output tile ----
   for (int grp = tid; grp < th * (tw / 4); grp += kUpThreads) {
     const int ry = grp / (tw / 4), rx = (grp % (tw / 4)) * 4;
     const int oy = by * th + ry;
     if (oy >= OH) continue;
     // o = i*s + t - k/2  =>  t = (o + k/2) mod s, + s, ... ;  i = (o + k/2 - t) / s
     const int ty0 = (oy + kh / 2) % s;
-    if (g.passes > 1 && ty0 != pass) continue;
     const int py0 = (oy + kh / 2 - ty0) / s - (by * 8 - g.dmax_y);       // patch row of tap ty0; ty0 + s: one row up
     unsigned short outv[16];
 #pragma unroll
@@ -1816,7 +1801,7 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
           const int tx = tx0 + jx * s;
           if (tx >= kw) break;
           const float* zp = z + static_cast<size_t>((py0 - jy) * g.PW + (px0 - jx)) * kUpZStride +
-                            ((g.passes > 1 ? jy : ty) * kw + tx) * cout;
+                            (ty * kw + tx) * cout;
 #pragma unroll
           for (int c = 0; c < (COUT ? COUT : 4); ++c)
             if (c < cout) a[c] += zp[c];
@@ -1838,7 +1823,6 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
         if (c < cout) dst[k * cout + c] = __builtin_bit_cast(__bf16, outv[k * 4 + c]);
     }
   }
-  }     // passes
 }
 
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
@@ -1848,8 +1832,7 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
 // Fused variant of the transposed convolution into few channels: 0 = launched, -1 = not this shape, > 0 = error.
 int run_conv_up_fused(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
                       int64_t cin, int64_t cout, int kh, int kw, int stride, int activation, hipStream_t st) {
-  static const bool unfused = [] { const char* e = std::getenv("TFC_CONV_UP_UNFUSED"); return e && std::atoi(e) != 0; }();
-  if (unfused || cout > 4 || cin % 64 || stride < 2) return -1;
+  if (cout > 4 || cin % 64 || stride < 2) return -1;
   auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
   UpFusedGeom g{};
   g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin);
@@ -1860,25 +1843,17 @@ int run_conv_up_fused(const void* x, const float* w, const float* bias, void* y,
   g.PH = 8 + g.dmax_y - dmin_y; g.PW = 32 + g.dmax_x - dmin_x;
   g.BXn = (g.W + 31) / 32; g.BYn = (g.H + 7) / 8;
   g.NC = kh * kw * g.Cout;
-  // all taps at once, or a pass per kernel-row residue (its (kh - r + s - 1) / s rows x kw x Cout columns)
-  g.passes = 1;
-  if (g.NC > kUpZStride) {
-    // measured level with the implicit GEMM over output pixels (bls2017's 9x9 x4 into 3 channels at 512 x 64x64: 1.22
-    // against 1.21 ms — four passes over the patch cost what the products' round trip through HBM saved), so it is
-    // opt-in: TFC_CONV_UP_PASSES=1
-    const char* e = std::getenv("TFC_CONV_UP_PASSES");
-    if (!e || std::atoi(e) == 0) return -1;
-    g.passes = stride;
-    if (((kh + stride - 1) / stride) * kw * g.Cout > kUpZStride) return -1;
-  }
+  // all kh * kw * Cout tap products of a patch pixel in one LDS row; kernels with more of them (bls2017's 9 x 9 x 3)
+  // keep the implicit GEMM over output pixels (a pass per kernel-row residue was built and measured level with it)
+  if (g.NC > kUpZStride) return -1;
   const int tiles = (g.PH * g.PW + 31) / 32;
   const size_t lds = static_cast<size_t>(tiles) * 32 * kUpZStride * 4 + static_cast<size_t>(cin / 16) * kUpColTiles * 64 * 16;
   if (lds > 160 * 1024 || n * g.BXn * g.BYn >= (1ll << 31)) return -1;
   DevBuf wpk;
-  const int frags = g.passes * static_cast<int>(cin / 16) * kUpColTiles * 64;
+  const int frags = static_cast<int>(cin / 16) * kUpColTiles * 64;
   TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
   hipLaunchKernelGGL(conv_up_fused_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, kh, kw,
-                     static_cast<int>(cin), static_cast<int>(cout), g.passes, wpk.as<bf16x8>());
+                     static_cast<int>(cin), static_cast<int>(cout), wpk.as<bf16x8>());
   KernelTimer timer("conv2d", st);
 #define TFC_UP_FUSED_LAUNCH(...)                                                                              \
   do {                                                                                                       \

@@ -2,6 +2,8 @@
 (python/entropy_models/continuous_indexed.py:30-633)."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -207,6 +209,83 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         if self.decode_sanity_check and not bool(sanity.all()):
             raise RuntimeError("Sanity check failed.")
         return out
+
+    def compress_many(self, bottlenecks, indexes):
+        """compress() of several independent batches (same shapes) with ONE coder launch per stage
+        (tfc_encoder_encode_quantized_indexed_many: the pipelined lane kernels quantise and look the tables up in
+        their parallel expansion pass; the serial chain of all batches' streams is one small grid).  Nothing is read
+        back: one finalized encoder handle per batch (`gen_ops.fetch_strings`, `decompress_many`); same strings as
+        compress() batch by batch.  `indexes`: one tensor per batch (continuous_indexed.py:355-386)."""
+        self._check_compression()
+        device = _lib.require_device()
+        bottlenecks = [torch.as_tensor(b).to(device, self.bottleneck_dtype).contiguous() for b in bottlenecks]
+        flats = [self._table_indexes(torch.as_tensor(i).to(device)) for i in indexes]
+        if not bottlenecks:
+            return []
+        if len(flats) != len(bottlenecks):
+            raise ValueError("compress_many: one index tensor per bottleneck")
+        shape = tuple(flats[0].shape)
+        if any(tuple(f.shape) != shape for f in flats) or any(tuple(b.shape) != tuple(bottlenecks[0].shape) for b in bottlenecks):
+            raise ValueError("compress_many: all batches must have the same shape")
+        batch_shape = shape[:len(shape) - self.coding_rank] if self.coding_rank else shape
+        cdf_offset = self._device_offsets(device)
+        n = len(bottlenecks)
+        handles = gen_ops.create_range_encoders(n, batch_shape, self.cdf, mode="throughput", deferred_errors=True)
+        if handles[0].streams == 0:
+            raise ValueError(f"`handle` is empty: handle.shape={list(batch_shape)}")
+        if self.fused and bottlenecks[0].dtype in _DTYPE_CODE:
+            elems = flats[0].numel() // handles[0].streams
+            hp = (C.c_void_p * n)(*[h.ptr for h in handles])
+            yp = (C.c_void_p * n)(*[b.data_ptr() for b in bottlenecks])
+            ip = (C.c_void_p * n)(*[f.data_ptr() for f in flats])
+            _lib.check(_lib.lib().tfc_encoder_encode_quantized_indexed_many(
+                n, hp, yp, _DTYPE_CODE[bottlenecks[0].dtype], ip, cdf_offset.data_ptr(), elems, _lib.stream_ptr()))
+        else:
+            for k in range(n):
+                symbols = torch.round(bottlenecks[k]).to(torch.int32) - cdf_offset[flats[k].long()]
+                handles[k] = gen_ops.entropy_encode_index(handles[k], flats[k], symbols.contiguous())
+        handles = gen_ops.entropy_encode_finalize_device_many(handles)
+        for h, b, f in zip(handles, bottlenecks, flats):
+            h.coder_inputs = (b, f)
+            h._keep += [b, f, cdf_offset]
+        return handles
+
+    def decompress_many(self, handles, indexes):
+        """decompress() for the handles of compress_many: one decoder launch per stage for all of them; returns
+        ([values per batch], ok) with `ok` the device-resident EntropyDecodeFinalize flags — nothing is read back."""
+        self._check_compression()
+        device = _lib.require_device()
+        handles = list(handles)
+        if not handles:
+            return [], None
+        flats = [self._table_indexes(torch.as_tensor(i).to(device)) for i in indexes]
+        shape = tuple(flats[0].shape)
+        decode_shape = shape[len(shape) - self.coding_rank:] if self.coding_rank else ()
+        cdf_offset = self._device_offsets(device)
+        decoders = gen_ops.create_range_decoders(handles, self.cdf, mode="throughput")
+        n = len(decoders)
+        if tuple(decoders[0].shape) + tuple(decode_shape) != shape:
+            raise ValueError(
+                "'index' shape should match 'handle' shape + 'shape': "
+                f"index.shape={list(shape)}, handle.shape={list(decoders[0].shape)}, shape={list(decode_shape)}")
+        if self.fused and self.bottleneck_dtype in _DTYPE_CODE:
+            outs = [torch.empty(shape, dtype=self.bottleneck_dtype, device=device) for _ in range(n)]
+            elems = flats[0].numel() // decoders[0].streams
+            dp = (C.c_void_p * n)(*[d.ptr for d in decoders])
+            ip = (C.c_void_p * n)(*[f.data_ptr() for f in flats])
+            yp = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+            _lib.check(_lib.lib().tfc_decoder_decode_dequantized_indexed_many(
+                n, dp, ip, yp, _DTYPE_CODE[self.bottleneck_dtype], cdf_offset.data_ptr(), elems, _lib.stream_ptr()))
+            for d, f, o in zip(decoders, flats, outs):
+                d._keep += [f, o, cdf_offset]
+        else:
+            outs = []
+            for k in range(n):
+                decoders[k], symbols = gen_ops.entropy_decode_index(decoders[k], flats[k], decode_shape, torch.int32)
+                outs.append((symbols + cdf_offset[flats[k].long()]).to(self.bottleneck_dtype))
+        ok = gen_ops.entropy_decode_finalize_device_many(decoders)
+        ok._tfc_handle = decoders
+        return outs, ok
 
     def get_config(self):
         raise NotImplementedError("Serializing indexed entropy models is not yet implemented.")

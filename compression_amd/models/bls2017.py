@@ -116,33 +116,6 @@ class BLS2017Model(torch.nn.Module):
         return (x_hat, ok) if defer_sanity else x_hat
 
     @torch.no_grad()
-    def codec_stages(self, x):
-        """One compress() + decompress() of `x` as ([(kind, fn)], state) for
-        `compression_amd.pipeline.SoftwarePipeline` (see BMSHJ2018Model.codec_stages)."""
-        s = {}
-        if x.dim() == 3:
-            x = x[None]
-
-        def analysis():
-            s["y"] = y = self.analysis_transform.unit(functional.image_to_unit(x, self.compute_dtype))
-            s["shapes"] = tuple(x.shape[1:-1]), tuple(y.shape[1:-1])
-
-        def code():
-            string = self.entropy_model.compress(s["y"], device_result=True)
-            s["packed"] = (string,) + s["shapes"]
-            s["y_hat"], ok = self.entropy_model.decompress(string, s["shapes"][1], defer_sanity=True)
-            s["ok"] = [ok]
-
-        def synthesis():
-            x_shape = s["shapes"][0]
-            s["x_hat"] = x_hat = functional.unit_to_image(
-                self.synthesis_transform.unit(s["y_hat"])[:, :x_shape[0], :x_shape[1], :])
-            return x_hat
-
-        stages = [("transform", analysis), ("coder", code), ("transform", synthesis)]
-        return [(kind, torch.no_grad()(fn)) for kind, fn in stages], s      # the stages run after this call returns
-
-    @torch.no_grad()
     def compress_many(self, xs):
         """compress() of several batches with one coder launch (ContinuousBatchedEntropyModel.compress_many):
         [(handle, x_shape, y_shape)] — the handles keep the strings in HBM."""

@@ -179,55 +179,39 @@ class BMSHJ2018Model(torch.nn.Module):
         return (x_hat, ok) if defer_sanity else x_hat
 
     @torch.no_grad()
-    def codec_stages(self, x):
-        """One compress() + decompress() of the batch `x`, cut where the work changes between the transforms and the
-        coder: ([(kind, fn)], state) for `compression_amd.pipeline.SoftwarePipeline`.  Same calls in the same order as
-        compress(device_result=True) followed by decompress(defer_sanity=True); `state` ends up holding `packed`
-        (what compress returns), `ok` (the device-resident sanity flags) and `x_hat`, and keeps every tensor that
-        crosses between the two streams alive."""
-        s = {}
-        if x.dim() == 3:
-            x = x[None]
-
-        def analysis():
-            s["y"] = y = self.analysis_transform.unit(functional.image_to_unit(x, self.compute_dtype))
-            s["z"] = z = self.hyper_analysis_transform(torch.abs(y))
-            s["shapes"] = tuple(x.shape[1:-1]), tuple(y.shape[1:-1]), tuple(z.shape[1:-1])
+    def compress_many(self, xs):
+        """compress() of several batches with ONE coder launch per stage and latent (the entropy models' compress_many:
+        the pipelined lane kernels, whose serial chain is a few waves however many batches share the launch — the
+        convolutions of other batches keep the rest of the chip): [(string handle, side handle, x_shape, y_shape,
+        z_shape)], strings in HBM.  Same strings as compress() batch by batch."""
+        ys, zs, idxs, shapes = [], [], [], []
+        for x in xs:
+            x = x if x.dim() == 4 else x[None]
+            y = self.analysis_transform.unit(functional.image_to_unit(x, self.compute_dtype))
+            z = self.hyper_analysis_transform(torch.abs(y))
+            shapes.append((tuple(x.shape[1:-1]), tuple(y.shape[1:-1]), tuple(z.shape[1:-1])))
             z_hat = self.side_entropy_model.quantize(z)
-            s["indexes"] = self.hyper_synthesis_transform(z_hat)[:, :y.shape[1], :y.shape[2], :]
+            idxs.append(self.hyper_synthesis_transform(z_hat)[:, :y.shape[1], :y.shape[2], :])
+            ys.append(y)
+            zs.append(z)
+        side = self.side_entropy_model.compress_many(zs)
+        main = self.entropy_model.compress_many(ys, idxs)
+        return [(h, sh) + shp for h, sh, shp in zip(main, side, shapes)]
 
-        def code_and_side_decode():
-            # the long kernel first: what the pipeline schedules transform work beside (the strings do not depend
-            # on the order the two are coded in)
-            string = self.entropy_model.compress(s["y"], s["indexes"], device_result=True)
-            side_string = self.side_entropy_model.compress(s["z"], device_result=True)
-            s["packed"] = (string, side_string) + s["shapes"]
-            s["z_hat"], okz = self.side_entropy_model.decompress(side_string, s["shapes"][2], defer_sanity=True)
-            s["ok"] = [okz]
-
-        def hyper_synthesis():
-            y_shape = s["shapes"][1]
-            s["indexes_hat"] = self.hyper_synthesis_transform(s["z_hat"])[:, :y_shape[0], :y_shape[1], :]
-
-        def main_decode():
-            s["y_hat"], oky = self.entropy_model.decompress(s["packed"][0], s["indexes_hat"], defer_sanity=True)
-            s["ok"].append(oky)
-
-        def synthesis_head():
-            t = self.synthesis_transform
-            s["u"] = t.layer_1(t.layer_0(s["y_hat"]))
-
-        def synthesis_rest():
-            t, x_shape = self.synthesis_transform, s["shapes"][0]
-            s["x_hat"] = x_hat = functional.unit_to_image(
-                t.layer_3(t.layer_2(s.pop("u")))[:, :x_shape[0], :x_shape[1], :])
-            return x_hat
-
-        # the synthesis in two stages: its first two layers (a third of its time, shorter than the encode) can run
-        # beside the NEXT step's encode, the rest beside that step's decode
-        stages = [("transform", analysis), ("coder", code_and_side_decode), ("transform", hyper_synthesis),
-                  ("coder", main_decode), ("transform", synthesis_head), ("transform", synthesis_rest)]
-        return [(kind, torch.no_grad()(fn)) for kind, fn in stages], s      # the stages run after this call returns
+    @torch.no_grad()
+    def decompress_many(self, packed):
+        """decompress() for the results of compress_many: ([x_hat per batch], [ok_z, ok_y] flags on the device).  Two
+        phases like decompress(): all side latents, their hyper-synthesis, then all main latents."""
+        packed = list(packed)
+        z_hats, okz = self.side_entropy_model.decompress_many([p[1] for p in packed], packed[0][4])
+        idxs = [self.hyper_synthesis_transform(z_hat)[:, :p[3][0], :p[3][1], :] for z_hat, p in zip(z_hats, packed)]
+        y_hats, oky = self.entropy_model.decompress_many([p[0] for p in packed], idxs)
+        outs = []
+        for p, z_hat, ix, y_hat in zip(packed, z_hats, idxs, y_hats):
+            x_hat = functional.unit_to_image(self.synthesis_transform.unit(y_hat)[:, :p[2][0], :p[2][1], :])
+            x_hat._tfc_keep = (z_hat, ix, y_hat)
+            outs.append(x_hat)
+        return outs, [okz, oky]
 
 
 if __name__ == "__main__":      # python -m compression_amd.models.bmshj2018 compress in.png out.tfci

@@ -66,29 +66,11 @@ int tfc_pipe_counters(int64_t* launches, int64_t* fallback_blocks);
 int tfc_set_default_mode(int mode);
 int tfc_get_default_mode(void);
 
-/* HIP streams restricted to a subset of the compute units (hipExtStreamCreateWithCUMask).  No
- * reference counterpart: the reference's coder ops and its transforms share TensorFlow's intra-op thread
- * pool (range_coder_kernels.cc:212-215, ParallelFor over the streams); here the coder's serial chains
- * need one wave per SIMD on a few CUs for a long time while the transforms want every remaining CU, so a
- * model pipeline gives the two disjoint CU sets and lets them overlap (compression_amd/parallel.py,
- * CoderPartition).  `mask`: one bit per CU, `words` 32-bit words, bit i of word i/32 = CU i in the
- * driver's numbering (consecutive bits alternate over the XCDs).  The stream is a plain hipStream_t.
- * tfc_stream_destroy synchronises the stream and parks it for the next request with the same mask instead
- * of destroying it: coder handles free their buffers in the order of the stream that used them last and
- * may outlive the pipeline that created the stream. */
-/* "Coder gate" of the calling host thread: a hipEvent_t (NULL to clear) that the library records ONCE, on the launch
- * stream, immediately in front of the next long coding kernel (the per-symbol encode / decode kernel, not the
- * preparation kernels ahead of it) it launches from this thread, and then forgets.  A model pipeline lets the
- * transform work of OTHER batches wait for it, so that those kernels are released together with the coding
- * kernel instead of ahead of it: on this hardware a small-grid kernel that becomes ready while another queue is
- * running large grids back to back is not dispatched until that queue drains, whereas kernels released together
- * (or coder first) run side by side (tools/queue_pair_probe.py). */
-int tfc_set_coder_gate(void* event);
 /* Process-wide hint: 1 = the caller keeps other kernels (the transforms of other batches) in flight beside the coder's,
  * 0 (default) = a coder call has the chip to itself.  Shared: handles of 512 streams and more are created with two
  * waves per SIMD (half the CUs; a convolution workgroup cannot use a CU that hosts a coder wave).  Takes effect for
  * handles created afterwards.  No reference counterpart (TensorFlow's executor owns such placement). */
-int tfc_set_chip_shared(int shared);
+int tfc_set_chip_shared(int shared);     /* -> the previous value */
 /* Device memory the library keeps for reuse: every buffer a call or handle releases goes to per-size free lists instead
  * of back to the driver (hipFreeAsync behind a running kernel holds the calling thread until that kernel ends).
  * tfc_cache_bytes: bytes cached now; tfc_cache_trim: returns the blocks whose last use has completed to the driver
@@ -104,9 +86,6 @@ int tfc_unit_to_image(const void* x, int dtype, void* y, int64_t n, void* stream
 int tfc_index_prepare(const void* indexes, int dtype, int32_t* out, int64_t n, int num_tables, void* stream);
 int tfc_cache_bytes(long long* bytes);
 int tfc_cache_trim(long long* released);
-int tfc_device_compute_units(int* cus);
-int tfc_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
-int tfc_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* CDF tables                                                               */
@@ -195,6 +174,11 @@ int tfc_encoder_encode_quantized_indexed(tfc_encoder* e, const void* y, int dtyp
 int tfc_encoder_encode_quantized_many(int n, tfc_encoder* const* e, const void* const* y, int dtype,
                                       const float* qoffset, const int32_t* cdf_offset,
                                       int64_t channels, int64_t elems, void* stream);
+/* ... and in index mode (tfc_encoder_encode_quantized_indexed for n handles): the main latents of several batches
+ * of a hyperprior model (continuous_indexed.py:355-386) as one launch.  y, index: HOST arrays of n DEV pointers. */
+int tfc_encoder_encode_quantized_indexed_many(int n, tfc_encoder* const* e, const void* const* y, int dtype,
+                                              const int32_t* const* index, const int32_t* cdf_offset,
+                                              int64_t elems, void* stream);
 
 /* EntropyEncodeFinalize — cc/ops/range_coder_ops.cc:129-135,
  * cc/kernels/range_coder_kernels.cc:274-287 + cc/lib/range_coder.cc:266-307.
@@ -272,6 +256,10 @@ int tfc_decoder_decode_dequantized(tfc_decoder* d, const int32_t* index, void* y
 int tfc_decoder_decode_dequantized_many(int n, tfc_decoder* const* d, void* const* y, int dtype,
                                         const float* qoffset, const int32_t* cdf_offset,
                                         int64_t channels, int64_t elems, void* stream);
+/* ... and in index mode (continuous_indexed.py:388-417 for n handles).  index, y: HOST arrays of n DEV pointers. */
+int tfc_decoder_decode_dequantized_indexed_many(int n, tfc_decoder* const* d, const int32_t* const* index,
+                                                void* const* y, int dtype, const int32_t* cdf_offset,
+                                                int64_t elems, void* stream);
 
 /* EntropyDecodeFinalize — cc/ops/range_coder_ops.cc:239-246,
  * cc/lib/range_coder.h:144-169.  ok: HOST uint8 [streams] (1 = the weak

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); run with -m gpu")
+    config.addinivalue_line("markers", "slow: full-size configurations (tens of seconds each on the GPU)")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -90,6 +90,24 @@ def test_bmshj2018_roundtrip_kodak_shape():
     assert 0 < bpp < 24
 
 
+def test_bmshj2018_compress_many_equals_batch_by_batch():
+    """Several batches behind one coder launch per stage (the pipelined lane kernels in index mode for the main
+    latent, channel mode for the side latent): same strings and same reconstructions as compress() / decompress()
+    one batch at a time (bmshj2018.py:219-264)."""
+    torch.manual_seed(4)
+    model = tfc.models.BMSHJ2018Model(num_filters=64).cuda().init_compression()
+    xs = [torch.from_numpy(synthetic.lowpass_images(3, 200, 136, seed=10 + k)).cuda() for k in range(3)]
+    packed = model.compress_many(xs)
+    x_hats, oks = model.decompress_many(packed)
+    assert all(bool(ok.cpu().all()) for ok in oks)
+    for x, p, x_hat in zip(xs, packed, x_hats):
+        string, side_string, x_shape, y_shape, z_shape = model.compress(x)
+        assert (x_shape, y_shape, z_shape) == tuple(p[2:])
+        assert [bytes(s) for s in tfc.fetch_strings(p[0])] == [bytes(s) for s in string]
+        assert [bytes(s) for s in tfc.fetch_strings(p[1])] == [bytes(s) for s in side_string]
+        assert torch.equal(x_hat, model.decompress(string, side_string, x_shape, y_shape, z_shape))
+
+
 def test_training_forward_runs():
     torch.manual_seed(3)
     model = tfc.models.BLS2017Model(num_filters=32).cuda()

@@ -1,8 +1,8 @@
-"""GPU tier: the stream-ordered (nothing read back) coding path and the CU-partitioned model pipeline.
+"""GPU tier: the stream-ordered (nothing read back) coding path and model steps in flight on several streams.
 
 What must hold: a deferred-error handle of the wave-per-stream family codes without a host round trip and
 still produces the oracle's bytes; range errors and an outgrown speculative slab surface at status /
-fetch; `compress(device_result=True)` + `decompress(defer_sanity=True)` on a lane of a CoderPartition give
+fetch; `compress(device_result=True)` + `decompress(defer_sanity=True)` on a lane of pipeline.StepLanes give
 the strings and images of the plain calls; several steps in flight do not disturb each other."""
 import os
 
@@ -114,8 +114,8 @@ def test_model_device_path_equals_plain_calls(which):
         assert [bytes(s) for s in tfc.fetch_strings(out[k])] == [bytes(s) for s in plain[k]]
     assert torch.equal(x_hat, want_hat) and all(bool(ok.cpu().all()) for ok in oks)
     assert out[nstr:] == plain[nstr:]
-    # two steps in flight on a CU partition (coder on 16 CUs, transforms on the rest)
-    part = pipeline.CoderPartition(coder_cus=16, depth=2)
+    # steps in flight on two lanes (one ordinary stream each)
+    part = pipeline.StepLanes(2)
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         recs = []
@@ -129,69 +129,7 @@ def test_model_device_path_equals_plain_calls(which):
             for k in range(nstr):
                 assert [bytes(s) for s in tfc.fetch_strings(o[k])] == [bytes(s) for s in plain[k]]
             assert torch.equal(xh, want_hat) and all(bool(f.cpu().all()) for f in ok)
-    part.close()
-
-
-@pytest.mark.parametrize("which", [0, 1])
-@pytest.mark.parametrize("mode", ["masked", "plain"])
-def test_software_pipeline_equals_plain_calls(which, mode):
-    """Model steps software-pipelined over one transform and one coder stream (synthesis of step k - 1 and analysis
-    of step k + 1 beside the coding of step k, released by the library's coder gate): every step's strings and
-    reconstruction are those of compress() / decompress() one call at a time — on DIFFERENT images per step, so
-    a stage reading a neighbouring step's tensors would show."""
-    model, hw, batch = _models()[which]
-    xs = [torch.from_numpy(synthetic.lowpass_images(batch, hw[0], hw[1], seed=30 + k)).cuda() for k in range(5)]
-    plain = [model.compress(x) for x in xs]
-    want = [model.decompress(*p) for p in plain]
-    nstr = model.num_strings
-    part = pipeline.CoderPartition(coder_cus=16, depth=1, mode=mode)
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        sp = pipeline.SoftwarePipeline(part.lane(0))
-        states, ends = [], []
-        for x in xs:
-            stages, state = model.codec_stages(x)
-            states.append(state)
-            out, ev = sp.submit(stages, after=side)
-            if ev is not None:
-                ends.append(ev)
-                assert out is states[len(ends) - 1]["x_hat"]
-        ends.append(sp.drain()[1])
-        for k, (state, ev) in enumerate(zip(states, ends)):
-            ev.synchronize()
-            for j in range(nstr):
-                assert [bytes(s) for s in tfc.fetch_strings(state["packed"][j])] == [bytes(s) for s in plain[k][j]]
-            assert state["packed"][nstr:] == plain[k][nstr:]
-            assert torch.equal(state["x_hat"], want[k]) and all(bool(f.cpu().all()) for f in state["ok"])
-    part.close()
-
-
-def test_coder_gate_is_recorded_once_in_front_of_the_next_coding_kernel():
-    """tfc_set_coder_gate: recorded in front of the next long coding kernel of this thread, then forgotten (a
-    second encode behind ~10 ms of other work does not move it)."""
-    from compression_amd import _lib
-    L = _lib.lib()
-    _, lookup = _tables()
-    lt = torch.from_numpy(lookup)
-    v = torch.from_numpy(synthetic.sample_symbols(lookup, 24, 5000, seed=3)).cuda()
-    spin = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
-    start, gate, end = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    gate.record()                                    # creates the HIP event
-    for _ in range(2):                               # first pass: warm-up (table upload, allocations)
-        torch.cuda.synchronize()
-        start.record()
-        _lib.check(L.tfc_set_coder_gate(gate.cuda_event))
-        h1 = tfc.entropy_encode_channel(tfc.create_range_encoder([24], lt, deferred_errors=True), v)
-        for _ in range(100):
-            spin.add_(1)
-        h2 = tfc.entropy_encode_channel(tfc.create_range_encoder([24], lt, deferred_errors=True), v)
-        _lib.check(L.tfc_set_coder_gate(None))
-        end.record()
-        torch.cuda.synchronize()
-    total = start.elapsed_time(end)
-    assert total > 4.0 and start.elapsed_time(gate) < 0.25 * total
-    assert [bytes(s) for s in tfc.fetch_strings(tfc.entropy_encode_finalize_device(h1))] == \
-        [bytes(s) for s in tfc.fetch_strings(tfc.entropy_encode_finalize_device(h2))]
+    part.synchronize()
 
 
 def test_chip_shared_hint_changes_only_the_launch_shape():
@@ -237,12 +175,9 @@ def test_library_cache_trim():
     assert once() == first
 
 
-def test_cu_partition_masks():
-    part = pipeline.CoderPartition(coder_cus=32, depth=1)
-    assert part.total_cus >= 64 and part.coder_cus == 32
-    lane = part.lane(0)
-    assert lane.transform is not lane.coder
-    # work runs on both streams and they are ordered by the lane's events
+def test_lane_orders_its_streams():
+    """A lane with two streams orders them by events where the stream changes; chip_shared() nests."""
+    lane = pipeline.Lane(torch.cuda.Stream(), torch.cuda.Stream())
     a = torch.zeros(1 << 20, device="cuda")
     lane.begin()
     with lane.on("transform"):
@@ -253,7 +188,12 @@ def test_cu_partition_masks():
         a -= 1
     lane.join()
     assert float(a.sum()) == 2.0 * (1 << 20)
-    part.close()
+    from compression_amd import _lib
+    with pipeline.chip_shared():
+        with pipeline.chip_shared():
+            pass
+        assert _lib.lib().tfc_set_chip_shared(1) == 1       # the inner context restored the outer's value
+    assert _lib.lib().tfc_set_chip_shared(0) == 0
 
 
 def test_compress_many_equals_batch_by_batch():

@@ -164,12 +164,11 @@ def test_up_into_few_channels_bf16(k, s, cin, cout, hw):
                                   # more product columns than an LDS row: a pass per kernel-row residue
                                   (9, 4, 128, 3, (20, 40)), (9, 4, 192, 3, (9, 33)), (7, 3, 64, 4, (9, 34))])
 def test_up_into_few_channels_fused_equals_unfused(case, monkeypatch):
-    """conv_up_fused_kernel (tap products of a block kept in LDS) against the unfused pair (TFC_CONV_UP_UNFUSED=1 is read
-    once per process, so the comparison is with the float32 definition, at the tolerance of one bf16 rounding) — blocks
-    hanging over every edge, several column tiles, even kernels."""
+    """conv_up_fused_kernel (tap products of a block kept in LDS; kernels with more product columns than an LDS row
+    take the implicit GEMM) against the float32 definition, at the tolerance of one bf16 rounding — blocks hanging
+    over every edge, several column tiles, even kernels."""
     from compression_amd.layers import conv2d_up
     k, s, cin, cout, hw = case
-    monkeypatch.setenv("TFC_CONV_UP_PASSES", "1")      # (the several-pass variant is opt-in: no faster than the implicit GEMM)
     torch.manual_seed(k + cin)
     x = torch.randn(2, hw[0], hw[1], cin).bfloat16()
     ker = (torch.randn(k, k, cin, cout) / (k * cin ** 0.5)).bfloat16().float()
