@@ -1554,6 +1554,70 @@ inline bool pipe_fallback_launch() {
   return on;
 }
 std::atomic<long long> g_pipe_launches{0};
+
+// TFC_PIPE_OVERLAP (default 2): how the encoder's chain kernel is launched relative to the expansion that feeds it.
+//   0  behind it, on the caller's stream (the chain starts when every call word is in memory);
+//   1  on a stream of the library's own, enqueued behind the expansion;  2  the same, enqueued in front of it.
+// On its own stream the chain consumes the call words tile by tile while the expansion is still producing them
+// (range_pipe.h: `done` flags); whichever way the two kernels end up scheduled, the result is the same — a chain
+// that went first and is not fed within TFC_PIPE_POLL_MS (default 250) gives its job to the lane-per-stream kernel.
+inline int pipe_overlap() {
+  static const int v = [] {
+    const char* e = std::getenv("TFC_PIPE_OVERLAP");
+    return e ? std::atoi(e) : 2;
+  }();
+  return v;
+}
+// LDS a chain workgroup of a small launch asks for so that no other kernel's workgroups share its CU
+// (TFC_PIPE_RESERVE_KB, default 96 of the CU's 160; 0: only what it needs)
+inline int pipe_reserve_lds() {
+  static const int v = [] {
+    const char* e = std::getenv("TFC_PIPE_RESERVE_KB");
+    return std::min(e ? std::atoi(e) : 96, 160) * 1024;
+  }();
+  return v;
+}
+inline long long pipe_poll_ticks() {
+  static const long long v = [] {
+    const char* e = std::getenv("TFC_PIPE_POLL_MS");
+    return static_cast<long long>(e ? std::atoi(e) : 250) * 100000;     // wall_clock64(): 100 MHz
+  }();
+  return v;
+}
+
+// The library's own stream next to a caller's stream (one per caller stream and device, made on first use, never
+// destroyed), with the two events that tie a launch on it into the caller's order.  It is a HIGH-priority stream
+// (unless the caller's is): HIP multiplexes the streams of one priority onto a few hardware queues and kernels that
+// share a queue run one after the other — a different priority is a different queue, and the chain is the critical
+// path of an encode call.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+inline int side_stream(hipStream_t st, SideStream* out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SideStream> streams;
+  int dev = 0;
+  TFC_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto f = streams.find({dev, st});
+  if (f == streams.end()) {
+    SideStream ss;
+    int least = 0, greatest = 0, mine = 0;
+    TFC_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (hipStreamGetPriority(st, &mine) != hipSuccess) {
+      (void)hipGetLastError();
+      mine = least;
+    }
+    const int prio = (mine == greatest && least != greatest) ? least : greatest;
+    TFC_HIP(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, prio));
+    TFC_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+    TFC_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+    f = streams.emplace(std::make_pair(dev, st), ss).first;
+  }
+  *out = f->second;
+  return 0;
+}
 // temporaries of one pipelined launch are bounded: more jobs than this go out as several launches
 constexpr size_t kPipeTempBytes = size_t{6} << 30;
 
@@ -1586,17 +1650,20 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   const void* fn = indexed ? reinterpret_cast<const void*>(&enc_lanes_kernel<true, Src>)
                            : reinterpret_cast<const void*>(&enc_lanes_kernel<false, Src>);
   TFC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-  // pipelined launch plan: groups of 64 streams, tiles of kPipeTile symbols; rows (coder calls) per group: one per
-  // symbol, room for escape codes when the tables have escape rows, and the rounding of every tile to whole blocks
+  // pipelined launch plan: groups of 64 streams, tiles of kPipeTile symbols; rows (coder calls) per stream: one per
+  // symbol, and room for escape codes when the tables have escape rows (half more than the symbols)
   PipeEncArgs pa;
   pa.nt = static_cast<int>(ceil_div(elems, kPipeTile));
-  // (a tile takes the rows of its LONGEST lane, so the budget for escape codes is generous: half more than the symbols)
-  const int64_t rows64 = elems + (t->any_escape ? elems / 2 + 64 : 0) + static_cast<int64_t>(kPipeBlock) * pa.nt;
-  pa.rows = static_cast<int>(std::min<int64_t>((rows64 + kPipeBlock - 1) / kPipeBlock * kPipeBlock, int64_t{1} << 30));
+  const int64_t rows64 = elems + (t->any_escape ? elems / 2 + 64 : 0);
+  // (the streams of a group are 64 regions a fixed distance apart, read side by side: a distance of 80 words modulo 1024
+  // spreads them over the memory channels)
+  pa.rows = static_cast<int>(std::min<int64_t>((rows64 + 1023) / 1024 * 1024 + 80, int64_t{1} << 30));
   pa.groups_per_job = static_cast<int>(ceil_div(streams, 64));
-  const size_t group_bytes = static_cast<size_t>(pa.rows) * 256 + sizeof(unsigned int) * pa.nt;
+  pa.poll_ticks = pipe_poll_ticks();
+  pa.dbg = std::getenv("TFC_PIPE_DBG") ? std::atoi(std::getenv("TFC_PIPE_DBG")) : 0;
+  const size_t group_bytes = static_cast<size_t>(pa.rows) * 256 + (sizeof(unsigned int) * 65 * pa.nt) + 64 * (sizeof(uint4) + sizeof(uint2));
   const size_t job_bytes = group_bytes * pa.groups_per_job;
-  const bool pipe = pipe_enabled() && rows64 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
+  const bool pipe = pipe_enabled() && rows64 + 2048 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
                     static_cast<int64_t>(pa.nt) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
   const int per_launch = !pipe ? kMaxLaneJobs
                                : static_cast<int>(std::max<size_t>(1, std::min<size_t>(kMaxLaneJobs, kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
@@ -1642,35 +1709,62 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
       DevBuf temp;
       if (pipe) {
         const size_t groups = static_cast<size_t>(pa.groups_per_job) * gn;
-        // (one block of rows behind the last group: the chain requests a block ahead)
-        const size_t calls_bytes = (groups * pa.rows + kPipeBlock) * 64 * sizeof(unsigned int);
-        const size_t end_bytes = (groups * pa.nt * sizeof(unsigned int) + 255) & ~size_t{255};
-        TFC_HIP(temp.alloc(calls_bytes + end_bytes + 256, st));
+        // (room behind the last stream: the chain requests an iteration's rows ahead)
+        const size_t calls_bytes = (groups * 64 * pa.rows + 4 * kPipeBlock) * sizeof(unsigned int);
+        const size_t stage_bytes = groups * 64 * (sizeof(uint4) + sizeof(uint2));
+        const size_t status_bytes = groups * pa.nt * 64 * sizeof(unsigned int);
+        const size_t done_bytes = (groups * pa.nt * sizeof(unsigned int) + 255) & ~size_t{255};
+        TFC_HIP(temp.alloc(calls_bytes + stage_bytes + status_bytes + done_bytes + 256, st));
         uint8_t* base = temp.as<uint8_t>();
         pa.calls = reinterpret_cast<unsigned int*>(base);
-        pa.tileend = reinterpret_cast<unsigned int*>(base + calls_bytes);
-        pa.fallback = reinterpret_cast<unsigned int*>(base + calls_bytes + end_bytes);
+        pa.stage_state = reinterpret_cast<uint4*>(base + calls_bytes);
+        pa.stage_out = reinterpret_cast<uint2*>(base + calls_bytes + groups * 64 * sizeof(uint4));
+        pa.status = reinterpret_cast<unsigned int*>(base + calls_bytes + stage_bytes);
+        pa.done = reinterpret_cast<unsigned int*>(base + calls_bytes + stage_bytes + status_bytes);
+        pa.fallback = reinterpret_cast<unsigned int*>(base + calls_bytes + stage_bytes + status_bytes + done_bytes);
         pa.groups = static_cast<int>(groups);
         g_pipe_launches.fetch_add(1, std::memory_order_relaxed);
         pa.fast16 = t->d_fast.as<uint16_t>();
         pa.rows_fast = t->d_rows_fast.as<int2>();
         pa.ntab = la.ntab;
         pa.cap = la.cap;
-        TFC_HIP(hipMemsetAsync(pa.tileend, 0, end_bytes + 256, st));       // tile ends not yet known, no fallback
-        const dim3 xgrid(static_cast<unsigned>(groups * pa.nt));
-        {
-          KernelTimer t2("enc_expand", st);
-          if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
-          else hipLaunchKernelGGL((enc_expand_kernel<false, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
-        }
+        // nothing known about any tile, no tile released, no fallback
+        TFC_HIP(hipMemsetAsync(pa.status, 0, status_bytes + done_bytes + 256, st));
         PipeChainJobs cj;
         cj.streams = streams;
         for (int k = 0; k < gn; ++k)
           cj.job[k] = PipeChainJob{jobs.job[k].state, jobs.job[k].chunk, jobs.job[k].chunk_len, jobs.job[k].overflow_flag};
-        {
-          KernelTimer t2("enc_chain", st);
-          hipLaunchKernelGGL(enc_chain_kernel, dim3(static_cast<unsigned>(groups)), dim3(64), 0, st, cj, pa);
+        const int overlap = pipe_overlap();
+        SideStream side;
+        if (overlap) {
+          if (side_stream(st, &side)) return 1;
+          TFC_HIP(hipEventRecord(side.fork, st));
+          TFC_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
         }
+        const hipStream_t cst = overlap ? side.stream : st;
+        const dim3 xgrid(static_cast<unsigned>(groups * pa.nt));
+        auto expand = [&] {
+          KernelTimer t2("enc_expand", st);
+          if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
+          else hipLaunchKernelGGL((enc_expand_kernel<false, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
+        };
+        // chain workgroups: four waves (one per SIMD) where there are groups enough; a small launch keeps its CUs to
+        // itself (range_pipe.h, enc_chain_kernel)
+        const int cwaves = groups >= 64 ? 4 : 1;
+        const unsigned cblocks = static_cast<unsigned>(ceil_div(static_cast<int64_t>(groups), cwaves));
+        const int clds = std::max(cwaves * PipeEncChainLds::kWave, cblocks <= 128 ? pipe_reserve_lds() : 0);
+        TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, clds));
+        auto chain = [&] {
+          KernelTimer t2("enc_chain", cst);
+          hipLaunchKernelGGL(enc_chain_kernel, dim3(cblocks), dim3(64 * cwaves), clds, cst, cj, pa);
+        };
+        if (overlap == 2) { chain(); expand(); }
+        else { expand(); chain(); }
+        if (overlap) {
+          TFC_HIP(hipEventRecord(side.join, side.stream));
+          TFC_HIP(hipStreamWaitEvent(st, side.join, 0));
+        }
+        hipLaunchKernelGGL(enc_commit_kernel, dim3(static_cast<unsigned>(groups)), dim3(64), 0, st, cj, pa);
         la.guard = pa.fallback;
       }
       const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
@@ -2061,6 +2155,13 @@ extern "C" int tfc_encoder_finalize_device_many(int n, tfc_encoder* const* es, v
     e->chunks.clear();       // stream-ordered frees behind the pack launch
     e->finalized = true;
   }
+  return 0;
+}
+
+// (measurement aid, not part of the ABI: tools/chain_clock_probe.py)
+extern "C" int tfc_debug_pipe_clocks(unsigned long long* out8) {
+  TFC_HIP(hipDeviceSynchronize());
+  TFC_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(tfc::g_pipe_clock), 8 * sizeof(unsigned long long)));
   return 0;
 }
 

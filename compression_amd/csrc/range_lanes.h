@@ -63,6 +63,9 @@ namespace tfc {
 // Workgroups of the lane-per-stream kernels that ran as the FALLBACK of the pipelined kernels (range_pipe.h): a job
 // the latter gave up on.  Read by tfc_pipe_counters (tests: the fast path really is the one that ran).
 __device__ unsigned long long g_pipe_fallback_blocks;
+// (measurement aid, tools/chain_clock_probe.py) core-clock cycles and 100 MHz ticks the first chain workgroup of the
+// last pipelined encode / decode launch ran for: the clock the chain ran at
+__device__ unsigned long long g_pipe_clock[8];
 
 struct LaneArgs {
   const uint32_t* image;       // device copy of the LDS image

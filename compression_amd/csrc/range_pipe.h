@@ -40,20 +40,30 @@ constexpr int kPipeEscMax = 32;       // escape codes per stream and tile the ex
 constexpr unsigned int kPipeBlock = 16;          // rows per hand-scheduled block of the chain kernels
 // A call word that no table produces (lower bound 0xFFFF above upper bound 1): "this lane has no call in this row"
 constexpr unsigned int kPipeNoCall = 0x0001FFFFu;
-constexpr unsigned int kPipeReady = 0x80000000u;
+// Status word of a (tile, stream) of the expansion: kind << 30 | rows.  A tile first publishes the rows (coder calls)
+// its own symbols take, then — once it has looked back over the tiles before it — the rows of the stream up to and
+// including itself.
+constexpr unsigned int kPipeAggregate = 1u << 30;
+constexpr unsigned int kPipePrefix = 2u << 30;
+constexpr unsigned int kPipeRowsMask = (1u << 30) - 1u;
 
 struct PipeEncArgs {
   const uint16_t* fast16;       // tables scaled to 16 bits (tfc_tables::d_fast)
   const int2* rows_fast;        // (offset, length | escape row << 31) per table
   int ntab;
-  unsigned int* calls;          // [group][row][lane]; a lane without a call in a row holds kPipeNoCall there
-  unsigned int* tileend;        // [group][tile]: kPipeReady | first row behind the tile (0: not yet known)
+  unsigned int* calls;          // [group][lane][rows]: the call words of a stream, in order, contiguous
+  unsigned int* status;         // [group][tile][lane]: see kPipeAggregate / kPipePrefix (0: not yet known)
+  unsigned int* done;           // [group][tile]: 1 once the tile's call words are in memory
   unsigned int* fallback;       // [job]
+  uint4* stage_state;           // [group][lane]: the chain's successor state ...
+  uint2* stage_out;             // ... bytes written, slab outgrown; committed by enc_commit_kernel unless the job fell back
   int nt;                       // tiles per stream
-  int rows;                     // row capacity of a group
+  int rows;                     // row capacity of a stream
   int groups_per_job;           // groups of 64 streams per job
   int groups;                   // of the launch
   unsigned int cap;             // slab bytes per stream (chain kernel)
+  long long poll_ticks;         // wall_clock64() ticks the chain waits for a tile before it gives the job up
+  int dbg;                      // (measurement aid) 1: the chain stores no digits; 2: requests no rows
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -72,22 +82,22 @@ __device__ inline unsigned int pipe_escape_word(unsigned int g, unsigned int neg
 }
 
 // One workgroup per (tile of kPipeTile symbols, group of 64 streams); blockIdx = tile * groups + group, so that the
-// tiles of one group are dispatched in order and far apart.  The rows of a tile start at the same row for all 64
-// lanes (the chain wave reads row k of every lane with one load) and take as many rows as its longest lane has calls,
-// rounded up to whole blocks; where a tile starts is the sum over the tiles before it — a chained look-back over the
-// group's tiles (each workgroup publishes its end row once it has counted its calls, and needs its predecessor's
-// only when it starts writing).
+// tiles of one group are dispatched in order and far apart.  The call words of a stream are contiguous in memory (the
+// chain's lane reads its own stream, 16 rows per request), so a tile has to know how many rows the tiles before it
+// took — per stream: a decoupled look-back over the status words (every workgroup publishes its own row counts as
+// soon as it has them, and needs its predecessors' only when it starts writing; the 64 lanes of one wave look back
+// for the 64 streams side by side).
 constexpr int kExpandThreads = 512;
 template <bool INDEXED, typename Src>
 __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const EncLaneJobs<Src> jobs, const PipeEncArgs pa) {
-  constexpr int kRow = kPipeTile + 1;                     // padded: the transposed reads of phase C hit 64 banks
+  constexpr int kRow = kPipeTile + 1;
   constexpr int kHalves = kExpandThreads / kPipeTile;     // thread = (half, symbol): half h takes streams h, h + kHalves, ...
   __shared__ unsigned int W[64 * kRow];                   // call word of every (stream, symbol) of the tile
   // escape codes per stream (appended in phase A, put in order in phase B):
   // position | neg << 8 | extra calls << 9 | low 16 bits of gamma << 16 (all of gamma when extra < 34)
   __shared__ unsigned int esc[64][kPipeEscMax];
   __shared__ unsigned short ecum[64][kPipeEscMax];        // extra calls of the stream's escape codes before this one
-  __shared__ unsigned int ecount[64], cnt[64], nesc[64], tmax, tstart;
+  __shared__ unsigned int ecount[64], nesc[64], start[64];
 
   const unsigned int gi = blockIdx.x % static_cast<unsigned int>(pa.groups);
   const unsigned int T = blockIdx.x / static_cast<unsigned int>(pa.groups);
@@ -100,7 +110,6 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   const unsigned int elems = static_cast<unsigned int>(jobs.elems);
   const int64_t s0 = static_cast<int64_t>(gidx) * 64;
   const unsigned int ntab = static_cast<unsigned int>(pa.ntab);
-  if (tid == 0) tmax = 0u;
   if (tid < 64u) ecount[tid] = 0u;
   __syncthreads();
 
@@ -122,11 +131,10 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   // ---- phase A: one call word per symbol (an escape: the word of its row's escape symbol).  Written in stages
   // over register arrays — all loads of a stage are in flight together (interleaved with the LDS stores, hipcc
   // waits for every single load: a load through a pointer out of the kernel arguments is a flat load, which may
-  // alias LDS).  Which symbols take an escape code is collected by ballot: lane L of a wave keeps the mask of the
-  // wave's 64 symbols for the L-th stream it handles --------------------------------------------------------
+  // alias LDS) -------------------------------------------------------------------------------------------
   {
     constexpr int N = 64 / kHalves;       // streams per thread ...
-    constexpr int NB = 16;                // ... taken NB at a time (registers: two workgroups per CU)
+    constexpr int NB = INDEXED ? 8 : 16;  // ... taken NB at a time (registers: two workgroups per CU, nothing spilled)
     const unsigned int p = tid % kPipeTile, half = tid / kPipeTile;
     const unsigned int j = T * kPipeTile + p;             // this thread's symbol of every stream it handles
     const bool inpos = j < elems;
@@ -172,8 +180,8 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
         const int nplain = hasesc ? len - 3 : len - 2;
         const bool plain = static_cast<unsigned int>(val[i]) < static_cast<unsigned int>(nplain);
         const int sym = plain ? val[i] : (hasesc ? len - 3 : 0);
-        const unsigned short* e = pa.fast16 + rw[i].x + 1 + sym;
-        word[i] = static_cast<unsigned int>(e[0]) | (static_cast<unsigned int>(e[1]) << 16);
+        // (one 4-byte load at 2-byte alignment: lo | hi << 16 as they lie in the table)
+        word[i] = reinterpret_cast<const TFC_AS1 LanePacked<unsigned int>*>((const TFC_AS1 void*)(pa.fast16 + rw[i].x + 1 + sym))->v;
         const bool live = inpos && s0 + (i0 + i) * kHalves + static_cast<int>(half) < jobs.streams;
         if (live && !plain && !hasesc) badpos = min(badpos, static_cast<unsigned long long>(position(i0 + i)));
         escbits |= (live && !plain && hasesc) ? 1u << i : 0u;
@@ -197,11 +205,13 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   }
   __syncthreads();
 
-  // ---- phase B: a thread per stream puts its escape codes in order and counts its rows ----------------
+  const unsigned int valid = min(static_cast<unsigned int>(kPipeTile), elems > T * kPipeTile ? elems - T * kPipeTile : 0u);
+
+  // ---- phase B: a thread per stream puts its escape codes in order, counts its rows and finds where they start ----
   if (tid < 64u) {
     const int64_t s = s0 + tid;
-    unsigned int n = ecount[tid], cum = 0u, valid = 0u;
-    if (s < jobs.streams && T * kPipeTile < elems) valid = min(static_cast<unsigned int>(kPipeTile), elems - T * kPipeTile);
+    unsigned int n = ecount[tid], cum = 0u;
+    const unsigned int nsym = s < jobs.streams ? valid : 0u;
     if (n > static_cast<unsigned int>(kPipeEscMax)) {
       atomicOr(&pa.fallback[job], 1u);      // more escape codes than planned for: the lane-per-stream kernel codes this job
       n = 0u;
@@ -216,100 +226,121 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
       ecum[tid][a] = static_cast<unsigned short>(cum);
       cum += (esc[tid][a] >> 9) & 0x7Fu;
     }
-    cnt[tid] = valid + cum;
+    const unsigned int cnt = nsym + cum;
     nesc[tid] = n;
-    atomicMax(&tmax, valid + cum);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    // first row of this tile = end of the tile before it (published by that workgroup; dispatched before this one)
-    unsigned int start = 0u;
-    unsigned int* const ends = pa.tileend + static_cast<size_t>(gi) * pa.nt;
-    if (T > 0u) {
+    // rows of the stream before this tile: its predecessors' counts, back to the first one that already knows its own
+    // prefix (tiles are dispatched in order, so every predecessor is running or done).  Relaxed atomics: a status word
+    // carries everything its reader needs.
+    unsigned int* const st = pa.status + static_cast<size_t>(gi) * pa.nt * 64 + tid;
+    __hip_atomic_store(st + static_cast<size_t>(T) * 64, kPipeAggregate | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int before = 0u;
+    for (unsigned int t = T; t-- > 0u;) {
       unsigned int v;
       do {
-        v = __hip_atomic_load(&ends[T - 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((v & kPipeReady) == 0u);
-      start = v & ~kPipeReady;
+        v = __hip_atomic_load(st + static_cast<size_t>(t) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((v >> 30) == 0u);
+      before += v & kPipeRowsMask;
+      if (v & kPipePrefix) break;
     }
-    unsigned int end = start + ((tmax + kPipeBlock - 1u) & ~(kPipeBlock - 1u));
-    if (end > static_cast<unsigned int>(pa.rows)) {
-      // more rows than the launch planned for (escape codes far beyond the tables' tail mass): this job is left
-      // to the lane-per-stream kernel; the tiles behind still get a consistent (empty) position
-      atomicOr(&pa.fallback[job], 1u);
-      end = start;
-    }
-    __hip_atomic_store(&ends[T], end | kPipeReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    tstart = end == start ? 0xFFFFFFFFu : start;
+    const unsigned int limit = static_cast<unsigned int>(pa.rows);
+    const bool fits = before + cnt <= limit;
+    if (!fits) atomicOr(&pa.fallback[job], 1u);     // more rows than the launch planned for (escape codes far beyond the tables' tail mass)
+    __hip_atomic_store(st + static_cast<size_t>(T) * 64, kPipePrefix | (fits ? before + cnt : limit + 1u), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    start[tid] = fits ? before : 0xFFFFFFFFu;
   }
   __syncthreads();
-  if (tstart == 0xFFFFFFFFu) return;
 
-  // ---- phase C: rows out, transposed (a wave = the 64 lanes of one row: one coalesced store).  Three passes, each
-  // with a thread (q, l) taking every 8th item of lane l: the plain call words from their symbol's position to its
-  // row (position + extra calls of the escape codes before it), the bit rows of the escape codes, and "no call" for
-  // the rows behind a lane's last call up to the next whole block ------------------------------------------
+  // ---- phase C: call words out, a wave per stream at a time (64 consecutive words: one coalesced store): the
+  // plain words from their symbol's position to its row (position + extra calls of the escape codes before it),
+  // then the bit rows of the stream's escape codes (a lane per code) ------------------------------------
   {
-    constexpr unsigned int kPass = kExpandThreads / 64;
-    const unsigned int l = lane, q = tid >> 6;
-    const unsigned int mx = (tmax + kPipeBlock - 1u) & ~(kPipeBlock - 1u), mine = cnt[l], ne = nesc[l];
-    const unsigned int first = __builtin_amdgcn_readfirstlane(tstart);
-    unsigned int* const out = pa.calls + (static_cast<size_t>(gi) * pa.rows + first) * 64;
-    const unsigned int valid = min(static_cast<unsigned int>(kPipeTile), elems > T * kPipeTile ? elems - T * kPipeTile : 0u);
-    const unsigned int nsym = s0 + l < jobs.streams ? valid : 0u;
-    {
-      unsigned int i = 0u, cum = 0u;
-      unsigned int nextpos = ne ? (esc[l][0] & 0xFFu) : 0xFFFFFFFFu;
-      for (unsigned int p = q; p < nsym; p += kPass) {
-        while (nextpos < p) {                 // escape codes in front of symbol p: their bits push it back
-          cum += (esc[l][i] >> 9) & 0x7Fu;
-          ++i;
-          nextpos = i < ne ? (esc[l][i] & 0xFFu) : 0xFFFFFFFFu;
+    constexpr unsigned int kWaves = kExpandThreads / 64;
+    const unsigned int q = tid >> 6;
+    for (unsigned int sl = q; sl < 64u; sl += kWaves) {
+      const unsigned int first = start[sl];
+      if (first == 0xFFFFFFFFu || s0 + sl >= jobs.streams) continue;
+      unsigned int* const out = pa.calls + (static_cast<size_t>(gi) * 64 + sl) * pa.rows + first;
+      const unsigned int ne = nesc[sl];
+      for (unsigned int p = lane; p < valid; p += 64u) {
+        unsigned int cum = 0u;
+        for (unsigned int i = 0; i < ne; ++i) {
+          const unsigned int e = esc[sl][i];
+          cum += (e & 0xFFu) < p ? (e >> 9) & 0x7Fu : 0u;
         }
-        out[(p + cum) * 64u + l] = W[l * kRow + p];
+        out[p + cum] = W[sl * kRow + p];
+      }
+      if (lane < ne) {
+        const unsigned int e = esc[sl][lane];
+        const unsigned int epos = e & 0xFFu, neg = (e >> 8) & 1u, extra = (e >> 9) & 0x7Fu;
+        unsigned int g = e >> 16, ng;
+        if (extra >= 34u) escape_of(s0 + sl, T * kPipeTile + epos, g, ng);      // 2^16 and more: the value again
+        const unsigned int row = epos + ecum[sl][lane];                          // the escape symbol's own call
+        for (unsigned int k = 1; k <= extra; ++k) out[row + k] = pipe_escape_word(g, neg, extra, k);
       }
     }
-    for (unsigned int i = q; i < ne; i += kPass) {
-      const unsigned int e = esc[l][i];
-      const unsigned int epos = e & 0xFFu, neg = (e >> 8) & 1u, extra = (e >> 9) & 0x7Fu;
-      unsigned int g = e >> 16, ng;
-      if (extra >= 34u) escape_of(s0 + l, T * kPipeTile + epos, g, ng);      // 2^16 and more: the value again
-      const unsigned int row = epos + ecum[l][i];                              // the escape symbol's own call
-      for (unsigned int k = 1; k <= extra; ++k) out[(row + k) * 64u + l] = pipe_escape_word(g, neg, extra, k);
-    }
-    for (unsigned int r = mine + q; r < mx; r += kPass) out[r * 64u + l] = kPipeNoCall;
   }
+  // the tile's words are in memory: the barrier orders every thread's stores before thread 0's release
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&pa.done[static_cast<size_t>(gi) * pa.nt + T], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Encoder, stage 2: the chain
 // ---------------------------------------------------------------------------------------------
 
-// One row: a lane whose word is "no call" leaves EXEC for the rest of the block (tiles are whole blocks and a lane's
-// calls are the first rows of its tile, so nothing follows a "no call" inside a block); the call word is unpacked
-// into the (lo, 0) / (hi, 0) register pairs TFC_LENC_B multiplies from.
+// One row: a lane whose word is "no call" leaves EXEC for the rest of the block (a stream's calls are the first rows
+// of its last block, so nothing follows a "no call" inside a block); the call word is unpacked into the (lo, 0) /
+// (hi, 0) register pairs TFC_LENC_B multiplies from.
 #define TFC_PENC_STEP(W)                                                                   \
   "v_cmpx_ne_u32 vcc, %[NOCALL], %[" #W "]\n\t"                                            \
   "v_and_b32 v152, %[KFFFF], %[" #W "]\n\t"                                                \
   "v_lshrrev_b32 v154, 16, %[" #W "]\n\t"                                                  \
   TFC_LENC_B(152, 153, 154, 155, "")
 
+// LDS of one chain wave: the digits of an iteration, per lane
+struct PipeEncChainLds {
+  static constexpr unsigned int kRows = 2 * kPipeBlock;
+  static constexpr unsigned int kDigits = 2 * kRows;     // digit bytes staged per lane between two flushes (one digit per call at most)
+  static constexpr int kStride = lane_stride(kDigits + 8);
+  static constexpr int kWave = 64 * kStride;
+};
 struct PipeChainJob { uint4* state; uint8_t* chunk; unsigned int* chunk_len; unsigned int* overflow_flag; };
 struct PipeChainJobs {
   int64_t streams;
   PipeChainJob job[64];
 };
 
-__global__ void __launch_bounds__(64) enc_chain_kernel(const PipeChainJobs jobs, const PipeEncArgs pa) {
-  constexpr int kStride = lane_stride(kEncDigitBytes + 8);
-  __shared__ __attribute__((aligned(16))) unsigned char stage[64 * kStride];
+// The chain of one group of 64 streams, lane per stream: row k of the launch is call k of every stream (a stream with
+// escape codes has more rows; the shorter streams sit out the last blocks).  It may run WHILE the expansion is still
+// writing (the host launches it on a stream of its own): before it requests rows it makes sure, tile by tile, that
+// the expansion has released them (`done`, acquire) and takes the stream's row count up to that tile from the status
+// words.  A tile that does not arrive within `poll_ticks` (the two kernels were not scheduled side by side after all
+// and this one went first) gives the job to the fallback.  Successor states are staged: enc_commit_kernel, behind both
+// kernels, hands them to the handles unless the job fell back.
+// A workgroup is one to four such waves (one per SIMD), each with its own group.  The host gives it more dynamic LDS
+// than the waves need when the launch is small: a lone wave's time is the latency of its instruction chain, and another
+// kernel's waves on the same SIMD (the expansion's, a convolution's) stretch it by a third even at the highest wave
+// priority — issue is not pre-emptive — so the chain keeps its CUs to itself by leaving no room for anybody's LDS.
+__global__ void __launch_bounds__(256) enc_chain_kernel(const PipeChainJobs jobs, const PipeEncArgs pa) {
+  // rows per iteration of the main loop: two hand-scheduled blocks, so that the rows requested in one iteration have a
+  // whole iteration (~6 k cycles) to arrive — a lane's request is 64 bytes of its own stream, 64 different cache lines per
+  // wave instruction, and takes its time
+  constexpr unsigned int kRows = PipeEncChainLds::kRows;
+  constexpr unsigned int kDigits = PipeEncChainLds::kDigits;
+  constexpr int kStride = PipeEncChainLds::kStride;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_lds[];
+  unsigned char* const stage = chain_lds + (threadIdx.x >> 6) * PipeEncChainLds::kWave;
+  __builtin_amdgcn_s_setprio(3);                        // next to the expansion's waves this one is the critical path
+  const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
 
-  const unsigned int gi = blockIdx.x;
+  const unsigned int gi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (gi >= static_cast<unsigned int>(pa.groups)) return;
   const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
   const unsigned int gidx = gi % static_cast<unsigned int>(pa.groups_per_job);
-  if (pa.fallback[job] != 0u) return;
+  if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   const PipeChainJob& J = jobs.job[job];
-  const unsigned int lane = threadIdx.x;
+  const unsigned int lane = threadIdx.x & 63u;
   const int64_t s = static_cast<int64_t>(gidx) * 64 + lane;
   const bool live = s < jobs.streams;
 
@@ -329,12 +360,13 @@ __global__ void __launch_bounds__(64) enc_chain_kernel(const PipeChainJobs jobs,
   };
   auto flush = [&]() {
 #pragma unroll
-    for (unsigned int c = 0; c < kEncDigitBytes / 16u; ++c) {
+    for (unsigned int c = 0; c < kDigits / 16u; ++c) {
       if (16u * c < n) {
         uint2 v[2];
         v[0] = reinterpret_cast<const uint2*>(dstage)[2 * c];
         v[1] = reinterpret_cast<const uint2*>(dstage)[2 * c + 1];
-        if (wpos + 16u * c + 16u <= pa.cap) lanes_gstore16(out + wpos + 16u * c, v[0], v[1]);
+        if (pa.dbg & 1) {}
+        else if (wpos + 16u * c + 16u <= pa.cap) lanes_gstore16(out + wpos + 16u * c, v[0], v[1]);
         else overflow = 1u;
       }
     }
@@ -384,33 +416,55 @@ __global__ void __launch_bounds__(64) enc_chain_kernel(const PipeChainJobs jobs,
     s1 = act ? (ren ? (t1 << 16) | 0xFFFFu : t1) : s1;
   };
 
-  const unsigned int* const calls = pa.calls + static_cast<size_t>(gi) * pa.rows * 64 + lane;
-  // rows of the group: the end of its last tile (whole blocks)
-  const unsigned int nb = (__builtin_amdgcn_readfirstlane(pa.tileend[static_cast<size_t>(gi) * pa.nt + pa.nt - 1]) & ~kPipeReady) / kPipeBlock;
-
-  // The rows of block b.  Requested a whole block before they are used, and taken over (`w = wn`) in front of the
-  // iteration's own loads and stores: hipcc turns any wait for a load into s_waitcnt vmcnt(0) while a store may be
-  // in flight (gfx9 counts both on vmcnt), so the one wait of an iteration has to sit where everything in flight
-  // is a block old.
-  unsigned int w[kPipeBlock] = {}, wn[kPipeBlock] = {};
-  auto load_block = [&](unsigned int b) {
-    const unsigned int* p = calls + static_cast<size_t>(b) * (kPipeBlock * 64u);
-#pragma unroll
-    for (unsigned int k = 0; k < kPipeBlock; ++k) wn[k] = p[k * 64u];
+  // ---- what the expansion has released so far --------------------------------------------------------
+  const unsigned int nt = static_cast<unsigned int>(pa.nt);
+  const unsigned int* const status = pa.status + static_cast<size_t>(gi) * nt * 64 + lane;
+  const unsigned int* const done = pa.done + static_cast<size_t>(gi) * nt;
+  unsigned int avail = 0u;      // rows of this lane's stream that are in memory; all of them once tn == nt
+  unsigned int tn = 0u;         // tiles [0, tn) are in
+  bool bail = false;
+  long long waited = 0, waits = 0;
+  // rows [0, need) of every stream in memory (or all the stream has)
+  auto ensure = [&](unsigned int need) {
+    while (tn < nt && __any(live && avail < need)) {
+      const unsigned int* const flag = done + tn;
+      long long t0 = 0;
+      bool timing = false;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        const long long now = static_cast<long long>(wall_clock64());
+        if (!timing) { t0 = now; timing = true; }
+        else if (now - t0 > pa.poll_ticks) { bail = true; return; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (timing) { waited += static_cast<long long>(wall_clock64()) - t0; ++waits; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      avail = __hip_atomic_load(status + static_cast<size_t>(tn) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kPipeRowsMask;
+      ++tn;
+      // a tile that did not fit, or too many escape codes somewhere in the job: nothing of it is kept
+      if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bail = true; return; }
+    }
   };
 
-  if (nb) load_block(0u);
-  // (waited for here: a value that may still be in flight when the loop is entered would put a wait in front of
-  // the block in every iteration)
-  asm volatile("" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(wn[4]), "+v"(wn[5]), "+v"(wn[6]), "+v"(wn[7]),
-                    "+v"(wn[8]), "+v"(wn[9]), "+v"(wn[10]), "+v"(wn[11]), "+v"(wn[12]), "+v"(wn[13]), "+v"(wn[14]), "+v"(wn[15]));
-  for (unsigned int b = 0; b < nb; ++b) {
+  const unsigned char* const mine = reinterpret_cast<const unsigned char*>(pa.calls + (static_cast<size_t>(gi) * 64 + lane) * pa.rows);
+  // The rows of iteration b.  Requested a whole iteration before they are used, and taken over (`w = wn`) in front of
+  // the iteration's own loads and stores: hipcc turns any wait for a load into s_waitcnt vmcnt(0) while a store may be
+  // in flight (gfx9 counts both on vmcnt), so the one wait of an iteration has to sit where everything in flight
+  // is an iteration old.
+  unsigned int w[kRows] = {}, wn[kRows] = {};
+  auto load_rows = [&](unsigned int b) {
+    const unsigned char* p = mine + static_cast<size_t>(b) * (kRows * 4u);
 #pragma unroll
-    for (unsigned int k = 0; k < kPipeBlock; ++k) w[k] = wn[k];
-    load_block(b + 1u);           // (one block of rows is allocated behind the group's last)
-    flush();                      // the digits of the block before this one
+    for (unsigned int c = 0; c < kRows / 4u; ++c) {
+      const uint4 v = (pa.dbg & 2) ? make_uint4(0x80004000u, 0x80004000u, 0x80004000u, 0x80004000u) : lanes_gload16(p + 16u * c);
+      wn[4 * c] = v.x; wn[4 * c + 1] = v.y; wn[4 * c + 2] = v.z; wn[4 * c + 3] = v.w;
+    }
+  };
+  // one hand-scheduled block on 16 call words
+  auto block = [&](unsigned int w0, unsigned int w1, unsigned int w2, unsigned int w3, unsigned int w4, unsigned int w5,
+                   unsigned int w6, unsigned int w7, unsigned int w8, unsigned int w9, unsigned int w10, unsigned int w11,
+                   unsigned int w12, unsigned int w13, unsigned int w14, unsigned int w15) __attribute__((always_inline)) {
     const unsigned int base0 = base, s10 = s1, hd0 = hd, had0 = had;
-    unsigned int flag = rn, na = ds_off;
+    unsigned int flag = rn, na = ds_off + n;
     asm volatile(
         "s_mov_b64 s[56:57], exec\n\t"
         "v_mov_b32 v153, 0\n\tv_mov_b32 v155, 0\n\t"
@@ -422,9 +476,9 @@ __global__ void __launch_bounds__(64) enc_chain_kernel(const PipeChainJobs jobs,
         "s_waitcnt lgkmcnt(0)\n\t"
         : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na), [FLAG] "+v"(flag)
         : [NOCALL] "s"(kPipeNoCall), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u),
-          [W0] "v"(w[0]), [W1] "v"(w[1]), [W2] "v"(w[2]), [W3] "v"(w[3]), [W4] "v"(w[4]), [W5] "v"(w[5]),
-          [W6] "v"(w[6]), [W7] "v"(w[7]), [W8] "v"(w[8]), [W9] "v"(w[9]), [W10] "v"(w[10]), [W11] "v"(w[11]),
-          [W12] "v"(w[12]), [W13] "v"(w[13]), [W14] "v"(w[14]), [W15] "v"(w[15])
+          [W0] "v"(w0), [W1] "v"(w1), [W2] "v"(w2), [W3] "v"(w3), [W4] "v"(w4), [W5] "v"(w5),
+          [W6] "v"(w6), [W7] "v"(w7), [W8] "v"(w8), [W9] "v"(w9), [W10] "v"(w10), [W11] "v"(w11),
+          [W12] "v"(w12), [W13] "v"(w13), [W14] "v"(w14), [W15] "v"(w15)
         : "vcc", "memory", "s52", "s53", "s56", "s57", "v152", "v153", "v154", "v155", "v160", "v161", "v162", "v163",
           "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v173", "v174", "v175");
     if (__builtin_expect(!__any(flag != 0u), 1)) {
@@ -433,27 +487,87 @@ __global__ void __launch_bounds__(64) enc_chain_kernel(const PipeChainJobs jobs,
       // a digit 0xFFFF was shifted out (it opens a run a later carry may ripple through), or a lane came
       // in inside such a run: the block again from the saved state, call by call
       base = base0; s1 = s10; hd = hd0; had = had0;
+      const unsigned int ww[kPipeBlock] = {w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15};
 #pragma nounroll
       for (unsigned int k = 0; k < kPipeBlock; ++k) {
-        unsigned int word = w[0];
+        unsigned int word = ww[0];
 #pragma unroll
-        for (unsigned int q = 1; q < kPipeBlock; ++q) word = k == q ? w[q] : word;
+        for (unsigned int q = 1; q < kPipeBlock; ++q) word = k == q ? ww[q] : word;
         const unsigned int hi = word >> 16;
         call(word & 0xFFFFu, hi == 0u ? 65536u : hi, word != kPipeNoCall);
       }
     }
+  };
+
+  ensure(kRows);
+  if (!bail) load_rows(0u);
+  // (waited for here: a value that may still be in flight when the loop is entered would put a wait in front of
+  // the blocks in every iteration)
+#pragma unroll
+  for (unsigned int k = 0; k < kRows; ++k) asm volatile("" : "+v"(wn[k]));
+  // (while tiles are outstanding every stream has the whole iteration's rows — ensure() — and more to come)
+  unsigned long long stalled = 0;
+  for (unsigned int b = 0; !bail && (tn < nt || __any(b * kRows < avail)); ++b) {
+    {
+      const unsigned long long c0 = clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stalled += clock64() - c0;
+    }
+#pragma unroll
+    for (unsigned int k = 0; k < kRows; ++k) w[k] = wn[k];
+    ensure((b + 2u) * kRows);
+    if (bail) break;
+    load_rows(b + 1u);            // (one iteration's rows are allocated behind the last stream's)
+    flush();                      // the digits of the iteration before this one
+    if (__any(avail < (b + 1u) * kRows)) {
+      // the last rows of the shorter streams (every tile is in by now): "no call" behind a stream's last
+#pragma unroll
+      for (unsigned int k = 0; k < kRows; ++k) w[k] = b * kRows + k < avail ? w[k] : kPipeNoCall;
+    }
+    block(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+    block(w[16], w[17], w[18], w[19], w[20], w[21], w[22], w[23], w[24], w[25], w[26], w[27], w[28], w[29], w[30], w[31]);
   }
   flush();
-  if (live) {
-    J.state[s] = make_uint4(base, s1, (hd & 0xFFFFu) | (had << 31), rn);
-    J.chunk_len[s] = wpos;
-    if (overflow) atomicOr(J.overflow_flag, 1u);
+  if (bail) {
+    if (lane == 0) atomicOr(&pa.fallback[job], 1u);
+    return;
   }
+  if (gi == 0 && lane == 0) {
+    g_pipe_clock[0] = clock64() - clk0;
+    g_pipe_clock[1] = wall_clock64() - wall0;
+    g_pipe_clock[4] = waited;
+    g_pipe_clock[6] = stalled;
+    g_pipe_clock[5] = waits;
+  }
+  if (live) {
+    pa.stage_state[static_cast<size_t>(gi) * 64 + lane] = make_uint4(base, s1, (hd & 0xFFFFu) | (had << 31), rn);
+    pa.stage_out[static_cast<size_t>(gi) * 64 + lane] = make_uint2(wpos, overflow);
+  }
+}
+
+// Behind the expansion and the chain: the staged successor states become the handles' — unless the job fell back
+// (then the lane-per-stream kernel codes it from the untouched state).
+__global__ void __launch_bounds__(64) enc_commit_kernel(const PipeChainJobs jobs, const PipeEncArgs pa) {
+  const unsigned int gi = blockIdx.x;
+  const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
+  const unsigned int gidx = gi % static_cast<unsigned int>(pa.groups_per_job);
+  if (pa.fallback[job] != 0u) return;
+  const int64_t s = static_cast<int64_t>(gidx) * 64 + threadIdx.x;
+  if (s >= jobs.streams) return;
+  const PipeChainJob& J = jobs.job[job];
+  J.state[s] = pa.stage_state[static_cast<size_t>(gi) * 64 + threadIdx.x];
+  const uint2 o = pa.stage_out[static_cast<size_t>(gi) * 64 + threadIdx.x];
+  J.chunk_len[s] = o.x;
+  if (o.y) atomicOr(J.overflow_flag, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Decoder
 // ---------------------------------------------------------------------------------------------
+
+// Raw-plane entry of a row in which a lane made no step (it waits for the wave's tail phase, see dec_chain_kernel):
+// not the start of an element, and skipped when an escape code's bit rows are collected
+constexpr unsigned int kPipeSkipRow = 0x7FFF0000u;
 
 struct PipeDecArgs {
   unsigned int* raw;             // [group][row][lane]: symbol | M << 16 of every step (M: see dec_chain_kernel)
@@ -603,6 +717,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   lanes_load_image(lanes_lds, la);
   using L = PipeDecLds;
 
+  const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
   const unsigned int job = blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job);
   const unsigned int wv = (blockIdx.x % static_cast<unsigned int>(jobs.blocks_per_job)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (wv >= static_cast<unsigned int>(pa.groups_per_job)) return;
@@ -742,6 +857,12 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
     }
   };
 
+  // Two phases.  While any lane has a whole block of elements left, the lanes that do take blocks (hand-scheduled
+  // steps; a block never runs past a lane's last element) and a lane that does not — its stream is nearly done, it met
+  // more escape codes than its neighbours and fell behind, or fewer and is ahead — sits them out, marking its rows
+  // kPipeSkipRow.  Then the tail: every lane's last elements (fewer than a block each, plus their escape bits) with
+  // the generic steps, all lanes together — so that the wave does not drop to the generic steps for as long as its
+  // lanes are spread out, only for one short pass at the end.
   bool gave_up = false;
   while (__any(pos < elems)) {
     if (k + kPipeBlock > static_cast<unsigned int>(pa.rows)) {
@@ -766,8 +887,28 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
       if (M == 0) load_row(); else R = bin;
       row_loaded = true;
     }
-    const bool busy = pos < elems;
-    if (__builtin_expect(lds0 == 0u && !__any(busy && pos + kPipeBlock > elems), 1)) {
+    const bool whole = pos + kPipeBlock <= elems;          // a whole block of elements left
+    const bool blocks = __any(whole);                      // first phase
+    if (blocks && __any(!whole && pos < elems && M != 0)) {
+      // A lane that is about to sit out is inside an escape code: it finishes the code first (generic steps, everybody
+      // else sits these rows out), so that a code's bit rows stay together in the raw plane.
+      if (pos < elems) {
+#pragma unroll
+        for (unsigned int i = 0; i < kPipeBlock; ++i) raw[static_cast<size_t>(k + i) * 64 + lane] = kPipeSkipRow;
+      }
+#pragma nounroll
+      for (unsigned int i = 0; i < kPipeBlock; ++i) gstep(!whole && pos < elems && M != 0, k + i);
+      k += kPipeBlock;
+      continue;
+    }
+    const bool busy = blocks ? whole : pos < elems;
+    if (blocks && __any(!whole && pos < elems)) {
+      if (!whole && pos < elems) {
+#pragma unroll
+        for (unsigned int i = 0; i < kPipeBlock; ++i) raw[static_cast<size_t>(k + i) * 64 + lane] = kPipeSkipRow;
+      }
+    }
+    if (__builtin_expect(lds0 == 0u && blocks, 1)) {
       const unsigned int D0 = D, s10 = s1, cp0 = cp, pw0 = pw;
       const int M0 = M;
       const uint4 R0 = R;
@@ -806,7 +947,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
       D = D0; s1 = s10; cp = cp0; pw = pw0; M = M0; R = R0;      // an exception somewhere in the wave: the generic steps
     }
 #pragma nounroll
-    for (unsigned int i = 0; i < kPipeBlock; ++i) gstep(pos < elems, k + i);
+    for (unsigned int i = 0; i < kPipeBlock; ++i) gstep(busy && pos < elems, k + i);
     k += kPipeBlock;
   }
   posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos;
@@ -815,6 +956,10 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
     return;
   }
   if (lane == 0) pa.kend[gi] = k;
+  if (gi == 0 && lane == 0) {
+    g_pipe_clock[2] = clock64() - clk0;
+    g_pipe_clock[3] = wall_clock64() - wall0;
+  }
   if (live) {
     // back to the (base, span - 1, window, digits pulled) form shared with the other kernels
     const unsigned int cpos = cw.base + (cp - cw_off);
@@ -906,6 +1051,7 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
             const unsigned int x = q - k0 < nrows ? buf[(q - k0) * kPitch + l] : raw[static_cast<size_t>(q) * 64 + l];
             const int m = static_cast<int>(x) >> 16;
             const unsigned int bit = x & 1u;
+            if ((x & 0xFFFF0000u) == kPipeSkipRow) continue;      // the lane sat this row out
             if (m < 0) {
               if (bit) val = 1u << (-m - 1);
               else if (m == -31) val = 1u << 31;

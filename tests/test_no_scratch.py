@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HOT = ["conv_bf16_kernel", "conv3_bf16_kernel", "conv_image_kernel", "conv_up_fused_kernel",
        "image_to_unit_kernel", "unit_to_image_kernel", "index_prepare_kernel",
        "enc_lanes_kernel", "dec_lanes_kernel", "enc_fast_kernel", "dec_fast_kernel",
+       "enc_expand_kernel", "enc_chain_kernel", "dec_chain_kernel", "dec_parse_kernel",
        "gdn_fwd_bf16_kernelILi6E", "gdn_bwd_fused_bf16_kernelILi6E", "gdn_param_grad_kernelItLi6E",
        "noisy_normal_forward_kernel", "noisy_normal_backward_kernel", "factorized_forward_kernel",
        "ELi256EEEvNS_10BitsParamsE"]        # factorized_backward_kernel<..., MAXT = 256>: every MLP shape
