@@ -1568,15 +1568,6 @@ inline int pipe_overlap() {
   }();
   return v;
 }
-// LDS a chain workgroup of a small launch asks for so that no other kernel's workgroups share its CU
-// (TFC_PIPE_RESERVE_KB, default 96 of the CU's 160; 0: only what it needs)
-inline int pipe_reserve_lds() {
-  static const int v = [] {
-    const char* e = std::getenv("TFC_PIPE_RESERVE_KB");
-    return std::min(e ? std::atoi(e) : 96, 160) * 1024;
-  }();
-  return v;
-}
 inline long long pipe_poll_ticks() {
   static const long long v = [] {
     const char* e = std::getenv("TFC_PIPE_POLL_MS");
@@ -1655,15 +1646,12 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   PipeEncArgs pa;
   pa.nt = static_cast<int>(ceil_div(elems, kPipeTile));
   const int64_t rows64 = elems + (t->any_escape ? elems / 2 + 64 : 0);
-  // (the streams of a group are 64 regions a fixed distance apart, read side by side: a distance of 80 words modulo 1024
-  // spreads them over the memory channels)
-  pa.rows = static_cast<int>(std::min<int64_t>((rows64 + 1023) / 1024 * 1024 + 80, int64_t{1} << 30));
+  pa.rows = static_cast<int>(std::min<int64_t>((rows64 + 31) / 32 * 32, int64_t{1} << 30));
   pa.groups_per_job = static_cast<int>(ceil_div(streams, 64));
   pa.poll_ticks = pipe_poll_ticks();
-  pa.dbg = std::getenv("TFC_PIPE_DBG") ? std::atoi(std::getenv("TFC_PIPE_DBG")) : 0;
   const size_t group_bytes = static_cast<size_t>(pa.rows) * 256 + (sizeof(unsigned int) * 65 * pa.nt) + 64 * (sizeof(uint4) + sizeof(uint2));
   const size_t job_bytes = group_bytes * pa.groups_per_job;
-  const bool pipe = pipe_enabled() && rows64 + 2048 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
+  const bool pipe = pipe_enabled() && rows64 + 2048 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes && t->host.size() <= 65536 &&
                     static_cast<int64_t>(pa.nt) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
   const int per_launch = !pipe ? kMaxLaneJobs
                                : static_cast<int>(std::max<size_t>(1, std::min<size_t>(kMaxLaneJobs, kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
@@ -1714,7 +1702,7 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         const size_t stage_bytes = groups * 64 * (sizeof(uint4) + sizeof(uint2));
         const size_t status_bytes = groups * pa.nt * 64 * sizeof(unsigned int);
         const size_t done_bytes = (groups * pa.nt * sizeof(unsigned int) + 255) & ~size_t{255};
-        TFC_HIP(temp.alloc(calls_bytes + stage_bytes + status_bytes + done_bytes + 256, st));
+        TFC_HIP(temp.alloc(calls_bytes + stage_bytes + status_bytes + done_bytes + 512, st));
         uint8_t* base = temp.as<uint8_t>();
         pa.calls = reinterpret_cast<unsigned int*>(base);
         pa.stage_state = reinterpret_cast<uint4*>(base + calls_bytes);
@@ -1722,14 +1710,16 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         pa.status = reinterpret_cast<unsigned int*>(base + calls_bytes + stage_bytes);
         pa.done = reinterpret_cast<unsigned int*>(base + calls_bytes + stage_bytes + status_bytes);
         pa.fallback = reinterpret_cast<unsigned int*>(base + calls_bytes + stage_bytes + status_bytes + done_bytes);
+        pa.started = pa.fallback + 64;          // (behind the 64 jobs' flags)
         pa.groups = static_cast<int>(groups);
         g_pipe_launches.fetch_add(1, std::memory_order_relaxed);
         pa.fast16 = t->d_fast.as<uint16_t>();
         pa.rows_fast = t->d_rows_fast.as<int2>();
         pa.ntab = la.ntab;
+        pa.tab_entries = t->host.size() * 2 <= static_cast<size_t>(kExpandTabBytes) ? static_cast<int>(t->host.size()) : 0;
         pa.cap = la.cap;
         // nothing known about any tile, no tile released, no fallback
-        TFC_HIP(hipMemsetAsync(pa.status, 0, status_bytes + done_bytes + 256, st));
+        TFC_HIP(hipMemsetAsync(pa.status, 0, status_bytes + done_bytes + 512, st));
         PipeChainJobs cj;
         cj.streams = streams;
         for (int k = 0; k < gn; ++k)
@@ -1748,15 +1738,19 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
           if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
           else hipLaunchKernelGGL((enc_expand_kernel<false, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
         };
-        // chain workgroups: four waves (one per SIMD) where there are groups enough; a small launch keeps its CUs to
-        // itself (range_pipe.h, enc_chain_kernel)
-        const int cwaves = groups >= 64 ? 4 : 1;
-        const unsigned cblocks = static_cast<unsigned>(ceil_div(static_cast<int64_t>(groups), cwaves));
-        const int clds = std::max(cwaves * PipeEncChainLds::kWave, cblocks <= 128 ? pipe_reserve_lds() : 0);
-        TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, clds));
+        // chain workgroups: a chain wave and three helper waves per group; four groups each (a CU to themselves) when
+        // the launch is large (range_pipe.h, enc_chain_kernel)
+        const int cgroups = groups >= 64 ? PipeEncChainLds::kGroups : 1;
+        const unsigned cblocks = static_cast<unsigned>(ceil_div(static_cast<int64_t>(groups), cgroups));
+        const int clds = cgroups * PipeEncChainLds::kGroup;
+        TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    PipeEncChainLds::kGroups * PipeEncChainLds::kGroup));
         auto chain = [&] {
           KernelTimer t2("enc_chain", cst);
-          hipLaunchKernelGGL(enc_chain_kernel, dim3(cblocks), dim3(64 * cwaves), clds, cst, cj, pa);
+          hipLaunchKernelGGL(enc_chain_kernel, dim3(cblocks), dim3(256 * cgroups), clds, cst, cj, pa);
+          // (the expansion behind the chain's workgroups, not in their way)
+          if (overlap == 2 && cgroups > 1)
+            hipLaunchKernelGGL(enc_gate_kernel, dim3(1), dim3(1), 0, st, pa.started, cblocks, static_cast<long long>(20000));
         };
         if (overlap == 2) { chain(); expand(); }
         else { expand(); chain(); }

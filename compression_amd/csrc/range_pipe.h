@@ -51,10 +51,12 @@ struct PipeEncArgs {
   const uint16_t* fast16;       // tables scaled to 16 bits (tfc_tables::d_fast)
   const int2* rows_fast;        // (offset, length | escape row << 31) per table
   int ntab;
-  unsigned int* calls;          // [group][lane][rows]: the call words of a stream, in order, contiguous
+  int tab_entries;              // entries of fast16 when the image fits the expansion's LDS copy, else 0
+  unsigned int* calls;          // [group][rows / 32][lane][32]: call word r of a stream at [r / 32][lane][r % 32]
   unsigned int* status;         // [group][tile][lane]: see kPipeAggregate / kPipePrefix (0: not yet known)
   unsigned int* done;           // [group][tile]: 1 once the tile's call words are in memory
   unsigned int* fallback;       // [job]
+  unsigned int* started;        // chain workgroups that are running (enc_gate_kernel)
   uint4* stage_state;           // [group][lane]: the chain's successor state ...
   uint2* stage_out;             // ... bytes written, slab outgrown; committed by enc_commit_kernel unless the job fell back
   int nt;                       // tiles per stream
@@ -63,7 +65,6 @@ struct PipeEncArgs {
   int groups;                   // of the launch
   unsigned int cap;             // slab bytes per stream (chain kernel)
   long long poll_ticks;         // wall_clock64() ticks the chain waits for a tile before it gives the job up
-  int dbg;                      // (measurement aid) 1: the chain stores no digits; 2: requests no rows
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -88,11 +89,18 @@ __device__ inline unsigned int pipe_escape_word(unsigned int g, unsigned int neg
 // soon as it has them, and needs its predecessors' only when it starts writing; the 64 lanes of one wave look back
 // for the 64 streams side by side).
 constexpr int kExpandThreads = 512;
+constexpr int kExpandTabBytes = 32 * 1024;     // table images up to this size are staged in LDS (two workgroups per CU)
 template <bool INDEXED, typename Src>
 __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const EncLaneJobs<Src> jobs, const PipeEncArgs pa) {
-  constexpr int kRow = kPipeTile + 1;
+  constexpr int kRow = kPipeTile;
   constexpr int kHalves = kExpandThreads / kPipeTile;     // thread = (half, symbol): half h takes streams h, h + kHalves, ...
-  __shared__ unsigned int W[64 * kRow];                   // call word of every (stream, symbol) of the tile
+  // table entry of every (stream, symbol) of the tile: offset of the symbol's lower bound in the 16-bit table image
+  // (the call word is the 4 bytes there: lo | hi << 16)
+  __shared__ unsigned short W[64 * kRow];
+  // the table image, when it fits (pa.tab_entries != 0): phase C's look-ups are LDS reads instead of 4-byte gathers
+  // from 64 different cache lines per wave instruction — measured, those gathers were what the kernel's time went
+  // into, and what made the memory system slow for everybody else
+  __shared__ __attribute__((aligned(16))) unsigned short tab[kExpandTabBytes / 2];
   // escape codes per stream (appended in phase A, put in order in phase B):
   // position | neg << 8 | extra calls << 9 | low 16 bits of gamma << 16 (all of gamma when extra < 34)
   __shared__ unsigned int esc[64][kPipeEscMax];
@@ -111,6 +119,13 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   const int64_t s0 = static_cast<int64_t>(gidx) * 64;
   const unsigned int ntab = static_cast<unsigned int>(pa.ntab);
   if (tid < 64u) ecount[tid] = 0u;
+  const bool tab_lds = pa.tab_entries != 0;
+  if (tab_lds) {
+    // (in flight next to phase A's loads; first read behind the barriers in front of phase C)
+    const uint4* const src16 = reinterpret_cast<const uint4*>(pa.fast16);
+    for (unsigned int i = tid; i < (static_cast<unsigned int>(pa.tab_entries) + 7u) / 8u; i += kExpandThreads)
+      reinterpret_cast<uint4*>(tab)[i] = src16[i];
+  }
   __syncthreads();
 
   // table and value of symbol `at` of stream s (phase C looks again at the rare escape code of 2^16 and more)
@@ -151,7 +166,7 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
       int32_t val[NB];
       int tt[NB];
       int2 rw[NB];
-      unsigned int word[NB];
+      unsigned int entry[NB];
       if (INDEXED) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) tt[i] = index[position(i0 + i)];
@@ -180,17 +195,16 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
         const int nplain = hasesc ? len - 3 : len - 2;
         const bool plain = static_cast<unsigned int>(val[i]) < static_cast<unsigned int>(nplain);
         const int sym = plain ? val[i] : (hasesc ? len - 3 : 0);
-        // (one 4-byte load at 2-byte alignment: lo | hi << 16 as they lie in the table)
-        word[i] = reinterpret_cast<const TFC_AS1 LanePacked<unsigned int>*>((const TFC_AS1 void*)(pa.fast16 + rw[i].x + 1 + sym))->v;
+        entry[i] = static_cast<unsigned int>(rw[i].x + 1 + sym);
         const bool live = inpos && s0 + (i0 + i) * kHalves + static_cast<int>(half) < jobs.streams;
         if (live && !plain && !hasesc) badpos = min(badpos, static_cast<unsigned long long>(position(i0 + i)));
         escbits |= (live && !plain && hasesc) ? 1u << i : 0u;
-        word[i] = live ? word[i] : 0u;
+        entry[i] = live ? entry[i] : 0u;
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int sl = (i0 + i) * kHalves + static_cast<int>(half);
-        W[sl * kRow + p] = word[i];
+        W[sl * kRow + p] = static_cast<unsigned short>(entry[i]);
         if ((escbits >> i) & 1u) {
           // the code's magnitude (range_coder_kernels.cc:296-303) next to the symbol's position
           const int32_t vmax = (rw[i].y & 0x7FFFFFFF) - 3;
@@ -260,7 +274,12 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
     for (unsigned int sl = q; sl < 64u; sl += kWaves) {
       const unsigned int first = start[sl];
       if (first == 0xFFFFFFFFu || s0 + sl >= jobs.streams) continue;
-      unsigned int* const out = pa.calls + (static_cast<size_t>(gi) * 64 + sl) * pa.rows + first;
+      // call word r of the stream: 32 consecutive rows of a stream are 128 contiguous bytes, the 64 streams' side by
+      // side (what the chain's loaders read per iteration is one contiguous 8 KB)
+      unsigned int* const gbase = pa.calls + static_cast<size_t>(gi) * 64 * pa.rows;
+      auto out = [&](unsigned int r) -> unsigned int& {
+        return gbase[((static_cast<size_t>(r >> 5) * 64 + sl) << 5) + (r & 31u)];
+      };
       const unsigned int ne = nesc[sl];
       for (unsigned int p = lane; p < valid; p += 64u) {
         unsigned int cum = 0u;
@@ -268,7 +287,11 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
           const unsigned int e = esc[sl][i];
           cum += (e & 0xFFu) < p ? (e >> 9) & 0x7Fu : 0u;
         }
-        out[p + cum] = W[sl * kRow + p];
+        const unsigned int at = W[sl * kRow + p];
+        // (lo | hi << 16 as they lie in the table; from global memory one 4-byte load at 2-byte alignment)
+        const unsigned int word = tab_lds ? static_cast<unsigned int>(tab[at]) | (static_cast<unsigned int>(tab[at + 1u]) << 16)
+                                          : reinterpret_cast<const TFC_AS1 LanePacked<unsigned int>*>((const TFC_AS1 void*)(pa.fast16 + at))->v;
+        out(first + p + cum) = word;
       }
       if (lane < ne) {
         const unsigned int e = esc[sl][lane];
@@ -276,7 +299,7 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
         unsigned int g = e >> 16, ng;
         if (extra >= 34u) escape_of(s0 + sl, T * kPipeTile + epos, g, ng);      // 2^16 and more: the value again
         const unsigned int row = epos + ecum[sl][lane];                          // the escape symbol's own call
-        for (unsigned int k = 1; k <= extra; ++k) out[row + k] = pipe_escape_word(g, neg, extra, k);
+        for (unsigned int k = 1; k <= extra; ++k) out(first + row + k) = pipe_escape_word(g, neg, extra, k);
       }
     }
   }
@@ -292,95 +315,253 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 // One row: a lane whose word is "no call" leaves EXEC for the rest of the block (a stream's calls are the first rows
 // of its last block, so nothing follows a "no call" inside a block); the call word is unpacked into the (lo, 0) /
 // (hi, 0) register pairs TFC_LENC_B multiplies from.
+// (TFC_LENC_B of range_lanes.h with its temporaries at v100-v119: a chain workgroup is sixteen waves, four per SIMD,
+// 128 registers each)
 #define TFC_PENC_STEP(W)                                                                   \
   "v_cmpx_ne_u32 vcc, %[NOCALL], %[" #W "]\n\t"                                            \
-  "v_and_b32 v152, %[KFFFF], %[" #W "]\n\t"                                                \
-  "v_lshrrev_b32 v154, 16, %[" #W "]\n\t"                                                  \
-  TFC_LENC_B(152, 153, 154, 155, "")
+  "v_and_b32 v100, %[KFFFF], %[" #W "]\n\t"                                                \
+  "v_lshrrev_b32 v102, 16, %[" #W "]\n\t"                                                  \
+  "v_mad_u64_u32 v[104:105], s[52:53], v100, %[S], v[100:101]\n\t"                         \
+  "v_mad_u64_u32 v[106:107], s[52:53], v102, %[S], v[102:103]\n\t"                         \
+  "v_alignbit_b32 v104, v105, v104, 16\n\t"                                               \
+  "v_alignbit_b32 v106, v107, v106, 16\n\t"                                               \
+  "v_add_u32 v106, -1, v106\n\t"                                                          \
+  "v_min_u32 v106, v106, %[S]\n\t"                                                        \
+  "v_add_co_u32 v108, vcc, %[BASE], v104\n\t"                                             \
+  "v_addc_co_u32 v111, vcc, 0, %[H], vcc\n\t"                                             \
+  "v_sub_u32 v109, v106, v104\n\t"                                                        \
+  "v_sub_u32 v117, v111, %[H]\n\t"                                                        \
+  "v_cmp_gt_u32 vcc, %[K64K], v109\n\t"                                                   \
+  "v_cndmask_b32 v118, 0, 1, vcc\n\t"                                                     \
+  "v_perm_b32 v110, 0, v111, %[PERM]\n\t"                                                 \
+  "ds_write_b16 %[NA], v110\n\t"                                                          \
+  "v_or_b32 v112, v117, v118\n\t"                                                         \
+  "v_and_b32 v112, v112, %[HAD]\n\t"                                                      \
+  "v_lshl_add_u32 %[NA], v112, 1, %[NA]\n\t"                                              \
+  "v_lshrrev_b32 v113, 16, v108\n\t"                                                      \
+  "v_lshlrev_b32 v114, 16, v108\n\t"                                                      \
+  "v_lshl_or_b32 v115, v109, 16, %[KFFFF]\n\t"                                            \
+  "v_cndmask_b32 %[BASE], v108, v114, vcc\n\t"                                            \
+  "v_cndmask_b32 %[S], v109, v115, vcc\n\t"                                               \
+  "v_cndmask_b32 %[H], %[H], v113, vcc\n\t"                                               \
+  "v_or_b32 v119, %[HAD], v118\n\t"                                                       \
+  "v_bfi_b32 %[HAD], v117, v118, v119\n\t"                                                \
+  "v_cmp_eq_u32 vcc, %[KFFFF], %[H]\n\t"                                                  \
+  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"
 
-// LDS of one chain wave: the digits of an iteration, per lane
+// LDS of one group of a chain workgroup: call words in, digits out (see enc_chain_kernel)
 struct PipeEncChainLds {
-  static constexpr unsigned int kRows = 2 * kPipeBlock;
-  static constexpr unsigned int kDigits = 2 * kRows;     // digit bytes staged per lane between two flushes (one digit per call at most)
-  static constexpr int kStride = lane_stride(kDigits + 8);
-  static constexpr int kWave = 64 * kStride;
+  static constexpr unsigned int kRows = 2 * kPipeBlock;      // rows per iteration: two hand-scheduled blocks
+  static constexpr unsigned int kSlots = 2;                  // iterations of call words in LDS (one per loader; each has its next one in registers)
+  static constexpr unsigned int kDigSlots = 2;               // iterations of digits the helper may be behind
+  static constexpr unsigned int kDigits = 2 * kRows + 32;    // digit bytes of a lane and iteration: one digit per call at most, and
+                                                             // room for runs of 0xFFFF digits that settle (longer: the fallback)
+  static constexpr int kCallStride = 4 * kRows + 16;         // a lane's words of an iteration, 16-byte accesses without bank conflicts
+  static constexpr int kCallSlot = 64 * kCallStride;
+  static constexpr int kDigStride = lane_stride(kDigits + 8);   // + the speculative write behind a full area
+  static constexpr int kDigSlot = 64 * kDigStride;
+  static constexpr int kCalls = 0;
+  static constexpr int kDig = kCalls + kSlots * kCallSlot;
+  static constexpr int kRec = kDig + kDigSlots * kDigSlot;   // (position in the slab, bytes) of every lane's digits, per digit slot
+  static constexpr int kSync = kRec + kDigSlots * 64 * 8;
+  static constexpr int kGroup = kSync + 64;
+  static constexpr int kGroups = 4;                          // groups (chain waves) of a large launch's workgroups: one per SIMD
+  // words at kSync
+  static constexpr int kSeq = 0;            // [kSlots] iteration + 1 whose call words the slot holds | kLast | kBail
+  static constexpr int kConsumed = 3;       // iterations the chain has read (kSeq takes kSlots <= 3 words)
+  static constexpr int kDigPub = 4;         // iterations whose digits the chain has handed over
+  static constexpr int kDigDone = 5;        // ... the helper has stored
+  static constexpr int kExit = 6;           // the chain has left its loop
+  static constexpr unsigned int kLast = 0x80000000u, kBail = 0x40000000u;
 };
+static_assert(PipeEncChainLds::kGroups * PipeEncChainLds::kGroup <= 160 * 1024 && PipeEncChainLds::kSlots <= 3, "a chain workgroup's LDS");
 struct PipeChainJob { uint4* state; uint8_t* chunk; unsigned int* chunk_len; unsigned int* overflow_flag; };
 struct PipeChainJobs {
   int64_t streams;
   PipeChainJob job[64];
 };
 
-// The chain of one group of 64 streams, lane per stream: row k of the launch is call k of every stream (a stream with
-// escape codes has more rows; the shorter streams sit out the last blocks).  It may run WHILE the expansion is still
-// writing (the host launches it on a stream of its own): before it requests rows it makes sure, tile by tile, that
-// the expansion has released them (`done`, acquire) and takes the stream's row count up to that tile from the status
-// words.  A tile that does not arrive within `poll_ticks` (the two kernels were not scheduled side by side after all
-// and this one went first) gives the job to the fallback.  Successor states are staged: enc_commit_kernel, behind both
-// kernels, hands them to the handles unless the job fell back.
-// A workgroup is one to four such waves (one per SIMD), each with its own group.  The host gives it more dynamic LDS
-// than the waves need when the launch is small: a lone wave's time is the latency of its instruction chain, and another
-// kernel's waves on the same SIMD (the expansion's, a convolution's) stretch it by a third even at the highest wave
-// priority — issue is not pre-emptive — so the chain keeps its CUs to itself by leaving no room for anybody's LDS.
-__global__ void __launch_bounds__(256) enc_chain_kernel(const PipeChainJobs jobs, const PipeEncArgs pa) {
-  // rows per iteration of the main loop: two hand-scheduled blocks, so that the rows requested in one iteration have a
-  // whole iteration (~6 k cycles) to arrive — a lane's request is 64 bytes of its own stream, 64 different cache lines per
-  // wave instruction, and takes its time
-  constexpr unsigned int kRows = PipeEncChainLds::kRows;
-  constexpr unsigned int kDigits = PipeEncChainLds::kDigits;
-  constexpr int kStride = PipeEncChainLds::kStride;
+// The chain of a group of 64 streams, lane per stream: row k of the launch is call k of every stream (a stream with
+// escape codes has more rows; the shorter streams sit out the last ones).  It may run WHILE the expansion is still
+// writing (the host launches it on a stream of its own), and next to anything else that keeps the memory system busy —
+// which a lone wave whose time is the latency of its instruction chain must not feel: measured with the expansion
+// running, every global load or store the chain wave issued itself held it up at ISSUE (full request queues), 3.7 ->
+// 5.9 ms for BASELINE config 2 — and one helper wave doing all of it in turn did not keep up (the same 5.9).  So a
+// workgroup is four groups of four waves, wave 4 r + g of group g on SIMD g, the three helpers asleep most of the time:
+//   loaders (2)  make sure, tile by tile, that the expansion has released the rows they are about to request (`done`,
+//                acquire; the stream's row count up to that tile from the status words) and load the call words of every
+//                other iteration — 128 bytes of every lane's own stream — into an LDS ring up to kSlots iterations
+//                ahead ("no call" behind a stream's last row);
+//   storer       stores the digits of finished iterations from LDS to the slabs, exactly the bytes;
+//   chain        touches LDS only: 32 call words per lane in, the hand-scheduled blocks, digits out.
+// Hand-over by counters in LDS (one writer each; LDS executes a wave's accesses in order).  A tile that does not arrive
+// within `poll_ticks` (the two kernels were not scheduled side by side after all and this one went first) gives the job
+// to the fallback.  Successor states are staged: enc_commit_kernel, behind both kernels, hands them to the handles
+// unless the job fell back.  A large launch's workgroups are four groups: their LDS (131 KB) also keeps other kernels'
+// workgroups off the CU; a small launch's (a model step's few groups, next to convolutions that leave no CU empty)
+// are one group each and fit in anywhere.
+__global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs jobs, const PipeEncArgs pa) {
+  using L = PipeEncChainLds;
+  constexpr unsigned int kRows = L::kRows;
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_lds[];
-  unsigned char* const stage = chain_lds + (threadIdx.x >> 6) * PipeEncChainLds::kWave;
-  __builtin_amdgcn_s_setprio(3);                        // next to the expansion's waves this one is the critical path
-  const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+  const unsigned int G = blockDim.x >> 8;            // groups of this workgroup: four waves each
+  if (threadIdx.x == 0u) __hip_atomic_fetch_add(pa.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned int i = threadIdx.x; i < G * 16u; i += blockDim.x)
+    reinterpret_cast<unsigned int*>(chain_lds + (i / 16u) * L::kGroup + L::kSync)[i % 16u] = 0u;
+  __syncthreads();
 
-  const unsigned int gi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const unsigned int gi = blockIdx.x * G + (wave % G);
   if (gi >= static_cast<unsigned int>(pa.groups)) return;
+  const unsigned int role = wave / G;                // 0: chain; 1, 2: loaders (even / odd iterations); 3: the digits' way out
+  unsigned char* const area = chain_lds + (wave % G) * L::kGroup;
+  // (the hand-over counters through LDS-address-space pointers: a volatile access through a generic pointer is a FLAT
+  // instruction, which goes down the vector-memory path the chain wave has to stay out of)
+  typedef __attribute__((address_space(3))) unsigned int lds_u32;
+  volatile lds_u32* const sync = reinterpret_cast<volatile lds_u32*>(
+      (__attribute__((address_space(3))) unsigned char*)chain_lds + (wave % G) * L::kGroup + L::kSync);
+  const unsigned int area_off = static_cast<unsigned int>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)area));
+
   const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
   const unsigned int gidx = gi % static_cast<unsigned int>(pa.groups_per_job);
-  if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   const PipeChainJob& J = jobs.job[job];
-  const unsigned int lane = threadIdx.x & 63u;
   const int64_t s = static_cast<int64_t>(gidx) * 64 + lane;
   const bool live = s < jobs.streams;
+  unsigned char* const out = J.chunk + (live ? s : 0) * static_cast<int64_t>(pa.cap);
 
+  if (role == 1u || role == 2u) {
+    // ================================ loader wave: iterations role - 1, role + 1, ... ================================
+    const unsigned int nt = static_cast<unsigned int>(pa.nt);
+    const unsigned int* const status = pa.status + static_cast<size_t>(gi) * nt * 64 + lane;
+    const unsigned int* const done = pa.done + static_cast<size_t>(gi) * nt;
+    const unsigned char* const words = reinterpret_cast<const unsigned char*>(pa.calls + static_cast<size_t>(gi) * 64 * pa.rows);
+    unsigned int avail = 0u;      // rows of this lane's stream that are in memory; all of them once tn == nt
+    unsigned int tn = 0u;         // tiles [0, tn) are in
+    bool bail = __hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    // rows [0, need) of every stream in memory (or all the stream has)
+    auto ensure = [&](unsigned int need) {
+      while (tn < nt && __any(live && avail < need)) {
+        const unsigned int* const flag = done + tn;
+        long long t0 = 0;
+        bool timing = false;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          const long long now = static_cast<long long>(wall_clock64());
+          if (!timing) { t0 = now; timing = true; }
+          else if (now - t0 > pa.poll_ticks) { bail = true; return; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        avail = __hip_atomic_load(status + static_cast<size_t>(tn) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kPipeRowsMask;
+        ++tn;
+        // a tile that did not fit, or too many escape codes somewhere in the job: nothing of it is kept
+        if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bail = true; return; }
+      }
+    };
+    for (unsigned int b = role - 1u;; b += 2u) {
+      const unsigned int slot = b % L::kSlots;
+      if (!bail) ensure((b + 1u) * kRows);
+      if (!bail && tn == nt && !__any(b * kRows < avail)) break;       // no such iteration: the other loader had the last one
+      uint4 v[kRows / 4u];
+      if (!bail) {
+        // requested before the slot is free: the words arrive while the chain is still reading the slot's last ones.
+        // The iteration's words are 8 KB in a row, [stream][32]; request c of this lane is words 4 (lane % 8) ... of
+        // stream 8 c + lane / 8 (coalesced: eight cache lines per request instead of 64)
+        const unsigned char* const p = words + static_cast<size_t>(b) * (64u * kRows * 4u) + 16u * lane;
+#pragma unroll
+        for (unsigned int c = 0; c < kRows / 4u; ++c) v[c] = lanes_gload16(p + 1024u * c);
+        if (__any(avail < (b + 1u) * kRows)) {
+          // the last rows of the shorter streams (every tile is in by now): "no call" behind a stream's last
+          const unsigned int r0 = b * kRows + 4u * (lane & 7u);
+#pragma unroll
+          for (unsigned int c = 0; c < kRows / 4u; ++c) {
+            const unsigned int theirs = static_cast<unsigned int>(__shfl(static_cast<int>(avail), static_cast<int>(8u * c + (lane >> 3))));
+            v[c].x = r0 + 0u < theirs ? v[c].x : kPipeNoCall;
+            v[c].y = r0 + 1u < theirs ? v[c].y : kPipeNoCall;
+            v[c].z = r0 + 2u < theirs ? v[c].z : kPipeNoCall;
+            v[c].w = r0 + 3u < theirs ? v[c].w : kPipeNoCall;
+          }
+        }
+      }
+      // a free slot (the chain leaves its loop behind the last iteration, or when the other loader gave up)
+      bool gone = false;
+      while (b >= sync[L::kConsumed] + L::kSlots) {
+        if (sync[L::kExit] != 0u) { gone = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (gone) break;
+      if (bail) {
+        if (lane == 0u) {
+          sync[L::kSeq + slot] = L::kBail;
+          atomicOr(&pa.fallback[job], 1u);
+        }
+        break;
+      }
+#pragma unroll
+      for (unsigned int c = 0; c < kRows / 4u; ++c)
+        *reinterpret_cast<uint4*>(area + L::kCalls + slot * L::kCallSlot + L::kCallStride * (8u * c + (lane >> 3)) + 16u * (lane & 7u)) = v[c];
+      const bool last = tn == nt && !__any((b + 1u) * kRows < avail);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the words are in the slot
+      if (lane == 0u) sync[L::kSeq + slot] = (b + 1u) | (last ? L::kLast : 0u);
+      if (last) break;
+    }
+    return;
+  }
+
+  if (role == 3u) {
+    // ================================ digits of finished iterations: LDS -> slab =================================
+    for (unsigned int b_store = 0u;;) {
+      if (b_store < sync[L::kDigPub]) {
+        const unsigned int ds = b_store % L::kDigSlots;
+        const uint2 rec = reinterpret_cast<const uint2*>(area + L::kRec)[ds * 64u + lane];      // (position, bytes)
+        const unsigned char* const src = area + L::kDig + ds * L::kDigSlot + L::kDigStride * lane;
+        // 16 bytes at a time from the stream's position; what a piece carries beyond the iteration's bytes is overwritten
+        // by the next iteration's first piece (this wave stores all of a stream's bytes, in order).  A stream that
+        // outgrows its slab: nothing is stored beyond it; the chain raises the handle's flag.
+        unsigned char* const dst = out + rec.x;
+#pragma unroll
+        for (unsigned int c = 0; c < L::kDigits / 16u; ++c) {
+          if (16u * c < rec.y && rec.x + 16u * c + 16u <= pa.cap) {
+            const uint2 lo = reinterpret_cast<const uint2*>(src)[2 * c], hi = reinterpret_cast<const uint2*>(src)[2 * c + 1];
+            lanes_gstore16(dst + 16u * c, lo, hi);
+          }
+        }
+        ++b_store;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read
+        if (lane == 0u) sync[L::kDigDone] = b_store;
+      } else {
+        // (the chain publishes its last digits, then its exit)
+        if (sync[L::kExit] != 0u && b_store == sync[L::kDigPub]) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    return;
+  }
+
+  // ================================ chain wave ================================
+  __builtin_amdgcn_s_setprio(3);
+  const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
   uint4 st = live ? J.state[s] : make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
   unsigned int base = st.x, s1 = st.y, hd = st.z & 0xFFFFu, had = st.z >> 31, rn = st.w;
   lanes_pin(base, s1, hd, rn);
 
-  const unsigned int ds_off = static_cast<unsigned int>(reinterpret_cast<size_t>(
-                                  (__attribute__((address_space(3))) unsigned char*)stage)) + kStride * lane;
-  unsigned char* const dstage = stage + kStride * lane;
-  unsigned char* const out = J.chunk + (live ? s : 0) * static_cast<int64_t>(pa.cap);
   unsigned int wpos = 0u, n = 0u, overflow = 0u;
+  unsigned char* dstage = area + L::kDig + L::kDigStride * lane;               // this lane's digits of the iteration
+  unsigned int ds_off = area_off + L::kDig + L::kDigStride * lane;             // ... as an LDS address
 
   auto put = [&](unsigned int d, bool on) {
     *reinterpret_cast<unsigned short*>(dstage + n) = __builtin_bswap16(static_cast<unsigned short>(d));
     n += on ? 2u : 0u;
   };
-  auto flush = [&]() {
-#pragma unroll
-    for (unsigned int c = 0; c < kDigits / 16u; ++c) {
-      if (16u * c < n) {
-        uint2 v[2];
-        v[0] = reinterpret_cast<const uint2*>(dstage)[2 * c];
-        v[1] = reinterpret_cast<const uint2*>(dstage)[2 * c + 1];
-        if (pa.dbg & 1) {}
-        else if (wpos + 16u * c + 16u <= pa.cap) lanes_gstore16(out + wpos + 16u * c, v[0], v[1]);
-        else overflow = 1u;
-      }
-    }
-    wpos += n;
-    n = 0u;
-  };
+  // (rare: a run of 0xFFFF digits settles) the run's bytes behind the iteration's digits; a run that does not fit the
+  // slot gives the job to the fallback
+  bool too_long = false;
   auto put_run = [&](unsigned int fill, unsigned int bytes) {
-    flush();
-    for (unsigned int k = 0; k < bytes; k += 2u) {
-      const unsigned short be = static_cast<unsigned short>(fill);
-      if (wpos + 2u <= pa.cap) lanes_gstore_elem(reinterpret_cast<unsigned short*>(out + wpos), be);
-      else overflow = 1u;
-      wpos += 2u;
+    if (n + bytes + 2u > L::kDigits) {
+      too_long = true;
+      return;
     }
+    for (unsigned int k = 0; k < bytes; k += 2u) *reinterpret_cast<unsigned short*>(dstage + n + k) = static_cast<unsigned short>(fill);
+    n += bytes;
   };
   // one coder call on [lo, hi) / 2^16 for the lanes with `act` — the generic call of range_lanes.h
   // (enc_lanes_kernel::call), every case of the held-digit bookkeeping
@@ -415,59 +596,13 @@ __global__ void __launch_bounds__(256) enc_chain_kernel(const PipeChainJobs jobs
     base = act ? (ren ? bs << 16 : bs) : base;
     s1 = act ? (ren ? (t1 << 16) | 0xFFFFu : t1) : s1;
   };
-
-  // ---- what the expansion has released so far --------------------------------------------------------
-  const unsigned int nt = static_cast<unsigned int>(pa.nt);
-  const unsigned int* const status = pa.status + static_cast<size_t>(gi) * nt * 64 + lane;
-  const unsigned int* const done = pa.done + static_cast<size_t>(gi) * nt;
-  unsigned int avail = 0u;      // rows of this lane's stream that are in memory; all of them once tn == nt
-  unsigned int tn = 0u;         // tiles [0, tn) are in
-  bool bail = false;
-  long long waited = 0, waits = 0;
-  // rows [0, need) of every stream in memory (or all the stream has)
-  auto ensure = [&](unsigned int need) {
-    while (tn < nt && __any(live && avail < need)) {
-      const unsigned int* const flag = done + tn;
-      long long t0 = 0;
-      bool timing = false;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        const long long now = static_cast<long long>(wall_clock64());
-        if (!timing) { t0 = now; timing = true; }
-        else if (now - t0 > pa.poll_ticks) { bail = true; return; }
-        __builtin_amdgcn_s_sleep(8);
-      }
-      if (timing) { waited += static_cast<long long>(wall_clock64()) - t0; ++waits; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      avail = __hip_atomic_load(status + static_cast<size_t>(tn) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kPipeRowsMask;
-      ++tn;
-      // a tile that did not fit, or too many escape codes somewhere in the job: nothing of it is kept
-      if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bail = true; return; }
-    }
-  };
-
-  const unsigned char* const mine = reinterpret_cast<const unsigned char*>(pa.calls + (static_cast<size_t>(gi) * 64 + lane) * pa.rows);
-  // The rows of iteration b.  Requested a whole iteration before they are used, and taken over (`w = wn`) in front of
-  // the iteration's own loads and stores: hipcc turns any wait for a load into s_waitcnt vmcnt(0) while a store may be
-  // in flight (gfx9 counts both on vmcnt), so the one wait of an iteration has to sit where everything in flight
-  // is an iteration old.
-  unsigned int w[kRows] = {}, wn[kRows] = {};
-  auto load_rows = [&](unsigned int b) {
-    const unsigned char* p = mine + static_cast<size_t>(b) * (kRows * 4u);
-#pragma unroll
-    for (unsigned int c = 0; c < kRows / 4u; ++c) {
-      const uint4 v = (pa.dbg & 2) ? make_uint4(0x80004000u, 0x80004000u, 0x80004000u, 0x80004000u) : lanes_gload16(p + 16u * c);
-      wn[4 * c] = v.x; wn[4 * c + 1] = v.y; wn[4 * c + 2] = v.z; wn[4 * c + 3] = v.w;
-    }
-  };
   // one hand-scheduled block on 16 call words
-  auto block = [&](unsigned int w0, unsigned int w1, unsigned int w2, unsigned int w3, unsigned int w4, unsigned int w5,
-                   unsigned int w6, unsigned int w7, unsigned int w8, unsigned int w9, unsigned int w10, unsigned int w11,
-                   unsigned int w12, unsigned int w13, unsigned int w14, unsigned int w15) __attribute__((always_inline)) {
+  auto block = [&](const unsigned int (&ww)[kPipeBlock]) __attribute__((always_inline)) {
     const unsigned int base0 = base, s10 = s1, hd0 = hd, had0 = had;
     unsigned int flag = rn, na = ds_off + n;
     asm volatile(
         "s_mov_b64 s[56:57], exec\n\t"
-        "v_mov_b32 v153, 0\n\tv_mov_b32 v155, 0\n\t"
+        "v_mov_b32 v101, 0\n\tv_mov_b32 v103, 0\n\t"
         TFC_PENC_STEP(W0) TFC_PENC_STEP(W1) TFC_PENC_STEP(W2) TFC_PENC_STEP(W3)
         TFC_PENC_STEP(W4) TFC_PENC_STEP(W5) TFC_PENC_STEP(W6) TFC_PENC_STEP(W7)
         TFC_PENC_STEP(W8) TFC_PENC_STEP(W9) TFC_PENC_STEP(W10) TFC_PENC_STEP(W11)
@@ -476,18 +611,17 @@ __global__ void __launch_bounds__(256) enc_chain_kernel(const PipeChainJobs jobs
         "s_waitcnt lgkmcnt(0)\n\t"
         : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na), [FLAG] "+v"(flag)
         : [NOCALL] "s"(kPipeNoCall), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u),
-          [W0] "v"(w0), [W1] "v"(w1), [W2] "v"(w2), [W3] "v"(w3), [W4] "v"(w4), [W5] "v"(w5),
-          [W6] "v"(w6), [W7] "v"(w7), [W8] "v"(w8), [W9] "v"(w9), [W10] "v"(w10), [W11] "v"(w11),
-          [W12] "v"(w12), [W13] "v"(w13), [W14] "v"(w14), [W15] "v"(w15)
-        : "vcc", "memory", "s52", "s53", "s56", "s57", "v152", "v153", "v154", "v155", "v160", "v161", "v162", "v163",
-          "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v173", "v174", "v175");
+          [W0] "v"(ww[0]), [W1] "v"(ww[1]), [W2] "v"(ww[2]), [W3] "v"(ww[3]), [W4] "v"(ww[4]), [W5] "v"(ww[5]),
+          [W6] "v"(ww[6]), [W7] "v"(ww[7]), [W8] "v"(ww[8]), [W9] "v"(ww[9]), [W10] "v"(ww[10]), [W11] "v"(ww[11]),
+          [W12] "v"(ww[12]), [W13] "v"(ww[13]), [W14] "v"(ww[14]), [W15] "v"(ww[15])
+        : "vcc", "memory", "s52", "s53", "s56", "s57", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v117", "v118", "v119");
     if (__builtin_expect(!__any(flag != 0u), 1)) {
       n = na - ds_off;
     } else {
       // a digit 0xFFFF was shifted out (it opens a run a later carry may ripple through), or a lane came
       // in inside such a run: the block again from the saved state, call by call
       base = base0; s1 = s10; hd = hd0; had = had0;
-      const unsigned int ww[kPipeBlock] = {w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15};
 #pragma nounroll
       for (unsigned int k = 0; k < kPipeBlock; ++k) {
         unsigned int word = ww[0];
@@ -498,51 +632,89 @@ __global__ void __launch_bounds__(256) enc_chain_kernel(const PipeChainJobs jobs
       }
     }
   };
-
-  ensure(kRows);
-  if (!bail) load_rows(0u);
-  // (waited for here: a value that may still be in flight when the loop is entered would put a wait in front of
-  // the blocks in every iteration)
+  // the call words of an iteration's first / second block out of their slot
+  auto read_words = [&](unsigned int (&ww)[kPipeBlock], unsigned int slot, unsigned int half) {
+    const uint4* const p = reinterpret_cast<const uint4*>(area + L::kCalls + slot * L::kCallSlot + L::kCallStride * lane + 64u * half);
 #pragma unroll
-  for (unsigned int k = 0; k < kRows; ++k) asm volatile("" : "+v"(wn[k]));
-  // (while tiles are outstanding every stream has the whole iteration's rows — ensure() — and more to come)
-  unsigned long long stalled = 0;
-  for (unsigned int b = 0; !bail && (tn < nt || __any(b * kRows < avail)); ++b) {
+    for (unsigned int c = 0; c < kPipeBlock / 4u; ++c) {
+      const uint4 v = p[c];
+      ww[4 * c] = v.x; ww[4 * c + 1] = v.y; ww[4 * c + 2] = v.z; ww[4 * c + 3] = v.w;
+    }
+  };
+  // -> the slot's sequence word once it holds iteration b (or the helper has given up)
+  unsigned long long waited_words = 0, waited_digits = 0;
+  auto wait_words = [&](unsigned int b) {
+    unsigned int v;
+    const unsigned long long c0 = clock64();
+    while ((((v = sync[L::kSeq + b % L::kSlots]) & ~(L::kLast | L::kBail)) != b + 1u) && !(v & L::kBail)) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    waited_words += clock64() - c0;
+    return v;
+  };
+
+  unsigned int wa[kPipeBlock], wb[kPipeBlock];
+  unsigned int seq = wait_words(0u);
+  bool bail = (seq & L::kBail) != 0u;
+  if (!bail) read_words(wa, 0u, 0u);
+  for (unsigned int b = 0; !bail; ++b) {
+    const bool last = (seq & L::kLast) != 0u;
+    read_words(wb, b % L::kSlots, 1u);
+    // the digit slot of this iteration: free once the helper has stored the iteration that used it before
     {
       const unsigned long long c0 = clock64();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stalled += clock64() - c0;
+      while (sync[L::kDigDone] + L::kDigSlots <= b) __builtin_amdgcn_s_sleep(1);
+      waited_digits += clock64() - c0;
     }
-#pragma unroll
-    for (unsigned int k = 0; k < kRows; ++k) w[k] = wn[k];
-    ensure((b + 2u) * kRows);
-    if (bail) break;
-    load_rows(b + 1u);            // (one iteration's rows are allocated behind the last stream's)
-    flush();                      // the digits of the iteration before this one
-    if (__any(avail < (b + 1u) * kRows)) {
-      // the last rows of the shorter streams (every tile is in by now): "no call" behind a stream's last
-#pragma unroll
-      for (unsigned int k = 0; k < kRows; ++k) w[k] = b * kRows + k < avail ? w[k] : kPipeNoCall;
+    const unsigned int dslot = b % L::kDigSlots;
+    dstage = area + L::kDig + dslot * L::kDigSlot + L::kDigStride * lane;
+    ds_off = area_off + L::kDig + dslot * L::kDigSlot + L::kDigStride * lane;
+    n = 0u;
+    block(wa);
+    // (the block waited for `wb`: the slot has been read)
+    if (lane == 0u) sync[L::kConsumed] = b + 1u;
+    if (!last) {
+      seq = wait_words(b + 1u);
+      if (seq & L::kBail) { bail = true; break; }
+      read_words(wa, (b + 1u) % L::kSlots, 0u);
     }
-    block(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
-    block(w[16], w[17], w[18], w[19], w[20], w[21], w[22], w[23], w[24], w[25], w[26], w[27], w[28], w[29], w[30], w[31]);
+    block(wb);
+    // hand the iteration's digits over: (position in the slab, bytes) next to them
+    reinterpret_cast<uint2*>(area + L::kRec)[dslot * 64u + lane] = make_uint2(wpos, n);
+    overflow |= (n != 0u && wpos + ((n + 15u) & ~15u) > pa.cap) ? 1u : 0u;
+    wpos += n;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0u) sync[L::kDigPub] = b + 1u;
+    if (__any(too_long)) {
+      bail = true;
+      if (lane == 0u) atomicOr(&pa.fallback[job], 1u);
+      break;
+    }
+    if (last) break;
   }
-  flush();
-  if (bail) {
-    if (lane == 0) atomicOr(&pa.fallback[job], 1u);
-    return;
-  }
-  if (gi == 0 && lane == 0) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0u) sync[L::kExit] = 1u;
+  if (gi == 0u && lane == 0u) {
     g_pipe_clock[0] = clock64() - clk0;
     g_pipe_clock[1] = wall_clock64() - wall0;
-    g_pipe_clock[4] = waited;
-    g_pipe_clock[6] = stalled;
-    g_pipe_clock[5] = waits;
+    g_pipe_clock[4] = waited_words;
+    g_pipe_clock[6] = waited_digits;
   }
+  if (bail) return;
   if (live) {
     pa.stage_state[static_cast<size_t>(gi) * 64 + lane] = make_uint4(base, s1, (hd & 0xFFFFu) | (had << 31), rn);
     pa.stage_out[static_cast<size_t>(gi) * 64 + lane] = make_uint2(wpos, overflow);
   }
+}
+
+// In front of the expansion, on its stream, when the chain's workgroups take a CU each: returns once they are all
+// running (or `ticks` of wall_clock64() have passed).  Launched side by side, the expansion's thirty thousand
+// workgroups would fill every CU first and a chain workgroup — it needs a CU with nothing else on it — would only be
+// placed when they are through.
+__global__ void enc_gate_kernel(const unsigned int* started, unsigned int want, long long ticks) {
+  const long long t0 = static_cast<long long>(wall_clock64());
+  while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
+         static_cast<long long>(wall_clock64()) - t0 < ticks)
+    __builtin_amdgcn_s_sleep(8);
 }
 
 // Behind the expansion and the chain: the staged successor states become the handles' — unless the job fell back

@@ -22,5 +22,5 @@ for rep in range(3):
     print("overlap", os.environ.get("TFC_PIPE_OVERLAP", "default"), "rep", rep,
           "enc chain: %.3f ms at %.0f MHz;" % (e_w / 1e5, 100.0 * e_c / max(e_w, 1)),
           "dec chain: %.3f ms at %.0f MHz;" % (d_w / 1e5, 100.0 * d_c / max(d_w, 1)),
-          "enc chain waited %.3f ms for tiles in %d waits, %.3f ms at the iteration's vmcnt(0)" % (waited / 1e5, waits, stalled / 2.4e6), flush=True)
+          "enc chain waited %.3f ms for call words, %.3f ms for digit slots" % (waited / 2.4e6, stalled / 2.4e6), flush=True)
     del res
