@@ -2714,10 +2714,13 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
     DevBuf temp;
     if (pipe) {
       const size_t groups = static_cast<size_t>(pa.groups_per_job) * gn;
+      const size_t tiles = static_cast<size_t>(pa.rows) / kParseRows + 1;
       const size_t raw_all = raw_bytes * groups, rec_all = rec_bytes * groups, st_all = 64 * sizeof(uint4) * groups;
       const size_t kend_all = (sizeof(unsigned int) * groups + 255) & ~size_t{255};
       const size_t addr_all = indexed ? ((2 * static_cast<size_t>(streams) * elems * gn + 255) & ~size_t{255}) : 0;
-      TFC_HIP(temp.alloc(raw_all + rec_all + st_all + kend_all + addr_all + 256, st));
+      // zeroed per launch: fallback flags (64 jobs), chain workgroups started, rows released per group, tiles taken
+      const size_t flags_all = (512 + sizeof(unsigned int) * groups * (1 + tiles) + 255) & ~size_t{255};
+      TFC_HIP(temp.alloc(raw_all + rec_all + st_all + kend_all + addr_all + flags_all, st));
       uint8_t* base = temp.as<uint8_t>();
       pa.raw = reinterpret_cast<unsigned int*>(base);
       pa.posrec = reinterpret_cast<unsigned int*>(base + raw_all);
@@ -2726,8 +2729,13 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
       unsigned short* rowaddr = reinterpret_cast<unsigned short*>(base + raw_all + rec_all + st_all + kend_all);
       pa.rowaddr = rowaddr;
       pa.fallback = reinterpret_cast<unsigned int*>(base + raw_all + rec_all + st_all + kend_all + addr_all);
+      pa.started = pa.fallback + 64;
+      pa.progress = pa.fallback + 128;
+      pa.tile_done = pa.progress + groups;
+      pa.groups = static_cast<int>(groups);
+      pa.poll_ticks = 200000;         // 2 ms: the chain releases rows every ~0.2 ms
       // (kend of a group the chain gave up on stays unset: the parse skips the whole job under its fallback flag)
-      TFC_HIP(hipMemsetAsync(pa.fallback, 0, 256, st));
+      TFC_HIP(hipMemsetAsync(pa.fallback, 0, flags_all, st));
       g_pipe_launches.fetch_add(1, std::memory_order_relaxed);
       PipeDecJobs cj;
       cj.streams = streams;
@@ -2744,17 +2752,39 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
         hipLaunchKernelGGL(dec_rows_kernel, dim3(static_cast<unsigned>(ceil_div(rj.per_job, 1024)), static_cast<unsigned>(gn)),
                            dim3(256), 0, st, rj, rowaddr);
       }
-      const dim3 cgrid(static_cast<unsigned>(cj.blocks_per_job * gn));
-      const dim3 pgrid(static_cast<unsigned>(groups * (static_cast<size_t>(pa.rows) / kParseRows + 1)));
-      {
-        KernelTimer t2("dec_chain", st);
-        if (indexed) hipLaunchKernelGGL((dec_chain_kernel<true>), cgrid, dim3(pblock), plds, st, cj, pla, pa);
-        else hipLaunchKernelGGL((dec_chain_kernel<false>), cgrid, dim3(pblock), plds, st, cj, pla, pa);
+      // The chain on the library's own stream, the parse next to it on the caller's: tiles of raw rows are turned
+      // into elements as the chain releases them, and a second pass behind the chain takes what the first left
+      // (the last rows, tiles it did not get in time) and commits the successor states.
+      const int overlap = pipe_overlap();
+      SideStream side;
+      if (overlap) {
+        if (side_stream(st, &side)) return 1;
+        TFC_HIP(hipEventRecord(side.fork, st));
+        TFC_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
       }
+      const hipStream_t cst = overlap ? side.stream : st;
+      const dim3 cgrid(static_cast<unsigned>(cj.blocks_per_job * gn));
+      const dim3 pgrid(static_cast<unsigned>(groups * tiles));
       {
-        KernelTimer t2("dec_parse", st);
+        KernelTimer t2("dec_chain", cst);
+        if (indexed) hipLaunchKernelGGL((dec_chain_kernel<true>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
+        else hipLaunchKernelGGL((dec_chain_kernel<false>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
+      }
+      auto parse = [&](int concurrent) {
+        pa.concurrent = concurrent;
         if (indexed) hipLaunchKernelGGL((dec_parse_kernel<true, Dst>), pgrid, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
         else hipLaunchKernelGGL((dec_parse_kernel<false, Dst>), pgrid, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
+      };
+      {
+        KernelTimer t2("dec_parse", st);
+        if (overlap) {
+          // (the chain's workgroups first: where one takes a CU's whole LDS it cannot be placed next to parse workgroups)
+          hipLaunchKernelGGL(enc_gate_kernel, dim3(1), dim3(1), 0, st, pa.started, cgrid.x, static_cast<long long>(20000));
+          parse(1);
+          TFC_HIP(hipEventRecord(side.join, side.stream));
+          TFC_HIP(hipStreamWaitEvent(st, side.join, 0));
+        }
+        parse(0);
       }
       la.guard = pa.fallback;
     }

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 struct PipeEncChainLds {
   static constexpr unsigned int kRows = 2 * kPipeBlock;      // rows per iteration: two hand-scheduled blocks
   static constexpr unsigned int kSlots = 2;                  // iterations of call words in LDS (one per loader; each has its next one in registers)
-  static constexpr unsigned int kDigSlots = 2;               // iterations of digits the helper may be behind
+  static constexpr unsigned int kDigSlots = 3;               // iterations of digits the storer may be behind
   static constexpr unsigned int kDigits = 2 * kRows + 32;    // digit bytes of a lane and iteration: one digit per call at most, and
                                                              // room for runs of 0xFFFF digits that settle (longer: the fallback)
   static constexpr int kCallStride = 4 * kRows + 16;         // a lane's words of an iteration, 16-byte accesses without bank conflicts
@@ -748,9 +748,17 @@ struct PipeDecArgs {
   uint4* state_out;              // [group][lane]: successor state, committed by dec_parse_kernel
   const unsigned short* rowaddr; // index mode: [job][stream][element] LDS address of the element's directory entry
   unsigned int* fallback;        // [job]
+  unsigned int* progress;        // [group]: rows (and their block records) the chain has released | kPipeFinal at its end
+  unsigned int* tile_done;       // [group][tile of kParseRows rows]: the parse running next to the chain has taken it
+  unsigned int* started;         // chain workgroups that are running (enc_gate_kernel)
   int rows;                      // row capacity of a group (multiple of kPipeBlock)
   int groups_per_job;
+  int groups;                    // of the launch
+  int concurrent;                // dec_parse_kernel: 1 next to the chain (tiles as they are released), 0 behind it (the rest)
+  long long poll_ticks;          // wall_clock64() ticks a concurrent parse workgroup watches its group make no progress before it gives up
 };
+constexpr unsigned int kPipeFinal = 0x80000000u;
+constexpr unsigned int kPipeRelease = 64;      // blocks between two releases of the chain's rows
 struct PipeDecJob { const uint8_t* blob; const long long* off; const uint4* state; };
 struct PipeDecJobs {
   int64_t streams, elems;
@@ -890,6 +898,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   using L = PipeDecLds;
 
   const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+  if (threadIdx.x == 0u) __hip_atomic_fetch_add(pa.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned int job = blockIdx.x / static_cast<unsigned int>(jobs.blocks_per_job);
   const unsigned int wv = (blockIdx.x % static_cast<unsigned int>(jobs.blocks_per_job)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (wv >= static_cast<unsigned int>(pa.groups_per_job)) return;
@@ -1041,6 +1050,13 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
       gave_up = true;                // more rows than planned for (escape codes far beyond the tables' tail mass)
       break;
     }
+    if (k != 0u && (k / kPipeBlock) % kPipeRelease == 0u) {
+      // the rows so far (and their block records) to the parse running next to this kernel: a release costs the wave a
+      // wait for its stores, so it is rare
+      posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos + (M != 0 ? 1u : 0u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0u) __hip_atomic_store(&pa.progress[gi], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     {
       // memory phase: park the windows requested at the previous phase, request from the current positions
       const unsigned int cpos = cw.base + (cp - cw_off);
@@ -1124,10 +1140,15 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   }
   posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos;
   if (gave_up) {
-    if (lane == 0) atomicOr(&pa.fallback[job], 1u);
+    if (lane == 0) {
+      atomicOr(&pa.fallback[job], 1u);
+      __hip_atomic_store(&pa.progress[gi], kPipeFinal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   if (lane == 0) pa.kend[gi] = k;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) __hip_atomic_store(&pa.progress[gi], k | kPipeFinal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (gi == 0 && lane == 0) {
     g_pipe_clock[2] = clock64() - clk0;
     g_pipe_clock[3] = wall_clock64() - wall0;
@@ -1151,6 +1172,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
 // the block records of the chain, an escape symbol collects its value from the bit rows behind it, and the
 // elements of a stream leave in order (coalesced along the stream).
 constexpr int kParseRows = 128;
+constexpr unsigned int kParseMargin = 96;     // rows behind a tile the parse next to the chain waits for
 
 constexpr int kParseEscTables = 2048;     // escape symbols of up to this many tables are staged in LDS
 
@@ -1159,19 +1181,52 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
   constexpr int kPitch = 65;
   __shared__ unsigned int buf[kParseRows * kPitch];
   __shared__ int escsym[kParseEscTables];
+  __shared__ unsigned int incomplete;
   const unsigned int tiles = static_cast<unsigned int>(pa.rows) / kParseRows + 1u;
-  const unsigned int gi = blockIdx.x / tiles, kt = blockIdx.x % tiles;
+  // (tile-major: next to the chain, the tiles it releases first are dispatched first)
+  const unsigned int gi = blockIdx.x % static_cast<unsigned int>(pa.groups), kt = blockIdx.x / static_cast<unsigned int>(pa.groups);
   const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
   const unsigned int wv = gi % static_cast<unsigned int>(pa.groups_per_job);
-  if (pa.fallback[job] != 0u) return;
   const DecLaneJob<Dst>& J = jobs.job[job];
   const unsigned int tid = threadIdx.x, lane = tid & 63u;
-  const unsigned int kend = pa.kend[gi];
   const unsigned int k0 = kt * kParseRows;
-  if (kt == 0u && tid < 64u) {
-    // the chain's successor states become the handle's (nothing is committed when the job fell back)
-    const int64_t s = static_cast<int64_t>(wv) * 64 + tid;
-    if (s < jobs.streams) J.state[s] = pa.state_out[static_cast<size_t>(gi) * 64 + tid];
+  unsigned int* const tile_done = pa.tile_done + static_cast<size_t>(gi) * tiles + kt;
+  unsigned int kend;               // rows that may be read
+  bool final = true;               // ... are all the chain wrote
+  if (pa.concurrent) {
+    // Next to the chain: this tile once the chain has released its rows and a margin behind them (the bit rows of an
+    // escape code that starts in the tile).  Rows that do not arrive in time, or a code that runs past the margin:
+    // the tile is left to the pass behind the chain.
+    const unsigned int need = k0 + kParseRows + kParseMargin;
+    unsigned int* const abandon = pa.started + 1;      // a workgroup saw its group stand still: the chain is not running next to us
+    if (__hip_atomic_load(abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    unsigned int v, seen = ~0u;
+    long long t0 = 0;
+    for (;;) {
+      v = __hip_atomic_load(&pa.progress[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v & kPipeFinal) || v >= need) break;
+      const long long now = static_cast<long long>(wall_clock64());
+      if (v != seen) { seen = v; t0 = now; }
+      else if (now - t0 > pa.poll_ticks) {
+        if (tid == 0u) __hip_atomic_store(abandon, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    final = (v & kPipeFinal) != 0u;
+    kend = v & ~kPipeFinal;
+    if (tid == 0u) incomplete = 0u;
+  } else {
+    if (pa.fallback[job] != 0u) return;
+    if (kt == 0u && tid < 64u) {
+      // the chain's successor states become the handle's (nothing is committed when the job fell back)
+      const int64_t s = static_cast<int64_t>(wv) * 64 + tid;
+      if (s < jobs.streams) J.state[s] = pa.state_out[static_cast<size_t>(gi) * 64 + tid];
+    }
+    if (*tile_done != 0u) return;
+    kend = pa.kend[gi];
   }
   if (k0 >= kend) return;
   const unsigned int* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
@@ -1218,7 +1273,7 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
           // the rows behind an escape symbol carry its Elias-gamma code: M < 0 the unary prefix (-M - 1 zeros
           // before the row), M > 0 calls to go (M = 1: the sign; bit M - 2 of the magnitude otherwise)
           unsigned int val = 0u;
-          bool neg = false;
+          bool neg = false, closed = false;
           for (unsigned int q = k0 + i + 1u; q < kend; ++q) {
             const unsigned int x = q - k0 < nrows ? buf[(q - k0) * kPitch + l] : raw[static_cast<size_t>(q) * 64 + l];
             const int m = static_cast<int>(x) >> 16;
@@ -1231,9 +1286,11 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
               val |= bit << (m - 2);
             } else {
               neg = bit != 0u;
+              closed = true;
               break;
             }
           }
+          if (!closed && !final) incomplete = 1u;      // the code's last rows are not released yet: the pass behind the chain
           v = neg ? -static_cast<int>(val) : static_cast<int>(val) + es - 1;
         }
         dst.store(at, t, v);
@@ -1241,6 +1298,10 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
       p += total;
       pmod = (pmod + total) % untab;
     }
+  }
+  if (pa.concurrent) {
+    __syncthreads();
+    if (tid == 0u && incomplete == 0u) *tile_done = 1u;     // (read by the pass behind the chain: another kernel)
   }
 }
 
