@@ -85,6 +85,8 @@ SIGNATURES = {
                                _int, _int, _int, _vp]),
     "tfc_conv2d_up": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int,
                              _int, _int, _int, _vp]),
+    "tfc_conv2d_gdn": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _vp, _int,
+                              C.POINTER(_int), _vp]),
     "tfc_conv2d_wgrad": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int,
                                 _int, _int, _int, _vp]),
     "tfc_factorized_bits_forward": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _int, _int,

@@ -1,16 +1,9 @@
 // GDN / IGDN forward entry point (kernels: gdn_common.h).
 #include "gdn_common.h"
+#include "gdn_params.h"
 
 #include <cmath>
 #include <memory>
-
-// Prepared parameters of the forward kernels: the fragment-ordered image of (gamma, beta) the kernels copy
-// into LDS, built once instead of once per call (inference: the parameters do not change between calls).
-struct tfc_gdn_params {
-  tfc::DevBuf image;
-  int64_t channels = 0;
-  int dtype = 0;
-};
 
 namespace {
 int gdn_forward_any(const void* x, void* y, int dtype, int64_t pixels, int64_t channels, const float* beta,

@@ -1697,8 +1697,8 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
       DevBuf temp;
       if (pipe) {
         const size_t groups = static_cast<size_t>(pa.groups_per_job) * gn;
-        // (room behind the last stream: the chain requests an iteration's rows ahead)
-        const size_t calls_bytes = (groups * 64 * pa.rows + 4 * kPipeBlock) * sizeof(unsigned int);
+        // (room behind the last group: the one-wave chain requests an iteration's rows ahead)
+        const size_t calls_bytes = (groups * 64 * pa.rows + 64 * PipeEncChainLds::kRows) * sizeof(unsigned int);
         const size_t stage_bytes = groups * 64 * (sizeof(uint4) + sizeof(uint2));
         const size_t status_bytes = groups * pa.nt * 64 * sizeof(unsigned int);
         const size_t done_bytes = (groups * pa.nt * sizeof(unsigned int) + 255) & ~size_t{255};
@@ -1724,7 +1724,13 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         cj.streams = streams;
         for (int k = 0; k < gn; ++k)
           cj.job[k] = PipeChainJob{jobs.job[k].state, jobs.job[k].chunk, jobs.job[k].chunk_len, jobs.job[k].overflow_flag};
-        const int overlap = pipe_overlap();
+        // A large launch: the chain (workgroups of four groups, helper waves: range_pipe.h) on the library's own stream
+        // next to the expansion.  A small one — a model step's few groups, next to other steps' convolutions — one-wave
+        // chain workgroups behind the expansion on the caller's stream: measured on bmshj2018 with steps in flight, the
+        // second stream, its events and the large workgroups cost more (45 against 36 ms per step) than the overlap of
+        // two short kernels gives.
+        const bool large = groups >= 64;
+        const int overlap = large ? pipe_overlap() : 0;
         SideStream side;
         if (overlap) {
           if (side_stream(st, &side)) return 1;
@@ -1738,18 +1744,20 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
           if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
           else hipLaunchKernelGGL((enc_expand_kernel<false, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
         };
-        // chain workgroups: a chain wave and three helper waves per group; four groups each (a CU to themselves) when
-        // the launch is large (range_pipe.h, enc_chain_kernel)
-        const int cgroups = groups >= 64 ? PipeEncChainLds::kGroups : 1;
+        const int cgroups = PipeEncChainLds::kGroups;
         const unsigned cblocks = static_cast<unsigned>(ceil_div(static_cast<int64_t>(groups), cgroups));
         const int clds = cgroups * PipeEncChainLds::kGroup;
-        TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    PipeEncChainLds::kGroups * PipeEncChainLds::kGroup));
+        if (large)
+          TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, clds));
         auto chain = [&] {
           KernelTimer t2("enc_chain", cst);
+          if (!large) {
+            hipLaunchKernelGGL(enc_chain_direct_kernel, dim3(static_cast<unsigned>(groups)), dim3(64), 0, cst, cj, pa);
+            return;
+          }
           hipLaunchKernelGGL(enc_chain_kernel, dim3(cblocks), dim3(256 * cgroups), clds, cst, cj, pa);
           // (the expansion behind the chain's workgroups, not in their way)
-          if (overlap == 2 && cgroups > 1)
+          if (overlap == 2)
             hipLaunchKernelGGL(enc_gate_kernel, dim3(1), dim3(1), 0, st, pa.started, cblocks, static_cast<long long>(20000));
         };
         if (overlap == 2) { chain(); expand(); }
@@ -2755,7 +2763,8 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
       // The chain on the library's own stream, the parse next to it on the caller's: tiles of raw rows are turned
       // into elements as the chain releases them, and a second pass behind the chain takes what the first left
       // (the last rows, tiles it did not get in time) and commits the successor states.
-      const int overlap = pipe_overlap();
+      // (a large launch only: see encode_lanes_many)
+      const int overlap = groups >= 64 ? pipe_overlap() : 0;
       SideStream side;
       if (overlap) {
         if (side_stream(st, &side)) return 1;
@@ -2775,15 +2784,18 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
         if (indexed) hipLaunchKernelGGL((dec_parse_kernel<true, Dst>), pgrid, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
         else hipLaunchKernelGGL((dec_parse_kernel<false, Dst>), pgrid, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
       };
+      if (overlap) {
+        KernelTimer t2("dec_parse_next", st);      // (next to the chain: as long as the chain, by construction)
+        // (the chain's workgroups first: where one takes a CU's whole LDS it cannot be placed next to parse workgroups)
+        hipLaunchKernelGGL(enc_gate_kernel, dim3(1), dim3(1), 0, st, pa.started, cgrid.x, static_cast<long long>(20000));
+        parse(1);
+      }
+      if (overlap) {
+        TFC_HIP(hipEventRecord(side.join, side.stream));
+        TFC_HIP(hipStreamWaitEvent(st, side.join, 0));
+      }
       {
-        KernelTimer t2("dec_parse", st);
-        if (overlap) {
-          // (the chain's workgroups first: where one takes a CU's whole LDS it cannot be placed next to parse workgroups)
-          hipLaunchKernelGGL(enc_gate_kernel, dim3(1), dim3(1), 0, st, pa.started, cgrid.x, static_cast<long long>(20000));
-          parse(1);
-          TFC_HIP(hipEventRecord(side.join, side.stream));
-          TFC_HIP(hipStreamWaitEvent(st, side.join, 0));
-        }
+        KernelTimer t2("dec_parse", st);           // behind the chain: what the first pass left
         parse(0);
       }
       la.guard = pa.fallback;

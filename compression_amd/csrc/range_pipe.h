@@ -353,8 +353,8 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 struct PipeEncChainLds {
   static constexpr unsigned int kRows = 2 * kPipeBlock;      // rows per iteration: two hand-scheduled blocks
   static constexpr unsigned int kSlots = 2;                  // iterations of call words in LDS (one per loader; each has its next one in registers)
-  static constexpr unsigned int kDigSlots = 3;               // iterations of digits the storer may be behind
-  static constexpr unsigned int kDigits = 2 * kRows + 32;    // digit bytes of a lane and iteration: one digit per call at most, and
+  static constexpr unsigned int kDigSlots = 2;               // iterations of digits the storer may be behind
+  static constexpr unsigned int kDigits = 2 * kRows + 16;    // digit bytes of a lane and iteration: one digit per call at most, and
                                                              // room for runs of 0xFFFF digits that settle (longer: the fallback)
   static constexpr int kCallStride = 4 * kRows + 16;         // a lane's words of an iteration, 16-byte accesses without bank conflicts
   static constexpr int kCallSlot = 64 * kCallStride;
@@ -375,6 +375,8 @@ struct PipeEncChainLds {
   static constexpr unsigned int kLast = 0x80000000u, kBail = 0x40000000u;
 };
 static_assert(PipeEncChainLds::kGroups * PipeEncChainLds::kGroup <= 160 * 1024 && PipeEncChainLds::kSlots <= 3, "a chain workgroup's LDS");
+// (a model step's few groups go out one group per workgroup: it has to fit in beside two 64 KB convolution workgroups)
+static_assert(PipeEncChainLds::kGroup <= 32 * 1024, "a one-group chain workgroup next to the convolutions");
 struct PipeChainJob { uint4* state; uint8_t* chunk; unsigned int* chunk_len; unsigned int* overflow_flag; };
 struct PipeChainJobs {
   int64_t streams;
@@ -705,6 +707,213 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
     pa.stage_out[static_cast<size_t>(gi) * 64 + lane] = make_uint2(wpos, overflow);
   }
 }
+
+// The same chain as ONE wave that requests its call words and stores its digits itself: the workgroups of a small
+// launch (a model step's few groups) — 64 threads and 5 KB of LDS find room on a CU that convolutions of other steps
+// keep busy, where a chain workgroup with helpers (30 KB, four waves) waits for one to come free (bmshj2018 with
+// steps in flight: 36.2 against 33.4 ms per step).  Runs behind the expansion on the caller's stream.
+__global__ void __launch_bounds__(64) enc_chain_direct_kernel(const PipeChainJobs jobs, const PipeEncArgs pa) {
+  // rows per iteration of the main loop: two hand-scheduled blocks, so that the rows requested in one iteration have a
+  // whole iteration (~6 k cycles) to arrive
+  constexpr unsigned int kRows = PipeEncChainLds::kRows;
+  constexpr unsigned int kDigits = 2 * kRows;           // digit bytes staged per lane between two flushes (one digit per call at most)
+  constexpr int kStride = lane_stride(kDigits + 8);
+  __shared__ __attribute__((aligned(16))) unsigned char stage[64 * kStride];
+  const unsigned int gi = blockIdx.x;
+  const unsigned int job = gi / static_cast<unsigned int>(pa.groups_per_job);
+  const unsigned int gidx = gi % static_cast<unsigned int>(pa.groups_per_job);
+  if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  const PipeChainJob& J = jobs.job[job];
+  const unsigned int lane = threadIdx.x;
+  const int64_t s = static_cast<int64_t>(gidx) * 64 + lane;
+  const bool live = s < jobs.streams;
+
+  uint4 st = live ? J.state[s] : make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
+  unsigned int base = st.x, s1 = st.y, hd = st.z & 0xFFFFu, had = st.z >> 31, rn = st.w;
+  lanes_pin(base, s1, hd, rn);
+
+  const unsigned int ds_off = static_cast<unsigned int>(reinterpret_cast<size_t>(
+                                  (__attribute__((address_space(3))) unsigned char*)stage)) + kStride * lane;
+  unsigned char* const dstage = stage + kStride * lane;
+  unsigned char* const out = J.chunk + (live ? s : 0) * static_cast<int64_t>(pa.cap);
+  unsigned int wpos = 0u, n = 0u, overflow = 0u;
+
+  auto put = [&](unsigned int d, bool on) {
+    *reinterpret_cast<unsigned short*>(dstage + n) = __builtin_bswap16(static_cast<unsigned short>(d));
+    n += on ? 2u : 0u;
+  };
+  auto flush = [&]() {
+#pragma unroll
+    for (unsigned int c = 0; c < kDigits / 16u; ++c) {
+      if (16u * c < n) {
+        uint2 v[2];
+        v[0] = reinterpret_cast<const uint2*>(dstage)[2 * c];
+        v[1] = reinterpret_cast<const uint2*>(dstage)[2 * c + 1];
+        if (wpos + 16u * c + 16u <= pa.cap) lanes_gstore16(out + wpos + 16u * c, v[0], v[1]);
+        else overflow = 1u;
+      }
+    }
+    wpos += n;
+    n = 0u;
+  };
+  auto put_run = [&](unsigned int fill, unsigned int bytes) {
+    flush();
+    for (unsigned int k = 0; k < bytes; k += 2u) {
+      const unsigned short be = static_cast<unsigned short>(fill);
+      if (wpos + 2u <= pa.cap) lanes_gstore_elem(reinterpret_cast<unsigned short*>(out + wpos), be);
+      else overflow = 1u;
+      wpos += 2u;
+    }
+  };
+  // one coder call on [lo, hi) / 2^16 for the lanes with `act` — the generic call of range_lanes.h
+  // (enc_lanes_kernel::call), every case of the held-digit bookkeeping
+  auto call = [&](unsigned int lo, unsigned int hi, bool act) __attribute__((always_inline)) {
+    const unsigned int a = scale16(s1, lo);
+    const unsigned int b = scale16(s1, hi) - 1u;
+    const unsigned int bs = base + a;
+    const unsigned int t1 = b - a;
+    const bool carry = act && bs < a;
+    const bool ren = act && (t1 >> 16) == 0u;
+    const unsigned int e = bs >> 16;
+    const bool solid = ren && e != 0xFFFFu;
+    const bool ffff = ren && e == 0xFFFFu;
+    const bool held = had != 0u;
+    const unsigned int X = (hd + (carry ? 1u : 0u)) & 0xFFFFu;
+    const bool emit = held && (solid || (carry && (!ffff || rn != 0u)));
+    put(X, emit);
+    const unsigned int run_out = !held ? 0u : solid ? rn : (carry && rn != 0u) ? (ffff ? rn - 1u : rn) : 0u;
+    if (__any(run_out != 0u)) {
+      if (run_out != 0u) put_run(carry ? 0u : 0xFFFFu, 2u * run_out);
+    }
+    if (solid) {
+      hd = e; had = 1u; rn = 0u;
+    } else if (ffff) {
+      if (!held) { hd = 0xFFFFu; had = 1u; rn = 0u; }
+      else if (!carry) { rn += 1u; }
+      else if (rn == 0u) { hd = X; rn = 1u; }
+      else { hd = 0u; rn = 1u; }
+    } else if (carry && held) {
+      had = 0u; rn = 0u;
+    }
+    base = act ? (ren ? bs << 16 : bs) : base;
+    s1 = act ? (ren ? (t1 << 16) | 0xFFFFu : t1) : s1;
+  };
+
+  // ---- what the expansion has released so far --------------------------------------------------------
+  const unsigned int nt = static_cast<unsigned int>(pa.nt);
+  const unsigned int* const status = pa.status + static_cast<size_t>(gi) * nt * 64 + lane;
+  const unsigned int* const done = pa.done + static_cast<size_t>(gi) * nt;
+  unsigned int avail = 0u;      // rows of this lane's stream that are in memory; all of them once tn == nt
+  unsigned int tn = 0u;         // tiles [0, tn) are in
+  bool bail = false;
+  // rows [0, need) of every stream in memory (or all the stream has)
+  auto ensure = [&](unsigned int need) {
+    while (tn < nt && __any(live && avail < need)) {
+      const unsigned int* const flag = done + tn;
+      long long t0 = 0;
+      bool timing = false;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        const long long now = static_cast<long long>(wall_clock64());
+        if (!timing) { t0 = now; timing = true; }
+        else if (now - t0 > pa.poll_ticks) { bail = true; return; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      avail = __hip_atomic_load(status + static_cast<size_t>(tn) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kPipeRowsMask;
+      ++tn;
+      // a tile that did not fit, or too many escape codes somewhere in the job: nothing of it is kept
+      if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bail = true; return; }
+    }
+  };
+
+  // (an iteration's words of the group are 8 KB in a row, [stream][32]: this lane's are 128 bytes of them)
+  const unsigned char* const mine = reinterpret_cast<const unsigned char*>(pa.calls + static_cast<size_t>(gi) * 64 * pa.rows) + 128u * lane;
+  // The rows of iteration b.  Requested a whole iteration before they are used, and taken over (`w = wn`) in front of
+  // the iteration's own loads and stores: hipcc turns any wait for a load into s_waitcnt vmcnt(0) while a store may be
+  // in flight (gfx9 counts both on vmcnt), so the one wait of an iteration has to sit where everything in flight
+  // is an iteration old.
+  unsigned int w[kRows] = {}, wn[kRows] = {};
+  auto load_rows = [&](unsigned int b) {
+    const unsigned char* p = mine + static_cast<size_t>(b) * (64u * kRows * 4u);
+#pragma unroll
+    for (unsigned int c = 0; c < kRows / 4u; ++c) {
+      const uint4 v = lanes_gload16(p + 16u * c);
+      wn[4 * c] = v.x; wn[4 * c + 1] = v.y; wn[4 * c + 2] = v.z; wn[4 * c + 3] = v.w;
+    }
+  };
+  // one hand-scheduled block on 16 call words
+  auto block = [&](unsigned int w0, unsigned int w1, unsigned int w2, unsigned int w3, unsigned int w4, unsigned int w5,
+                   unsigned int w6, unsigned int w7, unsigned int w8, unsigned int w9, unsigned int w10, unsigned int w11,
+                   unsigned int w12, unsigned int w13, unsigned int w14, unsigned int w15) __attribute__((always_inline)) {
+    const unsigned int base0 = base, s10 = s1, hd0 = hd, had0 = had;
+    unsigned int flag = rn, na = ds_off + n;
+    asm volatile(
+        "s_mov_b64 s[56:57], exec\n\t"
+        "v_mov_b32 v101, 0\n\tv_mov_b32 v103, 0\n\t"
+        TFC_PENC_STEP(W0) TFC_PENC_STEP(W1) TFC_PENC_STEP(W2) TFC_PENC_STEP(W3)
+        TFC_PENC_STEP(W4) TFC_PENC_STEP(W5) TFC_PENC_STEP(W6) TFC_PENC_STEP(W7)
+        TFC_PENC_STEP(W8) TFC_PENC_STEP(W9) TFC_PENC_STEP(W10) TFC_PENC_STEP(W11)
+        TFC_PENC_STEP(W12) TFC_PENC_STEP(W13) TFC_PENC_STEP(W14) TFC_PENC_STEP(W15)
+        "s_mov_b64 exec, s[56:57]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na), [FLAG] "+v"(flag)
+        : [NOCALL] "s"(kPipeNoCall), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u),
+          [W0] "v"(w0), [W1] "v"(w1), [W2] "v"(w2), [W3] "v"(w3), [W4] "v"(w4), [W5] "v"(w5),
+          [W6] "v"(w6), [W7] "v"(w7), [W8] "v"(w8), [W9] "v"(w9), [W10] "v"(w10), [W11] "v"(w11),
+          [W12] "v"(w12), [W13] "v"(w13), [W14] "v"(w14), [W15] "v"(w15)
+        : "vcc", "memory", "s52", "s53", "s56", "s57", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v117", "v118", "v119");
+    if (__builtin_expect(!__any(flag != 0u), 1)) {
+      n = na - ds_off;
+    } else {
+      // a digit 0xFFFF was shifted out (it opens a run a later carry may ripple through), or a lane came
+      // in inside such a run: the block again from the saved state, call by call
+      base = base0; s1 = s10; hd = hd0; had = had0;
+      const unsigned int ww[kPipeBlock] = {w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15};
+#pragma nounroll
+      for (unsigned int k = 0; k < kPipeBlock; ++k) {
+        unsigned int word = ww[0];
+#pragma unroll
+        for (unsigned int q = 1; q < kPipeBlock; ++q) word = k == q ? ww[q] : word;
+        const unsigned int hi = word >> 16;
+        call(word & 0xFFFFu, hi == 0u ? 65536u : hi, word != kPipeNoCall);
+      }
+    }
+  };
+
+  ensure(kRows);
+  if (!bail) load_rows(0u);
+  // (waited for here: a value that may still be in flight when the loop is entered would put a wait in front of
+  // the blocks in every iteration)
+#pragma unroll
+  for (unsigned int k = 0; k < kRows; ++k) asm volatile("" : "+v"(wn[k]));
+  // (while tiles are outstanding every stream has the whole iteration's rows — ensure() — and more to come)
+  for (unsigned int b = 0; !bail && (tn < nt || __any(b * kRows < avail)); ++b) {
+#pragma unroll
+    for (unsigned int k = 0; k < kRows; ++k) w[k] = wn[k];
+    ensure((b + 2u) * kRows);
+    if (bail) break;
+    load_rows(b + 1u);            // (one iteration's rows are allocated behind the last stream's)
+    flush();                      // the digits of the iteration before this one
+    if (__any(avail < (b + 1u) * kRows)) {
+      // the last rows of the shorter streams (every tile is in by now): "no call" behind a stream's last
+#pragma unroll
+      for (unsigned int k = 0; k < kRows; ++k) w[k] = b * kRows + k < avail ? w[k] : kPipeNoCall;
+    }
+    block(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+    block(w[16], w[17], w[18], w[19], w[20], w[21], w[22], w[23], w[24], w[25], w[26], w[27], w[28], w[29], w[30], w[31]);
+  }
+  flush();
+  if (bail) {
+    if (lane == 0) atomicOr(&pa.fallback[job], 1u);
+    return;
+  }
+  if (live) {
+    pa.stage_state[static_cast<size_t>(gi) * 64 + lane] = make_uint4(base, s1, (hd & 0xFFFFu) | (had << 31), rn);
+    pa.stage_out[static_cast<size_t>(gi) * 64 + lane] = make_uint2(wpos, overflow);
+  }
+}
+
 
 // In front of the expansion, on its stream, when the chain's workgroups take a CU each: returns once they are all
 // running (or `ticks` of wall_clock64() have passed).  Launched side by side, the expansion's thirty thousand

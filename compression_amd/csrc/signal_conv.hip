@@ -31,6 +31,7 @@
 
 #include "../../include/tfc_hip.h"
 #include "common.h"
+#include "gdn_params.h"
 
 namespace tfc {
 
@@ -82,6 +83,10 @@ struct ConvGeom {
   // Third-generation kernel: K runs channel block by channel block, a group's taps inside each
   // (K step = cbi * taps + tap); with `compact` tap rectangles for every group.
   int cbmajor;
+  // GDN / IGDN as the layer's activation (third-generation kernel: a workgroup holds all channels of its pixels):
+  // 0 none, 1 y / (beta + gamma^T |y|), 2 y * (beta + gamma^T |y|); the prepared bfloat16 image of tfc_gdn_params
+  int gdn;
+  const void* gdn_image;
 };
 
 // Third-generation kernel: a workgroup computes an 8 x 32 block of low-resolution output pixels of ONE image
@@ -765,7 +770,7 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
     __builtin_amdgcn_s_barrier();                                        \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      \
   } while (0)
-template <int TILES, int CH, int NCH, int NPG>
+template <int TILES, int CH, int NCH, int NPG, bool GDN = false>
 __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, const void* packed,
                                                             const float* bias, __bf16* y, ConvGeom c,
                                                             Conv3Geom d) {
@@ -896,9 +901,122 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
 
   // ---- epilogue of an item: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel
   // (qy0 + 2 wid + p, qx0 + l); 16-byte stores as in the second generation (Cout % 8 == 0) ----
-  auto epilogue = [&](const Item& it) __attribute__((always_inline)) {
+  // ---- GDN / IGDN as the activation (GDN): the block's accumulators are all TILES * 32 channels of its pixels, in
+  // the register layout the GDN kernel's B fragments have (gdn_common.h: K step s of a lane = channels 16 s + 4 h +
+  // {0..3} and + 8), so |y| goes into the gamma contraction straight from the accumulators: 4 TILES^2 MFMAs per wave
+  // against the K loop's thousands.  gamma's A fragments (the prepared image, 72 KB at 192 channels) are staged in LDS
+  // over the two weight buffers — from L2 a K step of them is ~0.7 us away and 0.1 us of MFMAs (measured: +50 % on the
+  // layer) — so the next item's first weight chunk, which the K loop had already parked there, is requested again
+  // behind the contraction (its second chunk stays in `stage`).  y is rounded to bfloat16 first: the same values the
+  // unfused pair (convolution, then the GDN kernel on its output) works on, contracted in the same order ----
+  constexpr int GDN_PIECES = (TILES * 2 * TILES * 64 * 16 + TILES * 32 * 4 + 4095) / 4096;      // 16-byte pieces per thread
+  auto gdn_stage = [&](int wbuf_next, __amdgpu_buffer_rsrc_t wnext, bf16x8 (&afirst)[TILES]) __attribute__((always_inline)) {
+    constexpr int KT = TILES, KS = 2 * TILES;
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(c.gdn_image), 0, KT * KS * 64 * 16 + KT * 32 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(bias), 0, bias ? KT * 32 * 4 : 0, 0x00020000);      // (no bias: reads as zeros)
+    const unsigned int h16 = static_cast<unsigned int>(h) * 16u;
+    // the image -> LDS, in two rounds of requests (registers); pieces past its end read as zeros
+    TFC_LDS_BARRIER();                  // every wave is through with the weight buffers
+    constexpr int R0 = (GDN_PIECES + 1) / 2;
+    {
+      u32x4 g0[R0];
+#pragma unroll
+      for (int i = 0; i < R0; ++i) g0[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, tid * 16u, i * 4096, 0);
+#pragma unroll
+      for (int i = 0; i < R0; ++i) *reinterpret_cast<u32x4*>(wl + i * 4096 + tid * 16) = g0[i];
+    }
+    u32x4 g1[GDN_PIECES - R0];
+#pragma unroll
+    for (int i = R0; i < GDN_PIECES; ++i) g1[i - R0] = __builtin_amdgcn_raw_buffer_load_b128(gr, tid * 16u, i * 4096, 0);
+    // (under the second round) y = convolution + bias as the bfloat16 tensor would hold it, packed: K step s of the
+    // contraction is xb[p][s] with the sign bits cleared, and the accumulators are free to take the norm
+    u32x4 xb[MT][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int t0 = s >> 1, q0 = 2 * (s & 1);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(br, h16, (32 * t0 + 8 * (q0 + half)) * 4, 0));
+        const int e = 4 * (q0 + half);
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+          xb[p][s][2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
+                                   f32x2{acc[p][t0][e] + b4[0], acc[p][t0][e + 1] + b4[1]}, bf16x2));
+          xb[p][s][2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
+                                       f32x2{acc[p][t0][e + 2] + b4[2], acc[p][t0][e + 3] + b4[3]}, bf16x2));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // (else every bias load of the loop is hoisted to its top)
+    }
+#pragma unroll
+    for (int i = R0; i < GDN_PIECES; ++i) *reinterpret_cast<u32x4*>(wl + i * 4096 + tid * 16) = g1[i - R0];
+    zero_acc();
+    TFC_LDS_BARRIER();
+    const bf16x8* const afr = reinterpret_cast<const bf16x8*>(wl) + lane;
+    const float* const beta_s = reinterpret_cast<const float*>(wl + KT * KS * 1024);
+    bf16x8 ga[2][KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) ga[0][t] = afr[(t * KS) * 64];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int cs = s & 1, ns = cs ^ 1;
+      if (s + 1 < KS) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t) ga[ns][t] = afr[(t * KS + s + 1) * 64];
+      }
+#pragma unroll
+      for (int p = 0; p < MT; ++p) {
+        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, xb[p][s] & 0x7FFF7FFFu);
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+          acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[cs][t], bfrag, acc[p][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the norm's beta out of the image, then the weight buffers go back to the K loop: the next item's first chunk again
+    f32x4 bt[KT][4];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bt[t][q] = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+    TFC_LDS_BARRIER();                  // every wave is through with the image
+    u32x4 st0[STAGE];
+    {
+      const unsigned int v0 = tid * 16u;
+#pragma unroll
+      for (int i = 0; i < STAGE; ++i) st0[i] = __builtin_amdgcn_raw_buffer_load_b128(wnext, v0 + i * 4096u, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < MT; ++p)
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int s = 2 * t + (q >> 1), half = q & 1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned int word = xb[p][s][2 * half + (r >> 1)];
+            const float yv = __uint_as_float((r & 1) ? (word & 0xFFFF0000u) : (word << 16));
+            const float n = acc[p][t][4 * q + r] + bt[t][q][r];
+            acc[p][t][4 * q + r] = yv * (c.gdn == 2 ? n : __builtin_amdgcn_rcpf(n));
+          }
+        }
+    {
+      u32x4* dst = reinterpret_cast<u32x4*>(wl + wbuf_next * WBUF_BYTES) + tid;
+#pragma unroll
+      for (int i = 0; i < STAGE; ++i) dst[i * 256] = st0[i];
+    }
+    TFC_LDS_BARRIER();
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) afirst[t] = (reinterpret_cast<const bf16x8*>(wl + wbuf_next * WBUF_BYTES) + lane)[t * 64];
+  };
+  auto epilogue = [&](const Item& it, int wbuf_next, __amdgpu_buffer_rsrc_t wnext, bf16x8 (&afirst)[TILES])
+                      __attribute__((always_inline)) {
     const int colbase = it.group * TILES * 32;
     const int qx = it.qx0 + l;
+    if constexpr (GDN) gdn_stage(wbuf_next, wnext, afirst);
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
@@ -907,7 +1025,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
         if (col0 >= c.cols) continue;
         const int co = col0 % c.Cout;
         f32x4 be = f32x4{0.f, 0.f, 0.f, 0.f}, bo = be;
-        if (bias) {
+        if (bias && !GDN) {
           be = *reinterpret_cast<const f32x4*>(bias + co + 4 * h);
           if (col0 + 8 < c.cols) bo = *reinterpret_cast<const f32x4*>(bias + (col0 + 8) % c.Cout + 4 * h);
         }
@@ -1083,7 +1201,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       gchunk += NCH;
       ++pcb;
     }
-    epilogue(cur);
+    epilogue(cur, gchunk & 1, wrn, af[0]);
     zero_acc();
     cur = nxt;
     xr = xrn;
@@ -1196,18 +1314,27 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
       if (nts[grp] == ntv) d.glist[d.gcount++] = grp;
     if (!d.gcount) continue;
     const int chv = ntv == 25 ? 5 : ntv == 4 ? 4 : 3;
-    const size_t lds = 2 * patch_bytes + 2 * static_cast<size_t>((chv * c.tiles * 64 + 255) / 256) * 4096;
+    // (with GDN as the activation the two weight buffers and the room behind them also take gamma's fragment image)
+    const size_t gdn_pieces = (static_cast<size_t>(c.tiles) * 2 * c.tiles * 64 * 16 + static_cast<size_t>(c.tiles) * 32 * 4 + 4095) / 4096;
+    const size_t lds = 2 * patch_bytes + std::max(2 * static_cast<size_t>((chv * c.tiles * 64 + 255) / 256) * 4096,
+                                                  c.gdn ? gdn_pieces * 4096 : size_t{0});
+    if (lds > 160 * 1024) return -1;
     // One workgroup per block (its items = the launch's groups).  (A grid of one workgroup per CU, each taking every
     // W-th block, is the same speed alone on the chip but keeps the kernels of other steps in flight out of its CUs:
     // C4 51.6 instead of 47.6 ms per step, profiles/r03_notes.md.)
     const long long nblk = c.N * d.BXn * d.BYn;
     if (nblk >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
     const dim3 grid(static_cast<unsigned>(nblk));
+#define TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, G)                                                          \
+    do {                                                                                                   \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G>),  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
+      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
+    } while (0)
 #define TFC_CONV3_LAUNCH(NT, CHV, NCHV, NPGV)                                                              \
     do {                                                                                                   \
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV>),  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
-      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
+      if (c.gdn) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, true);                                            \
+      else TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, false);                                                 \
     } while (0)
 #define TFC_CONV3_TAPS(NT)                                                   \
     do {                                                                     \
@@ -1219,6 +1346,7 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     if (c.tiles == 6) TFC_CONV3_TAPS(6); else TFC_CONV3_TAPS(4);
 #undef TFC_CONV3_TAPS
 #undef TFC_CONV3_LAUNCH
+#undef TFC_CONV3_LAUNCH_G
   }
   TFC_HIP(hipGetLastError());
   return 0;
@@ -1226,12 +1354,14 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
 
 template <typename T>
 int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom c, PackGeom g,
-             hipStream_t st) {
+             hipStream_t st, int* gdn_fused = nullptr) {
   constexpr int FB = ConvTraits<T>::kFragBytes;
   if constexpr (std::is_same<T, __bf16>::value) {
     const int rc = run_conv3(static_cast<const __bf16*>(x), w, bias, static_cast<__bf16*>(y), c, g, st);
+    if (rc == 0 && c.gdn && gdn_fused) *gdn_fused = 1;
     if (rc >= 0) return rc;
   }
+  c.gdn = 0;                          // (the other kernels leave the activation to the caller)
   const int tiles_total = (c.cols + 31) / 32;
   // image-side layers (first kernel): 3 column tiles per group — half the accumulators, twice the waves per
   // CU; measured 3.39 -> 2.98 ms on the 5x5 3 -> 192 /2 layer of bmshj2018 at 128 x 768x512 (for the 192 -> 192
@@ -1827,7 +1957,8 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
 
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
-               int activation, int up, void* stream, bool out_f32 = false);
+               int activation, int up, void* stream, bool out_f32 = false, const tfc_gdn_params* gdn = nullptr,
+               int gdn_inverse = 0, int* gdn_fused = nullptr);
 
 // Fused variant of the transposed convolution into few channels: 0 = launched, -1 = not this shape, > 0 = error.
 int run_conv_up_fused(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
@@ -1899,7 +2030,9 @@ int conv_up_small_cout(const void* x, const float* w, const float* bias, void* y
 
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
-               int activation, int up, void* stream, bool out_f32) {
+               int activation, int up, void* stream, bool out_f32, const tfc_gdn_params* gdn, int gdn_inverse,
+               int* gdn_fused) {
+  if (gdn_fused) *gdn_fused = 0;
   if (dtype != 0 && dtype != 1) return fail("tfc_conv2d: dtype must be 0 (float32) or 1 (bfloat16)");
   if (kh < 1 || kw < 1 || stride < 1 || cin < 1 || cout < 1) return fail("tfc_conv2d: bad geometry");
   if (!(cin % 16 == 0 || cin <= 4))
@@ -1969,7 +2102,13 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float* wf = static_cast<const float*>(w);
-  return dtype == 1 ? run_conv<__bf16>(x, wf, bias, y, c, g, st) : run_conv<float>(x, wf, bias, y, c, g, st);
+  if (gdn && gdn_fused && dtype == 1 && gdn->dtype == 1 && gdn->channels == cout && activation == 0 && !out_f32) {
+    // GDN / IGDN as the activation: where the third-generation kernel takes the layer (it says so through *gdn_fused)
+    c.gdn = gdn_inverse ? 2 : 1;
+    c.gdn_image = gdn->image.p;
+    const_cast<tfc_gdn_params*>(gdn)->image.touch(st);
+  }
+  return dtype == 1 ? run_conv<__bf16>(x, wf, bias, y, c, g, st, gdn_fused) : run_conv<float>(x, wf, bias, y, c, g, st, gdn_fused);
 }
 
 }  // namespace tfc
@@ -1978,6 +2117,15 @@ extern "C" int tfc_conv2d_down(const void* x, const void* w, const float* bias, 
                                int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh,
                                int kw, int stride, int activation, void* stream) {
   return tfc::conv_entry(x, w, bias, y, dtype, n, h, wd, cin, cout, kh, kw, stride, activation, 0, stream);
+}
+
+extern "C" int tfc_conv2d_gdn(const void* x, const void* w, const float* bias, void* y, int dtype,
+                              int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh,
+                              int kw, int stride, int up, const tfc_gdn_params* gdn, int inverse, int* fused,
+                              void* stream) {
+  if (!gdn || !fused) return tfc::fail("tfc_conv2d_gdn: gdn and fused must not be null");
+  return tfc::conv_entry(x, w, bias, y, dtype, n, h, wd, cin, cout, kh, kw, stride, 0, up, stream, false, gdn, inverse,
+                         fused);
 }
 
 extern "C" int tfc_conv2d_up(const void* x, const void* w, const float* bias, void* y, int dtype,

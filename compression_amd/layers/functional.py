@@ -99,6 +99,30 @@ def _conv(fn_name, x, kernel, bias, stride, activation, up):
     return y
 
 
+def conv2d_gdn(x, kernel, bias, stride, up, prepared: GDNPrepared, inverse: bool):
+    """SignalConv2D with GDN / IGDN as its activation (inference, bfloat16): -> (y, fused).  fused: the convolution
+    kernel applied the activation itself (include/tfc_hip.h, tfc_conv2d_gdn); else y is the convolution's output and
+    the caller applies the GDN kernel."""
+    import ctypes
+    _lib.require_device()
+    x = x.contiguous()
+    n, h, w, cin = x.shape
+    kh, kw, kcin, cout = kernel.shape
+    if kcin != cin:
+        raise ValueError(f"kernel expects {kcin} input channels, input has {cin}")
+    kernel = kernel.detach().to(x.device, torch.float32).contiguous()
+    if bias is not None:
+        bias = bias.detach().to(x.device, torch.float32).contiguous()
+    oh, ow = (h * stride, w * stride) if up else (-(-h // stride), -(-w // stride))
+    y = torch.empty((n, oh, ow, cout), dtype=x.dtype, device=x.device)
+    fused = ctypes.c_int(0)
+    _lib.check(_lib.lib().tfc_conv2d_gdn(
+        x.data_ptr(), kernel.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+        _DTYPE_CODE[x.dtype], n, h, w, cin, cout, kh, kw, int(stride), int(bool(up)), prepared.ptr, int(bool(inverse)),
+        ctypes.byref(fused), _lib.stream_ptr()))
+    return y, bool(fused.value)
+
+
 def conv2d_wgrad(a, b, kernel_support, stride, transpose):
     """Weight gradient kernel: G[t][ca][cb] = sum A[n, q*s + t - k/2, ca] B[n, q, cb] as a float32
     [kh, kw, Cin, Cout] tensor (transpose=True: A carries Cout, B carries Cin)."""

@@ -4,6 +4,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 
 from . import functional, parameters
@@ -168,15 +170,53 @@ class SignalConv2D(torch.nn.Module):
             if not odd:
                 self._check_implemented_fail()
             corr, kernel = False, kernel.flip(0, 1)            # signal_conv.py:875-880
-        if corr:
-            y = functional.conv2d_down(x, kernel, self._bias_value(), down, fused)
+        gdn = self._fusable_gdn(act, x, kernel, corr, up, down)
+        if gdn is not None:
+            # GDN / IGDN as the activation (signal_conv.py:948-950 applying gdn.py:371-421): one kernel where the
+            # convolution kernel that takes the layer can (functional.conv2d_gdn), else the GDN kernel on its output
+            prepared = act._prepared_params(gdn[0], gdn[1], x.dtype)
+            y, done = functional.conv2d_gdn(x, kernel, self._bias_value(), down if corr else up, not corr, prepared,
+                                            act.inverse)
+            if not done:
+                y = functional.gdn_forward(y, gdn[0], gdn[1], act.inverse, False, 1.0, 1.0, prepared=prepared)
         else:
-            y = functional.conv2d_up(x, kernel, self._bias_value(), up, fused)
-            if down != 1:
-                y = y[:, ::down, ::down]
-        if act is not None and fused is None:
-            y = act(y)
+            if corr:
+                y = functional.conv2d_down(x, kernel, self._bias_value(), down, fused)
+            else:
+                y = functional.conv2d_up(x, kernel, self._bias_value(), up, fused)
+                if down != 1:
+                    y = y[:, ::down, ::down]
+            if act is not None and fused is None:
+                y = act(y)
         return y.movedim(-1, 1) if self.data_format == "channels_first" else y
+
+    # GDN / IGDN as the activation inside the convolution kernel (functional.conv2d_gdn).  Off unless asked for
+    # (this attribute, or TFC_CONV_GDN=1 in the environment): measured on bmshj2018 at 128 x 768x512, the fused layers
+    # save 0.6 ms of a lone step's 87 — and cost 1.5 ms of 36.5 per step with several steps in flight, where the separate
+    # GDN kernel (bound by HBM) runs beside other steps' convolutions (bound by the matrix cores) and the fused epilogue
+    # keeps a CU's matrix cores waiting at its barriers (profiles/r04_notes.md).
+    fuse_gdn_activation = os.environ.get("TFC_CONV_GDN", "0") not in ("", "0")
+
+    def _fusable_gdn(self, act, x, kernel, corr, up, down):
+        """(beta, gamma) when `act` is a GDN layer in the configuration the fused entry point covers — inference on the
+        layer's own variables, bfloat16, alpha = epsilon = 1, no rectification, channels-last inside — else None."""
+        from .gdn import GDN
+        if not self.fuse_gdn_activation or not isinstance(act, GDN) or torch.is_grad_enabled() or not x.is_cuda \
+                or x.dtype != torch.bfloat16:
+            return None
+        if (not corr and down != 1) or act.rectify or act._beta_fixed is not None or act._gamma_fixed is not None:
+            return None
+        if act.data_format != "channels_last":          # (the activation is applied to the channels-last tensor inside)
+            return None
+        alpha, epsilon = act.alpha, act.epsilon
+        if torch.is_tensor(alpha) or torch.is_tensor(epsilon) or float(alpha) != 1.0 or float(epsilon) != 1.0:
+            return None
+        cout = kernel.shape[-1]
+        act.build(cout, x.device)
+        beta, gamma = act.beta.to(x.device), act.gamma.to(x.device)
+        if beta.shape != (cout,) or cout % 32 or cout > 256:
+            return None
+        return beta, gamma
 
     def _check_implemented_fail(self):
         raise NotImplementedError("cross-correlation with upsampling needs odd-length kernels")

@@ -408,6 +408,19 @@ int tfc_conv2d_up(const void* x, const void* w, const float* bias, void* y, int 
                   int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout,
                   int kh, int kw, int stride, int activation, void* stream);
 
+/* The layer with GDN / IGDN as its activation — SignalConv2D(activation=GDN(...)), python/layers/signal_conv.py:948-950
+ * applying python/layers/gdn.py:371-421 to the convolution's output, as models/bls2017.py:61-91 and bmshj2018.py build
+ * their transforms — in ONE kernel where the convolution kernel that takes the layer holds all output channels of its
+ * pixels (the third-generation bfloat16 kernel: transposed 5x5 stride-2 layers and small stride-2 maps, Cout 128 / 192):
+ * y = conv(x) + bias rounded to bfloat16, then y / (beta + gamma^T |y|) (inverse = 0) or y * (...) (inverse = 1), alpha =
+ * epsilon = 1, no rectification; `gdn` = tfc_gdn_params_create of the layer's (beta, gamma) for bfloat16.  *fused = 1:
+ * done; *fused = 0: `y` holds the convolution only (another kernel took the layer) and the caller applies
+ * tfc_gdn_forward_prepared to it.  up = 0: tfc_conv2d_down's geometry, 1: tfc_conv2d_up's. */
+int tfc_conv2d_gdn(const void* x, const void* w, const float* bias, void* y, int dtype,
+                   int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh,
+                   int kw, int stride, int up, const tfc_gdn_params* gdn, int inverse, int* fused,
+                   void* stream);
+
 /* Weight gradient of either direction (the reference relies on TF autodiff of
  * signal_conv.py:663-690 / 778-847).  G[t][ca][cb] = sum_{n,q} A[n, q*stride + t - k/2, ca] *
  * B[n, q, cb] with zeros outside A; q runs over B's grid.

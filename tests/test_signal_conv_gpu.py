@@ -345,3 +345,41 @@ def test_bf16_model_layer_shapes_against_scipy(label, shape, kshape, stride, up)
     assert y.shape == want.shape, label
     tol = 2.0 ** -8
     assert np.max(np.abs(y - want) - tol * np.abs(want)) <= 0.51 * tol, label   # exact small sums, 1/2 ulp elsewhere
+
+
+@pytest.mark.parametrize("up,hw,cout", [(True, (24, 64), 192), (True, (32, 64), 128), (False, (64, 64), 192)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_as_the_activation_is_one_kernel(up, hw, cout, inverse):
+    """SignalConv2D(activation=GDN) (signal_conv.py:948-950 applying gdn.py:371-421, the way bls2017.py:61-91 builds its
+    transforms): where the third-generation kernel takes the layer the activation is its epilogue — same values as the
+    convolution followed by the GDN kernel (both work on the bfloat16-rounded convolution output; one bfloat16 unit of
+    the result at most), and no GDN kernel is launched."""
+    import ctypes as C
+    from compression_amd import _lib, layers
+    torch.manual_seed(3)
+    gdn = layers.GDN(inverse=inverse)
+    kw = dict(corr=False, strides_up=2) if up else dict(corr=True, strides_down=2)
+    conv = layers.SignalConv2D(cout, (5, 5), padding="same_zeros", in_channels=192, use_bias=True, activation=gdn, **kw).cuda()
+    plain = layers.SignalConv2D(cout, (5, 5), padding="same_zeros", in_channels=192, use_bias=True, activation=None, **kw).cuda()
+    x = (torch.randn(3, hw[0], hw[1], 192, device="cuda") * 2).to(torch.bfloat16)
+    conv.fuse_gdn_activation = True
+    with torch.no_grad():
+        conv.build(192, x.device)
+        conv.bias.normal_()
+        gdn.build(cout, x.device)
+        gdn.reparam_gamma.add_(torch.rand_like(gdn.reparam_gamma) * 0.05)       # off-diagonal weights too
+        gdn.invalidate_kernel_cache()
+        plain.load_state_dict({k: v for k, v in conv.state_dict().items() if not k.startswith("activation")}, strict=False)
+        lib = _lib.lib()
+        lib.tfc_profile_enable(1)
+        y = conv(x)
+        torch.cuda.synchronize()
+        ms, n = C.c_double(), C.c_int64()
+        lib.tfc_profile_query(b"gdn_forward", C.byref(ms), C.byref(n))
+        lib.tfc_profile_enable(0)
+        assert n.value == 0, "the GDN kernel ran behind a convolution that applies it itself"
+        want = gdn(plain(x))
+    assert y.shape == want.shape
+    err = (y.float() - want.float()).abs()
+    tol = want.float().abs() * 2.0 ** -7 + 1e-6
+    assert bool((err <= tol).all()), float((err - tol).max())
