@@ -16,7 +16,7 @@ def source_stamp():
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for rel in ("compression_amd/csrc/range_coder.hip", "compression_amd/csrc/range_lanes.h",
+    for rel in ("compression_amd/csrc/range_coder.hip", "compression_amd/csrc/range_lanes.h", "compression_amd/csrc/range_pipe.h",
                 "compression_amd/csrc/range_encoder_fast.h", "compression_amd/csrc/range_decoder_fast.h",
                 "compression_amd/csrc/gdn.hip", "compression_amd/csrc/gdn_common.h",
                 "compression_amd/csrc/gdn_backward.hip"):
