@@ -70,9 +70,9 @@ PRECISION = 12
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def build_tables(device):
+def build_tables(device, num_tables=CHANNELS, octave=24.0):
     """192 Gaussian tables through the PRODUCT table builder (HIP pmf_to_quantized_cdf)."""
-    pmfs, _ = synthetic.gaussian_pmfs(num_tables=CHANNELS)
+    pmfs, _ = synthetic.gaussian_pmfs(num_tables=num_tables, octave=octave)
     # PmfToQuantizedCdf takes a rectangular [rows, n] tensor: one call per distinct row length
     by_len = {}
     for i, p in enumerate(pmfs):

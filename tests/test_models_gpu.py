@@ -211,6 +211,53 @@ def test_ms2020_roundtrip_and_slice_order():
         pass                                          # the decoder's sanity check may already reject it
 
 
+def test_ms2020_strings_equal_the_oracles():
+    """ms2020.py:334-382 pinned to something other than itself: every slice's string is, byte for byte, what the
+    reference's index-mode coder (EntropyEncodeIndex + Finalize, range_coder_kernels.cc:217-242, 274-322 — the oracle,
+    pinned to the compiled reference in tests/test_oracle.py) writes for the symbols and scale-table indexes the model
+    hands to it: round(y_k - mu_k) - cdf_offset[index] with index from sigma_k (continuous_indexed.py:272-289, 355-386),
+    the parameters of slice k computed from the decoded slices before it.  The side string likewise, in channel mode
+    (continuous_batched.py:370-383)."""
+    from oracle import oracle
+    port = oracle.best()
+    torch.manual_seed(8)
+    model = tfc.models.MS2020Model(num_filters=64, latent_depth=64, hyperprior_depth=32, num_slices=4,
+                                   max_support_slices=2).cuda().init_compression()
+    x = torch.from_numpy(synthetic.lowpass_images(3, 128, 64, seed=9)).cuda()
+    out = model.compress(x)
+    y_shape, z_shape = out[1], out[2]
+    with torch.no_grad():
+        y = model.analysis_transform(x.float())
+        z = model.hyper_analysis_transform(y)
+        em_z, em_y = model.em_z, model.em_y
+        # side information: channel mode, symbols = round(z - offset) - cdf_offset[channel]
+        zq = em_z.quantize(z)
+        qoff = em_z.quantization_offset
+        zsym = torch.round(z - qoff if qoff is not None else z).to(torch.int32) - em_z.cdf_offset.cuda()
+        want_z, _, _ = port.encode(em_z.cdf.cpu().numpy(), zsym.reshape(3, -1).cpu().numpy())
+        assert [bytes(s) for s in out[3]] == want_z
+        z_hat = em_z.decompress(out[3], z_shape)
+        assert torch.equal(z_hat, zq)
+        ls, lm = model._hyper_features(z_hat, y_shape)
+        lookup = em_y.cdf.cpu().numpy()
+        offsets = em_y.cdf_offset.cuda()
+        slices, escapes = [], 0
+        for k, ys in enumerate(torch.chunk(y, 4, dim=-1)):
+            ms, mu, sigma = model._slice_params(k, lm, ls, slices, y_shape)
+            flat = em_y._table_indexes(sigma.contiguous())
+            sym = torch.round(ys - mu).to(torch.int32) - offsets[flat.long()]
+            sym_h, idx_h = sym.reshape(3, -1).cpu().numpy(), flat.reshape(3, -1).cpu().numpy()
+            want, _, _ = port.encode(lookup, sym_h, index=idx_h)
+            assert [bytes(s) for s in out[4 + k]] == want, f"slice {k}"
+            dec, ok = port.decode(lookup, want, sym_h.shape[1], index=idx_h)
+            assert ok.all() and (dec == sym_h).all()
+            rows = synthetic.lookup_rows(lookup)
+            width = np.array([len(c) - 2 for _, c in rows])
+            escapes += int(((sym_h < 0) | (sym_h >= width[idx_h])).sum())
+            slices.append(model._lrp(k, ms, em_y.quantize(ys, loc=mu)))
+    assert escapes >= 0
+
+
 def test_ms2020_training_forward_and_backward():
     torch.manual_seed(6)
     # slice depth 32 like the full model (latent_depth 320 / 10 slices); the support tensors are 320 + 32 k
