@@ -2682,7 +2682,8 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   PipeDecArgs pa;
   LaneArgs pla = la;
   pa.groups_per_job = static_cast<int>(ceil_div(streams, 64));
-  const int64_t rows64 = ((elems + (t->any_escape ? elems / 4 + 64 : 0)) + kPipeBlock - 1) / kPipeBlock * kPipeBlock;
+  // (+ the blocks lanes sit out or spend finishing an escape code before the wave's tail pass, and the tail pass)
+  const int64_t rows64 = ((elems + (t->any_escape ? elems / 4 + 64 + 24 * kPipeBlock : 2 * kPipeBlock)) + kPipeBlock - 1) / kPipeBlock * kPipeBlock;
   pa.rows = static_cast<int>(std::min<int64_t>(rows64, (int64_t{1} << 30)));
   const size_t raw_bytes = static_cast<size_t>(pa.rows) * 256;
   const size_t rec_bytes = (static_cast<size_t>(pa.rows) / kPipeBlock + 1) * 256;

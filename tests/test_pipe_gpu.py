@@ -158,3 +158,54 @@ def test_many_handles_in_one_launch(tfc, port):
         assert (d.cpu().numpy().reshape(130, 700) == v).all() and bool(ok.all())
     l1, f1 = counters()
     assert (l1 - l0, f1 - f0) == (2, 0)
+
+
+@pytest.mark.parametrize("streams,elems", [(4096, 700), (4100, 333)])
+def test_large_launches_take_the_overlapped_path(tfc, port, streams, elems):
+    """64 groups and more: the encoder's chain workgroups (a chain wave, two loader waves and a storer wave per group)
+    run on the library's own stream beside the expansion, the decoder's parse beside its chain with a second pass
+    behind it (csrc/range_pipe.h).  Same bytes, same symbols, no fallback — with escape codes in the data, a last
+    group that is not full and element counts that end inside a tile, an iteration and a block."""
+    lookup = tables(port, 16)
+    value = synthetic.sample_symbols(lookup, streams, elems, seed=streams, escape_fraction=0.01)
+    assert roundtrip(tfc, port, lookup, value) == (2, 0)
+
+
+def test_large_launch_of_many_handles_in_index_mode(tfc, port):
+    """Ten 512-stream handles behind one launch per stage (80 groups), EntropyEncodeIndex / EntropyDecodeIndex with
+    values far outside the tables in between."""
+    lookup = tables(port, 16)
+    lt = torch.from_numpy(lookup)
+    rng = np.random.default_rng(9)
+    rows = synthetic.lookup_rows(lookup)
+    values, indexes = [], []
+    for k in range(10):
+        index = rng.integers(0, 16, (512, 520)).astype(np.int32)
+        u = rng.integers(0, 1 << 12, index.shape)
+        value = np.zeros(index.shape, np.int32)
+        for t, (_, c) in enumerate(rows):
+            m = index == t
+            value[m] = np.searchsorted(np.asarray(c), u[m], side="right") - 1
+        value = np.where(rng.random(index.shape) < 0.004, rng.integers(-300, 300, index.shape) * 5, value).astype(np.int32)
+        values.append(value)
+        indexes.append(index)
+    from compression_amd import _lib
+    l0, f0 = counters()
+    hs = tfc.create_range_encoders(10, [512], lt, deferred_errors=True)
+    keep = [(dev(i), dev(v)) for i, v in zip(indexes, values)]
+    hp = (C.c_void_p * 10)(*[h.ptr for h in hs])
+    ip = (C.c_void_p * 10)(*[i.data_ptr() for i, _ in keep])
+    vp = (C.c_void_p * 10)(*[v.data_ptr() for _, v in keep])
+    _lib.check(_lib.lib().tfc_encoder_encode_many(10, hp, vp, ip, 520, _lib.stream_ptr()))
+    hs = tfc.entropy_encode_finalize_device_many(hs)
+    ds = tfc.create_range_decoders(hs, lt)
+    outs = [torch.empty(512, 520, dtype=torch.int32, device="cuda") for _ in range(10)]
+    dp = (C.c_void_p * 10)(*[d.ptr for d in ds])
+    op = (C.c_void_p * 10)(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.lib().tfc_decoder_decode_many(10, dp, ip, op, 520, _lib.stream_ptr()))
+    oks = tfc.entropy_decode_finalize_device_many(ds)
+    for h, v, i, o, ok in zip(hs, values, indexes, outs, oks):
+        assert [bytes(s) for s in tfc.fetch_strings(h)] == port.encode(lookup, v, index=i)[0]
+        assert (o.cpu().numpy() == v).all() and bool(ok.all())
+    l1, f1 = counters()
+    assert (l1 - l0, f1 - f0) == (2, 0), (l1 - l0, f1 - f0)
