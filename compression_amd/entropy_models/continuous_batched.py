@@ -141,7 +141,11 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         `device_result=True`: nothing is read back — the call is enqueued on the current HIP stream and
         returns the finalized encoder handle, whose strings stay in HBM (`gen_ops.device_strings`,
         `gen_ops.fetch_strings`; `decompress` takes the handle in place of the strings).  Range errors are
-        then reported by `fetch_strings` / `gen_ops.entropy_encode_status`."""
+        then reported by `fetch_strings` / `gen_ops.entropy_encode_status`.  So is a stream that outgrows the output
+        slab such a call sizes without reading anything back (2 bytes per symbol, a quarter more when the tables have
+        escape rows — i.e. more than ~16-20 bits per symbol on average over a whole stream, which only data far off
+        the model's tables produces): "a stream outgrew its output slab".  The plain call (`device_result=False`)
+        repeats itself with the bound that cannot be exceeded instead; call it for such data."""
         self._check_compression()
         device = _lib.require_device()
         bottleneck = torch.as_tensor(bottleneck).to(device, self.bottleneck_dtype).contiguous()
@@ -226,7 +230,8 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         is set by the symbols per stream, not by the number of streams, until every SIMD holds a wave — the
         way a server that has several batches in flight fills the chip.  Nothing is read back: returns one
         finalized encoder handle per batch (`gen_ops.fetch_strings`, `decompress_many`).  Same strings as
-        compress() batch by batch."""
+        compress() batch by batch.  (Like `compress(device_result=True)`: a stream of more than ~16-20 bits per
+        symbol outgrows the slab, which `fetch_strings` reports.)"""
         self._check_compression()
         device = _lib.require_device()
         bottlenecks = [torch.as_tensor(b).to(device, self.bottleneck_dtype).contiguous() for b in bottlenecks]
