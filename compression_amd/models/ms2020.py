@@ -198,17 +198,22 @@ class MS2020Model(torch.nn.Module):
         z_string = self.em_z.compress(z)
         z_hat = self.em_z.decompress(z_string, z_shape).to(self.compute_dtype)
         latent_scales, latent_means = self._hyper_features(z_hat, y_shape)
-        y_strings, y_hat_slices = [], []
+        residuals, scales, y_hat_slices = [], [], []
         for k, y_slice in enumerate(torch.chunk(y, self.num_slices, dim=-1)):
             mean_support, mu, sigma = self._slice_params(k, latent_means, latent_scales, y_hat_slices, y_shape)
-            s = self.em_y.compress(y_slice.contiguous(), sigma.contiguous(), mu.contiguous())
-            y_strings.append(s)
+            # what the coder gets for this slice (ms2020.py:362-364: compress(y_slice, sigma, loc=mu) codes y_slice - mu).
+            # The encoder needs no slice's string to go on — only the decoder's chain is serial — so the slices'
+            # coder calls go out together behind the loop, ONE launch per stage for all of them.
+            residuals.append((y_slice - mu).contiguous())
+            scales.append(sigma.contiguous())
             # What the decoder will see.  The reference decodes the string it has just written
             # (ms2020.py:366); decode(encode(y)) is round(y - mu) + mu, which quantize() computes without the
             # slice's serial decode (half of compress()'s coder time); the round-trip test checks that the two
             # sides reconstruct the same image bit for bit.
             y_hat_slice = self.em_y.quantize(y_slice, loc=mu).to(self.compute_dtype)
             y_hat_slices.append(self._lrp(k, mean_support, y_hat_slice))
+        from ..ops import gen_ops
+        y_strings = [gen_ops.fetch_strings(h) for h in self.em_y.compress_many(residuals, scales)]
         return (x_shape, y_shape, z_shape, z_string) + tuple(y_strings)
 
     @torch.no_grad()
@@ -217,13 +222,19 @@ class MS2020Model(torch.nn.Module):
         assert len(y_strings) == self.num_slices
         z_hat = self.em_z.decompress(z_string, z_shape).to(self.compute_dtype)
         latent_scales, latent_means = self._hyper_features(z_hat, y_shape)
-        y_hat_slices = []
+        y_hat_slices, checks = [], []
         for k, s in enumerate(y_strings):
             mean_support, mu, sigma = self._slice_params(k, latent_means, latent_scales, y_hat_slices, y_shape)
-            y_hat_slice = self.em_y.decompress(s, sigma.contiguous(), mu.contiguous()).to(self.compute_dtype)
-            y_hat_slices.append(self._lrp(k, mean_support, y_hat_slice))
+            # (the decoder's sanity flags stay on the device until the last slice is enqueued: a read-back per slice
+            # would put a host round trip between every two links of the slice chain)
+            y_hat_slice, ok = self.em_y.decompress(s, sigma.contiguous(), mu.contiguous(), defer_sanity=True)
+            checks.append(ok)
+            y_hat_slices.append(self._lrp(k, mean_support, y_hat_slice.to(self.compute_dtype)))
         x_hat = self.synthesis_transform(torch.cat(y_hat_slices, dim=-1))[:, :x_shape[0], :x_shape[1], :]
-        return torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+        out = torch.clamp(torch.round(x_hat.float()), 0, 255).to(torch.uint8)
+        if self.em_y.decode_sanity_check and not bool(torch.stack([c.all() for c in checks]).all()):
+            raise RuntimeError("Sanity check failed.")
+        return out
 
 
 if __name__ == "__main__":      # python -m compression_amd.models.ms2020 compress in.png out.tfci
