@@ -1800,6 +1800,198 @@ int run_conv_image(const void* x, const float* w, const float* bias, void* y, in
 }
 
 // ---------------------------------------------------------------------------
+// Image-side analysis layer WITH its GDN (bmshj2018's first layer: SignalConv2D(192, 5x5, /2, activation=GDN), Cin = 3).
+// conv_image_kernel writes 4.8 GB at the C4 shape and the GDN kernel reads and writes them again; here a wave takes 32
+// consecutive pixels of an output row at a time, computes their 32 x Cout convolution outputs with a handful of MFMAs
+// — the B fragments are 16 bytes of an image row each, straight from the image (the kw * Cin values of a kernel row are
+// contiguous there) — which leaves them in the accumulators in exactly the layout the GDN contraction wants as ITS B
+// fragments (gdn_common.h), contracts |y| with gamma (fragments in LDS, as in the GDN kernel), divides, and stores the
+// result eight lanes to a pixel (whole 128-byte lines) through a wave-private staging area.  HBM traffic: the image in,
+// the activations out, once.  Same values as conv_image_kernel followed by the GDN kernel: both round the
+// convolution's output to bfloat16 before the GDN and contract in the same order.
+// Persistent: a workgroup (8 waves) stages gamma's image and the convolution's fragments once and its waves walk the
+// tiles; the next tile's image rows are requested a tile ahead.  alpha = epsilon = 1, no rectification, not inverse.
+// ---------------------------------------------------------------------------
+template <int TILES, int NK>
+__global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x, const bf16x8* wpk, const float* bias,
+                                                                const void* gimage, __bf16* y, ImageConvGeom g) {
+  extern __shared__ unsigned char smem[];            // gamma fragments | beta | conv fragments | staging (per wave)
+  constexpr int KT = TILES, KS = 2 * TILES, C = 32 * TILES;
+  constexpr int GFR = KT * KS * 64;
+  constexpr int ROW = 144;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5, l = lane & 31;
+  const bf16x8* const ga = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const float* const beta_s = reinterpret_cast<const float*>(smem + GFR * 16);
+  bf16x8* const wl = reinterpret_cast<bf16x8*>(smem + GFR * 16 + C * 4);
+  constexpr int NFR = NK * TILES * 64;
+  unsigned char* const stg = reinterpret_cast<unsigned char*>(wl + NFR) + wid * (32 * ROW);
+  {
+    const u32x4* src = static_cast<const u32x4*>(gimage);
+    u32x4* dst = reinterpret_cast<u32x4*>(smem);
+    for (int i = tid; i < GFR + C / 4; i += 512) dst[i] = src[i];
+    for (int i = tid; i < NFR; i += 512) wl[i] = wpk[i];
+  }
+  __syncthreads();
+  const int tpr = g.OW / 32;                           // tiles per output row (host: OW % 32 == 0)
+  const long long ntiles = g.N * g.OH * tpr;
+  const long long nwaves = static_cast<long long>(gridDim.x) * 8, wave = static_cast<long long>(blockIdx.x) * 8 + wid;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x), 0, static_cast<unsigned int>(g.N * g.H * g.W * g.Cin * 2), 0x00020000);
+  // K step ks = kernel row ks (5 taps x 3 channels = 15 of its 16 values): lane (l, h) reads values 8 h ... + 7 of the
+  // row that starts two pixels left of pixel 2 l.  Zero padding: a row outside the image is read at an offset outside
+  // the buffer (zeros); left of the image lie the first six values of (l, h) = (0, 0) in a row's first tile — that lane
+  // reads six values further right and the fix-up below moves its first dword to the last; right of the image lie the
+  // last four values of lane (31, 1) in a row's last tile — it reads four values further left (so that no load leaves
+  // the tensor) and the fix-up moves its last two dwords to the front.
+  auto fetch = [&](long long tile, u32x4 (&bq)[NK]) __attribute__((always_inline)) {
+    const int tx = static_cast<int>(tile % tpr);
+    const long long r = tile / tpr;
+    const int oy = static_cast<int>(r % g.OH);
+    const long long n = r / g.OH;
+    const int shift = (tx == 0 && lane == 0) ? 6 : (tx == tpr - 1 && lane == 63) ? -4 : 0;
+    const int col = ((tx * 32 + l) * 2 - 2) * 3 + 8 * h + shift;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int iy = oy * 2 - 2 + ks;
+      const bool rowok = static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H);      // (wave-uniform)
+      const long long e = (n * g.H + iy) * g.W * 3 + col;
+      bq[ks] = __builtin_amdgcn_raw_buffer_load_b128(xr, rowok ? static_cast<unsigned int>(e * 2) : 0xFFFFFFF0u, 0, 0);
+    }
+  };
+  u32x4 bq[NK];
+  if (wave < ntiles) fetch(wave, bq);
+  for (long long tile = wave; tile < ntiles; tile += nwaves) {
+    const int tx = static_cast<int>(tile % tpr);
+    const long long r = tile / tpr;                    // = n * OH + oy
+    {
+      const bool first = tx == 0 && lane == 0, last = tx == tpr - 1 && lane == 63;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const u32x4 v = bq[ks];
+        bq[ks] = first ? u32x4{0u, 0u, 0u, v[0]} : last ? u32x4{v[2], v[3], 0u, 0u} : v;
+      }
+    }
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) acc[t][r2] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(ks * TILES + t) * 64 + lane],
+                                                        __builtin_bit_cast(bf16x8, bq[ks]), acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the next tile's image rows: in flight under the contraction and the epilogue (requested in front of this tile's
+    // stores, so the wait for them does not wait for the stores)
+    if (tile + nwaves < ntiles) fetch(tile + nwaves, bq);
+    // y = convolution + bias as the bfloat16 tensor would hold it: acc[t][4q + r] = channel 32 t + 8 q + 4 h + r of
+    // pixel l, and K step s of the contraction = channels 16 s + 4 h + {0..3} and + 8
+    u32x4 xb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int t0 = s >> 1, q0 = 2 * (s & 1);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + 32 * t0 + 8 * (q0 + half) + 4 * h);
+        const int e = 4 * (q0 + half);
+        xb[s][2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
+                              f32x2{acc[t0][e] + b4[0], acc[t0][e + 1] + b4[1]}, bf16x2));
+        xb[s][2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
+                                  f32x2{acc[t0][e + 2] + b4[2], acc[t0][e + 3] + b4[3]}, bf16x2));
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) acc[t][r2] = 0.f;
+    // gamma's fragments one K step ahead, each register set refilled as soon as its MFMA has read it (a second set
+    // does not fit: 96 accumulators + 48 of y + the next tile's image rows)
+    bf16x8 af[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) af[t] = ga[(t * KS) * 64];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, xb[s] & 0x7FFF7FFFu);
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bfrag, acc[t], 0, 0, 0);
+        if (s + 1 < KS) af[t] = ga[(t * KS + s + 1) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // y / (beta + gamma^T |y|), 64 channels at a time through the staging area, then eight lanes to a pixel
+    __bf16* const yrow = y + (r * g.OW + tx * 32) * C;
+#pragma unroll
+    for (int cnk = 0; cnk < TILES / 2; ++cnk) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * cnk + tt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+          const int s = 2 * t + (q >> 1), half = q & 1;
+          float v[4];
+#pragma unroll
+          for (int r2 = 0; r2 < 4; ++r2) {
+            const unsigned int word = xb[s][2 * half + (r2 >> 1)];
+            const float yv = __uint_as_float((r2 & 1) ? (word & 0xFFFF0000u) : (word << 16));
+            v[r2] = yv * __builtin_amdgcn_rcpf(acc[t][4 * q + r2] + b4[r2]);
+          }
+          uint2 o;
+          o.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          o.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          *reinterpret_cast<uint2*>(stg + l * ROW + (32 * tt + 8 * q + 4 * h) * 2) = o;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int px = 8 * j + (lane >> 3), piece = lane & 7;
+        const u32x4 o = *reinterpret_cast<const u32x4*>(stg + px * ROW + piece * 16);
+        *reinterpret_cast<u32x4*>(yrow + px * C + 64 * cnk + 8 * piece) = o;
+      }
+    }
+  }
+}
+
+// 0 = launched, -1 = not this shape, > 0 = error
+int run_conv_image_gdn(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
+                       int64_t cin, int64_t cout, int kh, int kw, int stride, const tfc_gdn_params* gdn, hipStream_t st) {
+  if (cin != 3 || cout != 192 || stride != 2 || gdn->channels != cout || gdn->dtype != 1) return -1;
+  ImageConvGeom g{};
+  g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin); g.Cout = static_cast<int>(cout);
+  g.kh = kh; g.kw = kw; g.sd = stride; g.py0 = kh / 2; g.px0 = kw / 2; g.activation = 0;
+  g.OH = static_cast<int>((h + stride - 1) / stride); g.OW = static_cast<int>((wd + stride - 1) / stride);
+  g.ksr = (kw * g.Cin + 15) / 16;
+  const int nk = kh * g.ksr;
+  if (kh != 5 || kw != 5 || nk != 5 || g.OW % 32 != 0 || g.W % 2 != 0 || reinterpret_cast<uintptr_t>(x) % 4 != 0) return -1;
+  if (static_cast<double>(n) * h * wd * cin * 2 >= 4294967280.0) return -1;       // one buffer resource over the tensor
+  constexpr int tiles = 6;
+  const size_t lds = static_cast<size_t>(tiles) * 2 * tiles * 64 * 16 + tiles * 32 * 4 +
+                     static_cast<size_t>(nk) * tiles * 64 * 16 + 8 * 32 * 144;
+  if (lds > 160 * 1024) return -1;
+  DevBuf wpk;
+  const int frags = nk * tiles * 64;
+  TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
+  hipLaunchKernelGGL(conv_image_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, g, tiles, wpk.as<bf16x8>());
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long long ntiles = n * g.OH * (g.OW / 32);
+  const unsigned grid = static_cast<unsigned>(std::min<long long>(cus, ceil_div(ntiles, 8)));
+  KernelTimer timer("conv2d", st);
+  TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_gdn_kernel<6, 5>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  hipLaunchKernelGGL((conv_image_gdn_kernel<6, 5>), dim3(grid), dim3(512), lds, st, static_cast<const __bf16*>(x),
+                     wpk.as<bf16x8>(), bias, gdn->image.p, static_cast<__bf16*>(y), g);
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // The same, fused: the tap products of a block never leave the CU.  A workgroup takes an 8 x 32 block of INPUT pixels
 // plus the halo the block's output pixels reach into ((8 + Uy - 1) x (32 + Ux - 1) patch pixels, 340 for a 5x5
 // stride-2 kernel), computes z[patch pixel][(tap, c)] for them with the MFMA (fp32, into LDS: <= 80 columns, row
@@ -2070,6 +2262,16 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
     return conv_up_small_cout(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, activation,
                               static_cast<hipStream_t>(stream));
 #endif
+  if (!up && dtype == 1 && cin <= 4 && !out_f32 && gdn && gdn_fused && !gdn_inverse && activation == 0) {
+    // the image-side layer with its GDN in one kernel: conv_image_gdn_kernel
+    const int rc = run_conv_image_gdn(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, gdn,
+                                      static_cast<hipStream_t>(stream));
+    if (rc == 0) {
+      const_cast<tfc_gdn_params*>(gdn)->image.touch(static_cast<hipStream_t>(stream));
+      *gdn_fused = 1;
+    }
+    if (rc >= 0) return rc;
+  }
   if (!up && dtype == 1 && cin <= 4 && !out_f32) {
     const int rc = run_conv_image(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, activation,
                                   static_cast<hipStream_t>(stream));

@@ -196,13 +196,18 @@ class SignalConv2D(torch.nn.Module):
     # GDN kernel (bound by HBM) runs beside other steps' convolutions (bound by the matrix cores) and the fused epilogue
     # keeps a CU's matrix cores waiting at its barriers (profiles/r04_notes.md).
     fuse_gdn_activation = os.environ.get("TFC_CONV_GDN", "0") not in ("", "0")
+    # The image-side layer (three input channels) is different: its time is its output's HBM traffic, not the matrix
+    # cores, and conv_image_gdn_kernel writes the normalised activations without the round trip (bmshj2018's first
+    # layer at 128 x 768x512: 1.83 + 2.2 ms as two kernels).  On unless TFC_CONV_GDN_IMAGE=0.
+    fuse_gdn_image = os.environ.get("TFC_CONV_GDN_IMAGE", "1") not in ("", "0")
 
     def _fusable_gdn(self, act, x, kernel, corr, up, down):
         """(beta, gamma) when `act` is a GDN layer in the configuration the fused entry point covers — inference on the
         layer's own variables, bfloat16, alpha = epsilon = 1, no rectification, channels-last inside — else None."""
         from .gdn import GDN
-        if not self.fuse_gdn_activation or not isinstance(act, GDN) or torch.is_grad_enabled() or not x.is_cuda \
-                or x.dtype != torch.bfloat16:
+        image_side = self.fuse_gdn_image and corr and kernel.shape[-2] <= 4 and not getattr(act, "inverse", True)
+        if not (self.fuse_gdn_activation or image_side) or not isinstance(act, GDN) or torch.is_grad_enabled() \
+                or not x.is_cuda or x.dtype != torch.bfloat16:
             return None
         if (not corr and down != 1) or act.rectify or act._beta_fixed is not None or act._gamma_fixed is not None:
             return None

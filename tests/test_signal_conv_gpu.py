@@ -383,3 +383,43 @@ def test_gdn_as_the_activation_is_one_kernel(up, hw, cout, inverse):
     err = (y.float() - want.float()).abs()
     tol = want.float().abs() * 2.0 ** -7 + 1e-6
     assert bool((err <= tol).all()), float((err - tol).max())
+
+
+@pytest.mark.parametrize("hw,batch", [((64, 64), 3), ((96, 192), 2), ((66, 128), 1), ((64, 72), 2)])
+def test_image_side_layer_applies_its_gdn_itself(hw, batch):
+    """bmshj2018's / bls2017's first analysis layer, SignalConv2D(192, (5, 5), corr=True, strides_down=2, activation=GDN)
+    on a three-channel image (bls2017.py:66-69): conv_image_gdn_kernel writes the normalised activations — same values
+    as conv_image_kernel followed by the GDN kernel (both normalise the bfloat16-rounded convolution output), all of
+    the map including its zero-padded border, and no GDN launch.  A width the fused kernel does not take (output rows
+    that are not a multiple of 32 pixels) goes through the two kernels."""
+    import ctypes as C
+    from compression_amd import _lib, layers
+    torch.manual_seed(5)
+    gdn = layers.GDN()
+    kw = dict(corr=True, strides_down=2, padding="same_zeros", in_channels=3, use_bias=True)
+    conv = layers.SignalConv2D(192, (5, 5), activation=gdn, **kw).cuda()
+    plain = layers.SignalConv2D(192, (5, 5), activation=None, **kw).cuda()
+    x = torch.rand(batch, hw[0], hw[1], 3, device="cuda").mul(255).to(torch.bfloat16)
+    assert conv.fuse_gdn_image
+    with torch.no_grad():
+        conv.build(3, x.device)
+        conv.bias.normal_()
+        gdn.build(192, x.device)
+        gdn.reparam_gamma.add_(torch.rand_like(gdn.reparam_gamma) * 0.05)
+        gdn.invalidate_kernel_cache()
+        plain.load_state_dict({k: v for k, v in conv.state_dict().items() if not k.startswith("activation")}, strict=False)
+        lib = _lib.lib()
+        lib.tfc_profile_enable(1)
+        y = conv(x)
+        torch.cuda.synchronize()
+        ms, n = C.c_double(), C.c_int64()
+        lib.tfc_profile_query(b"gdn_forward", C.byref(ms), C.byref(n))
+        lib.tfc_profile_enable(0)
+        fused = (hw[1] // 2) % 32 == 0
+        assert n.value == (0 if fused else 1)
+        want = gdn(plain(x))
+    assert y.shape == want.shape == (batch, (hw[0] + 1) // 2, hw[1] // 2, 192)
+    err = (y.float() - want.float()).abs()
+    tol = want.float().abs() * 2.0 ** -7 + 1e-6
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert float(want.float().abs().max()) > 0.1
