@@ -1807,22 +1807,28 @@ int run_conv_image(const void* x, const float* w, const float* bias, void* y, in
 // contiguous there) — which leaves them in the accumulators in exactly the layout the GDN contraction wants as ITS B
 // fragments (gdn_common.h), contracts |y| with gamma (fragments in LDS, as in the GDN kernel), divides, and stores the
 // result eight lanes to a pixel (whole 128-byte lines) through a wave-private staging area.  HBM traffic: the image in,
-// the activations out, once.  Same values as conv_image_kernel followed by the GDN kernel: both round the
-// convolution's output to bfloat16 before the GDN and contract in the same order.
+// the activations out, once.
+// Same values as conv_image_kernel followed by the GDN kernel: the bias and beta are added to the finished float32 sums
+// as there, the convolution's output is rounded to bfloat16 before the GDN as there.  (Carrying the bias in the spare
+// sixteenth value of a kernel row's K step and beta as the contraction's initial accumulator was measured: 1.43 against
+// %%B%% ms for the layer, and two float32 additions that move inside the sums — 32 of 590 000 values differ, some by two
+// bfloat16 units.)  Per tile 102 MFMAs = 3 300 cycles of the matrix core; the tile walk is scalar, the epilogue packed.
 // Persistent: a workgroup (8 waves) stages gamma's image and the convolution's fragments once and its waves walk the
 // tiles; the next tile's image rows are requested a tile ahead.  alpha = epsilon = 1, no rectification, not inverse.
 // ---------------------------------------------------------------------------
 template <int TILES, int NK>
 __global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x, const bf16x8* wpk, const float* bias,
                                                                 const void* gimage, __bf16* y, ImageConvGeom g) {
-  extern __shared__ unsigned char smem[];            // gamma fragments | beta | conv fragments | staging (per wave)
+  extern __shared__ unsigned char smem[];            // gamma fragments | beta | bias | conv fragments | staging (per wave)
   constexpr int KT = TILES, KS = 2 * TILES, C = 32 * TILES;
   constexpr int GFR = KT * KS * 64;
   constexpr int ROW = 144;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5, l = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l = lane & 31;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bf16x8* const ga = reinterpret_cast<const bf16x8*>(smem) + lane;
   const float* const beta_s = reinterpret_cast<const float*>(smem + GFR * 16);
-  bf16x8* const wl = reinterpret_cast<bf16x8*>(smem + GFR * 16 + C * 4);
+  float* const bias_s = reinterpret_cast<float*>(smem + GFR * 16 + C * 4);
+  bf16x8* const wl = reinterpret_cast<bf16x8*>(smem + GFR * 16 + 2 * C * 4);
   constexpr int NFR = NK * TILES * 64;
   unsigned char* const stg = reinterpret_cast<unsigned char*>(wl + NFR) + wid * (32 * ROW);
   {
@@ -1830,11 +1836,13 @@ __global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x,
     u32x4* dst = reinterpret_cast<u32x4*>(smem);
     for (int i = tid; i < GFR + C / 4; i += 512) dst[i] = src[i];
     for (int i = tid; i < NFR; i += 512) wl[i] = wpk[i];
+    if (tid < C) bias_s[tid] = bias ? bias[tid] : 0.f;
   }
   __syncthreads();
-  const int tpr = g.OW / 32;                           // tiles per output row (host: OW % 32 == 0)
-  const long long ntiles = g.N * g.OH * tpr;
-  const long long nwaves = static_cast<long long>(gridDim.x) * 8, wave = static_cast<long long>(blockIdx.x) * 8 + wid;
+  // (host: the tile count and the image's row count fit 32 bits)
+  const unsigned int tpr = static_cast<unsigned int>(g.OW) / 32u;                  // tiles per output row
+  const unsigned int ntiles = static_cast<unsigned int>(g.N) * g.OH * tpr;
+  const unsigned int nwaves = gridDim.x * 8u, wave = blockIdx.x * 8u + wid;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__bf16*>(x), 0, static_cast<unsigned int>(g.N * g.H * g.W * g.Cin * 2), 0x00020000);
   // K step ks = kernel row ks (5 taps x 3 channels = 15 of its 16 values): lane (l, h) reads values 8 h ... + 7 of the
@@ -1843,50 +1851,51 @@ __global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x,
   // reads six values further right and the fix-up below moves its first dword to the last; right of the image lie the
   // last four values of lane (31, 1) in a row's last tile — it reads four values further left (so that no load leaves
   // the tensor) and the fix-up moves its last two dwords to the front.
-  auto fetch = [&](long long tile, u32x4 (&bq)[NK]) __attribute__((always_inline)) {
-    const int tx = static_cast<int>(tile % tpr);
-    const long long r = tile / tpr;
-    const int oy = static_cast<int>(r % g.OH);
-    const long long n = r / g.OH;
+  auto fetch = [&](unsigned int tx, unsigned int r, bool valid, u32x4 (&bq)[NK]) __attribute__((always_inline)) {
+    const unsigned int n = r / static_cast<unsigned int>(g.OH), oy = r - n * g.OH;              // (scalar)
     const int shift = (tx == 0 && lane == 0) ? 6 : (tx == tpr - 1 && lane == 63) ? -4 : 0;
-    const int col = ((tx * 32 + l) * 2 - 2) * 3 + 8 * h + shift;
+    const int col = ((static_cast<int>(tx) * 32 + l) * 2 - 2) * 3 + 8 * h + shift;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-      const int iy = oy * 2 - 2 + ks;
-      const bool rowok = static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H);      // (wave-uniform)
-      const long long e = (n * g.H + iy) * g.W * 3 + col;
-      bq[ks] = __builtin_amdgcn_raw_buffer_load_b128(xr, rowok ? static_cast<unsigned int>(e * 2) : 0xFFFFFFF0u, 0, 0);
+      const int iy = static_cast<int>(oy) * 2 - 2 + ks;
+      const bool rowok = valid && static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H);
+      const unsigned int rowbytes = (n * g.H + iy) * static_cast<unsigned int>(g.W) * 6u;        // < 2^32 (host)
+      bq[ks] = __builtin_amdgcn_raw_buffer_load_b128(xr, rowok ? static_cast<unsigned int>(col * 2) : 0xFFFFFFF0u,
+                                                     rowok ? rowbytes : 0u, 0);
     }
   };
   u32x4 bq[NK];
-  if (wave < ntiles) fetch(wave, bq);
-  for (long long tile = wave; tile < ntiles; tile += nwaves) {
-    const int tx = static_cast<int>(tile % tpr);
-    const long long r = tile / tpr;                    // = n * OH + oy
-    {
-      const bool first = tx == 0 && lane == 0, last = tx == tpr - 1 && lane == 63;
+  f32x16 acc[KT];
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto convolve = [&](unsigned int tx) __attribute__((always_inline)) {
+    const bool first = tx == 0 && lane == 0, last = tx == tpr - 1 && lane == 63;
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) {
-        const u32x4 v = bq[ks];
-        bq[ks] = first ? u32x4{0u, 0u, 0u, v[0]} : last ? u32x4{v[2], v[3], 0u, 0u} : v;
-      }
+    for (int ks = 0; ks < NK; ++ks) {
+      const u32x4 v = bq[ks];
+      bq[ks] = first ? u32x4{0u, 0u, 0u, v[0]} : last ? u32x4{v[2], v[3], 0u, 0u} : v;
     }
-    f32x16 acc[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int r2 = 0; r2 < 16; ++r2) acc[t][r2] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
 #pragma unroll
       for (int t = 0; t < KT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(ks * TILES + t) * 64 + lane],
-                                                        __builtin_bit_cast(bf16x8, bq[ks]), acc[t], 0, 0, 0);
+                                                        __builtin_bit_cast(bf16x8, bq[ks]), ks ? acc[t] : zero, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the next tile's image rows: in flight under the contraction and the epilogue (requested in front of this tile's
-    // stores, so the wait for them does not wait for the stores)
-    if (tile + nwaves < ntiles) fetch(tile + nwaves, bq);
+  };
+  if (wave >= ntiles) return;
+  unsigned int tx = wave % tpr, r = wave / tpr;
+  fetch(tx, r, true, bq);
+  convolve(tx);
+  // One tile's convolution ahead of its normalisation: the next tile's image rows are requested in front of this
+  // tile's stores and waited for behind them — the memory counter retires in order, so a wait for loads issued
+  // BEHIND stores is a wait for the stores' acknowledgements (and the first, peeled, tile keeps the loop's own wait
+  // from being merged with a state that has no stores in it: measured 1.53 -> %%P%% ms for the layer).
+  for (unsigned int tile = wave;;) {
+    const unsigned int next = tile + nwaves, ntx = next % tpr, nr = next / tpr;
+    const bool more = next < ntiles;
+    fetch(ntx, nr, more, bq);                          // (nothing to come: every row out of range, no traffic)
+    __bf16* const yrow = y + (static_cast<long long>(r) * g.OW + tx * 32) * C;
     // y = convolution + bias as the bfloat16 tensor would hold it: acc[t][4q + r] = channel 32 t + 8 q + 4 h + r of
     // pixel l, and K step s of the contraction = channels 16 s + 4 h + {0..3} and + 8
     u32x4 xb[KS];
@@ -1895,36 +1904,30 @@ __global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x,
       const int t0 = s >> 1, q0 = 2 * (s & 1);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + 32 * t0 + 8 * (q0 + half) + 4 * h);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + 32 * t0 + 8 * (q0 + half) + 4 * h);
         const int e = 4 * (q0 + half);
         xb[s][2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
-                              f32x2{acc[t0][e] + b4[0], acc[t0][e + 1] + b4[1]}, bf16x2));
+                              f32x2{acc[t0][e], acc[t0][e + 1]} + f32x2{b4[0], b4[1]}, bf16x2));
         xb[s][2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
-                                  f32x2{acc[t0][e + 2] + b4[2], acc[t0][e + 3] + b4[3]}, bf16x2));
+                                  f32x2{acc[t0][e + 2], acc[t0][e + 3]} + f32x2{b4[2], b4[3]}, bf16x2));
       }
     }
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int r2 = 0; r2 < 16; ++r2) acc[t][r2] = 0.f;
-    // gamma's fragments one K step ahead, each register set refilled as soon as its MFMA has read it (a second set
-    // does not fit: 96 accumulators + 48 of y + the next tile's image rows)
     bf16x8 af[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) af[t] = ga[(t * KS) * 64];
+    // gamma's fragments one K step ahead, each register set refilled as soon as its MFMA has read it (a second set
+    // does not fit: 96 accumulators + 48 of y + the next tile's image rows)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const bf16x8 bfrag = __builtin_bit_cast(bf16x8, xb[s] & 0x7FFF7FFFu);
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bfrag, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bfrag, s ? acc[t] : zero, 0, 0, 0);
         if (s + 1 < KS) af[t] = ga[(t * KS + s + 1) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     // y / (beta + gamma^T |y|), 64 channels at a time through the staging area, then eight lanes to a pixel
-    __bf16* const yrow = y + (r * g.OW + tx * 32) * C;
 #pragma unroll
     for (int cnk = 0; cnk < TILES / 2; ++cnk) {
 #pragma unroll
@@ -1932,18 +1935,20 @@ __global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x,
         const int t = 2 * cnk + tt;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
           const int s = 2 * t + (q >> 1), half = q & 1;
-          float v[4];
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+          f32x2 v[2];
 #pragma unroll
-          for (int r2 = 0; r2 < 4; ++r2) {
-            const unsigned int word = xb[s][2 * half + (r2 >> 1)];
-            const float yv = __uint_as_float((r2 & 1) ? (word & 0xFFFF0000u) : (word << 16));
-            v[r2] = yv * __builtin_amdgcn_rcpf(acc[t][4 * q + r2] + b4[r2]);
+          for (int k = 0; k < 2; ++k) {
+            const unsigned int word = xb[s][2 * half + k];
+            const f32x2 yv = {__uint_as_float(word << 16), __uint_as_float(word & 0xFFFF0000u)};
+            const f32x2 nn = f32x2{acc[t][4 * q + 2 * k], acc[t][4 * q + 2 * k + 1]} + f32x2{b4[2 * k], b4[2 * k + 1]};
+            const f32x2 rn = {__builtin_amdgcn_rcpf(nn[0]), __builtin_amdgcn_rcpf(nn[1])};
+            v[k] = yv * rn;
           }
           uint2 o;
-          o.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
-          o.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          o.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(v[0], bf16x2));
+          o.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(v[1], bf16x2));
           *reinterpret_cast<uint2*>(stg + l * ROW + (32 * tt + 8 * q + 4 * h) * 2) = o;
         }
       }
@@ -1954,6 +1959,9 @@ __global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x,
         *reinterpret_cast<u32x4*>(yrow + px * C + 64 * cnk + 8 * piece) = o;
       }
     }
+    if (!more) break;
+    tile = next; tx = ntx; r = nr;
+    convolve(tx);
   }
 }
 
@@ -1968,9 +1976,11 @@ int run_conv_image_gdn(const void* x, const float* w, const float* bias, void* y
   g.ksr = (kw * g.Cin + 15) / 16;
   const int nk = kh * g.ksr;
   if (kh != 5 || kw != 5 || nk != 5 || g.OW % 32 != 0 || g.W % 2 != 0 || reinterpret_cast<uintptr_t>(x) % 4 != 0) return -1;
-  if (static_cast<double>(n) * h * wd * cin * 2 >= 4294967280.0) return -1;       // one buffer resource over the tensor
+  // one buffer resource over the tensor, 32-bit tile and row arithmetic in the kernel
+  if (static_cast<double>(n) * h * wd * cin * 2 >= 4294967280.0 || static_cast<double>(n) * g.OH * (g.OW / 32) >= 2147483648.0)
+    return -1;
   constexpr int tiles = 6;
-  const size_t lds = static_cast<size_t>(tiles) * 2 * tiles * 64 * 16 + tiles * 32 * 4 +
+  const size_t lds = static_cast<size_t>(tiles) * 2 * tiles * 64 * 16 + 2 * tiles * 32 * 4 +
                      static_cast<size_t>(nk) * tiles * 64 * 16 + 8 * 32 * 144;
   if (lds > 160 * 1024) return -1;
   DevBuf wpk;

@@ -23,3 +23,19 @@ for fused in (True, False, True, False):
     out_gb = y.numel() * 2 / 1e9
     ms = a.elapsed_time(b) / 20
     print(f"fused={fused}: {ms:.3f} ms per layer  (output {out_gb:.2f} GB -> {out_gb / ms * 1e3:.0f} GB/s of output alone)")
+
+# the memory system's side of it: writing (fill) and copying a tensor of the layer's output size
+y = torch.empty(128, 384, 256, 192, device="cuda", dtype=torch.bfloat16)
+z = torch.empty_like(y)
+for name, fn, gb in (("fill", lambda: y.fill_(1.0), y.numel() * 2 / 1e9), ("copy", lambda: z.copy_(y), y.numel() * 4 / 1e9)):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 10
+    print(f"{name} of {y.numel() * 2 / 1e9:.2f} GB: {ms:.3f} ms = {gb / ms * 1e3:.0f} GB/s")
