@@ -190,12 +190,15 @@ class SignalConv2D(torch.nn.Module):
                 y = act(y)
         return y.movedim(-1, 1) if self.data_format == "channels_first" else y
 
-    # GDN / IGDN as the activation inside the convolution kernel (functional.conv2d_gdn).  Off unless asked for
-    # (this attribute, or TFC_CONV_GDN=1 in the environment): measured on bmshj2018 at 128 x 768x512, the fused layers
-    # save 0.6 ms of a lone step's 87 — and cost 1.5 ms of 36.5 per step with several steps in flight, where the separate
-    # GDN kernel (bound by HBM) runs beside other steps' convolutions (bound by the matrix cores) and the fused epilogue
-    # keeps a CU's matrix cores waiting at its barriers (profiles/r04_notes.md).
-    fuse_gdn_activation = os.environ.get("TFC_CONV_GDN", "0") not in ("", "0")
+    # GDN / IGDN as the activation inside the convolution kernel (functional.conv2d_gdn): True / False, or None = by the
+    # size of the layer's output (TFC_CONV_GDN=1 / 0 in the environment set it; unset = None).  Measured with steps in
+    # flight (profiles/r04_notes.md): on bls2017 at 512 x 256x256 (outputs of 0.2 - 0.8 GB) the fused layers take
+    # 9.5 -> 8.4 ms per step; on bmshj2018 at 128 x 768x512 fusing ALL layers saves 0.6 ms of a lone step's 87 and
+    # costs 1.5 ms of 36.5 per step in flight — there the separate GDN kernel on a 4.8 GB map (bound by HBM) runs
+    # beside other steps' convolutions (bound by the matrix cores), and the fused epilogue keeps a CU's matrix cores
+    # waiting at its barriers.  Hence the limit on the output's size, TFC_CONV_GDN_MAX_MB.
+    fuse_gdn_activation = {"": None, "0": False}.get(os.environ.get("TFC_CONV_GDN", ""), True)
+    fuse_gdn_max_bytes = int(os.environ.get("TFC_CONV_GDN_MAX_MB", "1024")) << 20
     # The image-side layer (three input channels) is different: its time is its output's HBM traffic, not the matrix
     # cores, and conv_image_gdn_kernel writes the normalised activations without the round trip (bmshj2018's first
     # layer at 128 x 768x512: 1.83 + 2.2 ms as two kernels).  On unless TFC_CONV_GDN_IMAGE=0.
@@ -206,7 +209,11 @@ class SignalConv2D(torch.nn.Module):
         layer's own variables, bfloat16, alpha = epsilon = 1, no rectification, channels-last inside — else None."""
         from .gdn import GDN
         image_side = self.fuse_gdn_image and corr and kernel.shape[-2] <= 4 and not getattr(act, "inverse", True)
-        if not (self.fuse_gdn_activation or image_side) or not isinstance(act, GDN) or torch.is_grad_enabled() \
+        wanted = self.fuse_gdn_activation
+        if wanted is None:
+            scale = (1.0 / down if corr else float(up)) ** 2
+            wanted = x.shape[0] * x.shape[1] * x.shape[2] * scale * kernel.shape[-1] * 2 <= self.fuse_gdn_max_bytes
+        if not (wanted or image_side) or not isinstance(act, GDN) or torch.is_grad_enabled() \
                 or not x.is_cuda or x.dtype != torch.bfloat16:
             return None
         if (not corr and down != 1) or act.rectify or act._beta_fixed is not None or act._gamma_fixed is not None:
