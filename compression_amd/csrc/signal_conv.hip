@@ -1800,41 +1800,54 @@ int run_conv_image(const void* x, const float* w, const float* bias, void* y, in
 }
 
 // ---------------------------------------------------------------------------
-// Image-side analysis layer WITH its GDN (bmshj2018's first layer: SignalConv2D(192, 5x5, /2, activation=GDN), Cin = 3).
-// conv_image_kernel writes 4.8 GB at the C4 shape and the GDN kernel reads and writes them again; here a wave takes 32
-// consecutive pixels of an output row at a time, computes their 32 x Cout convolution outputs with a handful of MFMAs
-// — the B fragments are 16 bytes of an image row each, straight from the image (the kw * Cin values of a kernel row are
-// contiguous there) — which leaves them in the accumulators in exactly the layout the GDN contraction wants as ITS B
-// fragments (gdn_common.h), contracts |y| with gamma (fragments in LDS, as in the GDN kernel), divides, and stores the
-// result eight lanes to a pixel (whole 128-byte lines) through a wave-private staging area.  HBM traffic: the image in,
-// the activations out, once.
+// Image-side analysis layer, B fragments straight from the image, optionally WITH its GDN (bmshj2018's / ms2020's first
+// layer: SignalConv2D(192, 5x5, /2, activation=GDN); bls2017's: 9x9, /4, its GDN as a kernel of its own — the 108 KB of
+// 9x9 weight fragments and gamma's 74 KB do not share the LDS).  Cin = 3, Cout = 192, output rows of whole 32-pixel
+// tiles.
+// conv_image_kernel stages an image patch in LDS with 4-byte loads (0.79 ms for the 0.8 GB of bls2017's first layer at
+// 512 x 256x256), and writes 4.8 GB at the C4 shape that the GDN kernel reads and writes again.  Here a wave takes 32
+// consecutive pixels of an output row at a time and computes their 32 x Cout convolution outputs with KH * KSR K steps
+// of MFMAs whose B fragments are 16 bytes of an image row each (the KW * Cin values of a kernel row are contiguous
+// there; KSR = ceil(KW * Cin / 16) K steps per row) — which leaves them in the accumulators in exactly the layout the
+// GDN contraction wants as ITS B fragments (gdn_common.h): contract |y| with gamma (fragments in LDS, as in the GDN
+// kernel), divide, and store the result eight lanes to a pixel (whole 128-byte lines) through a wave-private staging
+// area.  HBM traffic: the image in, the activations out, once.
 // Same values as conv_image_kernel followed by the GDN kernel: the bias and beta are added to the finished float32 sums
 // as there, the convolution's output is rounded to bfloat16 before the GDN as there.  (Carrying the bias in the spare
 // sixteenth value of a kernel row's K step and beta as the contraction's initial accumulator was measured: 1.43 against
-// %%B%% ms for the layer, and two float32 additions that move inside the sums — 32 of 590 000 values differ, some by two
-// bfloat16 units.)  Per tile 102 MFMAs = 3 300 cycles of the matrix core; the tile walk is scalar, the epilogue packed.
+// 1.53 ms for the 5x5 layer, and two float32 additions that move inside the sums — 32 of 590 000 values differ, some by
+// two bfloat16 units.  Interleaving a channel pair's epilogue with the next pair's MFMAs inside the wave: no change.)
 // Persistent: a workgroup (8 waves) stages gamma's image and the convolution's fragments once and its waves walk the
-// tiles; the next tile's image rows are requested a tile ahead.  alpha = epsilon = 1, no rectification, not inverse.
+// tiles (scalar arithmetic); image fragments live in a ring of PF registers sets, refilled — with this tile's later K
+// steps, then the next tile's first ones — as soon as their MFMAs have read them.
+// alpha = epsilon = 1, no rectification, not inverse.
 // ---------------------------------------------------------------------------
-template <int TILES, int NK>
-__global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x, const bf16x8* wpk, const float* bias,
-                                                                const void* gimage, __bf16* y, ImageConvGeom g) {
-  extern __shared__ unsigned char smem[];            // gamma fragments | beta | bias | conv fragments | staging (per wave)
+template <int TILES, int KH, int KW, int SD, bool GDN>
+__global__ void __launch_bounds__(512, 1) conv_image_direct_kernel(const __bf16* x, const bf16x8* wpk, const float* bias,
+                                                                   const void* gimage, __bf16* y, ImageConvGeom g) {
+  extern __shared__ unsigned char smem[];            // [gamma fragments | beta] | bias | conv fragments | staging (per wave)
   constexpr int KT = TILES, KS = 2 * TILES, C = 32 * TILES;
-  constexpr int GFR = KT * KS * 64;
+  constexpr int GFR = GDN ? KT * KS * 64 : 0, GBYTES = GDN ? GFR * 16 + C * 4 : 0;
   constexpr int ROW = 144;
+  constexpr int CIN = 3, KSR = (KW * CIN + 15) / 16, NK = KH * KSR, PX0 = KW / 2, PY0 = KH / 2, PF = NK < 6 ? NK : 6;
+  // zero padding left and right of an image row touches one lane each: (l, h) = (0, *) of a row's first tile, whose
+  // fragment starts PX0 pixels left of the image, and (31, *) of its last tile
+  static_assert(PX0 % 2 == 0 && (SD + PX0) % 2 == 0, "edge fix-ups move whole dwords");
+  static_assert(SD >= PX0 && 16 * KSR <= CIN * (2 * SD + PX0), "only lanes 0 and 31 reach over the row's ends");
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l = lane & 31;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bf16x8* const ga = reinterpret_cast<const bf16x8*>(smem) + lane;
   const float* const beta_s = reinterpret_cast<const float*>(smem + GFR * 16);
-  float* const bias_s = reinterpret_cast<float*>(smem + GFR * 16 + C * 4);
-  bf16x8* const wl = reinterpret_cast<bf16x8*>(smem + GFR * 16 + 2 * C * 4);
+  float* const bias_s = reinterpret_cast<float*>(smem + GBYTES);
+  bf16x8* const wl = reinterpret_cast<bf16x8*>(smem + GBYTES + C * 4);
   constexpr int NFR = NK * TILES * 64;
   unsigned char* const stg = reinterpret_cast<unsigned char*>(wl + NFR) + wid * (32 * ROW);
   {
-    const u32x4* src = static_cast<const u32x4*>(gimage);
-    u32x4* dst = reinterpret_cast<u32x4*>(smem);
-    for (int i = tid; i < GFR + C / 4; i += 512) dst[i] = src[i];
+    if constexpr (GDN) {
+      const u32x4* src = static_cast<const u32x4*>(gimage);
+      u32x4* dst = reinterpret_cast<u32x4*>(smem);
+      for (int i = tid; i < GFR + C / 4; i += 512) dst[i] = src[i];
+    }
     for (int i = tid; i < NFR; i += 512) wl[i] = wpk[i];
     if (tid < C) bias_s[tid] = bias ? bias[tid] : 0.f;
   }
@@ -1843,144 +1856,218 @@ __global__ void __launch_bounds__(512, 1) conv_image_gdn_kernel(const __bf16* x,
   const unsigned int tpr = static_cast<unsigned int>(g.OW) / 32u;                  // tiles per output row
   const unsigned int ntiles = static_cast<unsigned int>(g.N) * g.OH * tpr;
   const unsigned int nwaves = gridDim.x * 8u, wave = blockIdx.x * 8u + wid;
+  if (wave >= ntiles) return;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__bf16*>(x), 0, static_cast<unsigned int>(g.N * g.H * g.W * g.Cin * 2), 0x00020000);
-  // K step ks = kernel row ks (5 taps x 3 channels = 15 of its 16 values): lane (l, h) reads values 8 h ... + 7 of the
-  // row that starts two pixels left of pixel 2 l.  Zero padding: a row outside the image is read at an offset outside
-  // the buffer (zeros); left of the image lie the first six values of (l, h) = (0, 0) in a row's first tile — that lane
-  // reads six values further right and the fix-up below moves its first dword to the last; right of the image lie the
-  // last four values of lane (31, 1) in a row's last tile — it reads four values further left (so that no load leaves
-  // the tensor) and the fix-up moves its last two dwords to the front.
-  auto fetch = [&](unsigned int tx, unsigned int r, bool valid, u32x4 (&bq)[NK]) __attribute__((always_inline)) {
-    const unsigned int n = r / static_cast<unsigned int>(g.OH), oy = r - n * g.OH;              // (scalar)
-    const int shift = (tx == 0 && lane == 0) ? 6 : (tx == tpr - 1 && lane == 63) ? -4 : 0;
-    const int col = ((static_cast<int>(tx) * 32 + l) * 2 - 2) * 3 + 8 * h + shift;
+      const_cast<__bf16*>(x), 0, static_cast<unsigned int>(g.N * g.H * g.W * CIN * 2), 0x00020000);
+  // Fragment (K step ks = kernel row ks / KSR, part kk = ks % KSR) of lane (l, h): values 16 kk + 8 h ... + 7 of the
+  // image row, counted from PX0 pixels left of pixel SD * (32 tx + l).  A row outside the image is read at an offset
+  // outside the buffer (zeros).  Left of the image lie the first values of lane (0, h) in a row's first tile: that lane
+  // reads DL dwords further right and the fix-up at the MFMA moves the fragment up by as much; right of it the last
+  // values of lane (31, h) in the row's last tile: DT dwords further left (no load leaves the tensor), moved down.
+  constexpr unsigned int kOutside = 0xFFFFFFF0u;
+  auto clamp4 = [](int v) constexpr { return v < 0 ? 0 : v > 4 ? 4 : v; };
+  struct Pos {
+    unsigned int tx, n, oy;
+    bool valid;
+  };
+  auto pos_of = [&](unsigned int tile) __attribute__((always_inline)) {
+    Pos p;
+    p.valid = tile < ntiles;
+    p.tx = tile % tpr;
+    const unsigned int r = tile / tpr;
+    p.n = r / static_cast<unsigned int>(g.OH);
+    p.oy = r - p.n * g.OH;
+    return p;
+  };
+  auto columns = [&](const Pos& p, unsigned int (&cb)[KSR]) __attribute__((always_inline)) {
+    const bool first = p.tx == 0 && l == 0, last = p.tx == tpr - 1 && l == 31;
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      const int iy = static_cast<int>(oy) * 2 - 2 + ks;
-      const bool rowok = valid && static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H);
-      const unsigned int rowbytes = (n * g.H + iy) * static_cast<unsigned int>(g.W) * 6u;        // < 2^32 (host)
-      bq[ks] = __builtin_amdgcn_raw_buffer_load_b128(xr, rowok ? static_cast<unsigned int>(col * 2) : 0xFFFFFFF0u,
-                                                     rowok ? rowbytes : 0u, 0);
+    for (int kk = 0; kk < KSR; ++kk) {
+      const int dla = clamp4((PX0 * CIN - 16 * kk + 1) / 2), dlb = clamp4((PX0 * CIN - 16 * kk - 8 + 1) / 2);
+      const int dta = clamp4((16 * kk + 8 - CIN * (SD + PX0) + 1) / 2), dtb = clamp4((16 * kk + 16 - CIN * (SD + PX0) + 1) / 2);
+      const int dl = h ? dlb : dla, dt = h ? dtb : dta;
+      const int col = ((static_cast<int>(p.tx) * 32 + l) * SD - PX0) * CIN + 16 * kk + 8 * h;
+      const bool none = (first && dl == 4) || (last && dt == 4);
+      cb[kk] = none ? kOutside : static_cast<unsigned int>((col + (first ? 2 * dl : 0) - (last ? 2 * dt : 0)) * 2);
     }
   };
-  u32x4 bq[NK];
-  f32x16 acc[KT];
+  auto fragment = [&](const Pos& p, const unsigned int (&cb)[KSR], int ks) __attribute__((always_inline)) {
+    const int iy = static_cast<int>(p.oy) * SD - PY0 + ks / KSR;
+    const bool rowok = p.valid && static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H);
+    const unsigned int rowbytes = (p.n * g.H + iy) * static_cast<unsigned int>(g.W) * (CIN * 2u);   // < 2^32 (host)
+    return __builtin_amdgcn_raw_buffer_load_b128(xr, rowok ? cb[ks % KSR] : kOutside, rowok ? rowbytes : 0u, 0);
+  };
+  auto up = [](u32x4 v, int d) __attribute__((always_inline)) {
+    return d == 0 ? v : d == 1 ? u32x4{0u, v[0], v[1], v[2]} : d == 2 ? u32x4{0u, 0u, v[0], v[1]}
+         : d == 3 ? u32x4{0u, 0u, 0u, v[0]} : u32x4{0u, 0u, 0u, 0u};
+  };
+  auto down = [](u32x4 v, int d) __attribute__((always_inline)) {
+    return d == 0 ? v : d == 1 ? u32x4{v[1], v[2], v[3], 0u} : d == 2 ? u32x4{v[2], v[3], 0u, 0u}
+         : d == 3 ? u32x4{v[3], 0u, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
+  };
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto convolve = [&](unsigned int tx) __attribute__((always_inline)) {
-    const bool first = tx == 0 && lane == 0, last = tx == tpr - 1 && lane == 63;
+  Pos cur = pos_of(wave);
+  unsigned int cb[KSR];
+  columns(cur, cb);
+  u32x4 bq[PF];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) bq[k] = fragment(cur, cb, k);
+  for (unsigned int tile = wave;; tile += nwaves) {
+    const Pos nxt = pos_of(tile + nwaves);
+    unsigned int ncb[KSR];
+    columns(nxt, ncb);
+    const bool first = cur.tx == 0 && l == 0, last = cur.tx == tpr - 1 && l == 31;
+    __bf16* const yrow = y + ((static_cast<long long>(cur.n) * g.OH + cur.oy) * g.OW + cur.tx * 32) * C;
+    // ---- convolution: the weights' fragments one K step ahead of their MFMAs ----
+    f32x16 acc[KT];
+    bf16x8 aw[2][KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) aw[0][t] = wl[t * 64 + lane];
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-      const u32x4 v = bq[ks];
-      bq[ks] = first ? u32x4{0u, 0u, 0u, v[0]} : last ? u32x4{v[2], v[3], 0u, 0u} : v;
-    }
+      const int kk = ks % KSR, slot = ks % PF;
+      if (ks + 1 < NK) {
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
+        for (int t = 0; t < KT; ++t) aw[(ks + 1) & 1][t] = wl[((ks + 1) * TILES + t) * 64 + lane];
+      }
+      u32x4 v = bq[slot];
+      {
+        const int dla = clamp4((PX0 * CIN - 16 * kk + 1) / 2), dlb = clamp4((PX0 * CIN - 16 * kk - 8 + 1) / 2);
+        const int dta = clamp4((16 * kk + 8 - CIN * (SD + PX0) + 1) / 2), dtb = clamp4((16 * kk + 16 - CIN * (SD + PX0) + 1) / 2);
+        if (dla || dlb) v = first ? (h ? up(v, dlb) : up(v, dla)) : v;
+        if (dta || dtb) v = last ? (h ? down(v, dtb) : down(v, dta)) : v;
+      }
+      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
       for (int t = 0; t < KT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(ks * TILES + t) * 64 + lane],
-                                                        __builtin_bit_cast(bf16x8, bq[ks]), ks ? acc[t] : zero, 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[ks & 1][t], bfrag, ks ? acc[t] : zero, 0, 0, 0);
+      // the slot's next fragment: a later K step of this tile, then the next tile's first ones
+      const int kn = ks + PF;
+      bq[slot] = kn < NK ? fragment(cur, cb, kn) : fragment(nxt, ncb, kn - NK);
       __builtin_amdgcn_sched_barrier(0);
     }
-  };
-  if (wave >= ntiles) return;
-  unsigned int tx = wave % tpr, r = wave / tpr;
-  fetch(tx, r, true, bq);
-  convolve(tx);
-  // One tile's convolution ahead of its normalisation: the next tile's image rows are requested in front of this
-  // tile's stores and waited for behind them — the memory counter retires in order, so a wait for loads issued
-  // BEHIND stores is a wait for the stores' acknowledgements (and the first, peeled, tile keeps the loop's own wait
-  // from being merged with a state that has no stores in it: measured 1.53 -> %%P%% ms for the layer).
-  for (unsigned int tile = wave;;) {
-    const unsigned int next = tile + nwaves, ntx = next % tpr, nr = next / tpr;
-    const bool more = next < ntiles;
-    fetch(ntx, nr, more, bq);                          // (nothing to come: every row out of range, no traffic)
-    __bf16* const yrow = y + (static_cast<long long>(r) * g.OW + tx * 32) * C;
-    // y = convolution + bias as the bfloat16 tensor would hold it: acc[t][4q + r] = channel 32 t + 8 q + 4 h + r of
-    // pixel l, and K step s of the contraction = channels 16 s + 4 h + {0..3} and + 8
-    u32x4 xb[KS];
+    if constexpr (GDN) {
+      // y = convolution + bias as the bfloat16 tensor would hold it: acc[t][4q + r] = channel 32 t + 8 q + 4 h + r of
+      // pixel l, and K step s of the contraction = channels 16 s + 4 h + {0..3} and + 8
+      u32x4 xb[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int t0 = s >> 1, q0 = 2 * (s & 1);
+      for (int s = 0; s < KS; ++s) {
+        const int t0 = s >> 1, q0 = 2 * (s & 1);
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + 32 * t0 + 8 * (q0 + half) + 4 * h);
-        const int e = 4 * (q0 + half);
-        xb[s][2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
-                              f32x2{acc[t0][e], acc[t0][e + 1]} + f32x2{b4[0], b4[1]}, bf16x2));
-        xb[s][2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
-                                  f32x2{acc[t0][e + 2], acc[t0][e + 3]} + f32x2{b4[2], b4[3]}, bf16x2));
-      }
-    }
-    bf16x8 af[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t) af[t] = ga[(t * KS) * 64];
-    // gamma's fragments one K step ahead, each register set refilled as soon as its MFMA has read it (a second set
-    // does not fit: 96 accumulators + 48 of y + the next tile's image rows)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, xb[s] & 0x7FFF7FFFu);
-#pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bfrag, s ? acc[t] : zero, 0, 0, 0);
-        if (s + 1 < KS) af[t] = ga[(t * KS + s + 1) * 64];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // y / (beta + gamma^T |y|), 64 channels at a time through the staging area, then eight lanes to a pixel
-#pragma unroll
-    for (int cnk = 0; cnk < TILES / 2; ++cnk) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * cnk + tt;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int s = 2 * t + (q >> 1), half = q & 1;
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
-          f32x2 v[2];
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const unsigned int word = xb[s][2 * half + k];
-            const f32x2 yv = {__uint_as_float(word << 16), __uint_as_float(word & 0xFFFF0000u)};
-            const f32x2 nn = f32x2{acc[t][4 * q + 2 * k], acc[t][4 * q + 2 * k + 1]} + f32x2{b4[2 * k], b4[2 * k + 1]};
-            const f32x2 rn = {__builtin_amdgcn_rcpf(nn[0]), __builtin_amdgcn_rcpf(nn[1])};
-            v[k] = yv * rn;
-          }
-          uint2 o;
-          o.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(v[0], bf16x2));
-          o.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(v[1], bf16x2));
-          *reinterpret_cast<uint2*>(stg + l * ROW + (32 * tt + 8 * q + 4 * h) * 2) = o;
+        for (int half = 0; half < 2; ++half) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + 32 * t0 + 8 * (q0 + half) + 4 * h);
+          const int e = 4 * (q0 + half);
+          xb[s][2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
+                                f32x2{acc[t0][e], acc[t0][e + 1]} + f32x2{b4[0], b4[1]}, bf16x2));
+          xb[s][2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(
+                                    f32x2{acc[t0][e + 2], acc[t0][e + 3]} + f32x2{b4[2], b4[3]}, bf16x2));
         }
       }
+      // gamma's fragments one K step ahead, each register set refilled as soon as its MFMA has read it (a second
+      // set does not fit: 96 accumulators + 48 of y + the image fragments in flight)
+      bf16x8 af[KT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int px = 8 * j + (lane >> 3), piece = lane & 7;
-        const u32x4 o = *reinterpret_cast<const u32x4*>(stg + px * ROW + piece * 16);
-        *reinterpret_cast<u32x4*>(yrow + px * C + 64 * cnk + 8 * piece) = o;
+      for (int t = 0; t < KT; ++t) af[t] = ga[(t * KS) * 64];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, xb[s] & 0x7FFF7FFFu);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bfrag, s ? acc[t] : zero, 0, 0, 0);
+          if (s + 1 < KS) af[t] = ga[(t * KS + s + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // y / (beta + gamma^T |y|), 64 channels at a time through the staging area, then eight lanes to a pixel
+#pragma unroll
+      for (int cnk = 0; cnk < TILES / 2; ++cnk) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * cnk + tt;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int s = 2 * t + (q >> 1), half = q & 1;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+            f32x2 v[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const unsigned int word = xb[s][2 * half + k];
+              const f32x2 yv = {__uint_as_float(word << 16), __uint_as_float(word & 0xFFFF0000u)};
+              const f32x2 nn = f32x2{acc[t][4 * q + 2 * k], acc[t][4 * q + 2 * k + 1]} + f32x2{b4[2 * k], b4[2 * k + 1]};
+              const f32x2 rn = {__builtin_amdgcn_rcpf(nn[0]), __builtin_amdgcn_rcpf(nn[1])};
+              v[k] = yv * rn;
+            }
+            uint2 o;
+            o.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(v[0], bf16x2));
+            o.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(v[1], bf16x2));
+            *reinterpret_cast<uint2*>(stg + l * ROW + (32 * tt + 8 * q + 4 * h) * 2) = o;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int px = 8 * j + (lane >> 3), piece = lane & 7;
+          const u32x4 o = *reinterpret_cast<const u32x4*>(stg + px * ROW + piece * 16);
+          *reinterpret_cast<u32x4*>(yrow + px * C + 64 * cnk + 8 * piece) = o;
+        }
+      }
+    } else {
+      // bias, activation, round; 64 channels at a time through the staging area, then eight lanes to a pixel
+#pragma unroll
+      for (int cnk = 0; cnk < TILES / 2; ++cnk) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * cnk + tt;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + 32 * t + 8 * q + 4 * h);
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[k] = acc[t][4 * q + k] + b4[k];
+              if (g.activation == 1) v[k] = fmaxf(v[k], 0.f);
+            }
+            uint2 o;
+            o.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+            o.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+            *reinterpret_cast<uint2*>(stg + l * ROW + (32 * tt + 8 * q + 4 * h) * 2) = o;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int px = 8 * j + (lane >> 3), piece = lane & 7;
+          const u32x4 o = *reinterpret_cast<const u32x4*>(stg + px * ROW + piece * 16);
+          *reinterpret_cast<u32x4*>(yrow + px * C + 64 * cnk + 8 * piece) = o;
+        }
       }
     }
-    if (!more) break;
-    tile = next; tx = ntx; r = nr;
-    convolve(tx);
+    if (!nxt.valid) break;
+    cur = nxt;
+#pragma unroll
+    for (int kk = 0; kk < KSR; ++kk) cb[kk] = ncb[kk];
   }
 }
 
-// 0 = launched, -1 = not this shape, > 0 = error
-int run_conv_image_gdn(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
-                       int64_t cin, int64_t cout, int kh, int kw, int stride, const tfc_gdn_params* gdn, hipStream_t st) {
-  if (cin != 3 || cout != 192 || stride != 2 || gdn->channels != cout || gdn->dtype != 1) return -1;
+// 0 = launched, -1 = not this shape, > 0 = error.  gdn != null: with the GDN (5x5 / 2 only).
+int run_conv_image_direct(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
+                          int64_t cin, int64_t cout, int kh, int kw, int stride, int activation, const tfc_gdn_params* gdn,
+                          hipStream_t st) {
+  if (cin != 3 || cout != 192 || kh != kw) return -1;
+  const bool k5 = kh == 5 && stride == 2, k9 = kh == 9 && stride == 4;
+  if (!k5 && !k9) return -1;
+  if (gdn && (!k5 || gdn->channels != cout || gdn->dtype != 1 || activation != 0)) return -1;
   ImageConvGeom g{};
   g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin); g.Cout = static_cast<int>(cout);
-  g.kh = kh; g.kw = kw; g.sd = stride; g.py0 = kh / 2; g.px0 = kw / 2; g.activation = 0;
+  g.kh = kh; g.kw = kw; g.sd = stride; g.py0 = kh / 2; g.px0 = kw / 2; g.activation = activation;
   g.OH = static_cast<int>((h + stride - 1) / stride); g.OW = static_cast<int>((wd + stride - 1) / stride);
   g.ksr = (kw * g.Cin + 15) / 16;
   const int nk = kh * g.ksr;
-  if (kh != 5 || kw != 5 || nk != 5 || g.OW % 32 != 0 || g.W % 2 != 0 || reinterpret_cast<uintptr_t>(x) % 4 != 0) return -1;
+  // whole tiles, the row's last pixel a whole stride from its end, dword-aligned rows
+  if (g.OW % 32 != 0 || g.W % stride != 0 || reinterpret_cast<uintptr_t>(x) % 4 != 0) return -1;
   // one buffer resource over the tensor, 32-bit tile and row arithmetic in the kernel
   if (static_cast<double>(n) * h * wd * cin * 2 >= 4294967280.0 || static_cast<double>(n) * g.OH * (g.OW / 32) >= 2147483648.0)
     return -1;
   constexpr int tiles = 6;
-  const size_t lds = static_cast<size_t>(tiles) * 2 * tiles * 64 * 16 + 2 * tiles * 32 * 4 +
+  const size_t lds = (gdn ? static_cast<size_t>(tiles) * 2 * tiles * 64 * 16 + tiles * 32 * 4 : 0) + tiles * 32 * 4 +
                      static_cast<size_t>(nk) * tiles * 64 * 16 + 8 * 32 * 144;
   if (lds > 160 * 1024) return -1;
   DevBuf wpk;
@@ -1993,10 +2080,18 @@ int run_conv_image_gdn(const void* x, const float* w, const float* bias, void* y
   const long long ntiles = n * g.OH * (g.OW / 32);
   const unsigned grid = static_cast<unsigned>(std::min<long long>(cus, ceil_div(ntiles, 8)));
   KernelTimer timer("conv2d", st);
-  TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_gdn_kernel<6, 5>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-  hipLaunchKernelGGL((conv_image_gdn_kernel<6, 5>), dim3(grid), dim3(512), lds, st, static_cast<const __bf16*>(x),
-                     wpk.as<bf16x8>(), bias, gdn->image.p, static_cast<__bf16*>(y), g);
+#define TFC_IMAGE_DIRECT_LAUNCH(...)                                                                              \
+  do {                                                                                                           \
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_direct_kernel<__VA_ARGS__>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));             \
+    hipLaunchKernelGGL((conv_image_direct_kernel<__VA_ARGS__>), dim3(grid), dim3(512), lds, st,                   \
+                       static_cast<const __bf16*>(x), wpk.as<bf16x8>(), bias, gdn ? gdn->image.p : nullptr,       \
+                       static_cast<__bf16*>(y), g);                                                              \
+  } while (0)
+  if (k5 && gdn) TFC_IMAGE_DIRECT_LAUNCH(6, 5, 5, 2, true);
+  else if (k5) TFC_IMAGE_DIRECT_LAUNCH(6, 5, 5, 2, false);
+  else TFC_IMAGE_DIRECT_LAUNCH(6, 9, 9, 4, false);
+#undef TFC_IMAGE_DIRECT_LAUNCH
   TFC_HIP(hipGetLastError());
   return 0;
 }
@@ -2272,11 +2367,12 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
     return conv_up_small_cout(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, activation,
                               static_cast<hipStream_t>(stream));
 #endif
-  if (!up && dtype == 1 && cin <= 4 && !out_f32 && gdn && gdn_fused && !gdn_inverse && activation == 0) {
-    // the image-side layer with its GDN in one kernel: conv_image_gdn_kernel
-    const int rc = run_conv_image_gdn(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, gdn,
-                                      static_cast<hipStream_t>(stream));
-    if (rc == 0) {
+  if (!up && dtype == 1 && cin <= 4 && !out_f32) {
+    // the image-side layer from the image's own rows (conv_image_direct_kernel), with its GDN where it is the 5x5 / 2 one
+    const bool with_gdn = gdn && gdn_fused && !gdn_inverse && activation == 0 && kh == 5;
+    const int rc = run_conv_image_direct(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride,
+                                         activation, with_gdn ? gdn : nullptr, static_cast<hipStream_t>(stream));
+    if (rc == 0 && with_gdn) {
       const_cast<tfc_gdn_params*>(gdn)->image.touch(static_cast<hipStream_t>(stream));
       *gdn_fused = 1;
     }

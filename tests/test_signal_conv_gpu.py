@@ -326,6 +326,11 @@ def scipy_same_zeros(x, kernel, stride, up):
     ("analysis 5x5 192->192 /2", (2, 14, 18, 192), (5, 5, 192, 192), 2, False),
     ("synthesis 5x5 192->192 x2", (2, 9, 7, 192), (5, 5, 192, 192), 2, True),
     ("analysis 9x9 3->192 /4", (2, 29, 23, 3), (9, 9, 3, 192), 4, False),
+    # whole 32-pixel tiles per output row: conv_image_direct_kernel (fragments straight from the image's rows)
+    ("analysis 9x9 3->192 /4, rows of tiles", (2, 37, 128, 3), (9, 9, 3, 192), 4, False),
+    ("analysis 9x9 3->192 /4, two tiles a row", (1, 16, 256, 3), (9, 9, 3, 192), 4, False),
+    ("analysis 5x5 3->192 /2, rows of tiles", (2, 21, 64, 3), (5, 5, 3, 192), 2, False),
+    ("analysis 5x5 3->192 /2, three tiles a row", (1, 6, 192, 3), (5, 5, 3, 192), 2, False),
     ("synthesis 9x9 192->3 x4", (1, 6, 7, 192), (9, 9, 192, 3), 4, True),
     ("synthesis 5x5 192->3 x2", (2, 8, 9, 192), (5, 5, 192, 3), 2, True),
     ("hyper 3x3 192->192 s1", (1, 8, 8, 192), (3, 3, 192, 192), 1, False),

@@ -33,7 +33,7 @@ if __name__ == "__main__":
     dev = torch.device("cuda")
     C_ = 192
     for dtype in (torch.bfloat16, torch.float32):
-        B = 64 if dtype == torch.bfloat16 else 8
+        B = int(os.environ.get("BATCH", 64)) if dtype == torch.bfloat16 else int(os.environ.get("BATCH_F32", 8))
         img = torch.rand(B, 256, 256, 3, device=dev)
         run("bls2017 analysis L0 9x9 3->C /4", conv2d_down, img, torch.randn(9, 9, 3, C_) / 16, torch.zeros(C_), 4, False, dtype)
         x1 = torch.randn(B, 64, 64, C_, device=dev)
