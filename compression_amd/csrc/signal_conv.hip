@@ -2270,6 +2270,242 @@ __global__ void __launch_bounds__(kUpThreads) conv_up_fused_kernel(const __bf16*
   }
 }
 
+// ---------------------------------------------------------------------------
+// Transposed convolution into three channels (the synthesis transforms' last layer: bls2017's 9x9 x4, bmshj2018's 5x5
+// x2, 192 -> 3) as a 3x3 convolution over the INPUT grid with S * S * 3 output columns, one per (output phase, channel):
+//   y[S I + ry, S J + rx, c] = sum over dy, dx in {-1, 0, 1}, ci of x[I + dy, J + dx, ci] * w[t(ry, dy), t(rx, dx), ci, c]
+// with t(r, d) = (r + K/2) mod S + S ((r + K/2) div S - d), taps outside [0, K) contributing nothing (from
+// o = S i + t - K/2, the transposed convolution behind signal_conv.py:778-847's same_zeros padding).  The sums run in
+// the MFMA's K dimension (v_mfma_f32_16x16x32_bf16: 16 columns x 16 pixels x 32 channels), so no tap products pass
+// through memory or LDS (conv_up_fused_kernel parks 80 float32 products per input pixel in LDS and gathers; a 9x9
+// kernel's 243 do not fit and that layer ran as an implicit GEMM over output pixels: 1.12 ms at 512 x 64x64).
+// Columns: 16 per MFMA — S = 4: the twelve (rx, c) of one output row phase ry (+ 4 unused), four groups; S = 2: eight
+// per ry (six used), one group.  Lane (n, g) of an accumulator then holds four consecutive values of output pixel
+// row S I + ry at byte 2 (3 S (J0 + n) + 4 g): a wave's stores cover whole contiguous runs of the output row.
+// A workgroup (8 waves) takes 8 input rows x 32 pixels, a wave one row (two 16-pixel halves); per 32-channel chunk the
+// block's input tile (10 x 34 pixels, 96-byte pixel stride: conflict-free ds_read_b128 for the b128 lane groups) and
+// the chunk's weight fragments are staged in LDS, the next chunk's global loads in flight under the MFMAs.  Two
+// workgroups per CU.  For S = 4 the row phases ry >= 1 have no tap at dy = -1: those MFMAs are not issued.
+// ---------------------------------------------------------------------------
+struct UpPhaseGeom {
+  long long N;
+  int H, W, Cin;
+  int activation;
+  int nchunk;               // Cin / 32
+};
+constexpr int kPhaseRows = 8;                          // input rows per workgroup
+constexpr int kPhasePixStride = 96;                    // bytes per tile pixel in LDS (64 of data)
+constexpr int kPhaseTilePix = (kPhaseRows + 2) * 34;
+
+template <int K, int S>
+struct UpPhase {
+  static constexpr int GROUPS = S == 4 ? 4 : 1;        // MFMA column groups
+  // fragments per chunk, in the order the kernel walks them: dy, dx, group (skipping the groups without a tap)
+  static constexpr int FRAGS = S == 4 ? 3 * 1 + 2 * 3 * 4 : 9;
+  __host__ __device__ static constexpr int tap(int r, int d) { return (r + K / 2) % S + S * ((r + K / 2) / S - d); }
+  __host__ __device__ static constexpr bool group_has(int grp, int dy) {
+    return S != 4 || (tap(grp, dy) >= 0 && tap(grp, dy) < K);
+  }
+};
+
+template <int K, int S>
+__global__ void conv_up_phase_weights_kernel(const float* w, int cin, int cout, bf16x8* packed) {
+  // packed[(chunk * FRAGS + slot) * 64 + lane], lane (m, g): column m of the slot's group, channels 32 chunk + 8 g ... + 7
+  using P = UpPhase<K, S>;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = (cin / 32) * P::FRAGS * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63, m = lane & 15, gq = lane >> 4;
+  int slot = (idx >> 6) % P::FRAGS;
+  const int chunk = (idx >> 6) / P::FRAGS;
+  int dy = -1, dx = -1, grp = 0;
+  {
+    int s = 0;
+    bool found = false;
+    for (int a = -1; a <= 1 && !found; ++a)
+      for (int b = -1; b <= 1 && !found; ++b)
+        for (int gr = 0; gr < P::GROUPS && !found; ++gr) {
+          if (!P::group_has(gr, a)) continue;
+          if (s == slot) { dy = a; dx = b; grp = gr; found = true; }
+          ++s;
+        }
+  }
+  // column m of the group -> (ry, rx, c)
+  int ry, rest;
+  if (S == 4) { ry = grp; rest = m; } else { ry = m >> 3; rest = m & 7; }
+  const int rx = rest / 3, c = rest % 3;
+  const bool col_ok = rest < 3 * S && c < cout;
+  const int ty = P::tap(ry, dy), tx = col_ok ? P::tap(rx, dx) : -1;
+  const bool ok = col_ok && ty >= 0 && ty < K && tx >= 0 && tx < K;
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = 32 * chunk + 8 * gq + e;
+    v[e] = static_cast<__bf16>(ok ? w[((static_cast<long long>(ty) * K + tx) * cin + ci) * cout + c] : 0.f);
+  }
+  packed[idx] = v;
+}
+
+template <int K, int S>
+__global__ void __launch_bounds__(512, 2) conv_up_phase_kernel(const __bf16* x, const bf16x8* wpk, const float* bias,
+                                                               __bf16* y, UpPhaseGeom g) {
+  using P = UpPhase<K, S>;
+  constexpr int GROUPS = P::GROUPS, FRAGS = P::FRAGS, HALVES = 2;
+  extern __shared__ unsigned char smem[];            // input tile (one chunk) | weight fragments (one chunk)
+  unsigned char* const xt = smem;
+  bf16x8* const wt = reinterpret_cast<bf16x8*>(smem + kPhaseTilePix * kPhasePixStride);
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, gq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bxn = (g.W + 31) / 32, byn = (g.H + kPhaseRows - 1) / kPhaseRows;
+  long long b = blockIdx.x;
+  const int bx = static_cast<int>(b % bxn); b /= bxn;
+  const int by = static_cast<int>(b % byn);
+  const long long img = b / byn;
+  const int I0 = by * kPhaseRows, J0 = bx * 32;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x + img * g.H * g.W * g.Cin), 0, static_cast<unsigned int>(g.H * g.W * g.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16x8*>(wpk), 0, static_cast<unsigned int>(g.nchunk * FRAGS * 1024), 0x00020000);
+  // staging: 16-byte pieces, tile pixel t = piece / 4 (row t / 34, column t % 34 of the tile, origin (I0 - 1, J0 - 1))
+  constexpr int XP = (kPhaseTilePix * 4 + 511) / 512, WP = (FRAGS * 64 + 511) / 512;
+  unsigned int xoff[XP];
+#pragma unroll
+  for (int r = 0; r < XP; ++r) {
+    const int piece = tid + 512 * r, t = piece >> 2, q = piece & 3;
+    const int iy = I0 - 1 + t / 34, ix = J0 - 1 + t % 34;
+    const bool ok = t < kPhaseTilePix && static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H) &&
+                    static_cast<unsigned int>(ix) < static_cast<unsigned int>(g.W);
+    xoff[r] = ok ? static_cast<unsigned int>(((iy * g.W + ix) * g.Cin) * 2 + q * 16) : 0x80000000u;
+  }
+  u32x4 xs[XP], ws[WP];
+  auto request = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < XP; ++r) xs[r] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[r], chunk * 64, 0);
+#pragma unroll
+    for (int r = 0; r < WP; ++r) {
+      const int i = tid + 512 * r;
+      ws[r] = __builtin_amdgcn_raw_buffer_load_b128(wr, i < FRAGS * 64 ? i * 16u : 0x80000000u, chunk * (FRAGS * 1024), 0);
+    }
+  };
+  auto park = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < XP; ++r) {
+      const int piece = tid + 512 * r;
+      if (piece < kPhaseTilePix * 4)
+        *reinterpret_cast<u32x4*>(xt + (piece >> 2) * kPhasePixStride + (piece & 3) * 16) = xs[r];
+    }
+#pragma unroll
+    for (int r = 0; r < WP; ++r) {
+      const int i = tid + 512 * r;
+      if (i < FRAGS * 64) reinterpret_cast<u32x4*>(wt)[i] = ws[r];
+    }
+  };
+  f32x4 acc[GROUPS][HALVES];
+#pragma unroll
+  for (int gr = 0; gr < GROUPS; ++gr)
+#pragma unroll
+    for (int p = 0; p < HALVES; ++p) acc[gr][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's B fragment of tap (0, 0), half 0: tile pixel (wid + 1, n + 1), channels 8 gq ... + 7 of the chunk
+  const unsigned char* const bbase = xt + ((wid + 1) * 34 + n + 1) * kPhasePixStride + 16 * gq;
+  request(0);
+  for (int chunk = 0; chunk < g.nchunk; ++chunk) {
+    __syncthreads();                                 // every wave is through with the previous chunk
+    park();
+    __syncthreads();
+    if (chunk + 1 < g.nchunk) request(chunk + 1);
+    int slot = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        bf16x8 bf[HALVES];
+#pragma unroll
+        for (int p = 0; p < HALVES; ++p)
+          bf[p] = *reinterpret_cast<const bf16x8*>(bbase + (dy * 34 + dx + 16 * p) * kPhasePixStride);
+#pragma unroll
+        for (int gr = 0; gr < GROUPS; ++gr) {
+          if (!P::group_has(gr, dy)) continue;
+          const bf16x8 a = wt[slot * 64 + lane];
+          ++slot;
+#pragma unroll
+          for (int p = 0; p < HALVES; ++p)
+            acc[gr][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[p], acc[gr][p], 0, 0, 0);
+        }
+      }
+  }
+  // ---- epilogue: acc[gr][p][i] = column 4 gq + i of the group, input pixel (I0 + wid, J0 + 16 p + n) ----
+  const int I = I0 + wid;
+  if (I >= g.H) return;
+  const int OW = g.W * S;
+  // the values of this lane: S = 4: (rx, c) = 4 gq + i of 12 (gq = 3: none); S = 2: ry = gq >> 1, 4 (gq & 1) + i of 6
+  const int first = S == 4 ? 4 * gq : 4 * (gq & 1);
+  const int count = S == 4 ? (gq < 3 ? 4 : 0) : ((gq & 1) ? 2 : 4);
+  float bc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bc[i] = bias ? bias[(first + i) % 3] : 0.f;
+#pragma unroll
+  for (int gr = 0; gr < GROUPS; ++gr) {
+    const int ry = S == 4 ? gr : (gq >> 1);
+    __bf16* const yrow = y + ((img * g.H * S + static_cast<long long>(I) * S + ry) * OW) * 3;
+#pragma unroll
+    for (int p = 0; p < HALVES; ++p) {
+      const int J = J0 + 16 * p + n;
+      if (J >= g.W || count == 0) continue;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = acc[gr][p][i] + bc[i];
+        if (g.activation == 1) v[i] = fmaxf(v[i], 0.f);
+      }
+      unsigned int* dst = reinterpret_cast<unsigned int*>(yrow + static_cast<long long>(J) * (3 * S) + first);
+      dst[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+      if (count == 4) dst[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+    }
+  }
+}
+
+// 0 = launched, -1 = not this shape, > 0 = error
+int run_conv_up_phase(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
+                      int64_t cin, int64_t cout, int kh, int kw, int stride, int activation, hipStream_t st) {
+  static const bool off = [] { const char* e = std::getenv("TFC_CONV_UP_PHASE"); return e && e[0] == '0'; }();
+  if (off || cout != 3 || cin % 32 || kh != kw) return -1;
+  const bool k5 = kh == 5 && stride == 2, k9 = kh == 9 && stride == 4;
+  if (!k5 && !k9) return -1;
+  if (static_cast<double>(h) * wd * cin * 2 >= 2147483648.0) return -1;          // one buffer resource per image
+  // (rows of 3 S bfloat16 per input pixel: 4-byte stores need S even — both are — and a 4-byte aligned y)
+  if (reinterpret_cast<uintptr_t>(y) % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return -1;
+  UpPhaseGeom g{};
+  g.N = n; g.H = static_cast<int>(h); g.W = static_cast<int>(wd); g.Cin = static_cast<int>(cin);
+  g.activation = activation; g.nchunk = static_cast<int>(cin / 32);
+  const long long blocks = n * ((g.H + kPhaseRows - 1) / kPhaseRows) * ((g.W + 31) / 32);
+  if (blocks >= (1ll << 31)) return -1;
+  const int frags_per_chunk = k9 ? UpPhase<9, 4>::FRAGS : UpPhase<5, 2>::FRAGS;
+  const int frags = g.nchunk * frags_per_chunk * 64;
+  DevBuf wpk;
+  TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
+  const size_t lds = static_cast<size_t>(kPhaseTilePix) * kPhasePixStride + static_cast<size_t>(frags_per_chunk) * 1024;
+  if (k9)
+    hipLaunchKernelGGL((conv_up_phase_weights_kernel<9, 4>), dim3((frags + 255) / 256), dim3(256), 0, st, w,
+                       static_cast<int>(cin), static_cast<int>(cout), wpk.as<bf16x8>());
+  else
+    hipLaunchKernelGGL((conv_up_phase_weights_kernel<5, 2>), dim3((frags + 255) / 256), dim3(256), 0, st, w,
+                       static_cast<int>(cin), static_cast<int>(cout), wpk.as<bf16x8>());
+  KernelTimer timer("conv2d", st);
+  if (k9) {
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up_phase_kernel<9, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((conv_up_phase_kernel<9, 4>), dim3(static_cast<unsigned>(blocks)), dim3(512), lds, st,
+                       static_cast<const __bf16*>(x), wpk.as<bf16x8>(), bias, static_cast<__bf16*>(y), g);
+  } else {
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up_phase_kernel<5, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((conv_up_phase_kernel<5, 2>), dim3(static_cast<unsigned>(blocks)), dim3(512), lds, st,
+                       static_cast<const __bf16*>(x), wpk.as<bf16x8>(), bias, static_cast<__bf16*>(y), g);
+  }
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
                int activation, int up, void* stream, bool out_f32 = false, const tfc_gdn_params* gdn = nullptr,
@@ -2358,6 +2594,12 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
 #ifndef TFC_CONV_NO_UP_GATHER
   // (up to 128 product columns, i.e. one column group: a 9x9 stride-4 kernel has 324 and measured the same
   // or slower this way — 0.19 against 0.16 ms at batch 64 — so it keeps the implicit GEMM over output pixels)
+  if (up && dtype == 1 && cout == 3 && !out_f32) {
+    // the synthesis transforms' last layer as a 3x3 convolution over the input grid: conv_up_phase_kernel
+    const int rc = run_conv_up_phase(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride,
+                                     activation, static_cast<hipStream_t>(stream));
+    if (rc >= 0) return rc;
+  }
   if (up && dtype == 1 && cout <= 4 && cin % 64 == 0 && stride >= 2 && !out_f32) {
     const int rc = run_conv_up_fused(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride,
                                      activation, static_cast<hipStream_t>(stream));

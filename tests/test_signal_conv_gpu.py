@@ -333,6 +333,9 @@ def scipy_same_zeros(x, kernel, stride, up):
     ("analysis 5x5 3->192 /2, three tiles a row", (1, 6, 192, 3), (5, 5, 3, 192), 2, False),
     ("synthesis 9x9 192->3 x4", (1, 6, 7, 192), (9, 9, 192, 3), 4, True),
     ("synthesis 5x5 192->3 x2", (2, 8, 9, 192), (5, 5, 192, 3), 2, True),
+    # several 8 x 32 input blocks with ragged edges (conv_up_phase_kernel)
+    ("synthesis 9x9 192->3 x4, blocks", (2, 19, 70, 192), (9, 9, 192, 3), 4, True),
+    ("synthesis 5x5 192->3 x2, blocks", (2, 17, 45, 192), (5, 5, 192, 3), 2, True),
     ("hyper 3x3 192->192 s1", (1, 8, 8, 192), (3, 3, 192, 192), 1, False),
 ])
 def test_bf16_model_layer_shapes_against_scipy(label, shape, kshape, stride, up):
