@@ -2294,7 +2294,6 @@ struct UpPhaseGeom {
   int nchunk;               // Cin / 32
 };
 constexpr int kPhaseRows = 8;                          // input rows per workgroup
-constexpr int kPhasePixStride = 96;                    // bytes per tile pixel in LDS (64 of data)
 constexpr int kPhaseTilePix = (kPhaseRows + 2) * 34;
 
 template <int K, int S>
@@ -2302,6 +2301,12 @@ struct UpPhase {
   static constexpr int GROUPS = S == 4 ? 4 : 1;        // MFMA column groups
   // fragments per chunk, in the order the kernel walks them: dy, dx, group (skipping the groups without a tap)
   static constexpr int FRAGS = S == 4 ? 3 * 1 + 2 * 3 * 4 : 9;
+  // 32-channel chunks staged at a time, and the tile's pixel stride in LDS (bytes; 64 of data per chunk): S = 2 takes two
+  // chunks = one whole 128-byte line of a pixel per stage (a half line per stage was measured: 1.22 against 1.18 ms at
+  // 128 x 256x384 — the other half has left the L2 by the next stage); S = 4 has 27 KB of fragments per chunk and
+  // stays with one.  Both strides keep ds_read_b128 conflict-free for the b128 lane groups (16 n + g -> n PXS + 16 g).
+  static constexpr int CPS = S == 4 ? 1 : 2;
+  static constexpr int PXS = CPS == 1 ? 96 : 160;
   __host__ __device__ static constexpr int tap(int r, int d) { return (r + K / 2) % S + S * ((r + K / 2) / S - d); }
   __host__ __device__ static constexpr bool group_has(int grp, int dy) {
     return S != 4 || (tap(grp, dy) >= 0 && tap(grp, dy) < K);
@@ -2350,10 +2355,10 @@ template <int K, int S>
 __global__ void __launch_bounds__(512, 2) conv_up_phase_kernel(const __bf16* x, const bf16x8* wpk, const float* bias,
                                                                __bf16* y, UpPhaseGeom g) {
   using P = UpPhase<K, S>;
-  constexpr int GROUPS = P::GROUPS, FRAGS = P::FRAGS, HALVES = 2;
-  extern __shared__ unsigned char smem[];            // input tile (one chunk) | weight fragments (one chunk)
+  constexpr int GROUPS = P::GROUPS, FRAGS = P::FRAGS, HALVES = 2, CPS = P::CPS, PXS = P::PXS;
+  extern __shared__ unsigned char smem[];            // input tile (CPS chunks) | weight fragments (CPS chunks)
   unsigned char* const xt = smem;
-  bf16x8* const wt = reinterpret_cast<bf16x8*>(smem + kPhaseTilePix * kPhasePixStride);
+  bf16x8* const wt = reinterpret_cast<bf16x8*>(smem + kPhaseTilePix * PXS);
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, gq = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bxn = (g.W + 31) / 32, byn = (g.H + kPhaseRows - 1) / kPhaseRows;
@@ -2366,38 +2371,40 @@ __global__ void __launch_bounds__(512, 2) conv_up_phase_kernel(const __bf16* x, 
       const_cast<__bf16*>(x + img * g.H * g.W * g.Cin), 0, static_cast<unsigned int>(g.H * g.W * g.Cin * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16x8*>(wpk), 0, static_cast<unsigned int>(g.nchunk * FRAGS * 1024), 0x00020000);
-  // staging: 16-byte pieces, tile pixel t = piece / 4 (row t / 34, column t % 34 of the tile, origin (I0 - 1, J0 - 1))
-  constexpr int XP = (kPhaseTilePix * 4 + 511) / 512, WP = (FRAGS * 64 + 511) / 512;
+  // staging: 16-byte pieces, 4 CPS to a tile pixel t (row t / 34, column t % 34 of the tile, origin (I0 - 1, J0 - 1))
+  constexpr int PPP = 4 * CPS;                         // pieces per pixel
+  constexpr int XP = (kPhaseTilePix * PPP + 511) / 512, WP = (CPS * FRAGS * 64 + 511) / 512;
   unsigned int xoff[XP];
 #pragma unroll
   for (int r = 0; r < XP; ++r) {
-    const int piece = tid + 512 * r, t = piece >> 2, q = piece & 3;
+    const int piece = tid + 512 * r, t = piece / PPP, q = piece % PPP;
     const int iy = I0 - 1 + t / 34, ix = J0 - 1 + t % 34;
     const bool ok = t < kPhaseTilePix && static_cast<unsigned int>(iy) < static_cast<unsigned int>(g.H) &&
                     static_cast<unsigned int>(ix) < static_cast<unsigned int>(g.W);
     xoff[r] = ok ? static_cast<unsigned int>(((iy * g.W + ix) * g.Cin) * 2 + q * 16) : 0x80000000u;
   }
   u32x4 xs[XP], ws[WP];
-  auto request = [&](int chunk) __attribute__((always_inline)) {
+  auto request = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < XP; ++r) xs[r] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[r], chunk * 64, 0);
+    for (int r = 0; r < XP; ++r) xs[r] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[r], stage * (64 * CPS), 0);
 #pragma unroll
     for (int r = 0; r < WP; ++r) {
       const int i = tid + 512 * r;
-      ws[r] = __builtin_amdgcn_raw_buffer_load_b128(wr, i < FRAGS * 64 ? i * 16u : 0x80000000u, chunk * (FRAGS * 1024), 0);
+      ws[r] = __builtin_amdgcn_raw_buffer_load_b128(wr, i < CPS * FRAGS * 64 ? i * 16u : 0x80000000u,
+                                                    stage * (CPS * FRAGS * 1024), 0);
     }
   };
   auto park = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < XP; ++r) {
       const int piece = tid + 512 * r;
-      if (piece < kPhaseTilePix * 4)
-        *reinterpret_cast<u32x4*>(xt + (piece >> 2) * kPhasePixStride + (piece & 3) * 16) = xs[r];
+      if (piece < kPhaseTilePix * PPP)
+        *reinterpret_cast<u32x4*>(xt + (piece / PPP) * PXS + (piece % PPP) * 16) = xs[r];
     }
 #pragma unroll
     for (int r = 0; r < WP; ++r) {
       const int i = tid + 512 * r;
-      if (i < FRAGS * 64) reinterpret_cast<u32x4*>(wt)[i] = ws[r];
+      if (i < CPS * FRAGS * 64) reinterpret_cast<u32x4*>(wt)[i] = ws[r];
     }
   };
   f32x4 acc[GROUPS][HALVES];
@@ -2406,32 +2413,36 @@ __global__ void __launch_bounds__(512, 2) conv_up_phase_kernel(const __bf16* x, 
 #pragma unroll
     for (int p = 0; p < HALVES; ++p) acc[gr][p] = f32x4{0.f, 0.f, 0.f, 0.f};
   // this lane's B fragment of tap (0, 0), half 0: tile pixel (wid + 1, n + 1), channels 8 gq ... + 7 of the chunk
-  const unsigned char* const bbase = xt + ((wid + 1) * 34 + n + 1) * kPhasePixStride + 16 * gq;
+  const unsigned char* const bbase = xt + ((wid + 1) * 34 + n + 1) * PXS + 16 * gq;
+  const int stages = g.nchunk / CPS;
   request(0);
-  for (int chunk = 0; chunk < g.nchunk; ++chunk) {
-    __syncthreads();                                 // every wave is through with the previous chunk
+  for (int stage = 0; stage < stages; ++stage) {
+    __syncthreads();                                 // every wave is through with the previous stage
     park();
     __syncthreads();
-    if (chunk + 1 < g.nchunk) request(chunk + 1);
-    int slot = 0;
+    if (stage + 1 < stages) request(stage + 1);
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+    for (int sub = 0; sub < CPS; ++sub) {
+      int slot = sub * FRAGS;
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        bf16x8 bf[HALVES];
+      for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int p = 0; p < HALVES; ++p)
-          bf[p] = *reinterpret_cast<const bf16x8*>(bbase + (dy * 34 + dx + 16 * p) * kPhasePixStride);
-#pragma unroll
-        for (int gr = 0; gr < GROUPS; ++gr) {
-          if (!P::group_has(gr, dy)) continue;
-          const bf16x8 a = wt[slot * 64 + lane];
-          ++slot;
+        for (int dx = -1; dx <= 1; ++dx) {
+          bf16x8 bf[HALVES];
 #pragma unroll
           for (int p = 0; p < HALVES; ++p)
-            acc[gr][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[p], acc[gr][p], 0, 0, 0);
+            bf[p] = *reinterpret_cast<const bf16x8*>(bbase + (dy * 34 + dx + 16 * p) * PXS + 64 * sub);
+#pragma unroll
+          for (int gr = 0; gr < GROUPS; ++gr) {
+            if (!P::group_has(gr, dy)) continue;
+            const bf16x8 a = wt[slot * 64 + lane];
+            ++slot;
+#pragma unroll
+            for (int p = 0; p < HALVES; ++p)
+              acc[gr][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[p], acc[gr][p], 0, 0, 0);
+          }
         }
-      }
+    }
   }
   // ---- epilogue: acc[gr][p][i] = column 4 gq + i of the group, input pixel (I0 + wid, J0 + 16 p + n) ----
   const int I = I0 + wid;
@@ -2483,7 +2494,9 @@ int run_conv_up_phase(const void* x, const float* w, const float* bias, void* y,
   const int frags = g.nchunk * frags_per_chunk * 64;
   DevBuf wpk;
   TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
-  const size_t lds = static_cast<size_t>(kPhaseTilePix) * kPhasePixStride + static_cast<size_t>(frags_per_chunk) * 1024;
+  const int cps = k9 ? UpPhase<9, 4>::CPS : UpPhase<5, 2>::CPS, pxs = k9 ? UpPhase<9, 4>::PXS : UpPhase<5, 2>::PXS;
+  if (g.nchunk % cps) return -1;
+  const size_t lds = static_cast<size_t>(kPhaseTilePix) * pxs + static_cast<size_t>(cps) * frags_per_chunk * 1024;
   if (k9)
     hipLaunchKernelGGL((conv_up_phase_weights_kernel<9, 4>), dim3((frags + 255) / 256), dim3(256), 0, st, w,
                        static_cast<int>(cin), static_cast<int>(cout), wpk.as<bf16x8>());
