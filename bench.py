@@ -674,6 +674,8 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
             conv_ms = kern["conv2d"][0] / lone_steps
             flops = model_conv_flops(workload, batch, hw)
             conv_tflops = flops / 1e12 / (conv_ms / 1e3) if conv_ms > 0 else 0.0
+            # dense matrix-core peak of the transforms' arithmetic type: bf16 MFMA, or v_mfma_f32_32x32x2_f32 (256 CUs x 256 flop/clk x 2.4 GHz)
+            mfma_peak = 2500.0 if dtype_name == "bf16" else 157.3
             res = {
                 "value": round(pixels / 1e6 / (elapsed / steps), 2), "unit": "Mpixels/s",
                 "ms_per_step": round(1e3 * elapsed / steps, 3), "steps": steps, "warmup": warmup,
@@ -693,8 +695,8 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
                               "note": "one step at a time, whole chip, nothing else resident: where the kernel split is measured"},
                 "bits_per_pixel": round(8.0 * nbytes / (batch * hw[0] * hw[1]), 4),
                 "roofline": {"bound": "mfma", "kernel": "conv2d (all SignalConv2D launches of a step)",
-                             "achieved": round(conv_tflops, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                             "frac": round(conv_tflops / 2500.0, 4), "traffic": None,
+                             "achieved": round(conv_tflops, 1), "peak": mfma_peak, "unit": "TFLOP/s",
+                             "frac": round(conv_tflops / mfma_peak, 4), "traffic": None,
                              "algorithmic_flops": int(flops)},
             }
             if hist is not None:
@@ -1140,6 +1142,11 @@ def main():
                                                  steps=args.model_steps or (32 if g == 1 else 16 * g),
                                                  warmup=2, lanes=step_lanes, cpu=not args.no_cpu_baseline,
                                                  group=g, queue=args.model_queue)
+            if args.model_dtype == "bf16":
+                # the reference's default policy: float32 transforms (v_mfma_f32_32x32x2_f32, first-generation kernel)
+                torch.cuda.empty_cache()
+                out["models"]["c1_f32"] = model_bench("bls2017", "f32", device, steps=8, warmup=1, lanes=step_lanes,
+                                                      cpu=False, group=1, queue=args.model_queue)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
