@@ -9,7 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HOT = ["conv_bf16_kernel", "conv3_bf16_kernel", "conv_image_kernel", "conv_up_fused_kernel",
+HOT = ["conv_bf16_kernel", "conv3_bf16_kernel", "conv_image_kernel", "conv_image_direct_kernel", "conv_up_fused_kernel",
+       "conv_up_phase_kernel",
        "image_to_unit_kernel", "unit_to_image_kernel", "index_prepare_kernel",
        "enc_lanes_kernel", "dec_lanes_kernel", "enc_fast_kernel", "dec_fast_kernel",
        "enc_expand_kernel", "enc_chain_kernel", "enc_chain_direct_kernel", "dec_chain_kernel", "dec_parse_kernel",

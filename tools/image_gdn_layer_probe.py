@@ -1,5 +1,6 @@
 """bmshj2018's first analysis layer at the C4 shape (128 x 768x512x3 -> 384x256x192, GDN behind it): one kernel
 (conv_image_gdn_kernel) against conv_image_kernel + the GDN kernel, lone, HIP-event time over 20 launches."""
+import os
 import torch
 from compression_amd import layers
 
