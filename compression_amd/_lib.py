@@ -87,6 +87,8 @@ SIGNATURES = {
                              _int, _int, _int, _vp]),
     "tfc_conv2d_gdn": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _vp, _int,
                               C.POINTER(_int), _vp]),
+    "tfc_conv2d_weights_key": (None, [C.c_uint64]),
+    "tfc_conv2d_drop_weights": (_int, [C.c_uint64]),
     "tfc_conv2d_wgrad": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int,
                                 _int, _int, _int, _vp]),
     "tfc_factorized_bits_forward": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _int, _int,

@@ -171,6 +171,78 @@ __device__ inline float packed_weight(const float* w, const PackGeom& g, const C
   return w[((static_cast<long long>(ty) * g.kw + tx) * g.Cin_real + ci) * g.Cout + co];
 }
 
+// ---------------------------------------------------------------------------
+// Packed weights of an inference layer, kept between calls.  Every kernel here reads the layer's float32 HWIO kernel as
+// fragments in its own order, packed by a small kernel in front of it — 60-90 us each, four to nine a model step (0.35 ms
+// of bls2017's 7.4 ms, profiles/r04_bls2017_stats.md).  A caller that knows the weights do not change between calls says
+// so with tfc_conv2d_weights_key (a number that names this VALUE of the weights; include/tfc_hip.h): the fragments of
+// (key, packing site, geometry) are then packed once and kept until tfc_conv2d_drop_weights(key).  Without a key —
+// training, or weights that are tensors computed per call — every call packs, as before.
+// The entry is made on the first caller's stream; another stream waits for its event (a completed event costs nothing).
+// ---------------------------------------------------------------------------
+thread_local unsigned long long t_next_weights_key = 0;      // set by tfc_conv2d_weights_key, taken by the next conv call
+thread_local unsigned long long t_weights_key = 0;           // of the call in progress on this thread
+struct WeightsCache {
+  struct Key {
+    unsigned long long key;
+    int site, dev;
+    long long dims[16];
+    bool operator<(const Key& o) const {
+      if (key != o.key) return key < o.key;
+      if (site != o.site) return site < o.site;
+      if (dev != o.dev) return dev < o.dev;
+      return std::lexicographical_compare(dims, dims + 16, o.dims, o.dims + 16);
+    }
+  };
+  struct Entry {
+    DevBuf buf;
+    hipEvent_t ready = nullptr;
+    hipStream_t made_on = nullptr;
+  };
+  std::mutex mu;
+  std::map<Key, Entry> entries;
+  static WeightsCache& get() {
+    static WeightsCache* c = new WeightsCache;               // leaked: entries may outlive static destruction order
+    return *c;
+  }
+};
+
+// The packed weights of this call: *p = `bytes` of fragments, written by pack(p) on `st` — now into `local` (no key), or
+// once into the cache.  site: which packing (the kernels' orders differ); dims: whatever the packing depends on.
+template <typename Pack>
+int packed_weights(int site, std::initializer_list<long long> dims, size_t bytes, hipStream_t st, DevBuf& local, void** p,
+                   Pack&& pack) {
+  const unsigned long long key = t_weights_key;
+  if (!key) {
+    TFC_HIP(local.alloc(bytes, st));
+    *p = local.p;
+    return pack(local.p);
+  }
+  WeightsCache& c = WeightsCache::get();
+  WeightsCache::Key k{};
+  k.key = key; k.site = site;
+  (void)hipGetDevice(&k.dev);
+  int i = 0;
+  for (long long d : dims) k.dims[i++] = d;
+  k.dims[15] = static_cast<long long>(bytes);
+  std::lock_guard<std::mutex> lock(c.mu);
+  auto it = c.entries.find(k);
+  if (it == c.entries.end()) {
+    WeightsCache::Entry e;
+    TFC_HIP(e.buf.alloc(bytes, st));
+    const int rc = pack(e.buf.p);
+    if (rc) return rc;
+    TFC_HIP(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+    TFC_HIP(hipEventRecord(e.ready, st));
+    e.made_on = st;
+    it = c.entries.emplace(k, std::move(e)).first;
+  } else if (it->second.made_on != st) {
+    TFC_HIP(hipStreamWaitEvent(st, it->second.ready, 0));
+  }
+  *p = it->second.buf.p;
+  return 0;
+}
+
 template <typename T>
 __global__ void conv_pack_kernel(const float* w, PackGeom g, ConvGeom c, void* packed) {
   const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
@@ -1295,13 +1367,19 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     if (!built) return -1;
     if (cb * (nts[grp] == 25 ? 5 : nts[grp] == 9 ? 3 : nts[grp] == 6 ? 2 : 1) < 2) return -1;   // (weights are requested two chunks ahead)
   }
-  DevBuf packed;
+  DevBuf packed_local;
+  DevView packed;
   const long long frags = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
-  TFC_HIP(packed.alloc(static_cast<size_t>(frags) * 16 + 64, st));
   {
-    SlowCall slow("conv_pack_kernel launch", __FILE__, __LINE__);
-    hipLaunchKernelGGL((conv_pack_kernel<__bf16>), dim3(static_cast<unsigned>(ceil_div(frags, 256))), dim3(256), 0, st,
-                       w, g, c, packed.p);
+    const int rc = packed_weights(1, {g.kh, g.kw, g.Cin_real, g.Cout, g.su, g.up, g.Uy, g.Ux, g.dmax_y, g.dmax_x, c.groups, c.ksteps,
+                                      c.tiles, c.compact * 4 + c.cbmajor * 2 + c.small_cin, c.kw4},
+                                  static_cast<size_t>(frags) * 16 + 64, st, packed_local, &packed.p, [&](void* dst) {
+      SlowCall slow("conv_pack_kernel launch", __FILE__, __LINE__);
+      hipLaunchKernelGGL((conv_pack_kernel<__bf16>), dim3(static_cast<unsigned>(ceil_div(frags, 256))), dim3(256), 0, st,
+                         w, g, c, dst);
+      return 0;
+    });
+    if (rc) return rc;
   }
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -1396,16 +1474,23 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
     }
     c.ksteps = most * (c.Cin / 16);          // packed K steps per group (the stride of the packed buffer)
   }
-  DevBuf packed, padded;
+  DevBuf packed_local, padded;
+  DevView packed;
   const long long frags = static_cast<long long>(c.groups) * c.ksteps * c.tiles * 64;
   // + a zero page behind the fragments: what lanes outside the image read (16 bytes; the per-chunk pointers of
   // the FASTK kernel read it at + 32 (kChunk2 - 1))
-  TFC_HIP(packed.alloc(static_cast<size_t>(frags) * FB + 32 * kChunk2, st));
-  TFC_HIP(hipMemsetAsync(static_cast<unsigned char*>(packed.p) + static_cast<size_t>(frags) * FB, 0, 32 * kChunk2, st));
   {
-    SlowCall slow("conv_pack_kernel launch", __FILE__, __LINE__);
-    hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(static_cast<unsigned>(ceil_div(frags, 256))),
-                       dim3(256), 0, st, w, g, c, packed.p);
+    const int rc = packed_weights(2, {g.kh, g.kw, g.Cin_real, g.Cout, g.su, g.up, g.Uy, g.Ux, g.dmax_y, g.dmax_x, c.groups,
+                                      c.ksteps, c.tiles, c.compact * 4 + c.cbmajor * 2 + c.small_cin + 8 * static_cast<int>(sizeof(T)),
+                                      c.kw4},
+                                  static_cast<size_t>(frags) * FB + 32 * kChunk2, st, packed_local, &packed.p, [&](void* dst) {
+      TFC_HIP(hipMemsetAsync(static_cast<unsigned char*>(dst) + static_cast<size_t>(frags) * FB, 0, 32 * kChunk2, st));
+      SlowCall slow("conv_pack_kernel launch", __FILE__, __LINE__);
+      hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(static_cast<unsigned>(ceil_div(frags, 256))),
+                         dim3(256), 0, st, w, g, c, dst);
+      return 0;
+    });
+    if (rc) return rc;
   }
   const T* xin = static_cast<const T*>(x);
   if (c.small_cin) {
@@ -1778,10 +1863,18 @@ int run_conv_image(const void* x, const float* w, const float* bias, void* y, in
   g.pairs = (g.W * g.Cin) % 2 == 0 && (g.px0 * g.Cin) % 2 == 0 && (g.H * g.W * g.Cin) % 2 == 0 &&
             reinterpret_cast<uintptr_t>(x) % 4 == 0;
   if (g.OW < 24) return -1;
-  DevBuf wpk;
+  DevBuf wpk_local;
+  DevView wpk;
   const int frags = kh * g.ksr * tiles * 64;
-  TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
-  hipLaunchKernelGGL(conv_image_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, g, tiles, wpk.as<bf16x8>());
+  {
+    const int rc = packed_weights(3, {kh, kw, cin, cout, tiles, g.ksr}, static_cast<size_t>(frags) * 16, st, wpk_local, &wpk.p,
+                                  [&](void* dst) {
+      hipLaunchKernelGGL(conv_image_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, g, tiles,
+                         static_cast<bf16x8*>(dst));
+      return 0;
+    });
+    if (rc) return rc;
+  }
   KernelTimer timer("conv2d", st);
   const dim3 grid(static_cast<unsigned>(ceil_div(n * g.BXn * g.BYn, g.items)));
   if (tiles == 6) {
@@ -2070,10 +2163,18 @@ int run_conv_image_direct(const void* x, const float* w, const float* bias, void
   const size_t lds = (gdn ? static_cast<size_t>(tiles) * 2 * tiles * 64 * 16 + tiles * 32 * 4 : 0) + tiles * 32 * 4 +
                      static_cast<size_t>(nk) * tiles * 64 * 16 + 8 * 32 * 144;
   if (lds > 160 * 1024) return -1;
-  DevBuf wpk;
+  DevBuf wpk_local;
+  DevView wpk;
   const int frags = nk * tiles * 64;
-  TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
-  hipLaunchKernelGGL(conv_image_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, g, tiles, wpk.as<bf16x8>());
+  {
+    const int rc = packed_weights(3, {kh, kw, cin, cout, tiles, g.ksr}, static_cast<size_t>(frags) * 16, st, wpk_local, &wpk.p,
+                                  [&](void* dst) {
+      hipLaunchKernelGGL(conv_image_weights_kernel, dim3((frags + 255) / 256), dim3(256), 0, st, w, g, tiles,
+                         static_cast<bf16x8*>(dst));
+      return 0;
+    });
+    if (rc) return rc;
+  }
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2492,17 +2593,24 @@ int run_conv_up_phase(const void* x, const float* w, const float* bias, void* y,
   if (blocks >= (1ll << 31)) return -1;
   const int frags_per_chunk = k9 ? UpPhase<9, 4>::FRAGS : UpPhase<5, 2>::FRAGS;
   const int frags = g.nchunk * frags_per_chunk * 64;
-  DevBuf wpk;
-  TFC_HIP(wpk.alloc(static_cast<size_t>(frags) * 16, st));
   const int cps = k9 ? UpPhase<9, 4>::CPS : UpPhase<5, 2>::CPS, pxs = k9 ? UpPhase<9, 4>::PXS : UpPhase<5, 2>::PXS;
   if (g.nchunk % cps) return -1;
   const size_t lds = static_cast<size_t>(kPhaseTilePix) * pxs + static_cast<size_t>(cps) * frags_per_chunk * 1024;
-  if (k9)
-    hipLaunchKernelGGL((conv_up_phase_weights_kernel<9, 4>), dim3((frags + 255) / 256), dim3(256), 0, st, w,
-                       static_cast<int>(cin), static_cast<int>(cout), wpk.as<bf16x8>());
-  else
-    hipLaunchKernelGGL((conv_up_phase_weights_kernel<5, 2>), dim3((frags + 255) / 256), dim3(256), 0, st, w,
-                       static_cast<int>(cin), static_cast<int>(cout), wpk.as<bf16x8>());
+  DevBuf wpk_local;
+  DevView wpk;
+  {
+    const int rc = packed_weights(5, {kh, kw, cin, cout, stride}, static_cast<size_t>(frags) * 16, st, wpk_local, &wpk.p,
+                                  [&](void* dst) {
+      if (k9)
+        hipLaunchKernelGGL((conv_up_phase_weights_kernel<9, 4>), dim3((frags + 255) / 256), dim3(256), 0, st, w,
+                           static_cast<int>(cin), static_cast<int>(cout), static_cast<bf16x8*>(dst));
+      else
+        hipLaunchKernelGGL((conv_up_phase_weights_kernel<5, 2>), dim3((frags + 255) / 256), dim3(256), 0, st, w,
+                           static_cast<int>(cin), static_cast<int>(cout), static_cast<bf16x8*>(dst));
+      return 0;
+    });
+    if (rc) return rc;
+  }
   KernelTimer timer("conv2d", st);
   if (k9) {
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up_phase_kernel<9, 4>),
@@ -2596,6 +2704,12 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
                int activation, int up, void* stream, bool out_f32, const tfc_gdn_params* gdn, int gdn_inverse,
                int* gdn_fused) {
+  // the weights key named for this call (tfc_conv2d_weights_key), for the packing sites below
+  struct KeyScope {
+    KeyScope() { t_weights_key = t_next_weights_key; t_next_weights_key = 0; }
+    ~KeyScope() { t_weights_key = 0; }
+  } key_scope;
+
   if (gdn_fused) *gdn_fused = 0;
   if (dtype != 0 && dtype != 1) return fail("tfc_conv2d: dtype must be 0 (float32) or 1 (bfloat16)");
   if (kh < 1 || kw < 1 || stride < 1 || cin < 1 || cout < 1) return fail("tfc_conv2d: bad geometry");
@@ -2693,6 +2807,27 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
 }
 
 }  // namespace tfc
+
+extern "C" void tfc_conv2d_weights_key(uint64_t key) { tfc::t_next_weights_key = key; }
+
+extern "C" int tfc_conv2d_drop_weights(uint64_t key) {
+  tfc::WeightsCache& c = tfc::WeightsCache::get();
+  std::lock_guard<std::mutex> lock(c.mu);
+  bool any = false;
+  for (auto it = c.entries.begin(); it != c.entries.end(); ++it) any = any || it->first.key == key;
+  if (!any) return 0;
+  // a kernel on any stream may still read the fragments: the device is drained before their memory goes back
+  TFC_HIP(hipDeviceSynchronize());
+  for (auto it = c.entries.begin(); it != c.entries.end();) {
+    if (it->first.key == key) {
+      (void)hipEventDestroy(it->second.ready);
+      it = c.entries.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  return 0;
+}
 
 extern "C" int tfc_conv2d_down(const void* x, const void* w, const float* bias, void* y, int dtype,
                                int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh,

@@ -73,7 +73,7 @@ def gdn_forward(x: torch.Tensor, beta: torch.Tensor, gamma: torch.Tensor, invers
     return y
 
 
-def _conv(fn_name, x, kernel, bias, stride, activation, up):
+def _conv(fn_name, x, kernel, bias, stride, activation, up, weights_key=0):
     _lib.require_device()
     if x.dtype not in _DTYPE_CODE:
         raise TypeError(f"conv kernel supports float32 and bfloat16, got {x.dtype}")
@@ -93,13 +93,15 @@ def _conv(fn_name, x, kernel, bias, stride, activation, up):
         oh, ow = -(-h // stride), -(-w // stride)
     y = torch.empty((n, oh, ow, cout), dtype=x.dtype, device=x.device)
     act = {None: 0, "relu": 1}[activation]
+    if weights_key:
+        _lib.lib().tfc_conv2d_weights_key(weights_key)      # this thread's next conv call: fragments packed once per value
     _lib.check(getattr(_lib.lib(), fn_name)(
         x.data_ptr(), kernel.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
         _DTYPE_CODE[x.dtype], n, h, w, cin, cout, kh, kw, int(stride), act, _lib.stream_ptr()))
     return y
 
 
-def conv2d_gdn(x, kernel, bias, stride, up, prepared: GDNPrepared, inverse: bool):
+def conv2d_gdn(x, kernel, bias, stride, up, prepared: GDNPrepared, inverse: bool, weights_key=0):
     """SignalConv2D with GDN / IGDN as its activation (inference, bfloat16): -> (y, fused).  fused: the convolution
     kernel applied the activation itself (include/tfc_hip.h, tfc_conv2d_gdn); else y is the convolution's output and
     the caller applies the GDN kernel."""
@@ -116,6 +118,8 @@ def conv2d_gdn(x, kernel, bias, stride, up, prepared: GDNPrepared, inverse: bool
     oh, ow = (h * stride, w * stride) if up else (-(-h // stride), -(-w // stride))
     y = torch.empty((n, oh, ow, cout), dtype=x.dtype, device=x.device)
     fused = ctypes.c_int(0)
+    if weights_key:
+        _lib.lib().tfc_conv2d_weights_key(weights_key)
     _lib.check(_lib.lib().tfc_conv2d_gdn(
         x.data_ptr(), kernel.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
         _DTYPE_CODE[x.dtype], n, h, w, cin, cout, kh, kw, int(stride), int(bool(up)), prepared.ptr, int(bool(inverse)),
@@ -195,22 +199,24 @@ class _ConvFunction(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
-def _conv_dispatch(x, kernel, bias, stride, activation, up):
+def _conv_dispatch(x, kernel, bias, stride, activation, up, weights_key=0):
     needs = torch.is_grad_enabled() and (x.requires_grad or kernel.requires_grad
                                          or (bias is not None and bias.requires_grad))
     if needs:
         return _ConvFunction.apply(x, kernel, bias, stride, activation, up)
-    return _conv("tfc_conv2d_up" if up else "tfc_conv2d_down", x, kernel, bias, stride, activation, up)
+    return _conv("tfc_conv2d_up" if up else "tfc_conv2d_down", x, kernel, bias, stride, activation, up, weights_key)
 
 
-def conv2d_down(x, kernel, bias=None, stride=1, activation=None):
-    """Analysis correlation (signal_conv.py:663-690): NHWC x, HWIO kernel, `same_zeros`."""
-    return _conv_dispatch(x, kernel, bias, stride, activation, False)
+def conv2d_down(x, kernel, bias=None, stride=1, activation=None, weights_key=0):
+    """Analysis correlation (signal_conv.py:663-690): NHWC x, HWIO kernel, `same_zeros`.  weights_key: a number that
+    names this VALUE of `kernel` (include/tfc_hip.h, tfc_conv2d_weights_key): its packed fragments are kept between
+    calls; 0: packed per call."""
+    return _conv_dispatch(x, kernel, bias, stride, activation, False, weights_key)
 
 
-def conv2d_up(x, kernel, bias=None, stride=1, activation=None):
+def conv2d_up(x, kernel, bias=None, stride=1, activation=None, weights_key=0):
     """Synthesis transposed convolution (signal_conv.py:778-847, extra_pad_end=True)."""
-    return _conv_dispatch(x, kernel, bias, stride, activation, True)
+    return _conv_dispatch(x, kernel, bias, stride, activation, True, weights_key)
 
 
 def gdn_backward(x, grad, beta, gamma, inverse=False, rectify=False, alpha=1, epsilon=1):

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import math
 
+import itertools
 import os
 
 import torch
@@ -136,12 +137,55 @@ class SignalConv2D(torch.nn.Module):
             cached = self._kernel_cache
         return cached[1]
 
+    # One number per distinct value of a layer's weights (include/tfc_hip.h, tfc_conv2d_weights_key): the library keeps
+    # the kernels' packed fragments of a keyed value between calls instead of packing them in front of every launch.
+    _WEIGHT_KEYS = itertools.count(1)
+
+    def _inference_weights_key(self):
+        """The key of the kernel's current value, or 0: gradients enabled (the weights are about to change), a kernel
+        given as a tensor / callable (computed per call), or parameters without version counters."""
+        if torch.is_grad_enabled() or self._kernel_given is not None:
+            return 0
+        src = (self.kernel_variable,) if self.kernel_variable is not None else (self.kernel_real, self.kernel_imag)
+        if any(t is None or not t.is_cuda for t in src):
+            return 0
+        ident = tuple((t.data_ptr(), _version_of(t)) for t in src) + (str(src[0].device),)
+        if any(v is None for _, v in ident[:-1]):
+            return 0
+        hit = self.__dict__.get("_wkey_cache")
+        if hit is None or hit[0] != ident or hit[2] != id(self):
+            if hit is not None and hit[2] == id(self):
+                self._drop_weights_key(hit[1])
+            hit = (ident, next(SignalConv2D._WEIGHT_KEYS), id(self))
+            object.__setattr__(self, "_wkey_cache", hit)
+        return hit[1]
+
+    @staticmethod
+    def _drop_weights_key(key):
+        try:
+            from .. import _lib
+            lib = _lib.lib()
+            lib.tfc_conv2d_drop_weights(key)
+            lib.tfc_conv2d_drop_weights(key | (1 << 62))         # (of the flipped kernel: forward)
+        except Exception:                                        # interpreter shutdown, library never loaded
+            pass
+
+    def __del__(self):
+        hit = self.__dict__.get("_wkey_cache")
+        if hit is not None and hit[2] == id(self):
+            self._drop_weights_key(hit[1])
+
     def invalidate_kernel_cache(self):
         """Drops the cached inference kernel.  The cache is keyed on the parameters' storage and version
         counters, which in-place writes through `.data` (`p.data.copy_()`: EMA weight swaps, manual weight
         loading) do NOT advance — call this after such an update.  Loading a state dict, `.to()` / `.cuda()` /
         `.half()` and `train()` invalidate it themselves."""
         object.__setattr__(self, "_kernel_cache", None)
+        hit = self.__dict__.get("_wkey_cache")
+        if hit is not None:
+            if hit[2] == id(self):
+                self._drop_weights_key(hit[1])
+            object.__setattr__(self, "_wkey_cache", None)
 
     def _load_from_state_dict(self, *args, **kwargs):
         self.invalidate_kernel_cache()
@@ -166,24 +210,26 @@ class SignalConv2D(torch.nn.Module):
             act, torch.nn.ReLU) else None
         corr, up, down = self.corr, self.strides_up[0], self.strides_down[0]
         odd = all(s % 2 == 1 for s in self.kernel_support)
+        wkey = self._inference_weights_key() if x.is_cuda else 0
         if corr and up != 1:
             if not odd:
                 self._check_implemented_fail()
             corr, kernel = False, kernel.flip(0, 1)            # signal_conv.py:875-880
+            wkey = wkey | (1 << 62) if wkey else 0
         gdn = self._fusable_gdn(act, x, kernel, corr, up, down)
         if gdn is not None:
             # GDN / IGDN as the activation (signal_conv.py:948-950 applying gdn.py:371-421): one kernel where the
             # convolution kernel that takes the layer can (functional.conv2d_gdn), else the GDN kernel on its output
             prepared = act._prepared_params(gdn[0], gdn[1], x.dtype)
             y, done = functional.conv2d_gdn(x, kernel, self._bias_value(), down if corr else up, not corr, prepared,
-                                            act.inverse)
+                                            act.inverse, weights_key=wkey)
             if not done:
                 y = functional.gdn_forward(y, gdn[0], gdn[1], act.inverse, False, 1.0, 1.0, prepared=prepared)
         else:
             if corr:
-                y = functional.conv2d_down(x, kernel, self._bias_value(), down, fused)
+                y = functional.conv2d_down(x, kernel, self._bias_value(), down, fused, weights_key=wkey)
             else:
-                y = functional.conv2d_up(x, kernel, self._bias_value(), up, fused)
+                y = functional.conv2d_up(x, kernel, self._bias_value(), up, fused, weights_key=wkey)
                 if down != 1:
                     y = y[:, ::down, ::down]
             if act is not None and fused is None:

@@ -421,6 +421,16 @@ int tfc_conv2d_gdn(const void* x, const void* w, const float* bias, void* y, int
                    int kw, int stride, int up, const tfc_gdn_params* gdn, int inverse, int* fused,
                    void* stream);
 
+/* Inference: the layer's weights do not change between calls.  Every convolution kernel reads the float32 HWIO kernel
+ * as fragments in its own order, packed by a small kernel in front of it (60-90 us, four to nine a model step).
+ * tfc_conv2d_weights_key(key) names the VALUE of `w` for the NEXT tfc_conv2d_* call of the calling thread (key != 0,
+ * chosen by the caller: one number per distinct weight tensor value, never reused for another): that call packs the
+ * fragments once per (key, kernel, geometry) and later calls with the same key reuse them, from any thread or stream.
+ * Without a key every call packs (training; the reference has no such notion: TF folds constants in its graph).
+ * tfc_conv2d_drop_weights(key) releases them (drains the device first): when the weights changed or the layer dies. */
+void tfc_conv2d_weights_key(uint64_t key);
+int tfc_conv2d_drop_weights(uint64_t key);
+
 /* Weight gradient of either direction (the reference relies on TF autodiff of
  * signal_conv.py:663-690 / 778-847).  G[t][ca][cb] = sum_{n,q} A[n, q*stride + t - k/2, ca] *
  * B[n, q, cb] with zeros outside A; q runs over B's grid.

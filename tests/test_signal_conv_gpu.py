@@ -431,3 +431,47 @@ def test_image_side_layer_applies_its_gdn_itself(hw, batch):
     tol = want.float().abs() * 2.0 ** -7 + 1e-6
     assert bool((err <= tol).all()), float((err - tol).max())
     assert float(want.float().abs().max()) > 0.1
+
+
+def test_keyed_weights_are_packed_once_per_value():
+    """tfc_conv2d_weights_key (include/tfc_hip.h): the fragments of a keyed weight value are packed on the first call and
+    reused — shown by overwriting the float32 kernel behind the library's back: the keyed call keeps the old value's
+    output until the key is dropped; an unkeyed call always sees the tensor.  The layer keys its kernel by the
+    parameters' version counters, so an in-place update under no_grad is a new value."""
+    from compression_amd import _lib, layers
+    from compression_amd.layers import conv2d_down, conv2d_up
+    torch.manual_seed(11)
+    lib = _lib.lib()
+    key = (1 << 40) + 12345
+    for fn, shape, kshape, stride in ((conv2d_down, (2, 32, 64, 192), (5, 5, 192, 192), 2),
+                                      (conv2d_up, (2, 16, 32, 192), (5, 5, 192, 3), 2),
+                                      (conv2d_down, (1, 64, 128, 3), (5, 5, 3, 192), 2)):
+        x = torch.randn(shape, device="cuda").to(torch.bfloat16)
+        w1 = torch.randn(kshape, device="cuda") / 30
+        w2 = torch.randn(kshape, device="cuda") / 30
+        w = w1.clone()
+        y1 = fn(x, w, None, stride)
+        y2 = fn(x, w2, None, stride)
+        assert not torch.equal(y1, y2)
+        assert torch.equal(fn(x, w, None, stride, weights_key=key), y1)
+        w.copy_(w2)
+        torch.cuda.synchronize()
+        assert torch.equal(fn(x, w, None, stride, weights_key=key), y1)       # the kept fragments
+        assert torch.equal(fn(x, w, None, stride), y2)                        # no key: packed from the tensor
+        assert lib.tfc_conv2d_drop_weights(key) == 0
+        assert torch.equal(fn(x, w, None, stride, weights_key=key), y2)
+        assert lib.tfc_conv2d_drop_weights(key) == 0
+    conv = layers.SignalConv2D(192, (5, 5), corr=True, strides_down=2, padding="same_zeros", in_channels=192,
+                               use_bias=True).cuda()
+    x = torch.randn(2, 32, 64, 192, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        conv.build(192, x.device)
+        a, b = conv(x), conv(x)
+        assert torch.equal(a, b) and conv._inference_weights_key() != 0
+        first = conv._inference_weights_key()
+        for p in conv.parameters():
+            p.mul_(2.0)
+        c = conv(x)
+        assert conv._inference_weights_key() != first
+        want = conv2d_down(x, conv.kernel, conv.bias, 2)
+        assert torch.equal(c, want) and not torch.equal(c, a)
