@@ -427,6 +427,8 @@ def test_image_side_layer_applies_its_gdn_itself(hw, batch):
         assert n.value == (0 if fused else 1)
         want = gdn(plain(x))
     assert y.shape == want.shape == (batch, (hw[0] + 1) // 2, hw[1] // 2, 192)
+    if fused:
+        assert torch.equal(y, want)       # bias and beta are added to the finished sums, rounding as in the two kernels
     err = (y.float() - want.float()).abs()
     tol = want.float().abs() * 2.0 ** -7 + 1e-6
     assert bool((err <= tol).all()), float((err - tol).max())
