@@ -87,6 +87,7 @@ struct ConvGeom {
   // 0 none, 1 y / (beta + gamma^T |y|), 2 y * (beta + gamma^T |y|); the prepared bfloat16 image of tfc_gdn_params
   int gdn;
   const void* gdn_image;
+  int xcd;                  // 1: the third-generation kernel's workgroups take their blocks in XCD order (xcd_order)
 };
 
 // Third-generation kernel: a workgroup computes an 8 x 32 block of low-resolution output pixels of ONE image
@@ -115,6 +116,27 @@ template <> struct ConvTraits<float> {
 // lane (i = lane & 31, h = lane >> 5), element e (0..7): K offset 8h + e of step ks,
 // output column group*tiles*32 + 32 t + i.
 // ---------------------------------------------------------------------------
+// Workgroup -> work item, XCD-aware.  The dispatcher hands consecutive workgroup ids to the 8 XCDs in turn, each with
+// its own L2: with work item = workgroup id, neighbouring blocks of an image — which read the same halo rows — run on
+// different XCDs and each fetches its own copy.  xcd_order gives XCD x the x-th contiguous eighth of the items instead
+// (a bijection for any count), so the blocks an XCD runs at one time are neighbours.  `on` = 0: the identity.
+// Measured at the C4 shapes (same box, alternating): the third-generation kernel's transposed layers 8.05-8.14 -> 7.92-7.96
+// ms (192x128 input) and 0.64 -> 0.61 ms (48x32); the second-generation stride-2 layers 6.79 -> 6.96 ms: only the third
+// generation uses it.
+constexpr unsigned int kXcds = 8;
+__device__ inline unsigned int xcd_order(unsigned int id, unsigned int count, int on) {
+  if (!on || count < 2 * kXcds) return id;
+  const unsigned int x = id % kXcds, k = id / kXcds;
+  const unsigned int per = count / kXcds, extra = count % kXcds;
+  return x * per + (x < extra ? x : extra) + k;
+}
+
+// (TFC_CONV_XCD=0 in the environment: workgroup id = work item, for same-box comparisons)
+inline int xcd_blocks() {
+  static const int on = [] { const char* e = std::getenv("TFC_CONV_XCD"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 struct PackGeom {
   int kh, kw, Cin_real, Cout, su, up;
   int Uy, Ux, dmax_y, dmax_x;
@@ -493,6 +515,7 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int h = lane >> 5;
+  // (workgroups in XCD order, xcd_order, were measured on this kernel: 6.79 -> 6.96 ms for the 384x256 stride-2 layer)
   const int group = blockIdx.x % c.groups;
   const long long pblock = blockIdx.x / c.groups;
   const long long M = c.N * c.OHq * c.OWq;
@@ -865,7 +888,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   // steps and its output stores drain under the next item's first ones (a workgroup per block paid ~6 us of
   // exposed prologue + epilogue per 25-50 us of K loop, with every CU in that phase at the same time) ----
   const long long nblk = c.N * d.BYn * d.BXn;
-  const int W = gridDim.x, w = blockIdx.x;
+  const int W = gridDim.x, w = static_cast<int>(xcd_order(blockIdx.x, gridDim.x, c.xcd));
   const long long nitems = w < nblk ? ((nblk - w + W - 1) / W) * d.gcount : 0;
   if (nitems == 0) return;
 
@@ -2463,7 +2486,7 @@ __global__ void __launch_bounds__(512, 2) conv_up_phase_kernel(const __bf16* x, 
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, gq = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bxn = (g.W + 31) / 32, byn = (g.H + kPhaseRows - 1) / kPhaseRows;
-  long long b = blockIdx.x;
+  long long b = blockIdx.x;                          // (blocks in XCD order, xcd_order: measured level, 1.17-1.22 ms)
   const int bx = static_cast<int>(b % bxn); b /= bxn;
   const int by = static_cast<int>(b % byn);
   const long long img = b / byn;
@@ -2753,6 +2776,7 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
     if (rc >= 0) return rc;
   }
   ConvGeom c{};
+  c.xcd = xcd_blocks();
   PackGeom g{};
   g.kh = kh; g.kw = kw; g.Cin_real = static_cast<int>(cin); g.Cout = static_cast<int>(cout);
   g.up = up; g.su = up ? stride : 1;
