@@ -477,3 +477,32 @@ def test_keyed_weights_are_packed_once_per_value():
         assert conv._inference_weights_key() != first
         want = conv2d_down(x, conv.kernel, conv.bias, 2)
         assert torch.equal(c, want) and not torch.equal(c, a)
+
+
+@pytest.mark.parametrize("label,shape,kshape,stride,up", [
+    ("analysis 9x9 3->192 /4", (2, 24, 128, 3), (9, 9, 3, 192), 4, False),
+    ("analysis 5x5 3->192 /2", (2, 14, 64, 3), (5, 5, 3, 192), 2, False),
+    ("synthesis 9x9 192->3 x4", (2, 11, 37, 192), (9, 9, 192, 3), 4, True),
+    ("synthesis 5x5 192->3 x2", (2, 9, 40, 192), (5, 5, 192, 3), 2, True),
+])
+@pytest.mark.parametrize("activation", [None, "relu"])
+def test_image_side_kernels_bias_and_relu_against_scipy(label, shape, kshape, stride, up, activation):
+    """The image-side kernels' own epilogues (conv_image_direct_kernel, conv_up_phase_kernel): bias per output channel
+    and the fused ReLU (signal_conv.py:940-950), against the scipy oracle with small integers — every sum exact in
+    float32, the only rounding the output's."""
+    from compression_amd.layers import conv2d_down, conv2d_up
+    rng = np.random.default_rng(len(label) + (7 if activation else 0))
+    x = rng.integers(0, 8, shape).astype(np.float32)
+    ker = rng.integers(-3, 4, kshape).astype(np.float32)
+    bias = rng.integers(-20, 21, kshape[-1]).astype(np.float32)
+    want = scipy_same_zeros(x, ker, stride, up) + bias
+    if activation == "relu":
+        want = np.maximum(want, 0.0)
+    fn = conv2d_up if up else conv2d_down
+    y = fn(torch.from_numpy(x).bfloat16().cuda(), torch.from_numpy(ker), torch.from_numpy(bias), stride,
+           activation).float().cpu().numpy()
+    assert y.shape == want.shape, label
+    tol = 2.0 ** -8
+    assert np.max(np.abs(y - want) - tol * np.abs(want)) <= 0.51 * tol, label
+    if activation == "relu":
+        assert (y >= 0).all() and (want == 0).any()
