@@ -1336,7 +1336,12 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
   // the batch it is coded in.
   // (small stride-2 maps — bls2017's 64x64 -> 32x32 at 512 images: 1.37 -> 1.26 ms — do not have that problem)
   const bool small_down = !g.up && c.sd == 2 && c.OWq * c.OHq <= 4096;
-  if (conv3_gen() < 4 && !(g.up && c.su == 2) && !small_down) return -1;
+  // Since its workgroups take their blocks in XCD order (xcd_order: neighbouring blocks' patches meet in one L2) it is
+  // ahead on the wide stride-2 maps too: 6.87-6.98 -> 6.32-6.37 ms at 384x256, 1.73-1.76 -> 1.57-1.61 at 192x128 (same
+  // box, alternating; TFC_CONV_DOWN3=0 keeps those on the second generation).
+  static const bool down3 = [] { const char* e = std::getenv("TFC_CONV_DOWN3"); return !(e && e[0] == '0'); }();
+  const bool wide_down = down3 && !g.up && c.sd == 2 && c.xcd;
+  if (conv3_gen() < 4 && !(g.up && c.su == 2) && !small_down && !wide_down) return -1;
   {
     const int bxn = (c.OWq + 31) / 32, byn = (c.OHq + 7) / 8;
     if (static_cast<double>(c.OWq) * c.OHq < 0.85 * (bxn * 32.0 * byn * 8.0)) return -1;   // blocks mostly outside the map
