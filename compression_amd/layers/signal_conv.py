@@ -239,12 +239,12 @@ class SignalConv2D(torch.nn.Module):
     # GDN / IGDN as the activation inside the convolution kernel (functional.conv2d_gdn): True / False, or None = by the
     # size of the layer's output (TFC_CONV_GDN=1 / 0 in the environment set it; unset = None).  Measured with steps in
     # flight (profiles/r04_notes.md): on bls2017 at 512 x 256x256 (outputs of 0.2 - 0.8 GB) the fused layers take
-    # 9.5 -> 8.4 ms per step; on bmshj2018 at 128 x 768x512 fusing ALL layers saves 0.6 ms of a lone step's 87 and
-    # costs 1.5 ms of 36.5 per step in flight — there the separate GDN kernel on a 4.8 GB map (bound by HBM) runs
-    # beside other steps' convolutions (bound by the matrix cores), and the fused epilogue keeps a CU's matrix cores
-    # waiting at its barriers.  Hence the limit on the output's size, TFC_CONV_GDN_MAX_MB.
+    # 9.5 -> 8.4 ms per step on one box, 8.78 -> 8.63 on another; on bmshj2018 at 128 x 768x512, whose 1.2 and 4.8 GB
+    # maps are HBM-bound GDN launches of 0.55 and 2.2 ms, the step is level whether none, the small or all layers fuse
+    # (four same-box comparisons), and a lone step wins 0.6 ms.  Default: no limit (TFC_CONV_GDN_MAX_MB = 0) — a model
+    # step then has no GDN launches behind third-generation convolutions; a limit in MB restores the by-size rule.
     fuse_gdn_activation = {"": None, "0": False}.get(os.environ.get("TFC_CONV_GDN", ""), True)
-    fuse_gdn_max_bytes = int(os.environ.get("TFC_CONV_GDN_MAX_MB", "1024")) << 20
+    fuse_gdn_max_bytes = int(os.environ.get("TFC_CONV_GDN_MAX_MB", "0")) << 20
     # The image-side layer (three input channels) is different: its time is its output's HBM traffic, not the matrix
     # cores, and conv_image_gdn_kernel writes the normalised activations without the round trip (bmshj2018's first
     # layer at 128 x 768x512: 1.83 + 2.2 ms as two kernels).  On unless TFC_CONV_GDN_IMAGE=0.
@@ -258,7 +258,8 @@ class SignalConv2D(torch.nn.Module):
         wanted = self.fuse_gdn_activation
         if wanted is None:
             scale = (1.0 / down if corr else float(up)) ** 2
-            wanted = x.shape[0] * x.shape[1] * x.shape[2] * scale * kernel.shape[-1] * 2 <= self.fuse_gdn_max_bytes
+            wanted = self.fuse_gdn_max_bytes <= 0 or \
+                x.shape[0] * x.shape[1] * x.shape[2] * scale * kernel.shape[-1] * 2 <= self.fuse_gdn_max_bytes
         if not (wanted or image_side) or not isinstance(act, GDN) or torch.is_grad_enabled() \
                 or not x.is_cuda or x.dtype != torch.bfloat16:
             return None
