@@ -9,17 +9,18 @@ HBM: CreateRangeEncoder -> EntropyEncodeChannel -> EntropyEncodeFinalize ->
 CreateRangeDecoder -> EntropyDecodeChannel -> EntropyDecodeFinalize, all through
 the C ABI (libtfc_hip.so).  Prints ONE JSON line on rank 0.
 
-Steps are independent batches, so `--inflight D` (default 32) of them are kept in flight, each on
-its own HIP stream, all enqueued by ONE host thread through the library's stream-ordered path
-(throughput-mode handles: one code stream per lane, range errors deferred, finalize on the device, the
-decoder reads the encoder's device-resident strings): a 512-stream step is 8 waves, so the chip only
-fills with many steps resident at once.  Every slot in flight codes its own seeded tensor.  The
-timed region contains EXACTLY `--steps` complete steps; `serial` in the output is one step at a time
-with latency-mode handles (one wave per stream).  After the timed region every step's decoded tensor
-is compared with its input, and slot 0's bytes with the CPU reference's bytes (sha256 over all 512
-streams).
+Steps are independent batches, so they go to the GPU in groups of `--inflight` (default 20, the headline's FIXED
+operating point: more steps are more groups of 20, not larger groups) as one launch per stage, all enqueued by ONE
+host thread through the library's stream-ordered path (throughput-mode handles: one code stream per lane, range
+errors deferred, finalize on the device, the decoder reads the encoder's device-resident strings): a 512-stream
+step is 8 waves, so the chip only fills with many steps resident at once.  Every slot of a group codes its own seeded
+tensor.  The timed region contains EXACTLY `--steps` complete steps; `single_batch` in the output is one step at a
+time (BASELINE config 2 as literally written), `saturation` the rate at 1 ... 128 batches per group.  After the timed
+region every step's decoded tensor is compared with its input, and the bytes of EVERY distinct input with the CPU
+reference's bytes (sha256 over all 512 streams of each).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...            (no launcher around it: starts the N ranks itself, fails without N devices)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: the batch dimension shards (independent code streams), so every rank
@@ -36,7 +37,8 @@ The same line carries, as sub-objects (N = 1 only; `--no-extras` drops them):
                 compress + decompress, several steps in flight on ordinary streams (compression_amd/pipeline.py),
                 every image's strings compared with the CPU reference coder on the model's own symbols;
   conv          SignalConv2D TFLOP/s per layer shape of config 4;
-  gdn_fwd       BASELINE config 3.
+  saturation    batches per launch group 1, 2, 4, 8, 20, 64, 128 -> Mpixels/s, kernel times, algorithmic GB/s;
+  gdn_fwd       BASELINE config 3, cold (rotating tensors): GDN / IGDN, forward / backward, (1, 1) and (2, 1/2).
 """
 from __future__ import annotations
 
@@ -187,70 +189,107 @@ def escape_share(lookup, value_t):
     return float(((value_t < 0) | (value_t >= lim)).float().mean().item())
 
 
+GDN_ROTATE = 4      # input / output pairs a timed loop rotates over: 4 x (101 + 101 MB) = 805 MB, the Infinity Cache is 256 MiB
+
+
 def gdn_forward_bandwidth(device, steps=20):
-    """BASELINE config 3 (second half of the metric): GDN forward on
-    256 x 192 x 32 x 32 bf16 (NHWC [262144, 192]); algorithmic bytes = read x + write y."""
-    from compression_amd.layers import functional, gdn_forward
+    """BASELINE config 3 (second half of the metric): GDN and IGDN, forward and backward, (alpha, epsilon) = (1, 1) and
+    (2, 1/2), on 256 x 192 x 32 x 32 bf16 (NHWC [262144, 192]).  Algorithmic bytes: forward read x + write y; backward
+    read x, g + write dx.  COLD numbers: every timed loop rotates over GDN_ROTATE distinct input tensors and as many
+    distinct outputs (kept alive, so the allocator hands out different blocks), 805 MB per rotation against 256 MiB of
+    Infinity Cache — no launch can find its input (or the lines it writes) in a cache; `warm` is the old measurement
+    (one input, 20 launches back to back: its 201 MB working set fits the Infinity Cache) for comparison."""
+    from compression_amd.layers import functional, gdn_backward, gdn_forward
     torch.manual_seed(3)
     C, M = 192, 256 * 32 * 32
-    x = torch.randn(M, C, device=device).bfloat16()
+    xs = [torch.randn(M, C, device=device).bfloat16() for _ in range(GDN_ROTATE)]
+    gs = [torch.randn(M, C, device=device).bfloat16() for _ in range(GDN_ROTATE)]
     beta = (1 + 0.1 * torch.rand(C)).to(device)
     gamma = (0.1 * torch.eye(C) + 0.01 * torch.rand(C, C)).to(device)
     # inference form: the kernels' image of (beta, gamma) is prepared once (tfc_gdn_params_create), every call is
     # one launch of the forward kernel
     prepared = functional.GDNPrepared(beta, gamma, torch.bfloat16)
-    for _ in range(3):
-        y = gdn_forward(x, beta, gamma, prepared=prepared)
-    torch.cuda.synchronize()
-    # (a) HIP events over the timed region, on the launch stream: `steps` launches back to back
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        y = gdn_forward(x, beta, gamma, prepared=prepared)
-    e1.record()
-    e1.synchronize()
-    avg_ms = e0.elapsed_time(e1) / steps
-    # (b) the library's own timers: an event pair around every single launch (includes the launch latency)
+    nbytes = 2 * xs[0].numel() * xs[0].element_size()
+    bwd_bytes = 3 * xs[0].numel() * xs[0].element_size()
+
+    def fwd_ms(inverse, alpha, epsilon, rotate):
+        ys = [None] * GDN_ROTATE
+        call = lambda k: gdn_forward(xs[k % rotate], beta, gamma, inverse=inverse, alpha=alpha, epsilon=epsilon, prepared=prepared)
+        for k in range(GDN_ROTATE):
+            ys[k] = call(k)
+        torch.cuda.synchronize()
+        # HIP events over the timed region, on the launch stream: `steps` launches back to back
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(steps):
+            ys[k % rotate] = call(k)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    def bwd_ms(inverse, alpha, epsilon):
+        keep = [None] * GDN_ROTATE
+        for k in range(GDN_ROTATE):
+            keep[k] = gdn_backward(xs[k], gs[k], beta, gamma, inverse=inverse, alpha=alpha, epsilon=epsilon)
+        torch.cuda.synchronize()
+        _lib.lib().tfc_profile_enable(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(steps):
+            keep[k % GDN_ROTATE] = gdn_backward(xs[k % GDN_ROTATE], gs[k % GDN_ROTATE], beta, gamma,
+                                                inverse=inverse, alpha=alpha, epsilon=epsilon)
+        e1.record()
+        e1.synchronize()
+        passes = {}
+        for name in ("gdn_backward_fused", "gdn_backward_t", "gdn_backward_dx", "gdn_backward_params"):
+            pms, pn = profile_query(name)
+            if pn:
+                passes[name] = round(pms / pn, 4)
+        _lib.lib().tfc_profile_enable(0)
+        # (the library's per-launch event pairs serialise the launches; their sum is the kernels' own time)
+        return sum(passes.values()), passes, e0.elapsed_time(e1) / steps
+
+    variants = {}
+    for name, inverse, alpha, epsilon in (("gdn", False, 1, 1), ("igdn", True, 1, 1),
+                                          ("gdn_alpha2_eps0.5", False, 2, 0.5), ("igdn_alpha2_eps0.5", True, 2, 0.5)):
+        cold = fwd_ms(inverse, alpha, epsilon, GDN_ROTATE)
+        warm = fwd_ms(inverse, alpha, epsilon, 1)
+        kms, passes, loop_ms = bwd_ms(inverse, alpha, epsilon)
+        variants[name] = {
+            "forward": {"kernel_ms": round(cold, 4), "achieved": round(nbytes / 1e6 / cold, 1),
+                        "frac": round(nbytes / 1e6 / cold / HBM_PEAK_GBS, 4),
+                        "warm_kernel_ms": round(warm, 4), "warm_achieved": round(nbytes / 1e6 / warm, 1)},
+            "backward": {"kernel_ms": round(kms, 4), "passes_ms": passes, "loop_ms_per_call": round(loop_ms, 4),
+                         "achieved": round(bwd_bytes / 1e6 / kms, 1) if kms else None,
+                         "frac": round(bwd_bytes / 1e6 / kms / HBM_PEAK_GBS, 4) if kms else None}}
+    # (b) the library's own timers for the headline variant: an event pair around every single launch (includes the launch latency)
     _lib.lib().tfc_profile_enable(1)
-    for _ in range(steps):
-        y = gdn_forward(x, beta, gamma, prepared=prepared)
+    ys = [None] * GDN_ROTATE
+    for k in range(steps):
+        ys[k % GDN_ROTATE] = gdn_forward(xs[k % GDN_ROTATE], beta, gamma, prepared=prepared)
     torch.cuda.synchronize()
     ms, n = profile_query("gdn_forward")
     _lib.lib().tfc_profile_enable(0)
-    per_launch_ms = ms / max(n, 1)
-    nbytes = 2 * x.numel() * x.element_size()
-    gbs = nbytes / 1e9 / (avg_ms / 1e3)
-    # backward: x, g in; dx out is the algorithmic minimum (3 tensors).  The fused kernel
-    # (x, g -> T, dx) plus the parameter pass (x, T -> dgamma, dbeta) move 4 + 2 tensors.
-    from compression_amd.layers import gdn_backward
-    g = torch.randn(M, C, device=device).bfloat16()
-    for _ in range(2):
-        gdn_backward(x, g, beta, gamma)
-    torch.cuda.synchronize()
-    _lib.lib().tfc_profile_enable(1)
-    for _ in range(steps):
-        gdn_backward(x, g, beta, gamma)
-    torch.cuda.synchronize()
-    passes = {}
-    for name in ("gdn_backward_fused", "gdn_backward_t", "gdn_backward_dx", "gdn_backward_params"):
-        pms, pn = profile_query(name)
-        if pn:
-            passes[name] = round(pms / pn, 4)
-    _lib.lib().tfc_profile_enable(0)
-    bwd_ms = sum(passes.values())
-    bwd_bytes = 3 * x.numel() * x.element_size()
-    return {"workload": "GDN fwd, [262144, 192] bf16 (= 256x192x32x32), alpha=1, eps=1",
-            "kernel_ms": round(avg_ms, 4), "kernel_ms_single_launch_events": round(per_launch_ms, 4),
+    head = variants["gdn"]
+    return {"workload": "GDN fwd, [262144, 192] bf16 (= 256x192x32x32), alpha=1, eps=1, COLD: rotating over "
+                        f"{GDN_ROTATE} input and {GDN_ROTATE} output tensors (805 MB per rotation > 256 MiB Infinity Cache)",
+            "kernel_ms": head["forward"]["kernel_ms"], "kernel_ms_single_launch_events": round(ms / max(n, 1), 4),
             "timing": f"HIP events around {steps} back-to-back launches on the launch stream (parameters prepared once, "
                       "as the layer does under no_grad); kernel_ms_single_launch_events = an event pair around every launch",
             "algorithmic_bytes": nbytes,
-            "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm",
+            "achieved": head["forward"]["achieved"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": head["forward"]["frac"], "bound": "hbm",
+            "warm": {"kernel_ms": head["forward"]["warm_kernel_ms"], "achieved": head["forward"]["warm_achieved"],
+                     "frac": round(head["forward"]["warm_achieved"] / HBM_PEAK_GBS, 4),
+                     "note": "one input tensor, launches back to back (rounds 1-4 measured this): the 201 MB working set "
+                             "fits the 256 MiB Infinity Cache"},
             "traffic": pmc_traffic("gdn_fwd_bf16_kernel", PMC_PROFILE, GDN_SOURCES),
-            "backward": {"kernel_ms": round(bwd_ms, 4), "passes_ms": passes,
-                         "algorithmic_bytes": bwd_bytes,
-                         "achieved": round(bwd_bytes / 1e9 / (bwd_ms / 1e3), 1) if bwd_ms else None,
-                         "unit": "GB/s"}}
+            "traffic_source": f"stored: profiles/{PMC_PROFILE} (rocprofv3 --pmc passes of this command on these sources; "
+                              "null = taken on other sources)",
+            "backward": dict(head["backward"], algorithmic_bytes=bwd_bytes, unit="GB/s"),
+            "variants": {"note": "all cold (rotating tensors); forward algorithmic bytes = x + y, backward = x + g + dx; "
+                                 "achieved in GB/s, frac of 8 TB/s; backward kernel_ms = sum of its kernels' own times",
+                         **variants}}
 
 
 CODER_SOURCES = ["compression_amd/csrc/range_coder.hip", "compression_amd/csrc/range_lanes.h", "compression_amd/csrc/range_pipe.h",
@@ -352,7 +391,7 @@ def usable_cores():
     return n, (min(n, quota) if quota else n), quota
 
 
-def cpu_baseline(lookup, value, gpu_blob_sha256, gpu_offsets_sha256):
+def cpu_baseline(lookup, slots, slot_shas):
     """Reference coder core (oracle/_ref) or its restatement on the host cores,
     sharded over streams like the reference's ThreadPool::ParallelFor.
     This is the ONLY place bench.py touches oracle/."""
@@ -362,6 +401,7 @@ def cpu_baseline(lookup, value, gpu_blob_sha256, gpu_offsets_sha256):
     # keep this process's own OpenMP / torch worker threads from spinning next to the pool
     torch.set_num_threads(1)
     time.sleep(1.0)
+    value = slots[0].cpu().numpy()
     pixels = value.shape[0] * PIXELS_PER_STREAM
     best = None
     # the usable core count and half of it (SMT siblings): report the faster
@@ -376,11 +416,10 @@ def cpu_baseline(lookup, value, gpu_blob_sha256, gpu_offsets_sha256):
     rt, threads, enc_s, dec_s, total, rt_min = best
     e1, d1, _, _ = lib.bench_roundtrip(lookup, value[:8], threads=1, reps=3)
     one_thread = (8 * PIXELS_PER_STREAM / 1e6) / float(np.median((e1 + d1)[1:]))
-    # the bytes themselves: all streams, compared by hash with what the GPU produced for the same input
-    import hashlib
-    _, cpu_blob, cpu_offs = lib.encode(lookup, value, threads=threads)
-    same = (hashlib.sha256(np.ascontiguousarray(cpu_blob).tobytes()).hexdigest() == gpu_blob_sha256 and
-            hashlib.sha256(np.ascontiguousarray(cpu_offs, np.int64).tobytes()).hexdigest() == gpu_offsets_sha256)
+    # the bytes themselves: all streams of EVERY distinct input of the timed region, compared by hash with what the GPU
+    # produced for the same input
+    compared, identical, total = compare_slots_with_cpu(lib, lookup, slots, slot_shas, threads)
+    same = compared == identical
     return {
         "value": round(pixels / 1e6 / rt, 2), "unit": "Mpixels/s", "cores": threads,
         "kind": lib.kind,
@@ -392,7 +431,9 @@ def cpu_baseline(lookup, value, gpu_blob_sha256, gpu_offsets_sha256):
         "encode_ms": round(1e3 * enc_s, 3), "decode_ms": round(1e3 * dec_s, 3),
         "one_thread_mpixels_s": round(one_thread, 2),
         "bytes_identical_to_gpu": bool(same),
-        "bytes_compared": f"sha256 of the packed blob ({int(total)} bytes, {value.shape[0]} streams) and of its offsets",
+        "slots_compared": compared, "slots_identical": identical,
+        "bytes_compared": f"sha256 of the packed blob and of its offsets, every one of the {compared} distinct inputs of the "
+                          f"timed region ({int(total)} bytes, {compared} x {value.shape[0]} streams)",
     }
 
 
@@ -467,14 +508,14 @@ def calibrate_hyperprior(model, x, index_mean=20.0, index_std=12.0, side_std=3.0
     return hist, share
 
 
-def model_symbols(model, handle, b0, b1):
+def model_symbols(model, handle, b0, b1, em=None):
     """The int32 symbols (and table indexes) the model's coder read for images [b0, b1) of a step — from
     the very tensors the encode call was given (`handle.coder_inputs`), so that the CPU reference codes
     the same symbols, not a recomputation of the transforms."""
     y, flat = handle.coder_inputs
     y = y[b0:b1]
     n = y.shape[0]
-    em = model.entropy_model
+    em = em if em is not None else model.entropy_model
     if flat is not None:
         flat = flat[b0:b1].reshape(n, -1)
         sym = torch.round(y.float()).to(torch.int32).reshape(n, -1) - em.cdf_offset.to(y.device)[flat.long()]
@@ -486,6 +527,27 @@ def model_symbols(model, handle, b0, b1):
     yq = torch.round(y.float()).to(torch.int32)
     sym = yq.reshape(n, -1) - em.cdf_offset.to(y.device).repeat(yq[0].numel() // em.cdf_offset.numel())
     return em.cdf.cpu().numpy(), sym.cpu().numpy(), None
+
+
+def side_strings_check(model, handle, strings, chunk=32):
+    """bmshj2018's SIDE string (the hyper latent z, channel mode on the deep-factorized prior's tables) of every image,
+    byte-compared with the CPU reference coder on the symbols the model coded."""
+    from oracle import oracle
+    lib = oracle.best()
+    _, cores, _ = usable_cores()
+    batch = handle.coder_inputs[0].shape[0]
+    mine = [bytes(s) for s in strings.reshape(-1)]
+    differing = nbytes = symbols = 0
+    for b0 in range(0, batch, chunk):
+        lookup, sym, _ = model_symbols(model, handle, b0, min(b0 + chunk, batch), em=model.side_entropy_model)
+        cpu_strings, _, _ = lib.encode(lookup, sym, threads=cores)
+        dec, ok = lib.decode(lookup, cpu_strings, sym.shape[1], threads=cores)
+        assert ok.all() and (dec == sym).all()
+        differing += sum(a != b for a, b in zip(mine[b0:b0 + len(cpu_strings)], cpu_strings))
+        nbytes += sum(len(c) for c in cpu_strings)
+        symbols += sym.size
+    return {"images_compared": batch, "images_differing": int(differing), "bytes": int(nbytes), "symbols": int(symbols),
+            "bytes_identical_to_gpu": differing == 0}
 
 
 def model_cpu_baseline(model, handle, strings, hw, chunk=32):
@@ -608,7 +670,7 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
 
 
 def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=None,
-                cpu=True, rank=0, world=1, distributed=False, group=1, queue=2):
+                cpu=True, rank=0, world=1, distributed=False, group=1, queue=2, inflight_warmup=0):
     """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5).  `lanes`: the
     pipeline.StepLanes the steps are spread over (made first thing in the process: which hardware queue a stream gets
     depends on what created streams before it, profiles/r03_notes.md); `queue` steps enqueued per lane; `group`
@@ -638,7 +700,8 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
         run = lambda n: run_model_steps(model, x, n, lanes, group=group)
         steps = max(group, steps - steps % group)
         _lib.lib().tfc_set_chip_shared(1)                   # several steps in flight: pipeline.chip_shared()
-        run(max(warmup, len(lanes), 2) * group)
+        # untimed: every lane once (its buffers and streams primed); `inflight_warmup` units for the slow float32 C4
+        run((inflight_warmup or max(warmup, len(lanes), 2)) * group)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -705,6 +768,10 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
                 res["cpu_baseline"] = model_cpu_baseline(model, rec.out[0], strings[0], hw)
                 assert res["cpu_baseline"]["bytes_identical_to_gpu"], (
                     "GPU strings differ from the CPU reference's: %s" % json.dumps(res["cpu_baseline"]))
+                if workload == "bmshj2018":
+                    res["cpu_baseline"]["side_strings"] = side_strings_check(model, rec.out[1], strings[1])
+                    assert res["cpu_baseline"]["side_strings"]["bytes_identical_to_gpu"], (
+                        "GPU side strings differ from the CPU reference's: %s" % json.dumps(res["cpu_baseline"]["side_strings"]))
         del rec
     return res
 
@@ -883,18 +950,104 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
-    # slot 0's bytes, for the comparison with the CPU reference
-    h0 = next(r[0] for r in results if r[4] == 0)
-    strings = tfc.entropy_encode_finalize(h0)
-    blob0 = h0.blob.cpu().numpy()
-    offs0 = h0.offsets.cpu().numpy().astype(np.int64)
-    del strings, results
+    # every distinct input's bytes (sha256 of the packed blob and of its offsets), for the comparison with the CPU reference
+    shas = {}
+    for r in results:
+        if r[4] not in shas:
+            shas[r[4]] = handle_hashes(r[0])
+    del results
     if sink is not None:
         m["host_bytes"] = sink.bytes
     m.update(stages=stages, elapsed=elapsed, elapsed_local=elapsed_local, t_enqueued=t_enqueued, enc_tr=cenc_ms / max(cenc_n, 1), dec_tr=cdec_ms / max(cdec_n, 1),
-             total_bytes=int(offs0[-1]), blob_sha=hashlib.sha256(blob0.tobytes()).hexdigest(),
-             offs_sha=hashlib.sha256(offs0.tobytes()).hexdigest(), slot0=slots[0])
+             total_bytes=shas[0][2], blob_sha=shas[0][0], offs_sha=shas[0][1], slot0=slots[0],
+             slots=slots, slot_shas=[shas[k] for k in sorted(shas)])
     return m
+
+
+def saturation_curve(lookup, lookup_t, device, points, bytes_per_batch, cpu_value=None, distinct=32):
+    """Batches per launch group -> Mpixels/s: the same round trip as the headline (throughput-mode handles, one group =
+    one encode call + one decode call for all its batches, nothing read back), for 1 ... 128 batches of 512 streams per
+    group.  A stream is a strict chain, so a group takes (symbols per stream) x (cycles per chain step) whatever its
+    size until every SIMD holds a chain wave; past that the chip-wide streaming kernels (expansion, parse) bound it.
+    Inputs: `distinct` differently seeded tensors used cyclically (each 100 MB, far beyond L2 / MALL).  Per point: rate,
+    the time of a group, per-kernel times (HIP events of the library around each kernel, summed over the group's
+    launches), the kernel that takes longest and its algorithmic HBM rate."""
+    top = max(points)
+    slots = [sample_symbols_device(lookup, 7000 + k, device) for k in range(min(top, distinct))]
+    symbols = STREAMS * ELEMS
+    alg_dir = 4 * symbols + bytes_per_batch            # one direction of one batch: symbols in + code bytes out (or the mirror)
+    rows = []
+    for nb in points:
+        values = [slots[k % len(slots)] for k in range(nb)]
+        res = step_group(lookup_t, values, "throughput")                 # untimed: primes the pools with this group's buffers
+        torch.cuda.synchronize()
+        for (h, d, dec_r, ok_r), v in zip(res, values):
+            assert bool(ok_r.all()) and torch.equal(dec_r.reshape(STREAMS, ELEMS), v), "decode(encode(x)) != x"
+        del res
+        reps = max(2, min(6, 120 // nb))
+        _lib.lib().tfc_profile_enable(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = step_group(lookup_t, values, "throughput")
+            del res                                                       # handles and tensors go back in stream order
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / reps
+        stages, launches = {}, {}
+        for name in ("enc_expand", "enc_chain", "dec_chain", "dec_parse_next", "dec_parse", "enc_kernel", "dec_kernel"):
+            ms, cnt = profile_query(name)
+            if cnt:
+                stages[name] = ms / reps
+                launches[name] = cnt / reps
+        _lib.lib().tfc_profile_enable(0)
+        # the kernel that takes longest (dec_parse_next rides beside dec_chain: its span is the chain's)
+        kernels = {k: v for k, v in stages.items() if k not in ("enc_kernel", "dec_kernel", "dec_parse_next")}
+        dom = max(kernels, key=kernels.get) if kernels else None
+        mpix = nb * STREAMS * PIXELS_PER_STREAM / 1e6 / sec
+        row = {"batches_per_launch": nb, "streams": nb * STREAMS, "mpixels_s": round(mpix, 1),
+               "ms_per_group": round(1e3 * sec, 3), "ms_per_batch": round(1e3 * sec / nb, 4),
+               "encode_call_ms": round(stages.get("enc_kernel", 0.0), 3), "decode_call_ms": round(stages.get("dec_kernel", 0.0), 3),
+               "kernels_ms": {k: round(v, 3) for k, v in kernels.items()},
+               "launches_per_direction": round(launches.get("enc_kernel", 1)),
+               "dominant_kernel": (dom + "_kernel") if dom else None,
+               "dominant_kernel_algorithmic_gbs": round(nb * alg_dir / 1e9 / (kernels[dom] / 1e3), 1) if dom else None,
+               "path_algorithmic_gbs": round(2 * nb * alg_dir / 1e9 / sec, 1),
+               "path_frac_of_hbm_peak": round(2 * nb * alg_dir / 1e9 / sec / HBM_PEAK_GBS, 4)}
+        if cpu_value:
+            row["speedup_vs_cpu_baseline"] = round(mpix / cpu_value, 2)
+        rows.append(row)
+        torch.cuda.empty_cache()
+    del slots
+    return {"note": "round trip of N batches (N x 512 streams x 49152 symbols) as ONE group: one encode call + one decode call "
+                    "(tfc_encoder_encode_many / tfc_decoder_decode_many; a call is split into several launches where the "
+                    "pipelined kernels' temporaries would pass 6 GB), throughput-mode handles, strings stay in HBM; "
+                    f"{len(rows)} points, each the mean of 2-6 groups after one untimed group; inputs: "
+                    f"{min(top, distinct)} differently seeded tensors used cyclically; every point's decode checked against its input",
+            "algorithmic_bytes_per_batch_and_direction": int(alg_dir),
+            "points": rows}
+
+
+def handle_hashes(h):
+    """(sha256 of the packed blob, sha256 of the int64 offsets, total bytes) of an encoder handle's strings — all its
+    streams."""
+    import hashlib
+    tfc.entropy_encode_finalize(h)
+    blob = h.blob.cpu().numpy()
+    offs = h.offsets.cpu().numpy().astype(np.int64)
+    return hashlib.sha256(blob.tobytes()).hexdigest(), hashlib.sha256(offs.tobytes()).hexdigest(), int(offs[-1])
+
+
+def compare_slots_with_cpu(lib, lookup, slots, shas, threads):
+    """Every distinct input of a run coded by the CPU reference, sha256 of blob and offsets against the GPU's: returns
+    (slots compared, slots identical, bytes compared)."""
+    import hashlib
+    same = total = 0
+    for value_t, (blob_sha, offs_sha, nbytes) in zip(slots, shas):
+        _, cpu_blob, cpu_offs = lib.encode(lookup, value_t.cpu().numpy(), threads=threads)
+        same += int(hashlib.sha256(np.ascontiguousarray(cpu_blob).tobytes()).hexdigest() == blob_sha and
+                    hashlib.sha256(np.ascontiguousarray(cpu_offs, np.int64).tobytes()).hexdigest() == offs_sha)
+        total += nbytes
+    return len(shas), same, total
 
 
 def escape_object(args, lookup, lookup_t, device, fraction, cpu_value, fold=False):
@@ -919,16 +1072,64 @@ def escape_object(args, lookup, lookup_t, device, fraction, cpu_value, fold=Fals
         enc, dec, total, ok = lib.bench_roundtrip(lookup, value_h, threads=cores, reps=4)
         assert ok
         rt = float(np.median((enc + dec)[1:]))
-        _, cpu_blob, cpu_offs = lib.encode(lookup, value_h, threads=cores)
-        same = (hashlib.sha256(np.ascontiguousarray(cpu_blob).tobytes()).hexdigest() == m["blob_sha"] and
-                hashlib.sha256(np.ascontiguousarray(cpu_offs, np.int64).tobytes()).hexdigest() == m["offs_sha"])
+        compared, identical, nbytes = compare_slots_with_cpu(lib, lookup, m["slots"], m["slot_shas"], cores)
+        same = compared == identical
         cpu_mpix = STREAMS * PIXELS_PER_STREAM / 1e6 / rt
         obj["cpu_baseline"] = {"value": round(cpu_mpix, 2), "unit": "Mpixels/s", "cores": cores, "kind": lib.kind,
                                "sample": "the same 512-stream batch (slot 0), 4 repetitions (first discarded)"}
         obj["speedup_vs_cpu_baseline"] = round(value / cpu_mpix, 2)
         obj["bytes_identical_to_gpu"] = bool(same)
+        obj["slots_compared"], obj["slots_identical"] = compared, identical
         assert same, "GPU bytes differ from the CPU reference's (escape run)"
     return obj
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def spawn_command(args_gpus, argv, port):
+    """The command `python bench.py --gpus N ...` re-executes itself as when no launcher has set WORLD_SIZE: the
+    driver's own multi-GPU form (one rank per GPU of one node, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_spawn(args):
+    """`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is not a rank, it STARTS the N ranks
+    (and fails loudly when the node has fewer than N devices).  Returns True when it did (the ranks' output is this
+    process's output, their exit status its own)."""
+    if "WORLD_SIZE" in os.environ or args.gpus <= 1:
+        return False
+    import subprocess
+    if not args.spawn_check:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {have} HIP device(s) visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    rc = subprocess.run(spawn_command(args.gpus, sys.argv[1:], free_port()), env=env).returncode
+    if rc:
+        raise SystemExit(rc)
+    return True
+
+
+def spawn_check(world, rank):
+    """The ranks of `--spawn-check`: rendezvous over gloo (no device), count each other, rank 0 prints one line."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = torch.zeros(world, dtype=torch.int64)
+    seen[rank] = 1
+    dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "world": world, "ranks_seen": int(seen.sum()),
+                          "launcher": "torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1"}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -939,8 +1140,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline measurement (no single_batch / escapes / models / conv sub-objects)")
-    ap.add_argument("--inflight", type=int, default=64,
-                    help="independent steps per launch group (one host thread); 1 = serial")
+    ap.add_argument("--inflight", type=int, default=20,
+                    help="batches per launch group (one host thread; 1 = one batch at a time): the headline's operating point. "
+                         "FIXED at 20 — `value` is the rate of groups of 20 batches whatever --steps is (fewer steps than "
+                         "that: one smaller group); the `saturation` sub-object has the curve 1 ... 128")
     ap.add_argument("--escape-fraction", type=float, default=0.0)
     ap.add_argument("--workload", default="c2", choices=["c2", "bls2017", "bmshj2018"],
                     help="c2 (default, the headline): coder round trip; bls2017 / bmshj2018: "
@@ -956,11 +1159,24 @@ def main():
     ap.add_argument("--model-queue", type=int, default=2, help="model steps enqueued per stream (--model-depth streams)")
     ap.add_argument("--model-steps", type=int, default=0,
                     help="timed steps of the `models` sub-objects (0: 32, and 128 where 8 batches share a coder launch)")
+    ap.add_argument("--saturation", default="1,2,4,8,20,64,128",
+                    help="batches per launch of the `saturation` sub-object (comma separated; empty: leave it out)")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="no measurement: start the --gpus ranks exactly as a measurement would, rendezvous over gloo on "
+                         "the host, and print {world, ranks} (the CPU-tier test of the launch path)")
     args = ap.parse_args()
 
+    if maybe_spawn(args):
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.spawn_check:
+        return spawn_check(world, rank)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs HIP device {local_rank}; {torch.cuda.device_count()} visible")
     distributed = world > 1
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -1054,8 +1270,11 @@ def main():
                 "distinct_inputs": inflight,
                 "library_mode": "TFC_MODE_THROUGHPUT handles (one code stream per lane), deferred errors, "
                                 "device finalize" if lanes else "TFC_MODE_LATENCY handles (one wave per stream)",
-                "value_depends_on_steps": "a launch takes the same time for 1 ... ~128 batches (one wave per SIMD), so "
-                                          "`value` grows with --steps; `single_batch` is one batch at a time",
+                "operating_point": f"{inflight} batches (= {inflight * STREAMS} streams, {inflight * STREAMS // 64} chain waves) per "
+                                   "launch group — fixed by --inflight (default 20), NOT by --steps: more steps are more "
+                                   "groups of the same size.  A stream is a strict chain, so a group takes the same time for "
+                                   "1 ... ~100 batches; `saturation` gives the rate at 1, 2, 4, 8, 20, 64, 128 batches per "
+                                   "group and `single_batch` BASELINE config 2 as literally written (one batch at a time)",
             },
             "bits_per_pixel": round(8.0 * total_bytes / (STREAMS * PIXELS_PER_STREAM), 5),
             "bits_per_symbol": round(8.0 * total_bytes / symbols, 4),
@@ -1088,8 +1307,9 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic(dom_symbol, PMC_PROFILE, CODER_SOURCES, jobs_per_launch),
-                "traffic_source": f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                  "this command; 2*FETCH + WRITE, KiB -> bytes); null = taken on other sources",
+                "traffic_source": f"stored: profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "this command on these kernel sources, taken by the builder — not measured in this run; "
+                                  "2*FETCH + WRITE, KiB -> bytes); null = taken on other sources",
                 "algorithmic_bytes": int(dom_bytes),
                 "steps_per_launch": jobs_per_launch,
                 "note": "serial chain per stream: bound by the latency of a step's instruction chain at one or two "
@@ -1107,7 +1327,7 @@ def main():
         if world == 1:
             out["gdn_fwd"] = gdn_forward_bandwidth(device)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(lookup, m["slot0"].cpu().numpy(), m["blob_sha"], m["offs_sha"])
+            out["cpu_baseline"] = cpu_baseline(lookup, m["slots"], m["slot_shas"])
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
             out["single_batch"]["latency_mode"]["speedup_vs_cpu_baseline"] = round(
                 out["single_batch"]["latency_mode"]["mpixels_s"] / out["cpu_baseline"]["value"], 2)
@@ -1115,7 +1335,20 @@ def main():
                 out["single_batch"]["throughput_mode"]["speedup_vs_cpu_baseline"] = round(
                     out["single_batch"]["throughput_mode"]["mpixels_s"] / out["cpu_baseline"]["value"], 2)
             assert out["cpu_baseline"]["bytes_identical_to_gpu"], "GPU bytes differ from the CPU reference's"
+        lat = out["single_batch"]["latency_mode"]
+        out["config"]["single_batch"] = (
+            f"BASELINE config 2 as literally written — ONE 512-stream batch at a time, host waits for every step: "
+            f"{lat['mpixels_s']} Mpixels/s ({lat['ms_per_step']} ms per batch"
+            + (f", {lat['speedup_vs_cpu_baseline']}x the CPU reference" if "speedup_vs_cpu_baseline" in lat else "")
+            + f"); the headline `value` is {inflight} such batches per launch group")
+        bytes_per_batch = int(total_bytes)
         del m
+        if extras and args.saturation:
+            points = sorted({int(v) for v in args.saturation.split(",") if v.strip()})
+            out["saturation"] = saturation_curve(lookup, lookup_t, device, points, bytes_per_batch,
+                                                 out.get("cpu_baseline", {}).get("value"))
+            out["saturation"]["headline_point"] = inflight
+            torch.cuda.empty_cache()
         if extras:
             torch.set_num_threads(1)
             mh = c2_run(args, lookup, lookup_t, device, 1, 0, False, args.escape_fraction, args.steps, args.inflight,
@@ -1147,6 +1380,12 @@ def main():
                 torch.cuda.empty_cache()
                 out["models"]["c1_f32"] = model_bench("bls2017", "f32", device, steps=8, warmup=1, lanes=step_lanes,
                                                       cpu=False, group=1, queue=args.model_queue)
+                torch.cuda.empty_cache()
+                g = model_group(args, "bmshj2018")
+                # (three of the lanes: a float32 step keeps ~25 GB of activations per stream)
+                few = type("Lanes", (), {"lanes": step_lanes.lanes[:3]})()
+                out["models"]["c4_f32"] = model_bench("bmshj2018", "f32", device, steps=2 * g, warmup=1, lanes=few,
+                                                      cpu=False, group=g, queue=1, inflight_warmup=3)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

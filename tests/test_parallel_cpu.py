@@ -57,3 +57,43 @@ def test_gather_encoded_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _run_bench(*argv, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must START two ranks (torch.distributed.run on
+    127.0.0.1) — here over gloo, without devices (`--spawn-check`): both ranks rendezvous and count each other."""
+    import json
+    r = _run_bench("--gpus", "2", "--spawn-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {**line, "spawn_check": True, "world": 2, "ranks_seen": 2}
+
+
+def test_bench_gpus_n_fails_loudly_without_n_devices():
+    """A measurement asked for on more devices than the node has is an error, not a one-GPU number."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this node has two devices")
+    r = _run_bench("--gpus", "2", "--no-extras", timeout=120)
+    assert r.returncode != 0
+    assert "--gpus 2 asked for" in r.stderr
+
+
+def test_bench_rejects_a_world_that_is_not_gpus():
+    """Under a launcher, WORLD_SIZE must be what --gpus says."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--spawn-check"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
