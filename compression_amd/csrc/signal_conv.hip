@@ -220,6 +220,7 @@ struct WeightsCache {
     DevBuf buf;
     hipEvent_t ready = nullptr;
     hipStream_t made_on = nullptr;
+    std::vector<hipStream_t> users;          // other streams whose kernels have read the fragments (a handful)
   };
   std::mutex mu;
   std::map<Key, Entry> entries;
@@ -260,6 +261,8 @@ int packed_weights(int site, std::initializer_list<long long> dims, size_t bytes
     it = c.entries.emplace(k, std::move(e)).first;
   } else if (it->second.made_on != st) {
     TFC_HIP(hipStreamWaitEvent(st, it->second.ready, 0));
+    auto& users = it->second.users;
+    if (std::find(users.begin(), users.end(), st) == users.end()) users.push_back(st);
   }
   *p = it->second.buf.p;
   return 0;
@@ -2842,19 +2845,35 @@ extern "C" void tfc_conv2d_weights_key(uint64_t key) { tfc::t_next_weights_key =
 extern "C" int tfc_conv2d_drop_weights(uint64_t key) {
   tfc::WeightsCache& c = tfc::WeightsCache::get();
   std::lock_guard<std::mutex> lock(c.mu);
-  bool any = false;
-  for (auto it = c.entries.begin(); it != c.entries.end(); ++it) any = any || it->first.key == key;
-  if (!any) return 0;
-  // a kernel on any stream may still read the fragments: the device is drained before their memory goes back
-  TFC_HIP(hipDeviceSynchronize());
+  // A kernel on any stream that used an entry may still read its fragments.  The memory goes back in STREAM order: the
+  // stream the entry was made on waits for an event on every other stream that read it, and the block returns to the
+  // library's cache behind that (DevBuf::release: reusable on that stream at once, on another once its event has
+  // completed).  Nothing here holds the host — model.eval() drops one key per layer.  Only when a reader's stream no
+  // longer takes an event (destroyed by its owner) is that entry's device drained instead.
+  int home = 0;
+  (void)hipGetDevice(&home);
   for (auto it = c.entries.begin(); it != c.entries.end();) {
-    if (it->first.key == key) {
-      (void)hipEventDestroy(it->second.ready);
-      it = c.entries.erase(it);
-    } else {
-      ++it;
+    if (it->first.key != key) { ++it; continue; }
+    tfc::WeightsCache::Entry& e = it->second;
+    if (it->first.dev != home) (void)hipSetDevice(it->first.dev);
+    bool ordered = true;
+    for (hipStream_t s : e.users) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ordered = false; break; }
+      if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(e.made_on, ev, 0) != hipSuccess) ordered = false;
+      (void)hipEventDestroy(ev);
+      if (!ordered) break;
     }
+    if (!ordered) {
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+    }
+    e.buf.touch(e.made_on);
+    (void)hipEventDestroy(e.ready);
+    it = c.entries.erase(it);          // ~DevBuf: release() in the order of made_on
+    if (it == c.entries.end() || it->first.dev != home) (void)hipSetDevice(home);
   }
+  (void)hipSetDevice(home);
   return 0;
 }
 
@@ -2868,7 +2887,10 @@ extern "C" int tfc_conv2d_gdn(const void* x, const void* w, const float* bias, v
                               int64_t n, int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh,
                               int kw, int stride, int up, const tfc_gdn_params* gdn, int inverse, int* fused,
                               void* stream) {
-  if (!gdn || !fused) return tfc::fail("tfc_conv2d_gdn: gdn and fused must not be null");
+  if (!gdn || !fused) {
+    tfc::t_next_weights_key = 0;       // the key named for THIS call must not reach another layer's
+    return tfc::fail("tfc_conv2d_gdn: gdn and fused must not be null");
+  }
   return tfc::conv_entry(x, w, bias, y, dtype, n, h, wd, cin, cout, kh, kw, stride, 0, up, stream, false, gdn, inverse,
                          fused);
 }

@@ -259,15 +259,22 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         if not handles:
             return [], None
         flats = [self._table_indexes(torch.as_tensor(i).to(device)) for i in indexes]
+        if len(flats) != len(handles):
+            raise ValueError(f"decompress_many: one index tensor per handle ({len(flats)} index tensors, {len(handles)} handles)")
         shape = tuple(flats[0].shape)
+        if any(tuple(f.shape) != shape for f in flats):
+            raise ValueError("decompress_many: all index tensors must have the same shape")
         decode_shape = shape[len(shape) - self.coding_rank:] if self.coding_rank else ()
         cdf_offset = self._device_offsets(device)
         decoders = gen_ops.create_range_decoders(handles, self.cdf, mode="throughput")
         n = len(decoders)
-        if tuple(decoders[0].shape) + tuple(decode_shape) != shape:
-            raise ValueError(
-                "'index' shape should match 'handle' shape + 'shape': "
-                f"index.shape={list(shape)}, handle.shape={list(decoders[0].shape)}, shape={list(decode_shape)}")
+        for d in decoders:
+            if d.streams == 0:
+                raise ValueError(f"`handle` is empty: handle.shape={list(d.shape)}")
+            if tuple(d.shape) + tuple(decode_shape) != shape:
+                raise ValueError(
+                    "'index' shape should match 'handle' shape + 'shape': "
+                    f"index.shape={list(shape)}, handle.shape={list(d.shape)}, shape={list(decode_shape)}")
         if self.fused and self.bottleneck_dtype in _DTYPE_CODE:
             outs = [torch.empty(shape, dtype=self.bottleneck_dtype, device=device) for _ in range(n)]
             elems = flats[0].numel() // decoders[0].streams

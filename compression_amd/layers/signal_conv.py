@@ -140,11 +140,27 @@ class SignalConv2D(torch.nn.Module):
     # One number per distinct value of a layer's weights (include/tfc_hip.h, tfc_conv2d_weights_key): the library keeps
     # the kernels' packed fragments of a keyed value between calls instead of packing them in front of every launch.
     _WEIGHT_KEYS = itertools.count(1)
+    # Keyed (kept) packed weights under no_grad: on unless TFC_CONV_KEYED_WEIGHTS=0, or per layer / per class by
+    # assigning `keyed_weights = False` (every call then packs its fragments from the tensor it is given, as training
+    # does).  WHAT THE KEY SEES: the parameters' storage address, their autograd version counter and the layer's
+    # `weights_generation`.  An in-place write through `.data` (`p.data.copy_(ema)`, manual weight loading) advances
+    # neither address nor version — after such a write call `weights_changed()` (bumps the generation; the old
+    # fragments are released in stream order) or `invalidate_kernel_cache()`.  load_state_dict, .to() / .cuda() /
+    # .half(), train() / eval() do it themselves; optimizer steps and every other autograd-visible in-place op advance
+    # the version counter.
+    keyed_weights = os.environ.get("TFC_CONV_KEYED_WEIGHTS", "1") not in ("", "0")
+    weights_generation = 0
+
+    def weights_changed(self):
+        """Tell the layer its weights were written behind autograd's back (`.data` writes): the kept inference kernel
+        and the library's packed fragments of the old value are dropped."""
+        self.weights_generation = self.weights_generation + 1
+        self.invalidate_kernel_cache()
 
     def _inference_weights_key(self):
         """The key of the kernel's current value, or 0: gradients enabled (the weights are about to change), a kernel
-        given as a tensor / callable (computed per call), or parameters without version counters."""
-        if torch.is_grad_enabled() or self._kernel_given is not None:
+        given as a tensor / callable (computed per call), parameters without version counters, or `keyed_weights` off."""
+        if torch.is_grad_enabled() or self._kernel_given is not None or not self.keyed_weights:
             return 0
         src = (self.kernel_variable,) if self.kernel_variable is not None else (self.kernel_real, self.kernel_imag)
         if any(t is None or not t.is_cuda for t in src):
@@ -152,6 +168,7 @@ class SignalConv2D(torch.nn.Module):
         ident = tuple((t.data_ptr(), _version_of(t)) for t in src) + (str(src[0].device),)
         if any(v is None for _, v in ident[:-1]):
             return 0
+        ident = ident + (self.weights_generation,)
         hit = self.__dict__.get("_wkey_cache")
         if hit is None or hit[0] != ident or hit[2] != id(self):
             if hit is not None and hit[2] == id(self):

@@ -203,6 +203,8 @@ class BMSHJ2018Model(torch.nn.Module):
         """decompress() for the results of compress_many: ([x_hat per batch], [ok_z, ok_y] flags on the device).  Two
         phases like decompress(): all side latents, their hyper-synthesis, then all main latents."""
         packed = list(packed)
+        if any(tuple(p[2:]) != tuple(packed[0][2:]) for p in packed):
+            raise ValueError("decompress_many: all batches must have the same x / y / z shapes")
         z_hats, okz = self.side_entropy_model.decompress_many([p[1] for p in packed], packed[0][4])
         idxs = [self.hyper_synthesis_transform(z_hat)[:, :p[3][0], :p[3][1], :] for z_hat, p in zip(z_hats, packed)]
         y_hats, oky = self.entropy_model.decompress_many([p[0] for p in packed], idxs)

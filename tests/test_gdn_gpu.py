@@ -37,7 +37,16 @@ def test_gdn_f32(C, inverse, rectify, alpha, eps):
     beta, gamma = params(C, 1)
     y = gdn_forward(x.cuda(), beta, gamma, inverse, rectify, alpha, eps).cpu().numpy()
     want = ref_gdn(x.numpy(), beta.numpy(), gamma.numpy(), inverse, rectify, alpha, eps)
-    assert np.max(np.abs(y - want)) <= 1e-5 * max(1.0, np.max(np.abs(want)))
+    err = np.abs(y - want)
+    print(f"gdn_f32 C={C} inverse={inverse} alpha={alpha} eps={eps}: max |y - want| = {err.max():.3e} "
+          f"(max |want| = {np.abs(want).max():.3f})")
+    if not inverse:
+        # GDN proper (BASELINE.json: "within 1e-5 on GDN float outputs"): ABSOLUTE, every element
+        assert err.max() <= 1e-5
+    else:
+        # IGDN multiplies by the norm (outputs up to ~30 on these inputs; one float32 ulp there is 2e-6): 1e-5 per
+        # element, relative to that element where it exceeds 1 — never to the tensor's maximum
+        assert np.max(err / np.maximum(1.0, np.abs(want))) <= 1e-5
 
 
 @pytest.mark.parametrize("C", [64, 192, 256])

@@ -477,6 +477,21 @@ def test_keyed_weights_are_packed_once_per_value():
         assert conv._inference_weights_key() != first
         want = conv2d_down(x, conv.kernel, conv.bias, 2)
         assert torch.equal(c, want) and not torch.equal(c, a)
+        # a write through `.data` advances neither address nor version counter: the layer is told (weights_changed), or
+        # runs with keyed weights off
+        for p in conv.parameters():
+            p.data.mul_(0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(conv(x), c)                                        # documented caveat: the kept fragments
+        conv.weights_changed()
+        d = conv(x)
+        assert torch.equal(d, conv2d_down(x, conv.kernel, conv.bias, 2)) and not torch.equal(d, c)
+        conv.keyed_weights = False
+        assert conv._inference_weights_key() == 0
+        for p in conv.parameters():
+            p.data.mul_(2.0)
+        conv.invalidate_kernel_cache()         # (the rdft kernel cache is keyed the same way)
+        assert torch.equal(conv(x), conv2d_down(x, conv.kernel, conv.bias, 2))
 
 
 @pytest.mark.parametrize("label,shape,kshape,stride,up", [
