@@ -249,6 +249,23 @@ def gdn_forward_bandwidth(device, steps=20):
         # (the library's per-launch event pairs serialise the launches; their sum is the kernels' own time)
         return sum(passes.values()), passes, e0.elapsed_time(e1) / steps
 
+    def copy_ms(rotate):
+        """A plain device copy of the same tensors (torch's elementwise copy kernel: read x, write y — GDN's
+        algorithmic traffic with no arithmetic), timed the same way: the HBM rate this box gives a 2-tensor stream."""
+        ys = [torch.empty_like(xs[0]) for _ in range(GDN_ROTATE)]
+        for k in range(GDN_ROTATE):
+            ys[k].copy_(xs[k % rotate])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(steps):
+            ys[k % rotate].copy_(xs[k % rotate])
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    fwd_ms(False, 1, 1, GDN_ROTATE)           # (clocks and allocator warm before the first figure)
+    copy_cold, copy_warm = copy_ms(GDN_ROTATE), copy_ms(1)
     variants = {}
     for name, inverse, alpha, epsilon in (("gdn", False, 1, 1), ("igdn", True, 1, 1),
                                           ("gdn_alpha2_eps0.5", False, 2, 0.5), ("igdn_alpha2_eps0.5", True, 2, 0.5)):
@@ -283,6 +300,11 @@ def gdn_forward_bandwidth(device, steps=20):
                      "frac": round(head["forward"]["warm_achieved"] / HBM_PEAK_GBS, 4),
                      "note": "one input tensor, launches back to back (rounds 1-4 measured this): the 201 MB working set "
                              "fits the 256 MiB Infinity Cache"},
+            "copy_reference": {"cold_ms": round(copy_cold, 4), "cold_gbs": round(nbytes / 1e6 / copy_cold, 1),
+                               "warm_ms": round(copy_warm, 4), "warm_gbs": round(nbytes / 1e6 / copy_warm, 1),
+                               "frac_of_cold_copy": round(copy_cold / head["forward"]["kernel_ms"], 4),
+                               "note": "torch's device copy of the same tensors, same rotation and timing: what this box "
+                                       "streams for read x + write y with no arithmetic; frac_of_cold_copy = copy time / GDN time"},
             "traffic": pmc_traffic("gdn_fwd_bf16_kernel", PMC_PROFILE, GDN_SOURCES),
             "traffic_source": f"stored: profiles/{PMC_PROFILE} (rocprofv3 --pmc passes of this command on these sources; "
                               "null = taken on other sources)",

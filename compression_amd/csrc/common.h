@@ -182,7 +182,16 @@ struct DevBuf {
     if (p) return hipSuccess;
     SlowCall slow("DevBuf::alloc", __FILE__, __LINE__);
     slow.detail = cap;
-    return mp ? hipMallocFromPoolAsync(&p, cap, mp, s) : hipMallocAsync(&p, cap, s);
+    hipError_t rc = mp ? hipMallocFromPoolAsync(&p, cap, mp, s) : hipMallocAsync(&p, cap, s);
+    if (rc != hipSuccess) {
+      // out of memory with idle blocks of other sizes in the library's own cache: hand those back and ask once more
+      (void)hipGetLastError();
+      p = nullptr;
+      if (BlockCache::get().trim() > 0)
+        rc = mp ? hipMallocFromPoolAsync(&p, cap, mp, s) : hipMallocAsync(&p, cap, s);
+      if (rc != hipSuccess) p = nullptr;
+    }
+    return rc;
   }
   // The library's pool on the current device, created on first use.  A stream-ordered pool hands freed
   // memory back to the driver at the next synchronisation unless its release threshold is raised (every

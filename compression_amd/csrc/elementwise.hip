@@ -62,7 +62,64 @@ __global__ void index_prepare_kernel(const void* idx, int32_t* out, long long n,
   }
 }
 
+// Spatial padding of an NHWC tensor in one pass (the pre-pad of SignalConv2D's `same_reflect` / pre-padded `same_zeros`
+// modes, signal_conv.py:880-893 `tf.pad(outputs, padding, self._pad_mode)`): a thread copies one UNIT of a pixel's
+// channel vector (16 bytes when the vector is a multiple of that, else one element) from the source pixel the mode
+// names — REFLECT mirrors without repeating the edge sample (tf.pad "REFLECT"), CONSTANT writes zeros.
+template <typename Unit>
+__global__ void pad2d_kernel(const Unit* x, Unit* y, int h, int w, long long units, int top, int left, int oh, int ow,
+                             int reflect, long long total) {
+  const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  if (idx >= total) return;
+  const long long u = idx % units;
+  long long rest = idx / units;
+  const int j = static_cast<int>(rest % ow); rest /= ow;
+  const int i = static_cast<int>(rest % oh);
+  const long long n = rest / oh;
+  int si = i - top, sj = j - left;
+  bool inside = si >= 0 && si < h && sj >= 0 && sj < w;
+  if (reflect) {
+    si = si < 0 ? -si : si;
+    si = si >= h ? 2 * (h - 1) - si : si;
+    sj = sj < 0 ? -sj : sj;
+    sj = sj >= w ? 2 * (w - 1) - sj : sj;
+    inside = true;
+  }
+  Unit v{};
+  if (inside) v = x[((n * h + si) * w + sj) * units + u];
+  y[idx] = v;
+}
+
 }  // namespace tfc
+
+extern "C" int tfc_pad2d(const void* x, void* y, int elem_bytes, int64_t n, int64_t h, int64_t w, int64_t c, int top,
+                         int bottom, int left, int right, int reflect, void* stream) {
+  if (elem_bytes != 2 && elem_bytes != 4) return tfc::fail("tfc_pad2d: elements of 2 or 4 bytes");
+  if (top < 0 || bottom < 0 || left < 0 || right < 0) return tfc::fail("tfc_pad2d: paddings must be non-negative");
+  if (reflect && (top >= h || bottom >= h || left >= w || right >= w))
+    return tfc::fail("tfc_pad2d: reflect padding must be smaller than the dimension (tf.pad REFLECT)");
+  if (n <= 0 || c <= 0) return 0;
+  const int64_t oh = h + top + bottom, ow = w + left + right;
+  if (oh <= 0 || ow <= 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  tfc::KernelTimer timer("elementwise", st);
+  const long long row_bytes = static_cast<long long>(c) * elem_bytes;
+  const bool aligned = row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+  const long long units = aligned ? row_bytes / 16 : c;
+  const long long total = n * oh * ow * units;
+  if (total >= (1ll << 31) * 256) return tfc::fail("tfc_pad2d: tensor too large for one launch");
+  const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+#define TFC_PAD_LAUNCH(Unit)                                                                                             \
+  hipLaunchKernelGGL(tfc::pad2d_kernel<Unit>, dim3(blocks), dim3(256), 0, st, static_cast<const Unit*>(x),               \
+                     static_cast<Unit*>(y), static_cast<int>(h), static_cast<int>(w), units, top, left,                  \
+                     static_cast<int>(oh), static_cast<int>(ow), reflect, total)
+  if (aligned) TFC_PAD_LAUNCH(uint4);
+  else if (elem_bytes == 4) TFC_PAD_LAUNCH(uint32_t);
+  else TFC_PAD_LAUNCH(uint16_t);
+#undef TFC_PAD_LAUNCH
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int tfc_image_to_unit(const void* x, void* y, int dtype, int64_t n, void* stream) {
   if (dtype != 0 && dtype != 1) return tfc::fail("tfc_image_to_unit: dtype must be 0 (float32) or 1 (bfloat16)");

@@ -1609,8 +1609,24 @@ inline int side_stream(hipStream_t st, SideStream* out) {
   *out = f->second;
   return 0;
 }
-// temporaries of one pipelined launch are bounded: more jobs than this go out as several launches
-constexpr size_t kPipeTempBytes = size_t{6} << 30;
+// Temporaries of one pipelined launch (call words / raw rows: ~150 / ~125 MB per 512-stream job of BASELINE config 2) are
+// bounded: more jobs than fit go out as several launches, one behind the other — and a launch takes the same time
+// whatever its size until the chip is full, so the bound is a throughput knob (round 5, bench.py `saturation`: with
+// 6 GB, 64 batches went out as 39 + 25 and took twice the time of 20).  An eighth of the device's memory, at most
+// 24 GB; TFC_PIPE_TEMP_MB overrides.  A launch whose temporaries cannot be allocated runs on the lane-per-stream
+// kernels, which need none.
+inline size_t pipe_temp_bytes() {
+  static const size_t v = [] {
+    if (const char* e = std::getenv("TFC_PIPE_TEMP_MB")) return static_cast<size_t>(std::max(1, std::atoi(e))) << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+      (void)hipGetLastError();
+      return size_t{2} << 30;
+    }
+    return std::min<size_t>(size_t{24} << 30, total_b / 8);
+  }();
+  return v;
+}
 
 // Lane-per-stream family: n handles (same tables, same stream count) coded by one launch per
 // kMaxLaneJobs of them; no counting pass, no read-back unless a handle wants its range errors now.
@@ -1651,6 +1667,7 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   pa.poll_ticks = pipe_poll_ticks();
   const size_t group_bytes = static_cast<size_t>(pa.rows) * 256 + (sizeof(unsigned int) * 65 * pa.nt) + 64 * (sizeof(uint4) + sizeof(uint2));
   const size_t job_bytes = group_bytes * pa.groups_per_job;
+  const size_t kPipeTempBytes = pipe_temp_bytes();
   const bool pipe = pipe_enabled() && rows64 + 2048 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes && t->host.size() <= 65536 &&
                     static_cast<int64_t>(pa.nt) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
   const int per_launch = !pipe ? kMaxLaneJobs
@@ -1695,14 +1712,22 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
     {
       KernelTimer timer("enc_kernel", st);
       DevBuf temp;
-      if (pipe) {
+      bool piped = pipe;
+      la.guard = nullptr;
+      if (pipe) do {
         const size_t groups = static_cast<size_t>(pa.groups_per_job) * gn;
         // (room behind the last group: the one-wave chain requests an iteration's rows ahead)
         const size_t calls_bytes = (groups * 64 * pa.rows + 64 * PipeEncChainLds::kRows) * sizeof(unsigned int);
         const size_t stage_bytes = groups * 64 * (sizeof(uint4) + sizeof(uint2));
         const size_t status_bytes = groups * pa.nt * 64 * sizeof(unsigned int);
         const size_t done_bytes = (groups * pa.nt * sizeof(unsigned int) + 255) & ~size_t{255};
-        TFC_HIP(temp.alloc(calls_bytes + stage_bytes + status_bytes + done_bytes + 512, st));
+        if (temp.alloc(calls_bytes + stage_bytes + status_bytes + done_bytes + 512, st) != hipSuccess) {
+          // no room for the call words (a smaller or busier device): the lane-per-stream kernel codes this launch
+          (void)hipGetLastError();
+          temp.p = nullptr;
+          piped = false;
+          break;
+        }
         uint8_t* base = temp.as<uint8_t>();
         pa.calls = reinterpret_cast<unsigned int*>(base);
         pa.stage_state = reinterpret_cast<uint4*>(base + calls_bytes);
@@ -1768,9 +1793,9 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         }
         hipLaunchKernelGGL(enc_commit_kernel, dim3(static_cast<unsigned>(groups)), dim3(64), 0, st, cj, pa);
         la.guard = pa.fallback;
-      }
+      } while (false);
       const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
-      if (pipe && !pipe_fallback_launch()) {}
+      if (piped && !pipe_fallback_launch()) {}
       else if (indexed) hipLaunchKernelGGL((enc_lanes_kernel<true, Src>), grid, dim3(block), lds_bytes, st, jobs, la);
       else hipLaunchKernelGGL((enc_lanes_kernel<false, Src>), grid, dim3(block), lds_bytes, st, jobs, la);
       // `temp` goes back to the library's cache in stream order, behind these launches
@@ -2691,6 +2716,7 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   const size_t job_bytes = group_bytes * pa.groups_per_job + (indexed ? 2 * static_cast<size_t>(streams) * elems : 0);
   pla.lds_wave = indexed ? PipeDecLds::kBytes : PipeDecLds::kRows;
   const int pblock = std::min(lanes_block(streams * n), 64 * std::max(0, (160 * 1024 - pla.lds_image) / pla.lds_wave));
+  const size_t kPipeTempBytes = pipe_temp_bytes();
   const bool pipe = pipe_enabled() && pblock >= 64 && rows64 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
                     (!indexed || la.ntab < 4096) &&
                     (static_cast<int64_t>(pa.rows) / kParseRows + 1) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
@@ -2721,7 +2747,9 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
     }
     KernelTimer timer("dec_kernel", st);
     DevBuf temp;
-    if (pipe) {
+    bool piped = pipe;
+    la.guard = nullptr;
+    if (pipe) do {
       const size_t groups = static_cast<size_t>(pa.groups_per_job) * gn;
       const size_t tiles = static_cast<size_t>(pa.rows) / kParseRows + 1;
       const size_t raw_all = raw_bytes * groups, rec_all = rec_bytes * groups, st_all = 64 * sizeof(uint4) * groups;
@@ -2729,7 +2757,13 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
       const size_t addr_all = indexed ? ((2 * static_cast<size_t>(streams) * elems * gn + 255) & ~size_t{255}) : 0;
       // zeroed per launch: fallback flags (64 jobs), chain workgroups started, rows released per group, tiles taken
       const size_t flags_all = (512 + sizeof(unsigned int) * groups * (1 + tiles) + 255) & ~size_t{255};
-      TFC_HIP(temp.alloc(raw_all + rec_all + st_all + kend_all + addr_all + flags_all, st));
+      if (temp.alloc(raw_all + rec_all + st_all + kend_all + addr_all + flags_all, st) != hipSuccess) {
+        // no room for the raw rows: the lane-per-stream kernel decodes this launch
+        (void)hipGetLastError();
+        temp.p = nullptr;
+        piped = false;
+        break;
+      }
       uint8_t* base = temp.as<uint8_t>();
       pa.raw = reinterpret_cast<unsigned int*>(base);
       pa.posrec = reinterpret_cast<unsigned int*>(base + raw_all);
@@ -2800,9 +2834,9 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
         parse(0);
       }
       la.guard = pa.fallback;
-    }
+    } while (false);
     const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
-    if (pipe && !pipe_fallback_launch()) {}
+    if (piped && !pipe_fallback_launch()) {}
     else if (indexed) hipLaunchKernelGGL((dec_lanes_kernel<true, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
     else hipLaunchKernelGGL((dec_lanes_kernel<false, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
   }

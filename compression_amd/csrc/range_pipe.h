@@ -247,17 +247,28 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
     // carries everything its reader needs.
     unsigned int* const st = pa.status + static_cast<size_t>(gi) * pa.nt * 64 + tid;
     __hip_atomic_store(st + static_cast<size_t>(T) * 64, kPipeAggregate | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (A predecessor that has not published yet is running or about to be dispatched — workgroups are dispatched in
+    // blockIdx order in practice, which HIP does not promise: after a short spin the wave sleeps between polls, and a
+    // predecessor that does not show up within `poll_ticks` gives the job to the lane-per-stream kernel — this tile
+    // then publishes "does not fit", which its successors pass on.)
     unsigned int before = 0u;
-    for (unsigned int t = T; t-- > 0u;) {
-      unsigned int v;
-      do {
-        v = __hip_atomic_load(st + static_cast<size_t>(t) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((v >> 30) == 0u);
+    bool stuck = false;
+    long long t0 = 0;
+    for (unsigned int t = T; t-- > 0u && !stuck;) {
+      unsigned int v, spins = 0u;
+      while (((v = __hip_atomic_load(st + static_cast<size_t>(t) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 30) == 0u) {
+        if (++spins < 64u) continue;
+        __builtin_amdgcn_s_sleep(16);
+        const long long now = static_cast<long long>(wall_clock64());
+        if (t0 == 0) t0 = now;
+        else if (now - t0 > pa.poll_ticks) { stuck = true; break; }
+      }
+      if (stuck) break;
       before += v & kPipeRowsMask;
       if (v & kPipePrefix) break;
     }
     const unsigned int limit = static_cast<unsigned int>(pa.rows);
-    const bool fits = before + cnt <= limit;
+    const bool fits = !stuck && before + cnt <= limit;
     if (!fits) atomicOr(&pa.fallback[job], 1u);     // more rows than the launch planned for (escape codes far beyond the tables' tail mass)
     __hip_atomic_store(st + static_cast<size_t>(T) * 64, kPipePrefix | (fits ? before + cnt : limit + 1u), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);

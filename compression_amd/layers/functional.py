@@ -285,3 +285,29 @@ def index_prepare(indexes, num_tables):
     _lib.check(_lib.lib().tfc_index_prepare(indexes.data_ptr(), _DTYPE_CODE[indexes.dtype], out.data_ptr(),
                                             indexes.numel(), int(num_tables), _lib.stream_ptr()))
     return out
+
+
+def pad2d(x, pad_h, pad_w, reflect=False):
+    """Spatial padding of an NHWC tensor: zeros (tf.pad CONSTANT) or mirror without the edge sample (tf.pad REFLECT) —
+    SignalConv2D's pre-pad (signal_conv.py:880-893).  One HBM-bound kernel (tfc_pad2d) where no gradient is wanted and
+    the tensor is on the device; differentiable tensor ops (zero pad / index gathers) otherwise."""
+    (t, b), (l, r) = (int(pad_h[0]), int(pad_h[1])), (int(pad_w[0]), int(pad_w[1]))
+    if t == b == l == r == 0:
+        return x
+    n, h, w, c = x.shape
+    if reflect and (max(t, b) >= h or max(l, r) >= w):
+        raise ValueError(f"reflect padding {(t, b), (l, r)} must be smaller than the input's {(h, w)}")
+    needs = torch.is_grad_enabled() and x.requires_grad
+    if x.is_cuda and not needs and x.element_size() in (2, 4):
+        x = x.contiguous()
+        y = torch.empty((n, h + t + b, w + l + r, c), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().tfc_pad2d(x.data_ptr(), y.data_ptr(), x.element_size(), n, h, w, c, t, b, l, r,
+                                        int(bool(reflect)), _lib.stream_ptr()))
+        return y
+    if not reflect:
+        return torch.nn.functional.pad(x, (0, 0, l, r, t, b))
+
+    def mirror(length, before, after):
+        i = torch.arange(-before, length + after, device=x.device).abs()
+        return torch.where(i >= length, 2 * (length - 1) - i, i)
+    return x.index_select(1, mirror(h, t, b)).index_select(2, mirror(w, l, r))

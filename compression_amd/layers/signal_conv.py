@@ -1,5 +1,7 @@
-"""`SignalConv2D` (python/layers/signal_conv.py:61-1028) for the configurations the
-target models use: 2-D, non-separable, `same_zeros`, explicit-padding paths."""
+"""`SignalConv2D` (python/layers/signal_conv.py:61-1028), every 2-D configuration the reference implements: the
+models' (`same_zeros`, explicit padding, one-sided square strides) straight on the fused kernels, the others (`valid`,
+`same_reflect`, extra_pad_end=False, up + down strides, unequal strides, even supports, channel_separable) as a pad and a
+crop around the same kernels."""
 from __future__ import annotations
 
 import math
@@ -66,18 +68,35 @@ class SignalConv2D(torch.nn.Module):
         if in_channels is not None:
             self.build(int(in_channels))
 
+    def _raise_notimplemented(self):
+        # (signal_conv.py:577-586: same text, so that callers' `assertRaisesRegex(NotImplementedError, "SignalConv")` hold)
+        raise NotImplementedError(
+            f"The provided combination of {type(self).__name__} arguments is not currently "
+            f"implemented (filters={self.filters}, kernel_support={self.kernel_support}, "
+            f"corr={self.corr}, strides_down={self.strides_down}, strides_up={self.strides_up}, "
+            f"channel_separable={self.channel_separable}, data_format={self.data_format}, "
+            f"padding={self.padding}). Try using odd-length kernels or turning off separability?")
+
     def _check_implemented(self):
-        ok = (self.padding == "same_zeros" and not self.channel_separable and self.use_explicit
-              and self.extra_pad_end and self.strides_down[0] == self.strides_down[1]
-              and self.strides_up[0] == self.strides_up[1]
-              and (self.strides_down[0] == 1 or self.strides_up[0] == 1))
-        if not ok:
-            raise NotImplementedError(
-                f"The provided combination of {type(self).__name__} arguments is not currently "
-                f"implemented (filters={self.filters}, kernel_support={self.kernel_support}, "
-                f"corr={self.corr}, strides_down={self.strides_down}, strides_up={self.strides_up}, "
-                f"channel_separable={self.channel_separable}, data_format={self.data_format}, "
-                f"padding={self.padding}). The HIP path covers 2-D `same_zeros` with explicit padding.")
+        """The combinations the reference implements for rank 2 (signal_conv_test.py:317-349 `is_implemented`): anything
+        else raises NotImplementedError, as there."""
+        odd = all(s % 2 == 1 for s in self.kernel_support)
+        upsampled = any(s != 1 for s in self.strides_up)
+        can_use_transpose = not self.corr or odd
+        must_use_transpose = upsampled or (not self.corr and not odd)
+        if must_use_transpose and not can_use_transpose:
+            self._raise_notimplemented()
+        if self.channel_separable and (self.strides_up[0] != self.strides_up[1]
+                                       or (must_use_transpose and self.filters != 1)):
+            self._raise_notimplemented()
+
+    def _is_model_configuration(self):
+        """The configuration the models use and the fused paths serve directly: `same_zeros`, explicit padding, square
+        strides on one side only, extra_pad_end."""
+        return (self.padding == "same_zeros" and not self.channel_separable and self.use_explicit
+                and self.extra_pad_end and self.strides_down[0] == self.strides_down[1]
+                and self.strides_up[0] == self.strides_up[1]
+                and (self.strides_down[0] == 1 or self.strides_up[0] == 1))
 
     def build(self, cin, device=None):
         if self.kernel_real is not None or self.kernel_variable is not None:
@@ -216,12 +235,106 @@ class SignalConv2D(torch.nn.Module):
         self.invalidate_kernel_cache()
         return super().train(mode)
 
+    # ---------------------------------------------------------------------------------------------------------------
+    # Every other configuration of the reference (`valid` — its default —, `same_reflect`, pre-padded `same_zeros`,
+    # extra_pad_end=False, up- AND downsampling, unequal strides, even kernel supports, channel_separable), as a pad and a
+    # crop around the same two kernels.  With u the zero-upsampled (pre-padded) input, the reference computes
+    # (signal_conv.py:692-847)
+    #   correlation:  c[i] = sum_t u[i + t] w[t]           ("valid"), kept at i = 0, sd, 2 sd, ...
+    #   convolution:  f[m] = sum_j w[j] u[m - j]           ("full"),  kept at m = start, start + sd, ... < L_full - stop
+    # and the kernels compute  corr_down_s(x)[i] = sum_t x[i s + t - k // 2] w[t]  (zeros outside x) and
+    # conv_up_s(x)[n] = f[n + k // 2] over n in [0, len(x) s): a few zero samples in front / behind the input move the
+    # kernels' windows onto the positions wanted, per dimension.
+    # ---------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _zero_upsample(x, su, extra_pad_end):
+        n, h, w, c = x.shape
+        up = x.new_zeros((n, h * su[0], w * su[1], c))
+        up[:, ::su[0], ::su[1]] = x
+        return up if extra_pad_end else up[:, :h * su[0] - (su[0] - 1), :w * su[1] - (su[1] - 1)]
+
+    def _forward_general(self, x, kernel):
+        from ..ops.padding_ops import same_padding_for_kernel
+        corr = self.corr
+        ks, su, sd = self.kernel_support, self.strides_up, self.strides_down
+        odd = all(s % 2 == 1 for s in ks)
+        # the reference's kernel flips (signal_conv.py:861-880)
+        if not corr and all(s == 1 for s in su) and odd:
+            corr, kernel = True, kernel.flip(0, 1)
+        elif corr and any(s != 1 for s in su) and odd:
+            corr, kernel = False, kernel.flip(0, 1)
+        if self.channel_separable:
+            # out[..., c * F + f] = in[..., c] * kernel[..., c, f]: as a dense kernel that is zero off its diagonal blocks
+            kh, kw, cin, f = kernel.shape
+            dense = kernel.new_zeros((kh, kw, cin, cin * f))
+            for ch in range(cin):
+                dense[:, :, ch, ch * f:(ch + 1) * f] = kernel[:, :, ch]
+            kernel = dense
+        cin = x.shape[-1]
+        if cin > 4 and cin % 16:
+            # (the kernels take 1 ... 4 or a multiple of 16 input channels: zero channels change nothing)
+            extra = 16 - cin % 16
+            x = torch.nn.functional.pad(x, (0, extra))
+            kernel = torch.nn.functional.pad(kernel, (0, 0, 0, extra))
+        if self.padding == "valid":
+            prepad = ((0, 0), (0, 0))
+        else:
+            prepad = same_padding_for_kernel(ks, corr, su)
+            x = functional.pad2d(x, prepad[0], prepad[1], reflect=self.padding == "same_reflect")
+        if corr and all(s == 1 for s in su):
+            s = sd[0] if sd[0] == sd[1] else 1
+            lens = [x.shape[1 + d] for d in range(2)]
+            if any(lens[d] < ks[d] for d in range(2)):
+                return x.new_zeros((x.shape[0], 0, 0, kernel.shape[-1]))
+            e = [(-(ks[d] // 2)) % s for d in range(2)]
+            xs = functional.pad2d(x, (e[0], 0), (e[1], 0))
+            y = functional.conv2d_down(xs, kernel, None, s)
+            sl = []
+            for d in range(2):
+                a = (ks[d] // 2 + e[d]) // s
+                if s == sd[d]:
+                    sl.append(slice(a, a + (lens[d] - ks[d]) // s + 1))
+                else:
+                    sl.append(slice(a, a + lens[d] - ks[d] + 1, sd[d]))
+            return y[:, sl[0], sl[1]]
+        if corr:
+            self._raise_notimplemented()
+        square = su[0] == su[1]
+        s = su[0] if square else 1
+        if not square:
+            x = self._zero_upsample(x, su, True)
+        pads, sl = [], []
+        for d in range(2):
+            k, length = ks[d], x.shape[1 + d]                  # length: of the kernel's input (upsampled already when not square)
+            lup = length * s if square else length
+            lfull = lup + (k - 1) - (0 if self.extra_pad_end else su[d] - 1)
+            if self.padding == "valid":
+                start = stop = k - 1
+            else:
+                start, stop = prepad[d][0] * su[d] + k // 2, prepad[d][1] * su[d] + (k - 1) // 2
+            end = lfull - stop
+            a = max(0, -(-(k // 2 - start) // s))
+            b = max(0, -(-(end - k // 2 - lup) // s))
+            pads.append((a, b))
+            lo = start - k // 2 + a * s
+            sl.append(slice(lo, max(lo, end - k // 2 + a * s), sd[d]))
+        y = functional.conv2d_up(functional.pad2d(x, pads[0], pads[1]), kernel, None, s)
+        return y[:, sl[0], sl[1]]
+
     def forward(self, inputs):
         if inputs.dim() != 4:
             raise ValueError(f"Input tensor must have rank 4, received shape {tuple(inputs.shape)}.")
         x = inputs.movedim(1, -1) if self.data_format == "channels_first" else inputs
         self.build(x.shape[-1], x.device)
         kernel = self.kernel
+        if not self._is_model_configuration():
+            y = self._forward_general(x, kernel.to(x.device))
+            bias = self._bias_value()
+            if bias is not None:
+                y = y + bias.to(y.device, y.dtype)
+            if self.activation is not None:
+                y = torch.relu(y) if self.activation == "relu" else self.activation(y)
+            return y.movedim(-1, 1) if self.data_format == "channels_first" else y
         act = self.activation
         fused = "relu" if act in (torch.relu, torch.nn.functional.relu, "relu") or isinstance(
             act, torch.nn.ReLU) else None

@@ -84,6 +84,11 @@ int tfc_set_chip_shared(int shared);     /* -> the previous value */
 int tfc_image_to_unit(const void* x, void* y, int dtype, int64_t n, void* stream);
 int tfc_unit_to_image(const void* x, int dtype, void* y, int64_t n, void* stream);
 int tfc_index_prepare(const void* indexes, int dtype, int32_t* out, int64_t n, int num_tables, void* stream);
+/* Spatial padding of an NHWC tensor [n, h, w, c] of 2- or 4-byte elements into y [n, top + h + bottom, left + w + right, c]:
+ * reflect = 0 zeros, 1 mirror without repeating the edge (tf.pad "CONSTANT" / "REFLECT") — the pre-pad of
+ * SignalConv2D's `same_reflect` / pre-padded `same_zeros` modes (python/layers/signal_conv.py:880-893). */
+int tfc_pad2d(const void* x, void* y, int elem_bytes, int64_t n, int64_t h, int64_t w, int64_t c, int top, int bottom,
+              int left, int right, int reflect, void* stream);
 int tfc_cache_bytes(long long* bytes);
 int tfc_cache_trim(long long* released);
 

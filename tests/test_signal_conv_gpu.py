@@ -521,3 +521,107 @@ def test_image_side_kernels_bias_and_relu_against_scipy(label, shape, kshape, st
     assert np.max(np.abs(y - want) - tol * np.abs(want)) <= 0.51 * tol, label
     if activation == "relu":
         assert (y >= 0).all() and (want == 0).any()
+
+
+# ---- every 2-D configuration of the reference's own test, on the kernels (the CPU tier checks the same cases' pad / crop
+# arithmetic around emulations: tests/test_signal_conv_cpu.py) -----------------------------------------------------------
+import signal_conv_cases as cases  # noqa: E402
+
+
+def _run_layer_gpu(kernel, x_nchw, dtype=torch.float32, **kw):
+    from compression_amd import layers
+    layer = layers.SignalConv2D(kernel.shape[-1], kw.pop("kernel_support"), kernel_parameter=torch.from_numpy(kernel).cuda(), **kw)
+    with torch.no_grad():
+        y = layer(torch.from_numpy(np.moveaxis(x_nchw, 1, -1).copy()).to(dtype).cuda())
+    return np.moveaxis(y.float().cpu().numpy(), -1, 1), layer
+
+
+@pytest.mark.parametrize("case", [c for c in cases.valid_cases()
+                                  if cases.is_implemented(c["kernel_support"], c["corr"], c["strides_up"], c["channel_separable"], c["filters"])],
+                         ids=lambda c: "-".join(f"{k[:2]}{v}" for k, v in c.items()))
+def test_reference_valid_cases_against_scipy(case):
+    """signal_conv_test.py:224-260 `run_valid` (padding="valid", the reference's default): small integers, float32 —
+    every product and sum exact, so the layer must equal SciPy exactly (the reference allows 1e-3)."""
+    case = dict(case)
+    rng = np.random.default_rng(1)
+    support, channels, filters = case.pop("input_support"), case.pop("channels"), case.pop("filters")
+    x = rng.integers(0, 32, (1, channels) + support).astype(np.float32)
+    kernel = rng.integers(0, 16, case["kernel_support"] + (channels, filters)).astype(np.float32)
+    want = cases.scipy_convolve_valid(case["corr"], x, kernel, case["strides_down"], case["strides_up"],
+                                      case["extra_pad_end"], case["channel_separable"])
+    got, layer = _run_layer_gpu(kernel, x, padding="valid", activation=(lambda t: t) if case["use_bias"] else None, **case)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", [c for c in cases.same_cases() if cases.is_implemented(c["kernel_support"], c["corr"], c["strides_up"], False, 1)],
+                         ids=lambda c: "-".join(f"{k[:2]}{v}" for k, v in c.items()))
+def test_reference_same_cases_identity_kernels(case):
+    """signal_conv_test.py:262-315 `run_same`: `same_zeros` (explicit and pre-padded) and `same_reflect`."""
+    case = dict(case)
+    support = case.pop("input_support")
+    x = np.arange(np.prod(support), dtype=np.float32).reshape((1, 1) + support)
+    got, _ = _run_layer_gpu(cases.identity_kernel(case["kernel_support"], case["corr"]), x, **case)
+    want = x
+    if not all(s == 1 for s in case["strides_up"]):
+        want = cases.numpy_upsample(want, case["strides_up"], case["extra_pad_end"])
+    want = want[(slice(None), slice(None)) + tuple(slice(None, None, s) for s in case["strides_down"])]
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("corr,ks,cin,cout", [(True, (3, 3), 3, 2), (False, (5, 3), 3, 2), (True, (5, 5), 192, 192),
+                                              (False, (4, 3), 16, 8)])
+def test_same_reflect_general_kernel_gpu(corr, ks, cin, cout, dtype):
+    """`same_reflect` with a general kernel at small and model widths: the tfc_pad2d pre-pad + the `valid` path,
+    against reflect-padded SciPy (small integers: exact in float32; bfloat16 rounds the output only)."""
+    if not cases.is_implemented(ks, corr, (1, 1), False, cout):
+        pytest.skip("not implemented by the reference either")
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 8, (2, cin, 9, 34)).astype(np.float32)
+    kernel = rng.integers(-3, 4, ks + (cin, cout)).astype(np.float32)
+    got, _ = _run_layer_gpu(kernel, x, dtype=dtype, kernel_support=ks, corr=corr, padding="same_reflect")
+    want = cases.same_reflect_oracle(x, kernel, ks, corr)
+    assert got.shape == want.shape
+    if dtype == torch.float32:
+        assert np.array_equal(got, want)
+    else:
+        tol = 2.0 ** -8
+        assert np.max(np.abs(got - want) - tol * np.abs(want)) <= 0.51 * tol
+
+
+def test_pad2d_kernel_against_numpy():
+    from compression_amd.layers import functional
+    rng = np.random.default_rng(3)
+    for shape, ph, pw in (((2, 5, 7, 3), (2, 1), (0, 3)), ((1, 9, 6, 192), (3, 3), (2, 2)), ((3, 4, 4, 8), (0, 0), (1, 0))):
+        for dtype in (torch.float32, torch.bfloat16):
+            x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dtype).cuda()
+            for reflect in (False, True):
+                with torch.no_grad():
+                    y = functional.pad2d(x, ph, pw, reflect=reflect)
+                want = np.pad(x.float().cpu().numpy(), ((0, 0), ph, pw, (0, 0)), mode="reflect" if reflect else "constant")
+                assert np.array_equal(y.float().cpu().numpy(), want), (shape, ph, pw, dtype, reflect)
+    # with a gradient wanted: the differentiable tensor ops, same values
+    x = torch.randn(1, 5, 6, 4, device="cuda", requires_grad=True)
+    y = functional.pad2d(x, (2, 1), (1, 2), reflect=True)
+    assert np.array_equal(y.detach().cpu().numpy(), np.pad(x.detach().cpu().numpy(), ((0, 0), (2, 1), (1, 2), (0, 0)), mode="reflect"))
+    y.sum().backward()
+    assert x.grad is not None and float(x.grad.sum()) == y.numel()
+
+
+def test_default_argument_layer_on_the_device():
+    """`SignalConv2D(filters, k)` with default arguments (padding="valid", convolution, rdft kernel) constructs, runs, and
+    matches SciPy; gradients reach its parameters through the pad / crop."""
+    from compression_amd import layers
+    torch.manual_seed(0)
+    layer = layers.SignalConv2D(4, 3).cuda()
+    x = torch.randn(2, 8, 9, 3, device="cuda")
+    with torch.no_grad():
+        y = layer(x)
+    assert tuple(y.shape) == (2, 6, 7, 4)
+    want = cases.scipy_convolve_valid(False, np.moveaxis(x.cpu().numpy(), -1, 1), layer.kernel.detach().cpu().numpy(),
+                                      (1, 1), (1, 1), True, False)
+    assert np.max(np.abs(np.moveaxis(y.cpu().numpy(), -1, 1) - want)) <= 1e-5
+    layer(x).square().sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in layer.parameters())
