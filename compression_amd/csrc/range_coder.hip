@@ -1610,11 +1610,12 @@ inline int side_stream(hipStream_t st, SideStream* out) {
   return 0;
 }
 // Temporaries of one pipelined launch (call words / raw rows: ~150 / ~125 MB per 512-stream job of BASELINE config 2) are
-// bounded: more jobs than fit go out as several launches, one behind the other — and a launch takes the same time
-// whatever its size until the chip is full, so the bound is a throughput knob (round 5, bench.py `saturation`: with
-// 6 GB, 64 batches went out as 39 + 25 and took twice the time of 20).  An eighth of the device's memory, at most
-// 24 GB; TFC_PIPE_TEMP_MB overrides.  A launch whose temporaries cannot be allocated runs on the lane-per-stream
-// kernels, which need none.
+// bounded: more jobs than fit go out as several launches, one behind the other.  6 GB, at most an eighth of the device's
+// memory; TFC_PIPE_TEMP_MB overrides.  Measured (round 5, bench.py `saturation`, profiles/r05_notes.md): a launch takes
+// the same ~14 ms up to ~40 jobs, but more per launch does not help — with 24 GB, 64 jobs in ONE launch took 12.4 ms of
+// encode (the expansion, 0.19 ms per job, is what bounds it beyond ~20 jobs) + 31 ms of decode (512 chain waves: two per
+// CU behind one 149 KB table image, and the parse beside them finds no CU) against 12.0 + 28.6 ms as 39 + 25 jobs.
+// A launch whose temporaries cannot be allocated runs on the lane-per-stream kernels, which need none.
 inline size_t pipe_temp_bytes() {
   static const size_t v = [] {
     if (const char* e = std::getenv("TFC_PIPE_TEMP_MB")) return static_cast<size_t>(std::max(1, std::atoi(e))) << 20;
@@ -1623,7 +1624,7 @@ inline size_t pipe_temp_bytes() {
       (void)hipGetLastError();
       return size_t{2} << 30;
     }
-    return std::min<size_t>(size_t{24} << 30, total_b / 8);
+    return std::min<size_t>(size_t{6} << 30, total_b / 8);
   }();
   return v;
 }
