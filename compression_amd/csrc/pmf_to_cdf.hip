@@ -146,7 +146,89 @@ __global__ void __launch_bounds__(64) pmf_to_cdf_kernel(const float* pmf, int64_
   }
 }
 
+// ---- a whole model's tables in one launch (continuous_base.py:217-296 `_build_tables`) ---------------------------
+// Row r of `pmf` [rows, stride] holds lengths[r] probabilities (the prior sampled on the row's integer support); the
+// reference appends the mass the support does not cover,
+//     overflow = max(1 - sum(pmf[:length]), 0)                                        (continuous_base.py:277-279)
+// runs PmfToQuantizedCdf on the length + 1 values and writes the row as [-precision, cdf...] into a ragged 1-D table.
+// Here a wave does all of that for its row: the sum in float32 in a FIXED order (lane l adds elements l, l + 64, ... in
+// turn, then the 64 partial sums are combined by the xor butterfly 32, 16, ..., 1 — what tests/test_tables_gpu.py
+// restates in numpy), the quantisation of pmf_to_cdf_kernel above on an LDS copy of the row, and the header + cdf at
+// out[offsets[r]] — offsets are the caller's prefix sums of length + 3.
+__global__ void __launch_bounds__(64) pmf_to_cdf_ragged_kernel(const float* pmf, int64_t stride, const int32_t* lengths,
+                                                               const int64_t* offsets, int precision, int32_t* out) {
+  extern __shared__ unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int64_t r = blockIdx.x;
+  const int len = lengths[r];
+  const int n = len + 1;
+  double* key = reinterpret_cast<double*>(smem);
+  int* v = reinterpret_cast<int*>(key + n);
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(v + n);
+  float* p = reinterpret_cast<float*>(ticket + n);
+  const float* src = pmf + r * stride;
+  float part = 0.f;
+  for (int i = lane; i < len; i += 64) {
+    const float x = src[i];
+    p[i] = x;
+    part += x;
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if (lane == 0) p[len] = fmaxf(1.f - part, 0.f);
+  __syncthreads();
+  const int total = 1 << precision;
+  int sum = 0;
+  for (int i = lane; i < n; i += 64) {
+    int q = static_cast<int>(rintf(p[i] * static_cast<float>(total)));
+    q = max(q, 1);
+    v[i] = q;
+    sum += q;
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  __syncthreads();
+  if (sum > total) {
+    rebalance<true>(p, n, sum - total, v, key, ticket, lane);
+  } else if (sum < total) {
+    rebalance<false>(p, n, total - sum, v, key, ticket, lane);
+  }
+  __syncthreads();
+  int32_t* dst = out + offsets[r];
+  if (lane == 0) { dst[0] = -precision; dst[1] = 0; }
+  int carry = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    int x = i < n ? v[i] : 0;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (i < n) dst[i + 2] = carry + x;
+    carry += __shfl(x, 63, 64);
+  }
+}
+
 }  // namespace tfc
+
+extern "C" int tfc_build_tables(const float* pmf, int64_t rows, int64_t stride, const int32_t* lengths,
+                                const int64_t* offsets, int64_t max_length, int precision, int32_t* out, void* stream) {
+  using namespace tfc;
+  if (!(0 < precision && precision <= 16))
+    return fail("`precision` must be in [1, 16]: %d", precision);
+  if (max_length < 1 || max_length > stride) return fail("tfc_build_tables: max_length must be in [1, stride]");
+  if (rows == 0) return 0;
+  const size_t n = static_cast<size_t>(max_length) + 1;
+  const size_t lds = n * (sizeof(double) + 2 * sizeof(int) + sizeof(float));
+  if (lds > 160 * 1024)
+    return fail("`pmf` rows of %lld elements exceed the on-chip table builder's limit (%d)",
+                static_cast<long long>(n), static_cast<int>(160 * 1024 / 20));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pmf_to_cdf_ragged_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  hipLaunchKernelGGL(pmf_to_cdf_ragged_kernel, dim3(static_cast<unsigned>(rows)), dim3(64), lds, st, pmf, stride,
+                     lengths, offsets, precision, out);
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int tfc_pmf_to_quantized_cdf(const float* pmf, int64_t rows, int64_t n, int precision,
                                         int32_t* cdf, void* stream) {

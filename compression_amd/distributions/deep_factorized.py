@@ -83,12 +83,40 @@ class DeepFactorized(Distribution):
         s = torch.sigmoid(logits)
         return s * (1 - s) * d
 
+    def _solve_device(self, targets):
+        """helpers.estimate_tails for this prior with the whole iteration on the device (csrc/deep_factorized_tails.hip:
+        one workgroup per target, a thread per channel; the reference's update and stopping rule) -> [len(targets),
+        *batch_shape], or None where the kernel does not apply (parameters not on a HIP device, unequal hidden widths,
+        more than 1024 channels, another dtype)."""
+        m0 = self.matrices[0]
+        channels = self._batch_shape.numel()
+        if (not m0.is_cuda or self.dtype != torch.float32 or len(set(self.num_filters)) != 1
+                or self.num_filters[0] > 8 or channels > 1024):
+            return None
+        from .. import _lib
+        from ..ops.bottleneck_ops import pack_factorized_params
+        with torch.no_grad():
+            params = pack_factorized_params(self)
+            t = torch.tensor([float(v) for v in targets], dtype=torch.float32, device=m0.device)
+            out = torch.empty((len(targets), channels), dtype=torch.float32, device=m0.device)
+            with torch.cuda.device(m0.device):
+                _lib.check(_lib.lib().tfc_deep_factorized_tails(
+                    params.data_ptr(), channels, params.shape[1], len(self.num_filters) + 1, self.num_filters[0],
+                    t.data_ptr(), len(targets), out.data_ptr(), None, _lib.stream_ptr()))
+        return out.reshape((len(targets),) + tuple(self._batch_shape))
+
     def _quantization_offset(self):
+        solved = self._solve_device([0.0])
+        if solved is not None:
+            return solved[0]
         with torch.no_grad():
             dev = self.matrices[0].device
         return helpers.estimate_tails(self._logits_cumulative, 0.0, self._batch_shape, self.dtype, dev)
 
     def _tail(self, logits):
+        solved = self._solve_device([logits])
+        if solved is not None:
+            return solved[0]
         dev = self.matrices[0].device
         return helpers.estimate_tails(self._logits_cumulative, logits, self._batch_shape, self.dtype, dev)
 

@@ -8,6 +8,7 @@ import logging
 
 import torch
 
+from .. import _lib
 from ..distributions import helpers, uniform_noise
 from ..ops import gen_ops
 
@@ -126,18 +127,28 @@ class ContinuousEntropyModelBase(torch.nn.Module, metaclass=abc.ABCMeta):
         pmf = prior.prob(samples).detach()
         pmf_shape = pmf.shape[1:]
         num_pmfs = int(torch.Size(pmf_shape).numel())
-        pmf = pmf.reshape(max_length, num_pmfs).t().contiguous()
-        pmf_length = pmf_length.expand(pmf_shape).reshape(num_pmfs).cpu()
         cdf_offset = minima.expand(pmf_shape).reshape(num_pmfs)
-        pieces = []
-        head = torch.tensor([-precision], dtype=torch.int32)
-        for i in range(num_pmfs):
-            p = pmf[i, :int(pmf_length[i])]
-            overflow = torch.clamp(1.0 - p.sum(dim=0, keepdim=True), min=0.0)
-            p = torch.cat([p, overflow]).to(torch.float32)
-            c = gen_ops.pmf_to_quantized_cdf(p, precision)
-            pieces += [head, c.cpu()]
-        return torch.cat(pieces), cdf_offset.cpu()
+        # All rows in ONE launch (include/tfc_hip.h tfc_build_tables): overflow mass, PmfToQuantizedCdf and the ragged
+        # [-precision, cdf...] layout per row on the device, one read-back for the whole model (round 4: a launch, a
+        # device sum and a read-back per row — 192 of each for bls2017)
+        device = _lib.require_device()
+        pmf = pmf.reshape(max_length, num_pmfs).t().to(device, torch.float32).contiguous()
+        lengths = pmf_length.expand(pmf_shape).reshape(num_pmfs).to(device, torch.int32).contiguous()
+        ends = torch.cumsum(lengths.to(torch.int64) + 3, 0)
+        inside = torch.arange(max_length, device=device)[None, :] < lengths[:, None]
+        bad = inside & ~(torch.isfinite(pmf) & (pmf >= 0))
+        total, any_bad = (int(v) for v in torch.stack([ends[-1], bad.any().to(torch.int64)]).cpu())
+        if any_bad:
+            raise ValueError(
+                f"`pmf` has non-finite or negative element: {pmf[bad][0].item()}. Please check for numerical "
+                "problems in the probability computation.")
+        offsets = (ends - (lengths.to(torch.int64) + 3)).contiguous()
+        cdf = torch.empty(total, dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().tfc_build_tables(pmf.data_ptr(), num_pmfs, max_length, lengths.data_ptr(),
+                                                   offsets.data_ptr(), max_length, precision, cdf.data_ptr(),
+                                                   _lib.stream_ptr()))
+        return cdf.cpu(), cdf_offset.cpu()
 
     def _log_prob(self, prior, bottleneck_perturbed):
         """continuous_base.py:298-334 (optional Laplace-mixture tail for stability)."""

@@ -159,10 +159,9 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         cdf_offset, qoff, _ = self._device_tables(device)
         if self.fused and bottleneck.dtype in _DTYPE_CODE:
             handle._keep += [bottleneck, cdf_offset, qoff]
-            _lib.check(_lib.lib().tfc_encoder_encode_quantized(
-                handle.ptr, bottleneck.data_ptr(), _DTYPE_CODE[bottleneck.dtype],
-                None if qoff is None else qoff.data_ptr(), cdf_offset.data_ptr(), channels, elems,
-                _lib.stream_ptr()))
+            quantized = self._quantized_call(bottleneck, qoff, cdf_offset, channels, elems)
+            handle.record(quantized)
+            quantized(handle)
         else:
             offset = self.quantization_offset
             if offset is not None:
@@ -214,6 +213,18 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             raise RuntimeError("Sanity check failed.")
         return out
 
+    @staticmethod
+    def _quantized_call(bottleneck, qoff, cdf_offset, channels, elems):
+        """The fused quantise + encode call of one handle as a closure over its inputs (what a deferred handle keeps to be
+        coded again: gen_ops._retry_outgrown)."""
+        def call(handle):
+            handle._keep += [bottleneck, cdf_offset, qoff]
+            _lib.check(_lib.lib().tfc_encoder_encode_quantized(
+                handle.ptr, bottleneck.data_ptr(), _DTYPE_CODE[bottleneck.dtype],
+                None if qoff is None else qoff.data_ptr(), cdf_offset.data_ptr(), channels, elems,
+                _lib.stream_ptr()))
+        return call
+
     # ------------------------------------------------------------------ several batches per launch
     def _symbols(self, bottleneck, cdf_offset, qoff_native):
         """int32 symbols of continuous_batched.py:370-380 as tensor ops (the `*_many` path hands the coder
@@ -231,7 +242,7 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         way a server that has several batches in flight fills the chip.  Nothing is read back: returns one
         finalized encoder handle per batch (`gen_ops.fetch_strings`, `decompress_many`).  Same strings as
         compress() batch by batch.  (Like `compress(device_result=True)`: a stream of more than ~16-20 bits per
-        symbol outgrows the slab, which `fetch_strings` reports.)"""
+        symbol outgrows the speculative slab; `fetch_strings` then codes that handle again, synchronously.)"""
         self._check_compression()
         device = _lib.require_device()
         bottlenecks = [torch.as_tensor(b).to(device, self.bottleneck_dtype).contiguous() for b in bottlenecks]
@@ -254,6 +265,8 @@ class ContinuousBatchedEntropyModel(continuous_base.ContinuousEntropyModelBase):
                 n, hp, yp, _DTYPE_CODE[bottlenecks[0].dtype], None if qoff is None else qoff.data_ptr(),
                 cdf_offset.data_ptr(), channels, elems, _lib.stream_ptr()))
             keep = [[b, cdf_offset, qoff] for b in bottlenecks]
+            for h, b in zip(handles, bottlenecks):
+                h.record(self._quantized_call(b, qoff, cdf_offset, channels, elems))
         else:
             symbols = [self._symbols(b, cdf_offset, qn) for b in bottlenecks]
             handles = gen_ops.entropy_encode_channel_many(handles, symbols)

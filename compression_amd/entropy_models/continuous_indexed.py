@@ -165,9 +165,9 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
         if self.fused and bottleneck.dtype in _DTYPE_CODE:
             elems = flat.numel() // handle.streams
             handle._keep += [bottleneck, flat, cdf_offset]
-            _lib.check(_lib.lib().tfc_encoder_encode_quantized_indexed(
-                handle.ptr, bottleneck.data_ptr(), _DTYPE_CODE[bottleneck.dtype], flat.data_ptr(),
-                cdf_offset.data_ptr(), elems, _lib.stream_ptr()))
+            quantized = self._quantized_call(bottleneck, flat, cdf_offset, elems)
+            handle.record(quantized)
+            quantized(handle)
         else:
             symbols = torch.round(bottleneck).to(torch.int32) - cdf_offset[flat.long()]
             handle = gen_ops.entropy_encode_index(handle, flat, symbols.contiguous())
@@ -210,6 +210,17 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             raise RuntimeError("Sanity check failed.")
         return out
 
+    @staticmethod
+    def _quantized_call(bottleneck, flat, cdf_offset, elems):
+        """The fused quantise + indexed encode call of one handle as a closure over its inputs (what a deferred handle
+        keeps to be coded again: gen_ops._retry_outgrown)."""
+        def call(handle):
+            handle._keep += [bottleneck, flat, cdf_offset]
+            _lib.check(_lib.lib().tfc_encoder_encode_quantized_indexed(
+                handle.ptr, bottleneck.data_ptr(), _DTYPE_CODE[bottleneck.dtype], flat.data_ptr(),
+                cdf_offset.data_ptr(), elems, _lib.stream_ptr()))
+        return call
+
     def compress_many(self, bottlenecks, indexes):
         """compress() of several independent batches (same shapes) with ONE coder launch per stage
         (tfc_encoder_encode_quantized_indexed_many: the pipelined lane kernels quantise and look the tables up in
@@ -240,6 +251,8 @@ class ContinuousIndexedEntropyModel(continuous_base.ContinuousEntropyModelBase):
             ip = (C.c_void_p * n)(*[f.data_ptr() for f in flats])
             _lib.check(_lib.lib().tfc_encoder_encode_quantized_indexed_many(
                 n, hp, yp, _DTYPE_CODE[bottlenecks[0].dtype], ip, cdf_offset.data_ptr(), elems, _lib.stream_ptr()))
+            for h, b, f in zip(handles, bottlenecks, flats):
+                h.record(self._quantized_call(b, f, cdf_offset, elems))
         else:
             for k in range(n):
                 symbols = torch.round(bottlenecks[k]).to(torch.int32) - cdf_offset[flats[k].long()]

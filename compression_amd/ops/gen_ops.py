@@ -129,9 +129,20 @@ class EncoderHandle:
             _lib.check(_lib.lib().tfc_encoder_set_mode(out, _mode_code(mode)))
         if deferred_errors:
             _lib.check(_lib.lib().tfc_encoder_set_deferred_errors(out, 1))
+        self.mode = mode
+        self.deferred = bool(deferred_errors)
         self._keep = []       # inputs of in-flight kernels
+        # deferred handles: how to issue every encode call again (one closure per call, taking a handle) — see
+        # _retry_outgrown
+        self._replay = []
         self.blob = None      # after finalize: device uint8 [total]
         self.offsets = None   # after finalize: device int64 [streams + 1]
+
+    def record(self, call):
+        """`call(handle)` issues an encode call of this handle again: kept for deferred handles, whose slab is sized
+        without looking at the data."""
+        if self.deferred:
+            self._replay.append(call)
 
     def __del__(self):
         try:
@@ -139,6 +150,45 @@ class EncoderHandle:
                 _lib.lib().tfc_encoder_destroy(self.ptr)
         except Exception:
             pass
+
+
+_OUTGROWN = "outgrew its output slab"
+
+
+def _retry_outgrown(handle: EncoderHandle) -> None:
+    """A deferred handle codes into a slab sized from the geometry alone (2 bytes per symbol and a margin); a stream of
+    mostly long escape codes can need more, which the kernels notice (they never write past the slab) and the handle
+    reports at its first synchronising call.  The reference never fails on encodable input
+    (cc/kernels/range_coder_kernels.cc:191-322 grows a std::string), so that report is not passed on: every encode call
+    of the handle is issued again on a fresh SYNCHRONISING encoder — whose calls size their slabs from a counting pass,
+    or repeat with the bound no stream can exceed — and the handle continues as that encoder.  (A decoder that was
+    created on the handle's device strings before the report was read decoded the incomplete strings: its
+    EntropyDecodeFinalize flags say so.)"""
+    fresh = EncoderHandle(handle.shape, handle.tables, handle.device, handle.mode, deferred_errors=False)
+    for call in handle._replay:
+        call(fresh)
+    old = handle.ptr
+    handle.ptr, fresh.ptr = fresh.ptr, None
+    handle._keep += fresh._keep
+    handle.deferred = False
+    handle._replay = []
+    handle.blob = handle.offsets = None
+    handle.retried = True
+    _lib.lib().tfc_encoder_destroy(old)
+    if getattr(handle, "finalized_on_device", False):
+        # the state the caller left it in: finalized, strings in HBM (device_strings views have to be taken again)
+        _lib.check(_lib.lib().tfc_encoder_finalize_device(handle.ptr, _lib.stream_ptr()))
+
+
+def _with_retry(handle: EncoderHandle, fn):
+    """fn() on the handle; an outgrown speculative slab is repaired once (see _retry_outgrown) and fn() repeated."""
+    try:
+        return fn()
+    except ValueError as e:
+        if _OUTGROWN not in str(e) or not handle.deferred or not handle._replay:
+            raise
+    _retry_outgrown(handle)
+    return fn()
 
 
 class DecoderHandle:
@@ -207,6 +257,7 @@ def entropy_encode_channel(handle: EncoderHandle, value) -> EncoderHandle:
     _check_prefix(handle.shape, value.shape)
     elems = value.numel() // handle.streams
     handle._keep.append(value)
+    handle.record(lambda h, v=value: entropy_encode_channel(h, v))
     _lib.check(_lib.lib().tfc_encoder_encode(handle.ptr, value.data_ptr(), None, elems,
                                              _lib.stream_ptr()))
     return handle
@@ -226,6 +277,7 @@ def entropy_encode_channel_many(handles, values):
         _check_prefix(h.shape, v.shape)
         vals.append(v)
         h._keep.append(v)
+        h.record(lambda hh, vv=v: entropy_encode_channel(hh, vv))
     elems = {v.numel() // h.streams for h, v in zip(handles, vals)}
     if len(elems) != 1:
         raise ValueError("entropy_encode_channel_many: all values must have the same shape")
@@ -249,6 +301,7 @@ def entropy_encode_index(handle: EncoderHandle, index, value) -> EncoderHandle:
             f"!= value.shape={list(value.shape)}")
     elems = value.numel() // handle.streams
     handle._keep += [value, index]
+    handle.record(lambda h, i=index, v=value: entropy_encode_index(h, i, v))
     _lib.check(_lib.lib().tfc_encoder_encode(handle.ptr, value.data_ptr(), index.data_ptr(),
                                              elems, _lib.stream_ptr()))
     return handle
@@ -256,8 +309,9 @@ def entropy_encode_index(handle: EncoderHandle, index, value) -> EncoderHandle:
 
 def _finalize_device(handle: EncoderHandle):
     total = C.c_int64()
-    _lib.check(_lib.lib().tfc_encoder_finalize(handle.ptr, _lib.stream_ptr(), C.byref(total)))
+    _with_retry(handle, lambda: _lib.check(_lib.lib().tfc_encoder_finalize(handle.ptr, _lib.stream_ptr(), C.byref(total))))
     handle._keep.clear()
+    handle._replay = []
     blob = torch.empty(max(total.value, 1), dtype=torch.uint8, device=handle.device)
     offsets = torch.empty(handle.streams + 1, dtype=torch.int64, device=handle.device)
     _lib.check(_lib.lib().tfc_encoder_read(handle.ptr, blob.data_ptr(), offsets.data_ptr(), 1,
@@ -274,6 +328,7 @@ def entropy_encode_finalize_device(handle: EncoderHandle) -> EncoderHandle:
     if handle.streams == 0:
         raise ValueError(f"`handle` is empty: {list(handle.shape)}")
     _lib.check(_lib.lib().tfc_encoder_finalize_device(handle.ptr, _lib.stream_ptr()))
+    handle.finalized_on_device = True
     return handle
 
 
@@ -285,6 +340,8 @@ def entropy_encode_finalize_device_many(handles):
     if n:
         hp = (C.c_void_p * n)(*[h.ptr for h in handles])
         _lib.check(_lib.lib().tfc_encoder_finalize_device_many(n, hp, _lib.stream_ptr()))
+        for h in handles:
+            h.finalized_on_device = True
     return handles
 
 
@@ -333,9 +390,10 @@ def fetch_strings(handle: EncoderHandle):
 
 
 def entropy_encode_status(handle: EncoderHandle) -> int:
-    """Synchronises; raises a deferred range error, returns the total byte count (-1 before finalize)."""
+    """Synchronises; raises a deferred range error, returns the total byte count (-1 before finalize).  A deferred
+    handle whose speculative slab a stream outgrew is coded again here (_retry_outgrown): never an error."""
     total = C.c_int64()
-    _lib.check(_lib.lib().tfc_encoder_status(handle.ptr, _lib.stream_ptr(), C.byref(total)))
+    _with_retry(handle, lambda: _lib.check(_lib.lib().tfc_encoder_status(handle.ptr, _lib.stream_ptr(), C.byref(total))))
     return int(total.value)
 
 

@@ -344,6 +344,22 @@ void tfc_free(void* p);
 int tfc_pmf_to_quantized_cdf(const float* pmf, int64_t rows, int64_t n, int precision,
                              int32_t* cdf, void* stream);
 
+/* A whole model's range-coding tables in one launch — python/entropy_models/continuous_base.py:217-296
+ * (`_build_tables`) from the sampled PMFs on: row r of pmf DEV [rows, stride] holds lengths[r] (DEV int32, >= 1)
+ * probabilities; the kernel appends overflow = max(1 - sum(pmf[:length]), 0) (continuous_base.py:277-279; float32, in
+ * the fixed order csrc/pmf_to_cdf.hip states), runs PmfToQuantizedCdf (pmf_to_cdf_kernels.cc:159-208) on the
+ * length + 1 values and writes [-precision, cdf[0 .. length + 1]] at out[offsets[r]] (offsets DEV int64: the caller's
+ * prefix sums of length + 3; out DEV int32 [sum]).  max_length = the largest length (sizes the kernel's LDS). */
+int tfc_build_tables(const float* pmf, int64_t rows, int64_t stride, const int32_t* lengths, const int64_t* offsets,
+                     int64_t max_length, int precision, int32_t* out, void* stream);
+/* helpers.estimate_tails (python/distributions/helpers.py:29-104) for a deep factorized prior
+ * (python/distributions/deep_factorized.py:166-246), whole iteration on the device: for every target t (DEV float32
+ * [num_targets]) and channel c, the x where the channel's logits of the cumulative reach t — out DEV [num_targets,
+ * channels]; iterations DEV int32 [num_targets] or null.  params DEV [channels, params_per_channel]: the
+ * reparameterised MLP weights in the layout of tfc_factorized_bits_forward. */
+int tfc_deep_factorized_tails(const float* params, int64_t channels, int64_t params_per_channel, int layers, int width,
+                              const float* targets, int num_targets, float* out, int* iterations, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* GDN / IGDN                                                               */
 /* ------------------------------------------------------------------------ */
