@@ -218,14 +218,20 @@ def gdn_forward_bandwidth(device, steps=20):
         for k in range(GDN_ROTATE):
             ys[k] = call(k)
         torch.cuda.synchronize()
-        # HIP events over the timed region, on the launch stream: `steps` launches back to back
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for k in range(steps):
-            ys[k % rotate] = call(k)
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / steps
+        # HIP events over the timed region, on the launch stream: `steps` launches back to back.  Twice, the faster
+        # counts: replacing an output while the old one is still referenced makes torch's allocator fetch one more
+        # 100 MB block the first time round (a hipMalloc of ~20 ms inside the loop: 1.04 ms "per launch" in one line).
+        best = None
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(steps):
+                ys[k % rotate] = call(k)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            best = ms if best is None else min(best, ms)
+        return best
 
     def bwd_ms(inverse, alpha, epsilon):
         keep = [None] * GDN_ROTATE

@@ -769,7 +769,9 @@ __global__ void __launch_bounds__(512) enc_lanes_kernel(const EncLaneJobs<Src> j
   flush();
   if (live) {
     J.state[s] = make_uint4(base, s1, (hd & 0xFFFFu) | (had << 31), rn);
-    J.chunk_len[s] = wpos;
+    // (past the slab's end wpos only counts, nothing is stored: the piece gets length 0 so that finalize packs
+    // nothing from behind the slab — the handle is flagged, and the caller codes it again)
+    J.chunk_len[s] = overflow ? 0u : wpos;
     if (overflow) atomicOr(J.overflow_flag, 1u);
   }
 }

@@ -949,7 +949,9 @@ __global__ void __launch_bounds__(64) enc_commit_kernel(const PipeChainJobs jobs
   const PipeChainJob& J = jobs.job[job];
   J.state[s] = pa.stage_state[static_cast<size_t>(gi) * 64 + threadIdx.x];
   const uint2 o = pa.stage_out[static_cast<size_t>(gi) * 64 + threadIdx.x];
-  J.chunk_len[s] = o.x;
+  // (a stream that outgrew its slab kept counting without storing: its piece gets length 0, like the wave family's
+  // guard, so that finalize packs nothing from behind the slab; the handle is flagged and coded again by the caller)
+  J.chunk_len[s] = o.y ? 0u : o.x;
   if (o.y) atomicOr(J.overflow_flag, 1u);
 }
 

@@ -236,7 +236,9 @@ def test_modes_per_handle_and_device_finalize(tfc, port):
                 assert (out.cpu().numpy() == x).all()
                 assert [bytes(b) for b in tfc.entropy_encode_finalize(h).reshape(-1)] == port.encode(lookup, x)[0], (mode, batched)
     # streams that outgrow the speculative slab (more than 16 bits per symbol): coded again with the
-    # worst-case slab when the call synchronises, reported when errors are deferred
+    # worst-case slab when the call synchronises; with deferred errors the C ABI reports the flagged handle and the op
+    # layer codes it again on a synchronising encoder (gen_ops._retry_outgrown) — never an error, the reference codes
+    # any encodable input
     rng = np.random.default_rng(3)
     big = (rng.integers(1 << 20, 1 << 29, (3, 400)) * rng.choice([-1, 1], (3, 400))).astype(np.int32)
     want_big = port.encode(lookup, big)[0]
@@ -246,8 +248,7 @@ def test_modes_per_handle_and_device_finalize(tfc, port):
     assert [bytes(b) for b in tfc.entropy_encode_finalize(h).reshape(-1)] == want_big
     h = tfc.create_range_encoder([3], lt, mode="throughput", deferred_errors=True)
     h = tfc.entropy_encode_channel(h, dev(big))
-    with pytest.raises(ValueError, match="outgrew its output slab"):
-        tfc.entropy_encode_finalize(h)
+    assert [bytes(b) for b in tfc.entropy_encode_finalize(h).reshape(-1)] == want_big and h.retried
     # deferred range error: the encode call returns, finalize reports value and range
     plain = torch.tensor([[8, 0, 100, 256, 256]], dtype=torch.int32)
     h = tfc.create_range_encoder([3], plain, mode="throughput", deferred_errors=True)
