@@ -46,6 +46,10 @@ def test_build_tables_equals_the_oracle_row_by_row(port, precision):
     rng = np.random.default_rng(precision)
     rows = []
     for n in (1, 2, 3, 17, 63, 64, 65, 130, 200, 500):
+        if n + 1 > (1 << precision):
+            # more symbols than quanta: the reference aborts there (CHECK at pmf_to_cdf_kernels.cc:110, every symbol
+            # must keep a frequency >= 1), so there is nothing to compare with
+            continue
         for kind in range(3):
             if kind == 0:        # a discretised Gaussian with mass left over (the usual row)
                 x = np.arange(n) - (n - 1) / 2
