@@ -2715,11 +2715,12 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   const size_t rec_bytes = (static_cast<size_t>(pa.rows) / kPipeBlock + 1) * 256;
   const size_t group_bytes = raw_bytes + rec_bytes + 64 * sizeof(uint4) + sizeof(unsigned int);
   const size_t job_bytes = group_bytes * pa.groups_per_job + (indexed ? 2 * static_cast<size_t>(streams) * elems : 0);
-  pla.lds_wave = indexed ? PipeDecLds::kBytes : PipeDecLds::kRows;
+  pla.lds_wave = (indexed ? PipeDecLds::kBytes : PipeDecLds::kRows) + PipeDecLds::kStage;
   const int pblock = std::min(lanes_block(streams * n), 64 * std::max(0, (160 * 1024 - pla.lds_image) / pla.lds_wave));
   const size_t kPipeTempBytes = pipe_temp_bytes();
+  // (precision 16: a quotient can equal the "no escape symbol" mark of dec_chain_kernel's directory, 0xFFFF)
   const bool pipe = pipe_enabled() && pblock >= 64 && rows64 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
-                    (!indexed || la.ntab < 4096) &&
+                    (!indexed || la.ntab < 4096) && t->lane_precision <= 15 &&
                     (static_cast<int64_t>(pa.rows) / kParseRows + 1) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
   const int per_launch = !pipe ? kMaxLaneJobs
                                : static_cast<int>(std::max<size_t>(1, std::min<size_t>(kMaxLaneJobs, kPipeTempBytes / std::max<size_t>(job_bytes, 1))));

@@ -1019,6 +1019,8 @@ struct PipeDecLds {
   static constexpr int kCodes = 0;
   static constexpr int kRows = kCodes + 64 * kStride;
   static constexpr int kBytes = kRows + 64 * kStride;
+  // behind the windows (channel mode: behind the code window): the raw entries of a block, [row][lane] dwords
+  static constexpr int kStage = kPipeBlock * 256;
 };
 
 // ---- one decoder step of every lane, hand-scheduled -------------------------------------------------
@@ -1029,38 +1031,76 @@ struct PipeDecLds {
 //   M < 0   unary prefix of an Elias-gamma code, -M - 1 zeros seen: a zero decrements M, a one leaves
 //           M = -M calls to go (the magnitude's lower bits, then the sign)
 //   M > 0   M binary calls to go
-// in arithmetic:  t = M - (M != 0);  u = t + (symbol & (M >> 31)) (1 - 2 M);  M' = u - [escape symbol].
-// A lane with M' = 0 has completed an element: its row pointer PW moves on and the next step's row is the one
-// requested at the top of this step; with M' != 0 the next row is the built-in binary row B0..B3.  Both LDS
-// round trips of the step are covered by this bookkeeping.  Every step stores symbol | M << 16 (M before the
-// step) to row K of the raw plane.  FLAG: the verification failed (estimate one off, ~1e-5, or damaged input);
-// MACC: min of M (31 zeros in a prefix: damaged input, the reference stops counting there) — the caller then
-// repeats the block from its saved state with the generic steps.
-// Fixed temporaries v104-v140; v123 = v125 = 0.
-#define TFC_PDEC_STEP(KOFF, TOP, MID, SEL_EARLY, SEL_LATE, PWSTEP)                         \
-  TOP                                                                                     \
-  "ds_read_u16 v109, %[CP]\n\t"                                                           \
-  "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
+// (the arithmetic and its place in the step: "Round 5" below.)
+// A lane with M' = 0 has completed an element: its row pointer PW moves on and the next step's row is the directory
+// entry requested during this step; with M' != 0 the next row is the built-in binary row B0..B3.  Every step stores
+// symbol | M << 16 (M before the step) to row K of the raw plane.  FLAG: the verification failed (estimate one off,
+// ~1e-5, or damaged input); MACC: min of M (31 zeros in a prefix: damaged input, the reference stops counting there) —
+// the caller then repeats the block from its saved state with the generic steps.
+// Fixed temporaries v104-v141; v123 = v125 = 0.
+// TFC_PDEC_ABL (build switch, timing experiments only — results are wrong): 1 the step stores nothing
+#ifndef TFC_PDEC_ABL
+#define TFC_PDEC_ABL 0
+#endif
+#ifndef TFC_PDEC_TIMING
+#define TFC_PDEC_TIMING 0
+#endif
+// A step's raw entry goes to the wave's staging area in LDS ([row of the block][lane], flushed by the memory phase).
+#if TFC_PDEC_ABL & 1
+#define TFC_PDEC_STORE(KOFF)
+#define TFC_PDEC_WAIT2 "s_waitcnt lgkmcnt(2)\n\t"
+#define TFC_PDEC_WAIT3 "s_waitcnt lgkmcnt(0)\n\t"
+#else
+#define TFC_PDEC_STORE(KOFF) "ds_write_b32 %[STG], v139 offset:" #KOFF "\n\t"
+#define TFC_PDEC_WAIT2 "s_waitcnt lgkmcnt(3)\n\t"
+#define TFC_PDEC_WAIT3 "s_waitcnt lgkmcnt(1)\n\t"
+#endif
+// Round 5: the schedule of a step.  The wave issues one instruction per ~4.3 cycles whatever it is, and the two LDS
+// round trips (quotient -> bitmap word + count; symbol -> cdf entries) cost ~85-105 cycles each with 64 lanes in
+// different rows (bank conflicts: ~35 cycles of a step, tools/chain_clock_probe.py with IDENTICAL_STREAMS) — so what a
+// step costs is its instructions ON the chain (quotient 12, rank 6, bounds + renormalisation 14) plus whatever part of
+// the two trips the other instructions do not cover.  Round 4's step derived the mode counter from the SYMBOL, which is
+// only known after the first trip: 15 of its 21 bookkeeping instructions sat in the second trip's shadow, 6 in the
+// first's, and the wave waited ~80 + ~40 cycles.  But whether a step's symbol is the escape symbol (or, on the binary
+// row, which bit it is) is a comparison of the QUOTIENT with one boundary of the row — q >= cdf[escape symbol]
+// (q >= 2^(p-1) on the binary row) <=> rank(q) is the last symbol — and the rank structure returns exactly rank(q_est),
+// so the comparison on q_est gives the bookkeeping the very symbol class the verification then checks.  The row's
+// boundary (ESCLO) sits in the upper half of the directory entry's info word (dec_chain_kernel rewrites the directory
+// of its LDS copy), the whole mode arithmetic and the row select need nothing the trips return, and the step spreads
+// them over both shadows; the verification flag and the code cursor's increment are taken in the NEXT step's shadow
+// (v130 / v131 / v133 survive until its tail), the digit's byte swap is folded into the v_perm that renormalises D.
+//   M' = M - 1 + [M = 0] + (q >= ESCLO ? delta : 0),   delta = -1 (M = 0), 1 - 2 M (M < 0), 0 (M > 0).
+// LDS operations of a step, in issue order (they complete in order): bitmap word, count | next entry (index mode: next
+// row address), digit | (index mode: next entry) cdf lo, cdf hi, the raw entry's write.
+#define TFC_PDEC_STEP(KOFF, AHEAD, WAIT1, MID, PWSTEP)                                      \
   "v_cvt_f32_u32 v111, %[S]\n\t"                                                          \
   "v_rcp_f32 v111, v111\n\t"                                                              \
+  "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
   "v_fma_f32 v110, v110, %[SCALE], %[HSCALE]\n\t"                                         \
-  "s_nop 0\n\t"                                                                           \
   "v_mul_f32 v110, v110, v111\n\t"                                                        \
   "v_cvt_u32_f32 v110, v110\n\t"                                                          \
   "v_min_u32 v110, %[QMAX], v110\n\t"                                                     \
   "v_lshrrev_b32 v111, 6, v110\n\t"                                                       \
   "v_lshl_add_u32 v112, v111, 3, %[R2]\n\t"                                               \
-  "v_lshl_add_u32 v113, v111, 1, %[R3]\n\t"                                               \
   "ds_read_b64 v[114:115], v112\n\t"                                                      \
+  "v_lshl_add_u32 v113, v111, 1, %[R3]\n\t"                                               \
   "ds_read_i16 v116, v113\n\t"                                                            \
-  "v_not_b32 v110, v110\n\t"                                                              \
-  "v_cmp_ne_u32 vcc, 0, %[M]\n\t"                                                         \
-  "v_subbrev_co_u32 v134, vcc, 0, %[M], vcc\n\t"                                          \
+  AHEAD                                                                                   \
+  "v_add_u32 %[CP], %[CP], v133\n\t"                                                      \
+  "ds_read_u16 v109, %[CP]\n\t"                                                           \
+  "v_lshlrev_b32 v141, 16, %[M]\n\t"                                                      \
   "v_ashrrev_i32 v135, 31, %[M]\n\t"                                                      \
   "v_mad_i32_i24 v136, %[M], -2, 1\n\t"                                                   \
-  "s_waitcnt lgkmcnt(2)\n\t"                                                              \
-  "v_perm_b32 v109, 0, v109, %[PERM]\n\t"                                                 \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                              \
+  "v_and_b32 v137, v135, v136\n\t"                                                        \
+  "v_cmp_eq_u32 vcc, 0, %[M]\n\t"                                                         \
+  "v_cndmask_b32_e64 v137, v137, -1, vcc\n\t"                                             \
+  "v_addc_co_u32 v134, vcc, -1, %[M], vcc\n\t"                                            \
+  "v_cmp_ge_u32_sdwa vcc, v110, %[R1] src0_sel:DWORD src1_sel:WORD_1\n\t"                 \
+  "v_not_b32 v110, v110\n\t"                                                              \
+  "v_cndmask_b32 v137, 0, v137, vcc\n\t"                                                  \
+  "v_add_u32 %[M], v134, v137\n\t"                                                        \
+  "v_min_i32 %[MACC], %[MACC], %[M]\n\t"                                                  \
+  "s_waitcnt lgkmcnt(" #WAIT1 ")\n\t"                                                     \
   MID                                                                                     \
   "v_lshlrev_b64 v[118:119], v110, v[114:115]\n\t"                                        \
   "v_bcnt_u32_b32 v116, v118, v116\n\t"                                                   \
@@ -1068,56 +1108,69 @@ struct PipeDecLds {
   "v_lshl_add_u32 v112, v117, 1, %[R0]\n\t"                                               \
   "ds_read_u16 v122, v112 offset:2\n\t"                                                   \
   "ds_read_u16 v124, v112 offset:4\n\t"                                                   \
-  "v_xad_u32 v113, v117, %[R1], %[K31]\n\t"                                               \
-  "v_and_b32 v137, v117, v135\n\t"                                                        \
-  "v_mad_i32_i24 v138, v137, v136, v134\n\t"                                              \
-  "v_lshl_or_b32 v139, %[M], 16, v117\n\t"                                                \
-  "global_store_dword %[VOFF], v139, %[RAW] offset:" #KOFF "\n\t"                         \
-  "v_cmp_eq_u32 vcc, 0, v113\n\t"                                                         \
-  "v_subbrev_co_u32 %[M], vcc, 0, v138, vcc\n\t"                                          \
-  "v_min_i32 %[MACC], %[MACC], %[M]\n\t"                                                  \
+  "v_or_b32 v139, v141, v117\n\t"                                                         \
+  TFC_PDEC_STORE(KOFF)                                                                    \
+  "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
+  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
   "v_cmp_eq_u32 vcc, 0, %[M]\n\t"                                                         \
-  SEL_EARLY                                                                               \
   "v_cndmask_b32 v140, 0, " #PWSTEP ", vcc\n\t"                                           \
   "v_add_u32 %[PW], %[PW], v140\n\t"                                                      \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                              \
-  SEL_LATE                                                                                \
+  TFC_PDEC_WAIT2                                                                          \
+  "v_cndmask_b32 %[R0], %[B0], v104, vcc\n\t"                                             \
+  "v_cndmask_b32 %[R1], %[B1], v105, vcc\n\t"                                             \
+  "v_cndmask_b32 %[R2], %[B2], v106, vcc\n\t"                                             \
+  "v_cndmask_b32 %[R3], %[B3], v107, vcc\n\t"                                             \
+  TFC_PDEC_WAIT3                                                                          \
   "v_mad_u64_u32 v[126:127], s[52:53], v122, %[S], v[122:123]\n\t"                        \
   "v_mad_u64_u32 v[128:129], s[52:53], v124, %[S], v[124:125]\n\t"                        \
   "v_alignbit_b32 v126, v127, v126, 16\n\t"                                               \
   "v_alignbit_b32 v128, v129, v128, 16\n\t"                                               \
   "v_add_u32 v128, -1, v128\n\t"                                                          \
   "v_min_u32 v128, v128, %[S]\n\t"                                                        \
-  "v_sub_u32 v130, %[D], v126\n\t"                                                        \
   "v_sub_u32 v131, v128, v126\n\t"                                                        \
-  "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
-  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
   "v_cmp_gt_u32 vcc, %[K64K], v131\n\t"                                                   \
-  "v_lshl_or_b32 v132, v130, 16, v109\n\t"                                                \
-  "v_cndmask_b32 %[D], v130, v132, vcc\n\t"                                               \
   "v_lshl_or_b32 v132, v131, 16, %[KFFFF]\n\t"                                            \
   "v_cndmask_b32 %[S], v131, v132, vcc\n\t"                                               \
-  "v_cndmask_b32 v132, 0, 2, vcc\n\t"                                                     \
-  "v_add_u32 %[CP], %[CP], v132\n\t"
-#define TFC_PDEC_SELECT                                                                   \
-  "v_cndmask_b32 %[R0], %[B0], v104, vcc\n\t"                                             \
-  "v_cndmask_b32 %[R1], %[B1], v105, vcc\n\t"                                             \
-  "v_cndmask_b32 %[R2], %[B2], v106, vcc\n\t"                                             \
-  "v_cndmask_b32 %[R3], %[B3], v107, vcc\n\t"
-// channel mode: the next directory entry is requested at the top of the step; index mode: the next element's row
-// address there, the entry itself once the address has arrived, and the select waits for it
-#define TFC_PDEC_STEP_CH(KOFF) TFC_PDEC_STEP(KOFF, "ds_read_b128 v[104:107], %[PW] offset:16\n\t", "", TFC_PDEC_SELECT, "", 16)
-#define TFC_PDEC_STEP_IX(KOFF) TFC_PDEC_STEP(KOFF, "ds_read_u16 v108, %[PW] offset:2\n\t", "ds_read_b128 v[104:107], v108\n\t", "", TFC_PDEC_SELECT, 2)
+  "v_sub_u32 v130, %[D], v126\n\t"                                                        \
+  "v_perm_b32 v132, v130, v109, %[PERM]\n\t"                                              \
+  "v_cndmask_b32 %[D], v130, v132, vcc\n\t"                                               \
+  "v_cndmask_b32 v133, 0, 2, vcc\n\t"
+// channel mode: the next directory entry is requested in the first shadow; index mode: the next element's row address
+// there, and the entry itself in front of the cdf entries, once the address has arrived
+#define TFC_PDEC_STEP_CH(KOFF) TFC_PDEC_STEP(KOFF, "ds_read_b128 v[104:107], %[PW] offset:16\n\t", 2, "", 16)
+#define TFC_PDEC_STEP_IX(KOFF) TFC_PDEC_STEP(KOFF, "ds_read_u16 v108, %[PW] offset:2\n\t", 1, "ds_read_b128 v[104:107], v108\n\t", 2)
+// a block: nothing pending from a step before it (v130 <= v131, v133 = 0), and the last step's pending flag and
+// cursor increment behind it
 #define TFC_PDEC_BLOCK(STEP)                                                              \
   "v_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t"                                           \
+  "v_mov_b32 v130, 0\n\tv_mov_b32 v131, 0\n\tv_mov_b32 v133, 0\n\t"                       \
   STEP(0) STEP(256) STEP(512) STEP(768) STEP(1024) STEP(1280) STEP(1536) STEP(1792)       \
-  STEP(2048) STEP(2304) STEP(2560) STEP(2816) STEP(3072) STEP(3328) STEP(3584) STEP(3840)
+  STEP(2048) STEP(2304) STEP(2560) STEP(2816) STEP(3072) STEP(3328) STEP(3584) STEP(3840) \
+  "v_add_u32 %[CP], %[CP], v133\n\t"                                                      \
+  "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
+  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"
 
 template <bool INDEXED>
 __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, const LaneArgs la, const PipeDecArgs pa) {
   extern __shared__ unsigned char lanes_lds[];
   lanes_load_image(lanes_lds, la);
   using L = PipeDecLds;
+  {
+    // This kernel's form of a directory entry's info word (its LDS copy only; the image on the device is shared with
+    // the lane-per-stream kernels):  limit | has_escape << 15 | ESCLO << 16,  ESCLO = the escape symbol's lower bound on
+    // the tables' own scale (0xFFFF, which no quotient reaches at precision <= 15, for a row without one; 2^(p-1) for
+    // the binary row behind the repeated entries: there the comparison q >= ESCLO is the decoded bit).
+    const unsigned int entries = static_cast<unsigned int>(la.ntab) + kLaneDirRepeat + 1u;
+    for (unsigned int i = threadIdx.x; i < entries; i += blockDim.x) {
+      LaneRow* e = reinterpret_cast<LaneRow*>(lanes_lds) + i;
+      const unsigned int info = e->info, limit = info & 0x7FFFu, esc = info >> 31;
+      unsigned int esclo = 0xFFFFu;
+      if (i + 1u == entries) esclo = 1u << (la.precision - 1);
+      else if (esc) esclo = lds_u16(lanes_lds, e->cdf + 2u * limit + 2u) >> (16 - la.precision);
+      e->info = limit | (esc << 15) | (esclo << 16);
+    }
+    __syncthreads();
+  }
 
   const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
   if (threadIdx.x == 0u) __hip_atomic_fetch_add(pa.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1160,10 +1213,18 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
     iw.base = 0u;
   }
 
+  // Raw entries of a block are collected in LDS and leave as whole lines in the NEXT memory phase, in front of its
+  // window requests: a store issued inside the block sat between the window's loads and the wait for them (vmcnt counts
+  // both in order), so every block waited for its own sixteen stores to reach memory (~110 cycles per row outside the
+  // hand-scheduled steps, tools/chain_clock_probe.py on a TFC_PDEC_TIMING build), and a store cost its step ~20 cycles.
+  const unsigned int stg_off = wave_off + (INDEXED ? L::kBytes : L::kRows);
+  const unsigned int stg = stg_off + 4u * lane;
+  bool staged = false;               // wave-uniform: the staging area holds the rows staged_k ... + kPipeBlock
+  unsigned int staged_k = 0u;
+
   const float scale = static_cast<float>(1u << la.precision);
   float hscale = 0.5f * scale;
-  unsigned int k31 = 0x80000000u;
-  asm volatile("" : "+v"(hscale), "+v"(k31));
+  asm volatile("" : "+v"(hscale));
   const unsigned int cp_max = (1u << la.precision) - 1u;
   const unsigned int dir_end = 16u * static_cast<unsigned int>(la.ntab);
   // the built-in binary row: directory entry behind the repeated ones
@@ -1179,8 +1240,17 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
 
   unsigned int* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
   unsigned int* const posrec = pa.posrec + static_cast<size_t>(gi) * (pa.rows / kPipeBlock + 1) * 64 + lane;
-  const unsigned int voff = 4u * lane;
   unsigned int k = 0u;               // rows written
+  auto flush = [&]() {
+    if (!staged) return;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(raw + static_cast<size_t>(staged_k) * 64) + 16u * lane;
+#pragma unroll
+    for (unsigned int j = 0; j < L::kStage / 1024u; ++j) {
+      const uint4 v = *reinterpret_cast<const uint4*>(lanes_lds + stg_off + 1024u * j + 16u * lane);
+      lanes_gstore16(dst + 1024u * j, make_uint2(v.x, v.y), make_uint2(v.z, v.w));
+    }
+    staged = false;
+  };
 
   // the row of element `pos` (channel mode: pw is kept inside the directory)
   auto load_row = [&]() {
@@ -1207,7 +1277,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         unsigned int A = scale16(s1, lo);
         unsigned int b = scale16(s1, hi) - 1u;
         b = hi == 0u ? s1 : b;
-        const unsigned int nsym = (R.y & 0x7FFFFFFFu) + (R.y >> 31);
+        const unsigned int nsym = (R.y & 0x7FFFu) + ((R.y >> 15) & 1u);
         for (int fix = 0; fix < 4; ++fix) {
           if (D - A > b - A) {
             if (D < A) sym = sym > 0u ? sym - 1u : 0u;
@@ -1226,7 +1296,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
         cp += ren ? 2u : 0u;
         entry = sym;
-        M = sym == (R.y ^ 0x80000000u) ? -1 : 0;
+        M = ((R.y >> 15) & 1u) != 0u && sym == (R.y & 0x7FFFu) ? -1 : 0;
       } else {
         // ---- one bit of an Elias-gamma code (range_coder_kernels.cc:449-471): the uniform binary cdf at
         // precision 1 needs no table ------------------------------------------------------------------
@@ -1266,12 +1336,29 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   // kPipeSkipRow.  Then the tail: every lane's last elements (fewer than a block each, plus their escape bits) with
   // the generic steps, all lanes together — so that the wave does not drop to the generic steps for as long as its
   // lanes are spread out, only for one short pass at the end.
-  bool gave_up = false;
-  while (__any(pos < elems)) {
-    if (k + kPipeBlock > static_cast<unsigned int>(pa.rows)) {
-      gave_up = true;                // more rows than planned for (escape codes far beyond the tables' tail mass)
-      break;
+#if TFC_PDEC_TIMING
+  // (measurement aid, tools/chain_clock_probe.py: cycles inside the hand-scheduled blocks / their number)
+  unsigned long long t_asm = 0ull, n_asm = 0ull, t_commit = 0ull, t_rest = 0ull, t_steady = 0ull;
+#endif
+  // memory phase of a block: park the windows requested at the previous phase, send the previous block's raw rows off,
+  // request the windows from the current positions
+  auto memory_phase = [&]() __attribute__((always_inline)) {
+#if TFC_PDEC_TIMING
+    const unsigned long long tm0 = clock64();
+#endif
+    const unsigned int cpos = cw.base + (cp - cw_off);
+    cw.commit();
+    cp = cw_off + (cpos - cw.base);
+    if (INDEXED) {
+      iw.commit();
+      pw = iw_off + (2u * pos - iw.base);
     }
+#if TFC_PDEC_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long tm1 = clock64();
+    t_commit += tm1 - tm0;
+#endif
+    flush();
     if (k != 0u && (k / kPipeBlock) % kPipeRelease == 0u) {
       // the rows so far (and their block records) to the parse running next to this kernel: a release costs the wave a
       // wait for its stores, so it is rare
@@ -1279,20 +1366,76 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       if (lane == 0u) __hip_atomic_store(&pa.progress[gi], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    {
-      // memory phase: park the windows requested at the previous phase, request from the current positions
-      const unsigned int cpos = cw.base + (cp - cw_off);
-      cw.commit();
-      cp = cw_off + (cpos - cw.base);
-      cw.request(cpos);
-      if (INDEXED) {
-        iw.commit();
-        pw = iw_off + (2u * pos - iw.base);
-        iw.request(2u * pos);
+    cw.request(cpos);
+    if (INDEXED) iw.request(2u * pos);
+    // elements STARTED before row k (an escape code in progress has its first row behind us)
+    posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos + (M != 0 ? 1u : 0u);
+#if TFC_PDEC_TIMING
+    t_rest += clock64() - tm1;
+#endif
+  };
+  // kPipeBlock hand-scheduled steps of the lanes in EXEC
+  auto fast_block = [&](unsigned int& flag, int& macc) __attribute__((always_inline)) {
+#define TFC_PDEC_OPERANDS                                                                                              \
+        : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [M] "+v"(M), [PW] "+v"(pw), [FLAG] "+v"(flag), [MACC] "+v"(macc), \
+          [R0] "+v"(R.x), [R1] "+v"(R.y), [R2] "+v"(R.z), [R3] "+v"(R.w)                                              \
+        : [STG] "v"(stg), [B0] "v"(bin.x), [B1] "v"(bin.y), [B2] "v"(bin.z), [B3] "v"(bin.w),       \
+          [SCALE] "s"(scale), [HSCALE] "v"(hscale), [QMAX] "s"(cp_max),                                               \
+          [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x05040001u)                                         \
+        : "vcc", "memory", "s52", "s53", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
+          "v114", "v115", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",      \
+          "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v139", "v140", "v141"
+#if TFC_PDEC_TIMING
+    const unsigned long long ta = clock64();
+#endif
+    if constexpr (INDEXED) asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
+    else asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_CH) TFC_PDEC_OPERANDS);
+#if TFC_PDEC_TIMING
+    t_asm += clock64() - ta;
+    ++n_asm;
+#endif
+#undef TFC_PDEC_OPERANDS
+  };
+  bool gave_up = false;
+  while (__any(pos < elems)) {
+    // Steady state — every stream of the wave has a whole block of elements left — as a loop of its own: a memory
+    // phase, a hand-scheduled block, three wave-wide tests.  (Round 4 ran these blocks through the general body below,
+    // whose tests, state copies and branches for lanes that sit out, finish an escape code or take generic steps cost
+    // ~1 900 cycles per block of ~4 800 — tools/chain_clock_probe.py on a TFC_PDEC_TIMING build.)  Anything else — the
+    // first block, a lane near its end, a failed verification, a plane that runs out — leaves it for the general body;
+    // a block that fails here is repeated there from its saved state (its memory phase once more: the same requests).
+    if (lds0 == 0u && row_loaded && (INDEXED || static_cast<unsigned int>(la.ntab) >= kPipeBlock)) {
+#if TFC_PDEC_TIMING
+      const unsigned long long ts0 = clock64();
+#endif
+      while (__all(!live || pos + kPipeBlock <= elems) && k + kPipeBlock <= static_cast<unsigned int>(pa.rows)) {
+        memory_phase();
+        const unsigned int D0 = D, s10 = s1, cp0 = cp, pw0 = pw;
+        const int M0 = M;
+        const uint4 R0 = R;
+        unsigned int flag = 0u;
+        int macc = 0;
+        if (live) fast_block(flag, macc);
+        if (__builtin_expect(__any(live && (flag != 0u || macc <= -32)), 0)) {
+          D = D0; s1 = s10; cp = cp0; pw = pw0; M = M0; R = R0;
+          break;
+        }
+        pos += (pw - pw0) / (INDEXED ? 2u : 16u);
+        if (!INDEXED) pw -= pw >= dir_end ? dir_end : 0u;      // (a block is at most one turn of the directory: ntab >= kPipeBlock)
+        staged = true;
+        staged_k = k;
+        k += kPipeBlock;
       }
-      // elements STARTED before row k (an escape code in progress has its first row behind us)
-      posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos + (M != 0 ? 1u : 0u);
+#if TFC_PDEC_TIMING
+      t_steady += clock64() - ts0;
+#endif
+      if (!__any(pos < elems)) break;
     }
+    if (k + kPipeBlock > static_cast<unsigned int>(pa.rows)) {
+      gave_up = true;                // more rows than planned for (escape codes far beyond the tables' tail mass)
+      break;
+    }
+    memory_phase();
     if (!row_loaded) {
       if (M == 0) load_row(); else R = bin;
       row_loaded = true;
@@ -1312,37 +1455,21 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
       continue;
     }
     const bool busy = blocks ? whole : pos < elems;
-    if (blocks && __any(!whole && pos < elems)) {
-      if (!whole && pos < elems) {
-#pragma unroll
-        for (unsigned int i = 0; i < kPipeBlock; ++i) raw[static_cast<size_t>(k + i) * 64 + lane] = kPipeSkipRow;
-      }
-    }
+    const bool sitting = blocks && !whole && pos < elems;      // this lane sits the block out
     if (__builtin_expect(lds0 == 0u && blocks, 1)) {
+      if (__any(sitting)) {
+        if (sitting) {
+#pragma unroll
+          for (unsigned int i = 0; i < kPipeBlock; ++i) *reinterpret_cast<unsigned int*>(lanes_lds + stg + 256u * i) = kPipeSkipRow;
+        }
+      }
       const unsigned int D0 = D, s10 = s1, cp0 = cp, pw0 = pw;
       const int M0 = M;
       const uint4 R0 = R;
       unsigned int flag = 0u;
       int macc = 0;
       if (busy) {
-        // (the plane's address is the same for every lane; hipcc cannot see that through threadIdx.x >> 6)
-        const unsigned long long rawa = reinterpret_cast<unsigned long long>(raw + static_cast<size_t>(k) * 64);
-        // (readfirstlane returns int: through unsigned, or a low half with bit 31 set smears into the high half)
-        const unsigned int rawlo = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned int>(rawa)));
-        const unsigned int rawhi = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned int>(rawa >> 32)));
-        const unsigned long long rawk = static_cast<unsigned long long>(rawlo) | (static_cast<unsigned long long>(rawhi) << 32);
-#define TFC_PDEC_OPERANDS                                                                                              \
-            : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [M] "+v"(M), [PW] "+v"(pw), [FLAG] "+v"(flag), [MACC] "+v"(macc), \
-              [R0] "+v"(R.x), [R1] "+v"(R.y), [R2] "+v"(R.z), [R3] "+v"(R.w)                                              \
-            : [VOFF] "v"(voff), [RAW] "s"(rawk), [B0] "v"(bin.x), [B1] "v"(bin.y), [B2] "v"(bin.z), [B3] "v"(bin.w),       \
-              [SCALE] "s"(scale), [HSCALE] "v"(hscale), [QMAX] "s"(cp_max), [K31] "v"(k31),                               \
-              [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u)                                         \
-            : "vcc", "memory", "s52", "s53", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
-              "v114", "v115", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",      \
-              "v129", "v130", "v131", "v132", "v134", "v135", "v136", "v137", "v138", "v139", "v140"
-        if constexpr (INDEXED) asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
-        else asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_CH) TFC_PDEC_OPERANDS);
-#undef TFC_PDEC_OPERANDS
+        fast_block(flag, macc);
       }
       if (__builtin_expect(!__any(flag != 0u || macc <= -32), 1)) {
         if (busy) {
@@ -1351,15 +1478,23 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         // (fewer tables than rows in a block: the directory cursor wraps more than once)
         if (!INDEXED)
           while (__any(busy && pw >= dir_end)) pw -= pw >= dir_end ? dir_end : 0u;
+        staged = true;
+        staged_k = k;
         k += kPipeBlock;
         continue;
       }
       D = D0; s1 = s10; cp = cp0; pw = pw0; M = M0; R = R0;      // an exception somewhere in the wave: the generic steps
     }
+    if (sitting) {
+      // (the generic steps store their rows themselves: so do the lanes that sit them out)
+#pragma unroll
+      for (unsigned int i = 0; i < kPipeBlock; ++i) raw[static_cast<size_t>(k + i) * 64 + lane] = kPipeSkipRow;
+    }
 #pragma nounroll
     for (unsigned int i = 0; i < kPipeBlock; ++i) gstep(busy && pos < elems, k + i);
     k += kPipeBlock;
   }
+  flush();
   posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos;
   if (gave_up) {
     if (lane == 0) {
@@ -1374,6 +1509,11 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   if (gi == 0 && lane == 0) {
     g_pipe_clock[2] = clock64() - clk0;
     g_pipe_clock[3] = wall_clock64() - wall0;
+#if TFC_PDEC_TIMING
+    g_pipe_clock[4] = t_steady;
+    g_pipe_clock[5] = t_asm | (t_commit << 32);
+    g_pipe_clock[7] = n_asm | (static_cast<unsigned long long>(k) << 16) | (t_rest << 32);
+#endif
   }
   if (live) {
     // back to the (base, span - 1, window, digits pulled) form shared with the other kernels

@@ -13,6 +13,10 @@ dev = torch.device("cuda", 0)
 lookup = bench.build_tables(dev)
 lt = torch.from_numpy(lookup)
 vals = [bench.sample_symbols_device(lookup, k, dev) for k in range(20)]
+if os.environ.get("IDENTICAL_STREAMS"):
+    # every stream of a batch the same symbols: the 64 lanes of a chain wave read the same LDS addresses (broadcasts,
+    # no bank conflicts) — what the random rows' conflicts cost a step
+    vals = [v[:1].expand_as(v).contiguous() for v in vals]
 for rep in range(3):
     res = bench.step_group(lt, vals, "throughput")
     torch.cuda.synchronize()
@@ -23,4 +27,12 @@ for rep in range(3):
           "enc chain: %.3f ms at %.0f MHz;" % (e_w / 1e5, 100.0 * e_c / max(e_w, 1)),
           "dec chain: %.3f ms at %.0f MHz;" % (d_w / 1e5, 100.0 * d_c / max(d_w, 1)),
           "enc chain waited %.3f ms for call words, %.3f ms for digit slots" % (waited / 2.4e6, stalled / 2.4e6), flush=True)
+    if out[5]:
+        blocks, rows, t_rest = int(out[7]) & 0xFFFF, (int(out[7]) >> 16) & 0xFFFF, int(out[7]) >> 32
+        t_asm, t_commit = int(out[5]) & 0xFFFFFFFF, int(out[5]) >> 32
+        print("   dec chain (build with -DTFC_PDEC_TIMING=1): %d rows, %d hand-scheduled blocks, %.1f cycles per row inside them, %.1f per row over the kernel; "
+              "memory phases: %.0f cycles per block waiting for + parking the windows, %.0f flush + requests"
+              % (rows, blocks, t_asm / max(16 * blocks, 1), d_c / max(rows, 1), t_commit / max(blocks, 1), t_rest / max(blocks, 1)), flush=True)
+        print("   of %.2f M cycles: %.2f M in the steady-state loop (out[4]; the encoder's wait for call words in an untimed build), %d blocks more than rows / 16"
+              % (d_c / 1e6, int(out[4]) / 1e6, blocks - rows // 16), flush=True)
     del res
