@@ -7,6 +7,6 @@ if [ -z "${SKIP_BASE:-}" ]; then echo "== base"; run; fi
 for v in ab/*/; do
   [ -f $v/libtfc_hip.so ] || continue
   cp $v/libtfc_hip.so compression_amd/libtfc_hip.so
-  echo "== $(basename $v)"; LINES=2 run
+  echo "== $(basename $v)"; LINES=3 run
 done
 cp /tmp/libtfc_hip.keep compression_amd/libtfc_hip.so
