@@ -33,6 +33,12 @@
 // kernel of range_lanes.h is launched behind them under that flag (LaneArgs::guard) and codes the job.
 #pragma once
 
+// TFC_PIPE_TIMING (build switch, tools/chain_clock_probe.py): the chain waves time their waits and their hand-scheduled
+// blocks (g_pipe_clock); off in the shipped library — a clock read is an s_memtime and a wait for it.
+#ifndef TFC_PIPE_TIMING
+#define TFC_PIPE_TIMING 0
+#endif
+
 namespace tfc {
 
 constexpr int kPipeTile = 256;        // symbols of a stream per expansion workgroup
@@ -364,7 +370,13 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 struct PipeEncChainLds {
   static constexpr unsigned int kRows = 2 * kPipeBlock;      // rows per iteration: two hand-scheduled blocks
   static constexpr unsigned int kSlots = 2;                  // iterations of call words in LDS (one per loader; each has its next one in registers)
-  static constexpr unsigned int kDigSlots = 2;               // iterations of digits the storer may be behind
+  // iterations of digits the storer may be behind: 3 (round 5; 2 before: beside the expansion the chain waited 0.8 ms
+  // of 4.7 for a free digit slot — the storer's stores queue behind the expansion's — 0.48 with 3; a fourth does not
+  // fit the CU's LDS beside four groups)
+#ifndef TFC_ENC_DIGSLOTS
+#define TFC_ENC_DIGSLOTS 3
+#endif
+  static constexpr unsigned int kDigSlots = TFC_ENC_DIGSLOTS;
   static constexpr unsigned int kDigits = 2 * kRows + 16;    // digit bytes of a lane and iteration: one digit per call at most, and
                                                              // room for runs of 0xFFFF digits that settle (longer: the fallback)
   static constexpr int kCallStride = 4 * kRows + 16;         // a lane's words of an iteration, 16-byte accesses without bank conflicts
@@ -386,8 +398,6 @@ struct PipeEncChainLds {
   static constexpr unsigned int kLast = 0x80000000u, kBail = 0x40000000u;
 };
 static_assert(PipeEncChainLds::kGroups * PipeEncChainLds::kGroup <= 160 * 1024 && PipeEncChainLds::kSlots <= 3, "a chain workgroup's LDS");
-// (a model step's few groups go out one group per workgroup: it has to fit in beside two 64 KB convolution workgroups)
-static_assert(PipeEncChainLds::kGroup <= 32 * 1024, "a one-group chain workgroup next to the convolutions");
 struct PipeChainJob { uint4* state; uint8_t* chunk; unsigned int* chunk_len; unsigned int* overflow_flag; };
 struct PipeChainJobs {
   int64_t streams;
@@ -655,13 +665,19 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
     }
   };
   // -> the slot's sequence word once it holds iteration b (or the helper has given up)
+  // (the two waits are timed in TFC_PIPE_TIMING builds only — tools/chain_clock_probe.py: four clock reads per iteration
+  // are ~7 cycles per row of a 177-cycle row)
   unsigned long long waited_words = 0, waited_digits = 0;
   auto wait_words = [&](unsigned int b) {
     unsigned int v;
+#if TFC_PIPE_TIMING
     const unsigned long long c0 = clock64();
+#endif
     while ((((v = sync[L::kSeq + b % L::kSlots]) & ~(L::kLast | L::kBail)) != b + 1u) && !(v & L::kBail)) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
+#if TFC_PIPE_TIMING
     waited_words += clock64() - c0;
+#endif
     return v;
   };
 
@@ -674,9 +690,13 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
     read_words(wb, b % L::kSlots, 1u);
     // the digit slot of this iteration: free once the helper has stored the iteration that used it before
     {
+#if TFC_PIPE_TIMING
       const unsigned long long c0 = clock64();
+#endif
       while (sync[L::kDigDone] + L::kDigSlots <= b) __builtin_amdgcn_s_sleep(1);
+#if TFC_PIPE_TIMING
       waited_digits += clock64() - c0;
+#endif
     }
     const unsigned int dslot = b % L::kDigSlots;
     dstage = area + L::kDig + dslot * L::kDigSlot + L::kDigStride * lane;
@@ -1041,9 +1061,6 @@ struct PipeDecLds {
 #ifndef TFC_PDEC_ABL
 #define TFC_PDEC_ABL 0
 #endif
-#ifndef TFC_PDEC_TIMING
-#define TFC_PDEC_TIMING 0
-#endif
 // A step's raw entry goes to the wave's staging area in LDS ([row of the block][lane], flushed by the memory phase).
 #if TFC_PDEC_ABL & 1
 #define TFC_PDEC_STORE(KOFF)
@@ -1227,7 +1244,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   // Raw entries of a block are collected in LDS and leave as whole lines in the NEXT memory phase, in front of its
   // window requests: a store issued inside the block sat between the window's loads and the wait for them (vmcnt counts
   // both in order), so every block waited for its own sixteen stores to reach memory (~110 cycles per row outside the
-  // hand-scheduled steps, tools/chain_clock_probe.py on a TFC_PDEC_TIMING build), and a store cost its step ~20 cycles.
+  // hand-scheduled steps, tools/chain_clock_probe.py on a TFC_PIPE_TIMING build), and a store cost its step ~20 cycles.
   const unsigned int stg_off = wave_off + (INDEXED ? L::kBytes : L::kRows);
   const unsigned int stg = stg_off + 4u * lane;
   bool staged = false;               // wave-uniform: the staging area holds the rows staged_k ... + kPipeBlock
@@ -1352,14 +1369,14 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   // kPipeSkipRow.  Then the tail: every lane's last elements (fewer than a block each, plus their escape bits) with
   // the generic steps, all lanes together — so that the wave does not drop to the generic steps for as long as its
   // lanes are spread out, only for one short pass at the end.
-#if TFC_PDEC_TIMING
+#if TFC_PIPE_TIMING
   // (measurement aid, tools/chain_clock_probe.py: cycles inside the hand-scheduled blocks / their number)
-  unsigned long long t_asm = 0ull, n_asm = 0ull, t_commit = 0ull, t_rest = 0ull, t_steady = 0ull;
+  unsigned long long t_asm = 0ull, n_asm = 0ull, t_commit = 0ull, t_rest = 0ull;
 #endif
   // memory phase of a block: park the windows requested at the previous phase, send the previous block's raw rows off,
   // request the windows from the current positions
   auto memory_phase = [&]() __attribute__((always_inline)) {
-#if TFC_PDEC_TIMING
+#if TFC_PIPE_TIMING
     const unsigned long long tm0 = clock64();
 #endif
     const unsigned int cpos = cw.base + (cp - cw_off);
@@ -1369,7 +1386,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
       iw.commit();
       pw = iw_off + (2u * pos - iw.base);
     }
-#if TFC_PDEC_TIMING
+#if TFC_PIPE_TIMING
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long tm1 = clock64();
     t_commit += tm1 - tm0;
@@ -1386,7 +1403,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
     if (INDEXED) iw.request(2u * pos);
     // elements STARTED before row k (an escape code in progress has its first row behind us)
     posrec[static_cast<size_t>(k / kPipeBlock) * 64] = pos + (M != 0 ? 1u : 0u);
-#if TFC_PDEC_TIMING
+#if TFC_PIPE_TIMING
     t_rest += clock64() - tm1;
 #endif
   };
@@ -1400,12 +1417,12 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         : "vcc", "memory", "s52", "s53", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
           "v114", "v115", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",      \
           "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v142"
-#if TFC_PDEC_TIMING
+#if TFC_PIPE_TIMING
     const unsigned long long ta = clock64();
 #endif
     if constexpr (INDEXED) asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
     else asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_CH) TFC_PDEC_OPERANDS);
-#if TFC_PDEC_TIMING
+#if TFC_PIPE_TIMING
     t_asm += clock64() - ta;
     ++n_asm;
 #endif
@@ -1425,13 +1442,10 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
     // Steady state — every stream of the wave has a whole block of elements left — as a loop of its own: a memory
     // phase, a hand-scheduled block, three wave-wide tests.  (Round 4 ran these blocks through the general body below,
     // whose tests, state copies and branches for lanes that sit out, finish an escape code or take generic steps cost
-    // ~1 900 cycles per block of ~4 800 — tools/chain_clock_probe.py on a TFC_PDEC_TIMING build.)  Anything else — the
+    // ~1 900 cycles per block of ~4 800 — tools/chain_clock_probe.py on a TFC_PIPE_TIMING build.)  Anything else — the
     // first block, a lane near its end, a failed verification, a plane that runs out — leaves it for the general body;
-    // a block that fails here is repeated there from its saved state (its memory phase once more: the same requests).
+    // a block whose verification fails is repeated on the spot, step by step.
     if (lds0 == 0u && row_loaded && (INDEXED || static_cast<unsigned int>(la.ntab) >= kPipeBlock)) {
-#if TFC_PDEC_TIMING
-      const unsigned long long ts0 = clock64();
-#endif
       // (M > -16: a lane's unary prefix cannot reach its 31st zero — where the reference stops counting — inside a block)
       while (__all(!live || (pos + kPipeBlock <= elems && M > -16)) && k + kPipeBlock <= static_cast<unsigned int>(pa.rows)) {
         memory_phase();
@@ -1471,9 +1485,6 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         staged_k = k;
         k += kPipeBlock;
       }
-#if TFC_PDEC_TIMING
-      t_steady += clock64() - ts0;
-#endif
       if (!__any(pos < elems)) break;
     }
     if (k + kPipeBlock > static_cast<unsigned int>(pa.rows)) {
@@ -1553,8 +1564,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   if (gi == 0 && lane == 0) {
     g_pipe_clock[2] = clock64() - clk0;
     g_pipe_clock[3] = wall_clock64() - wall0;
-#if TFC_PDEC_TIMING
-    g_pipe_clock[4] = t_steady;
+#if TFC_PIPE_TIMING
     g_pipe_clock[5] = t_asm | (t_commit << 32);
     g_pipe_clock[7] = n_asm | (static_cast<unsigned long long>(k) << 16) | (t_rest << 32);
 #endif

@@ -26,13 +26,12 @@ for rep in range(3):
     print("overlap", os.environ.get("TFC_PIPE_OVERLAP", "default"), "rep", rep,
           "enc chain: %.3f ms at %.0f MHz;" % (e_w / 1e5, 100.0 * e_c / max(e_w, 1)),
           "dec chain: %.3f ms at %.0f MHz;" % (d_w / 1e5, 100.0 * d_c / max(d_w, 1)),
-          "enc chain waited %.3f ms for call words, %.3f ms for digit slots" % (waited / 2.4e6, stalled / 2.4e6), flush=True)
+          "enc chain waited %.3f ms for call words, %.3f ms for digit slots (0: not a TFC_PIPE_TIMING build)" % (waited / 2.4e6, stalled / 2.4e6), flush=True)
     if out[5]:
         blocks, rows, t_rest = int(out[7]) & 0xFFFF, (int(out[7]) >> 16) & 0xFFFF, int(out[7]) >> 32
         t_asm, t_commit = int(out[5]) & 0xFFFFFFFF, int(out[5]) >> 32
-        print("   dec chain (build with -DTFC_PDEC_TIMING=1): %d rows, %d hand-scheduled blocks, %.1f cycles per row inside them, %.1f per row over the kernel; "
+        print("   dec chain (build with -DTFC_PIPE_TIMING=1): %d rows, %d hand-scheduled blocks, %.1f cycles per row inside them, %.1f per row over the kernel; "
               "memory phases: %.0f cycles per block waiting for + parking the windows, %.0f flush + requests"
               % (rows, blocks, t_asm / max(16 * blocks, 1), d_c / max(rows, 1), t_commit / max(blocks, 1), t_rest / max(blocks, 1)), flush=True)
-        print("   of %.2f M cycles: %.2f M in the steady-state loop (out[4]; the encoder's wait for call words in an untimed build), %d blocks more than rows / 16"
-              % (d_c / 1e6, int(out[4]) / 1e6, blocks - rows // 16), flush=True)
+        print("   %d blocks more than rows / 16 (repeated step by step)" % (blocks - rows // 16), flush=True)
     del res
