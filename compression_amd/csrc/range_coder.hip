@@ -2711,7 +2711,7 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   // (+ the blocks lanes sit out or spend finishing an escape code before the wave's tail pass, and the tail pass)
   const int64_t rows64 = ((elems + (t->any_escape ? elems / 4 + 64 + 24 * kPipeBlock : 2 * kPipeBlock)) + kPipeBlock - 1) / kPipeBlock * kPipeBlock;
   pa.rows = static_cast<int>(std::min<int64_t>(rows64, (int64_t{1} << 30)));
-  const size_t raw_bytes = static_cast<size_t>(pa.rows) * 256;
+  const size_t raw_bytes = static_cast<size_t>(pa.rows) * 128;      // 16-bit entries, 64 lanes
   const size_t rec_bytes = (static_cast<size_t>(pa.rows) / kPipeBlock + 1) * 256;
   const size_t group_bytes = raw_bytes + rec_bytes + 64 * sizeof(uint4) + sizeof(unsigned int);
   const size_t job_bytes = group_bytes * pa.groups_per_job + (indexed ? 2 * static_cast<size_t>(streams) * elems : 0);
@@ -2767,7 +2767,7 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
         break;
       }
       uint8_t* base = temp.as<uint8_t>();
-      pa.raw = reinterpret_cast<unsigned int*>(base);
+      pa.raw = reinterpret_cast<unsigned short*>(base);
       pa.posrec = reinterpret_cast<unsigned int*>(base + raw_all);
       pa.state_out = reinterpret_cast<uint4*>(base + raw_all + rec_all);
       pa.kend = reinterpret_cast<unsigned int*>(base + raw_all + rec_all + st_all);

@@ -981,10 +981,21 @@ __global__ void __launch_bounds__(64) enc_commit_kernel(const PipeChainJobs jobs
 
 // Raw-plane entry of a row in which a lane made no step (it waits for the wave's tail phase, see dec_chain_kernel):
 // not the start of an element, and skipped when an escape code's bit rows are collected
-constexpr unsigned int kPipeSkipRow = 0x7FFF0000u;
+constexpr unsigned int kPipeSkipRow = 0xFFFFu;
+// A row's entry, 16 bits (round 5; 32 before: the raw plane was the largest intermediate of a decode launch):
+//   element rows (M = 0)   the symbol (< 2^15: rows of at most 32 767 symbols take these kernels)
+//   bit rows (M != 0)      0x8000 | bit — the mode counter itself is not stored: dec_parse_kernel walks a code's bit rows
+//                          in order and steps the counter as the chain did (pipe_mode_step)
+//   kPipeSkipRow           0xFFFF (a bit row's low bits are 0 or 1)
+__device__ inline unsigned int pipe_raw_entry(unsigned int sym_or_bit, int M) { return (M != 0 ? 0x8000u : 0u) | sym_or_bit; }
+// the mode counter behind a bit row (see TFC_PDEC_STEP): M < 0 unary prefix, -M - 1 zeros seen; M > 0 calls to go
+__device__ inline int pipe_mode_step(int M, unsigned int bit) {
+  if (M < 0) return bit ? -M : (M == -31 ? 32 : M - 1);      // the 31st zero: the prefix ends here (range_lanes.h, bit_step)
+  return M - 1;
+}
 
 struct PipeDecArgs {
-  unsigned int* raw;             // [group][row][lane]: symbol | M << 16 of every step (M: see dec_chain_kernel)
+  unsigned short* raw;           // [group][row][lane]: every step's entry (pipe_raw_entry; M: see dec_chain_kernel)
   unsigned int* posrec;          // [group][block + 1][lane]: elements started before the block
   unsigned int* kend;            // [group]: rows written (a multiple of kPipeBlock)
   uint4* state_out;              // [group][lane]: successor state, committed by dec_parse_kernel
@@ -1040,7 +1051,7 @@ struct PipeDecLds {
   static constexpr int kRows = kCodes + 64 * kStride;
   static constexpr int kBytes = kRows + 64 * kStride;
   // behind the windows (channel mode: behind the code window): the raw entries of a block, [row][lane] dwords
-  static constexpr int kStage = kPipeBlock * 256;
+  static constexpr int kStage = kPipeBlock * 128;
 };
 
 // ---- one decoder step of every lane, hand-scheduled -------------------------------------------------
@@ -1066,7 +1077,7 @@ struct PipeDecLds {
 #define TFC_PDEC_STORE(KOFF)
 #define TFC_PDEC_WAIT2 "s_waitcnt lgkmcnt(1)\n\t"
 #else
-#define TFC_PDEC_STORE(KOFF) "ds_write_b32 %[STG], v139 offset:" #KOFF "\n\t"
+#define TFC_PDEC_STORE(KOFF) "ds_write_b16 %[STG], v139 offset:" #KOFF "\n\t"
 #define TFC_PDEC_WAIT2 "s_waitcnt lgkmcnt(2)\n\t"
 #endif
 // Round 5: the schedule of a step.  The wave issues one instruction per ~4.3 cycles whatever it is, and the two LDS
@@ -1087,10 +1098,12 @@ struct PipeDecLds {
 // With these the step is bound by its instruction count (298 cycles for 61 slots, the LDS waits nearly gone), so:
 // the ROW of the next step is one LDS read of the directory entry at the SELECTED address (M' = 0: the next element's
 // entry, else the binary row's) straight into v104-v107, where a block keeps the current row — instead of a
-// speculative read of the next entry and four selects; the raw entry is one v_perm of the symbol and the mode counter
-// the step came in with (the counter alternates between two registers, MI -> MO, so that the old value is still there
-// when the symbol arrives); and the "31 zeros in a prefix" test (damaged input) is the caller's, once per block: a lane
-// that enters a block with M > -16 cannot get to -32 inside it.
+// speculative read of the next entry and four selects; the raw entry (16 bits, pipe_raw_entry) is the symbol or'd with
+// v143 = 0x8000 where the step came in with M != 0, kept from the previous step's M' = 0 test (one more select; the mode
+// counter alternates between two registers, MI -> MO); and the "31 zeros in a prefix" test (damaged input) is the
+// caller's, once per block: a lane that enters a block with M > -16 cannot get to -32 inside it.  (Every instruction
+// counts, also in a shadow: with the entry as 0x8000 | (M & 0x7F) << 1 | bit — four instructions more in the second
+// shadow — the step took 305 cycles instead of 288.)
 // LDS operations of a step, in issue order (they complete in order): bitmap word, count | (index mode: next row
 // address) digit | cdf lo, cdf hi, the raw entry's write, the next step's row.
 #define TFC_PDEC_STEP(KOFF, MI, MO, AHEAD, NEXT, PWSTEP)                                    \
@@ -1129,9 +1142,10 @@ struct PipeDecLds {
   "v_lshl_add_u32 v112, v117, 1, v104\n\t"                                                \
   "ds_read_u16 v122, v112 offset:2\n\t"                                                   \
   "ds_read_u16 v124, v112 offset:4\n\t"                                                   \
-  "v_perm_b32 v139, " MI ", v117, %[PERME]\n\t"                                           \
+  "v_or_b32 v139, v143, v117\n\t"                                                         \
   TFC_PDEC_STORE(KOFF)                                                                    \
   "v_cmp_eq_u32 vcc, 0, " MO "\n\t"                                                       \
+  "v_cndmask_b32_e64 v143, %[K8000], 0, vcc\n\t"                                              \
   "v_add_u32 v140, " #PWSTEP ", %[PW]\n\t"                                                \
   "v_cndmask_b32 %[PW], %[PW], v140, vcc\n\t"                                             \
   "v_cndmask_b32 v142, %[BINROW], " NEXT ", vcc\n\t"                                      \
@@ -1161,7 +1175,8 @@ struct PipeDecLds {
 #define TFC_PDEC_BLOCK_HEAD                                                               \
   "v_mov_b32 v104, %[R0]\n\tv_mov_b32 v105, %[R1]\n\tv_mov_b32 v106, %[R2]\n\tv_mov_b32 v107, %[R3]\n\t" \
   "v_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t"                                           \
-  "v_mov_b32 v130, 0\n\tv_mov_b32 v131, 0\n\tv_mov_b32 v133, 0\n\t"
+  "v_mov_b32 v130, 0\n\tv_mov_b32 v131, 0\n\tv_mov_b32 v133, 0\n\t"                       \
+  "v_cmp_eq_u32 vcc, 0, %[M]\n\tv_cndmask_b32_e64 v143, %[K8000], 0, vcc\n\t"
 #define TFC_PDEC_BLOCK_TAIL                                                               \
   "v_add_u32 %[CP], %[CP], v133\n\t"                                                      \
   "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
@@ -1173,9 +1188,9 @@ struct PipeDecLds {
 #define TFC_PDEC_ONE(STEP) TFC_PDEC_BLOCK_HEAD STEP(0, "%[M]", "v138") "v_mov_b32 %[M], v138\n\t" TFC_PDEC_BLOCK_TAIL
 #define TFC_PDEC_BLOCK(STEP)                                                              \
   TFC_PDEC_BLOCK_HEAD                                                                     \
-  TFC_PDEC_STEP2(STEP, 0, 256) TFC_PDEC_STEP2(STEP, 512, 768) TFC_PDEC_STEP2(STEP, 1024, 1280)          \
-  TFC_PDEC_STEP2(STEP, 1536, 1792) TFC_PDEC_STEP2(STEP, 2048, 2304) TFC_PDEC_STEP2(STEP, 2560, 2816)    \
-  TFC_PDEC_STEP2(STEP, 3072, 3328) TFC_PDEC_STEP2(STEP, 3584, 3840)                       \
+  TFC_PDEC_STEP2(STEP, 0, 128) TFC_PDEC_STEP2(STEP, 256, 384) TFC_PDEC_STEP2(STEP, 512, 640)            \
+  TFC_PDEC_STEP2(STEP, 768, 896) TFC_PDEC_STEP2(STEP, 1024, 1152) TFC_PDEC_STEP2(STEP, 1280, 1408)      \
+  TFC_PDEC_STEP2(STEP, 1536, 1664) TFC_PDEC_STEP2(STEP, 1792, 1920)                       \
   TFC_PDEC_BLOCK_TAIL
 
 template <bool INDEXED>
@@ -1246,7 +1261,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   // both in order), so every block waited for its own sixteen stores to reach memory (~110 cycles per row outside the
   // hand-scheduled steps, tools/chain_clock_probe.py on a TFC_PIPE_TIMING build), and a store cost its step ~20 cycles.
   const unsigned int stg_off = wave_off + (INDEXED ? L::kBytes : L::kRows);
-  const unsigned int stg = stg_off + 4u * lane;
+  const unsigned int stg = stg_off + 2u * lane;
   bool staged = false;               // wave-uniform: the staging area holds the rows staged_k ... + kPipeBlock
   unsigned int staged_k = 0u;
 
@@ -1259,8 +1274,8 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   const unsigned int bin_addr = dir_end + 16u * kLaneDirRepeat;
   uint4 bin = *reinterpret_cast<const uint4*>(lanes_lds + bin_addr);
   asm volatile("" : "+v"(bin.x), "+v"(bin.y), "+v"(bin.z), "+v"(bin.w));
-  unsigned int bin_addr_v = bin_addr;          // (in a vector register: v_cndmask takes one scalar operand, and that is vcc)
-  asm volatile("" : "+v"(bin_addr_v));
+  unsigned int bin_addr_v = bin_addr, k8000 = 0x8000u;     // (in vector registers: v_cndmask takes one scalar operand, and that is vcc)
+  asm volatile("" : "+v"(bin_addr_v), "+v"(k8000));
 
   unsigned int pos = 0u;             // elements completed
   int M = 0;
@@ -1269,7 +1284,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   uint4 R = make_uint4(0u, 0u, 0u, 0u);   // the row the next step decodes from (loaded behind the first memory phase)
   bool row_loaded = false;
 
-  unsigned int* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
+  unsigned short* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
   unsigned int* const posrec = pa.posrec + static_cast<size_t>(gi) * (pa.rows / kPipeBlock + 1) * 64 + lane;
   unsigned int k = 0u;               // rows written
   auto flush = [&]() {
@@ -1326,7 +1341,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         D = ren ? (D << 16) | dig : D;
         s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
         cp += ren ? 2u : 0u;
-        entry = sym;
+        entry = pipe_raw_entry(sym, 0);
         M = ((R.y >> 15) & 1u) != 0u && sym == (R.y & 0x7FFFu) ? -1 : 0;
       } else {
         // ---- one bit of an Elias-gamma code (range_coder_kernels.cc:449-471): the uniform binary cdf at
@@ -1341,7 +1356,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         D = ren ? (D << 16) | dig : D;
         s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
         cp += ren ? 2u : 0u;
-        entry = bit | (static_cast<unsigned int>(M) << 16);
+        entry = pipe_raw_entry(bit, M);
         if (M < 0) {
           if (bit) M = -M;
           else M = M == -31 ? 32 : M - 1;      // the 31st zero: the prefix ends here (range_lanes.h, bit_step)
@@ -1358,8 +1373,8 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         R = bin;
       }
       // (a block repeated inside the steady-state loop keeps its rows in the staging area, like the steps it replaces)
-      if (to_stage) *reinterpret_cast<unsigned int*>(lanes_lds + stg + 256u * (row - k)) = entry;
-      else raw[static_cast<size_t>(row) * 64 + lane] = entry;
+      if (to_stage) *reinterpret_cast<unsigned short*>(lanes_lds + stg + 128u * (row - k)) = static_cast<unsigned short>(entry);
+      else raw[static_cast<size_t>(row) * 64 + lane] = static_cast<unsigned short>(entry);
     }
   };
 
@@ -1413,10 +1428,10 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [M] "+v"(M), [PW] "+v"(pw), [FLAG] "+v"(flag),                    \
           [R0] "+v"(R.x), [R1] "+v"(R.y), [R2] "+v"(R.z), [R3] "+v"(R.w)                                              \
         : [STG] "v"(stg), [BINROW] "v"(bin_addr_v), [SCALE] "s"(scale), [HSCALE] "v"(hscale), [QMAX] "s"(cp_max),        \
-          [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x05040001u), [PERME] "s"(0x05040100u)               \
+          [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x05040001u), [K8000] "v"(k8000)               \
         : "vcc", "memory", "s52", "s53", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
           "v114", "v115", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",      \
-          "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v142"
+          "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v142", "v143"
 #if TFC_PIPE_TIMING
     const unsigned long long ta = clock64();
 #endif
@@ -1429,7 +1444,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   };
   // one hand-scheduled step, its raw entry to row `slot` of the staging area
   auto fast_step = [&](unsigned int& flag, unsigned int slot) __attribute__((always_inline)) {
-    const unsigned int stg_row = stg + 256u * slot;
+    const unsigned int stg_row = stg + 128u * slot;
     {
       const unsigned int stg = stg_row;       // (the operand list names `stg`)
       if constexpr (INDEXED) asm volatile(TFC_PDEC_ONE(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
@@ -1503,7 +1518,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
       // else sits these rows out), so that a code's bit rows stay together in the raw plane.
       if (pos < elems) {
 #pragma unroll
-        for (unsigned int i = 0; i < kPipeBlock; ++i) raw[static_cast<size_t>(k + i) * 64 + lane] = kPipeSkipRow;
+        for (unsigned int i = 0; i < kPipeBlock; ++i) raw[static_cast<size_t>(k + i) * 64 + lane] = static_cast<unsigned short>(kPipeSkipRow);
       }
 #pragma nounroll
       for (unsigned int i = 0; i < kPipeBlock; ++i) gstep(!whole && pos < elems && M != 0, k + i);
@@ -1516,7 +1531,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
       if (__any(sitting)) {
         if (sitting) {
 #pragma unroll
-          for (unsigned int i = 0; i < kPipeBlock; ++i) *reinterpret_cast<unsigned int*>(lanes_lds + stg + 256u * i) = kPipeSkipRow;
+          for (unsigned int i = 0; i < kPipeBlock; ++i) *reinterpret_cast<unsigned short*>(lanes_lds + stg + 128u * i) = static_cast<unsigned short>(kPipeSkipRow);
         }
       }
       const unsigned int D0 = D, s10 = s1, cp0 = cp, pw0 = pw;
@@ -1543,7 +1558,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
     if (sitting) {
       // (the generic steps store their rows themselves: so do the lanes that sit them out)
 #pragma unroll
-      for (unsigned int i = 0; i < kPipeBlock; ++i) raw[static_cast<size_t>(k + i) * 64 + lane] = kPipeSkipRow;
+      for (unsigned int i = 0; i < kPipeBlock; ++i) raw[static_cast<size_t>(k + i) * 64 + lane] = static_cast<unsigned short>(kPipeSkipRow);
     }
 #pragma nounroll
     for (unsigned int i = 0; i < kPipeBlock; ++i) gstep(busy && pos < elems, k + i);
@@ -1645,7 +1660,7 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
     kend = pa.kend[gi];
   }
   if (k0 >= kend) return;
-  const unsigned int* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
+  const unsigned short* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
   const unsigned int nrows = min(static_cast<unsigned int>(kParseRows), kend - k0);
   for (unsigned int r = tid >> 6; r < nrows; r += 4u) buf[r * kPitch + lane] = raw[static_cast<size_t>(k0 + r) * 64 + lane];
   const bool esc_in_lds = ntab <= kParseEscTables;
@@ -1665,8 +1680,8 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
     unsigned int pmod = p % untab;                 // channel mode: table of element p
     for (unsigned int c = 0; c < nrows; c += 64u) {
       const unsigned int i = c + lane;
-      const unsigned int e = i < nrows ? buf[i * kPitch + l] : 0xFFFF0000u;
-      const bool start = (e >> 16) == 0u;
+      const unsigned int e = i < nrows ? buf[i * kPitch + l] : kPipeSkipRow;
+      const bool start = (e & 0x8000u) == 0u;
       const unsigned long long mask = __ballot(start);
       const unsigned int before = static_cast<unsigned int>(__popcll(mask & lt));
       const unsigned int ord = p + before;
@@ -1690,11 +1705,11 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
           // before the row), M > 0 calls to go (M = 1: the sign; bit M - 2 of the magnitude otherwise)
           unsigned int val = 0u;
           bool neg = false, closed = false;
+          int m = -1;                             // the mode counter in front of the row (the escape symbol left -1)
           for (unsigned int q = k0 + i + 1u; q < kend; ++q) {
             const unsigned int x = q - k0 < nrows ? buf[(q - k0) * kPitch + l] : raw[static_cast<size_t>(q) * 64 + l];
-            const int m = static_cast<int>(x) >> 16;
             const unsigned int bit = x & 1u;
-            if ((x & 0xFFFF0000u) == kPipeSkipRow) continue;      // the lane sat this row out
+            if (x == kPipeSkipRow) continue;      // the lane sat this row out
             if (m < 0) {
               if (bit) val = 1u << (-m - 1);
               else if (m == -31) val = 1u << 31;
@@ -1705,6 +1720,7 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
               closed = true;
               break;
             }
+            m = pipe_mode_step(m, bit);
           }
           if (!closed && !final) incomplete = 1u;      // the code's last rows are not released yet: the pass behind the chain
           v = neg ? -static_cast<int>(val) : static_cast<int>(val) + es - 1;
