@@ -372,8 +372,8 @@ def pmc_traffic(kernel_substring, profile, sources, steps_per_launch=None):
     return None
 
 
-PMC_PROFILE = "r04_pmc_traffic.json"
-SQ_PROFILE = "r04_sq_inflight.json"
+PMC_PROFILE = "r05_pmc_traffic.json"
+SQ_PROFILE = "r05_sq_inflight.json"
 
 
 def valu_issue_floor(ms_per_step, kernels, steps_per_launch):

@@ -2811,6 +2811,12 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
       const hipStream_t cst = overlap ? side.stream : st;
       const dim3 cgrid(static_cast<unsigned>(cj.blocks_per_job * gn));
       const dim3 pgrid(static_cast<unsigned>(groups * tiles));
+      // The pass next to the chain takes the tiles every stream is sure to reach (a row per element at least); the rows
+      // beyond — escape codes' bit rows past the last element's place, a fraction of a percent — and the planned-for
+      // capacity behind them (a quarter more) are the second pass's: workgroups of tiles that never fill would only be
+      // dispatched behind the last real ones, wait for the chain's end and leave (16 000 of them in the 20-batch launch).
+      const size_t ctiles = std::min<size_t>(tiles, static_cast<size_t>(ceil_div(elems, static_cast<int64_t>(kParseRows))));
+      const dim3 pgrid_next(static_cast<unsigned>(groups * ctiles));
       {
         KernelTimer t2("dec_chain", cst);
         if (indexed) hipLaunchKernelGGL((dec_chain_kernel<true>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
@@ -2818,8 +2824,9 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
       }
       auto parse = [&](int concurrent) {
         pa.concurrent = concurrent;
-        if (indexed) hipLaunchKernelGGL((dec_parse_kernel<true, Dst>), pgrid, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
-        else hipLaunchKernelGGL((dec_parse_kernel<false, Dst>), pgrid, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
+        const dim3 g = concurrent ? pgrid_next : pgrid;
+        if (indexed) hipLaunchKernelGGL((dec_parse_kernel<true, Dst>), g, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
+        else hipLaunchKernelGGL((dec_parse_kernel<false, Dst>), g, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
       };
       if (overlap) {
         KernelTimer t2("dec_parse_next", st);      // (next to the chain: as long as the chain, by construction)

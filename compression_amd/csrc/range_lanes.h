@@ -79,13 +79,6 @@ struct LaneArgs {
   const unsigned int* guard;   // null, or one flag per job: the job is coded only if its flag is set (fallback of range_pipe.h)
 };
 
-__device__ inline void lanes_load_image(unsigned char* lds, const LaneArgs& a) {
-  const uint4* src = reinterpret_cast<const uint4*>(a.image);
-  uint4* dst = reinterpret_cast<uint4*>(lds);
-  for (int i = threadIdx.x; i < (a.bytes + 15) / 16; i += blockDim.x) dst[i] = src[i];
-  __syncthreads();
-}
-
 __device__ inline unsigned int lds_u16(const unsigned char* lds, unsigned int off) {
   return *reinterpret_cast<const unsigned short*>(lds + off);
 }
@@ -167,6 +160,24 @@ __device__ inline void lanes_gstore_elem(T* p, const T& v) {
     __builtin_memcpy(&bits, &v, 4);
     reinterpret_cast<TFC_AS1 LanePacked<unsigned int>*>((TFC_AS1 void*)p)->v = bits;
   }
+}
+
+__device__ inline void lanes_load_image(unsigned char* lds, const LaneArgs& a) {
+  const uint4* src = reinterpret_cast<const uint4*>(a.image);
+  uint4* dst = reinterpret_cast<uint4*>(lds);
+  // eight loads in flight per thread: a one-wave workgroup (the pipelined decoder on config 2's tables: 150 KB by 64
+  // threads) otherwise pays a memory latency per 1 KB
+  const int n = (a.bytes + 15) / 16, step = static_cast<int>(blockDim.x);
+  int i = threadIdx.x;
+  for (; i + 7 * step < n; i += 8 * step) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = lanes_gload16(src + i + u * step);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[i + u * step] = v[u];
+  }
+  for (; i < n; i += step) dst[i] = src[i];
+  __syncthreads();
 }
 
 // Values loaded before the main loop are "used" here, so that hipcc waits for them HERE: it places

@@ -369,7 +369,10 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 // LDS of one group of a chain workgroup: call words in, digits out (see enc_chain_kernel)
 struct PipeEncChainLds {
   static constexpr unsigned int kRows = 2 * kPipeBlock;      // rows per iteration: two hand-scheduled blocks
-  static constexpr unsigned int kSlots = 2;                  // iterations of call words in LDS (one per loader; each has its next one in registers)
+#ifndef TFC_ENC_SLOTS
+#define TFC_ENC_SLOTS 2
+#endif
+  static constexpr unsigned int kSlots = TFC_ENC_SLOTS;      // iterations of call words in LDS (each loader has its next one in registers)
   // iterations of digits the storer may be behind: 3 (round 5; 2 before: beside the expansion the chain waited 0.8 ms
   // of 4.7 for a free digit slot — the storer's stores queue behind the expansion's — 0.48 with 3; a fourth does not
   // fit the CU's LDS beside four groups)
@@ -388,7 +391,10 @@ struct PipeEncChainLds {
   static constexpr int kRec = kDig + kDigSlots * kDigSlot;   // (position in the slab, bytes) of every lane's digits, per digit slot
   static constexpr int kSync = kRec + kDigSlots * 64 * 8;
   static constexpr int kGroup = kSync + 64;
-  static constexpr int kGroups = 4;                          // groups (chain waves) of a large launch's workgroups: one per SIMD
+#ifndef TFC_ENC_GROUPS
+#define TFC_ENC_GROUPS 4
+#endif
+  static constexpr int kGroups = TFC_ENC_GROUPS;             // groups (chain waves) of a large launch's workgroups: one per SIMD
   // words at kSync
   static constexpr int kSeq = 0;            // [kSlots] iteration + 1 whose call words the slot holds | kLast | kBail
   static constexpr int kConsumed = 3;       // iterations the chain has read (kSeq takes kSlots <= 3 words)
@@ -1011,7 +1017,10 @@ struct PipeDecArgs {
   long long poll_ticks;          // wall_clock64() ticks a concurrent parse workgroup watches its group make no progress before it gives up
 };
 constexpr unsigned int kPipeFinal = 0x80000000u;
-constexpr unsigned int kPipeRelease = 64;      // blocks between two releases of the chain's rows
+#ifndef TFC_PIPE_RELEASE
+#define TFC_PIPE_RELEASE 64
+#endif
+constexpr unsigned int kPipeRelease = TFC_PIPE_RELEASE;      // blocks between two releases of the chain's rows
 struct PipeDecJob { const uint8_t* blob; const long long* off; const uint4* state; };
 struct PipeDecJobs {
   int64_t streams, elems;
