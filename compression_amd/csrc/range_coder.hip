@@ -1750,7 +1750,7 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         cj.streams = streams;
         for (int k = 0; k < gn; ++k)
           cj.job[k] = PipeChainJob{jobs.job[k].state, jobs.job[k].chunk, jobs.job[k].chunk_len, jobs.job[k].overflow_flag};
-        // A large launch: the chain (workgroups of four groups, helper waves: range_pipe.h) on the library's own stream
+        // A large launch: the chain (workgroups of PipeEncChainLds::kGroups groups, helper waves: range_pipe.h) on the library's own stream
         // next to the expansion.  A small one — a model step's few groups, next to other steps' convolutions — one-wave
         // chain workgroups behind the expansion on the caller's stream: measured on bmshj2018 with steps in flight, the
         // second stream, its events and the large workgroups cost more (45 against 36 ms per step) than the overlap of

@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 // One row: a lane whose word is "no call" leaves EXEC for the rest of the block (a stream's calls are the first rows
 // of its last block, so nothing follows a "no call" inside a block); the call word is unpacked into the (lo, 0) /
 // (hi, 0) register pairs TFC_LENC_B multiplies from.
-// (TFC_LENC_B of range_lanes.h with its temporaries at v100-v119: a chain workgroup is sixteen waves, four per SIMD,
+// (TFC_LENC_B of range_lanes.h with its temporaries at v100-v119: a chain workgroup is eight waves (sixteen before round 5), two per SIMD,
 // 128 registers each)
 #define TFC_PENC_STEP(W)                                                                   \
   "v_cmpx_ne_u32 vcc, %[NOCALL], %[" #W "]\n\t"                                            \
@@ -369,17 +369,21 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 // LDS of one group of a chain workgroup: call words in, digits out (see enc_chain_kernel)
 struct PipeEncChainLds {
   static constexpr unsigned int kRows = 2 * kPipeBlock;      // rows per iteration: two hand-scheduled blocks
+  // Round 5: what the chain lost beside the expansion (4.7 ms against 3.6 alone) was waiting for its helpers — 0.6 ms for
+  // call words, 0.5-0.8 ms for a free digit slot: their loads and stores queue behind the expansion's — and the cure is
+  // depth: four iterations of call words in LDS (each loader has its next one in registers) and six of digits.  That is
+  // 74 KB per group, so a workgroup is TWO groups (eight waves) instead of four: 80 CUs to the chains of the 20-batch
+  // launch instead of 40 (the expansion beside them 3.2 -> 3.5 ms), the chain 4.66 -> 3.82 ms.  Measured
+  // (tools/r05_line_ab.sh, encode call of the 20-batch group): 4 groups x (2, 2) slots 4.79 ms; 4 x (2, 3) 4.71;
+  // 3 x (2, 5) 4.32; 3 x (3, 4) 4.18; 2 x (3, 8) 3.89; 2 x (4, 6) 3.88.
 #ifndef TFC_ENC_SLOTS
-#define TFC_ENC_SLOTS 2
+#define TFC_ENC_SLOTS 4
 #endif
-  static constexpr unsigned int kSlots = TFC_ENC_SLOTS;      // iterations of call words in LDS (each loader has its next one in registers)
-  // iterations of digits the storer may be behind: 3 (round 5; 2 before: beside the expansion the chain waited 0.8 ms
-  // of 4.7 for a free digit slot — the storer's stores queue behind the expansion's — 0.48 with 3; a fourth does not
-  // fit the CU's LDS beside four groups)
+  static constexpr unsigned int kSlots = TFC_ENC_SLOTS;      // iterations of call words in LDS
 #ifndef TFC_ENC_DIGSLOTS
-#define TFC_ENC_DIGSLOTS 3
+#define TFC_ENC_DIGSLOTS 6
 #endif
-  static constexpr unsigned int kDigSlots = TFC_ENC_DIGSLOTS;
+  static constexpr unsigned int kDigSlots = TFC_ENC_DIGSLOTS;   // iterations of digits the storer may be behind
   static constexpr unsigned int kDigits = 2 * kRows + 16;    // digit bytes of a lane and iteration: one digit per call at most, and
                                                              // room for runs of 0xFFFF digits that settle (longer: the fallback)
   static constexpr int kCallStride = 4 * kRows + 16;         // a lane's words of an iteration, 16-byte accesses without bank conflicts
@@ -392,18 +396,18 @@ struct PipeEncChainLds {
   static constexpr int kSync = kRec + kDigSlots * 64 * 8;
   static constexpr int kGroup = kSync + 64;
 #ifndef TFC_ENC_GROUPS
-#define TFC_ENC_GROUPS 4
+#define TFC_ENC_GROUPS 2
 #endif
   static constexpr int kGroups = TFC_ENC_GROUPS;             // groups (chain waves) of a large launch's workgroups: one per SIMD
   // words at kSync
   static constexpr int kSeq = 0;            // [kSlots] iteration + 1 whose call words the slot holds | kLast | kBail
-  static constexpr int kConsumed = 3;       // iterations the chain has read (kSeq takes kSlots <= 3 words)
-  static constexpr int kDigPub = 4;         // iterations whose digits the chain has handed over
-  static constexpr int kDigDone = 5;        // ... the helper has stored
-  static constexpr int kExit = 6;           // the chain has left its loop
+  static constexpr int kConsumed = 4;       // iterations the chain has read (kSeq takes kSlots <= 4 words)
+  static constexpr int kDigPub = 5;         // iterations whose digits the chain has handed over
+  static constexpr int kDigDone = 6;        // ... the helper has stored
+  static constexpr int kExit = 7;           // the chain has left its loop
   static constexpr unsigned int kLast = 0x80000000u, kBail = 0x40000000u;
 };
-static_assert(PipeEncChainLds::kGroups * PipeEncChainLds::kGroup <= 160 * 1024 && PipeEncChainLds::kSlots <= 3, "a chain workgroup's LDS");
+static_assert(PipeEncChainLds::kGroups * PipeEncChainLds::kGroup <= 160 * 1024 && PipeEncChainLds::kSlots <= 4, "a chain workgroup's LDS");
 struct PipeChainJob { uint4* state; uint8_t* chunk; unsigned int* chunk_len; unsigned int* overflow_flag; };
 struct PipeChainJobs {
   int64_t streams;
@@ -416,7 +420,7 @@ struct PipeChainJobs {
 // which a lone wave whose time is the latency of its instruction chain must not feel: measured with the expansion
 // running, every global load or store the chain wave issued itself held it up at ISSUE (full request queues), 3.7 ->
 // 5.9 ms for BASELINE config 2 — and one helper wave doing all of it in turn did not keep up (the same 5.9).  So a
-// workgroup is four groups of four waves, wave 4 r + g of group g on SIMD g, the three helpers asleep most of the time:
+// workgroup is kGroups groups (two; four before round 5) of four waves, wave kGroups r + g of group g, the three helpers asleep most of the time:
 //   loaders (2)  make sure, tile by tile, that the expansion has released the rows they are about to request (`done`,
 //                acquire; the stream's row count up to that tile from the status words) and load the call words of every
 //                other iteration — 128 bytes of every lane's own stream — into an LDS ring up to kSlots iterations
@@ -426,7 +430,7 @@ struct PipeChainJobs {
 // Hand-over by counters in LDS (one writer each; LDS executes a wave's accesses in order).  A tile that does not arrive
 // within `poll_ticks` (the two kernels were not scheduled side by side after all and this one went first) gives the job
 // to the fallback.  Successor states are staged: enc_commit_kernel, behind both kernels, hands them to the handles
-// unless the job fell back.  A large launch's workgroups are four groups: their LDS (131 KB) also keeps other kernels'
+// unless the job fell back.  A large launch's workgroups are two groups: their LDS (148 KB) also keeps other kernels'
 // workgroups off the CU; a small launch's (a model step's few groups, next to convolutions that leave no CU empty)
 // are one group each and fit in anywhere.
 __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs jobs, const PipeEncArgs pa) {
