@@ -12,7 +12,7 @@ from compression_amd import _lib
 dev = torch.device("cuda", 0)
 lookup = bench.build_tables(dev)
 lt = torch.from_numpy(lookup)
-vals = [bench.sample_symbols_device(lookup, k, dev) for k in range(20)]
+vals = [bench.sample_symbols_device(lookup, k, dev) for k in range(int(os.environ.get("BATCHES", "20")))]
 if os.environ.get("IDENTICAL_STREAMS"):
     # every stream of a batch the same symbols: the 64 lanes of a chain wave read the same LDS addresses (broadcasts,
     # no bank conflicts) — what the random rows' conflicts cost a step
