@@ -31,3 +31,6 @@ for wl in bls2017 bmshj2018; do
   tail -1 /tmp/st_$wl.log | cut -c1-200
   python $R/tools/rocprof_summary.py /tmp/st_$wl $OUT/r05_${wl}_stats.md "Round 5: python bench.py --workload $wl --steps 16 --warmup 2 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)" | head -8 || true
 done
+# the driver's default line of the same tree (bench_summary prints what the notes quote)
+( cd $R && timeout -s KILL 600 python bench.py > $OUT/r05_bench_line.json 2> /tmp/bench.err ) || tail -5 /tmp/bench.err
+python $R/tools/bench_summary.py $OUT/r05_bench_line.json 2>&1 | head -60
