@@ -1671,8 +1671,16 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   const size_t kPipeTempBytes = pipe_temp_bytes();
   const bool pipe = pipe_enabled() && rows64 + 2048 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes && t->host.size() <= 65536 &&
                     static_cast<int64_t>(pa.nt) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
+  // A launch's chain workgroups must all be resident at once, next to an expansion that needs CUs of its own: a chain
+  // workgroup (PipeEncChainLds::kGroups groups) takes a CU's whole LDS, so at most half the CUs go to chains — beyond
+  // that the chains starve the expansion they wait for (and time out into the fallback).
+  int dev_e = 0, cus_e = 256;
+  (void)hipGetDevice(&dev_e);
+  (void)hipDeviceGetAttribute(&cus_e, hipDeviceAttributeMultiprocessorCount, dev_e);
+  const size_t resident_jobs = std::max<size_t>(1, static_cast<size_t>(cus_e / 2) * PipeEncChainLds::kGroups / std::max(1, pa.groups_per_job));
   const int per_launch = !pipe ? kMaxLaneJobs
-                               : static_cast<int>(std::max<size_t>(1, std::min<size_t>(kMaxLaneJobs, kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
+                               : static_cast<int>(std::max<size_t>(1, std::min<size_t>(std::min<size_t>(kMaxLaneJobs, resident_jobs),
+                                                                                      kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
   for (int g0 = 0; g0 < n; g0 += per_launch) {
     const int gn = std::min(per_launch, n - g0);
     EncLaneJobs<Src> jobs;
@@ -2722,9 +2730,19 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   const bool pipe = pipe_enabled() && pblock >= 64 && rows64 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
                     (!indexed || la.ntab < 4096) && t->lane_precision <= 15 &&
                     (static_cast<int64_t>(pa.rows) / kParseRows + 1) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
-  const int per_launch = !pipe ? kMaxLaneJobs
-                               : static_cast<int>(std::max<size_t>(1, std::min<size_t>(kMaxLaneJobs, kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
   const int plds = pla.lds_image + (pblock / 64) * pla.lds_wave;
+  // A launch's chain workgroups must all be resident at once (each holds the tables' image: one per CU for config 2's
+  // 150 KB): a second round of them doubles the launch's time, and the parse next to the chain gives up on groups that
+  // do not move (round 5: 16-bit raw rows made 64 config-2 batches fit the temporaries' budget — 512 groups on 256 CUs).
+  int dev_d = 0, cus_d = 256;
+  (void)hipGetDevice(&dev_d);
+  (void)hipDeviceGetAttribute(&cus_d, hipDeviceAttributeMultiprocessorCount, dev_d);
+  const size_t chain_wgs_per_job = static_cast<size_t>(ceil_div(pa.groups_per_job, std::max(1, pblock / 64)));
+  const size_t resident_wgs = static_cast<size_t>(cus_d) * std::max<size_t>(1, (160 * 1024) / std::max(1, plds));
+  const size_t resident_jobs = std::max<size_t>(1, resident_wgs / std::max<size_t>(1, chain_wgs_per_job));
+  const int per_launch = !pipe ? kMaxLaneJobs
+                               : static_cast<int>(std::max<size_t>(1, std::min<size_t>(std::min<size_t>(kMaxLaneJobs, resident_jobs),
+                                                                                      kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
   if (pipe) {
     const void* pfn = indexed ? reinterpret_cast<const void*>(&dec_chain_kernel<true>) : reinterpret_cast<const void*>(&dec_chain_kernel<false>);
     TFC_HIP(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, plds));

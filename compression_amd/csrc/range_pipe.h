@@ -1643,20 +1643,34 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
     // the tile is left to the pass behind the chain.
     const unsigned int need = k0 + kParseRows + kParseMargin;
     unsigned int* const abandon = pa.started + 1;      // a workgroup saw its group stand still: the chain is not running next to us
-    if (__hip_atomic_load(abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    unsigned int v, seen = ~0u;
-    long long t0 = 0;
-    for (;;) {
-      v = __hip_atomic_load(&pa.progress[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((v & kPipeFinal) || v >= need) break;
-      const long long now = static_cast<long long>(wall_clock64());
-      if (v != seen) { seen = v; t0 = now; }
-      else if (now - t0 > pa.poll_ticks) {
-        if (tid == 0u) __hip_atomic_store(abandon, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+    // ONE thread watches the flags and the whole workgroup takes its verdict (round 5).  Every thread used to poll for
+    // itself: a workgroup that started while another one was raising `abandon` (or whose threads read `progress` on both
+    // sides of a release at their time-out) went on with SOME of its threads, whose missing neighbours then never loaded
+    // their columns of the tile — wrong elements for 16-64 streams of one tile, seen once a launch had more groups than
+    // the chip has CUs (two rounds of chain workgroups: the first pass is abandoned after 2 ms).
+    unsigned int v = 0u;
+    if (tid == 0u) {
+      unsigned int seen = ~0u, go = 1u;
+      long long t0 = 0;
+      if (__hip_atomic_load(abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) go = 0u;
+      while (go) {
+        v = __hip_atomic_load(&pa.progress[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v & kPipeFinal) || v >= need) break;
+        const long long now = static_cast<long long>(wall_clock64());
+        if (v != seen) { seen = v; t0 = now; }
+        else if (now - t0 > pa.poll_ticks) {
+          __hip_atomic_store(abandon, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          go = 0u;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(32);
       }
-      __builtin_amdgcn_s_sleep(32);
+      incomplete = go ? v : 0xFFFFFFFFu;     // (the verdict travels in `incomplete`, which the tile's parse clears below)
     }
+    __syncthreads();
+    v = incomplete;
+    __syncthreads();
+    if (v == 0xFFFFFFFFu) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (__hip_atomic_load(&pa.fallback[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     final = (v & kPipeFinal) != 0u;

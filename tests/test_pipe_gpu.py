@@ -209,3 +209,29 @@ def test_large_launch_of_many_handles_in_index_mode(tfc, port):
         assert (o.cpu().numpy() == v).all() and bool(ok.all())
     l1, f1 = counters()
     assert (l1 - l0, f1 - f0) == (2, 0), (l1 - l0, f1 - f0)
+
+
+def test_more_groups_than_the_chip_hosts_at_once(tfc, port):
+    """40 handles of 512 streams behind one call per direction = 320 groups: a launch takes only as many batches as its
+    chain workgroups can be resident at once (an encoder chain workgroup per 2 groups on at most half the CUs, a decoder
+    chain workgroup per CU at most), so the call is several launches — and none of them leaves a job to the fallback.
+    (Round 5: with two rounds of chain workgroups in ONE launch the parse next to the chain was abandoned mid-way, and
+    workgroups that started at that moment went on with some of their threads: wrong elements for 16-64 streams of a
+    tile.)  Every batch's bytes against the oracle, every element back."""
+    lookup = tables(port, 16)
+    lt = torch.from_numpy(lookup)
+    n = 40
+    values = [synthetic.sample_symbols(lookup, 512, 600, seed=900 + k, escape_fraction=0.01) for k in range(n)]
+    l0, f0 = counters()
+    hs = tfc.create_range_encoders(n, [512], lt, deferred_errors=True)
+    hs = tfc.entropy_encode_channel_many(hs, [dev(v) for v in values])
+    hs = tfc.entropy_encode_finalize_device_many(hs)
+    ds = tfc.create_range_decoders(hs, lt)
+    ds, decoded = tfc.entropy_decode_channel_many(ds, [600], torch.int32)
+    oks = tfc.entropy_decode_finalize_device_many(ds)
+    for k, (h, v, d, ok) in enumerate(zip(hs, values, decoded, oks)):
+        assert (d.cpu().numpy().reshape(512, 600) == v).all() and bool(ok.all()), k
+        if k % 8 == 0:
+            assert [bytes(s) for s in tfc.fetch_strings(h)] == port.encode(lookup, v)[0], k
+    l1, f1 = counters()
+    assert l1 - l0 >= 3 and f1 - f0 == 0, (l1 - l0, f1 - f0)
