@@ -2200,6 +2200,11 @@ extern "C" int tfc_debug_pipe_clocks(unsigned long long* out8) {
   TFC_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(tfc::g_pipe_clock), 8 * sizeof(unsigned long long)));
   return 0;
 }
+extern "C" int tfc_debug_enc_clocks(unsigned long long* out4) {
+  TFC_HIP(hipDeviceSynchronize());
+  TFC_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(tfc::g_enc_clock), 4 * sizeof(unsigned long long)));
+  return 0;
+}
 
 extern "C" int tfc_pipe_counters(int64_t* launches, int64_t* fallback_blocks) {
   if (launches) *launches = g_pipe_launches.load();

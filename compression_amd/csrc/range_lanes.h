@@ -66,6 +66,9 @@ __device__ unsigned long long g_pipe_fallback_blocks;
 // (measurement aid, tools/chain_clock_probe.py) core-clock cycles and 100 MHz ticks the first chain workgroup of the
 // last pipelined encode / decode launch ran for: the clock the chain ran at
 __device__ unsigned long long g_pipe_clock[8];
+// (TFC_PIPE_TIMING builds) the encoder chain's hand-scheduled blocks: cycles inside them, their number, blocks repeated
+// call by call, cycles of those repetitions
+__device__ unsigned long long g_enc_clock[4];
 
 struct LaneArgs {
   const uint32_t* image;       // device copy of the LDS image

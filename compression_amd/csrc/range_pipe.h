@@ -629,10 +629,16 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
     base = act ? (ren ? bs << 16 : bs) : base;
     s1 = act ? (ren ? (t1 << 16) | 0xFFFFu : t1) : s1;
   };
+#if TFC_PIPE_TIMING
+  unsigned long long t_blocks = 0ull, n_blocks = 0ull, n_redone = 0ull, t_redo = 0ull;
+#endif
   // one hand-scheduled block on 16 call words
   auto block = [&](const unsigned int (&ww)[kPipeBlock]) __attribute__((always_inline)) {
     const unsigned int base0 = base, s10 = s1, hd0 = hd, had0 = had;
     unsigned int flag = rn, na = ds_off + n;
+#if TFC_PIPE_TIMING
+    const unsigned long long tb0 = clock64();
+#endif
     asm volatile(
         "s_mov_b64 s[56:57], exec\n\t"
         "v_mov_b32 v101, 0\n\tv_mov_b32 v103, 0\n\t"
@@ -649,9 +655,17 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
           [W12] "v"(ww[12]), [W13] "v"(ww[13]), [W14] "v"(ww[14]), [W15] "v"(ww[15])
         : "vcc", "memory", "s52", "s53", "s56", "s57", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
           "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v117", "v118", "v119");
+#if TFC_PIPE_TIMING
+    t_blocks += clock64() - tb0;
+    ++n_blocks;
+#endif
     if (__builtin_expect(!__any(flag != 0u), 1)) {
       n = na - ds_off;
     } else {
+#if TFC_PIPE_TIMING
+      ++n_redone;
+      const unsigned long long tr0 = clock64();
+#endif
       // a digit 0xFFFF was shifted out (it opens a run a later carry may ripple through), or a lane came
       // in inside such a run: the block again from the saved state, call by call
       base = base0; s1 = s10; hd = hd0; had = had0;
@@ -663,6 +677,9 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
         const unsigned int hi = word >> 16;
         call(word & 0xFFFFu, hi == 0u ? 65536u : hi, word != kPipeNoCall);
       }
+#if TFC_PIPE_TIMING
+      t_redo += clock64() - tr0;
+#endif
     }
   };
   // the call words of an iteration's first / second block out of their slot
@@ -741,6 +758,9 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
     g_pipe_clock[1] = wall_clock64() - wall0;
     g_pipe_clock[4] = waited_words;
     g_pipe_clock[6] = waited_digits;
+#if TFC_PIPE_TIMING
+    g_enc_clock[0] = t_blocks; g_enc_clock[1] = n_blocks; g_enc_clock[2] = n_redone; g_enc_clock[3] = t_redo;
+#endif
   }
   if (bail) return;
   if (live) {

@@ -27,6 +27,11 @@ for rep in range(3):
           "enc chain: %.3f ms at %.0f MHz;" % (e_w / 1e5, 100.0 * e_c / max(e_w, 1)),
           "dec chain: %.3f ms at %.0f MHz;" % (d_w / 1e5, 100.0 * d_c / max(d_w, 1)),
           "enc chain waited %.3f ms for call words, %.3f ms for digit slots (0: not a TFC_PIPE_TIMING build)" % (waited / 2.4e6, stalled / 2.4e6), flush=True)
+    eo = (C.c_ulonglong * 4)()
+    C.CDLL(_lib.LIB_PATH).tfc_debug_enc_clocks(eo)
+    if eo[1]:
+        print("   enc chain (TFC_PIPE_TIMING): %d blocks, %.1f cycles per row inside them, %d repeated call by call (%.0f cycles each), %.1f per row over the kernel"
+              % (eo[1], eo[0] / (16.0 * eo[1]), eo[2], eo[3] / max(int(eo[2]), 1), e_c / (16.0 * eo[1])), flush=True)
     if out[5]:
         blocks, rows, t_rest = int(out[7]) & 0xFFFF, (int(out[7]) >> 16) & 0xFFFF, int(out[7]) >> 32
         t_asm, t_commit = int(out[5]) & 0xFFFFFFFF, int(out[5]) >> 32
