@@ -328,13 +328,17 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
   {
     // Image of the lane-per-stream kernels: directory (one entry per table), 16-bit scaled cdf entries
     // (modulo 2^16: only a row's last entry is 2^16), then per row the bitmap of its boundaries over
-    // [0, 2^precision) and the running count of boundaries before each 64-bit word.  Rows must be strictly
-    // increasing (rank = popcount) and share one precision (the quotient scale is a kernel constant) —
-    // other tables keep the wave-per-stream kernels.
+    // [0, 2^precision) and the running count of boundaries before each 64-bit word.  The counts of a row have one
+    // more entry, for the word BEHIND the row (the next row's first, or one empty word behind the last row): the
+    // quotient estimate of an offset at the very top of the span is 2^precision, and the pipelined decoder
+    // (range_pipe.h) reads that word — of which its shift keeps bit 0 only, which it has cleared in its own copy —
+    // instead of clamping.  Rows must be strictly increasing (rank = popcount) and share one precision (the
+    // quotient scale is a kernel constant) — other tables keep the wave-per-stream kernels.
     const size_t ntab = t->rows.size();
     bool ok = ntab > 0;
     const int prec = ok ? std::abs(t->host[t->rows[0].x]) : 0;
-    size_t cdf_entries = 0, words = 0;
+    const size_t nw = std::max<size_t>(1, (size_t{1} << prec) / 64);
+    size_t cdf_entries = 0;
     for (const int2& r : t->rows) {
       const int nsym = r.y - 2;
       if (std::abs(t->host[r.x]) != prec) ok = false;
@@ -342,12 +346,11 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       for (int k = 1; ok && k <= nsym; ++k)
         if (t->host[r.x + 1 + k] <= t->host[r.x + k]) ok = false;
       cdf_entries += static_cast<size_t>(nsym + 1);
-      words += std::max<size_t>(1, (size_t{1} << prec) / 64);
     }
     // behind the tables' rows: the uniform binary row {0, 1/2, 1} the pipelined decoder (range_pipe.h) decodes the
     // bits of an escape code from (range_coder_kernels.cc:449-471: DecodeLinearly on {0, 1, 2} at precision 1)
     cdf_entries += 3;
-    words += std::max<size_t>(1, (size_t{1} << prec) / 64);
+    const size_t words = (ntab + 1) * nw + 1, counts = (ntab + 1) * (nw + 1);
     // the directory repeats its first entries behind its end: a block of kEncCadence / kDecCadence steps
     // reads that many consecutive entries without a wrap test per step
     constexpr size_t kDirRepeat = 16;
@@ -355,7 +358,7 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
     const size_t dir_bytes = sizeof(tfc::LaneRow) * (ntab + kDirRepeat + 1);
     const size_t cdf_bytes = (2 * cdf_entries + 15) & ~size_t{15};
     const size_t enc_bytes = dir_bytes + cdf_bytes;
-    const size_t dec_bytes = enc_bytes + 8 * words + ((2 * words + 15) & ~size_t{15});
+    const size_t dec_bytes = enc_bytes + 8 * words + ((2 * counts + 15) & ~size_t{15});
     // (the encoder needs directory + cdf entries only; a decoder image over the CU's LDS keeps the decoder on the
     // wave-per-stream kernels — decoder_family checks — and the encoder may still run lane-per-stream)
     if (enc_bytes > 128 * 1024) ok = false;
@@ -365,48 +368,46 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       uint16_t* cdf16 = reinterpret_cast<uint16_t*>(image.data() + dir_bytes);
       uint64_t* bits = reinterpret_cast<uint64_t*>(image.data() + enc_bytes);
       uint16_t* cum = reinterpret_cast<uint16_t*>(image.data() + enc_bytes + 8 * words);
-      size_t ce = 0, wo = 0;
-      const size_t nw = std::max<size_t>(1, (size_t{1} << prec) / 64);
+      size_t ce = 0;
+      // per word: the boundaries before it MINUS ONE, as int16 (rank - 1 = symbol: the decoder adds the
+      // popcount inside the word and has the symbol; -1 for the first word), and once more behind the row
+      auto count_row = [&](size_t i) {
+        unsigned int run = 0;
+        for (size_t w = 0; w <= nw; ++w) {
+          cum[i * (nw + 1) + w] = static_cast<uint16_t>(static_cast<int16_t>(static_cast<int>(run) - 1));
+          if (w < nw) run += static_cast<unsigned int>(__builtin_popcountll(bits[i * nw + w]));
+        }
+      };
+      auto place_row = [&](tfc::LaneRow& d, size_t i) {
+        d.cdf = static_cast<unsigned int>(dir_bytes + 2 * ce) - 2u;     // of cdf[0], minus 2: lo / hi of symbol s at + 2 s + 2 / + 4
+        d.bits = static_cast<unsigned int>(enc_bytes + 8 * i * nw);
+        d.cum = static_cast<unsigned int>(enc_bytes + 8 * words + 2 * i * (nw + 1));
+      };
       for (size_t i = 0; i < ntab; ++i) {
         const int2 r = t->rows[i];
         const int32_t* cdf = &t->host[r.x + 1];
         const int nsym = r.y - 2;
         const bool esc = t->host[r.x] < 0;
         tfc::LaneRow& d = dir[i];
-        d.cdf = static_cast<unsigned int>(dir_bytes + 2 * ce) - 2u;     // of cdf[0], minus 2: lo / hi of symbol s at + 2 s + 2 / + 4
-        d.bits = static_cast<unsigned int>(enc_bytes + 8 * wo);
-        d.cum = static_cast<unsigned int>(enc_bytes + 8 * words + 2 * wo);
+        place_row(d, i);
         d.info = static_cast<unsigned int>(esc ? nsym - 1 : nsym) | (esc ? 0x80000000u : 0u);
         for (int k = 0; k <= nsym; ++k) cdf16[ce + k] = static_cast<uint16_t>(cdf[k] << (16 - prec));
-        for (int k = 0; k < nsym; ++k) bits[wo + (cdf[k] >> 6)] |= uint64_t{1} << (cdf[k] & 63);
-        // per word: the boundaries before it MINUS ONE, as int16 (rank - 1 = symbol: the decoder adds the
-        // popcount inside the word and has the symbol; -1 for the first word)
-        unsigned int run = 0;
-        for (size_t w = 0; w < nw; ++w) {
-          cum[wo + w] = static_cast<uint16_t>(static_cast<int16_t>(static_cast<int>(run) - 1));
-          run += static_cast<unsigned int>(__builtin_popcountll(bits[wo + w]));
-        }
+        for (int k = 0; k < nsym; ++k) bits[i * nw + (cdf[k] >> 6)] |= uint64_t{1} << (cdf[k] & 63);
+        count_row(i);
         ce += static_cast<size_t>(nsym + 1);
-        wo += nw;
       }
       for (size_t i = 0; i < kDirRepeat; ++i) dir[ntab + i] = dir[i % ntab];
       {
         // the binary row, at the table set's precision (the quotient scale is a kernel constant); at precision 0
         // (no such tables: precision >= 1) its two boundaries would coincide
         tfc::LaneRow& d = dir[ntab + kDirRepeat];
-        d.cdf = static_cast<unsigned int>(dir_bytes + 2 * ce) - 2u;
-        d.bits = static_cast<unsigned int>(enc_bytes + 8 * wo);
-        d.cum = static_cast<unsigned int>(enc_bytes + 8 * words + 2 * wo);
+        place_row(d, ntab);
         d.info = 2u;
         cdf16[ce] = 0; cdf16[ce + 1] = 0x8000; cdf16[ce + 2] = 0;
         const unsigned int mid = 1u << (prec - 1);
-        bits[wo] |= 1ull;
-        bits[wo + (mid >> 6)] |= uint64_t{1} << (mid & 63);
-        unsigned int run = 0;
-        for (size_t w = 0; w < nw; ++w) {
-          cum[wo + w] = static_cast<uint16_t>(static_cast<int16_t>(static_cast<int>(run) - 1));
-          run += static_cast<unsigned int>(__builtin_popcountll(bits[wo + w]));
-        }
+        bits[ntab * nw] |= 1ull;
+        bits[ntab * nw + (mid >> 6)] |= uint64_t{1} << (mid & 63);
+        count_row(ntab);
       }
       TFC_HIP(t->d_lane_image.alloc(image.size(), st));
       TFC_HIP(hipMemcpyAsync(t->d_lane_image.p, image.data(), image.size(), hipMemcpyHostToDevice, st));

@@ -1110,7 +1110,7 @@ struct PipeDecLds {
 #define TFC_PDEC_STORE(KOFF)
 #define TFC_PDEC_WAIT2 "s_waitcnt lgkmcnt(1)\n\t"
 #else
-#define TFC_PDEC_STORE(KOFF) "ds_write_b16 %[STG], v139 offset:" #KOFF "\n\t"
+#define TFC_PDEC_STORE(KOFF) "ds_write_b16 %[STG], v117 offset:" #KOFF "\n\t"
 #define TFC_PDEC_WAIT2 "s_waitcnt lgkmcnt(2)\n\t"
 #endif
 // Round 5: the schedule of a step.  The wave issues one instruction per ~4.3 cycles whatever it is, and the two LDS
@@ -1139,35 +1139,88 @@ struct PipeDecLds {
 // shadow — the step took 305 cycles instead of 288.)
 // LDS operations of a step, in issue order (they complete in order): bitmap word, count | (index mode: next row
 // address) digit | cdf lo, cdf hi, the raw entry's write, the next step's row.
+// Round 5, second pass (tools/r05_step_pad.sh: two dummy instructions cost 8.0 cycles in ANY of the step's four parts —
+// the waits are gone, a step is its instruction count at 4 cycles each), 54 -> 45 instructions:
+//  * the quotient is kept NEGATED, nq = ~q = trunc(-(D + 1/2) 2^p / S - 1): its low six bits are the left shift that
+//    brings the quotient's bit of the bitmap word to the top (no v_not), ~q >> 6 = ~w addresses the word and its count
+//    downwards from the entry's pointers (v_mad_i32_i24 with -8 / -2; the kernel's LDS copy of the directory holds bits - 8
+//    and cum - 2), and q >= ESCLO is (~q & 0xFFFF) <= 0xFFFF - ESCLO on 16-bit halves (the info word's upper half holds
+//    0xFFFF - ESCLO);
+//  * no clamp of the quotient: an offset at the very top of the span estimates 2^p = bit 0 of the word BEHIND the row's
+//    bitmap — the next row's first word (bit 0 cleared, below) or the spare word behind the last row — and every row's
+//    counts have an entry for that word (tfc_tables_create);
+//  * the counts are unsigned and the bitmaps leave out cdf[0] (the kernel clears bit 0 of a row's first word in its LDS
+//    copy and sets that word's count to 0), and the binary row's counts carry 0x8000: the rank there is 0x8000 | bit — the
+//    raw entry as it is stored, no flag register, no or — with the row's cdf pointer 0x10000 lower;
+//  * mode counter: with t = M - 1, X = M >> 31 (all ones inside a unary prefix), z = -[M = 0]:  M' = t ^ (e ? X : z)
+//    (M = 0: -1 ^ 0 opens a prefix, -1 ^ -1 stays; M < 0: ~(M - 1) = -M ends the prefix; M > 0: M - 1).  t' and z' of the
+//    next step come out of the v_subrev_co that also yields the "M' = 0" condition of the row select (its borrow);
+//  * the verification through EXEC: v_cmpx keeps the lanes whose offset lies inside the symbol's interval, a lane that
+//    fails drops out of the rest of the block (the caller restores its state anyway); the block's head sets FLAG and its
+//    tail clears it for the lanes still there.
+// With these the two shadows (8 and 7 instructions) are as long as the LDS trips they cover, within two instructions (two
+// dummy instructions in the first shadow cost nothing, anywhere else 8 cycles): moving the row select's five instructions
+// from the second shadow into the first made the step 10 cycles slower (the second trip exposed), three of them 5 cycles,
+// one nothing — a step is now  quotient 11 + rank 6 + bounds 13 instructions + the two trips: 264.5 cycles (291.8 before
+// this pass); a wait that waits for nothing costs ~3 cycles.
+// Measured and dropped: 1 / S issued four instructions early (no gain: nothing waits for v_rcp_f32), the two bounds as
+// three v_mad_u32_u16 / shift / v_mad_u32_u16 each instead of v_mad_u64_u32 + v_alignbit (+8 cycles: the 64-bit multiply
+// costs one slot like everything else).
+// TFC_PDEC_PAD = 1 .. 4 (build switch, tools/r05_step_pad.sh): two extra instructions in the quotient part, the first
+// shadow, the second shadow, the bounds part of every step — which parts of a step are bound by instruction issue
+#ifndef TFC_PDEC_PAD
+#define TFC_PDEC_PAD 0
+#endif
+#define TFC_PDEC_PAD2 "v_mov_b32 v139, v139\n\tv_mov_b32 v139, v139\n\t"
+#if TFC_PDEC_PAD == 1
+#define TFC_PDEC_PAD_A TFC_PDEC_PAD2
+#elif TFC_PDEC_PAD == 5
+#define TFC_PDEC_PAD_A "s_waitcnt lgkmcnt(15)\n\ts_waitcnt lgkmcnt(15)\n\t"      /* (what a wait that waits for nothing costs) */
+#else
+#define TFC_PDEC_PAD_A
+#endif
+#if TFC_PDEC_PAD == 2
+#define TFC_PDEC_PAD_B TFC_PDEC_PAD2
+#else
+#define TFC_PDEC_PAD_B
+#endif
+#if TFC_PDEC_PAD == 3
+#define TFC_PDEC_PAD_C TFC_PDEC_PAD2
+#else
+#define TFC_PDEC_PAD_C
+#endif
+#if TFC_PDEC_PAD == 4
+#define TFC_PDEC_PAD_D TFC_PDEC_PAD2
+#else
+#define TFC_PDEC_PAD_D
+#endif
+// Registers across steps: v104-v107 the row, v135 = M - 1, v136 = -[M = 0], v130 / v131 the previous step's pending
+// verification, s[56:57] its "renormalised" condition (the code cursor moves on in the next step's first shadow, which has
+// two slots to spare; the bounds part has none); v123 = v125 = 0.
 #define TFC_PDEC_STEP(KOFF, MI, MO, AHEAD, NEXT, PWSTEP)                                    \
   "v_cvt_f32_u32 v111, %[S]\n\t"                                                          \
   "v_rcp_f32 v111, v111\n\t"                                                              \
+  TFC_PDEC_PAD_A                                                                          \
   "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
-  "v_fma_f32 v110, v110, %[SCALE], %[HSCALE]\n\t"                                         \
-  "v_mul_f32 v110, v110, v111\n\t"                                                        \
-  "v_cvt_u32_f32 v110, v110\n\t"                                                          \
-  "v_min_u32 v110, %[QMAX], v110\n\t"                                                     \
-  "v_lshrrev_b32 v111, 6, v110\n\t"                                                       \
+  "v_fma_f32 v110, -v110, %[SCALE], -%[HSCALE]\n\t"                                       \
+  "v_fma_f32 v110, v110, v111, -1.0\n\t"                                                  \
+  "v_cvt_i32_f32 v110, v110\n\t"                                                          \
+  "v_ashrrev_i32 v111, 6, v110\n\t"                                                       \
   "s_waitcnt lgkmcnt(0)\n\t"                                                              \
-  "v_lshl_add_u32 v112, v111, 3, v106\n\t"                                                \
+  "v_mad_i32_i24 v112, v111, -8, v106\n\t"                                                \
   "ds_read_b64 v[114:115], v112\n\t"                                                      \
-  "v_lshl_add_u32 v113, v111, 1, v107\n\t"                                                \
-  "ds_read_i16 v116, v113\n\t"                                                            \
+  "v_mad_i32_i24 v113, v111, -2, v107\n\t"                                                \
+  "ds_read_u16 v116, v113\n\t"                                                            \
   AHEAD                                                                                   \
+  "v_cndmask_b32_e64 v133, 0, 2, s[56:57]\n\t"                                            \
   "v_add_u32 %[CP], %[CP], v133\n\t"                                                      \
   "ds_read_u16 v109, %[CP]\n\t"                                                           \
-  "v_ashrrev_i32 v135, 31, " MI "\n\t"                                                    \
-  "v_mad_i32_i24 v136, " MI ", -2, 1\n\t"                                                 \
-  "v_and_b32 v137, v135, v136\n\t"                                                        \
-  "v_cmp_eq_u32 vcc, 0, " MI "\n\t"                                                       \
-  "v_cndmask_b32_e64 v137, v137, -1, vcc\n\t"                                             \
-  "v_addc_co_u32 v134, vcc, -1, " MI ", vcc\n\t"                                          \
-  "v_cmp_ge_u32_sdwa vcc, v110, v105 src0_sel:DWORD src1_sel:WORD_1\n\t"                  \
-  "v_not_b32 v110, v110\n\t"                                                              \
-  "v_cndmask_b32 v137, 0, v137, vcc\n\t"                                                  \
-  "v_add_u32 " MO ", v134, v137\n\t"                                                      \
-  "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
-  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
+  "v_ashrrev_i32 v137, 31, " MI "\n\t"                                                    \
+  "v_cmp_le_u32_sdwa vcc, v110, v105 src0_sel:WORD_0 src1_sel:WORD_1\n\t"                 \
+  "v_cndmask_b32 v137, v136, v137, vcc\n\t"                                               \
+  "v_xor_b32 " MO ", v135, v137\n\t"                                                      \
+  "v_cmpx_le_u32 vcc, v130, v131\n\t"                                                     \
+  TFC_PDEC_PAD_B                                                                          \
   "s_waitcnt lgkmcnt(1)\n\t"                                                              \
   "v_lshlrev_b64 v[118:119], v110, v[114:115]\n\t"                                        \
   "v_bcnt_u32_b32 v116, v118, v116\n\t"                                                   \
@@ -1175,15 +1228,16 @@ struct PipeDecLds {
   "v_lshl_add_u32 v112, v117, 1, v104\n\t"                                                \
   "ds_read_u16 v122, v112 offset:2\n\t"                                                   \
   "ds_read_u16 v124, v112 offset:4\n\t"                                                   \
-  "v_or_b32 v139, v143, v117\n\t"                                                         \
+  TFC_PDEC_PAD_C                                                                          \
   TFC_PDEC_STORE(KOFF)                                                                    \
-  "v_cmp_eq_u32 vcc, 0, " MO "\n\t"                                                       \
-  "v_cndmask_b32_e64 v143, %[K8000], 0, vcc\n\t"                                              \
+  "v_subrev_co_u32 v135, vcc, 1, " MO "\n\t"                                              \
+  "v_cndmask_b32_e64 v136, 0, -1, vcc\n\t"                                                \
   "v_add_u32 v140, " #PWSTEP ", %[PW]\n\t"                                                \
   "v_cndmask_b32 %[PW], %[PW], v140, vcc\n\t"                                             \
   "v_cndmask_b32 v142, %[BINROW], " NEXT ", vcc\n\t"                                      \
   "ds_read_b128 v[104:107], v142\n\t"                                                     \
   TFC_PDEC_WAIT2                                                                          \
+  TFC_PDEC_PAD_D                                                                          \
   "v_mad_u64_u32 v[126:127], s[52:53], v122, %[S], v[122:123]\n\t"                        \
   "v_mad_u64_u32 v[128:129], s[52:53], v124, %[S], v[124:125]\n\t"                        \
   "v_alignbit_b32 v126, v127, v126, 16\n\t"                                               \
@@ -1191,30 +1245,30 @@ struct PipeDecLds {
   "v_add_u32 v128, -1, v128\n\t"                                                          \
   "v_min_u32 v128, v128, %[S]\n\t"                                                        \
   "v_sub_u32 v131, v128, v126\n\t"                                                        \
-  "v_cmp_gt_u32 vcc, %[K64K], v131\n\t"                                                   \
+  "v_cmp_gt_u32_e64 s[56:57], %[K64K], v131\n\t"                                          \
   "v_lshl_or_b32 v132, v131, 16, %[KFFFF]\n\t"                                            \
-  "v_cndmask_b32 %[S], v131, v132, vcc\n\t"                                               \
+  "v_cndmask_b32_e64 %[S], v131, v132, s[56:57]\n\t"                                      \
   "v_sub_u32 v130, %[D], v126\n\t"                                                        \
   "v_perm_b32 v132, v130, v109, %[PERM]\n\t"                                              \
-  "v_cndmask_b32 %[D], v130, v132, vcc\n\t"                                               \
-  "v_cndmask_b32 v133, 0, 2, vcc\n\t"
+  "v_cndmask_b32_e64 %[D], v130, v132, s[56:57]\n\t"
 // channel mode: the next element's entry is the one behind the current (PW + 16); index mode: its address comes out
 // of the lane's window of row addresses, requested in the first shadow
 #define TFC_PDEC_STEP_CH(KOFF, MI, MO) TFC_PDEC_STEP(KOFF, MI, MO, "", "v140", 16)
 #define TFC_PDEC_STEP_IX(KOFF, MI, MO) TFC_PDEC_STEP(KOFF, MI, MO, "ds_read_u16 v108, %[PW] offset:2\n\t", "v108", 2)
-// a block: the row into v104-v107, nothing pending from a step before it (v130 <= v131, v133 = 0); behind it the last
-// step's pending flag and cursor increment, and the row the next step decodes from back to the caller
+// a block: the row into v104-v107, nothing pending from a step before it (v130 <= v131, s[56:57] = 0); behind it the last
+// step's pending verification and cursor increment, and the row the next step decodes from back to the caller
 #define TFC_PDEC_STEP2(STEP, K0, K1) STEP(K0, "%[M]", "v138") STEP(K1, "v138", "%[M]")
 #define TFC_PDEC_BLOCK_HEAD                                                               \
   "v_mov_b32 v104, %[R0]\n\tv_mov_b32 v105, %[R1]\n\tv_mov_b32 v106, %[R2]\n\tv_mov_b32 v107, %[R3]\n\t" \
   "v_mov_b32 v123, 0\n\tv_mov_b32 v125, 0\n\t"                                           \
-  "v_mov_b32 v130, 0\n\tv_mov_b32 v131, 0\n\tv_mov_b32 v133, 0\n\t"                       \
-  "v_cmp_eq_u32 vcc, 0, %[M]\n\tv_cndmask_b32_e64 v143, %[K8000], 0, vcc\n\t"
+  "v_mov_b32 v130, 0\n\tv_mov_b32 v131, 0\n\ts_mov_b64 s[56:57], 0\n\t"                   \
+  "v_subrev_co_u32 v135, vcc, 1, %[M]\n\tv_cndmask_b32_e64 v136, 0, -1, vcc\n\t"           \
+  "s_mov_b64 s[54:55], exec\n\tv_mov_b32 %[FLAG], 1\n\t"
 #define TFC_PDEC_BLOCK_TAIL                                                               \
+  "v_cndmask_b32_e64 v133, 0, 2, s[56:57]\n\t"                                            \
   "v_add_u32 %[CP], %[CP], v133\n\t"                                                      \
-  "v_cmp_gt_u32 vcc, v130, v131\n\t"                                                      \
-  "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"                                       \
   "s_waitcnt lgkmcnt(0)\n\t"                                                              \
+  "v_cmpx_le_u32 vcc, v130, v131\n\tv_mov_b32 %[FLAG], 0\n\ts_mov_b64 exec, s[54:55]\n\t"   \
   "v_mov_b32 %[R0], v104\n\tv_mov_b32 %[R1], v105\n\tv_mov_b32 %[R2], v106\n\tv_mov_b32 %[R3], v107\n\t"
 // one step as a block of its own (its raw entry at %[STG] + 0): what a block whose verification failed is repeated with,
 // step by step, so that only the step that fails again takes the generic path
@@ -1232,18 +1286,40 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   lanes_load_image(lanes_lds, la);
   using L = PipeDecLds;
   {
-    // This kernel's form of a directory entry's info word (its LDS copy only; the image on the device is shared with
-    // the lane-per-stream kernels):  limit | has_escape << 15 | ESCLO << 16,  ESCLO = the escape symbol's lower bound on
-    // the tables' own scale (0xFFFF, which no quotient reaches at precision <= 15, for a row without one; 2^(p-1) for
-    // the binary row behind the repeated entries: there the comparison q >= ESCLO is the decoded bit).
+    // This kernel's form of the image (its LDS copy only; the image on the device is shared with the lane-per-stream
+    // kernels) — see "Round 5, second pass" above:
+    //  * tables: bit 0 of a row's first bitmap word (cdf[0] = 0) cleared and that word's count 0 instead of -1: the counts
+    //    are unsigned, rank = count + popcount as before; the binary row's counts + 0x8000 (its rank is the raw entry
+    //    0x8000 | bit) and its cdf pointer 0x10000 lower;
+    //  * directory: info = limit | has_escape << 15 | (0xFFFF - ESCLO) << 16, ESCLO = the escape symbol's lower bound on the
+    //    tables' own scale (0xFFFF, which no quotient reaches at precision <= 15, for a row without one; 2^(p-1) for the
+    //    binary row behind the repeated entries: there q >= ESCLO is the decoded bit); bits - 8 and cum - 2 (the step
+    //    addresses a word from the NEGATED quotient).
     const unsigned int entries = static_cast<unsigned int>(la.ntab) + kLaneDirRepeat + 1u;
+    const unsigned int nw = max(1u, (1u << la.precision) >> 6) + 1u;      // counts of a row: its words and the word behind it
+    for (unsigned int i = threadIdx.x; i < entries; i += blockDim.x) {
+      if (i >= static_cast<unsigned int>(la.ntab) && i + 1u != entries) continue;     // (repeated entries: tables patched already)
+      const LaneRow* e = reinterpret_cast<const LaneRow*>(lanes_lds) + i;
+      *reinterpret_cast<unsigned long long*>(lanes_lds + e->bits) &= ~1ull;
+      *reinterpret_cast<unsigned short*>(lanes_lds + e->cum) = 0;
+    }
+    __syncthreads();
+    {
+      const LaneRow* e = reinterpret_cast<const LaneRow*>(lanes_lds) + (entries - 1u);
+      for (unsigned int w = threadIdx.x; w < nw; w += blockDim.x)
+        *reinterpret_cast<unsigned short*>(lanes_lds + e->cum + 2u * w) += 0x8000u;
+    }
+    __syncthreads();
     for (unsigned int i = threadIdx.x; i < entries; i += blockDim.x) {
       LaneRow* e = reinterpret_cast<LaneRow*>(lanes_lds) + i;
       const unsigned int info = e->info, limit = info & 0x7FFFu, esc = info >> 31;
       unsigned int esclo = 0xFFFFu;
       if (i + 1u == entries) esclo = 1u << (la.precision - 1);
       else if (esc) esclo = lds_u16(lanes_lds, e->cdf + 2u * limit + 2u) >> (16 - la.precision);
-      e->info = limit | (esc << 15) | (esclo << 16);
+      e->info = limit | (esc << 15) | ((0xFFFFu - esclo) << 16);
+      e->bits -= 8u;
+      e->cum -= 2u;
+      if (i + 1u == entries) e->cdf -= 0x10000u;
     }
     __syncthreads();
   }
@@ -1307,8 +1383,8 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   const unsigned int bin_addr = dir_end + 16u * kLaneDirRepeat;
   uint4 bin = *reinterpret_cast<const uint4*>(lanes_lds + bin_addr);
   asm volatile("" : "+v"(bin.x), "+v"(bin.y), "+v"(bin.z), "+v"(bin.w));
-  unsigned int bin_addr_v = bin_addr, k8000 = 0x8000u;     // (in vector registers: v_cndmask takes one scalar operand, and that is vcc)
-  asm volatile("" : "+v"(bin_addr_v), "+v"(k8000));
+  unsigned int bin_addr_v = bin_addr;     // (in vector registers: v_cndmask takes one scalar operand, and that is vcc)
+  asm volatile("" : "+v"(bin_addr_v));
 
   unsigned int pos = 0u;             // elements completed
   int M = 0;
@@ -1347,10 +1423,11 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         const float fq = (static_cast<float>(D) + 0.5f) * __builtin_amdgcn_rcpf(static_cast<float>(s1)) * scale;
         const unsigned int q = min(static_cast<unsigned int>(fq), cp_max);
         const unsigned int w = q >> 6;
-        const unsigned long long word = *reinterpret_cast<const unsigned long long*>(lanes_lds + R.z + 8u * w);
-        const int cum_m1 = *reinterpret_cast<const short*>(lanes_lds + R.w + 2u * w);
+        // (this kernel's LDS copy: entry pointers 8 / 2 bytes low, counts without the "- 1", bitmaps without cdf[0])
+        const unsigned long long word = *reinterpret_cast<const unsigned long long*>(lanes_lds + R.z + 8u + 8u * w);
+        const unsigned int cum = *reinterpret_cast<const unsigned short*>(lanes_lds + R.w + 2u + 2u * w);
         const unsigned long long below = ~0ull >> (63u - (q & 63u));
-        unsigned int sym = static_cast<unsigned int>(cum_m1 + __popcll(word & below));
+        unsigned int sym = cum + static_cast<unsigned int>(__popcll(word & below));
         unsigned int lo = lds_u16(lanes_lds, R.x + 2u * sym + 2u);
         unsigned int hi = lds_u16(lanes_lds, R.x + 2u * sym + 4u);
         unsigned int A = scale16(s1, lo);
@@ -1460,9 +1537,9 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
 #define TFC_PDEC_OPERANDS                                                                                              \
         : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [M] "+v"(M), [PW] "+v"(pw), [FLAG] "+v"(flag),                    \
           [R0] "+v"(R.x), [R1] "+v"(R.y), [R2] "+v"(R.z), [R3] "+v"(R.w)                                              \
-        : [STG] "v"(stg), [BINROW] "v"(bin_addr_v), [SCALE] "s"(scale), [HSCALE] "v"(hscale), [QMAX] "s"(cp_max),        \
-          [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x05040001u), [K8000] "v"(k8000)               \
-        : "vcc", "memory", "s52", "s53", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
+        : [STG] "v"(stg), [BINROW] "v"(bin_addr_v), [SCALE] "s"(scale), [HSCALE] "v"(hscale),        \
+          [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x05040001u)               \
+        : "vcc", "memory", "s52", "s53", "s54", "s55", "s56", "s57", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
           "v114", "v115", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",      \
           "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v142", "v143"
 #if TFC_PIPE_TIMING
