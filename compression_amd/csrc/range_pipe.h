@@ -1578,7 +1578,9 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         const int M0 = M;
         const uint4 R0 = R;
         unsigned int flag = 0u;
-        if (live) fast_block(flag);
+        // (every lane, also those of a last group that have no stream — they decode zeros from their own windows and
+        // are ignored: under `if (live)` the compiler copied the block's nine operands twice)
+        fast_block(flag);
         if (__builtin_expect(__any(live && flag != 0u), 0)) {
           // A verification failed somewhere in the block (the quotient estimate one off: ~1e-5 of the symbols, 2.5 % of the
           // blocks): again from the saved state, one hand-scheduled step at a time, and only the step that fails again
