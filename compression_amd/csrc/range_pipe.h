@@ -1141,7 +1141,13 @@ struct PipeDecLds {
 // address) digit | cdf lo, cdf hi, the raw entry's write, the next step's row.
 // Round 5, second pass (tools/r05_step_pad.sh: two dummy instructions cost 8.0 cycles in ANY of the step's four parts —
 // the waits are gone, a step is its instruction count at 4 cycles each), 54 -> 45 instructions:
-//  * the quotient is kept NEGATED, nq = ~q = trunc(-(D + 1/2) 2^p / S - 1): its low six bits are the left shift that
+//  * the quotient estimate is the EXACT quotient's float image: the symbol of an offset D is the rank of
+//    q* = ceil((D + 1) 2^p / (S + 1)) - 1 among the row's boundaries (D >= ((S + 1) c) >> 16  <=>  c < (D + 1) 2^p / (S + 1)),
+//    and floor(float((D + 1) 2^p) / float(S + 1)) differs from it across a boundary for 1.3e-6 of the (D, S) of config 2's
+//    tables — (D + 1/2) 2^p / S, round 4's estimate, for 3.1e-5 (it is off by up to 2^p / 2 S, 1 / 32 at the smallest span;
+//    simulated, and measured: 76 of 3 086 blocks repeated, ~9 000 cycles each = 14 cycles per row) — for one more
+//    instruction (S + 1 in float);
+//  * it is kept NEGATED, nq = ~q = trunc(-(D + 1) 2^p / (S + 1) - 1): its low six bits are the left shift that
 //    brings the quotient's bit of the bitmap word to the top (no v_not), ~q >> 6 = ~w addresses the word and its count
 //    downwards from the entry's pointers (v_mad_i32_i24 with -8 / -2; the kernel's LDS copy of the directory holds bits - 8
 //    and cum - 2), and q >= ESCLO is (~q & 0xFFFF) <= 0xFFFF - ESCLO on 16-bit halves (the info word's upper half holds
@@ -1199,6 +1205,7 @@ struct PipeDecLds {
 // two slots to spare; the bounds part has none); v123 = v125 = 0.
 #define TFC_PDEC_STEP(KOFF, MI, MO, AHEAD, NEXT, PWSTEP)                                    \
   "v_cvt_f32_u32 v111, %[S]\n\t"                                                          \
+  "v_add_f32 v111, 1.0, v111\n\t"                                                         \
   "v_rcp_f32 v111, v111\n\t"                                                              \
   TFC_PDEC_PAD_A                                                                          \
   "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
@@ -1375,7 +1382,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   unsigned int staged_k = 0u;
 
   const float scale = static_cast<float>(1u << la.precision);
-  float hscale = 0.5f * scale;
+  float hscale = scale;              // (the quotient estimate's numerator is (D + 1) 2^p: see the step)
   asm volatile("" : "+v"(hscale));
   const unsigned int cp_max = (1u << la.precision) - 1u;
   const unsigned int dir_end = 16u * static_cast<unsigned int>(la.ntab);
