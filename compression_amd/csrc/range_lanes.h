@@ -218,7 +218,12 @@ struct LaneWindow {
     if (pos + 8u * WORDS <= len) {
 #pragma unroll
       for (int w = 0; w < WORDS; w += 2) {
+#if defined(TFC_PDEC_ABL) && (TFC_PDEC_ABL & 2)
+        // (timing experiment, results wrong: one 16-byte load per request instead of WORDS / 2)
+        const uint4 v = w == 0 ? lanes_gload16(g + pos) : make_uint4(pend[0].x, pend[0].y, pend[1].x, pend[1].y);
+#else
         const uint4 v = lanes_gload16(g + pos + 8u * w);
+#endif
         pend[w] = make_uint2(v.x, v.y);
         pend[w + 1] = make_uint2(v.z, v.w);
       }

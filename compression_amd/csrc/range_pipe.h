@@ -712,15 +712,21 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
   unsigned int seq = wait_words(0u);
   bool bail = (seq & L::kBail) != 0u;
   if (!bail) read_words(wa, 0u, 0u);
+  // A look at a counter in LDS is a round trip this wave has nothing to cover with (~100 cycles, two per iteration of 32
+  // rows): the storer's counter is read again only when the value read last does not free this iteration's slot (the
+  // helpers are usually slots ahead), and the next iteration's sequence word is read in front of the block and looked at
+  // behind it.
+  unsigned int dig_done = 0u;
   for (unsigned int b = 0; !bail; ++b) {
     const bool last = (seq & L::kLast) != 0u;
     read_words(wb, b % L::kSlots, 1u);
+    const unsigned int seq_early = last ? 0u : sync[L::kSeq + (b + 1u) % L::kSlots];
     // the digit slot of this iteration: free once the helper has stored the iteration that used it before
-    {
+    if (dig_done + L::kDigSlots <= b) {
 #if TFC_PIPE_TIMING
       const unsigned long long c0 = clock64();
 #endif
-      while (sync[L::kDigDone] + L::kDigSlots <= b) __builtin_amdgcn_s_sleep(1);
+      while ((dig_done = sync[L::kDigDone]) + L::kDigSlots <= b) __builtin_amdgcn_s_sleep(1);
 #if TFC_PIPE_TIMING
       waited_digits += clock64() - c0;
 #endif
@@ -733,7 +739,7 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
     // (the block waited for `wb`: the slot has been read)
     if (lane == 0u) sync[L::kConsumed] = b + 1u;
     if (!last) {
-      seq = wait_words(b + 1u);
+      seq = ((seq_early & ~(L::kLast | L::kBail)) == b + 2u || (seq_early & L::kBail)) ? seq_early : wait_words(b + 1u);
       if (seq & L::kBail) { bail = true; break; }
       read_words(wa, (b + 1u) % L::kSlots, 0u);
     }
@@ -1101,7 +1107,8 @@ struct PipeDecLds {
 // symbol | M << 16 (M before the step) to row K of the raw plane.  FLAG: the verification failed (estimate one off,
 // ~1e-5, or damaged input) — the caller then repeats the block from its saved state with the generic steps.
 // Fixed temporaries v104-v141; v123 = v125 = 0.
-// TFC_PDEC_ABL (build switch, timing experiments only — results are wrong): 1 the step stores nothing
+// TFC_PDEC_ABL (build switch, bits, timing experiments only — results are wrong): 1 the step stores nothing, 2 one load per
+// window request instead of five, 4 no flush of the raw rows
 #ifndef TFC_PDEC_ABL
 #define TFC_PDEC_ABL 0
 #endif
@@ -1405,6 +1412,10 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   unsigned int k = 0u;               // rows written
   auto flush = [&]() {
     if (!staged) return;
+#if TFC_PDEC_ABL & 4
+    staged = false;                  // (timing experiment, results wrong: the raw rows stay in LDS)
+    return;
+#endif
     unsigned char* dst = reinterpret_cast<unsigned char*>(raw + static_cast<size_t>(staged_k) * 64) + 16u * lane;
 #pragma unroll
     for (unsigned int j = 0; j < L::kStage / 1024u; ++j) {
