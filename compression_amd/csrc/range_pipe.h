@@ -334,7 +334,13 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 // (hi, 0) register pairs TFC_LENC_B multiplies from.
 // (TFC_LENC_B of range_lanes.h with its temporaries at v100-v119: a chain workgroup is eight waves (sixteen before round 5), two per SIMD,
 // 128 registers each)
-#define TFC_PENC_STEP(W)                                                                   \
+// Three forms of the row's last part:
+//  * TFC_PENC_STEP (enc_chain_direct_kernel): the digit is stored big-endian, FLAG counts the steps that leave 0xFFFF held;
+//  * TFC_PENC_STEP_H (enc_chain_kernel, round 5): 27 instructions instead of 30 — the digit goes to LDS as it is (the storer
+//    wave swaps the bytes of what it copies), the new held digit is selected out of bs's upper half by the v_cndmask itself
+//    (SDWA), and a lane that holds 0xFFFF after a step leaves EXEC like one that meets "no call" (the caller looks at H
+//    behind the block: the wave repeats the block call by call either way).
+#define TFC_PENC_ROW(W)                                                                    \
   "v_cmpx_ne_u32 vcc, %[NOCALL], %[" #W "]\n\t"                                            \
   "v_and_b32 v100, %[KFFFF], %[" #W "]\n\t"                                                \
   "v_lshrrev_b32 v102, 16, %[" #W "]\n\t"                                                  \
@@ -349,7 +355,9 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   "v_sub_u32 v109, v106, v104\n\t"                                                        \
   "v_sub_u32 v117, v111, %[H]\n\t"                                                        \
   "v_cmp_gt_u32 vcc, %[K64K], v109\n\t"                                                   \
-  "v_cndmask_b32 v118, 0, 1, vcc\n\t"                                                     \
+  "v_cndmask_b32 v118, 0, 1, vcc\n\t"
+#define TFC_PENC_STEP(W)                                                                   \
+  TFC_PENC_ROW(W)                                                                          \
   "v_perm_b32 v110, 0, v111, %[PERM]\n\t"                                                 \
   "ds_write_b16 %[NA], v110\n\t"                                                          \
   "v_or_b32 v112, v117, v118\n\t"                                                         \
@@ -365,6 +373,20 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   "v_bfi_b32 %[HAD], v117, v118, v119\n\t"                                                \
   "v_cmp_eq_u32 vcc, %[KFFFF], %[H]\n\t"                                                  \
   "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"
+#define TFC_PENC_STEP_H(W)                                                                 \
+  TFC_PENC_ROW(W)                                                                          \
+  "ds_write_b16 %[NA], v111\n\t"                                                          \
+  "v_or_b32 v112, v117, v118\n\t"                                                         \
+  "v_and_b32 v112, v112, %[HAD]\n\t"                                                      \
+  "v_lshl_add_u32 %[NA], v112, 1, %[NA]\n\t"                                              \
+  "v_lshlrev_b32 v114, 16, v108\n\t"                                                      \
+  "v_lshl_or_b32 v115, v109, 16, %[KFFFF]\n\t"                                            \
+  "v_cndmask_b32 %[BASE], v108, v114, vcc\n\t"                                            \
+  "v_cndmask_b32 %[S], v109, v115, vcc\n\t"                                               \
+  "v_cndmask_b32_sdwa %[H], %[H], v108, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+  "v_or_b32 v119, %[HAD], v118\n\t"                                                       \
+  "v_bfi_b32 %[HAD], v117, v118, v119\n\t"                                                \
+  "v_cmpx_ne_u32 vcc, %[KFFFF], %[H]\n\t"
 
 // LDS of one group of a chain workgroup: call words in, digits out (see enc_chain_kernel)
 struct PipeEncChainLds {
@@ -554,7 +576,11 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
 #pragma unroll
         for (unsigned int c = 0; c < L::kDigits / 16u; ++c) {
           if (16u * c < rec.y && rec.x + 16u * c + 16u <= pa.cap) {
-            const uint2 lo = reinterpret_cast<const uint2*>(src)[2 * c], hi = reinterpret_cast<const uint2*>(src)[2 * c + 1];
+            // (the chain leaves its digits in LDS as 16-bit values; a stream is big-endian: a byte swap per half, here,
+            // off the chain)
+            uint2 lo = reinterpret_cast<const uint2*>(src)[2 * c], hi = reinterpret_cast<const uint2*>(src)[2 * c + 1];
+            lo.x = __builtin_amdgcn_perm(lo.x, lo.x, 0x02030001u); lo.y = __builtin_amdgcn_perm(lo.y, lo.y, 0x02030001u);
+            hi.x = __builtin_amdgcn_perm(hi.x, hi.x, 0x02030001u); hi.y = __builtin_amdgcn_perm(hi.y, hi.y, 0x02030001u);
             lanes_gstore16(dst + 16u * c, lo, hi);
           }
         }
@@ -582,7 +608,7 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
   unsigned int ds_off = area_off + L::kDig + L::kDigStride * lane;             // ... as an LDS address
 
   auto put = [&](unsigned int d, bool on) {
-    *reinterpret_cast<unsigned short*>(dstage + n) = __builtin_bswap16(static_cast<unsigned short>(d));
+    *reinterpret_cast<unsigned short*>(dstage + n) = static_cast<unsigned short>(d);      // (as it is: the storer swaps the bytes)
     n += on ? 2u : 0u;
   };
   // (rare: a run of 0xFFFF digits settles) the run's bytes behind the iteration's digits; a run that does not fit the
@@ -635,21 +661,21 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
   // one hand-scheduled block on 16 call words
   auto block = [&](const unsigned int (&ww)[kPipeBlock]) __attribute__((always_inline)) {
     const unsigned int base0 = base, s10 = s1, hd0 = hd, had0 = had;
-    unsigned int flag = rn, na = ds_off + n;
+    unsigned int na = ds_off + n;
 #if TFC_PIPE_TIMING
     const unsigned long long tb0 = clock64();
 #endif
     asm volatile(
         "s_mov_b64 s[56:57], exec\n\t"
         "v_mov_b32 v101, 0\n\tv_mov_b32 v103, 0\n\t"
-        TFC_PENC_STEP(W0) TFC_PENC_STEP(W1) TFC_PENC_STEP(W2) TFC_PENC_STEP(W3)
-        TFC_PENC_STEP(W4) TFC_PENC_STEP(W5) TFC_PENC_STEP(W6) TFC_PENC_STEP(W7)
-        TFC_PENC_STEP(W8) TFC_PENC_STEP(W9) TFC_PENC_STEP(W10) TFC_PENC_STEP(W11)
-        TFC_PENC_STEP(W12) TFC_PENC_STEP(W13) TFC_PENC_STEP(W14) TFC_PENC_STEP(W15)
+        TFC_PENC_STEP_H(W0) TFC_PENC_STEP_H(W1) TFC_PENC_STEP_H(W2) TFC_PENC_STEP_H(W3)
+        TFC_PENC_STEP_H(W4) TFC_PENC_STEP_H(W5) TFC_PENC_STEP_H(W6) TFC_PENC_STEP_H(W7)
+        TFC_PENC_STEP_H(W8) TFC_PENC_STEP_H(W9) TFC_PENC_STEP_H(W10) TFC_PENC_STEP_H(W11)
+        TFC_PENC_STEP_H(W12) TFC_PENC_STEP_H(W13) TFC_PENC_STEP_H(W14) TFC_PENC_STEP_H(W15)
         "s_mov_b64 exec, s[56:57]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na), [FLAG] "+v"(flag)
-        : [NOCALL] "s"(kPipeNoCall), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x0c0c0001u),
+        : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na)
+        : [NOCALL] "s"(kPipeNoCall), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu),
           [W0] "v"(ww[0]), [W1] "v"(ww[1]), [W2] "v"(ww[2]), [W3] "v"(ww[3]), [W4] "v"(ww[4]), [W5] "v"(ww[5]),
           [W6] "v"(ww[6]), [W7] "v"(ww[7]), [W8] "v"(ww[8]), [W9] "v"(ww[9]), [W10] "v"(ww[10]), [W11] "v"(ww[11]),
           [W12] "v"(ww[12]), [W13] "v"(ww[13]), [W14] "v"(ww[14]), [W15] "v"(ww[15])
@@ -659,7 +685,9 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
     t_blocks += clock64() - tb0;
     ++n_blocks;
 #endif
-    if (__builtin_expect(!__any(flag != 0u), 1)) {
+    // a lane that came in inside a run of 0xFFFF digits, or holds 0xFFFF behind some step of the block (it left the block
+    // there: the held digit is still the one)
+    if (__builtin_expect(!__any(rn != 0u || hd == 0xFFFFu), 1)) {
       n = na - ds_off;
     } else {
 #if TFC_PIPE_TIMING
