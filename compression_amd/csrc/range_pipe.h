@@ -336,10 +336,14 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
 // 128 registers each)
 // Three forms of the row's last part:
 //  * TFC_PENC_STEP (enc_chain_direct_kernel): the digit is stored big-endian, FLAG counts the steps that leave 0xFFFF held;
-//  * TFC_PENC_STEP_H (enc_chain_kernel, round 5): 27 instructions instead of 30 — the digit goes to LDS as it is (the storer
-//    wave swaps the bytes of what it copies), the new held digit is selected out of bs's upper half by the v_cndmask itself
-//    (SDWA), and a lane that holds 0xFFFF after a step leaves EXEC like one that meets "no call" (the caller looks at H
-//    behind the block: the wave repeats the block call by call either way).
+//  * TFC_PENC_STEP_H (enc_chain_kernel, round 5): 23 instructions instead of 30 — the digit goes to LDS as it is (the storer
+//    wave swaps the bytes of what it copies); the new held digit is selected out of bs's upper half by the v_cndmask itself
+//    (SDWA); a lane that holds 0xFFFF or more after a step leaves EXEC like one that meets "no call" (the caller looks at H
+//    behind the block: the wave repeats the block call by call either way); and a carry does not push the held digit out
+//    (the reference's form: the digit is final, nothing is held behind it) but stays in it, X = H + c held on — the digit
+//    leaves with the next renormalisation, the same bytes in the same order, no second carry can reach it, and
+//    (held, X) is a state every other kernel and finalize read the same way — which takes the carry out of the
+//    bookkeeping: emit = r & held, held' = held | r, with `held` kept as 0 / 2 (the cursor's increment; v119 = 2).
 #define TFC_PENC_ROW(W)                                                                    \
   "v_cmpx_ne_u32 vcc, %[NOCALL], %[" #W "]\n\t"                                            \
   "v_and_b32 v100, %[KFFFF], %[" #W "]\n\t"                                                \
@@ -374,19 +378,29 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   "v_cmp_eq_u32 vcc, %[KFFFF], %[H]\n\t"                                                  \
   "v_addc_co_u32 %[FLAG], vcc, 0, %[FLAG], vcc\n\t"
 #define TFC_PENC_STEP_H(W)                                                                 \
-  TFC_PENC_ROW(W)                                                                          \
+  "v_cmpx_ne_u32 vcc, %[NOCALL], %[" #W "]\n\t"                                            \
+  "v_and_b32 v100, %[KFFFF], %[" #W "]\n\t"                                                \
+  "v_lshrrev_b32 v102, 16, %[" #W "]\n\t"                                                  \
+  "v_mad_u64_u32 v[104:105], s[52:53], v100, %[S], v[100:101]\n\t"                         \
+  "v_mad_u64_u32 v[106:107], s[52:53], v102, %[S], v[102:103]\n\t"                         \
+  "v_alignbit_b32 v104, v105, v104, 16\n\t"                                               \
+  "v_alignbit_b32 v106, v107, v106, 16\n\t"                                               \
+  "v_add_u32 v106, -1, v106\n\t"                                                          \
+  "v_min_u32 v106, v106, %[S]\n\t"                                                        \
+  "v_add_co_u32 v108, vcc, %[BASE], v104\n\t"                                             \
+  "v_addc_co_u32 v111, vcc, 0, %[H], vcc\n\t"                                             \
+  "v_sub_u32 v109, v106, v104\n\t"                                                        \
+  "v_cmp_gt_u32 vcc, %[K64K], v109\n\t"                                                   \
   "ds_write_b16 %[NA], v111\n\t"                                                          \
-  "v_or_b32 v112, v117, v118\n\t"                                                         \
-  "v_and_b32 v112, v112, %[HAD]\n\t"                                                      \
-  "v_lshl_add_u32 %[NA], v112, 1, %[NA]\n\t"                                              \
+  "v_cndmask_b32 v112, 0, %[HAD], vcc\n\t"                                                \
+  "v_add_u32 %[NA], %[NA], v112\n\t"                                                      \
+  "v_cndmask_b32 %[HAD], %[HAD], v119, vcc\n\t"                                           \
   "v_lshlrev_b32 v114, 16, v108\n\t"                                                      \
   "v_lshl_or_b32 v115, v109, 16, %[KFFFF]\n\t"                                            \
   "v_cndmask_b32 %[BASE], v108, v114, vcc\n\t"                                            \
   "v_cndmask_b32 %[S], v109, v115, vcc\n\t"                                               \
-  "v_cndmask_b32_sdwa %[H], %[H], v108, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
-  "v_or_b32 v119, %[HAD], v118\n\t"                                                       \
-  "v_bfi_b32 %[HAD], v117, v118, v119\n\t"                                                \
-  "v_cmpx_ne_u32 vcc, %[KFFFF], %[H]\n\t"
+  "v_cndmask_b32_sdwa %[H], v111, v108, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+  "v_cmpx_gt_u32 vcc, %[KFFFF], %[H]\n\t"
 
 // LDS of one group of a chain workgroup: call words in, digits out (see enc_chain_kernel)
 struct PipeEncChainLds {
@@ -661,20 +675,20 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
   // one hand-scheduled block on 16 call words
   auto block = [&](const unsigned int (&ww)[kPipeBlock]) __attribute__((always_inline)) {
     const unsigned int base0 = base, s10 = s1, hd0 = hd, had0 = had;
-    unsigned int na = ds_off + n;
+    unsigned int na = ds_off + n, had2 = had << 1;
 #if TFC_PIPE_TIMING
     const unsigned long long tb0 = clock64();
 #endif
     asm volatile(
         "s_mov_b64 s[56:57], exec\n\t"
-        "v_mov_b32 v101, 0\n\tv_mov_b32 v103, 0\n\t"
+        "v_mov_b32 v101, 0\n\tv_mov_b32 v103, 0\n\tv_mov_b32 v119, 2\n\t"
         TFC_PENC_STEP_H(W0) TFC_PENC_STEP_H(W1) TFC_PENC_STEP_H(W2) TFC_PENC_STEP_H(W3)
         TFC_PENC_STEP_H(W4) TFC_PENC_STEP_H(W5) TFC_PENC_STEP_H(W6) TFC_PENC_STEP_H(W7)
         TFC_PENC_STEP_H(W8) TFC_PENC_STEP_H(W9) TFC_PENC_STEP_H(W10) TFC_PENC_STEP_H(W11)
         TFC_PENC_STEP_H(W12) TFC_PENC_STEP_H(W13) TFC_PENC_STEP_H(W14) TFC_PENC_STEP_H(W15)
         "s_mov_b64 exec, s[56:57]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had), [NA] "+v"(na)
+        : [BASE] "+v"(base), [S] "+v"(s1), [H] "+v"(hd), [HAD] "+v"(had2), [NA] "+v"(na)
         : [NOCALL] "s"(kPipeNoCall), [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu),
           [W0] "v"(ww[0]), [W1] "v"(ww[1]), [W2] "v"(ww[2]), [W3] "v"(ww[3]), [W4] "v"(ww[4]), [W5] "v"(ww[5]),
           [W6] "v"(ww[6]), [W7] "v"(ww[7]), [W8] "v"(ww[8]), [W9] "v"(ww[9]), [W10] "v"(ww[10]), [W11] "v"(ww[11]),
@@ -687,8 +701,9 @@ __global__ void __launch_bounds__(1024) enc_chain_kernel(const PipeChainJobs job
 #endif
     // a lane that came in inside a run of 0xFFFF digits, or holds 0xFFFF behind some step of the block (it left the block
     // there: the held digit is still the one)
-    if (__builtin_expect(!__any(rn != 0u || hd == 0xFFFFu), 1)) {
+    if (__builtin_expect(!__any(rn != 0u || hd >= 0xFFFFu), 1)) {
       n = na - ds_off;
+      had = had2 >> 1;
     } else {
 #if TFC_PIPE_TIMING
       ++n_redone;
