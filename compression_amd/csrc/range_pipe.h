@@ -1145,11 +1145,11 @@ struct PipeDecLds {
 //           M = -M calls to go (the magnitude's lower bits, then the sign)
 //   M > 0   M binary calls to go
 // (the arithmetic and its place in the step: "Round 5" below.)
-// A lane with M' = 0 has completed an element: its row pointer PW moves on and the next step's row is the directory
-// entry requested during this step; with M' != 0 the next row is the built-in binary row B0..B3.  Every step stores
-// symbol | M << 16 (M before the step) to row K of the raw plane.  FLAG: the verification failed (estimate one off,
-// ~1e-5, or damaged input) — the caller then repeats the block from its saved state with the generic steps.
-// Fixed temporaries v104-v141; v123 = v125 = 0.
+// A lane with M' = 0 has completed an element: its row pointer PW moves on and the next step's row is the next
+// element's directory entry; with M' != 0 the next row is the built-in binary row.  Every step writes its raw entry
+// (pipe_raw_entry: the symbol, or 0x8000 | bit on the binary row) to row K of the wave's staging area.  FLAG: the
+// verification failed (estimate one off, ~1e-6, or damaged input) — the caller then repeats the block from its saved
+// state step by step.  Fixed temporaries v104-v142; v123 = v125 = 0.
 // TFC_PDEC_ABL (build switch, bits, timing experiments only — results are wrong): 1 the step stores nothing, 2 one load per
 // window request instead of five, 4 no flush of the raw rows
 #ifndef TFC_PDEC_ABL
@@ -1163,30 +1163,21 @@ struct PipeDecLds {
 #define TFC_PDEC_STORE(KOFF) "ds_write_b16 %[STG], v117 offset:" #KOFF "\n\t"
 #define TFC_PDEC_WAIT2 "s_waitcnt lgkmcnt(2)\n\t"
 #endif
-// Round 5: the schedule of a step.  The wave issues one instruction per ~4.3 cycles whatever it is, and the two LDS
-// round trips (quotient -> bitmap word + count; symbol -> cdf entries) cost ~85-105 cycles each with 64 lanes in
-// different rows (bank conflicts: ~35 cycles of a step, tools/chain_clock_probe.py with IDENTICAL_STREAMS) — so what a
-// step costs is its instructions ON the chain (quotient 12, rank 6, bounds + renormalisation 14) plus whatever part of
-// the two trips the other instructions do not cover.  Round 4's step derived the mode counter from the SYMBOL, which is
-// only known after the first trip: 15 of its 21 bookkeeping instructions sat in the second trip's shadow, 6 in the
-// first's, and the wave waited ~80 + ~40 cycles.  But whether a step's symbol is the escape symbol (or, on the binary
-// row, which bit it is) is a comparison of the QUOTIENT with one boundary of the row — q >= cdf[escape symbol]
-// (q >= 2^(p-1) on the binary row) <=> rank(q) is the last symbol — and the rank structure returns exactly rank(q_est),
-// so the comparison on q_est gives the bookkeeping the very symbol class the verification then checks.  The row's
-// boundary (ESCLO) sits in the upper half of the directory entry's info word (dec_chain_kernel rewrites the directory
-// of its LDS copy), the whole mode arithmetic needs nothing the trips return, and the step spreads it and the row
-// select over both shadows; the verification flag and the code cursor's increment are taken in the NEXT step's shadow
-// (v130 / v131 / v133 survive until its tail), the digit's byte swap is folded into the v_perm that renormalises D.
-//   M' = M - 1 + [M = 0] + (q >= ESCLO ? delta : 0),   delta = -1 (M = 0), 1 - 2 M (M < 0), 0 (M > 0).
-// With these the step is bound by its instruction count (298 cycles for 61 slots, the LDS waits nearly gone), so:
-// the ROW of the next step is one LDS read of the directory entry at the SELECTED address (M' = 0: the next element's
-// entry, else the binary row's) straight into v104-v107, where a block keeps the current row — instead of a
-// speculative read of the next entry and four selects; the raw entry (16 bits, pipe_raw_entry) is the symbol or'd with
-// v143 = 0x8000 where the step came in with M != 0, kept from the previous step's M' = 0 test (one more select; the mode
-// counter alternates between two registers, MI -> MO); and the "31 zeros in a prefix" test (damaged input) is the
-// caller's, once per block: a lane that enters a block with M > -16 cannot get to -32 inside it.  (Every instruction
-// counts, also in a shadow: with the entry as 0x8000 | (M & 0x7F) << 1 | bit — four instructions more in the second
-// shadow — the step took 305 cycles instead of 288.)
+// Round 5, first pass: the schedule of a step.  The wave issues one instruction per ~4 cycles whatever it is, and the two
+// LDS round trips (quotient -> bitmap word + count; symbol -> cdf entries) have to be covered by instructions that do not
+// need what they return.  Round 4's step derived the mode counter from the SYMBOL, which is only known after the first
+// trip: 15 of its 21 bookkeeping instructions sat in the second trip's shadow, 6 in the first's, and the wave waited
+// ~80 + ~40 cycles.  But whether a step's symbol is the escape symbol (or, on the binary row, which bit it is) is a
+// comparison of the QUOTIENT with one boundary of the row — q >= cdf[escape symbol] (q >= 2^(p-1) on the binary row) <=>
+// rank(q) is the last symbol — and the rank structure returns exactly rank(q_est), so the comparison on q_est gives the
+// bookkeeping the very symbol class the verification then checks.  The row's boundary (ESCLO) sits in the upper half of
+// the directory entry's info word (dec_chain_kernel rewrites the directory of its LDS copy), the whole mode arithmetic
+// needs nothing the trips return, and the step spreads it and the row select over both shadows; the verification and the
+// code cursor's increment are taken in the NEXT step's first shadow, the digit's byte swap is folded into the v_perm that
+// renormalises D.  The ROW of the next step is one LDS read of the directory entry at the SELECTED address (M' = 0: the
+// next element's entry, else the binary row's) straight into v104-v107, where a block keeps the current row; the mode
+// counter alternates between two registers (MI -> MO); and the "31 zeros in a prefix" test (damaged input) is the
+// caller's, once per block: a lane that enters a block with M > -16 cannot get to -32 inside it.
 // LDS operations of a step, in issue order (they complete in order): bitmap word, count | (index mode: next row
 // address) digit | cdf lo, cdf hi, the raw entry's write, the next step's row.
 // Round 5, second pass (tools/r05_step_pad.sh: two dummy instructions cost 8.0 cycles in ANY of the step's four parts —
