@@ -17,7 +17,7 @@
 //     round trip whatever the row width (rows must be strictly increasing, checked on the host);
 //   * exact verification with the two bounds the state update needs anyway,
 //     A = (span * cdf[s]) >> p <= D < B = (span * cdf[s+1]) >> p  — the reference's search condition
-//     (range_coder.h:204-222, 249-258); the estimate is off for ~1e-5 of the symbols
+//     (range_coder.h:204-222, 249-258); the estimate is off for ~1e-6 of the symbols
 //     (tools/lanes_proto.py), which a wave-uniform rare branch corrects by stepping s.
 //   The Elias-gamma escape bits are decoded by the same step on a built-in binary row, with a small
 //   per-lane mode machine, so a lane that meets an escape falls behind its neighbours instead of
@@ -837,11 +837,11 @@ struct DecWaveLds {
 #define TFC_LDEC_STEP(ROW0, ROW1, ROW2, ROW3, PREFETCH, OUTOFF, ESC1, ESC2)                \
   PREFETCH                                                                                \
   "ds_read_u16 v109, %[CP]\n\t"                                                           \
-  "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
   "v_cvt_f32_u32 v111, %[S]\n\t"                                                          \
+  "v_add_f32 v111, 1.0, v111\n\t"                                                         \
   "v_rcp_f32 v111, v111\n\t"                                                              \
+  "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
   "v_fma_f32 v110, v110, %[SCALE], %[HSCALE]\n\t"                                         \
-  "s_nop 0\n\t"                                                                           \
   "v_mul_f32 v110, v110, v111\n\t"                                                        \
   "v_cvt_u32_f32 v110, v110\n\t"                                                          \
   "v_min_u32 v110, %[QMAX], v110\n\t"                                                     \
@@ -969,7 +969,10 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
   }
 
   const float scale = static_cast<float>(1u << la.precision);     // quotient scale: 2^precision
-  float hscale = 0.5f * scale;                                    // ... and half of it, in vector registers for the block
+  // The estimate is the float image of the exact quotient (D + 1) 2^p / (S + 1) — the symbol is the rank of its ceiling
+  // minus one (range_pipe.h, "Round 5, second pass": it lands across a boundary for ~1e-6 of the steps; (D + 1/2) 2^p / S,
+  // rounds 2 - 4, for 3e-5, a block of generic steps each time) — so the addend of the numerator is the scale itself.
+  float hscale = scale;                                           // (in a vector register for the block)
   unsigned int k31 = 0x80000000u;
   asm volatile("" : "+v"(hscale), "+v"(k31));
   const unsigned int cp_max = (1u << la.precision) - 1u;
@@ -1074,7 +1077,7 @@ __global__ void __launch_bounds__(512) dec_lanes_kernel(const DecLaneJobs<Dst> j
         unsigned int b = scale16(s1, hi) - 1u;      // B - 1
         b = hi == 0u ? s1 : b;                      // the row's last entry, 2^16, is stored as 0: B = span
         if (__any(D - A > b - A)) {
-          // the estimate was one boundary off (~1e-5 of the symbols), or the input is damaged (offset
+          // the estimate was one boundary off (~1e-6 of the symbols), or the input is damaged (offset
           // outside the interval: the step is then taken with the clamped symbol)
           const unsigned int nsym = (row.y & 0x7FFFFFFFu) + (row.y >> 31);
           for (int fix = 0; fix < 4; ++fix) {
