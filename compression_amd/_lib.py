@@ -27,6 +27,7 @@ SIGNATURES = {
     "tfc_unit_to_image": (_int, [_vp, _int, _vp, C.c_int64, _vp]),
     "tfc_index_prepare": (_int, [_vp, _int, _vp, C.c_int64, _int, _vp]),
     "tfc_build_tables": (_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int64, _int, _vp, _vp]),
+    "tfc_build_tables_overflow": (_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int64, _int, _vp, _vp, _vp]),
     "tfc_deep_factorized_tails": (_int, [_vp, C.c_int64, C.c_int64, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "tfc_pad2d": (_int, [_vp, _vp, _int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _int, _int, _int, _int, _int, _vp]),
     "tfc_cache_bytes": (_int, [C.POINTER(C.c_longlong)]),

@@ -155,8 +155,11 @@ __global__ void __launch_bounds__(64) pmf_to_cdf_kernel(const float* pmf, int64_
 // turn, then the 64 partial sums are combined by the xor butterfly 32, 16, ..., 1 — what tests/test_tables_gpu.py
 // restates in numpy), the quantisation of pmf_to_cdf_kernel above on an LDS copy of the row, and the header + cdf at
 // out[offsets[r]] — offsets are the caller's prefix sums of length + 3.
+// `overflow` (or null): the caller's overflow mass per row — a prior in another dtype than float32 sums in ITS arithmetic
+// before the cast (continuous_base.py:277-279: reduce_sum in prior.dtype, then tf.cast(..., float32)).
 __global__ void __launch_bounds__(64) pmf_to_cdf_ragged_kernel(const float* pmf, int64_t stride, const int32_t* lengths,
-                                                               const int64_t* offsets, int precision, int32_t* out) {
+                                                               const int64_t* offsets, int precision, const float* overflow,
+                                                               int32_t* out) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   const int64_t r = blockIdx.x;
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(64) pmf_to_cdf_ragged_kernel(const float* pmf,
     part += x;
   }
   for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-  if (lane == 0) p[len] = fmaxf(1.f - part, 0.f);
+  if (lane == 0) p[len] = overflow ? overflow[r] : fmaxf(1.f - part, 0.f);
   __syncthreads();
   const int total = 1 << precision;
   int sum = 0;
@@ -211,6 +214,12 @@ __global__ void __launch_bounds__(64) pmf_to_cdf_ragged_kernel(const float* pmf,
 
 extern "C" int tfc_build_tables(const float* pmf, int64_t rows, int64_t stride, const int32_t* lengths,
                                 const int64_t* offsets, int64_t max_length, int precision, int32_t* out, void* stream) {
+  return tfc_build_tables_overflow(pmf, rows, stride, lengths, offsets, max_length, precision, nullptr, out, stream);
+}
+
+extern "C" int tfc_build_tables_overflow(const float* pmf, int64_t rows, int64_t stride, const int32_t* lengths,
+                                         const int64_t* offsets, int64_t max_length, int precision, const float* overflow,
+                                         int32_t* out, void* stream) {
   using namespace tfc;
   if (!(0 < precision && precision <= 16))
     return fail("`precision` must be in [1, 16]: %d", precision);
@@ -225,7 +234,7 @@ extern "C" int tfc_build_tables(const float* pmf, int64_t rows, int64_t stride, 
   TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pmf_to_cdf_ragged_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
   hipLaunchKernelGGL(pmf_to_cdf_ragged_kernel, dim3(static_cast<unsigned>(rows)), dim3(64), lds, st, pmf, stride,
-                     lengths, offsets, precision, out);
+                     lengths, offsets, precision, overflow, out);
   TFC_HIP(hipGetLastError());
   return 0;
 }

@@ -132,10 +132,17 @@ class ContinuousEntropyModelBase(torch.nn.Module, metaclass=abc.ABCMeta):
         # [-precision, cdf...] layout per row on the device, one read-back for the whole model (round 4: a launch, a
         # device sum and a read-back per row — 192 of each for bls2017)
         device = _lib.require_device()
-        pmf = pmf.reshape(max_length, num_pmfs).t().to(device, torch.float32).contiguous()
+        pmf = pmf.reshape(max_length, num_pmfs).t().to(device)
         lengths = pmf_length.expand(pmf_shape).reshape(num_pmfs).to(device, torch.int32).contiguous()
-        ends = torch.cumsum(lengths.to(torch.int64) + 3, 0)
         inside = torch.arange(max_length, device=device)[None, :] < lengths[:, None]
+        overflow = None
+        if dtype != torch.float32:
+            # the reference sums in the prior's dtype and casts afterwards (continuous_base.py:277-279); a float32 prior's
+            # sum is the kernel's (fixed order, csrc/pmf_to_cdf.hip)
+            mass = torch.where(inside, pmf, torch.zeros((), dtype=pmf.dtype, device=device)).sum(1)
+            overflow = torch.clamp(1 - mass, min=0).to(torch.float32).contiguous()
+        pmf = pmf.to(torch.float32).contiguous()
+        ends = torch.cumsum(lengths.to(torch.int64) + 3, 0)
         bad = inside & ~(torch.isfinite(pmf) & (pmf >= 0))
         total, any_bad = (int(v) for v in torch.stack([ends[-1], bad.any().to(torch.int64)]).cpu())
         if any_bad:
@@ -145,9 +152,9 @@ class ContinuousEntropyModelBase(torch.nn.Module, metaclass=abc.ABCMeta):
         offsets = (ends - (lengths.to(torch.int64) + 3)).contiguous()
         cdf = torch.empty(total, dtype=torch.int32, device=device)
         with torch.cuda.device(device):
-            _lib.check(_lib.lib().tfc_build_tables(pmf.data_ptr(), num_pmfs, max_length, lengths.data_ptr(),
-                                                   offsets.data_ptr(), max_length, precision, cdf.data_ptr(),
-                                                   _lib.stream_ptr()))
+            _lib.check(_lib.lib().tfc_build_tables_overflow(
+                pmf.data_ptr(), num_pmfs, max_length, lengths.data_ptr(), offsets.data_ptr(), max_length, precision,
+                overflow.data_ptr() if overflow is not None else None, cdf.data_ptr(), _lib.stream_ptr()))
         return cdf.cpu(), cdf_offset.cpu()
 
     def _log_prob(self, prior, bottleneck_perturbed):

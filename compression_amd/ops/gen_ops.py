@@ -135,6 +135,9 @@ class EncoderHandle:
         # deferred handles: how to issue every encode call again (one closure per call, taking a handle) — see
         # _retry_outgrown
         self._replay = []
+        # native encoders this handle has been (see _retry_outgrown): decoders created on their device strings and
+        # device_strings views read their blobs in place, so they live as long as the handle does
+        self._retired = []
         self.blob = None      # after finalize: device uint8 [total]
         self.offsets = None   # after finalize: device int64 [streams + 1]
 
@@ -146,6 +149,8 @@ class EncoderHandle:
 
     def __del__(self):
         try:
+            for old in getattr(self, "_retired", ()):
+                _lib.lib().tfc_encoder_destroy(old)
             if getattr(self, "ptr", None):
                 _lib.lib().tfc_encoder_destroy(self.ptr)
         except Exception:
@@ -163,7 +168,13 @@ def _retry_outgrown(handle: EncoderHandle) -> None:
     of the handle is issued again on a fresh SYNCHRONISING encoder — whose calls size their slabs from a counting pass,
     or repeat with the bound no stream can exceed — and the handle continues as that encoder.  (A decoder that was
     created on the handle's device strings before the report was read decoded the incomplete strings: its
-    EntropyDecodeFinalize flags say so.)"""
+    EntropyDecodeFinalize flags say so.)  The encoder the handle was before is NOT destroyed here: decoders made by
+    create_range_decoders and device_strings views read its blob in place and only keep this Python object alive —
+    it is parked on the handle and freed with it.
+
+    The replayed calls read the caller's tensors again, at retry time: inputs of a deferred handle must stay
+    unmodified until its first synchronising call (fetch_strings / entropy_encode_status / entropy_encode_finalize),
+    which also drops the handle's references to them."""
     fresh = EncoderHandle(handle.shape, handle.tables, handle.device, handle.mode, deferred_errors=False)
     for call in handle._replay:
         call(fresh)
@@ -174,7 +185,7 @@ def _retry_outgrown(handle: EncoderHandle) -> None:
     handle._replay = []
     handle.blob = handle.offsets = None
     handle.retried = True
-    _lib.lib().tfc_encoder_destroy(old)
+    handle._retired.append(old)
     if getattr(handle, "finalized_on_device", False):
         # the state the caller left it in: finalized, strings in HBM (device_strings views have to be taken again)
         _lib.check(_lib.lib().tfc_encoder_finalize_device(handle.ptr, _lib.stream_ptr()))
@@ -394,6 +405,8 @@ def entropy_encode_status(handle: EncoderHandle) -> int:
     handle whose speculative slab a stream outgrew is coded again here (_retry_outgrown): never an error."""
     total = C.c_int64()
     _with_retry(handle, lambda: _lib.check(_lib.lib().tfc_encoder_status(handle.ptr, _lib.stream_ptr(), C.byref(total))))
+    # the calls are known to have fitted (or were repeated): nothing will be replayed, the inputs may go
+    handle._replay = []
     return int(total.value)
 
 

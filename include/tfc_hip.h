@@ -352,6 +352,12 @@ int tfc_pmf_to_quantized_cdf(const float* pmf, int64_t rows, int64_t n, int prec
  * prefix sums of length + 3; out DEV int32 [sum]).  max_length = the largest length (sizes the kernel's LDS). */
 int tfc_build_tables(const float* pmf, int64_t rows, int64_t stride, const int32_t* lengths, const int64_t* offsets,
                      int64_t max_length, int precision, int32_t* out, void* stream);
+/* The same with the overflow mass of every row given (overflow DEV float32 [rows]; null: as tfc_build_tables): the
+ * reference forms max(1 - reduce_sum(p), 0) in the PRIOR's dtype and casts to float32 afterwards
+ * (continuous_base.py:277-279), so a float64 / bfloat16 prior's caller sums in that arithmetic itself. */
+int tfc_build_tables_overflow(const float* pmf, int64_t rows, int64_t stride, const int32_t* lengths,
+                              const int64_t* offsets, int64_t max_length, int precision, const float* overflow,
+                              int32_t* out, void* stream);
 /* helpers.estimate_tails (python/distributions/helpers.py:29-104) for a deep factorized prior
  * (python/distributions/deep_factorized.py:166-246), whole iteration on the device: for every target t (DEV float32
  * [num_targets]) and channel c, the x where the channel's logits of the cumulative reach t — out DEV [num_targets,

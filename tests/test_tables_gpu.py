@@ -147,3 +147,37 @@ def test_invalid_masses_are_reported_like_the_op():
     with pytest.raises(ValueError, match="non-finite or negative element"):
         tfc.entropy_models.ContinuousBatchedEntropyModel(Broken(loc=torch.zeros(4).cuda(), scale=torch.ones(4).cuda()),
                                                         coding_rank=1, compression=True)
+
+
+def test_float64_prior_sums_its_overflow_in_float64(port):
+    """continuous_base.py:277-279: max(1 - reduce_sum(p), 0) in the PRIOR's dtype, the cast to float32 afterwards — a
+    float64 prior's rows equal the oracle's PmfToQuantizedCdf of float32(p) with float32(max(1 - sum64(p), 0)) appended
+    (tfc_build_tables_overflow), which differs from the float32 sum's table where the two overflow masses round apart."""
+    import compression_amd as tfc
+    from compression_amd import synthetic
+    scale = torch.linspace(0.3, 40.0, 48, dtype=torch.float64).cuda()
+    prior = tfc.distributions.NoisyNormal(loc=torch.zeros_like(scale), scale=scale, dtype=torch.float64)
+    assert prior.dtype == torch.float64
+    em = tfc.entropy_models.ContinuousBatchedEntropyModel(prior, coding_rank=1, compression=True)
+    precision = em.range_coder_precision
+    table, minima = em.cdf.cpu().numpy(), em.cdf_offset.cpu().numpy()
+    rows = synthetic.lookup_rows(table)
+    assert len(rows) == 48
+    lengths = np.array([len(c) - 2 for _, c in rows])
+    qoff = getattr(em, "quantization_offset", None)
+    with torch.no_grad():
+        start = torch.from_numpy(minima).to(torch.float64)
+        if qoff is not None:
+            start = start + qoff.reshape(-1).cpu().to(torch.float64)
+        samples = (torch.arange(int(lengths.max()), dtype=torch.float64).reshape(-1, 1) + start.reshape(1, -1)).cuda()
+        pmf = prior.prob(samples).t().cpu().numpy()
+    assert pmf.dtype == np.float64
+    differ = 0
+    for r, (sp, c) in enumerate(rows):
+        p64 = pmf[r, :lengths[r]]
+        overflow = np.float32(max(1.0 - p64.sum(dtype=np.float64), 0.0))
+        differ += int(overflow != overflow_like_the_kernel(p64.astype(np.float32)))
+        full = np.concatenate([p64.astype(np.float32), [overflow]]).astype(np.float32)
+        want = np.asarray(port.pmf_to_quantized_cdf(full, precision), np.int32)
+        assert sp == -precision and np.array_equal(np.asarray(c, np.int32), want), r
+    print(f"rows whose float64 and float32 overflow masses differ as float32: {differ} of {len(rows)}")
