@@ -640,15 +640,69 @@ class StepRecord:
     def __init__(self, out, x_hat, oks, end):
         self.out, self.x_hat, self.oks, self.end = out, x_hat, oks, end
         self.strings = None
+        self.gathered = None
 
 
-def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
+class StepGather:
+    """The collective a multi-GPU model step ends with: the coded strings of every rank's images on every
+    rank — per encoder handle one all-gather of lengths and totals and one of the bytes in fixed-capacity slots
+    (parallel.gather_encoded_async), enqueued on the step's own stream behind its kernels with nothing read back, so the
+    steps in flight stay in flight.  The slot size is a host-side number: twice the largest per-rank total the first
+    (untimed, synchronising) gather of each handle position saw, agreed between the ranks; a step that outgrows it is
+    flagged on the device and counted when it is retired."""
+
+    def __init__(self, device, group=None):
+        from compression_amd import parallel
+        self.parallel, self.device, self.group = parallel, device, group
+        self.caps = {}
+        self.gathers = self.steps = self.overflows = 0
+        self.events = []
+
+    def __call__(self, handles):
+        import torch.distributed as dist
+        from compression_amd.ops import gen_ops
+        out = []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i, h in enumerate(handles):
+            blob, off = gen_ops.device_strings(h)
+            if i not in self.caps:
+                total = off[-1:].clone()
+                dist.all_reduce(total, op=dist.ReduceOp.MAX, group=self.group)
+                self.caps[i] = max(4096, (2 * int(total) + 65535) // 65536 * 65536)
+                out.append(self.parallel.gather_encoded(blob[:int(off[-1])], off, group=self.group))
+            else:
+                out.append(self.parallel.gather_encoded_async(blob, off, self.caps[i], h.streams, group=self.group))
+            self.gathers += 1
+        e1.record()
+        self.events.append((e0, e1))
+        self.steps += 1
+        return out
+
+    def retire(self, gathered):
+        for g in gathered or ():
+            if isinstance(g, self.parallel.GatheredStrings) and bool(g.overflow):
+                self.overflows += 1
+
+    def reset(self):
+        self.gathers = self.steps = self.overflows = 0
+        self.events = []
+
+    def collective_ms_per_step(self):
+        """Mean time between the events around a step's gathers on the step's stream (after the timed region)."""
+        if not self.events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+
+def run_model_steps(model, x, steps, lanes, fetch=True, group=1, gather=None):
     """`steps` compress + decompress passes over `x`, step k on lanes[k % len(lanes)], all enqueued by this
     one thread with nothing read back inside a step; a lane's previous step is retired (host waits for its
     end event, fetches its strings and sanity flags) before the lane is reused — while the other lanes'
     steps keep the GPU busy.  group > 1: `group` steps (differently rolled copies of `x`) are enqueued as one
     unit through the model's compress_many / decompress_many — one coder launch per direction for all of
-    them.  Returns (seconds, last record)."""
+    them.  `gather` (a StepGather, multi-GPU runs): every unit ends with the variable-length gather of its strings across
+    the ranks, enqueued on the unit's stream.  Returns (seconds, last record)."""
     main = torch.cuda.current_stream()
     pending = [None] * len(lanes)
     last = None
@@ -667,7 +721,15 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
                         tfc.fetch_strings(h)
             for ok in rec.oks:
                 assert bool(ok.cpu().all()), "EntropyDecodeFinalize reported a failed stream"
+        if gather is not None:
+            gather.retire(rec.gathered)
         return rec
+
+    def handles_of(out, x_hat):
+        hs = [h for h in out if isinstance(h, tfc.gen_ops.EncoderHandle)]
+        for other in getattr(x_hat, "_tfc_group", (None, ()))[1]:
+            hs += [h for h in other if isinstance(h, tfc.gen_ops.EncoderHandle)]
+        return hs
 
     t0 = time.perf_counter()
     for k in range(units):
@@ -687,7 +749,12 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1):
             out = tuple(packed[0])
             x_hat, oks = x_hats[0], (ok if isinstance(ok, (list, tuple)) else [ok])
             x_hat._tfc_group = (x_hats, packed[1:])
+        gathered = None
+        if gather is not None:
+            with lane.on("coder"):
+                gathered = gather(handles_of(out, x_hat))
         pending[slot] = StepRecord(out, x_hat, oks, lane.end_event())
+        pending[slot].gathered = gathered
     order = [(k % len(lanes)) for k in range(max(0, units - len(lanes)), units)]
     for slot in order:
         if pending[slot] is not None:
@@ -725,30 +792,43 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
         # the host retires that step (waits for its end event, fetches strings and flags) and enqueues the next
         lanes = list(step_lanes.lanes) * max(1, queue)
         group = group if hasattr(model, "compress_many") else 1
-        run = lambda n: run_model_steps(model, x, n, lanes, group=group)
+        # multi-GPU: every step ENDS with the variable-length gather of its strings, inside the timed region
+        step_gather = StepGather(device) if distributed else None
+        run = lambda n: run_model_steps(model, x, n, lanes, group=group, gather=step_gather)
         steps = max(group, steps - steps % group)
         _lib.lib().tfc_set_chip_shared(1)                   # several steps in flight: pipeline.chip_shared()
         # untimed: every lane once (its buffers and streams primed); `inflight_warmup` units for the slow float32 C4
         run((inflight_warmup or max(warmup, len(lanes), 2)) * group)
         torch.cuda.synchronize()
         if distributed:
+            step_gather.reset()
             dist.barrier()
             torch.cuda.synchronize()
         elapsed, rec = run(steps)
         _lib.lib().tfc_set_chip_shared(0)
         gathered = None
+        collective = None
         if distributed:
-            # the coded strings of the whole batch on every rank: lengths, then padded bytes (two all-gathers)
-            gathered = []
-            for h in rec.out:
-                if isinstance(h, gen_ops.EncoderHandle):
-                    blob, off = gen_ops.device_strings(h)
-                    gathered.append(parallel.gather_encoded(blob[:int(off[-1])], off))
             dist.barrier()
             torch.cuda.synchronize()
+            gathered = [g.packed() if isinstance(g, parallel.GatheredStrings) else g for g in rec.gathered]
+            handles_per_unit = len(rec.gathered)
+            assert step_gather.steps == steps // group and step_gather.gathers == step_gather.steps * handles_per_unit, (
+                "every timed step must end with its gather", step_gather.steps, step_gather.gathers, steps, group)
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank_s = [float(v.item()) for v in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+            collective = {"gathers": step_gather.gathers, "steps": step_gather.steps,
+                          "collective_ms_per_step": round(step_gather.collective_ms_per_step() * step_gather.steps / steps, 4),
+                          "slot_bytes": [int(v) for _, v in sorted(step_gather.caps.items())],
+                          "slots_outgrown": step_gather.overflows,
+                          "per_rank_s": [round(v, 6) for v in per_rank_s],
+                          "note": "per unit of %d step(s): per encoder handle one all-gather of lengths + totals and one of "
+                                  "the bytes in fixed slots (parallel.gather_encoded_async), on the unit's stream, nothing "
+                                  "read back; ms between HIP events around them" % group}
         assert rec.x_hat.shape == x.shape
         # decode parity: what the decoder returned IS the quantised latent the encoder coded (every image)
         y_coded = rec.out[0].coder_inputs[0]
@@ -758,7 +838,13 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
         strings = rec.strings
         nbytes = sum(len(bytes(s)) for arr in strings for s in arr.reshape(-1))
         if gathered:
-            assert int(gathered[0][1][-1]) >= sum(len(bytes(s)) for s in strings[0].reshape(-1))
+            # the last unit's first handle as every rank now has it: this rank's images sit at their place, byte for byte
+            blob_all, offs_all = (t.cpu().numpy() for t in gathered[0])
+            mine = strings[0].reshape(-1)
+            assert len(offs_all) - 1 == world * len(mine)
+            for i, s_i in enumerate(mine):
+                k = rank * len(mine) + i
+                assert bytes(blob_all[offs_all[k]:offs_all[k + 1]]) == bytes(s_i), "gathered strings differ from this rank's own"
         res = None
         if rank == 0:
             pixels = world * batch * hw[0] * hw[1]
@@ -777,6 +863,7 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
                 "streams": len(step_lanes.lanes),
                 "steps_per_coder_launch": group,
                 "strings_fetched_to_host_in_timed_region": True,
+                "collective": collective,
                 "lone_step": {"ms_per_step": round(1e3 * lone_s / lone_steps, 3),
                               "mpixels_s": round(batch * hw[0] * hw[1] / 1e6 / (lone_s / lone_steps), 2),
                               "kernels_ms": {"conv2d": round(conv_ms, 3),
@@ -866,10 +953,16 @@ def model_workload(args, world, rank, device, distributed):
             "scaling": "weak", "vs_baseline": None, "dtype": args.model_dtype, "data": "synthetic",
             "config": {"workload": res["workload"], "parallelism": f"batch-sharded x{world}",
                        "steps_in_flight": res["steps_in_flight"], "steps_per_coder_launch": res["steps_per_coder_launch"],
-                       "collectives": "broadcast of weights + tables at setup; per step all-gather of string "
-                                      "lengths and padded bytes (RCCL)" if distributed else "none"},
+                       "collectives": "broadcast of weights + tables at setup; every step ends, inside the timed region, "
+                                      "with the all-gather of its strings' lengths and of their bytes in fixed slots "
+                                      "(RCCL, on the step's stream, nothing read back)" if distributed else "none"},
         }
-        for key in ("bits_per_pixel", "lone_step", "roofline", "scale_index_histogram", "cpu_baseline"):
+        if distributed and res.get("collective"):
+            pixels_rank = res["value"] * 1e6 * (res["ms_per_step"] / 1e3) / world      # pixels of one rank's step
+            line["per_rank"] = [{"rank": r, "mpixels_s": round(pixels_rank * res["steps"] / 1e6 / max(sec, 1e-9), 2)}
+                                for r, sec in enumerate(res["collective"]["per_rank_s"])]
+            line["collective_ms_per_step"] = res["collective"]["collective_ms_per_step"]
+        for key in ("bits_per_pixel", "lone_step", "roofline", "scale_index_histogram", "cpu_baseline", "collective"):
             if key in res:
                 line[key] = res[key]
         print(json.dumps(line))
@@ -1192,6 +1285,9 @@ def main():
     ap.add_argument("--spawn-check", action="store_true",
                     help="no measurement: start the --gpus ranks exactly as a measurement would, rendezvous over gloo on "
                          "the host, and print {world, ranks} (the CPU-tier test of the launch path)")
+    ap.add_argument("--collective-check", action="store_true",
+                    help="diagnostic for a one-GPU box: run the single rank inside an RCCL process group of world size 1, "
+                         "so that the model workloads' per-step gather (and every other distributed branch) executes")
     args = ap.parse_args()
 
     if maybe_spawn(args):
@@ -1205,12 +1301,16 @@ def main():
         return spawn_check(world, rank)
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs HIP device {local_rank}; {torch.cuda.device_count()} visible")
-    distributed = world > 1
+    distributed = world > 1 or args.collective_check
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     if args.workload != "c2":

@@ -79,19 +79,28 @@ __global__ void __launch_bounds__(1024) deep_factorized_tails_kernel(const float
   int count = 0, it = 0;
   for (;;) {
     // while loss.max() > 1e-8 and count.min() < 100 (helpers.py:78) — over the live channels
+    // (reduce_max propagates a NaN loss and `NaN > 1e-8` is false: the reference's loop ends at once and returns the
+    // best so far of every channel; fmaxf would drop the NaN, so it travels as +inf's complement: a flag)
     float wl = live ? loss : 0.f;
     int wc = live ? count : 0x7FFFFFFF;
+    const bool wn = __any(live && loss != loss);
     for (int off = 32; off > 0; off >>= 1) {
       wl = fmaxf(wl, __shfl_xor(wl, off, 64));
       wc = min(wc, __shfl_xor(wc, off, 64));
     }
-    if ((threadIdx.x & 63) == 0) { red_loss[threadIdx.x >> 6] = wl; red_count[threadIdx.x >> 6] = wc; }
+    // (a wave's NaN flag rides in its count word: -1 is below every count, tested before the minimum is used)
+    if ((threadIdx.x & 63) == 0) { red_loss[threadIdx.x >> 6] = wl; red_count[threadIdx.x >> 6] = wn ? -1 : wc; }
     __syncthreads();
     if (threadIdx.x == 0) {
       float ml = 0.f;
       int mc = 0x7FFFFFFF;
-      for (unsigned int w = 0; w < (blockDim.x + 63) / 64; ++w) { ml = fmaxf(ml, red_loss[w]); mc = min(mc, red_count[w]); }
-      go = (ml > 1e-8f && mc < 100 && it < kTailMaxIters) ? 1 : 0;
+      bool nan = false;
+      for (unsigned int w = 0; w < (blockDim.x + 63) / 64; ++w) {
+        ml = fmaxf(ml, red_loss[w]);
+        nan |= red_count[w] < 0;
+        mc = min(mc, red_count[w]);
+      }
+      go = (!nan && ml > 1e-8f && mc < 100 && it < kTailMaxIters) ? 1 : 0;
     }
     __syncthreads();
     const int cont = go;

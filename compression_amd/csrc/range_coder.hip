@@ -1617,18 +1617,40 @@ inline int side_stream(hipStream_t st, SideStream* out) {
 // encode (the expansion, 0.19 ms per job, is what bounds it beyond ~20 jobs) + 31 ms of decode (512 chain waves: two per
 // CU behind one 149 KB table image, and the parse beside them finds no CU) against 12.0 + 28.6 ms as 39 + 25 jobs.
 // A launch whose temporaries cannot be allocated runs on the lane-per-stream kernels, which need none.
-inline size_t pipe_temp_bytes() {
-  static const size_t v = [] {
-    if (const char* e = std::getenv("TFC_PIPE_TEMP_MB")) return static_cast<size_t>(std::max(1, std::atoi(e))) << 20;
+// (per device ordinal: a process may drive several devices of different memory sizes)
+struct PipeDeviceInfo {
+  size_t temp_bytes = 0;
+  int cus = 0;
+};
+inline const PipeDeviceInfo& pipe_device_info() {
+  constexpr int kMaxDevices = 64;
+  static PipeDeviceInfo info[kMaxDevices];
+  static std::once_flag once[kMaxDevices];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = std::min(std::max(dev, 0), kMaxDevices - 1);
+  std::call_once(once[dev], [dev] {
+    PipeDeviceInfo& d = info[dev];
+    d.cus = 256;
+    if (hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      d.cus = 256;
+    }
+    if (const char* e = std::getenv("TFC_PIPE_TEMP_MB")) {
+      d.temp_bytes = static_cast<size_t>(std::max(1, std::atoi(e))) << 20;
+      return;
+    }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
       (void)hipGetLastError();
-      return size_t{2} << 30;
+      d.temp_bytes = size_t{2} << 30;
+      return;
     }
-    return std::min<size_t>(size_t{6} << 30, total_b / 8);
-  }();
-  return v;
+    d.temp_bytes = std::min<size_t>(size_t{6} << 30, total_b / 8);
+  });
+  return info[dev];
 }
+inline size_t pipe_temp_bytes() { return pipe_device_info().temp_bytes; }
 
 // Lane-per-stream family: n handles (same tables, same stream count) coded by one launch per
 // kMaxLaneJobs of them; no counting pass, no read-back unless a handle wants its range errors now.
@@ -1675,9 +1697,7 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
   // A launch's chain workgroups must all be resident at once, next to an expansion that needs CUs of its own: a chain
   // workgroup (PipeEncChainLds::kGroups groups) takes a CU's whole LDS, so at most half the CUs go to chains — beyond
   // that the chains starve the expansion they wait for (and time out into the fallback).
-  int dev_e = 0, cus_e = 256;
-  (void)hipGetDevice(&dev_e);
-  (void)hipDeviceGetAttribute(&cus_e, hipDeviceAttributeMultiprocessorCount, dev_e);
+  const int cus_e = pipe_device_info().cus;
   const size_t resident_jobs = std::max<size_t>(1, static_cast<size_t>(cus_e / 2) * PipeEncChainLds::kGroups / std::max(1, pa.groups_per_job));
   const int per_launch = !pipe ? kMaxLaneJobs
                                : static_cast<int>(std::max<size_t>(1, std::min<size_t>(std::min<size_t>(kMaxLaneJobs, resident_jobs),
@@ -2740,9 +2760,7 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   // A launch's chain workgroups must all be resident at once (each holds the tables' image: one per CU for config 2's
   // 150 KB): a second round of them doubles the launch's time, and the parse next to the chain gives up on groups that
   // do not move (round 5: 16-bit raw rows made 64 config-2 batches fit the temporaries' budget — 512 groups on 256 CUs).
-  int dev_d = 0, cus_d = 256;
-  (void)hipGetDevice(&dev_d);
-  (void)hipDeviceGetAttribute(&cus_d, hipDeviceAttributeMultiprocessorCount, dev_d);
+  const int cus_d = pipe_device_info().cus;
   const size_t chain_wgs_per_job = static_cast<size_t>(ceil_div(pa.groups_per_job, std::max(1, pblock / 64)));
   const size_t resident_wgs = static_cast<size_t>(cus_d) * std::max<size_t>(1, (160 * 1024) / std::max(1, plds));
   const size_t resident_jobs = std::max<size_t>(1, resident_wgs / std::max<size_t>(1, chain_wgs_per_job));

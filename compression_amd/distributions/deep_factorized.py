@@ -3,6 +3,7 @@ per-channel monotone MLP for the logits of the cumulative, K = len(num_filters)+
 layers with softplus-reparameterised matrices and tanh gates."""
 from __future__ import annotations
 
+import logging
 import math
 
 import torch
@@ -12,6 +13,8 @@ from .base import Distribution
 from .uniform_noise import UniformNoiseAdapter
 
 __all__ = ["DeepFactorized", "NoisyDeepFactorized"]
+
+_DEVICE_TAIL_ITERATION_CAP = 100000       # kTailMaxIters of csrc/deep_factorized_tails.hip
 
 
 def _log_expm1(x: float) -> float:
@@ -99,10 +102,16 @@ class DeepFactorized(Distribution):
             params = pack_factorized_params(self)
             t = torch.tensor([float(v) for v in targets], dtype=torch.float32, device=m0.device)
             out = torch.empty((len(targets), channels), dtype=torch.float32, device=m0.device)
+            iters = torch.zeros(len(targets), dtype=torch.int32, device=m0.device)
             with torch.cuda.device(m0.device):
                 _lib.check(_lib.lib().tfc_deep_factorized_tails(
                     params.data_ptr(), channels, params.shape[1], len(self.num_filters) + 1, self.num_filters[0],
-                    t.data_ptr(), len(targets), out.data_ptr(), None, _lib.stream_ptr()))
+                    t.data_ptr(), len(targets), out.data_ptr(), iters.data_ptr(), _lib.stream_ptr()))
+            if int(iters.max()) >= _DEVICE_TAIL_ITERATION_CAP:
+                # the kernel's bound (the reference's loop has none): the tensor-op iteration decides instead
+                logging.warning("tfc_deep_factorized_tails stopped at its iteration cap (%d); falling back to the "
+                                "tensor-op iteration of helpers.estimate_tails", _DEVICE_TAIL_ITERATION_CAP)
+                return None
         return out.reshape((len(targets),) + tuple(self._batch_shape))
 
     def _quantization_offset(self):

@@ -8,7 +8,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_range", "gather_encoded", "broadcast_tables"]
+__all__ = ["shard_range", "gather_encoded", "gather_encoded_async", "GatheredStrings", "broadcast_tables"]
 
 
 def shard_range(total: int, rank: int, world: int):
@@ -46,6 +46,67 @@ def gather_encoded(blob: torch.Tensor, offsets: torch.Tensor, group=None):
     offs = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=device)
     offs[1:] = torch.cumsum(lens, 0)
     return blobs, offs
+
+
+class GatheredStrings:
+    """What gather_encoded_async leaves on every rank: the ranks' strings side by side, each rank's bytes in a slot of
+    `capacity_bytes`, its per-stream lengths in a slot of `capacity_streams`.  Stream i of rank r is
+    blob[r, starts[r, i] : starts[r, i] + lengths[r, i]]; `counts[r]` streams, `totals[r]` bytes.  `overflow` (device
+    bool): some rank had more bytes or streams than its slot takes — then packed() gathers again, exactly.  Nothing in
+    here has been looked at by the host."""
+
+    def __init__(self, blob, lengths, counts, totals, overflow, exact):
+        self.blob, self.lengths, self.counts, self.totals, self.overflow = blob, lengths, counts, totals, overflow
+        self._exact = exact          # () -> (blob_all, offsets_all) by the synchronising path
+
+    @property
+    def starts(self):
+        return torch.cumsum(self.lengths, 1) - self.lengths
+
+    def packed(self):
+        """(blob_all uint8, offsets_all int64) as gather_encoded returns them — ranks concatenated in rank order,
+        identical to one process coding the whole batch.  Synchronises (the host needs the sizes)."""
+        if bool(self.overflow):
+            return self._exact()
+        counts = [int(c) for c in self.counts.tolist()]
+        totals = [int(t) for t in self.totals.tolist()]
+        lens = torch.cat([self.lengths[r, :counts[r]] for r in range(len(counts))])
+        blobs = torch.cat([self.blob[r, :totals[r]] for r in range(len(totals))])
+        offs = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=lens.device)
+        offs[1:] = torch.cumsum(lens, 0)
+        return blobs, offs
+
+
+def gather_encoded_async(blob: torch.Tensor, offsets: torch.Tensor, capacity_bytes: int, capacity_streams: int = 0,
+                         group=None) -> GatheredStrings:
+    """The variable-length gather of SURVEY 8(e) without a host synchronisation: every rank contributes a slot of
+    FIXED capacity (`capacity_bytes`, `capacity_streams` — host-side numbers: a model's streams per rank, and a byte
+    bound the caller keeps from the steps it has already retired), so the two all-gathers (lengths + totals; padded
+    bytes) are enqueued with sizes the host knows and nothing is read back: a step in flight ends with its gather
+    and the host goes on enqueuing the next one.  Bytes beyond a slot are cut and flagged (GatheredStrings.overflow).
+    blob: uint8 [>= offsets[-1]] (a handle's device_strings view at slab capacity is fine), offsets int64 [streams + 1]."""
+    world = dist.get_world_size(group)
+    device = blob.device
+    streams = offsets.numel() - 1
+    cs = max(int(capacity_streams), streams, 1)
+    cb = max(int(capacity_bytes), 1)
+    # [lengths ... | streams | total bytes]: one collective for all the integers
+    meta = torch.zeros(cs + 2, dtype=torch.int64, device=device)
+    meta[:streams] = offsets[1:] - offsets[:-1]
+    meta[cs] = streams
+    meta[cs + 1] = offsets[-1]
+    pad = torch.zeros(cb, dtype=torch.uint8, device=device)
+    n = min(cb, blob.numel())
+    pad[:n] = blob[:n]            # (bytes past offsets[-1] inside the slot travel too: the receiver cuts at the total)
+    metas = torch.empty(world * (cs + 2), dtype=torch.int64, device=device)
+    blobs = torch.empty(world * cb, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(metas, meta, group=group)         # (flat outputs: the form gloo takes as well)
+    dist.all_gather_into_tensor(blobs, pad, group=group)
+    metas, blobs = metas.view(world, cs + 2), blobs.view(world, cb)
+    counts, totals = metas[:, cs], metas[:, cs + 1]
+    overflow = (totals > cb).any() | (counts > cs).any()
+    return GatheredStrings(blobs, metas[:, :cs], counts, totals, overflow,
+                           lambda: gather_encoded(blob[:int(offsets[-1])], offsets, group=group))
 
 
 def broadcast_tables(module: torch.nn.Module, src: int = 0, group=None):
