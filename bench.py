@@ -647,7 +647,7 @@ class StepGather:
     """The collective a multi-GPU model step ends with: the coded strings of every rank's images on every
     rank — per encoder handle one all-gather of lengths and totals and one of the bytes in fixed-capacity slots
     (parallel.gather_encoded_async), enqueued on the step's own stream behind its kernels with nothing read back, so the
-    steps in flight stay in flight.  The slot size is a host-side number: twice the largest per-rank total the first
+    steps in flight stay in flight.  The slot size is a host-side number: 5/4 of the largest per-rank total (+ 64 KB) the first
     (untimed, synchronising) gather of each handle position saw, agreed between the ranks; a step that outgrows it is
     flagged on the device and counted when it is retired."""
 
@@ -669,7 +669,7 @@ class StepGather:
             if i not in self.caps:
                 total = off[-1:].clone()
                 dist.all_reduce(total, op=dist.ReduceOp.MAX, group=self.group)
-                self.caps[i] = max(4096, (2 * int(total) + 65535) // 65536 * 65536)
+                self.caps[i] = (5 * int(total) // 4 + 2 * 65536 - 1) // 65536 * 65536
                 out.append(self.parallel.gather_encoded(blob[:int(off[-1])], off, group=self.group))
             else:
                 out.append(self.parallel.gather_encoded_async(blob, off, self.caps[i], h.streams, group=self.group))
@@ -725,11 +725,6 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1, gather=None):
             gather.retire(rec.gathered)
         return rec
 
-    def handles_of(out, x_hat):
-        hs = [h for h in out if isinstance(h, tfc.gen_ops.EncoderHandle)]
-        for other in getattr(x_hat, "_tfc_group", (None, ()))[1]:
-            hs += [h for h in other if isinstance(h, tfc.gen_ops.EncoderHandle)]
-        return hs
 
     t0 = time.perf_counter()
     for k in range(units):
@@ -737,22 +732,27 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1, gather=None):
         if pending[slot] is not None:
             last = retire(pending[slot])
         lane = lanes[slot].begin(main)
+        gathered = None
+        enc_handles = lambda outs: [h for out in outs for h in out if isinstance(h, tfc.gen_ops.EncoderHandle)]
         if group == 1:
             out = model.compress(x, device_result=True, lane=lane)
+            if gather is not None:
+                # the strings exist: their gather goes out while the decoders run (the reference's compress() returns
+                # its strings; decompress() is another call)
+                with lane.on("coder"):
+                    gathered = gather(enc_handles([out]))
             x_hat, oks = model.decompress(*out, defer_sanity=True, lane=lane)
         else:
             with lane.on("transform"):
                 packed = model.compress_many(xs)
+                if gather is not None:
+                    gathered = gather(enc_handles(packed))
                 x_hats, ok = model.decompress_many(packed)
             # the record of the unit: its first batch's result (the parity checks look at rec.out), the handles of
             # the other batches behind it (their strings are fetched with the record too)
             out = tuple(packed[0])
             x_hat, oks = x_hats[0], (ok if isinstance(ok, (list, tuple)) else [ok])
             x_hat._tfc_group = (x_hats, packed[1:])
-        gathered = None
-        if gather is not None:
-            with lane.on("coder"):
-                gathered = gather(handles_of(out, x_hat))
         pending[slot] = StepRecord(out, x_hat, oks, lane.end_event())
         pending[slot].gathered = gathered
     order = [(k % len(lanes)) for k in range(max(0, units - len(lanes)), units)]
@@ -765,7 +765,7 @@ def run_model_steps(model, x, steps, lanes, fetch=True, group=1, gather=None):
 
 
 def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=None,
-                cpu=True, rank=0, world=1, distributed=False, group=1, queue=2, inflight_warmup=0):
+                cpu=True, rank=0, world=1, distributed=False, group=1, queue=2, inflight_warmup=0, passes=3):
     """Full compress + decompress of a target model on synthetic images (BASELINE configs 1/4/5).  `lanes`: the
     pipeline.StepLanes the steps are spread over (made first thing in the process: which hardware queue a stream gets
     depends on what created streams before it, profiles/r03_notes.md); `queue` steps enqueued per lane; `group`
@@ -804,7 +804,20 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
             step_gather.reset()
             dist.barrier()
             torch.cuda.synchronize()
-        elapsed, rec = run(steps)
+        # `passes` timed passes, each bracketed like the first; the median counts (a pass whose buffers the allocators
+        # had to fetch first — seen on fresh boxes with the float32 C4 — is an outlier, not the figure)
+        pass_s = []
+        for k in range(max(1, passes)):
+            if k:
+                del rec
+                torch.cuda.synchronize()
+                if distributed:
+                    step_gather.reset()
+                    dist.barrier()
+                    torch.cuda.synchronize()
+            e, rec = run(steps)
+            pass_s.append(e)
+        elapsed = sorted(pass_s)[len(pass_s) // 2]
         _lib.lib().tfc_set_chip_shared(0)
         gathered = None
         collective = None
@@ -856,6 +869,7 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
             res = {
                 "value": round(pixels / 1e6 / (elapsed / steps), 2), "unit": "Mpixels/s",
                 "ms_per_step": round(1e3 * elapsed / steps, 3), "steps": steps, "warmup": warmup,
+                "timed_passes_ms_per_step": [round(1e3 * v / steps, 3) for v in pass_s],
                 "workload": f"{workload} compress+decompress, {batch} images of {hw[1]}x{hw[0]} per GPU, 192 filters, "
                             f"random-init weights" + (", hyperprior calibrated (scale_index_histogram)" if hist is not None else ""),
                 "dtype": dtype_name,
@@ -971,7 +985,7 @@ def model_workload(args, world, rank, device, distributed):
 
 
 def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_fraction, steps, inflight,
-           serial=True, fold=False, to_host=False):
+           serial=True, fold=False, to_host=False, repeats=1):
     """The coder round trip at BASELINE config 2 with `escape_fraction` of the symbols out of range: exactly
     `steps` steps, `inflight` per launch group.  Returns the measurements (every rank) — rank 0 formats."""
     import hashlib
@@ -1054,8 +1068,24 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
             del results
             m[key] = {"seconds": sec, "steps": n, "enc_ms": enc_ms / max(enc_n, 1), "dec_ms": dec_ms / max(dec_n, 1)}
     # the timed region: exactly `steps` steps
+    # `repeats` times over (median of >= 5 runs), each bracketed by its own barrier + synchronize; the
+    # median counts, every repetition's time is printed
     _lib.lib().tfc_profile_enable(1)
-    elapsed, results, t_enqueued = run_steps(steps, inflight, flight_mode)
+    reps, reps_local = [], []
+    results = None
+    for _ in range(max(1, repeats)):
+        if results is not None:
+            verify(results)
+            del results
+        e, results, t_enqueued = run_steps(steps, inflight, flight_mode)
+        reps_local.append(e)
+        if distributed:                         # every region's time is the slowest rank's
+            t = torch.tensor([e], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t[0].item())
+        reps.append(e)
+    elapsed = sorted(reps)[len(reps) // 2]
+    elapsed_local = sorted(reps_local)[len(reps_local) // 2]
     cenc_ms, cenc_n = profile_query("enc_kernel")
     cdec_ms, cdec_n = profile_query("dec_kernel")
     # the pipelined lane kernels (csrc/range_pipe.h): the launches inside an encode / decode call, each timed on its own
@@ -1066,11 +1096,6 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
             stages[name] = ms / cnt
     _lib.lib().tfc_profile_enable(0)
     verify(results)
-    elapsed_local = elapsed
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0].item())
     # every distinct input's bytes (sha256 of the packed blob and of its offsets), for the comparison with the CPU reference
     shas = {}
     for r in results:
@@ -1079,7 +1104,7 @@ def c2_run(args, lookup, lookup_t, device, world, rank, distributed, escape_frac
     del results
     if sink is not None:
         m["host_bytes"] = sink.bytes
-    m.update(stages=stages, elapsed=elapsed, elapsed_local=elapsed_local, t_enqueued=t_enqueued, enc_tr=cenc_ms / max(cenc_n, 1), dec_tr=cdec_ms / max(cdec_n, 1),
+    m.update(stages=stages, elapsed=elapsed, elapsed_local=elapsed_local, repetitions=reps, t_enqueued=t_enqueued, enc_tr=cenc_ms / max(cenc_n, 1), dec_tr=cdec_ms / max(cdec_n, 1),
              total_bytes=shas[0][2], blob_sha=shas[0][0], offs_sha=shas[0][1], slot0=slots[0],
              slots=slots, slot_shas=[shas[k] for k in sorted(shas)])
     return m
@@ -1258,6 +1283,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each (barrier + synchronize around every one); the median is `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline measurement (no single_batch / escapes / models / conv sub-objects)")
@@ -1323,7 +1350,7 @@ def main():
     lookup_t = torch.from_numpy(lookup)            # tables are uploaded once (cached per tensor)
     extras = not args.no_extras and world == 1
     m = c2_run(args, lookup, lookup_t, device, world, rank, distributed, args.escape_fraction, args.steps,
-               args.inflight, serial=True)
+               args.inflight, serial=True, repeats=args.repeats)
     inflight, elapsed, total_bytes = m["inflight"], m["elapsed"], m["total_bytes"]
     per_rank = None
     if distributed:
@@ -1373,6 +1400,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "timed_regions_ms_per_step": [round(1e3 * v / args.steps, 4) for v in m["repetitions"]],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1392,6 +1420,8 @@ def main():
                 "launch": "the coding calls of the steps in flight are one launch per direction "
                           "(tfc_encoder_encode_many / tfc_decoder_decode_many); every step keeps its own handles and strings",
                 "host_threads": 1,
+                "timing": f"{len(m['repetitions'])} timed regions of exactly --steps steps, each between its own barrier + "
+                          "synchronize; value / ms_per_step = their median, timed_regions_ms_per_step = all of them",
                 "strings": "stay in HBM inside their handles in the timed region (device finalize; the decoders read them "
                            "in place); sub-object strings_to_host: the same command with every string copied to pinned "
                            "host memory inside the timed region",

@@ -35,6 +35,7 @@ SIGNATURES = {
     "tfc_encoder_capacity": (_int, [_vp, C.POINTER(_i64)]),
     "tfc_profile_query": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "tfc_pipe_counters": (_int, [C.POINTER(_i64), C.POINTER(_i64)]),
+    "tfc_set_pipe_format": (_int, [_int, _int]),
     "tfc_tables_create": (_int, [_vp, _int, _i64, _i64, _vp, C.POINTER(_vp)]),
     "tfc_tables_count": (_i64, [_vp]),
     "tfc_tables_destroy": (None, [_vp]),

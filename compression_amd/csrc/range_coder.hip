@@ -197,6 +197,12 @@ struct tfc_tables {
   DevBuf d_lane_image;
   int lane_enc_bytes = 0, lane_dec_bytes = 0, lane_precision = 0;
   bool lanes_ok = false;
+  // the pipelined decoder's COMPACT image (range_pipe.h, dec_chain_kernel<..., true>): bitmaps of every second bound at
+  // PAIR resolution (one bit per two quotient values: half the bitmaps' bytes), and per row what dec_parse_kernel adds
+  // to a raw entry to have the symbol
+  DevBuf d_pair_image, d_pair_adjust;
+  int pair_dec_bytes = 0;
+  bool pairs_ok = false;
   int max_abs_prec = 0;
   bool any_escape = false;
   int64_t max_row = 0;
@@ -416,6 +422,111 @@ extern "C" int tfc_tables_create(const int32_t* lookup, int rank, int64_t rows, 
       t->lane_dec_bytes = static_cast<int>(dec_bytes);
       t->lane_precision = prec;
       t->lanes_ok = true;
+    }
+  }
+  if (t->lanes_ok && t->lane_precision <= 15) {
+    // Compact image of the pipelined decoder (round 6).  The boundary bitmaps are 2/3 of the lane image (98 of 154 KB for
+    // BASELINE config 2's tables; bls2017's 192 x 128-symbol tables need 176 KB and do not fit a CU at all): one bit per
+    // quotient value, because two bounds may be neighbours.  EVERY SECOND bound of a strictly increasing row is at least
+    // two apart from the next one marked, so a bitmap of those needs one bit per PAIR of quotient values {2 j, 2 j + 1}
+    // only — half the bytes — and its rank i says: bound k = 2 i + o is the last marked one whose pair is not behind
+    // q's, hence  cdf[k] - 1 <= q < cdf[k + 2]  and the symbol is k - 1, k or k + 1.  The step (TFC_PDEC_STEP_H) reads
+    // the four entries cdf[k - 1 .. k + 2] with one ds_read2_b32 and settles it with two comparisons of the quotient
+    // (t0 = [q >= cdf[k]], t1 = [q >= cdf[k + 1]]: lower / upper bound by four selects, symbol = k - 1 + t0 + t1) —
+    // verified by the exact interval test like every estimate.
+    //   * which bounds are marked: those with k = o (mod 2), o = symbols of the row (mod 2) — then the last marked one is
+    //     k = n - 2 and the row's END (2^16, stored as 0: the only entry a comparison must not meet) is only ever an
+    //     upper bound;
+    //   * in front of cdf[0] a row has two zero entries (an even row's first window starts at cdf[-1]; a row of one symbol
+    //     takes k = -1: both comparisons true, the window slides to (cdf[0], cdf[1])), and rows are placed so that the
+    //     window of rank i starts at a multiple of four bytes: the directory's cdf pointer is that address for i = 0;
+    //   * the step's raw entry is 2 i + t0 + t1 = symbol - (o - 1): dec_parse_kernel adds the row's o - 1 (pair_adjust).
+    // Layout: directory (final form: what dec_chain_kernel<..., false> makes of its copy of the lane image), entries,
+    // bitmaps (row i at word i * nw2, one spare word behind the last row), counts (nw2 + 1 per row).
+    const size_t ntab = t->rows.size();
+    const int prec = t->lane_precision, sh = 16 - prec;
+    const size_t npairs = size_t{1} << (prec - 1);
+    const size_t nw2 = std::max<size_t>(1, npairs / 64);
+    constexpr size_t kDirRepeat = 16;
+    const size_t dir_bytes = sizeof(tfc::LaneRow) * (ntab + kDirRepeat + 1);
+    std::vector<uint16_t> entries;            // all rows: [pad ... 0, 0, cdf[0] ... cdf[n]]
+    std::vector<int> adjust(ntab);
+    std::vector<uint64_t> bits((ntab + 1) * nw2 + 1, 0);
+    std::vector<uint16_t> cum((ntab + 1) * (nw2 + 1), 0);
+    std::vector<size_t> window0(ntab + 1);    // entry index of the window of rank 0: cdf[o - 1]
+    auto add_row = [&](size_t i, const int32_t* cdf, int nsym, unsigned int carry) {
+      // (a row of ONE symbol has no bound a comparison may meet — cdf[1] is its end: its window starts two entries in
+      // front of cdf[0], in the pad: o = -1, both comparisons true)
+      const int o = nsym == 1 ? -1 : (nsym & 1);
+      // entry index of cdf[0] such that the byte address of cdf[o - 1] (dir_bytes is a multiple of 16) is a multiple of 4
+      size_t at0 = entries.size() + 2;
+      if (((at0 + o - 1) & 1) != 0) ++at0;
+      entries.resize(at0, 0);
+      for (int k = 0; k <= nsym; ++k) entries.push_back(static_cast<uint16_t>(static_cast<unsigned int>(cdf[k]) << sh));
+      window0[i] = at0 + o - 1;
+      // (the first marked bound, k = o, is left out: the rank is then the index i of the last marked bound, and the
+      // quotients below it share its window)
+      for (int k = o + 2; k < nsym; k += 2) {
+        const unsigned int pair = static_cast<unsigned int>(cdf[k]) >> 1;
+        bits[i * nw2 + (pair >> 6)] |= uint64_t{1} << (pair & 63);
+      }
+      unsigned int run = carry;
+      for (size_t w = 0; w <= nw2; ++w) {
+        cum[i * (nw2 + 1) + w] = static_cast<uint16_t>(run);
+        if (w < nw2) run += static_cast<unsigned int>(__builtin_popcountll(bits[i * nw2 + w]));
+      }
+    };
+    for (size_t i = 0; i < ntab; ++i) {
+      const int2 r = t->rows[i];
+      const int nsym = r.y - 2;
+      adjust[i] = (nsym == 1 ? -1 : (nsym & 1)) - 1;
+      add_row(i, &t->host[r.x + 1], nsym, 0u);
+    }
+    {
+      // the binary row of an escape code's bits {0, 1/2, 1}: two symbols, bound 0 marked, window (pad, 0, 1/2, end):
+      // t0 = 1, t1 = the bit; its ranks carry 0x4000, so that 2 i + t0 + t1 = 0x8001 + bit — the raw entry of a bit row
+      // as it is stored (the bit is entry >> 1 & 1; 0xFFFF stays the mark of a row a lane sat out)
+      const int32_t bin[3] = {0, 1 << (prec - 1), 1 << prec};
+      add_row(ntab, bin, 2, 0x4000u);
+    }
+    entries.resize(entries.size() + 2, 0);    // (the last window's fourth entry)
+    const size_t cdf_bytes = (2 * entries.size() + 15) & ~size_t{15};
+    const size_t bits_off = dir_bytes + cdf_bytes;
+    const size_t cum_off = bits_off + 8 * bits.size();
+    const size_t total = cum_off + ((2 * cum.size() + 15) & ~size_t{15});
+    if (total <= 160 * 1024) {
+      std::vector<uint8_t> image(total, 0);
+      tfc::LaneRow* dir = reinterpret_cast<tfc::LaneRow*>(image.data());
+      auto entry_of = [&](size_t i, unsigned int limit, bool esc, unsigned int esclo, bool binary) {
+        tfc::LaneRow d;
+        // (the step addresses the window as cdf + 4 i; the binary row's ranks carry 0x4000)
+        d.cdf = static_cast<unsigned int>(dir_bytes + 2 * window0[i]) - (binary ? 0x10000u : 0u);
+        d.info = (limit & 0x7FFFu) | (esc ? 0x8000u : 0u) | ((0xFFFFu - esclo) << 16);
+        d.bits = static_cast<unsigned int>(bits_off + 8 * i * nw2) - 8u;
+        d.cum = static_cast<unsigned int>(cum_off + 2 * i * (nw2 + 1)) - 2u;
+        return d;
+      };
+      for (size_t i = 0; i < ntab; ++i) {
+        const int2 r = t->rows[i];
+        const bool esc = t->host[r.x] < 0;
+        const int nsym = r.y - 2;
+        // limit: plain symbols (= the escape symbol's index), as in the lane image; ESCLO: the escape symbol's lower bound
+        // on the tables' own scale (0xFFFF, which no quotient reaches at precision <= 15, for a row without one)
+        dir[i] = entry_of(i, static_cast<unsigned int>(esc ? nsym - 1 : nsym), esc,
+                          esc ? static_cast<unsigned int>(t->host[r.x + 1 + nsym - 1]) : 0xFFFFu, false);
+      }
+      for (size_t i = 0; i < kDirRepeat; ++i) dir[ntab + i] = dir[i % ntab];
+      dir[ntab + kDirRepeat] = entry_of(ntab, 2u, false, 1u << (prec - 1), true);
+      std::memcpy(image.data() + dir_bytes, entries.data(), 2 * entries.size());
+      std::memcpy(image.data() + bits_off, bits.data(), 8 * bits.size());
+      std::memcpy(image.data() + cum_off, cum.data(), 2 * cum.size());
+      TFC_HIP(t->d_pair_image.alloc(image.size(), st));
+      TFC_HIP(hipMemcpyAsync(t->d_pair_image.p, image.data(), image.size(), hipMemcpyHostToDevice, st));
+      TFC_HIP(t->d_pair_adjust.alloc(sizeof(int) * ntab, st));
+      TFC_HIP(hipMemcpyAsync(t->d_pair_adjust.p, adjust.data(), sizeof(int) * ntab, hipMemcpyHostToDevice, st));
+      TFC_HIP(hipStreamSynchronize(st));
+      t->pair_dec_bytes = static_cast<int>(total);
+      t->pairs_ok = true;
     }
   }
   TFC_HIP(hipStreamSynchronize(st));
@@ -1063,6 +1174,8 @@ struct DecParams {
   uint4* state;                    // base, span_m1, window, pulls
   unsigned long long* first_error; // index range error
   const unsigned int* only_flagged; // dec_fast_kernel: if set, decode only streams with a nonzero flag
+  const unsigned int* job_guard;    // null, or a flag: the whole launch decodes only if it is set (fallback of range_pipe.h
+                                    // for tables whose lane-per-stream image does not fit a CU)
   int blocks_after_escape;         // dec_fast_kernel: batches decoded as checked 8-symbol blocks after an escape
 };
 
@@ -1189,6 +1302,7 @@ struct OutDequant {
 template <bool LDS_TAB, typename Dst>
 __global__ void __launch_bounds__(kBlock) dec_kernel(DecParams p, Dst dst) {
   extern __shared__ int32_t lds_tab[];
+  if (p.job_guard != nullptr && *p.job_guard == 0u) return;
   if (LDS_TAB) {
     for (int i = threadIdx.x; i < p.tab.total; i += kBlock) lds_tab[i] = p.tab.data[i];
     __syncthreads();
@@ -1535,6 +1649,30 @@ int encoder_error(tfc_encoder* e, const unsigned long long* host_status) {
   return range_error_text(e->tables, e->indexed_last, static_cast<int32_t>(static_cast<long long>(host_status[2])),
                           ch, static_cast<int32_t>(static_cast<long long>(host_status[1])));
 }
+
+// Which image the pipelined decoder's chain runs on — 1 "full" (the lane-per-stream kernels' image, one bit per quotient
+// value), 2 "pairs" (the compact image, TFC_PDEC_STEP_H: half the bitmaps, ~10 % more cycles per row), 0: full where it
+// fits and its chain waves all find a CU, else pairs — and the chain waves per workgroup (0: by launch size).
+// tfc_set_pipe_format / TFC_PIPE_FORMAT, TFC_PIPE_WAVES: an A/B and test switch.
+std::atomic<int>& pipe_format_value() {
+  static std::atomic<int> v{[] {
+    const char* e = std::getenv("TFC_PIPE_FORMAT");
+    if (!e) return 0;
+    if (std::strcmp(e, "full") == 0) return 1;
+    if (std::strcmp(e, "pairs") == 0) return 2;
+    return 0;
+  }()};
+  return v;
+}
+std::atomic<int>& pipe_waves_value() {
+  static std::atomic<int> v{[] {
+    const char* e = std::getenv("TFC_PIPE_WAVES");
+    return e ? std::max(0, std::atoi(e)) : 0;
+  }()};
+  return v;
+}
+inline int pipe_format() { return pipe_format_value().load(std::memory_order_relaxed); }
+inline int pipe_waves_env() { return pipe_waves_value().load(std::memory_order_relaxed); }
 
 // The pipelined kernels of range_pipe.h in front of the lane-per-stream kernels (TFC_PIPE=0: the latter alone —
 // an A/B switch for measurements, not a product setting).
@@ -2238,6 +2376,15 @@ extern "C" int tfc_pipe_counters(int64_t* launches, int64_t* fallback_blocks) {
   return 0;
 }
 
+extern "C" int tfc_set_pipe_format(int format, int waves_per_workgroup) {
+  if (format < 0 || format > 2 || waves_per_workgroup < 0 || waves_per_workgroup > 8) {
+    tfc::fail("tfc_set_pipe_format: format 0 ... 2, waves per workgroup 0 ... 8");
+    return -1;
+  }
+  pipe_waves_value().store(waves_per_workgroup);
+  return pipe_format_value().exchange(format);
+}
+
 extern "C" int tfc_encoder_set_mode(tfc_encoder* e, int mode) {
   if (mode != TFC_MODE_AUTO && mode != TFC_MODE_LATENCY && mode != TFC_MODE_THROUGHPUT)
     return fail("unknown mode %d", mode);
@@ -2710,6 +2857,47 @@ extern "C" int tfc_decoder_set_mode(tfc_decoder* d, int mode) {
 
 namespace {
 
+// One wave per stream (dec_fast_kernel where the tables qualify, else dec_kernel) for ONE handle; `job_guard` (or null): a
+// device flag without which the launch does nothing.
+template <typename Dst>
+int launch_wave_decoder(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& dst, hipStream_t st,
+                        const unsigned int* job_guard) {
+  const tfc_tables* t = d->tables;
+  DecParams p;
+  p.tab = view_of(t);
+  p.index = index;
+  p.streams = d->streams;
+  p.elems = elems;
+  p.blob = d->blob_p;
+  p.off = d->off_p;
+  p.state = d->state.as<uint4>();
+  p.first_error = d->status.as<unsigned long long>();
+  p.only_flagged = nullptr;
+  p.job_guard = job_guard;
+  p.blocks_after_escape = 64;
+  const size_t lds = table_lds_bytes(t);
+  const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
+  const size_t fast_lds = sizeof(int32_t) * ((t->dec_words + 3) & ~3) + sizeof(int4) * t->rows.size();
+  const bool fast_ok = t->dec_fast_ok && fast_lds <= 160 * 1024;
+  if (fast_ok) {
+    const int waves = static_cast<int>(waves_wanted(d->streams));
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds_request(fast_lds))));
+    hipLaunchKernelGGL((dec_fast_kernel<Dst>),
+                       dim3(static_cast<unsigned>(ceil_div(d->streams, waves))), dim3(64 * waves),
+                       lds_request(fast_lds), st, p, dst);
+  } else if (lds) {
+    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_kernel<true, Dst>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((dec_kernel<true, Dst>), dim3(blocks), dim3(kBlock), lds, st, p, dst);
+  } else {
+    hipLaunchKernelGGL((dec_kernel<false, Dst>), dim3(blocks), dim3(kBlock), 0, st, p, dst);
+  }
+  TFC_HIP(hipGetLastError());
+  return 0;
+}
+
 // Lane-per-stream family: n handles (same tables, same stream count) decoded by one launch per
 // kMaxLaneJobs of them.  Where the geometry allows, the pipelined kernels of range_pipe.h take the launch (chain into
 // raw rows, then the parallel parse into `dsts`) and the lane-per-stream kernel behind them only decodes the jobs
@@ -2732,11 +2920,15 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   la.lds_image = (t->lane_dec_bytes + 1023) & ~1023;
   using WaveLds = DecWaveLds<typename Dst::elem>;
   la.lds_wave = indexed ? WaveLds::kBytes : WaveLds::kIndex;
-  const int block = std::min(lanes_block(streams * n), 64 * ((160 * 1024 - la.lds_image) / la.lds_wave));
+  // the lane-per-stream kernel (the pipelined kernels' fallback, or the launch's decoder) needs its image + a wave's
+  // staging in a CU's LDS; tables whose image is larger (bls2017's 192 x 128 symbols: 176 KB) have the wave-per-stream
+  // kernels as the fallback, handle by handle
+  const bool lanes_fit = la.lds_image + la.lds_wave <= 160 * 1024;
+  const int block = lanes_fit ? std::min(lanes_block(streams * n), 64 * ((160 * 1024 - la.lds_image) / la.lds_wave)) : 64;
   const int lds_bytes = la.lds_image + (block / 64) * la.lds_wave;
   const void* fn = indexed ? reinterpret_cast<const void*>(&dec_lanes_kernel<true, Dst>)
                            : reinterpret_cast<const void*>(&dec_lanes_kernel<false, Dst>);
-  TFC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  if (lanes_fit) TFC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   // pipelined launch plan: groups of 64 streams; rows = steps of the chain (one per element, plus the bits of
   // escape codes: a quarter more is planned for when the tables have escape rows)
   PipeDecArgs pa;
@@ -2750,27 +2942,66 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
   const size_t group_bytes = raw_bytes + rec_bytes + 64 * sizeof(uint4) + sizeof(unsigned int);
   const size_t job_bytes = group_bytes * pa.groups_per_job + (indexed ? 2 * static_cast<size_t>(streams) * elems : 0);
   pla.lds_wave = (indexed ? PipeDecLds::kBytes : PipeDecLds::kRows) + PipeDecLds::kStage;
-  const int pblock = std::min(lanes_block(streams * n), 64 * std::max(0, (160 * 1024 - pla.lds_image) / pla.lds_wave));
   const size_t kPipeTempBytes = pipe_temp_bytes();
+  // Which image the chain runs on, and how many chain waves share a workgroup's copy of it.  A launch's chain
+  // workgroups must all be resident at once (a second round doubles the launch's time and the parse next to the chain
+  // gives up on groups that do not move), one wave per SIMD at most: the full image where it fits and hosts the call's
+  // waves (BASELINE config 2: 150 KB, one wave per CU = 32 batches per launch), else the compact one (92 KB for config 2:
+  // four waves per CU, 128 batches per launch; 115 KB for bls2017's tables, whose full image does not fit at all).
+  const int cus_d = pipe_device_info().cus;
+  const int64_t waves_call = static_cast<int64_t>(pa.groups_per_job) * std::min(n, kMaxLaneJobs);
+  auto waves_fit = [&](int image_bytes) { return std::max(0, (160 * 1024 - image_bytes) / pla.lds_wave); };
+  const int pair_image = (t->pair_dec_bytes + 1023) & ~1023;
+  const int fit_full = waves_fit(pla.lds_image), fit_pairs = t->pairs_ok ? waves_fit(pair_image) : 0;
+  bool pairs = false;
+  switch (pipe_format()) {
+    case 1: pairs = false; break;
+    case 2: pairs = fit_pairs >= 1; break;
+    // (beyond three quarters of the CUs under full-image chain workgroups — each fills its CU's LDS — the parse next to the
+    // chain finds no room and runs behind it: 32 batches of config 2 decode in 10.1 ms on the full image, 9.1 on the
+    // compact one, whose workgroups leave 50 KB of every CU to two parse workgroups)
+    default: pairs = fit_pairs >= 1 && (fit_full < 1 || 4 * waves_call > 3 * static_cast<int64_t>(cus_d) * std::min(fit_full, 4));
+  }
+  if (pairs) {
+    pla.image = t->d_pair_image.as<uint32_t>();
+    pla.bytes = t->pair_dec_bytes;
+    pla.lds_image = pair_image;
+  }
+  const int fit = pairs ? fit_pairs : fit_full;
+  // waves per workgroup: as few as host the call on the chip's CUs (a chain wave wants a SIMD to itself); under
+  // tfc_set_chip_shared — other kernels beside the coder's — four, so that the chains hold few CUs' LDS
+  int per = static_cast<int>(std::min<int64_t>(8, std::max<int64_t>(1, ceil_div(waves_call, static_cast<int64_t>(cus_d)))));
+  if (g_chip_shared.load(std::memory_order_relaxed) != 0) per = std::max(per, static_cast<int>(std::min<int64_t>(4, pa.groups_per_job)));
+  if (pipe_waves_env() > 0) per = pipe_waves_env();
+  per = std::min(per, std::min(fit, pa.groups_per_job));
+  const int pblock = 64 * std::max(per, 0);
   // (precision 16: a quotient can equal the "no escape symbol" mark of dec_chain_kernel's directory, 0xFFFF)
   const bool pipe = pipe_enabled() && pblock >= 64 && rows64 < (int64_t{1} << 30) && job_bytes <= kPipeTempBytes &&
                     (!indexed || la.ntab < 4096) && t->lane_precision <= 15 &&
                     (static_cast<int64_t>(pa.rows) / kParseRows + 1) * pa.groups_per_job * kMaxLaneJobs < (int64_t{1} << 31);
   const int plds = pla.lds_image + (pblock / 64) * pla.lds_wave;
-  // A launch's chain workgroups must all be resident at once (each holds the tables' image: one per CU for config 2's
-  // 150 KB): a second round of them doubles the launch's time, and the parse next to the chain gives up on groups that
-  // do not move (round 5: 16-bit raw rows made 64 config-2 batches fit the temporaries' budget — 512 groups on 256 CUs).
-  const int cus_d = pipe_device_info().cus;
   const size_t chain_wgs_per_job = static_cast<size_t>(ceil_div(pa.groups_per_job, std::max(1, pblock / 64)));
   const size_t resident_wgs = static_cast<size_t>(cus_d) * std::max<size_t>(1, (160 * 1024) / std::max(1, plds));
   const size_t resident_jobs = std::max<size_t>(1, resident_wgs / std::max<size_t>(1, chain_wgs_per_job));
   const int per_launch = !pipe ? kMaxLaneJobs
                                : static_cast<int>(std::max<size_t>(1, std::min<size_t>(std::min<size_t>(kMaxLaneJobs, resident_jobs),
                                                                                       kPipeTempBytes / std::max<size_t>(job_bytes, 1))));
+  const void* pfn = nullptr;
   if (pipe) {
-    const void* pfn = indexed ? reinterpret_cast<const void*>(&dec_chain_kernel<true>) : reinterpret_cast<const void*>(&dec_chain_kernel<false>);
+    pfn = pairs ? (indexed ? reinterpret_cast<const void*>(&dec_chain_kernel<true, true>) : reinterpret_cast<const void*>(&dec_chain_kernel<false, true>))
+                : (indexed ? reinterpret_cast<const void*>(&dec_chain_kernel<true, false>) : reinterpret_cast<const void*>(&dec_chain_kernel<false, false>));
     TFC_HIP(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
   }
+  if (!pipe && !lanes_fit) {
+    // neither the pipelined kernels nor the lane-per-stream kernel can take the call: one wave per stream
+    for (int k = 0; k < n; ++k) {
+      ds[k]->family = kFast;
+      KernelTimer timer("dec_kernel", st);
+      if (launch_wave_decoder(ds[k], indexed ? indexes[k] : nullptr, elems, dsts[k], st, nullptr)) return 1;
+    }
+    return 0;
+  }
+  const PipePairMap pm{t->d_pair_adjust.as<int>()};
   for (int g0 = 0; g0 < n; g0 += per_launch) {
     const int gn = std::min(per_launch, n - g0);
     DecLaneJobs<Dst> jobs;
@@ -2861,14 +3092,19 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
       const dim3 pgrid_next(static_cast<unsigned>(groups * ctiles));
       {
         KernelTimer t2("dec_chain", cst);
-        if (indexed) hipLaunchKernelGGL((dec_chain_kernel<true>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
-        else hipLaunchKernelGGL((dec_chain_kernel<false>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
+        if (pairs && indexed) hipLaunchKernelGGL((dec_chain_kernel<true, true>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
+        else if (pairs) hipLaunchKernelGGL((dec_chain_kernel<false, true>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
+        else if (indexed) hipLaunchKernelGGL((dec_chain_kernel<true, false>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
+        else hipLaunchKernelGGL((dec_chain_kernel<false, false>), cgrid, dim3(pblock), plds, cst, cj, pla, pa);
       }
       auto parse = [&](int concurrent) {
         pa.concurrent = concurrent;
         const dim3 g = concurrent ? pgrid_next : pgrid;
-        if (indexed) hipLaunchKernelGGL((dec_parse_kernel<true, Dst>), g, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
-        else hipLaunchKernelGGL((dec_parse_kernel<false, Dst>), g, dim3(256), 0, st, jobs, pa, t->d_dec_dir.as<DecRow>(), la.ntab);
+        const DecRow* dd = t->d_dec_dir.as<DecRow>();
+        if (pairs && indexed) hipLaunchKernelGGL((dec_parse_kernel<true, true, Dst>), g, dim3(256), 0, st, jobs, pa, dd, la.ntab, pm);
+        else if (pairs) hipLaunchKernelGGL((dec_parse_kernel<false, true, Dst>), g, dim3(256), 0, st, jobs, pa, dd, la.ntab, pm);
+        else if (indexed) hipLaunchKernelGGL((dec_parse_kernel<true, false, Dst>), g, dim3(256), 0, st, jobs, pa, dd, la.ntab, pm);
+        else hipLaunchKernelGGL((dec_parse_kernel<false, false, Dst>), g, dim3(256), 0, st, jobs, pa, dd, la.ntab, pm);
       };
       if (overlap) {
         KernelTimer t2("dec_parse_next", st);      // (next to the chain: as long as the chain, by construction)
@@ -2888,6 +3124,12 @@ int decode_lanes_many(tfc_decoder* const* ds, int n, const Dst* dsts, const int3
     } while (false);
     const dim3 grid(static_cast<unsigned>(jobs.blocks_per_job * gn));
     if (piped && !pipe_fallback_launch()) {}
+    else if (!lanes_fit) {
+      // (the tables' lane image does not fit a CU) what the pipelined kernels gave up on — or, without temporaries, the
+      // whole launch — on the wave-per-stream kernels, handle by handle under its fallback flag
+      for (int k = 0; k < gn; ++k)
+        if (launch_wave_decoder(ds[g0 + k], jobs.job[k].index, elems, dsts[g0 + k], st, piped ? pa.fallback + k : nullptr)) return 1;
+    }
     else if (indexed) hipLaunchKernelGGL((dec_lanes_kernel<true, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
     else hipLaunchKernelGGL((dec_lanes_kernel<false, Dst>), grid, dim3(block), lds_bytes, st, jobs, la);
   }
@@ -2913,14 +3155,18 @@ int decode_lanes_dequantized(tfc_decoder* const* ds, int n, const Dst* dsts, int
   return 0;
 }
 
-// Family of a decode call; lanes only when the tables' image plus one wave's staging fits the CU.
+// Family of a decode call; lanes only when the tables' image plus one wave's staging fits the CU — the lane-per-stream
+// kernels' own image, or (round 6) the compact image of the pipelined decoder, whose fallback is then the wave-per-stream
+// kernel (decode_lanes_many).
 template <typename Elem>
 int decoder_family(const tfc_decoder* d, int64_t streams_in_launch, int64_t elems, bool indexed, bool fast_ok) {
   const tfc_tables* t = d->tables;
   int family = select_family(t, d->mode, streams_in_launch, elems, fast_ok);
   using WaveLds = DecWaveLds<Elem>;
   const int need = ((t->lane_dec_bytes + 1023) & ~1023) + (indexed ? WaveLds::kBytes : WaveLds::kIndex);
-  if (family == kLanes && need > 160 * 1024) family = fast_ok ? kFast : kGeneric;
+  const int need_pairs = ((t->pair_dec_bytes + 1023) & ~1023) + (indexed ? PipeDecLds::kBytes : PipeDecLds::kRows) + PipeDecLds::kStage;
+  const bool compact_ok = t->pairs_ok && pipe_enabled() && pipe_format() != 1 && need_pairs <= 160 * 1024;
+  if (family == kLanes && need > 160 * 1024 && !compact_ok) family = fast_ok ? kFast : kGeneric;
   return family;
 }
 
@@ -2932,19 +3178,6 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
   if (d->streams == 0 || elems == 0) return 0;
   const tfc_tables* t = d->tables;
   if (t->rows.empty()) return fail("index=0 not in range [0, 0)");
-  DecParams p;
-  p.tab = view_of(t);
-  p.index = index;
-  p.streams = d->streams;
-  p.elems = elems;
-  p.blob = d->blob_p;
-  p.off = d->off_p;
-  p.state = d->state.as<uint4>();
-  p.first_error = d->status.as<unsigned long long>();
-  p.only_flagged = nullptr;
-  p.blocks_after_escape = 64;
-  const size_t lds = table_lds_bytes(t);
-  const unsigned blocks = static_cast<unsigned>(ceil_div(d->streams, kWavesPerBlock));
   const size_t fast_lds = sizeof(int32_t) * ((t->dec_words + 3) & ~3) + sizeof(int4) * t->rows.size();
   const bool fast_ok = t->dec_fast_ok && fast_lds <= 160 * 1024;
   const int family = decoder_family<typename Dst::elem>(d, d->streams, elems, index != nullptr, fast_ok);
@@ -2955,27 +3188,9 @@ int run_decode(tfc_decoder* d, const int32_t* index, int64_t elems, const Dst& d
       if (!index && !pipe_enabled()) return decode_lanes_dequantized(&d, 1, &dst, elems, st);
     }
     return decode_lanes_many(&d, 1, &dst, &index, elems, st);
-  } else if (family == kFast) {
-    KernelTimer timer("dec_kernel", st);
-    const int waves = static_cast<int>(waves_wanted(d->streams));
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_fast_kernel<Dst>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds_request(fast_lds))));
-    hipLaunchKernelGGL((dec_fast_kernel<Dst>),
-                       dim3(static_cast<unsigned>(ceil_div(d->streams, waves))), dim3(64 * waves),
-                       lds_request(fast_lds), st, p, dst);
-  } else {
-    KernelTimer timer("dec_kernel", st);
-    if (lds) {
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_kernel<true, Dst>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-      hipLaunchKernelGGL((dec_kernel<true, Dst>), dim3(blocks), dim3(kBlock), lds, st, p, dst);
-    } else {
-      hipLaunchKernelGGL((dec_kernel<false, Dst>), dim3(blocks), dim3(kBlock), 0, st, p, dst);
-    }
   }
-  TFC_HIP(hipGetLastError());
-  return 0;
+  KernelTimer timer("dec_kernel", st);
+  return launch_wave_decoder(d, index, elems, dst, st, nullptr);
 }
 
 }  // namespace

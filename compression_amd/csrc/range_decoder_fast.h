@@ -516,6 +516,7 @@ __device__ unsigned long long g_dec_phase[4];
 template <typename Dst>
 __global__ void dec_fast_kernel(DecParams p, Dst dst) {
   extern __shared__ int32_t lds[];
+  if (p.job_guard != nullptr && *p.job_guard == 0u) return;     // (wave-uniform, in front of the table copy)
   const int waves = blockDim.x >> 6;
   int32_t* tab = lds;                                        // p.tab.dec_words ints
   DecRow* dir = reinterpret_cast<DecRow*>(lds + ((p.tab.dec_words + 3) & ~3));

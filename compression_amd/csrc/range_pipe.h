@@ -1299,10 +1299,86 @@ struct PipeDecLds {
   "v_sub_u32 v130, %[D], v126\n\t"                                                        \
   "v_perm_b32 v132, v130, v109, %[PERM]\n\t"                                              \
   "v_cndmask_b32_e64 %[D], v130, v132, s[56:57]\n\t"
+// Round 6: the same step on the COMPACT image (tfc_tables_create, "Compact image"): the bitmaps mark every SECOND bound of
+// a row, one bit per PAIR of quotient values — half the bytes.  The rank i among them says the symbol is one of three:
+// the window cdf[k - 1 .. k + 2], k = 2 i + o, comes with ONE ds_read2_b32 (the directory's cdf pointer is the window of
+// i = 0, windows are four bytes apart) as W0 = cdf[k - 1] | cdf[k] << 16, W1 = cdf[k + 1] | cdf[k + 2] << 16, and two
+// comparisons of Q = q << (16 - p) with the two middle entries (SDWA picks the halves) slide it:
+//     t0 = [Q >= cdf[k]], t1 = [Q >= cdf[k + 1]]:   (lower, upper) = t1 ? (W1.lo, W1.hi) : t0 ? (W0.hi, W1.lo) : (W0.lo, W0.hi)
+// — four SDWA selects straight into the registers the bounds multiply from — and the raw entry is 2 i + t0 + t1 (two
+// add-with-carry; its store moves behind the trip).  Nine instructions more than TFC_PDEC_STEP: nq >> 1 (the pair's place
+// in its word), Q (first shadow), 2 + 4 + 2 behind the second trip, one LDS read less.  The interval test of the next step
+// verifies the choice like every estimate.  %[NSH] = -(1 << (16 - p)).
+// Measured (TFC_PIPE_TIMING builds, profiles/r06_notes.md): 320.0 cycles per row inside the blocks against 265.3 of
+// TFC_PDEC_STEP — the nine instructions at the ~6 cycles a dependent instruction of this chain costs; Q formed in the
+// second shadow instead: 323.0; the window as two ds_read_b32: 320.0 (one instruction more, free: the trip is not what
+// is waited for); as one ds_read_b64 at its 4-byte alignment: 372.7.
+#define TFC_PDEC_STEP_H(KOFF, MI, MO, AHEAD, NEXT, PWSTEP)                                  \
+  "v_cvt_f32_u32 v111, %[S]\n\t"                                                          \
+  "v_add_f32 v111, 1.0, v111\n\t"                                                         \
+  "v_rcp_f32 v111, v111\n\t"                                                              \
+  "v_cvt_f32_u32 v110, %[D]\n\t"                                                          \
+  "v_fma_f32 v110, -v110, %[SCALE], -%[HSCALE]\n\t"                                       \
+  "v_fma_f32 v110, v110, v111, -1.0\n\t"                                                  \
+  "v_cvt_i32_f32 v110, v110\n\t"                                                          \
+  "v_ashrrev_i32 v143, 1, v110\n\t"                                                       \
+  "v_ashrrev_i32 v111, 6, v143\n\t"                                                       \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                              \
+  "v_mad_i32_i24 v112, v111, -8, v106\n\t"                                                \
+  "ds_read_b64 v[114:115], v112\n\t"                                                      \
+  "v_mad_i32_i24 v113, v111, -2, v107\n\t"                                                \
+  "ds_read_u16 v116, v113\n\t"                                                            \
+  AHEAD                                                                                   \
+  "v_cndmask_b32_e64 v133, 0, 2, s[56:57]\n\t"                                            \
+  "v_add_u32 %[CP], %[CP], v133\n\t"                                                      \
+  "ds_read_u16 v109, %[CP]\n\t"                                                           \
+  "v_ashrrev_i32 v137, 31, " MI "\n\t"                                                    \
+  "v_cmp_le_u32_sdwa vcc, v110, v105 src0_sel:WORD_0 src1_sel:WORD_1\n\t"                 \
+  "v_cndmask_b32 v137, v136, v137, vcc\n\t"                                               \
+  "v_xor_b32 " MO ", v135, v137\n\t"                                                      \
+  "v_cmpx_le_u32 vcc, v130, v131\n\t"                                                     \
+  "v_mad_i32_i24 v141, v110, %[NSH], %[NSH]\n\t"                                          \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                              \
+  "v_lshlrev_b64 v[118:119], v143, v[114:115]\n\t"                                        \
+  "v_bcnt_u32_b32 v116, v118, v116\n\t"                                                   \
+  "v_bcnt_u32_b32 v117, v119, v116\n\t"                                                   \
+  "v_lshl_add_u32 v112, v117, 2, v104\n\t"                                                \
+  "ds_read2_b32 v[144:145], v112 offset1:1\n\t"                                           \
+  "v_subrev_co_u32 v135, vcc, 1, " MO "\n\t"                                              \
+  "v_cndmask_b32_e64 v136, 0, -1, vcc\n\t"                                                \
+  "v_add_u32 v140, " #PWSTEP ", %[PW]\n\t"                                                \
+  "v_cndmask_b32 %[PW], %[PW], v140, vcc\n\t"                                             \
+  "v_cndmask_b32 v142, %[BINROW], " NEXT ", vcc\n\t"                                      \
+  "ds_read_b128 v[104:107], v142\n\t"                                                     \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                              \
+  "v_cmp_ge_u32_sdwa vcc, v141, v144 src0_sel:DWORD src1_sel:WORD_1\n\t"                  \
+  "v_cndmask_b32_sdwa v122, v144, v144, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
+  "v_cndmask_b32_sdwa v124, v144, v145, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t" \
+  "v_addc_co_u32_e64 v117, s[58:59], v117, v117, vcc\n\t"                                 \
+  "v_cmp_ge_u32_sdwa vcc, v141, v145 src0_sel:DWORD src1_sel:WORD_0\n\t"                  \
+  "v_cndmask_b32_sdwa v122, v122, v145, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" \
+  "v_cndmask_b32_sdwa v124, v124, v145, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+  "v_addc_co_u32_e64 v117, s[58:59], v117, v123, vcc\n\t"                                 \
+  TFC_PDEC_STORE(KOFF)                                                                    \
+  "v_mad_u64_u32 v[126:127], s[52:53], v122, %[S], v[122:123]\n\t"                        \
+  "v_mad_u64_u32 v[128:129], s[52:53], v124, %[S], v[124:125]\n\t"                        \
+  "v_alignbit_b32 v126, v127, v126, 16\n\t"                                               \
+  "v_alignbit_b32 v128, v129, v128, 16\n\t"                                               \
+  "v_add_u32 v128, -1, v128\n\t"                                                          \
+  "v_min_u32 v128, v128, %[S]\n\t"                                                        \
+  "v_sub_u32 v131, v128, v126\n\t"                                                        \
+  "v_cmp_gt_u32_e64 s[56:57], %[K64K], v131\n\t"                                          \
+  "v_lshl_or_b32 v132, v131, 16, %[KFFFF]\n\t"                                            \
+  "v_cndmask_b32_e64 %[S], v131, v132, s[56:57]\n\t"                                      \
+  "v_sub_u32 v130, %[D], v126\n\t"                                                        \
+  "v_perm_b32 v132, v130, v109, %[PERM]\n\t"                                              \
+  "v_cndmask_b32_e64 %[D], v130, v132, s[56:57]\n\t"
 // channel mode: the next element's entry is the one behind the current (PW + 16); index mode: its address comes out
 // of the lane's window of row addresses, requested in the first shadow
 #define TFC_PDEC_STEP_CH(KOFF, MI, MO) TFC_PDEC_STEP(KOFF, MI, MO, "", "v140", 16)
 #define TFC_PDEC_STEP_IX(KOFF, MI, MO) TFC_PDEC_STEP(KOFF, MI, MO, "ds_read_u16 v108, %[PW] offset:2\n\t", "v108", 2)
+#define TFC_PDEC_STEP_PCH(KOFF, MI, MO) TFC_PDEC_STEP_H(KOFF, MI, MO, "", "v140", 16)
+#define TFC_PDEC_STEP_PIX(KOFF, MI, MO) TFC_PDEC_STEP_H(KOFF, MI, MO, "ds_read_u16 v108, %[PW] offset:2\n\t", "v108", 2)
 // a block: the row into v104-v107, nothing pending from a step before it (v130 <= v131, s[56:57] = 0); behind it the last
 // step's pending verification and cursor increment, and the row the next step decodes from back to the caller
 #define TFC_PDEC_STEP2(STEP, K0, K1) STEP(K0, "%[M]", "v138") STEP(K1, "v138", "%[M]")
@@ -1328,12 +1404,14 @@ struct PipeDecLds {
   TFC_PDEC_STEP2(STEP, 1536, 1664) TFC_PDEC_STEP2(STEP, 1792, 1920)                       \
   TFC_PDEC_BLOCK_TAIL
 
-template <bool INDEXED>
+// PAIRS: `la.image` is the COMPACT image (tfc_tables_create builds it in this kernel's final form) and the steps are
+// TFC_PDEC_STEP_P; else the lane-per-stream kernels' image, patched below, and TFC_PDEC_STEP.
+template <bool INDEXED, bool PAIRS>
 __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, const LaneArgs la, const PipeDecArgs pa) {
   extern __shared__ unsigned char lanes_lds[];
   lanes_load_image(lanes_lds, la);
   using L = PipeDecLds;
-  {
+  if constexpr (!PAIRS) {
     // This kernel's form of the image (its LDS copy only; the image on the device is shared with the lane-per-stream
     // kernels) — see "Round 5, second pass" above:
     //  * tables: bit 0 of a row's first bitmap word (cdf[0] = 0) cleared and that word's count 0 instead of -1: the counts
@@ -1426,6 +1504,9 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
   float hscale = scale;              // (the quotient estimate's numerator is (D + 1) 2^p: see the step)
   asm volatile("" : "+v"(hscale));
   const unsigned int cp_max = (1u << la.precision) - 1u;
+  // compact image: the quotient on the entries' 2^16 scale, Q = q << (16 - p) = (nq + 1) * -(1 << (16 - p)) (TFC_PDEC_STEP_H)
+  const unsigned int pair_sh = 16u - static_cast<unsigned int>(la.precision);
+  const unsigned int pair_nsh = 0u - (1u << pair_sh);
   const unsigned int dir_end = 16u * static_cast<unsigned int>(la.ntab);
   // the built-in binary row: directory entry behind the repeated ones
   const unsigned int bin_addr = dir_end + 16u * kLaneDirRepeat;
@@ -1474,6 +1555,49 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         // ---- symbol first: quotient estimate -> rank among the row's boundaries (range_lanes.h) ----
         const float fq = (static_cast<float>(D) + 0.5f) * __builtin_amdgcn_rcpf(static_cast<float>(s1)) * scale;
         const unsigned int q = min(static_cast<unsigned int>(fq), cp_max);
+        if constexpr (PAIRS) {
+          // compact image: rank i among every second bound, at pair resolution -> the window's first candidate; the
+          // exact test below then steps the symbol as on the full image (entry e of the window of rank 0 is at
+          // R.x + 2 e: the original cdf entries, symbol s = entry s + 1 of that window minus the row's o - 1 ... the
+          // raw entry counts from the window: 2 i + t0 + t1)
+          const unsigned int j = q >> 1, w = j >> 6;
+          const unsigned long long word = *reinterpret_cast<const unsigned long long*>(lanes_lds + R.z + 8u + 8u * w);
+          const unsigned int cum = *reinterpret_cast<const unsigned short*>(lanes_lds + R.w + 2u + 2u * w);
+          const unsigned long long below = ~0ull >> (63u - (j & 63u));
+          const unsigned int i = cum + static_cast<unsigned int>(__popcll(word & below));
+          const unsigned int Q = q << pair_sh;
+          // u: entry index inside the row's window space (entry u = lower bound, u + 1 = upper bound)
+          unsigned int u = 2u * i;
+          u += Q >= lds_u16(lanes_lds, R.x + 2u * u + 2u) ? 1u : 0u;
+          u += (u & 1u) != 0u && Q >= lds_u16(lanes_lds, R.x + 4u * i + 4u) ? 1u : 0u;
+          unsigned int lo = lds_u16(lanes_lds, R.x + 2u * u), hi = lds_u16(lanes_lds, R.x + 2u * u + 2u);
+          unsigned int A = scale16(s1, lo);
+          unsigned int b = scale16(s1, hi) - 1u;
+          b = hi == 0u ? s1 : b;
+          // (u of symbol 0 and of the last symbol: the row's o - 1 is not in the image — found by the bounds themselves:
+          // no step below an entry whose lower bound is 0 with a zero in front of it... the ends are where hi wraps or
+          // lo is the pad's zero: stepping stops when the entry read is not a bound of the row)
+          for (int fix = 0; fix < 4; ++fix) {
+            if (D - A > b - A) {
+              if (D < A) u = u > 0u ? u - 1u : 0u;
+              else if (hi != 0u) u = u + 1u;
+              lo = lds_u16(lanes_lds, R.x + 2u * u);
+              hi = lds_u16(lanes_lds, R.x + 2u * u + 2u);
+              A = scale16(s1, lo);
+              b = scale16(s1, hi) - 1u;
+              b = hi == 0u ? s1 : b;
+            }
+          }
+          D -= A;
+          s1 = b - A;
+          const bool ren = (s1 >> 16) == 0u;
+          D = ren ? (D << 16) | dig : D;
+          s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
+          cp += ren ? 2u : 0u;
+          entry = u;
+          // the escape symbol is the one whose lower bound is ESCLO (info's upper half holds 0xFFFF - ESCLO)
+          M = ((R.y >> 15) & 1u) != 0u && lo == ((0xFFFFu - (R.y >> 16)) << pair_sh) ? -1 : 0;
+        } else {
         const unsigned int w = q >> 6;
         // (this kernel's LDS copy: entry pointers 8 / 2 bytes low, counts without the "- 1", bitmaps without cdf[0])
         const unsigned long long word = *reinterpret_cast<const unsigned long long*>(lanes_lds + R.z + 8u + 8u * w);
@@ -1505,6 +1629,7 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         cp += ren ? 2u : 0u;
         entry = pipe_raw_entry(sym, 0);
         M = ((R.y >> 15) & 1u) != 0u && sym == (R.y & 0x7FFFu) ? -1 : 0;
+        }
       } else {
         // ---- one bit of an Elias-gamma code (range_coder_kernels.cc:449-471): the uniform binary cdf at
         // precision 1 needs no table ------------------------------------------------------------------
@@ -1518,7 +1643,8 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         D = ren ? (D << 16) | dig : D;
         s1 = ren ? (s1 << 16) | 0xFFFFu : s1;
         cp += ren ? 2u : 0u;
-        entry = pipe_raw_entry(bit, M);
+        // (compact image: the fast step's entry of a bit row is 0x8000 + t0 + t1 = 0x8001 + bit)
+        entry = PAIRS ? 0x8001u + bit : pipe_raw_entry(bit, M);
         if (M < 0) {
           if (bit) M = -M;
           else M = M == -31 ? 32 : M - 1;      // the 31st zero: the prefix ends here (range_lanes.h, bit_step)
@@ -1590,14 +1716,16 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
         : [D] "+v"(D), [S] "+v"(s1), [CP] "+v"(cp), [M] "+v"(M), [PW] "+v"(pw), [FLAG] "+v"(flag),                    \
           [R0] "+v"(R.x), [R1] "+v"(R.y), [R2] "+v"(R.z), [R3] "+v"(R.w)                                              \
         : [STG] "v"(stg), [BINROW] "v"(bin_addr_v), [SCALE] "s"(scale), [HSCALE] "v"(hscale),        \
-          [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x05040001u)               \
-        : "vcc", "memory", "s52", "s53", "s54", "s55", "s56", "s57", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
+          [K64K] "s"(0x10000u), [KFFFF] "s"(0xFFFFu), [PERM] "s"(0x05040001u), [NSH] "s"(pair_nsh) \
+        : "vcc", "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
           "v114", "v115", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",      \
-          "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v142", "v143"
+          "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145"
 #if TFC_PIPE_TIMING
     const unsigned long long ta = clock64();
 #endif
-    if constexpr (INDEXED) asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
+    if constexpr (INDEXED && PAIRS) asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_PIX) TFC_PDEC_OPERANDS);
+    else if constexpr (PAIRS) asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_PCH) TFC_PDEC_OPERANDS);
+    else if constexpr (INDEXED) asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
     else asm volatile(TFC_PDEC_BLOCK(TFC_PDEC_STEP_CH) TFC_PDEC_OPERANDS);
 #if TFC_PIPE_TIMING
     t_asm += clock64() - ta;
@@ -1609,7 +1737,9 @@ __global__ void __launch_bounds__(512) dec_chain_kernel(const PipeDecJobs jobs, 
     const unsigned int stg_row = stg + 128u * slot;
     {
       const unsigned int stg = stg_row;       // (the operand list names `stg`)
-      if constexpr (INDEXED) asm volatile(TFC_PDEC_ONE(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
+      if constexpr (INDEXED && PAIRS) asm volatile(TFC_PDEC_ONE(TFC_PDEC_STEP_PIX) TFC_PDEC_OPERANDS);
+      else if constexpr (PAIRS) asm volatile(TFC_PDEC_ONE(TFC_PDEC_STEP_PCH) TFC_PDEC_OPERANDS);
+      else if constexpr (INDEXED) asm volatile(TFC_PDEC_ONE(TFC_PDEC_STEP_IX) TFC_PDEC_OPERANDS);
       else asm volatile(TFC_PDEC_ONE(TFC_PDEC_STEP_CH) TFC_PDEC_OPERANDS);
     }
 #undef TFC_PDEC_OPERANDS
@@ -1771,11 +1901,20 @@ constexpr unsigned int kParseMargin = 96;     // rows behind a tile the parse ne
 
 constexpr int kParseEscTables = 2048;     // escape symbols of up to this many tables are staged in LDS
 
-template <bool INDEXED, typename Dst>
-__global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> jobs, const PipeDecArgs pa, const DecRow* dir, int ntab) {
-  constexpr int kPitch = 65;
-  __shared__ unsigned int buf[kParseRows * kPitch];
-  __shared__ int escsym[kParseEscTables];
+// PAIRS: the chain ran on the compact image — an element row's entry is the symbol minus the row's adjust[t] (o - 1,
+// tfc_tables_create), a bit row's entry 0x8001 + bit.
+struct PipePairMap { const int* adjust; };
+template <bool INDEXED, bool PAIRS, typename Dst>
+__global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> jobs, const PipeDecArgs pa, const DecRow* dir, int ntab,
+                                                        const PipePairMap pm) {
+  // (16-bit entries at a pitch of 33 dwords: a wave's column walk — lane i reads row i — meets every bank twice, what 64
+  // lanes cost anyway; 17 KB + the rows' escape symbols, so that two of these workgroups fit a CU beside a chain
+  // workgroup of two waves on the compact image — 64 batches of BASELINE config 2 in one launch: the 32-bit buffer of
+  // round 5, 33 KB, left room for one, and 5 ms of the parse ran behind the chain)
+  constexpr int kPitch = 66;
+  __shared__ unsigned short buf[kParseRows * kPitch];
+  // escape symbol of the row, or -1, in the low half; compact image: the row's adjust + 2 above it
+  __shared__ unsigned int escsym[kParseEscTables];
   __shared__ unsigned int incomplete;
   const unsigned int tiles = static_cast<unsigned int>(pa.rows) / kParseRows + 1u;
   // (tile-major: next to the chain, the tiles it releases first are dispatched first)
@@ -1843,8 +1982,11 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
   for (unsigned int r = tid >> 6; r < nrows; r += 4u) buf[r * kPitch + lane] = raw[static_cast<size_t>(k0 + r) * 64 + lane];
   const bool esc_in_lds = ntab <= kParseEscTables;
   if (esc_in_lds)
-    for (int i = tid; i < ntab; i += 256) escsym[i] = dir[i].w;
+    for (int i = tid; i < ntab; i += 256) {
+      escsym[i] = (static_cast<unsigned int>(dir[i].w) & 0xFFFFu) | (PAIRS ? static_cast<unsigned int>(pm.adjust[i] + 2) << 16 : 0u);
+    }
   __syncthreads();
+  const unsigned int bitshift = PAIRS ? 1u : 0u;
   const unsigned int* const posrec = pa.posrec + static_cast<size_t>(gi) * (pa.rows / kPipeBlock + 1) * 64;
   const Dst dst = J.dst;
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1877,7 +2019,10 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
           t = static_cast<int>(m);
         }
         int v = static_cast<int>(e);
-        const int es = esc_in_lds ? escsym[t] : dir[t].w;      // escape symbol of the row, or -1
+        const unsigned int ew = esc_in_lds ? escsym[t] : 0u;
+        if constexpr (PAIRS) v += esc_in_lds ? static_cast<int>(ew >> 16) - 2 : pm.adjust[t];
+        // escape symbol of the row, or -1
+        const int es = esc_in_lds ? static_cast<int>(static_cast<short>(ew & 0xFFFFu)) : dir[t].w;
         if (v == es) {
           // the rows behind an escape symbol carry its Elias-gamma code: M < 0 the unary prefix (-M - 1 zeros
           // before the row), M > 0 calls to go (M = 1: the sign; bit M - 2 of the magnitude otherwise)
@@ -1886,7 +2031,7 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
           int m = -1;                             // the mode counter in front of the row (the escape symbol left -1)
           for (unsigned int q = k0 + i + 1u; q < kend; ++q) {
             const unsigned int x = q - k0 < nrows ? buf[(q - k0) * kPitch + l] : raw[static_cast<size_t>(q) * 64 + l];
-            const unsigned int bit = x & 1u;
+            const unsigned int bit = (x >> bitshift) & 1u;
             if (x == kPipeSkipRow) continue;      // the lane sat this row out
             if (m < 0) {
               if (bit) val = 1u << (-m - 1);

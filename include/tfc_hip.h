@@ -48,6 +48,13 @@ int tfc_profile_query(const char* kernel, double* total_ms, int64_t* launches);
  * kernels (csrc/range_pipe.h) since the library was loaded, and workgroups of the lane-per-stream kernels that
  * ran behind them as the fallback for a job they gave up on (synchronises the device).  Either may be null. */
 int tfc_pipe_counters(int64_t* launches, int64_t* fallback_blocks);
+/* A/B and test switch of the pipelined decoder (csrc/range_pipe.h): which table image its chain kernel runs on —
+ * 0 by launch (the full image where it fits a CU and the launch's chain waves all find one, else the compact image),
+ * 1 the full image (one bit per quotient value), 2 the compact image (every second bound at pair resolution: half the
+ * bitmaps, ~10 % more cycles per row) — and how many chain waves share a workgroup's copy of it (0: by launch size).
+ * Same symbols either way.  Returns the previous format; the environment (TFC_PIPE_FORMAT = full | pairs,
+ * TFC_PIPE_WAVES) sets the initial values. */
+int tfc_set_pipe_format(int format, int waves_per_workgroup);
 
 /* Kernel family of a coder handle (no reference counterpart: the reference's ops shard streams over the
  * intra-op thread pool, range_coder_kernels.cc:212-267).  The bytes / symbols produced are identical.
