@@ -55,9 +55,17 @@ class GatheredStrings:
     bool): some rank had more bytes or streams than its slot takes — then packed() gathers again, exactly.  Nothing in
     here has been looked at by the host."""
 
-    def __init__(self, blob, lengths, counts, totals, overflow, exact):
+    def __init__(self, blob, lengths, counts, totals, overflow, exact, works=()):
         self.blob, self.lengths, self.counts, self.totals, self.overflow = blob, lengths, counts, totals, overflow
         self._exact = exact          # () -> (blob_all, offsets_all) by the synchronising path
+        self._works = list(works)    # the collectives in flight (async_op): wait() orders the current stream behind them
+
+    def wait(self):
+        """Orders the CURRENT stream behind the two collectives (no host synchronisation with RCCL); the stream that
+        enqueued the gather was never made to wait for them."""
+        for w in self._works:
+            w.wait()
+        self._works = []
 
     @property
     def starts(self):
@@ -66,6 +74,7 @@ class GatheredStrings:
     def packed(self):
         """(blob_all uint8, offsets_all int64) as gather_encoded returns them — ranks concatenated in rank order,
         identical to one process coding the whole batch.  Synchronises (the host needs the sizes)."""
+        self.wait()
         if bool(self.overflow):
             return self._exact()
         counts = [int(c) for c in self.counts.tolist()]
@@ -84,6 +93,11 @@ def gather_encoded_async(blob: torch.Tensor, offsets: torch.Tensor, capacity_byt
     bound the caller keeps from the steps it has already retired), so the two all-gathers (lengths + totals; padded
     bytes) are enqueued with sizes the host knows and nothing is read back: a step in flight ends with its gather
     and the host goes on enqueuing the next one.  Bytes beyond a slot are cut and flagged (GatheredStrings.overflow).
+    The collectives are asynchronous also for the enqueuing STREAM (async_op): RCCL runs them on its own stream behind
+    what the current stream holds so far, and the current stream is not made to wait for them — the steps in flight on
+    other streams share that one RCCL stream, and a step whose next kernels waited for its gather would wait for every
+    gather enqueued before it, i.e. for the other steps' encoders (measured on one GPU with a world of 1: bls2017 10.0
+    instead of 5.9 ms per step); GatheredStrings.wait() / packed() order a consumer behind them.
     blob: uint8 [>= offsets[-1]] (a handle's device_strings view at slab capacity is fine), offsets int64 [streams + 1]."""
     world = dist.get_world_size(group)
     device = blob.device
@@ -100,13 +114,26 @@ def gather_encoded_async(blob: torch.Tensor, offsets: torch.Tensor, capacity_byt
     pad[:n] = blob[:n]            # (bytes past offsets[-1] inside the slot travel too: the receiver cuts at the total)
     metas = torch.empty(world * (cs + 2), dtype=torch.int64, device=device)
     blobs = torch.empty(world * cb, dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(metas, meta, group=group)         # (flat outputs: the form gloo takes as well)
-    dist.all_gather_into_tensor(blobs, pad, group=group)
+    works = [dist.all_gather_into_tensor(metas, meta, group=group, async_op=True),      # (flat outputs: the form gloo takes as well)
+             dist.all_gather_into_tensor(blobs, pad, group=group, async_op=True)]
     metas, blobs = metas.view(world, cs + 2), blobs.view(world, cb)
-    counts, totals = metas[:, cs], metas[:, cs + 1]
-    overflow = (totals > cb).any() | (counts > cs).any()
-    return GatheredStrings(blobs, metas[:, :cs], counts, totals, overflow,
-                           lambda: gather_encoded(blob[:int(offsets[-1])], offsets, group=group))
+    return _LazyGathered(blobs, metas, cs, cb, lambda: gather_encoded(blob[:int(offsets[-1])], offsets, group=group), works)
+
+
+class _LazyGathered(GatheredStrings):
+    """(the fields derived from the gathered integers are formed behind wait(): forming them at once would make the
+    enqueuing stream read what the collective has not written yet)"""
+
+    def __init__(self, blobs, metas, cs, cb, exact, works):
+        super().__init__(blobs, None, None, None, None, exact, works)
+        self._metas, self._cs, self._cb = metas, cs, cb
+
+    def wait(self):
+        super().wait()
+        if self.lengths is None:
+            m, cs = self._metas, self._cs
+            self.lengths, self.counts, self.totals = m[:, :cs], m[:, cs], m[:, cs + 1]
+            self.overflow = (self.totals > self._cb).any() | (self.counts > cs).any()
 
 
 def broadcast_tables(module: torch.nn.Module, src: int = 0, group=None):

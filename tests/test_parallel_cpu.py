@@ -102,6 +102,9 @@ def _async_worker(rank, world, port, q):
                 got = parallel.gather_encoded_async(slab, torch.from_numpy(offs), capacity_bytes=2048, capacity_streams=4)
             gathers += 1
             ok = ok and reads.count == 0                                    # nothing in the gather looks at a value
+            with _HostReads() as reads:
+                got.wait()                                                  # ... nor does ordering a consumer behind it
+            ok = ok and reads.count == 0
             blob_all, offs_all = got.packed()
             ok = ok and bool((offs_all.numpy() == want_offs).all() and (blob_all.numpy() == want_blob).all())
             ok = ok and not bool(got.overflow)
@@ -115,6 +118,7 @@ def _async_worker(rank, world, port, q):
                     k += 1
             # a slot that is too small: flagged on every rank, packed() gathers again, exactly
             small = parallel.gather_encoded_async(slab, torch.from_numpy(offs), capacity_bytes=16, capacity_streams=4)
+            small.wait()
             ok = ok and bool(small.overflow)
             blob_all, offs_all = small.packed()
             ok = ok and bool((offs_all.numpy() == want_offs).all() and (blob_all.numpy() == want_blob).all())
