@@ -562,15 +562,42 @@ struct TableView {
 };
 
 // Where symbols come from (encode) / go to (decode).
+// Loads and stores of the kernels' tensor arguments go through global-address-space pointers: the functors below travel
+// inside job arrays indexed at run time, where hipcc cannot tell that their pointers are global and emits FLAT
+// instructions — which count on lgkmcnt as well as vmcnt, so that every wait for an LDS read in the same loop becomes a
+// wait for the loop's stores too (seen in dec_parse_kernel and enc_expand_kernel, round 6).
+#ifndef TFC_AS1
+#define TFC_AS1 __attribute__((address_space(1)))
+#endif
+template <typename T>
+__device__ inline T tfc_gload(const T* p) {
+  static_assert(sizeof(T) == 2 || sizeof(T) == 4, "16- and 32-bit elements");
+  if constexpr (sizeof(T) == 2) {
+    return __builtin_bit_cast(T, *reinterpret_cast<const TFC_AS1 unsigned short*>((const TFC_AS1 void*)p));
+  } else {
+    return __builtin_bit_cast(T, *reinterpret_cast<const TFC_AS1 unsigned int*>((const TFC_AS1 void*)p));
+  }
+}
+template <typename T>
+__device__ inline void tfc_gstore(T* p, T v) {
+  static_assert(sizeof(T) == 2 || sizeof(T) == 4, "16- and 32-bit elements");
+  if constexpr (sizeof(T) == 2) {
+    *reinterpret_cast<TFC_AS1 unsigned short*>((TFC_AS1 void*)p) = __builtin_bit_cast(unsigned short, v);
+  } else {
+    *reinterpret_cast<TFC_AS1 unsigned int*>((TFC_AS1 void*)p) = __builtin_bit_cast(unsigned int, v);
+  }
+}
+
 struct SymInt32 {          // plain int32 symbols
   const int32_t* value;
-  __device__ int32_t load(int64_t pos, int /*table*/) const { return value[pos]; }
+  __device__ int32_t load(int64_t pos, int /*table*/) const { return tfc_gload(value + pos); }
   // split form for kernels that request an element before they know its table
-  __device__ int32_t raw(int64_t pos) const { return value[pos]; }
+  __device__ int32_t raw(int64_t pos) const { return tfc_gload(value + pos); }
   __device__ int32_t quant(int32_t r, int /*table*/) const { return r; }
   __device__ const int32_t* base() const { return value; }
   using raw_type = int32_t;
 };
+
 
 template <typename T>
 __device__ inline float to_float(T v);
@@ -592,14 +619,14 @@ struct SymQuant {
   const T* y;
   const float* qoffset;        // may be null
   const int32_t* cdf_offset;
-  __device__ int32_t load(int64_t pos, int table) const { return quant(y[pos], table); }
-  __device__ T raw(int64_t pos) const { return y[pos]; }
+  __device__ int32_t load(int64_t pos, int table) const { return quant(tfc_gload(y + pos), table); }
+  __device__ T raw(int64_t pos) const { return tfc_gload(y + pos); }
   __device__ const T* base() const { return y; }
   using raw_type = T;
   __device__ int32_t quant(T r, int table) const {
     float f = to_float<T>(r);
-    if (qoffset) f = to_float<T>(from_float<T>(f - to_float<T>(from_float<T>(qoffset[table]))));
-    return static_cast<int32_t>(rintf(f)) - cdf_offset[table];
+    if (qoffset) f = to_float<T>(from_float<T>(f - to_float<T>(from_float<T>(tfc_gload(qoffset + table)))));
+    return static_cast<int32_t>(rintf(f)) - tfc_gload(cdf_offset + table);
   }
 };
 
@@ -1276,7 +1303,7 @@ __device__ inline int dec_symbol(const TabFn& T, DecoderState& st, int cdf0, int
 
 struct OutInt32 {
   int32_t* out;
-  __device__ void store(int64_t pos, int /*table*/, int32_t sym) const { out[pos] = sym; }
+  __device__ void store(int64_t pos, int /*table*/, int32_t sym) const { tfc_gstore(out + pos, sym); }
   // split form for kernels that collect several elements per store
   using elem = int32_t;
   __device__ int32_t make(int /*table*/, int32_t sym) const { return sym; }
@@ -1288,12 +1315,12 @@ struct OutDequant {
   T* y;
   const float* qoffset;
   const int32_t* cdf_offset;
-  __device__ void store(int64_t pos, int table, int32_t sym) const { y[pos] = make(table, sym); }
+  __device__ void store(int64_t pos, int table, int32_t sym) const { tfc_gstore(y + pos, make(table, sym)); }
   using elem = T;
   __device__ T make(int table, int32_t sym) const {
     // outputs = cast(symbols + cdf_offset, dtype) (+ quantization_offset)
-    T v = from_float<T>(static_cast<float>(sym + cdf_offset[table]));
-    if (qoffset) v = from_float<T>(to_float<T>(v) + to_float<T>(from_float<T>(qoffset[table])));
+    T v = from_float<T>(static_cast<float>(sym + tfc_gload(cdf_offset + table)));
+    if (qoffset) v = from_float<T>(to_float<T>(v) + to_float<T>(from_float<T>(tfc_gload(qoffset + table))));
     return v;
   }
   __device__ T* ptr() const { return y; }
@@ -1934,8 +1961,11 @@ int encode_lanes_many(tfc_encoder* const* es, int n, const Src* srcs, const int3
         const dim3 xgrid(static_cast<unsigned>(groups * pa.nt));
         auto expand = [&] {
           KernelTimer t2("enc_expand", st);
-          if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
-          else hipLaunchKernelGGL((enc_expand_kernel<false, Src>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
+          const bool tlds = pa.tab_entries != 0;
+          if (indexed && tlds) hipLaunchKernelGGL((enc_expand_kernel<true, Src, true>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
+          else if (indexed) hipLaunchKernelGGL((enc_expand_kernel<true, Src, false>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
+          else if (tlds) hipLaunchKernelGGL((enc_expand_kernel<false, Src, true>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
+          else hipLaunchKernelGGL((enc_expand_kernel<false, Src, false>), xgrid, dim3(kExpandThreads), 0, st, jobs, pa);
         };
         const int cgroups = PipeEncChainLds::kGroups;
         const unsigned cblocks = static_cast<unsigned>(ceil_div(static_cast<int64_t>(groups), cgroups));

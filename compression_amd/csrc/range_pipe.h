@@ -96,7 +96,11 @@ __device__ inline unsigned int pipe_escape_word(unsigned int g, unsigned int neg
 // for the 64 streams side by side).
 constexpr int kExpandThreads = 512;
 constexpr int kExpandTabBytes = 32 * 1024;     // table images up to this size are staged in LDS (two workgroups per CU)
-template <bool INDEXED, typename Src>
+// TABLDS (= pa.tab_entries != 0): a template parameter since round 6 — as a run-time condition, phase C's word came either
+// out of LDS or from a global load, and at the point where the two paths meet hipcc waited with s_waitcnt vmcnt(0) for
+// the load that may be pending in the word's register: in front of every store of the loop, so every store also waited
+// for the one before it to reach memory (a wave had ONE store in flight: phase C was two thirds of the kernel).
+template <bool INDEXED, typename Src, bool TABLDS>
 __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const EncLaneJobs<Src> jobs, const PipeEncArgs pa) {
   constexpr int kRow = kPipeTile;
   constexpr int kHalves = kExpandThreads / kPipeTile;     // thread = (half, symbol): half h takes streams h, h + kHalves, ...
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
   const int64_t s0 = static_cast<int64_t>(gidx) * 64;
   const unsigned int ntab = static_cast<unsigned int>(pa.ntab);
   if (tid < 64u) ecount[tid] = 0u;
-  const bool tab_lds = pa.tab_entries != 0;
+  constexpr bool tab_lds = TABLDS;
   if (tab_lds) {
     // (in flight next to phase A's loads; first read behind the barriers in front of phase C)
     const uint4* const src16 = reinterpret_cast<const uint4*>(pa.fast16);
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
     const int64_t pos = s * jobs.elems + at;
     int t = static_cast<int>(at % ntab);
     if (INDEXED) {
-      t = index[pos];
+      t = tfc_gload(index + pos);
       if (t < 0 || t >= pa.ntab) t = 0;
     }
     const int2 row = pa.rows_fast[t];
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
       unsigned int entry[NB];
       if (INDEXED) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) tt[i] = index[position(i0 + i)];
+        for (int i = 0; i < NB; ++i) tt[i] = tfc_gload(index + position(i0 + i));
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           if (tt[i] < 0 || tt[i] >= pa.ntab) {
@@ -306,8 +310,19 @@ __global__ void __launch_bounds__(kExpandThreads, 4) enc_expand_kernel(const Enc
         }
         const unsigned int at = W[sl * kRow + p];
         // (lo | hi << 16 as they lie in the table; from global memory one 4-byte load at 2-byte alignment)
-        const unsigned int word = tab_lds ? static_cast<unsigned int>(tab[at]) | (static_cast<unsigned int>(tab[at + 1u]) << 16)
-                                          : reinterpret_cast<const TFC_AS1 LanePacked<unsigned int>*>((const TFC_AS1 void*)(pa.fast16 + at))->v;
+        unsigned int word;
+        if constexpr (tab_lds) word = static_cast<unsigned int>(tab[at]) | (static_cast<unsigned int>(tab[at + 1u]) << 16);
+        else word = reinterpret_cast<const TFC_AS1 LanePacked<unsigned int>*>((const TFC_AS1 void*)(pa.fast16 + at))->v;
+        // Stores a wave keeps in flight in this loop: TWO (TFC_EXPAND_INFLIGHT = 1 behind the current one).  Round 5's
+        // loop had one — hipcc's s_waitcnt vmcnt(0) where the LDS and the global path of the look-up met (see TABLDS) —
+        // and without any bound the kernel is fastest alone, but the chain next to it, whose helpers' loads queue behind
+        // these stores, loses more than the expansion gains.  20 / 32 batches per launch, encode call (expansion, chain
+        // beside it), ms: one 3.42 (3.31, 3.36) / 6.14; two 3.41 (3.11, 3.36) / 5.51; four 4.05 (3.27, 3.99) / 5.56;
+        // unbounded 4.11 (3.28, 4.06) / 5.84 (tools/r06_ab_sat.sh, profiles/r06_notes.md).
+#ifndef TFC_EXPAND_INFLIGHT
+#define TFC_EXPAND_INFLIGHT 1
+#endif
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TFC_EXPAND_INFLIGHT) : "memory");
         out(first + p + cum) = word;
       }
       if (lane < ne) {
@@ -1114,7 +1129,7 @@ __global__ void __launch_bounds__(256) dec_rows_kernel(const PipeRowJobs jobs, u
   unsigned short* out = rowaddr + static_cast<size_t>(k) * jobs.per_job;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x, e = min(jobs.per_job, (static_cast<int64_t>(blockIdx.x) + 1) * 1024);
        i < e; i += 256) {
-    int t = index[i];
+    int t = tfc_gload(index + i);
     if (t < 0 || t >= jobs.ntab) {
       atomicMin(jobs.job[k].first_error, static_cast<unsigned long long>(i));
       t = 0;
@@ -1980,8 +1995,8 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
   const unsigned short* const raw = pa.raw + static_cast<size_t>(gi) * pa.rows * 64;
   const unsigned int nrows = min(static_cast<unsigned int>(kParseRows), kend - k0);
   for (unsigned int r = tid >> 6; r < nrows; r += 4u) buf[r * kPitch + lane] = raw[static_cast<size_t>(k0 + r) * 64 + lane];
-  const bool esc_in_lds = ntab <= kParseEscTables;
-  if (esc_in_lds)
+  const bool esc_lds = ntab <= kParseEscTables;
+  if (esc_lds)
     for (int i = tid; i < ntab; i += 256) {
       escsym[i] = (static_cast<unsigned int>(dir[i].w) & 0xFFFFu) | (PAIRS ? static_cast<unsigned int>(pm.adjust[i] + 2) << 16 : 0u);
     }
@@ -1991,6 +2006,12 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
   const Dst dst = J.dst;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const unsigned int untab = static_cast<unsigned int>(ntab);
+  // (the loop exists twice — escape symbols in LDS, or read from the directory: as a run-time condition inside it the
+  // directory's load met the LDS path in front of the element's store, where hipcc then waits with s_waitcnt vmcnt(0) —
+  // also for the stores of the iteration before; and the bit rows behind the tile are read through a global-address-space
+  // pointer: a FLAT load anywhere in the loop makes every wait of the loop a wait for everything.  Round 6.)
+  auto walk = [&](auto in_lds) __attribute__((always_inline)) {
+  constexpr bool esc_in_lds = decltype(in_lds)::value;
   for (unsigned int l = tid >> 6; l < 64u; l += 4u) {
     const int64_t s = static_cast<int64_t>(wv) * 64 + l;
     if (s >= jobs.streams) continue;
@@ -2010,7 +2031,7 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
         const int64_t at = base + ord;
         int t;
         if (INDEXED) {
-          t = J.index[at];
+          t = tfc_gload(J.index + at);
           t = (t < 0 || t >= ntab) ? 0 : t;
         } else {
           unsigned int m = pmod + before;          // < ntab + 64
@@ -2030,7 +2051,8 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
           bool neg = false, closed = false;
           int m = -1;                             // the mode counter in front of the row (the escape symbol left -1)
           for (unsigned int q = k0 + i + 1u; q < kend; ++q) {
-            const unsigned int x = q - k0 < nrows ? buf[(q - k0) * kPitch + l] : raw[static_cast<size_t>(q) * 64 + l];
+            const unsigned int x = q - k0 < nrows ? buf[(q - k0) * kPitch + l]
+                                                  : *reinterpret_cast<const TFC_AS1 unsigned short*>((const TFC_AS1 void*)(raw + static_cast<size_t>(q) * 64 + l));
             const unsigned int bit = (x >> bitshift) & 1u;
             if (x == kPipeSkipRow) continue;      // the lane sat this row out
             if (m < 0) {
@@ -2054,6 +2076,8 @@ __global__ void __launch_bounds__(256) dec_parse_kernel(const DecLaneJobs<Dst> j
       pmod = (pmod + total) % untab;
     }
   }
+  };
+  if (esc_lds) walk(std::true_type{}); else walk(std::false_type{});
   if (pa.concurrent) {
     __syncthreads();
     if (tid == 0u && incomplete == 0u) *tile_done = 1u;     // (read by the pass behind the chain: another kernel)
