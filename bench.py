@@ -783,6 +783,11 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
     from compression_amd.ops import gen_ops
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     step_lanes = lanes if lanes is not None else pipeline.StepLanes(6, device)
+    # what the legs before this one left in the two block caches (torch's and the library's) goes back to the driver:
+    # the float32 / 8-batch C4 passes need the room as fresh blocks of their own sizes
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    pipeline.empty_cache()
     model, x, batch, hw, hist = make_model(workload, dtype, device, batch, rank)
     if distributed:
         parallel.broadcast_tables(model)
@@ -1520,6 +1525,7 @@ def main():
                                                  out.get("cpu_baseline", {}).get("value"))
             out["saturation"]["headline_point"] = inflight
             torch.cuda.empty_cache()
+            pipeline.empty_cache()
         if extras:
             torch.set_num_threads(1)
             mh = c2_run(args, lookup, lookup_t, device, 1, 0, False, args.escape_fraction, args.steps, args.inflight,
