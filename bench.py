@@ -311,8 +311,8 @@ def gdn_forward_bandwidth(device, steps=20):
                                "frac_of_cold_copy": round(copy_cold / head["forward"]["kernel_ms"], 4),
                                "note": "torch's device copy of the same tensors, same rotation and timing: what this box "
                                        "streams for read x + write y with no arithmetic; frac_of_cold_copy = copy time / GDN time"},
-            "traffic": pmc_traffic("gdn_fwd_bf16_kernel", PMC_PROFILE, GDN_SOURCES),
-            "traffic_source": f"stored: profiles/{PMC_PROFILE} (rocprofv3 --pmc passes of this command on these sources; "
+            "traffic": pmc_traffic("gdn_fwd_bf16_kernel", GDN_PMC_PROFILE, GDN_SOURCES),
+            "traffic_source": f"stored: profiles/{GDN_PMC_PROFILE} (rocprofv3 --pmc passes of this command on these sources; "
                               "null = taken on other sources)",
             "backward": dict(head["backward"], algorithmic_bytes=bwd_bytes, unit="GB/s"),
             "variants": {"note": "all cold (rotating tensors); forward algorithmic bytes = x + y, backward = x + g + dx; "
@@ -372,8 +372,9 @@ def pmc_traffic(kernel_substring, profile, sources, steps_per_launch=None):
     return None
 
 
-PMC_PROFILE = "r05_pmc_traffic.json"
-SQ_PROFILE = "r05_sq_inflight.json"
+PMC_PROFILE = "r06_pmc_traffic.json"
+GDN_PMC_PROFILE = "r06_pmc_gdn.json"
+SQ_PROFILE = "r06_sq_inflight.json"
 
 
 def valu_issue_floor(ms_per_step, kernels, steps_per_launch):
@@ -1325,6 +1326,11 @@ def main():
     ap.add_argument("--spawn-check", action="store_true",
                     help="no measurement: start the --gpus ranks exactly as a measurement would, rendezvous over gloo on "
                          "the host, and print {world, ranks} (the CPU-tier test of the launch path)")
+    ap.add_argument("--leg", default="all", choices=["all", "headline", "single_batch", "gdn"],
+                    help="profiling aid: run ONE leg of the default line only and print a short line for it — `headline` "
+                         "(the timed groups of --steps batches, throughput handles) or `single_batch` (BASELINE config 2 as "
+                         "written: one batch at a time, latency handles) — so that a rocprofv3 summary of the command is a "
+                         "summary of that leg's kernels (tools/r06_profiles.sh)")
     ap.add_argument("--collective-check", action="store_true",
                     help="diagnostic for a one-GPU box: run the single rank inside an RCCL process group of world size 1, "
                          "so that the model workloads' per-step gather (and every other distributed branch) executes")
@@ -1367,6 +1373,28 @@ def main():
     lookup = build_tables(device)
     lookup_t = torch.from_numpy(lookup)            # tables are uploaded once (cached per tensor)
     extras = not args.no_extras and world == 1
+    if args.leg == "gdn":
+        if rank == 0:
+            print(json.dumps({"leg": "gdn", "gdn_fwd": gdn_forward_bandwidth(device)}))
+        if distributed:
+            dist.destroy_process_group()
+        return
+    if args.leg != "all":
+        single = args.leg == "single_batch"
+        m = c2_run(args, lookup, lookup_t, device, world, rank, distributed, args.escape_fraction,
+                   5 if single else args.steps, 1 if single else args.inflight, serial=False, repeats=args.repeats)
+        if rank == 0:
+            steps = m["steps"]
+            print(json.dumps({"leg": args.leg, "metric": "Mpixels/s encode+decode round-trip (bit-exact)",
+                              "value": round(world * STREAMS * PIXELS_PER_STREAM / 1e6 / (m["elapsed"] / steps), 2),
+                              "unit": "Mpixels/s", "steps": steps, "steps_in_flight": m["inflight"],
+                              "ms_per_step": round(1e3 * m["elapsed"] / steps, 4),
+                              "timed_regions_ms_per_step": [round(1e3 * v / steps, 4) for v in m["repetitions"]],
+                              "kernels_ms_in_flight": {"enc_kernel": round(m["enc_tr"], 4), "dec_kernel": round(m["dec_tr"], 4),
+                                                       "stages": {k: round(v, 4) for k, v in (m.get("stages") or {}).items()}}}))
+        if distributed:
+            dist.destroy_process_group()
+        return
     m = c2_run(args, lookup, lookup_t, device, world, rank, distributed, args.escape_fraction, args.steps,
                args.inflight, serial=True, repeats=args.repeats)
     inflight, elapsed, total_bytes = m["inflight"], m["elapsed"], m["total_bytes"]
