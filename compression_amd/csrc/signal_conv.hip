@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -868,7 +869,9 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
     __builtin_amdgcn_s_barrier();                                        \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      \
   } while (0)
-template <int TILES, int CH, int NCH, int NPG, bool GDN = false>
+// OUTF32 (round 6): the float32 accumulators + bias leave as float32 (the float32 layers that run as six bfloat16
+// planes, conv_split_x_kernel).
+template <int TILES, int CH, int NCH, int NPG, bool GDN = false, bool OUTF32 = false>
 __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, const void* packed,
                                                             const float* bias, __bf16* y, ConvGeom c,
                                                             Conv3Geom d) {
@@ -1115,6 +1118,36 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     const int colbase = it.group * TILES * 32;
     const int qx = it.qx0 + l;
     if constexpr (GDN) gdn_stage(wbuf_next, wnext, afirst);
+    if constexpr (OUTF32) {
+      static_assert(!GDN, "float32 output: no fused GDN");
+      float* const yf = reinterpret_cast<float*>(y);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col0 = colbase + 32 * t + 8 * q + 4 * h;       // four consecutive columns: channels of one phase
+          if (col0 >= c.cols) continue;
+          const int co = col0 % c.Cout, ph = col0 / c.Cout;
+          f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+          for (int p = 0; p < MT; ++p) {
+            const int qy = it.qy0 + 2 * wid + p;
+            if (qy >= c.OHq || qx >= c.OWq) continue;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[p][t][4 * q + r] + b4[r];
+              if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
+            }
+            const int oy = qy * c.su + ph / c.su, ox = qx * c.su + ph % c.su;
+            *reinterpret_cast<f32x4*>(yf + ((it.n * c.OH + oy) * c.OW + ox) * c.Cout + co) = v;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
@@ -1330,7 +1363,7 @@ int conv3_gen() {
 
 int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, ConvGeom c, PackGeom g,
               hipStream_t st) {
-  if (conv3_gen() < 3 || c.small_cin || c.out_f32 || c.Cin % 16 || (c.sd != 1 && c.sd != 2)) return -1;
+  if (conv3_gen() < 3 || c.small_cin || (c.out_f32 && c.gdn) || c.Cin % 16 || (c.sd != 1 && c.sd != 2)) return -1;
   if (c.Cout != 128 && c.Cout != 192) return -1;
   // Where it is used (measured, tools/conv3_check.py and profiles/r03_notes.md): the transposed 5x5 layers, where it is
   // 18-25 % ahead of the second generation.  On the stride-2 analysis layers it is level with it (TFC_CONV_GEN=4 runs
@@ -1440,9 +1473,16 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
       hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
     } while (0)
+#define TFC_CONV3_LAUNCH_F(NT, CHV, NCHV, NPGV)                                                            \
+    do {                                                                                                   \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, false, true>),  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
+      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, false, true>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
+    } while (0)
 #define TFC_CONV3_LAUNCH(NT, CHV, NCHV, NPGV)                                                              \
     do {                                                                                                   \
-      if (c.gdn) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, true);                                            \
+      if (c.out_f32) TFC_CONV3_LAUNCH_F(NT, CHV, NCHV, NPGV);                                              \
+      else if (c.gdn) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, true);                                       \
       else TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, false);                                                 \
     } while (0)
 #define TFC_CONV3_TAPS(NT)                                                   \
@@ -1455,6 +1495,7 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     if (c.tiles == 6) TFC_CONV3_TAPS(6); else TFC_CONV3_TAPS(4);
 #undef TFC_CONV3_TAPS
 #undef TFC_CONV3_LAUNCH
+#undef TFC_CONV3_LAUNCH_F
 #undef TFC_CONV3_LAUNCH_G
   }
   TFC_HIP(hipGetLastError());
@@ -1560,13 +1601,23 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
     const bool fastk = kPF == kChunk2 && (c.Cin / 16) % kChunk2 == 0 && !TFC_CONV_NO_FASTK;
     // (the fp32-output variant is a compile-time property: as a run-time flag in the epilogue it cost the
     // 6-tile kernel 832 bytes of scratch per lane, accumulators spilled inside the K loop)
-#define TFC_CONV2_LAUNCH_F32(NT, MTV)                                                              \
+    // (round 6: with the one-tap-per-chunk K loop too, for the float32 layers that run as six bfloat16 planes — built for
+    // the 128- and 192-column groups, the widths of the models' layers)
+#define TFC_CONV2_LAUNCH_F32K(NT, MTV, FK)                                                         \
     do {                                                                                           \
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<NT, MTV, false, true>), \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<NT, MTV, FK, true>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2))); \
-      hipLaunchKernelGGL((conv_bf16_kernel<NT, MTV, false, true>), grid2, dim3(256), lds2, st,     \
+      hipLaunchKernelGGL((conv_bf16_kernel<NT, MTV, FK, true>), grid2, dim3(256), lds2, st,        \
                          static_cast<const __bf16*>(static_cast<const void*>(xin)), packed.p, bias,  \
                          static_cast<__bf16*>(y), c);                                              \
+    } while (0)
+#define TFC_CONV2_LAUNCH_F32(NT, MTV)                                                              \
+    do {                                                                                           \
+      if constexpr (NT == 6 || NT == 4) {                                                          \
+        if (fastk) TFC_CONV2_LAUNCH_F32K(NT, MTV, true); else TFC_CONV2_LAUNCH_F32K(NT, MTV, false); \
+      } else {                                                                                     \
+        TFC_CONV2_LAUNCH_F32K(NT, MTV, false);                                                     \
+      }                                                                                            \
     } while (0)
 #define TFC_CONV2_CASE(NT)                                                                         \
     case NT:                                                                                       \
@@ -1586,6 +1637,7 @@ int run_conv(const void* x, const float* w, const float* bias, void* y, ConvGeom
 #undef TFC_CONV2_CASE
 #undef TFC_CONV2_LAUNCH
 #undef TFC_CONV2_LAUNCH_F32
+#undef TFC_CONV2_LAUNCH_F32K
     TFC_HIP(hipGetLastError());
     return 0;
   }
@@ -2662,6 +2714,74 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
                int activation, int up, void* stream, bool out_f32 = false, const tfc_gdn_params* gdn = nullptr,
                int gdn_inverse = 0, int* gdn_fused = nullptr);
+// ---------------------------------------------------------------------------
+// float32 layers on the bfloat16 matrix cores (round 6).  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bfloat16 rate, and
+// the float32 model steps are 90 % convolutions.  A float32 value is the sum of three bfloat16 values to its last bit
+// (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2): 3 x 8 significant bits), and the product of two such sums is
+//     a b = a1 b1 + a1 b2 + a2 b1 + a1 b3 + a2 b2 + a3 b1 + (terms below 2^-25 |a b|),
+// every retained product exact in float32 and accumulated in float32 by the MFMA: the convolution of float32 tensors is
+// ONE bfloat16 convolution with six times the input channels, [x1 | x1 | x1 | x2 | x2 | x3] against the kernel planes
+// [w1 | w2 | w3 | w1 | w2 | w1], with float32 output — 6/16 of the float32 MFMA time on kernels that are also further
+// along (second generation: 16-byte gathers 4 K steps ahead, packed weights through LDS).  The result differs from a
+// float32 FMA chain by float32 rounding noise (a few 1e-7 relative; tests/test_signal_conv_gpu.py holds both to the float32
+// definition).  TFC_CONV_F32=native keeps the float32 MFMA kernel; layers with <= 4 channels on one side keep it anyway.
+// ---------------------------------------------------------------------------
+__device__ inline void split3(float a, __bf16* p1, __bf16* p2, __bf16* p3) {
+  const __bf16 a1 = static_cast<__bf16>(a);
+  const float r1 = a - static_cast<float>(a1);
+  const __bf16 a2 = static_cast<__bf16>(r1);
+  const float r2 = r1 - static_cast<float>(a2);
+  *p1 = a1; *p2 = a2; *p3 = static_cast<__bf16>(r2);
+}
+// x float32 [pixels, C] -> xs bfloat16 [pixels, 6 C]; a thread takes 8 channels of a pixel (C % 8 == 0)
+__global__ void __launch_bounds__(256) conv_split_x_kernel(const float* x, long long pixels, int C, __bf16* xs) {
+  const int per = C / 8;
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= pixels * per) return;
+  const long long pix = i / per;
+  const int c0 = static_cast<int>(i - pix * per) * 8;
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(x + pix * C + c0), hi = *reinterpret_cast<const f32x4*>(x + pix * C + c0 + 4);
+  bf16x8 p1, p2, p3;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 a, b, c;
+    split3(e < 4 ? lo[e] : hi[e - 4], &a, &b, &c);
+    p1[e] = a; p2[e] = b; p3[e] = c;
+  }
+  __bf16* row = xs + pix * 6 * C + c0;
+  *reinterpret_cast<bf16x8*>(row) = p1;
+  *reinterpret_cast<bf16x8*>(row + C) = p1;
+  *reinterpret_cast<bf16x8*>(row + 2 * C) = p1;
+  *reinterpret_cast<bf16x8*>(row + 3 * C) = p2;
+  *reinterpret_cast<bf16x8*>(row + 4 * C) = p2;
+  *reinterpret_cast<bf16x8*>(row + 5 * C) = p3;
+}
+// w float32 [taps, C, Cout] -> w6 float32 [taps, 6 C, Cout] holding the planes [w1 | w2 | w3 | w1 | w2 | w1] as float32
+// values (each exactly a bfloat16: the packing kernels' rounding leaves them as they are)
+__global__ void __launch_bounds__(256) conv_split_w_kernel(const float* w, long long taps, int C, int Cout, float* w6) {
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= taps * C * Cout) return;
+  const int co = static_cast<int>(i % Cout);
+  const long long tc = i / Cout;
+  const int c = static_cast<int>(tc % C);
+  const long long t = tc / C;
+  __bf16 a, b, d;
+  split3(w[i], &a, &b, &d);
+  const float p[3] = {static_cast<float>(a), static_cast<float>(b), static_cast<float>(d)};
+  const int plane[6] = {0, 1, 2, 0, 1, 0};
+  float* base = w6 + (t * 6 * C + c) * Cout + co;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) base[static_cast<long long>(q) * C * Cout] = p[plane[q]];
+}
+
+inline bool conv_f32_split_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("TFC_CONV_F32");
+    return !(e && std::strcmp(e, "native") == 0);
+  }();
+  return on;
+}
+
 
 // Fused variant of the transposed convolution into few channels: 0 = launched, -1 = not this shape, > 0 = error.
 int run_conv_up_fused(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t h, int64_t wd,
@@ -2749,6 +2869,29 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
                 static_cast<long long>(cin));
   if (activation != 0 && activation != 1) return fail("tfc_conv2d: activation must be 0 (none) or 1 (relu)");
   if (n == 0 || h == 0 || wd == 0) return 0;
+  if (dtype == 0 && conv_f32_split_enabled() && cin % 16 == 0 && cout % 4 == 0 && !gdn &&
+      6 * cin * static_cast<int64_t>(kh) * kw < (int64_t{1} << 24)) {
+    // float32 on the bfloat16 matrix cores: three planes per operand, six products (see conv_split_x_kernel)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long pixels = static_cast<long long>(n) * h * wd;
+    const long long taps = static_cast<long long>(kh) * kw;
+    DevBuf xs, w6;
+    TFC_HIP(xs.alloc(static_cast<size_t>(pixels) * 6 * cin * sizeof(__bf16), st));
+    TFC_HIP(w6.alloc(static_cast<size_t>(taps) * 6 * cin * cout * sizeof(float), st));
+    const long long xthreads = pixels * (cin / 8), wthreads = taps * cin * cout;
+    if (ceil_div(xthreads, 256) >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
+    {
+      KernelTimer timer("conv2d", st);
+      hipLaunchKernelGGL(conv_split_x_kernel, dim3(static_cast<unsigned>(ceil_div(xthreads, 256))), dim3(256), 0, st,
+                         static_cast<const float*>(x), pixels, static_cast<int>(cin), xs.as<__bf16>());
+      hipLaunchKernelGGL(conv_split_w_kernel, dim3(static_cast<unsigned>(ceil_div(wthreads, 256))), dim3(256), 0, st,
+                         static_cast<const float*>(w), taps, static_cast<int>(cin), static_cast<int>(cout), w6.as<float>());
+    }
+    TFC_HIP(hipGetLastError());
+    // (the weights key named for this call packs the six-plane kernel once, like any other layer's)
+    t_next_weights_key = t_weights_key ? (t_weights_key ^ 0x5bf1600000000000ull) : 0;
+    return conv_entry(xs.p, w6.p, bias, y, 1, n, h, wd, 6 * cin, cout, kh, kw, stride, activation, up, stream, true);
+  }
 #ifndef TFC_CONV_NO_UP_GATHER
   // (up to 128 product columns, i.e. one column group: a 9x9 stride-4 kernel has 324 and measured the same
   // or slower this way — 0.19 against 0.16 ms at batch 64 — so it keeps the implicit GEMM over output pixels)
@@ -2763,7 +2906,7 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
                                      activation, static_cast<hipStream_t>(stream));
     if (rc >= 0) return rc;
   }
-  if (up && dtype == 1 && cout <= 4 && cin % 16 == 0 && stride >= 2 && kh * kw * 4 <= 128)
+  if (up && dtype == 1 && cout <= 4 && cin % 16 == 0 && stride >= 2 && kh * kw * 4 <= 128 && !out_f32)
     return conv_up_small_cout(x, static_cast<const float*>(w), bias, y, n, h, wd, cin, cout, kh, kw, stride, activation,
                               static_cast<hipStream_t>(stream));
 #endif
@@ -2853,7 +2996,8 @@ extern "C" int tfc_conv2d_drop_weights(uint64_t key) {
   int home = 0;
   (void)hipGetDevice(&home);
   for (auto it = c.entries.begin(); it != c.entries.end();) {
-    if (it->first.key != key) { ++it; continue; }
+    // (and the six-plane kernel a float32 layer packed under the key derived from it: conv_entry's bf16 x 6 path)
+    if (it->first.key != key && it->first.key != (key ^ 0x5bf1600000000000ull)) { ++it; continue; }
     tfc::WeightsCache::Entry& e = it->second;
     if (it->first.dev != home) (void)hipSetDevice(it->first.dev);
     bool ordered = true;
