@@ -903,7 +903,12 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
                 "roofline": {"bound": "mfma", "kernel": "conv2d (all SignalConv2D launches of a step)",
                              "achieved": round(conv_tflops, 1), "peak": mfma_peak, "unit": "TFLOP/s",
                              "frac": round(conv_tflops / mfma_peak, 4), "traffic": None,
-                             "algorithmic_flops": int(flops)},
+                             "algorithmic_flops": int(flops),
+                             **({"note": "float32 layers of >= 16 channels run on the bfloat16 matrix cores: three bf16 planes per "
+                                         "operand, six bf16 MFMA products per float32 product (csrc/signal_conv.hip conv_split_x_kernel; "
+                                         "TFC_CONV_F32=native: the float32 MFMA kernel) — `achieved` counts the float32 problem's flops, "
+                                         "`peak` is the float32 MFMA's; the six-product ceiling is 2500 / 6 = 417 TFLOP/s"}
+                                if dtype_name != "bf16" else {})},
             }
             if hist is not None:
                 res["scale_index_histogram"] = [int(v) for v in hist]

@@ -2774,12 +2774,10 @@ __global__ void __launch_bounds__(256) conv_split_w_kernel(const float* w, long 
   for (int q = 0; q < 6; ++q) base[static_cast<long long>(q) * C * Cout] = p[plane[q]];
 }
 
+// (read per call: the tests compare the two in one process)
 inline bool conv_f32_split_enabled() {
-  static const bool on = [] {
-    const char* e = std::getenv("TFC_CONV_F32");
-    return !(e && std::strcmp(e, "native") == 0);
-  }();
-  return on;
+  const char* e = std::getenv("TFC_CONV_F32");
+  return !(e && std::strcmp(e, "native") == 0);
 }
 
 

@@ -625,3 +625,40 @@ def test_default_argument_layer_on_the_device():
     assert np.max(np.abs(np.moveaxis(y.cpu().numpy(), -1, 1) - want)) <= 1e-5
     layer(x).square().sum().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in layer.parameters())
+
+
+F32_SPLIT_CASES = [  # up, n, h, w, cin, cout, k, s — layer shapes of the models, float32
+    (False, 2, 64, 96, 192, 192, 5, 2),      # third-generation kernel, float32 output
+    (False, 1, 33, 47, 192, 192, 5, 2),      # second generation (ragged map)
+    (False, 2, 32, 48, 192, 192, 3, 1),
+    (True, 2, 32, 48, 192, 192, 5, 2),       # transposed: four phase groups
+    (True, 1, 9, 11, 128, 128, 5, 2),
+    (True, 1, 8, 7, 64, 4, 5, 2),            # few output channels: one partly filled column tile
+    (False, 1, 20, 20, 16, 40, 4, 2),
+]
+
+
+@pytest.mark.parametrize("case", F32_SPLIT_CASES)
+def test_float32_layers_on_the_bfloat16_matrix_cores(case, monkeypatch):
+    """Round 6: a float32 SignalConv2D runs as ONE bfloat16 convolution over six times the input channels — three bfloat16
+    planes per operand (a float32 is their exact sum), the six products above 2^-25 — with float32 accumulation and
+    output (conv_split_x_kernel).  Both it and the float32-MFMA kernel it replaces (TFC_CONV_F32=native) are held to a
+    float64 evaluation of the layer's definition (signal_conv.py:663-690, 778-847) at 4e-6 of the largest output — float32
+    rounding noise over K = 25 x 192 products — and to each other at twice that."""
+    from compression_amd.layers import conv2d_down, conv2d_up
+    up, n, h, w, cin, cout, k, s = case
+    torch.manual_seed(11)
+    x = torch.randn(n, h, w, cin)
+    ker = torch.randn(k, k, cin, cout) / np.sqrt(k * k * cin)
+    bias = torch.randn(cout)
+    fn = conv2d_up if up else conv2d_down
+    want = (ref_up if up else ref_down)(x.double(), ker.double(), bias.double(), s, False)
+    got = {}
+    for mode in ("split", "native"):
+        monkeypatch.setenv("TFC_CONV_F32", mode)
+        got[mode] = fn(x.cuda(), ker, bias, s).cpu().double()
+        assert got[mode].shape == want.shape
+    scale = max(1.0, want.abs().max().item())
+    for mode in got:
+        assert (got[mode] - want).abs().max().item() <= 4e-6 * scale, mode
+    assert (got["split"] - got["native"]).abs().max().item() <= 8e-6 * scale
