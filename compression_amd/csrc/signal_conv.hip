@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -2710,6 +2711,9 @@ int run_conv_up_phase(const void* x, const float* w, const float* bias, void* y,
   return 0;
 }
 
+}  // namespace tfc
+extern "C" int tfc_conv2d_drop_weights(uint64_t key);
+namespace tfc {
 int conv_entry(const void* x, const void* w, const float* bias, void* y, int dtype, int64_t n,
                int64_t h, int64_t wd, int64_t cin, int64_t cout, int kh, int kw, int stride,
                int activation, int up, void* stream, bool out_f32 = false, const tfc_gdn_params* gdn = nullptr,
@@ -2869,26 +2873,44 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
   if (n == 0 || h == 0 || wd == 0) return 0;
   if (dtype == 0 && conv_f32_split_enabled() && cin % 16 == 0 && cout % 4 == 0 && !gdn &&
       6 * cin * static_cast<int64_t>(kh) * kw < (int64_t{1} << 24)) {
-    // float32 on the bfloat16 matrix cores: three planes per operand, six products (see conv_split_x_kernel)
+    // float32 on the bfloat16 matrix cores: three planes per operand, six products (see conv_split_x_kernel).  The planes
+    // of the input are 3x its bytes: images go through in chunks of ~2 GB of planes (bmshj2018's first 192 -> 192 layer at
+    // 128 x 768x512 would need 29 GB at once), each chunk split and convolved before the next — the kernel's six planes
+    // are made and packed once, under the caller's weights key or a key of this call's own.
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const long long pixels = static_cast<long long>(n) * h * wd;
     const long long taps = static_cast<long long>(kh) * kw;
+    const long long pix_image = static_cast<long long>(h) * wd;
+    const size_t plane_bytes_image = static_cast<size_t>(pix_image) * 6 * cin * sizeof(__bf16);
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, static_cast<int64_t>((size_t{2} << 30) / std::max<size_t>(plane_bytes_image, 1))));
     DevBuf xs, w6;
-    TFC_HIP(xs.alloc(static_cast<size_t>(pixels) * 6 * cin * sizeof(__bf16), st));
+    TFC_HIP(xs.alloc(plane_bytes_image * static_cast<size_t>(chunk), st));
     TFC_HIP(w6.alloc(static_cast<size_t>(taps) * 6 * cin * cout * sizeof(float), st));
-    const long long xthreads = pixels * (cin / 8), wthreads = taps * cin * cout;
-    if (ceil_div(xthreads, 256) >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
-    {
-      KernelTimer timer("conv2d", st);
-      hipLaunchKernelGGL(conv_split_x_kernel, dim3(static_cast<unsigned>(ceil_div(xthreads, 256))), dim3(256), 0, st,
-                         static_cast<const float*>(x), pixels, static_cast<int>(cin), xs.as<__bf16>());
-      hipLaunchKernelGGL(conv_split_w_kernel, dim3(static_cast<unsigned>(ceil_div(wthreads, 256))), dim3(256), 0, st,
-                         static_cast<const float*>(w), taps, static_cast<int>(cin), static_cast<int>(cout), w6.as<float>());
+    const long long wthreads = taps * cin * cout;
+    if (ceil_div(pix_image * chunk * (cin / 8), 256) >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
+    hipLaunchKernelGGL(conv_split_w_kernel, dim3(static_cast<unsigned>(ceil_div(wthreads, 256))), dim3(256), 0, st,
+                       static_cast<const float*>(w), taps, static_cast<int>(cin), static_cast<int>(cout), w6.as<float>());
+    static std::atomic<unsigned long long> own_keys{0};
+    const unsigned long long caller_key = t_weights_key;
+    const unsigned long long key = caller_key ? (caller_key ^ 0x5bf1600000000000ull)
+                                              : (0xf32c000000000000ull | own_keys.fetch_add(1, std::memory_order_relaxed));
+    const long long out_image = (up ? static_cast<long long>(h) * stride * wd * stride
+                                    : static_cast<long long>((h + stride - 1) / stride) * ((wd + stride - 1) / stride)) * cout;
+    int rc = 0;
+    for (int64_t n0 = 0; n0 < n && rc == 0; n0 += chunk) {
+      const int64_t nc = std::min<int64_t>(chunk, n - n0);
+      const long long pixels = pix_image * nc;
+      {
+        KernelTimer timer("conv2d", st);
+        hipLaunchKernelGGL(conv_split_x_kernel, dim3(static_cast<unsigned>(ceil_div(pixels * (cin / 8), 256))), dim3(256), 0, st,
+                           static_cast<const float*>(x) + n0 * pix_image * cin, pixels, static_cast<int>(cin), xs.as<__bf16>());
+      }
+      t_next_weights_key = key;
+      rc = conv_entry(xs.p, w6.p, bias, static_cast<float*>(y) + n0 * out_image, 1, nc, h, wd, 6 * cin, cout, kh, kw, stride,
+                      activation, up, stream, true);
     }
     TFC_HIP(hipGetLastError());
-    // (the weights key named for this call packs the six-plane kernel once, like any other layer's)
-    t_next_weights_key = t_weights_key ? (t_weights_key ^ 0x5bf1600000000000ull) : 0;
-    return conv_entry(xs.p, w6.p, bias, y, 1, n, h, wd, 6 * cin, cout, kh, kw, stride, activation, up, stream, true);
+    if (!caller_key) (void)tfc_conv2d_drop_weights(key);
+    return rc;
   }
 #ifndef TFC_CONV_NO_UP_GATHER
   // (up to 128 product columns, i.e. one column group: a 9x9 stride-4 kernel has 324 and measured the same
