@@ -789,6 +789,7 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     pipeline.empty_cache()
+    torch.cuda.reset_peak_memory_stats(device)
     model, x, batch, hw, hist = make_model(workload, dtype, device, batch, rank)
     if distributed:
         parallel.broadcast_tables(model)
@@ -802,6 +803,10 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
         lone_s, rec = run_model_steps(model, x, lone_steps, inline)
         kern = {name: profile_query(name) for name in ("enc_kernel", "dec_kernel", "conv2d", "gdn_forward")}
         _lib.lib().tfc_profile_enable(0)
+        # the lone steps' blocks (this side stream's pool: no in-flight lane can reuse them) go back before the lanes fill theirs
+        del rec
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         # (b) the timed region: `queue` steps enqueued per lane — a stream whose step has finished still has work while
         # the host retires that step (waits for its end event, fetches strings and flags) and enqueues the next
         lanes = list(step_lanes.lanes) * max(1, queue)
@@ -821,9 +826,10 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
         # `passes` timed passes, each bracketed like the first; the median counts (a pass whose buffers the allocators
         # had to fetch first — seen on fresh boxes with the float32 C4 — is an outlier, not the figure)
         pass_s = []
+        rec = None
         for k in range(max(1, passes)):
             if k:
-                del rec
+                rec = None
                 torch.cuda.synchronize()
                 if distributed:
                     step_gather.reset()
@@ -884,6 +890,11 @@ def model_bench(workload, dtype_name, device, batch=0, steps=6, warmup=2, lanes=
                 "value": round(pixels / 1e6 / (elapsed / steps), 2), "unit": "Mpixels/s",
                 "ms_per_step": round(1e3 * elapsed / steps, 3), "steps": steps, "warmup": warmup,
                 "timed_passes_ms_per_step": [round(1e3 * v / steps, 3) for v in pass_s],
+                "memory_gb": {"torch_reserved": round(torch.cuda.memory_reserved(device) / 2 ** 30, 1),
+                              "torch_allocated_peak": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+                              "library_cached": round(pipeline.cached_bytes() / 2 ** 30, 1),
+                              "device_free": round(torch.cuda.mem_get_info(device)[0] / 2 ** 30, 1),
+                              "torch_alloc_retries": torch.cuda.memory_stats(device).get("num_alloc_retries", 0)},
                 "workload": f"{workload} compress+decompress, {batch} images of {hw[1]}x{hw[0]} per GPU, 192 filters, "
                             f"random-init weights" + (", hyperprior calibrated (scale_index_histogram)" if hist is not None else ""),
                 "dtype": dtype_name,
@@ -1597,8 +1608,10 @@ def main():
                                                       cpu=False, group=1, queue=args.model_queue)
                 torch.cuda.empty_cache()
                 g = model_group(args, "bmshj2018")
-                # (three of the lanes: a float32 step keeps ~25 GB of activations per stream)
-                few = type("Lanes", (), {"lanes": step_lanes.lanes[:3]})()
+                # (two of the lanes — as fast as three, measured — a float32 step keeps ~25 GB of activations per stream
+                # live and torch's per-stream pools reserve ~70 GB for them: with three, the allocator ran out and
+                # retried inside the timed passes, memory_gb.torch_alloc_retries)
+                few = type("Lanes", (), {"lanes": step_lanes.lanes[:2]})()
                 out["models"]["c4_f32"] = model_bench("bmshj2018", "f32", device, steps=2 * g, warmup=1, lanes=few,
                                                       cpu=False, group=g, queue=1, inflight_warmup=3)
         print(json.dumps(out))
