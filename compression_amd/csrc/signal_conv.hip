@@ -863,6 +863,19 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
 #ifndef TFC_CONV3_EXP
 #define TFC_CONV3_EXP 0
 #endif
+#if TFC_CONV3_EXP & 64
+// timing builds only (tools/conv3_clock_probe.py): per workgroup (the first kConv3ClockWgs of a launch) the 100 MHz
+// clock at entry, behind the prologue's barrier, at the end of its first item's K loop, with that item's stores issued,
+// and with them acknowledged; [5] = the CU (XCC, SE, CU id) it ran on
+constexpr int kConv3ClockWgs = 16384;
+__device__ unsigned long long g_conv3_clocks[kConv3ClockWgs * 8];
+#define TFC_CONV3_CLOCK(slot)                                                                              \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < kConv3ClockWgs) g_conv3_clocks[blockIdx.x * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define TFC_CONV3_CLOCK(slot) do {} while (0)
+#endif
 // workgroup barrier that orders LDS traffic only (a __syncthreads also waits for the global loads in flight)
 #define TFC_LDS_BARRIER()                                                \
   do {                                                                   \
@@ -898,6 +911,15 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   const int W = gridDim.x, w = static_cast<int>(xcd_order(blockIdx.x, gridDim.x, c.xcd));
   const long long nitems = w < nblk ? ((nblk - w + W - 1) / W) * d.gcount : 0;
   if (nitems == 0) return;
+  TFC_CONV3_CLOCK(0);
+#if TFC_CONV3_EXP & 64
+  if (threadIdx.x == 0 && blockIdx.x < kConv3ClockWgs) {
+    unsigned int hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_conv3_clocks[blockIdx.x * 8 + 5] = (static_cast<unsigned long long>(xcc & 0xF) << 32) | hwid;
+  }
+#endif
 
   struct Item {                  // wave-uniform
     long long n;
@@ -1228,6 +1250,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   wstore(0);
   wfetch(wr, 1);                          // (the host takes items of >= 2 chunks only)
   TFC_LDS_BARRIER();
+  TFC_CONV3_CLOCK(1);
 
   bf16x8 af[2][TILES];
   u32x4 bq[2][MT];
@@ -1333,7 +1356,17 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       gchunk += NCH;
       ++pcb;
     }
+#if TFC_CONV3_EXP & 64
+    if (t_item == 0) TFC_CONV3_CLOCK(2);
+#endif
     epilogue(cur, gchunk & 1, wrn, af[0]);
+#if TFC_CONV3_EXP & 64
+    if (t_item == 0) {
+      TFC_CONV3_CLOCK(3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TFC_CONV3_CLOCK(4);
+    }
+#endif
     zero_acc();
     cur = nxt;
     xr = xrn;
@@ -1357,6 +1390,14 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
 // were packed four waves to a CU it was the other way round, 48.8 against 47.0: the third generation's workgroups hold
 // 152 KB of LDS and found even fewer CUs free of coder waves).  Read per call: tests compare the generations in one
 // process.
+#if TFC_CONV3_EXP & 64
+extern "C" int tfc_debug_conv3_clocks(unsigned long long* out, int wgs) {
+  if (wgs > kConv3ClockWgs) wgs = kConv3ClockWgs;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv3_clocks), sizeof(unsigned long long) * 8 * wgs) != hipSuccess) return -1;
+  return wgs;
+}
+#endif
+
 int conv3_gen() {
   const char* e = std::getenv("TFC_CONV_GEN");
   return e ? std::atoi(e) : 3;
