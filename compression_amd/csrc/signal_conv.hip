@@ -102,7 +102,23 @@ struct Conv3Geom {
   int pixels;              // PH * PW
   int gcount;              // column groups this launch covers ...
   int glist[kMaxGroups];   // ... and which
+  int ostage;              // byte offset in LDS of the epilogue's staging area (4 waves x 8 KB), see the kernel
+  int obias;               // ... and of the bias (Cout floats, parked by the prologue)
+  unsigned int bx_mul, bx_sh, by_mul, by_sh, gc_mul, gc_sh, pw_mul, pw_sh;   // fast_div by BXn, BYn, gcount, PW
 };
+
+// n / d for 0 <= n < 2^31 as a multiplication: mul = ceil(2^(31 + s) / d), s = ceil(log2 d), n / d = (n * mul) >> (31 + s)
+// exactly (mul * d - 2^(31 + s) < d <= 2^s: the error term is below 1 / d); mul = 0: d = 1.
+inline void fast_div_setup(unsigned int d, unsigned int* mul, unsigned int* sh) {
+  if (d <= 1) { *mul = 0; *sh = 0; return; }
+  unsigned int s = 0;
+  while ((1ull << s) < d) ++s;
+  *mul = static_cast<unsigned int>(((1ull << (31 + s)) + d - 1) / d);
+  *sh = s - 1;
+}
+__device__ inline unsigned int fast_div(unsigned int n, unsigned int mul, unsigned int sh) {
+  return mul ? __umulhi(n, mul) >> sh : n;
+}
 
 template <typename T> struct ConvTraits;
 template <> struct ConvTraits<__bf16> {
@@ -853,8 +869,10 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
 //     chunk (here CH K steps = CH taps of one channel block, CH | taps), A / B fragments double-buffered in
 //     registers, 2 pixel tiles x TILES column tiles per wave, 16-byte output stores.
 // NPG = 16-byte patch pieces per thread (granules / 256, rounded up).
-//   * persistent workgroups (one per CU): a workgroup takes every W-th block and, for each, the launch's groups; the
-//     requests for an item's first patch and weight chunks run under the previous item's last K steps;
+//   * one ITEM per workgroup: a block and one of the launch's column groups (round 6; before: a workgroup took a
+//     block's groups, or every W-th block, one after the other with the next item's first requests under the last K
+//     steps — per item the same time, tools/conv3_clock_probe.py: what the prologue saved the longer K loop and the
+//     bookkeeping between items took, and it kept ~90 registers of next-item state alive through the epilogue);
 //   * the K steps of a channel block are unrolled into ONE basic block (template NCH chunks x CH K steps): taps are
 //     compile-time indexes into a table of scalar offsets, and the staging of a chunk boundary sits between the MFMAs.
 // TFC_CONV3_EXP (build switch, timing experiments only — results are wrong): 1 no barriers, 2 no weight staging,
@@ -865,8 +883,8 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
 #endif
 #if TFC_CONV3_EXP & 64
 // timing builds only (tools/conv3_clock_probe.py): per workgroup (the first kConv3ClockWgs of a launch) the 100 MHz
-// clock at entry, behind the prologue's barrier, at the end of its first item's K loop, with that item's stores issued,
-// and with them acknowledged; [5] = the CU (XCC, SE, CU id) it ran on
+// clock at entry, behind the prologue's barrier, at the end of the K loop, with the stores issued, and with them
+// acknowledged; [5] = the CU (XCC, SE, CU id) it ran on
 constexpr int kConv3ClockWgs = 16384;
 __device__ unsigned long long g_conv3_clocks[kConv3ClockWgs * 8];
 #define TFC_CONV3_CLOCK(slot)                                                                              \
@@ -903,14 +921,9 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   const int cb = c.Cin / 16;
   unsigned char* wl = smem + 2 * PATCH_BYTES;
 
-  // ---- the workgroup's ITEMS: item t = (block w + (t / gcount) * W, group glist[t % gcount]) for workgroup w of W:
-  // persistent, so that the loads of an item's first patch and weight chunks fly under the previous item's last K
-  // steps and its output stores drain under the next item's first ones (a workgroup per block paid ~6 us of
-  // exposed prologue + epilogue per 25-50 us of K loop, with every CU in that phase at the same time) ----
-  const long long nblk = c.N * d.BYn * d.BXn;
-  const int W = gridDim.x, w = static_cast<int>(xcd_order(blockIdx.x, gridDim.x, c.xcd));
-  const long long nitems = w < nblk ? ((nblk - w + W - 1) / W) * d.gcount : 0;
-  if (nitems == 0) return;
+  // ---- the workgroup's ITEM: (block u / gcount, group glist[u % gcount]) for workgroup u in XCD order (the groups
+  // of a block, and neighbouring blocks, meet in one L2) ----
+  const unsigned int u = xcd_order(blockIdx.x, gridDim.x, c.xcd);
   TFC_CONV3_CLOCK(0);
 #if TFC_CONV3_EXP & 64
   if (threadIdx.x == 0 && blockIdx.x < kConv3ClockWgs) {
@@ -926,13 +939,16 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     int qx0, qy0, group;
     int uy0, uy1, ux0, ux1;
   };
-  auto item_at = [&](long long t) -> Item {
+  // (divisions as multiplications, fast_div: a 64-bit division is a ~150-instruction loop in front of the first request)
+  auto item_at = [&](unsigned int t) -> Item {
     Item it;
-    const long long blk = w + (t / d.gcount) * W;
-    it.group = d.glist[t % d.gcount];
-    it.qx0 = static_cast<int>(blk % d.BXn) * 32;
-    it.qy0 = static_cast<int>((blk / d.BXn) % d.BYn) * 8;
-    it.n = blk / (static_cast<long long>(d.BXn) * d.BYn);
+    const unsigned int blk = fast_div(t, d.gc_mul, d.gc_sh);
+    it.group = d.glist[t - blk * d.gcount];
+    const unsigned int row = fast_div(blk, d.bx_mul, d.bx_sh);          // n * BYn + by
+    const unsigned int img = fast_div(row, d.by_mul, d.by_sh);
+    it.qx0 = static_cast<int>(blk - row * d.BXn) * 32;
+    it.qy0 = static_cast<int>(row - img * d.BYn) * 8;
+    it.n = img;
     it.uy0 = c.ty0[it.group]; it.uy1 = c.ty1[it.group]; it.ux0 = c.tx0[it.group]; it.ux1 = c.tx1[it.group];
     return it;
   };
@@ -944,7 +960,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
 #pragma unroll
   for (int j = 0; j < NPG / 2; ++j) {
     const int q = j * 256 + tid;
-    const int py = q / d.PW, px = q - py * d.PW;
+    const int py = fast_div(q, d.pw_mul, d.pw_sh), px = q - py * d.PW;
     // (pixels past the patch: a granule behind it, inside the padded buffer, that nobody reads)
     pdst[j] = q < d.pixels ? static_cast<unsigned int>((((py << lg) + (px & (sd - 1))) * 2 * PWh + (px >> lg)) * 16)
                            : PATCH_BYTES - 16u * PWh - 16u;
@@ -953,7 +969,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
 #pragma unroll
     for (int j = 0; j < NPG / 2; ++j) {
       const int q = j * 256 + tid;
-      const int py = q / d.PW, px = q - py * d.PW;
+      const int py = fast_div(q, d.pw_mul, d.pw_sh), px = q - py * d.PW;
       const int iy = qy0 * sd - c.py0 + py, ix = qx0 * sd - c.px0 + px;
       const bool ok = (q < d.pixels) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(c.H)) &
                       (static_cast<unsigned int>(ix) < static_cast<unsigned int>(c.W));
@@ -982,7 +998,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   };
 
   // ---- weights: the packed A fragments of a group, chunk by chunk; the request runs two chunks ahead of the K loop
-  // and on into the next item's group (chunks past a group's end read as zeros) ----
+  // (chunks past the group's end are outside the buffer: zeros, no traffic) ----
   auto weight_rsrc = [&](const Item& it) -> __amdgpu_buffer_rsrc_t {
     return __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(static_cast<const unsigned char*>(packed)) +
@@ -1030,11 +1046,10 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   // {0..3} and + 8), so |y| goes into the gamma contraction straight from the accumulators: 4 TILES^2 MFMAs per wave
   // against the K loop's thousands.  gamma's A fragments (the prepared image, 72 KB at 192 channels) are staged in LDS
   // over the two weight buffers — from L2 a K step of them is ~0.7 us away and 0.1 us of MFMAs (measured: +50 % on the
-  // layer) — so the next item's first weight chunk, which the K loop had already parked there, is requested again
-  // behind the contraction (its second chunk stays in `stage`).  y is rounded to bfloat16 first: the same values the
+  // layer).  y is rounded to bfloat16 first: the same values the
   // unfused pair (convolution, then the GDN kernel on its output) works on, contracted in the same order ----
   constexpr int GDN_PIECES = (TILES * 2 * TILES * 64 * 16 + TILES * 32 * 4 + 4095) / 4096;      // 16-byte pieces per thread
-  auto gdn_stage = [&](int wbuf_next, __amdgpu_buffer_rsrc_t wnext, bf16x8 (&afirst)[TILES]) __attribute__((always_inline)) {
+  auto gdn_stage = [&]() __attribute__((always_inline)) {
     constexpr int KT = TILES, KS = 2 * TILES;
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(c.gdn_image), 0, KT * KS * 64 * 16 + KT * 32 * 4, 0x00020000);
@@ -1099,19 +1114,12 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the norm's beta out of the image, then the weight buffers go back to the K loop: the next item's first chunk again
+    // the norm's beta out of the image
     f32x4 bt[KT][4];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) bt[t][q] = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
-    TFC_LDS_BARRIER();                  // every wave is through with the image
-    u32x4 st0[STAGE];
-    {
-      const unsigned int v0 = tid * 16u;
-#pragma unroll
-      for (int i = 0; i < STAGE; ++i) st0[i] = __builtin_amdgcn_raw_buffer_load_b128(wnext, v0 + i * 4096u, 0, 0);
-    }
 #pragma unroll
     for (int p = 0; p < MT; ++p)
 #pragma unroll
@@ -1127,94 +1135,121 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
             acc[p][t][4 * q + r] = yv * (c.gdn == 2 ? n : __builtin_amdgcn_rcpf(n));
           }
         }
-    {
-      u32x4* dst = reinterpret_cast<u32x4*>(wl + wbuf_next * WBUF_BYTES) + tid;
-#pragma unroll
-      for (int i = 0; i < STAGE; ++i) dst[i * 256] = st0[i];
-    }
-    TFC_LDS_BARRIER();
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) afirst[t] = (reinterpret_cast<const bf16x8*>(wl + wbuf_next * WBUF_BYTES) + lane)[t * 64];
   };
-  auto epilogue = [&](const Item& it, int wbuf_next, __amdgpu_buffer_rsrc_t wnext, bf16x8 (&afirst)[TILES])
-                      __attribute__((always_inline)) {
-    const int colbase = it.group * TILES * 32;
-    const int qx = it.qx0 + l;
-    if constexpr (GDN) gdn_stage(wbuf_next, wnext, afirst);
-    if constexpr (OUTF32) {
-      static_assert(!GDN, "float32 output: no fused GDN");
-      float* const yf = reinterpret_cast<float*>(y);
+  auto epilogue = [&](const Item& it, const int pb_last) __attribute__((always_inline)) {
+    if constexpr (GDN) gdn_stage();
+    // Output through LDS, a wave for itself.  The accumulators of a lane are 4 (+ 4 of its partner half) consecutive
+    // channels of ONE pixel: stored straight from them, an instruction is 32 pixels x 32 bytes — 32 partial lines, ~50
+    // cycles each in the CU's store path, 9-10 us per item (tools/conv3_clock_probe.py).  Instead one 128-byte line per
+    // pixel at a time (bfloat16: two column tiles, float32: one) goes to the wave's 8 KB of the staging area as
+    // [pixel][8 granules], granule g at g ^ (pixel / 2 & 7) (16 lanes of a ds_write_b128 / ds_read_b128: all banks
+    // once), and leaves as 8 pixels x 128 bytes per instruction: whole lines.  The bias comes from LDS (parked there by
+    // the prologue, zeros without one): a global load here would wait, in vmcnt order, for every store issued before
+    // it.  Straight-line code: pixels outside the map get a buffer offset outside the image (the store is dropped).
+    static_assert(TILES % 2 == 0, "two column tiles per output line");
+    static_assert(!(GDN && OUTF32), "float32 output: no fused GDN");
+    // (d.ostage < 0: no room of its own — the patch buffer of the LAST channel block instead: every read of it was
+    // complete at the K loop's last barrier, the loop's last K step reads ahead into the other buffers only)
+    unsigned char* const ost = smem + (d.ostage >= 0 ? d.ostage : pb_last * static_cast<int>(PATCH_BYTES)) + wid * 8192;
+    const float* const bias_s = reinterpret_cast<const float*>(smem + d.obias);
+    const int phy = it.group / c.su, phx = it.group % c.su;       // a group = one output phase, all its Cout channels
+    constexpr int ROUNDS = OUTF32 ? TILES : TILES / 2;
+    constexpr int ESZ = OUTF32 ? 4 : 2;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char*>(y) + it.n * c.OH * c.OW * c.Cout * ESZ, 0, c.OH * c.OW * c.Cout * ESZ, 0x00020000);
+    auto wave_sync = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto slot = [&](int pix, int g) -> unsigned char* { return ost + pix * 128 + ((g ^ ((pix >> 1) & 7)) << 4); };
+    // where this lane's 8 read-back granules go: granule j = pixel 8 j + lane / 8 = row p = j / 4 of the wave's two,
+    // column 8 (j & 3) + lane / 8 — 16 bytes at 16 (lane & 7) of its line.  Per row a lane offset (outside the image
+    // for a row outside the map), the column step and the line of the round as the scalar offset
+    unsigned int yrow[MT];
+    const int qxl = it.qx0 + (lane >> 3);
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int col0 = colbase + 32 * t + 8 * q + 4 * h;       // four consecutive columns: channels of one phase
-          if (col0 >= c.cols) continue;
-          const int co = col0 % c.Cout, ph = col0 / c.Cout;
-          f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + co);
-#pragma unroll
-          for (int p = 0; p < MT; ++p) {
-            const int qy = it.qy0 + 2 * wid + p;
-            if (qy >= c.OHq || qx >= c.OWq) continue;
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = acc[p][t][4 * q + r] + b4[r];
-              if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
-            }
-            const int oy = qy * c.su + ph / c.su, ox = qx * c.su + ph % c.su;
-            *reinterpret_cast<f32x4*>(yf + ((it.n * c.OH + oy) * c.OW + ox) * c.Cout + co) = v;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      return;
+    for (int p = 0; p < MT; ++p) {
+      const int qy = it.qy0 + 2 * wid + p;
+      yrow[p] = qy < c.OHq ? static_cast<unsigned int>(((qy * c.su + phy) * c.OW + qxl * c.su + phx) * c.Cout * ESZ + 16 * (lane & 7))
+                           : 0x80000000u;
     }
+    const int xroom = c.OWq - qxl;                       // column 8 k of the lane is inside the map iff 8 k < xroom
+    const unsigned int xstep = static_cast<unsigned int>(8 * c.su * c.Cout * ESZ);
+    auto rounds = [&](auto relu_tag) __attribute__((always_inline)) {
+      constexpr bool RELU = decltype(relu_tag)::value;
+      auto bias4 = [&](int ch) -> f32x4 {
+        if constexpr (GDN) return f32x4{0.f, 0.f, 0.f, 0.f};        // (added before the contraction)
+        else return *reinterpret_cast<const f32x4*>(bias_s + ch + 4 * h);
+      };
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        if constexpr (OUTF32) {
+          const int t = rd;
 #pragma unroll
-      for (int qp = 0; qp < 2; ++qp) {
-        const int col0 = colbase + 32 * t + 16 * qp;
-        if (col0 >= c.cols) continue;
-        const int co = col0 % c.Cout;
-        f32x4 be = f32x4{0.f, 0.f, 0.f, 0.f}, bo = be;
-        if (bias && !GDN) {
-          be = *reinterpret_cast<const f32x4*>(bias + co + 4 * h);
-          if (col0 + 8 < c.cols) bo = *reinterpret_cast<const f32x4*>(bias + (col0 + 8) % c.Cout + 4 * h);
-        }
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = bias4(32 * t + 8 * q);
 #pragma unroll
-        for (int p = 0; p < MT; ++p) {
-          u32x4 o;
+            for (int p = 0; p < MT; ++p) {
+              f32x4 v;
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const f32x4& b4 = half ? bo : be;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = acc[p][t][4 * (2 * qp + half) + r] + b4[r];
-              if (c.activation == 1) v[r] = fmaxf(v[r], 0.f);
+              for (int r = 0; r < 4; ++r) {
+                v[r] = acc[p][t][4 * q + r] + b4[r];
+                if (RELU) v[r] = fmaxf(v[r], 0.f);
+              }
+              *reinterpret_cast<f32x4*>(slot(32 * p + l, 2 * q + h)) = v;
             }
-            o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
-            o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+            __builtin_amdgcn_sched_barrier(0);        // 8 channels at a time (registers)
           }
-          const auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
-          const auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
-          const int colh = col0 + 8 * h;
-          const int qy = it.qy0 + 2 * wid + p;
+        } else {
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            const int t = 2 * rd + t2;
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+              const f32x4 be = bias4(32 * t + 16 * qp), bo = bias4(32 * t + 16 * qp + 8);
+#pragma unroll
+              for (int p = 0; p < MT; ++p) {
+                u32x4 o;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                  const f32x4& b4 = half ? bo : be;      // channels 32 t + 16 qp + 8 half + 4 h + {0 .. 3}
+                  float v[4];
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[p][t][4 * (2 * qp + half) + r] + b4[r];
+                    if (RELU) v[r] = fmaxf(v[r], 0.f);
+                  }
+                  o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+                  o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+                }
+                // the halves trade their inner words: this lane then holds channels 32 t + 16 qp + 8 h + {0 .. 7}
+                const auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+                *reinterpret_cast<u32x4*>(slot(32 * p + l, 4 * t2 + 2 * qp + h)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+              }
+              __builtin_amdgcn_sched_barrier(0);      // 16 channels at a time (registers)
+            }
+          }
+        }
+        wave_sync();
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {          // a row's four granules at a time (registers)
+          u32x4 v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4*>(slot(32 * p + 8 * k + (lane >> 3), lane & 7));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
 #if TFC_CONV3_EXP & 32
-          if (qy >= c.OHq || qx >= c.OWq || colh >= c.cols || be[0] != 12345.f) continue;     // (no stores)
-#else
-          if (qy >= c.OHq || qx >= c.OWq || colh >= c.cols) continue;
+            if (v[k].x != 0x12345u) continue;     // (no stores)
 #endif
-          const int coh = colh % c.Cout, ph = colh / c.Cout;
-          const int oy = qy * c.su + ph / c.su, ox = qx * c.su + ph % c.su;
-          *reinterpret_cast<u32x4*>(y + ((it.n * c.OH + oy) * c.OW + ox) * c.Cout + coh) =
-              u32x4{s0[0], s1[0], s0[1], s1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(v[k], yr, 8 * k < xroom ? yrow[p] : 0x80000000u, 128 * rd + k * xstep, 0);
+          }
         }
+        wave_sync();
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    if (c.activation == 1) rounds(std::true_type{}); else rounds(std::false_type{});
   };
 
   // Schedule of a chunk c (CH K steps, weights in LDS buffer c & 1):
@@ -1228,27 +1263,31 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   //                before the barrier, so no K step ever waits for a read it has just issued behind a barrier
   // (no __syncthreads: its fence would also wait for the global prefetches in flight).
   constexpr int NT = CH * NCH;            // taps of a group = K steps of a channel block
-  Item cur = item_at(0);
-  Item nxt = item_at(nitems > 1 ? 1 : 0);
-  unsigned int poff[NPG / 2], poffn[NPG / 2];
+  // (the first requests go out before the rest of the bookkeeping: it runs under their latency)
+  const Item cur = item_at(u);
+  unsigned int poff[NPG / 2];
+  const __amdgpu_buffer_rsrc_t wr = weight_rsrc(cur);
+  wfetch(wr, 0);
   patch_offsets(cur.qx0, cur.qy0, poff);
-  patch_offsets(nxt.qx0, nxt.qy0, poffn);
-  __amdgpu_buffer_rsrc_t xr = image_rsrc(cur.n), xrn = image_rsrc(nxt.n);
-  __amdgpu_buffer_rsrc_t wr = weight_rsrc(cur), wrn = weight_rsrc(nxt);
+  const __amdgpu_buffer_rsrc_t xr = image_rsrc(cur.n);
+  pfetch(xr, poff, 0);
   // the taps' patch offsets (wave-uniform, one SGPR each: the K steps below are unrolled over a whole channel block)
-  unsigned int toff[NT], toffn0;
+  unsigned int toff[NT];
   auto tap_table = [&](const Item& it) __attribute__((always_inline)) {
-    const int wx = it.ux1 - it.ux0;
+    int uy = it.uy0, ux = it.ux0;           // tap k = (uy0 + k / wx, ux0 + k % wx), walked
 #pragma unroll
-    for (int k = 0; k < NT; ++k) toff[k] = tap_offset(it.uy0 + k / wx, it.ux0 + k % wx);
+    for (int k = 0; k < NT; ++k) {
+      toff[k] = tap_offset(uy, ux);
+      if (++ux == it.ux1) { ux = it.ux0; ++uy; }
+    }
   };
   tap_table(cur);
-  toffn0 = tap_offset(nxt.uy0, nxt.ux0);
-  pfetch(xr, poff, 0);
-  wfetch(wr, 0);
+  if (!GDN && tid < TILES * 8)   // the epilogue's bias, zeros without one (the fused GDN adds it before its contraction)
+    *reinterpret_cast<f32x4*>(smem + d.obias + tid * 16) =
+        bias ? *reinterpret_cast<const f32x4*>(bias + tid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   pstore(0);
   wstore(0);
-  wfetch(wr, 1);                          // (the host takes items of >= 2 chunks only)
+  wfetch(wr, 1);
   TFC_LDS_BARRIER();
   TFC_CONV3_CLOCK(1);
 
@@ -1274,9 +1313,9 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   //                  before the barrier: no K step waits for a read it has just issued behind a barrier
   // Fragment register sets alternate per K step; a block of an odd number of K steps ends with a copy so that every
   // block starts from set 0.
-  auto channel_block = [&](const int cbi, const int chunk0, const int total_chunks, const int wpar, const int pb)
+  auto channel_block = [&](const int cbi, const int chunk0, const int wpar, const int pb)
                            __attribute__((always_inline)) {
-    const bool more = cbi + 1 < cb;       // else: the next channel block is the next item's first
+    const bool more = cbi + 1 < cb;
     const unsigned char* pbase = smem + pb * PATCH_BYTES;
     const unsigned char* pnext = smem + (pb ^ 1) * PATCH_BYTES;
 #pragma unroll
@@ -1286,14 +1325,10 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       const bf16x8* anext = reinterpret_cast<const bf16x8*>(wl + (buf ^ 1) * WBUF_BYTES) + lane;
 #if !(TFC_CONV3_EXP & 2)
       wstore(buf ^ 1);
-      {
-        const int f = chunk0 + ch + 2;
-        const bool here = f < total_chunks;
-        wfetch(here ? wr : wrn, here ? f : f - total_chunks);
-      }
+      wfetch(wr, chunk0 + ch + 2);          // (past the last chunk: outside the buffer)
 #endif
 #if !(TFC_CONV3_EXP & 4)
-      if (ch == 0) pfetch(more ? xr : xrn, more ? poff : poffn, more ? cbi + 1 : 0);
+      if (ch == 0 && more) pfetch(xr, poff, cbi + 1);
 #endif
 #pragma unroll
       for (int kk = 0; kk < CH; ++kk) {
@@ -1306,7 +1341,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
           for (int p = 0; p < MT; ++p) bq[nxt_set][p] = *reinterpret_cast<const u32x4*>(pbase + lb[p] + toff[k + 1 < NT ? k + 1 : 0]);
         } else {
           const bool block_end = ch + 1 == NCH;
-          const unsigned int tn = !block_end ? toff[k + 1 < NT ? k + 1 : 0] : (more ? toff[0] : toffn0);
+          const unsigned int tn = toff[!block_end && k + 1 < NT ? k + 1 : 0];      // (the item's last step reads ahead for nothing)
 #pragma unroll
           for (int t = 0; t < TILES; ++t) af[nxt_set][t] = anext[t * 64];
 #pragma unroll
@@ -1334,7 +1369,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
         if (kk == CH - 2) {
 #if !(TFC_CONV3_EXP & 4)
           // requested in the block's first chunk, stored in its last: the gather has the whole block to arrive
-          if (ch + 1 == NCH) pstore(pb ^ 1);
+          if (ch + 1 == NCH && more) pstore(pb ^ 1);
 #endif
 #if !(TFC_CONV3_EXP & 1)
           TFC_LDS_BARRIER();
@@ -1349,37 +1384,18 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       for (int p = 0; p < MT; ++p) bq[0][p] = bq[1][p];
     }
   };
-  for (long long t_item = 0; t_item < nitems; ++t_item) {
-    const int total_chunks = cb * NCH;
-    for (int cbi = 0; cbi < cb; ++cbi) {
-      channel_block(cbi, cbi * NCH, total_chunks, gchunk & 1, pcb & 1);
-      gchunk += NCH;
-      ++pcb;
-    }
-#if TFC_CONV3_EXP & 64
-    if (t_item == 0) TFC_CONV3_CLOCK(2);
-#endif
-    epilogue(cur, gchunk & 1, wrn, af[0]);
-#if TFC_CONV3_EXP & 64
-    if (t_item == 0) {
-      TFC_CONV3_CLOCK(3);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      TFC_CONV3_CLOCK(4);
-    }
-#endif
-    zero_acc();
-    cur = nxt;
-    xr = xrn;
-    wr = wrn;
-#pragma unroll
-    for (int j = 0; j < NPG / 2; ++j) poff[j] = poffn[j];
-    nxt = item_at(t_item + 2 < nitems ? t_item + 2 : nitems - 1);
-    xrn = image_rsrc(nxt.n);
-    wrn = weight_rsrc(nxt);
-    patch_offsets(nxt.qx0, nxt.qy0, poffn);
-    tap_table(cur);
-    toffn0 = tap_offset(nxt.uy0, nxt.ux0);
+  for (int cbi = 0; cbi < cb; ++cbi) {
+    channel_block(cbi, cbi * NCH, gchunk & 1, pcb & 1);
+    gchunk += NCH;
+    ++pcb;
   }
+  TFC_CONV3_CLOCK(2);
+  epilogue(cur, (pcb - 1) & 1);
+#if TFC_CONV3_EXP & 64
+  TFC_CONV3_CLOCK(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TFC_CONV3_CLOCK(4);
+#endif
 }
 
 // Host side of the third-generation kernel: 0 = launched, -1 = not this shape (the caller goes on with the second
@@ -1460,6 +1476,9 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
   d.PWh = (d.PW + c.sd - 1) / c.sd;
   d.granules = PH * c.sd * 2 * d.PWh;
   d.pixels = PH * d.PW;
+  fast_div_setup(d.BXn, &d.bx_mul, &d.bx_sh);
+  fast_div_setup(d.BYn, &d.by_mul, &d.by_sh);
+  fast_div_setup(d.PW, &d.pw_mul, &d.pw_sh);
   const int npg = 2 * ((d.pixels + 255) / 256);        // 16-byte pieces per thread: two per patch pixel
   const int npgt = npg <= 4 ? 4 : 10;                  // the built loader widths
   const size_t patch_bytes = static_cast<size_t>(npgt) * 4096 + (npgt > 4 ? 2048 : 0);
@@ -1497,29 +1516,48 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     for (int grp = 0; grp < c.groups; ++grp)
       if (nts[grp] == ntv) d.glist[d.gcount++] = grp;
     if (!d.gcount) continue;
+    fast_div_setup(d.gcount, &d.gc_mul, &d.gc_sh);
     const int chv = ntv == 25 ? 5 : ntv == 4 ? 4 : 3;
     // (with GDN as the activation the two weight buffers and the room behind them also take gamma's fragment image)
     const size_t gdn_pieces = (static_cast<size_t>(c.tiles) * 2 * c.tiles * 64 * 16 + static_cast<size_t>(c.tiles) * 32 * 4 + 4095) / 4096;
     const size_t lds = 2 * patch_bytes + std::max(2 * static_cast<size_t>((chv * c.tiles * 64 + 255) / 256) * 4096,
                                                   c.gdn ? gdn_pieces * 4096 : size_t{0});
     if (lds > 160 * 1024) return -1;
-    // One workgroup per block (its items = the launch's groups).  (A grid of one workgroup per CU, each taking every
-    // W-th block, is the same speed alone on the chip but keeps the kernels of other steps in flight out of its CUs:
-    // C4 51.6 instead of 47.6 ms per step, profiles/r03_notes.md.)
-    const long long nblk = c.N * d.BXn * d.BYn;
+    // the epilogue's staging area (4 waves x 8 KB): behind the buffers where a CU's LDS has the room, else the patch
+    // buffer the item's last channel block has left (the kernel's comment)
+    size_t lds_all = lds;
+    d.obias = 0;
+    if (!c.gdn) {                       // (the fused GDN adds the bias before its contraction)
+      d.obias = static_cast<int>(lds_all);
+      lds_all += 1024;
+    }
+    if (lds_all + 32768 <= 160 * 1024) {
+      d.ostage = static_cast<int>(lds_all);
+      lds_all += 32768;
+    } else if (patch_bytes >= 32768) {
+      d.ostage = -1;
+    } else {
+      return -1;
+    }
+    if (lds_all > 160 * 1024) return -1;
+    // One workgroup per block and group.  (A grid of one workgroup per CU, each taking every W-th block, is the same
+    // speed alone on the chip — round 6, with the cheaper epilogue: 2 % / 6 % ahead on the stride-2 / transposed layer —
+    // but keeps the kernels of other steps in flight out of its CUs: C4 51.6 instead of 47.6 ms per step,
+    // profiles/r03_notes.md.)
+    const long long nblk = c.N * d.BXn * d.BYn * d.gcount;
     if (nblk >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
     const dim3 grid(static_cast<unsigned>(nblk));
 #define TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, G)                                                          \
     do {                                                                                                   \
       TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G>),  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
-      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_all)));     \
+      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G>), grid, dim3(256), lds_all, st, x, packed.p, bias, y, c, d); \
     } while (0)
 #define TFC_CONV3_LAUNCH_F(NT, CHV, NCHV, NPGV)                                                            \
     do {                                                                                                   \
       TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, false, true>),  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
-      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, false, true>), grid, dim3(256), lds, st, x, packed.p, bias, y, c, d); \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_all)));     \
+      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, false, true>), grid, dim3(256), lds_all, st, x, packed.p, bias, y, c, d); \
     } while (0)
 #define TFC_CONV3_LAUNCH(NT, CHV, NCHV, NPGV)                                                              \
     do {                                                                                                   \

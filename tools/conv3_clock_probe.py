@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where a conv3_bf16_kernel workgroup's time goes and how the workgroups of a launch line up in time: a library built
 with -DTFC_CONV3_EXP=64 (tools/conv3_variants.sh build 64) records per workgroup the 100 MHz clock at entry, behind the
-prologue's barrier, at the end of the first item's K loop, with its stores issued, with them acknowledged, and the CU.
+prologue's barrier, at the end of the K loop, with the stores issued, with them acknowledged, and the CU.
 Usage (GPU box): TFC_LIB_PATH=tools/probe_libs/libtfc_conv3_exp64.so python tools/conv3_clock_probe.py [batch] [down|up]"""
 import ctypes as C
 import os
@@ -43,6 +43,8 @@ wgs = min(blocks, 16384)
 buf = (C.c_ulonglong * (8 * wgs))()
 assert lib.tfc_debug_conv3_clocks(buf, wgs) == wgs
 t = np.frombuffer(buf, dtype=np.uint64).reshape(wgs, 8).astype(np.int64)
+t = t[t[:, 0] > 0]
+wgs = len(t)
 t0 = t[:, 0].min()
 us = (t[:, :5] - t0) / 100.0
 hw = t[:, 5]
@@ -53,10 +55,10 @@ q = lambda v: "%.1f / %.1f / %.1f / %.1f" % tuple(np.percentile(v, [10, 50, 90, 
 print(f"{wgs} workgroups on {len(np.unique(cuid))} CUs, {us[:, 4].max():.1f} us from the first entry to the last acknowledged store")
 print("per workgroup, us (10 / 50 / 90 / 99 %):")
 print("  prologue (entry -> first patch + weights in LDS)   ", q(pro))
-print("  K loop of the first item                            ", q(kloop))
+print("  K loop                                              ", q(kloop))
 print("  epilogue: stores issued                             ", q(issue))
 print("  stores acknowledged                                 ", q(drain))
-print("  whole first item                                    ", q(us[:, 4] - us[:, 0]))
+print("  whole workgroup                                     ", q(us[:, 4] - us[:, 0]))
 # the gap on a CU between a workgroup's end and the next one's entry
 gaps = []
 for c in np.unique(cuid):
