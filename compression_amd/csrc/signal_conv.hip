@@ -1114,27 +1114,23 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the norm's beta out of the image
-    f32x4 bt[KT][4];
+    // y * norm^-1 (GDN) or y * norm (IGDN); the norm's beta out of the image, 8 channels at a time (registers)
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bt[t][q] = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
+        const int s = 2 * t + (q >> 1), half = q & 1;
 #pragma unroll
-    for (int p = 0; p < MT; ++p)
-#pragma unroll
-      for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int s = 2 * t + (q >> 1), half = q & 1;
+        for (int p = 0; p < MT; ++p)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const unsigned int word = xb[p][s][2 * half + (r >> 1)];
             const float yv = __uint_as_float((r & 1) ? (word & 0xFFFF0000u) : (word << 16));
-            const float n = acc[p][t][4 * q + r] + bt[t][q][r];
+            const float n = acc[p][t][4 * q + r] + bt[r];
             acc[p][t][4 * q + r] = yv * (c.gdn == 2 ? n : __builtin_amdgcn_rcpf(n));
           }
-        }
+      }
   };
   auto epilogue = [&](const Item& it, const int pb_last) __attribute__((always_inline)) {
     if constexpr (GDN) gdn_stage();

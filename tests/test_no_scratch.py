@@ -29,9 +29,10 @@ def test_hot_kernels_do_not_spill():
     for key in HOT:
         hits = {n: r for n, r in table.items() if key in n}
         if key == "conv3_bf16_kernel":
-            # the variant with GDN as the activation (last template argument true) keeps the six-tile block's results in
-            # scratch between its GDN stage and its stores — once per 8 x 32 block, outside the K loop (checked below)
-            hits = {n: r for n, r in hits.items() if "ELb1EEEv" not in n}
+            # the variants with GDN as the activation (template argument GDN = true) park ~50 registers of the block's
+            # results in scratch across their GDN stage — once per 8 x 32 block, outside the K loop (tools/isa_blocks.py on a -S listing: none in the MFMA blocks; the
+            # stage one pixel row at a time, 48 registers less of y, made the allocator spill MORE: profiles/r06_notes.md)
+            hits = {n: r for n, r in hits.items() if "ELb1ELb0EEEv" not in n}
         assert hits, key
         spilled = {n: r["scratch"] for n, r in hits.items() if r["scratch"]}
         assert not spilled, spilled
