@@ -104,6 +104,7 @@ struct Conv3Geom {
   int glist[kMaxGroups];   // ... and which
   int ostage;              // byte offset in LDS of the epilogue's staging area (4 waves x 8 KB), see the kernel
   int obias;               // ... and of the bias (Cout floats, parked by the prologue)
+  int oimage;              // GDN as the activation: where gamma's fragment image lives in LDS
   unsigned int bx_mul, bx_sh, by_mul, by_sh, gc_mul, gc_sh, pw_mul, pw_sh;   // fast_div by BXn, BYn, gcount, PW
 };
 
@@ -1048,36 +1049,46 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   // over the two weight buffers — from L2 a K step of them is ~0.7 us away and 0.1 us of MFMAs (measured: +50 % on the
   // layer).  y is rounded to bfloat16 first: the same values the
   // unfused pair (convolution, then the GDN kernel on its output) works on, contracted in the same order ----
-  constexpr int GDN_PIECES = (TILES * 2 * TILES * 64 * 16 + TILES * 32 * 4 + 4095) / 4096;      // 16-byte pieces per thread
+  constexpr int GDN_IMAGE_BYTES = TILES * 2 * TILES * 64 * 16 + TILES * 32 * 4;                   // fragments, beta
+  constexpr int GDN_PIECES = (GDN_IMAGE_BYTES + 4095) / 4096;                                     // 16-byte pieces per thread
+  // GRES: the transposed layers' builds (small patch, short weight chunks) have the LDS to keep the image for the whole
+  // item — copied by the prologue beside the first patch and weight chunk, no barriers or copy in the stage: their items
+  // are 4-9 taps long (17-40 us of K loop), the copy + its two barriers were ~3 us of each
+  constexpr bool GRES = GDN && NPG == 4;
+  const __amdgpu_buffer_rsrc_t gimage_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(GDN ? c.gdn_image : nullptr), 0, GDN ? GDN_IMAGE_BYTES : 0, 0x00020000);
+  // y = convolution + bias as the bfloat16 tensor would hold it, packed (K step s of the contraction is xb[p][s] with the
+  // sign bits cleared); the epilogue multiplies it with the norm's power as it packs the output — the 192 results of a
+  // lane never exist at once (as a loop of their own they sat in registers beside y: 50 of them went to scratch, and
+  // the reloads, each waited for, were 13 us of every item, tools/conv3_clock_probe.py)
+  unsigned int xb[GDN ? MT : 1][GDN ? 2 * TILES : 1][4];      // (single words: four-register tuples of them made the allocator spill)
   auto gdn_stage = [&]() __attribute__((always_inline)) {
     constexpr int KT = TILES, KS = 2 * TILES;
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(c.gdn_image), 0, KT * KS * 64 * 16 + KT * 32 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(bias), 0, bias ? KT * 32 * 4 : 0, 0x00020000);      // (no bias: reads as zeros)
-    const unsigned int h16 = static_cast<unsigned int>(h) * 16u;
-    // the image -> LDS, in two rounds of requests (registers); pieces past its end read as zeros
-    TFC_LDS_BARRIER();                  // every wave is through with the weight buffers
+    unsigned char* const gl = smem + d.oimage;
+    const float* const bias_s = reinterpret_cast<const float*>(smem + d.obias);      // (zeros without a bias)
     constexpr int R0 = (GDN_PIECES + 1) / 2;
-    {
-      u32x4 g0[R0];
+    u32x4 g1[GRES ? 1 : GDN_PIECES - R0];
+    if constexpr (!GRES) {
+      // the image -> LDS over the weight buffers, in two rounds of requests (registers); only the image's bytes are
+      // written (the bias sits behind it)
+      TFC_LDS_BARRIER();                  // every wave is through with the weight buffers
+      {
+        u32x4 g0[R0];
 #pragma unroll
-      for (int i = 0; i < R0; ++i) g0[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, tid * 16u, i * 4096, 0);
+        for (int i = 0; i < R0; ++i) g0[i] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * 4096, 0);
 #pragma unroll
-      for (int i = 0; i < R0; ++i) *reinterpret_cast<u32x4*>(wl + i * 4096 + tid * 16) = g0[i];
+        for (int i = 0; i < R0; ++i) *reinterpret_cast<u32x4*>(gl + i * 4096 + tid * 16) = g0[i];
+      }
+#pragma unroll
+      for (int i = R0; i < GDN_PIECES; ++i) g1[i - R0] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * 4096, 0);
     }
-    u32x4 g1[GDN_PIECES - R0];
-#pragma unroll
-    for (int i = R0; i < GDN_PIECES; ++i) g1[i - R0] = __builtin_amdgcn_raw_buffer_load_b128(gr, tid * 16u, i * 4096, 0);
-    // (under the second round) y = convolution + bias as the bfloat16 tensor would hold it, packed: K step s of the
-    // contraction is xb[p][s] with the sign bits cleared, and the accumulators are free to take the norm
-    u32x4 xb[MT][KS];
+    // (under the second round of the image) y, packed; the accumulators are then free to take the norm
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int t0 = s >> 1, q0 = 2 * (s & 1);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(br, h16, (32 * t0 + 8 * (q0 + half)) * 4, 0));
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + 32 * t0 + 8 * (q0 + half) + 4 * h);
         const int e = 4 * (q0 + half);
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
@@ -1087,50 +1098,40 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
                                        f32x2{acc[p][t0][e + 2] + b4[2], acc[p][t0][e + 3] + b4[3]}, bf16x2));
         }
       }
-      __builtin_amdgcn_sched_barrier(0);      // (else every bias load of the loop is hoisted to its top)
+      __builtin_amdgcn_sched_barrier(0);      // (16 channels at a time: registers)
     }
+    if constexpr (!GRES) {
 #pragma unroll
-    for (int i = R0; i < GDN_PIECES; ++i) *reinterpret_cast<u32x4*>(wl + i * 4096 + tid * 16) = g1[i - R0];
+      for (int i = R0; i < GDN_PIECES; ++i)
+        if (i * 4096 + tid * 16 < GDN_IMAGE_BYTES) *reinterpret_cast<u32x4*>(gl + i * 4096 + tid * 16) = g1[i - R0];
+    }
     zero_acc();
-    TFC_LDS_BARRIER();
-    const bf16x8* const afr = reinterpret_cast<const bf16x8*>(wl) + lane;
-    const float* const beta_s = reinterpret_cast<const float*>(wl + KT * KS * 1024);
-    bf16x8 ga[2][KT];
+    if constexpr (!GRES) TFC_LDS_BARRIER();
+    TFC_CONV3_CLOCK(6);
+    const bf16x8* const afr = reinterpret_cast<const bf16x8*>(gl) + lane;
+    // gamma's fragments in the order they are used, (s, t) = (f / KT, f % KT), through a ring of four (three reads ahead:
+    // a fragment serves two MFMAs, 64 cycles, an LDS read is ~150 away) — a whole K step of them ahead took 48 registers
+    bf16x8 ring[4];
+    auto frag_at = [&](int f) -> bf16x8 { return afr[((f % KT) * KS + f / KT) * 64]; };
 #pragma unroll
-    for (int t = 0; t < KT; ++t) ga[0][t] = afr[(t * KS) * 64];
+    for (int f = 0; f < 3; ++f) ring[f] = frag_at(f);
+    bf16x8 bfrag[MT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int cs = s & 1, ns = cs ^ 1;
-      if (s + 1 < KS) {
-#pragma unroll
-        for (int t = 0; t < KT; ++t) ga[ns][t] = afr[(t * KS + s + 1) * 64];
-      }
-#pragma unroll
-      for (int p = 0; p < MT; ++p) {
-        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, xb[p][s] & 0x7FFF7FFFu);
-#pragma unroll
-        for (int t = 0; t < KT; ++t)
-          acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[cs][t], bfrag, acc[p][t], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // y * norm^-1 (GDN) or y * norm (IGDN); the norm's beta out of the image, 8 channels at a time (registers)
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta_s + 32 * t + 8 * q + 4 * h);
-        const int s = 2 * t + (q >> 1), half = q & 1;
+    for (int f = 0; f < KS * KT; ++f) {
+      const int s = f / KT, t = f % KT;
+      if (f + 3 < KS * KT) ring[(f + 3) & 3] = frag_at(f + 3);
+      if (t == 0) {
 #pragma unroll
         for (int p = 0; p < MT; ++p)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const unsigned int word = xb[p][s][2 * half + (r >> 1)];
-            const float yv = __uint_as_float((r & 1) ? (word & 0xFFFF0000u) : (word << 16));
-            const float n = acc[p][t][4 * q + r] + bt[r];
-            acc[p][t][4 * q + r] = yv * (c.gdn == 2 ? n : __builtin_amdgcn_rcpf(n));
-          }
+          bfrag[p] = __builtin_bit_cast(bf16x8, u32x4{xb[p][s][0] & 0x7FFF7FFFu, xb[p][s][1] & 0x7FFF7FFFu,
+                                                       xb[p][s][2] & 0x7FFF7FFFu, xb[p][s][3] & 0x7FFF7FFFu});
       }
+#pragma unroll
+      for (int p = 0; p < MT; ++p)
+        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f & 3], bfrag[p], acc[p][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    TFC_CONV3_CLOCK(7);
   };
   auto epilogue = [&](const Item& it, const int pb_last) __attribute__((always_inline)) {
     if constexpr (GDN) gdn_stage();
@@ -1146,8 +1147,12 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     static_assert(!(GDN && OUTF32), "float32 output: no fused GDN");
     // (d.ostage < 0: no room of its own — the patch buffer of the LAST channel block instead: every read of it was
     // complete at the K loop's last barrier, the loop's last K step reads ahead into the other buffers only)
-    unsigned char* const ost = smem + (d.ostage >= 0 ? d.ostage : pb_last * static_cast<int>(PATCH_BYTES)) + wid * 8192;
-    const float* const bias_s = reinterpret_cast<const float*>(smem + d.obias);
+    // (d.ostage == -2, builds with the GDN image resident: the weight buffers — what the last K step reads ahead from
+    // them is never used)
+    unsigned char* const ost = smem + (d.ostage >= 0 ? d.ostage : d.ostage == -2 ? static_cast<int>(2 * PATCH_BYTES)
+                                                                                 : pb_last * static_cast<int>(PATCH_BYTES)) + wid * 8192;
+    // what is added to an accumulator: the bias; with GDN the norm's beta (behind gamma's fragments in the image)
+    const float* const bias_s = reinterpret_cast<const float*>(smem + (GDN ? d.oimage + TILES * 2 * TILES * 1024 : d.obias));
     const int phy = it.group / c.su, phx = it.group % c.su;       // a group = one output phase, all its Cout channels
     constexpr int ROUNDS = OUTF32 ? TILES : TILES / 2;
     constexpr int ESZ = OUTF32 ? 4 : 2;
@@ -1172,11 +1177,20 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     }
     const int xroom = c.OWq - qxl;                       // column 8 k of the lane is inside the map iff 8 k < xroom
     const unsigned int xstep = static_cast<unsigned int>(8 * c.su * c.Cout * ESZ);
-    auto rounds = [&](auto relu_tag) __attribute__((always_inline)) {
-      constexpr bool RELU = decltype(relu_tag)::value;
-      auto bias4 = [&](int ch) -> f32x4 {
-        if constexpr (GDN) return f32x4{0.f, 0.f, 0.f, 0.f};        // (added before the contraction)
-        else return *reinterpret_cast<const f32x4*>(bias_s + ch + 4 * h);
+    auto rounds = [&](auto relu_tag, auto inv_tag) __attribute__((always_inline)) {
+      constexpr bool RELU = decltype(relu_tag)::value, INV = decltype(inv_tag)::value;
+      auto bias4 = [&](int ch) -> f32x4 { return *reinterpret_cast<const f32x4*>(bias_s + ch + 4 * h); };
+      // output value of accumulator element 4 q + r of (p, t): + bias; with GDN y / norm (IGDN: y * norm), norm = the
+      // accumulator + beta, y = the packed word of the same channel
+      auto elem = [&](int p, int t, int q, int r, const f32x4& b4) -> float {
+        float v = acc[p][t][4 * q + r] + b4[r];
+        if constexpr (GDN) {
+          const unsigned int word = xb[p][2 * t + (q >> 1)][2 * (q & 1) + (r >> 1)];
+          const float yv = __uint_as_float((r & 1) ? (word & 0xFFFF0000u) : (word << 16));
+          v = yv * (INV ? v : __builtin_amdgcn_rcpf(v));
+        }
+        if (RELU) v = fmaxf(v, 0.f);
+        return v;
       };
 #pragma unroll
       for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -1189,10 +1203,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
             for (int p = 0; p < MT; ++p) {
               f32x4 v;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                v[r] = acc[p][t][4 * q + r] + b4[r];
-                if (RELU) v[r] = fmaxf(v[r], 0.f);
-              }
+              for (int r = 0; r < 4; ++r) v[r] = elem(p, t, q, r, b4);
               *reinterpret_cast<f32x4*>(slot(32 * p + l, 2 * q + h)) = v;
             }
             __builtin_amdgcn_sched_barrier(0);        // 8 channels at a time (registers)
@@ -1212,10 +1223,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
                   const f32x4& b4 = half ? bo : be;      // channels 32 t + 16 qp + 8 half + 4 h + {0 .. 3}
                   float v[4];
 #pragma unroll
-                  for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[p][t][4 * (2 * qp + half) + r] + b4[r];
-                    if (RELU) v[r] = fmaxf(v[r], 0.f);
-                  }
+                  for (int r = 0; r < 4; ++r) v[r] = elem(p, t, 2 * qp + half, r, b4);
                   o[2 * half] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
                   o[2 * half + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
                 }
@@ -1245,7 +1253,13 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
         wave_sync();
       }
     };
-    if (c.activation == 1) rounds(std::true_type{}); else rounds(std::false_type{});
+    using T = std::true_type;
+    using F = std::false_type;
+    if (GDN && c.gdn == 2) {
+      if (c.activation == 1) rounds(T{}, T{}); else rounds(F{}, T{});
+    } else {
+      if (c.activation == 1) rounds(T{}, F{}); else rounds(F{}, F{});
+    }
   };
 
   // Schedule of a chunk c (CH K steps, weights in LDS buffer c & 1):
@@ -1278,9 +1292,17 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     }
   };
   tap_table(cur);
-  if (!GDN && tid < TILES * 8)   // the epilogue's bias, zeros without one (the fused GDN adds it before its contraction)
+  if (tid < TILES * 8)           // the bias, zeros without one (the epilogue's; with GDN: added before its contraction)
     *reinterpret_cast<f32x4*>(smem + d.obias + tid * 16) =
         bias ? *reinterpret_cast<const f32x4*>(bias + tid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (GRES) {          // gamma's fragment image, for the whole item
+    u32x4 gi[GDN_PIECES];
+#pragma unroll
+    for (int i = 0; i < GDN_PIECES; ++i) gi[i] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * 4096, 0);
+#pragma unroll
+    for (int i = 0; i < GDN_PIECES; ++i)
+      if (i * 4096 + tid * 16 < GDN_IMAGE_BYTES) *reinterpret_cast<u32x4*>(smem + d.oimage + i * 4096 + tid * 16) = gi[i];
+  }
   pstore(0);
   wstore(0);
   wfetch(wr, 1);
@@ -1514,22 +1536,30 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     if (!d.gcount) continue;
     fast_div_setup(d.gcount, &d.gc_mul, &d.gc_sh);
     const int chv = ntv == 25 ? 5 : ntv == 4 ? 4 : 3;
-    // (with GDN as the activation the two weight buffers and the room behind them also take gamma's fragment image)
-    const size_t gdn_pieces = (static_cast<size_t>(c.tiles) * 2 * c.tiles * 64 * 16 + static_cast<size_t>(c.tiles) * 32 * 4 + 4095) / 4096;
-    const size_t lds = 2 * patch_bytes + std::max(2 * static_cast<size_t>((chv * c.tiles * 64 + 255) / 256) * 4096,
-                                                  c.gdn ? gdn_pieces * 4096 : size_t{0});
-    if (lds > 160 * 1024) return -1;
-    // the epilogue's staging area (4 waves x 8 KB): behind the buffers where a CU's LDS has the room, else the patch
-    // buffer the item's last channel block has left (the kernel's comment)
-    size_t lds_all = lds;
-    d.obias = 0;
-    if (!c.gdn) {                       // (the fused GDN adds the bias before its contraction)
-      d.obias = static_cast<int>(lds_all);
-      lds_all += 1024;
+    // LDS: two patch buffers | two weight chunks | with GDN as the activation gamma's fragment image + beta — over the
+    // weight buffers (copied in by the GDN stage) in the big-patch builds, behind them for the whole item in the
+    // small-patch ones | the bias | the epilogue's staging area (4 waves x 8 KB) where there is room; else it takes the
+    // weight buffers (image resident: nothing of them is needed after the K loop) or the patch buffer the last channel
+    // block has left (the kernel's comments)
+    const size_t wbufs = 2 * static_cast<size_t>((chv * c.tiles * 64 + 255) / 256) * 4096;
+    const size_t image_bytes = static_cast<size_t>(c.tiles) * 2 * c.tiles * 64 * 16 + static_cast<size_t>(c.tiles) * 32 * 4;
+    const bool resident = c.gdn && npgt == 4;
+    size_t lds_all = 2 * patch_bytes;
+    d.oimage = static_cast<int>(lds_all);
+    if (resident) {
+      lds_all += wbufs;
+      d.oimage = static_cast<int>(lds_all);
+      lds_all += (image_bytes + 1023) / 1024 * 1024;
+    } else {
+      lds_all += std::max(wbufs, c.gdn ? image_bytes : size_t{0});
     }
+    d.obias = static_cast<int>(lds_all);
+    lds_all += 1024;
     if (lds_all + 32768 <= 160 * 1024) {
       d.ostage = static_cast<int>(lds_all);
       lds_all += 32768;
+    } else if (resident && wbufs >= 32768) {
+      d.ostage = -2;
     } else if (patch_bytes >= 32768) {
       d.ostage = -1;
     } else {

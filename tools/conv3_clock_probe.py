@@ -15,15 +15,24 @@ import compression_amd._lib as _L
 _L.LIB_PATH = os.environ.get("TFC_LIB_PATH", os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_libs",
                                                           "libtfc_conv3_exp64.so"))
 from compression_amd.layers import conv2d_down, conv2d_up
+from compression_amd.layers.functional import GDNPrepared, conv2d_gdn
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 which = sys.argv[2] if len(sys.argv) > 2 else "down"
 dev = "cuda"
 gen = torch.Generator().manual_seed(3)
+gdn = which.endswith("_gdn")            # down_gdn / up_gdn: GDN / IGDN as the layer's activation, inside the kernel
+which = which.split("_")[0]
 if which == "down":
     fn, (H, W) = conv2d_down, (256, 384)
 else:
     fn, (H, W) = conv2d_up, (128, 192)
+if gdn:
+    prepared = GDNPrepared(torch.rand(192) + 1.0, torch.rand(192, 192) * 0.01 + 0.1 * torch.eye(192), torch.bfloat16)
+    def fn(x, w, bias, stride, act, up=(which == "up")):
+        y, fused = conv2d_gdn(x, w, bias, stride, up, prepared, up)
+        assert fused
+        return y
 x = torch.randn(batch, H, W, 192, generator=gen).to(torch.bfloat16).to(dev)
 w = (torch.randn(5, 5, 192, 192, generator=gen) / (25 * 192) ** 0.5).to(dev)
 bias = torch.randn(192, generator=gen).to(dev)
@@ -57,6 +66,10 @@ print("per workgroup, us (10 / 50 / 90 / 99 %):")
 print("  prologue (entry -> first patch + weights in LDS)   ", q(pro))
 print("  K loop                                              ", q(kloop))
 print("  epilogue: stores issued                             ", q(issue))
+if gdn:
+    print("  of the epilogue, GDN stage: y packed (+ image copied) ", q((t[:, 6] - t[:, 2]) / 100.0))
+    print("                              contraction               ", q((t[:, 7] - t[:, 6]) / 100.0))
+    print("                              y / norm + stores issued  ", q((t[:, 3] - t[:, 7]) / 100.0))
 print("  stores acknowledged                                 ", q(drain))
 print("  whole workgroup                                     ", q(us[:, 4] - us[:, 0]))
 # the gap on a CU between a workgroup's end and the next one's entry
