@@ -904,11 +904,15 @@ __device__ unsigned long long g_conv3_clocks[kConv3ClockWgs * 8];
   } while (0)
 // OUTF32 (round 6): the float32 accumulators + bias leave as float32 (the float32 layers that run as six bfloat16
 // planes, conv_split_x_kernel).
-template <int TILES, int CH, int NCH, int NPG, bool GDN = false, bool OUTF32 = false>
+template <int TILES, int CH, int NCH, int NPG, int GDNK = 0, bool OUTF32 = false>
 __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, const void* packed,
                                                             const float* bias, __bf16* y, ConvGeom c,
                                                             Conv3Geom d) {
   extern __shared__ unsigned char smem[];          // 2 patches of PATCH_BYTES | 2 weight chunks of STAGE * 4 KB
+  // GDNK: 0 none, 1 GDN (y / norm), 2 IGDN (y * norm) as the activation.  A build each — ONE straight-line epilogue: with
+  // the two as branches of one build the compiler hoisted what they share (every y word split into its two floats, 192
+  // registers) in front of the branch, and the epilogue ran out of scratch (12 us per item instead of 5)
+  constexpr bool GDN = GDNK != 0;
   constexpr int MT = 2;
   constexpr int CHUNK_FRAGS = CH * TILES * 64;
   constexpr int STAGE = (CHUNK_FRAGS + 255) / 256;          // 16-byte pieces per thread and weight chunk
@@ -1255,8 +1259,8 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     };
     using T = std::true_type;
     using F = std::false_type;
-    if (GDN && c.gdn == 2) {
-      if (c.activation == 1) rounds(T{}, T{}); else rounds(F{}, T{});
+    if constexpr (GDN) {
+      rounds(F{}, std::integral_constant<bool, GDNK == 2>{});       // (no other activation beside the GDN)
     } else {
       if (c.activation == 1) rounds(T{}, F{}); else rounds(F{}, F{});
     }
@@ -1581,15 +1585,16 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     } while (0)
 #define TFC_CONV3_LAUNCH_F(NT, CHV, NCHV, NPGV)                                                            \
     do {                                                                                                   \
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, false, true>),  \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, 0, true>),  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_all)));     \
-      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, false, true>), grid, dim3(256), lds_all, st, x, packed.p, bias, y, c, d); \
+      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, 0, true>), grid, dim3(256), lds_all, st, x, packed.p, bias, y, c, d); \
     } while (0)
 #define TFC_CONV3_LAUNCH(NT, CHV, NCHV, NPGV)                                                              \
     do {                                                                                                   \
       if (c.out_f32) TFC_CONV3_LAUNCH_F(NT, CHV, NCHV, NPGV);                                              \
-      else if (c.gdn) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, true);                                       \
-      else TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, false);                                                 \
+      else if (c.gdn == 2) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 2);                                     \
+      else if (c.gdn) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 1);                                          \
+      else TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 0);                                                     \
     } while (0)
 #define TFC_CONV3_TAPS(NT)                                                   \
     do {                                                                     \

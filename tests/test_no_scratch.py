@@ -28,11 +28,6 @@ def test_hot_kernels_do_not_spill():
     assert len(table) > 100
     for key in HOT:
         hits = {n: r for n, r in table.items() if key in n}
-        if key == "conv3_bf16_kernel":
-            # the variants with GDN as the activation (template argument GDN = true) park ~50 registers of the block's
-            # results in scratch across their GDN stage — once per 8 x 32 block, outside the K loop (tools/isa_blocks.py on a -S listing: none in the MFMA blocks; the
-            # stage one pixel row at a time, 48 registers less of y, made the allocator spill MORE: profiles/r06_notes.md)
-            hits = {n: r for n, r in hits.items() if "ELb1ELb0EEEv" not in n}
         assert hits, key
         spilled = {n: r["scratch"] for n, r in hits.items() if r["scratch"]}
         assert not spilled, spilled
