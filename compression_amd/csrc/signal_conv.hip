@@ -888,6 +888,9 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
 // acknowledged; [5] = the CU (XCC, SE, CU id) it ran on
 constexpr int kConv3ClockWgs = 16384;
 __device__ unsigned long long g_conv3_clocks[kConv3ClockWgs * 8];
+// ... and core-clock cycles its first wave waited in the K loop: [ch] for the weight chunk stored at the start of chunk ch of
+// a channel block (ch < 5), [5] at the barriers, [6] the K loop, [7] for the LDS reads in front of the MFMAs of a K step
+__device__ unsigned long long g_conv3_waits[kConv3ClockWgs * 8];
 #define TFC_CONV3_CLOCK(slot)                                                                              \
   do {                                                                                                     \
     if (threadIdx.x == 0 && blockIdx.x < kConv3ClockWgs) g_conv3_clocks[blockIdx.x * 8 + (slot)] = wall_clock64(); \
@@ -1335,6 +1338,9 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   //                  before the barrier: no K step waits for a read it has just issued behind a barrier
   // Fragment register sets alternate per K step; a block of an odd number of K steps ends with a copy so that every
   // block starts from set 0.
+#if TFC_CONV3_EXP & 64
+  long long kwait[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   auto channel_block = [&](const int cbi, const int chunk0, const int wpar, const int pb)
                            __attribute__((always_inline)) {
     const bool more = cbi + 1 < cb;
@@ -1345,6 +1351,15 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       const int buf = wpar ^ (ch & 1);
       const bf16x8* abase = reinterpret_cast<const bf16x8*>(wl + buf * WBUF_BYTES) + lane;
       const bf16x8* anext = reinterpret_cast<const bf16x8*>(wl + (buf ^ 1) * WBUF_BYTES) + lane;
+#if TFC_CONV3_EXP & 64
+      {   // (timing build: the wait the store below begins with, by hand — the chunk requested a chunk ago; behind it in
+          // this wave's queue only the patch gather of chunk 0)
+        const long long w0 = clock64();
+        if (ch == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPG) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        kwait[ch < 5 ? ch : 4] += clock64() - w0;
+      }
+#endif
 #if !(TFC_CONV3_EXP & 2)
       wstore(buf ^ 1);
       wfetch(wr, chunk0 + ch + 2);          // (past the last chunk: outside the buffer)
@@ -1394,7 +1409,13 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
           if (ch + 1 == NCH && more) pstore(pb ^ 1);
 #endif
 #if !(TFC_CONV3_EXP & 1)
+#if TFC_CONV3_EXP & 64
+          const long long b0 = clock64();
           TFC_LDS_BARRIER();
+          kwait[5] += clock64() - b0;
+#else
+          TFC_LDS_BARRIER();
+#endif
 #endif
         }
       }
@@ -1406,11 +1427,19 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       for (int p = 0; p < MT; ++p) bq[0][p] = bq[1][p];
     }
   };
+#if TFC_CONV3_EXP & 64
+  const long long k0 = clock64();
+#endif
   for (int cbi = 0; cbi < cb; ++cbi) {
     channel_block(cbi, cbi * NCH, gchunk & 1, pcb & 1);
     gchunk += NCH;
     ++pcb;
   }
+#if TFC_CONV3_EXP & 64
+  kwait[6] = clock64() - k0;
+  if (threadIdx.x == 0 && blockIdx.x < kConv3ClockWgs)
+    for (int i = 0; i < 8; ++i) g_conv3_waits[blockIdx.x * 8 + i] = kwait[i];
+#endif
   TFC_CONV3_CLOCK(2);
   epilogue(cur, (pcb - 1) & 1);
 #if TFC_CONV3_EXP & 64
@@ -1432,6 +1461,11 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
 extern "C" int tfc_debug_conv3_clocks(unsigned long long* out, int wgs) {
   if (wgs > kConv3ClockWgs) wgs = kConv3ClockWgs;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv3_clocks), sizeof(unsigned long long) * 8 * wgs) != hipSuccess) return -1;
+  return wgs;
+}
+extern "C" int tfc_debug_conv3_waits(unsigned long long* out, int wgs) {
+  if (wgs > kConv3ClockWgs) wgs = kConv3ClockWgs;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv3_waits), sizeof(unsigned long long) * 8 * wgs) != hipSuccess) return -1;
   return wgs;
 }
 #endif

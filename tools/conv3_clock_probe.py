@@ -88,3 +88,15 @@ print("workgroups in their epilogue at a moment: mean %.1f, 90 %% %.0f, max %d o
     inepi.mean(), np.percentile(inepi, 90), inepi.max(), live.mean()))
 starts = np.sort(us[:, 0])
 print("entries in the first 400 us, 20-us bins:", np.histogram(starts, bins=np.arange(0, 420, 20))[0].tolist())
+
+# where the first wave waited inside the K loop (core-clock cycles, tfc_debug_conv3_waits)
+wb = (C.c_ulonglong * (8 * wgs))()
+if hasattr(lib, "tfc_debug_conv3_waits") and lib.tfc_debug_conv3_waits(wb, wgs) == wgs:
+    wv = np.frombuffer(wb, dtype=np.uint64).reshape(wgs, 8).astype(np.float64)
+    wv = wv[wv[:, 6] > 0]
+    tot = np.median(wv[:, 6])
+    print("K loop of the first wave: %.0f core-clock cycles (median) = %.2f GHz against the 100 MHz clock; of them waiting" % (
+        tot, tot / (np.median(kloop) * 1e3)))
+    for i in range(5):
+        print("   weight chunk stored at chunk %d of a channel block: %5.1f %%" % (i, 100 * np.median(wv[:, i]) / tot))
+    print("   barriers: %5.1f %%" % (100 * np.median(wv[:, 5]) / tot))
