@@ -891,11 +891,23 @@ __device__ unsigned long long g_conv3_clocks[kConv3ClockWgs * 8];
 // ... and core-clock cycles its first wave waited in the K loop: [ch] for the weight chunk stored at the start of chunk ch of
 // a channel block (ch < 5), [5] at the barriers, [6] the K loop, [7] for the LDS reads in front of the MFMAs of a K step
 __device__ unsigned long long g_conv3_waits[kConv3ClockWgs * 8];
+// (timing build: the cycles a staging instruction takes to ISSUE — the wave issues in order, the matrix pipe has nothing
+// to start while it does — summed per kind in kwait[kind]: 0 weight requests, 1 patch requests, 2 / 3 their LDS writes)
+#define TFC_CONV3_ISSUE(kind, stmt)                       \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    const long long i0__ = __builtin_readcyclecounter();  \
+    stmt;                                                 \
+    const long long i1__ = __builtin_readcyclecounter();  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    kwait[kind] += i1__ - i0__;                           \
+  } while (0)
 #define TFC_CONV3_CLOCK(slot)                                                                              \
   do {                                                                                                     \
     if (threadIdx.x == 0 && blockIdx.x < kConv3ClockWgs) g_conv3_clocks[blockIdx.x * 8 + (slot)] = wall_clock64(); \
   } while (0)
 #else
+#define TFC_CONV3_ISSUE(kind, stmt) stmt
 #define TFC_CONV3_CLOCK(slot) do {} while (0)
 #endif
 // workgroup barrier that orders LDS traffic only (a __syncthreads also waits for the global loads in flight)
@@ -916,12 +928,18 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   // the two as branches of one build the compiler hoisted what they share (every y word split into its two floats, 192
   // registers) in front of the branch, and the epilogue ran out of scratch (12 us per item instead of 5)
   constexpr bool GDN = GDNK != 0;
+  // MT = 2 pixel tiles per wave: four waves, one per SIMD.  (Round 6, measured and not kept: MT = 1 with EIGHT waves, two
+  // per SIMD at <= 220 registers, so that one wave's MFMAs run while the other issues its staging instructions — the
+  // stride-2 5x5 layer took 5.68 ms against 5.64: the second wave of a SIMD does not fill those gaps, profiles/r06_notes.md)
   constexpr int MT = 2;
+  constexpr int NTHR = 256;
+  constexpr unsigned int TPIECE = NTHR * 16u;                // bytes of one 16-byte piece per thread
   constexpr int CHUNK_FRAGS = CH * TILES * 64;
-  constexpr int STAGE = (CHUNK_FRAGS + 255) / 256;          // 16-byte pieces per thread and weight chunk
+  constexpr int STAGE = (CHUNK_FRAGS + NTHR - 1) / NTHR;    // 16-byte pieces per thread and weight chunk
   // a patch buffer: the granules + room for the (unread) granules of threads past the patch's last pixel
   constexpr unsigned int PATCH_BYTES = NPG * 4096u + (NPG > 4 ? 2048u : 0u);
-  constexpr unsigned int WBUF_BYTES = STAGE * 4096u;
+  constexpr int NPT = NPG;
+  constexpr unsigned int WBUF_BYTES = STAGE * TPIECE;
   static_assert(NPG % 2 == 0, "two pieces per patch pixel");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6, h = lane >> 5, l = lane & 31;
@@ -961,48 +979,47 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     return it;
   };
 
-  // ---- patch loader.  Piece 2j + hh of a thread = half hh (8 of the 16 channels) of patch pixel j * 256 + tid; the
-  // granule it goes to is the same for every item, the place it comes from (poff) is per item.  Buffer loads: a pixel
-  // outside the image has an offset outside the image's buffer and reads as zeros ----
-  unsigned int pdst[NPG / 2];             // granule of (pixel, h = 0); h = 1 at + PWh granules
+  // ---- patch loader.  Piece j of a thread = half tid & 1 (8 of the 16 channels) of patch pixel j * 128 + tid / 2: a
+  // lane PAIR reads the 32 contiguous bytes a pixel has of the channel block, an instruction 32 pixels.  (Round 6;
+  // before, a thread read both halves of pixel j * 256 + tid with two instructions of 64 pixels each: the CU's address
+  // unit takes ~4 cycles per 128-byte line an instruction touches — 250 cycles measured for one of those, 13 for a
+  // request of 1 KB contiguous, tools/conv3_clock_probe.py — and with 64 lines each the patch requests of the four waves
+  // kept it busy 390 cycles of a K step's 650: half the lines per instruction, the same number of instructions.)
+  // The granule a piece goes to is the same for every item, the place it comes from (poff) is per item.  Buffer loads:
+  // a pixel outside the image has an offset outside the image's buffer and reads as zeros ----
+  unsigned int pdst[NPT];                 // granule of (pixel, h = tid & 1)
 #pragma unroll
-  for (int j = 0; j < NPG / 2; ++j) {
-    const int q = j * 256 + tid;
+  for (int j = 0; j < NPT; ++j) {
+    const int q = j * (NTHR / 2) + (tid >> 1);
     const int py = fast_div(q, d.pw_mul, d.pw_sh), px = q - py * d.PW;
     // (pixels past the patch: a granule behind it, inside the padded buffer, that nobody reads)
-    pdst[j] = q < d.pixels ? static_cast<unsigned int>((((py << lg) + (px & (sd - 1))) * 2 * PWh + (px >> lg)) * 16)
+    pdst[j] = q < d.pixels ? static_cast<unsigned int>(((((py << lg) + (px & (sd - 1))) * 2 + (tid & 1)) * PWh + (px >> lg)) * 16)
                            : PATCH_BYTES - 16u * PWh - 16u;
   }
   auto patch_offsets = [&](int qx0, int qy0, unsigned int* poff) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NPG / 2; ++j) {
-      const int q = j * 256 + tid;
+    for (int j = 0; j < NPT; ++j) {
+      const int q = j * (NTHR / 2) + (tid >> 1);
       const int py = fast_div(q, d.pw_mul, d.pw_sh), px = q - py * d.PW;
       const int iy = qy0 * sd - c.py0 + py, ix = qx0 * sd - c.px0 + px;
       const bool ok = (q < d.pixels) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(c.H)) &
                       (static_cast<unsigned int>(ix) < static_cast<unsigned int>(c.W));
-      poff[j] = ok ? static_cast<unsigned int>((iy * c.W + ix) * c.Cin * 2) : 0x80000000u;
+      poff[j] = ok ? static_cast<unsigned int>((iy * c.W + ix) * c.Cin * 2 + 16 * (tid & 1)) : 0x80000000u;
     }
   };
   auto image_rsrc = [&](long long n) -> __amdgpu_buffer_rsrc_t {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x + n * c.H * c.W * c.Cin), 0,
                                              c.H * c.W * c.Cin * 2, 0x00020000);
   };
-  u32x4 pst[NPG];
+  u32x4 pst[NPT];
   auto pfetch = [&](__amdgpu_buffer_rsrc_t xr, const unsigned int* poff, int cbi) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NPG / 2; ++j) {
-      pst[2 * j] = __builtin_amdgcn_raw_buffer_load_b128(xr, poff[j], cbi * 32, 0);
-      pst[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b128(xr, poff[j] + 16u, cbi * 32, 0);
-    }
+    for (int j = 0; j < NPT; ++j) pst[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, poff[j], cbi * 32, 0);
   };
   auto pstore = [&](int buf) __attribute__((always_inline)) {
     unsigned char* dst = smem + buf * PATCH_BYTES;
 #pragma unroll
-    for (int j = 0; j < NPG / 2; ++j) {
-      *reinterpret_cast<u32x4*>(dst + pdst[j]) = pst[2 * j];
-      *reinterpret_cast<u32x4*>(dst + pdst[j] + 16u * PWh) = pst[2 * j + 1];
-    }
+    for (int j = 0; j < NPT; ++j) *reinterpret_cast<u32x4*>(dst + pdst[j]) = pst[j];
   };
 
   // ---- weights: the packed A fragments of a group, chunk by chunk; the request runs two chunks ahead of the K loop
@@ -1017,19 +1034,19 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   auto wfetch = [&](__amdgpu_buffer_rsrc_t r, int chunk) __attribute__((always_inline)) {
     const unsigned int v0 = static_cast<unsigned int>(chunk) * (CHUNK_FRAGS * 16u) + tid * 16u;
 #pragma unroll
-    for (int i = 0; i < STAGE; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(r, v0 + i * 4096u, 0, 0);
+    for (int i = 0; i < STAGE; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(r, v0 + i * TPIECE, 0, 0);
   };
   auto wstore = [&](int buf) __attribute__((always_inline)) {
     u32x4* dst = reinterpret_cast<u32x4*>(wl + buf * WBUF_BYTES) + tid;
 #pragma unroll
-    for (int i = 0; i < STAGE; ++i) dst[i * 256] = stage[i];
+    for (int i = 0; i < STAGE; ++i) dst[i * NTHR] = stage[i];
   };
 
   // ---- B: per-lane granule of (tile p, tap (0, 0)); a tap adds a wave-uniform offset ----
   unsigned int lb[MT];
 #pragma unroll
   for (int p = 0; p < MT; ++p) {
-    const int row = 2 * wid + p;
+    const int row = MT * wid + p;
     lb[p] = static_cast<unsigned int>(((row * sd * sd * 2 + h) * PWh + l) * 16);
   }
   auto tap_offset = [&](int uy, int ux) -> unsigned int {
@@ -1048,7 +1065,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   zero_acc();
 
   // ---- epilogue of an item: acc[p][t][4q + r] = column group_base + 32t + 8q + 4h + r of pixel
-  // (qy0 + 2 wid + p, qx0 + l); 16-byte stores as in the second generation (Cout % 8 == 0) ----
+  // (qy0 + MT wid + p, qx0 + l); 16-byte stores as in the second generation (Cout % 8 == 0) ----
   // ---- GDN / IGDN as the activation (GDN): the block's accumulators are all TILES * 32 channels of its pixels, in
   // the register layout the GDN kernel's B fragments have (gdn_common.h: K step s of a lane = channels 16 s + 4 h +
   // {0..3} and + 8), so |y| goes into the gamma contraction straight from the accumulators: 4 TILES^2 MFMAs per wave
@@ -1057,7 +1074,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   // layer).  y is rounded to bfloat16 first: the same values the
   // unfused pair (convolution, then the GDN kernel on its output) works on, contracted in the same order ----
   constexpr int GDN_IMAGE_BYTES = TILES * 2 * TILES * 64 * 16 + TILES * 32 * 4;                   // fragments, beta
-  constexpr int GDN_PIECES = (GDN_IMAGE_BYTES + 4095) / 4096;                                     // 16-byte pieces per thread
+  constexpr int GDN_PIECES = (GDN_IMAGE_BYTES + static_cast<int>(TPIECE) - 1) / static_cast<int>(TPIECE);   // 16-byte pieces per thread
   // GRES: the transposed layers' builds (small patch, short weight chunks) have the LDS to keep the image for the whole
   // item — copied by the prologue beside the first patch and weight chunk, no barriers or copy in the stage: their items
   // are 4-9 taps long (17-40 us of K loop), the copy + its two barriers were ~3 us of each
@@ -1082,12 +1099,12 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       {
         u32x4 g0[R0];
 #pragma unroll
-        for (int i = 0; i < R0; ++i) g0[i] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * 4096, 0);
+        for (int i = 0; i < R0; ++i) g0[i] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * TPIECE, 0);
 #pragma unroll
-        for (int i = 0; i < R0; ++i) *reinterpret_cast<u32x4*>(gl + i * 4096 + tid * 16) = g0[i];
+        for (int i = 0; i < R0; ++i) *reinterpret_cast<u32x4*>(gl + i * TPIECE + tid * 16) = g0[i];
       }
 #pragma unroll
-      for (int i = R0; i < GDN_PIECES; ++i) g1[i - R0] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * 4096, 0);
+      for (int i = R0; i < GDN_PIECES; ++i) g1[i - R0] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * TPIECE, 0);
     }
     // (under the second round of the image) y, packed; the accumulators are then free to take the norm
 #pragma unroll
@@ -1110,7 +1127,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     if constexpr (!GRES) {
 #pragma unroll
       for (int i = R0; i < GDN_PIECES; ++i)
-        if (i * 4096 + tid * 16 < GDN_IMAGE_BYTES) *reinterpret_cast<u32x4*>(gl + i * 4096 + tid * 16) = g1[i - R0];
+        if (i * TPIECE + tid * 16 < GDN_IMAGE_BYTES) *reinterpret_cast<u32x4*>(gl + i * TPIECE + tid * 16) = g1[i - R0];
     }
     zero_acc();
     if constexpr (!GRES) TFC_LDS_BARRIER();
@@ -1157,7 +1174,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     // (d.ostage == -2, builds with the GDN image resident: the weight buffers — what the last K step reads ahead from
     // them is never used)
     unsigned char* const ost = smem + (d.ostage >= 0 ? d.ostage : d.ostage == -2 ? static_cast<int>(2 * PATCH_BYTES)
-                                                                                 : pb_last * static_cast<int>(PATCH_BYTES)) + wid * 8192;
+                                                                                 : pb_last * static_cast<int>(PATCH_BYTES)) + wid * (MT * 4096);
     // what is added to an accumulator: the bias; with GDN the norm's beta (behind gamma's fragments in the image)
     const float* const bias_s = reinterpret_cast<const float*>(smem + (GDN ? d.oimage + TILES * 2 * TILES * 1024 : d.obias));
     const int phy = it.group / c.su, phx = it.group % c.su;       // a group = one output phase, all its Cout channels
@@ -1178,7 +1195,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     const int qxl = it.qx0 + (lane >> 3);
 #pragma unroll
     for (int p = 0; p < MT; ++p) {
-      const int qy = it.qy0 + 2 * wid + p;
+      const int qy = it.qy0 + MT * wid + p;
       yrow[p] = qy < c.OHq ? static_cast<unsigned int>(((qy * c.su + phy) * c.OW + qxl * c.su + phx) * c.Cout * ESZ + 16 * (lane & 7))
                            : 0x80000000u;
     }
@@ -1282,7 +1299,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   constexpr int NT = CH * NCH;            // taps of a group = K steps of a channel block
   // (the first requests go out before the rest of the bookkeeping: it runs under their latency)
   const Item cur = item_at(u);
-  unsigned int poff[NPG / 2];
+  unsigned int poff[NPT];
   const __amdgpu_buffer_rsrc_t wr = weight_rsrc(cur);
   wfetch(wr, 0);
   patch_offsets(cur.qx0, cur.qy0, poff);
@@ -1305,10 +1322,10 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   if constexpr (GRES) {          // gamma's fragment image, for the whole item
     u32x4 gi[GDN_PIECES];
 #pragma unroll
-    for (int i = 0; i < GDN_PIECES; ++i) gi[i] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * 4096, 0);
+    for (int i = 0; i < GDN_PIECES; ++i) gi[i] = __builtin_amdgcn_raw_buffer_load_b128(gimage_rsrc, tid * 16u, i * TPIECE, 0);
 #pragma unroll
     for (int i = 0; i < GDN_PIECES; ++i)
-      if (i * 4096 + tid * 16 < GDN_IMAGE_BYTES) *reinterpret_cast<u32x4*>(smem + d.oimage + i * 4096 + tid * 16) = gi[i];
+      if (i * TPIECE + tid * 16 < GDN_IMAGE_BYTES) *reinterpret_cast<u32x4*>(smem + d.oimage + i * TPIECE + tid * 16) = gi[i];
   }
   pstore(0);
   wstore(0);
@@ -1341,73 +1358,99 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
 #if TFC_CONV3_EXP & 64
   long long kwait[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+  // Where the staging sits inside a chunk (round 6).  A K step is TILES * MT SLOTS — one MFMA each (32 cycles of the
+  // matrix pipe), the order pinned slot by slot (sched_barrier) — and every staging instruction of the wave gets a slot of
+  // its own: as bursts in front of a chunk's first MFMA (eight 13-cycle ds_write_b128 with a vmcnt wait each, then 8 + NPG
+  // buffer loads; the compiler's schedule, sched_group_barrier masks or not) the matrix pipe stood still for them — one
+  // wave per SIMD, nobody else to issue — and the builds without them (TFC_CONV3_EXP 2 / 4) were 12 % / 18 % faster.
+  //   every K step     slots 0 .. MT - 1: the next K step's B fragments, MT .. MT + TILES - 1: its A fragments
+  //   K step 0         slots 0 .. STAGE - 1: weight chunk c + 1, registers -> LDS
+  //   K step 1         slots 0 .. STAGE - 1: weight chunk c + 2 requested
+  //   K step PFK of a block's first chunk: the next channel block's patch requested (none behind the last block: a
+  //                    descriptor of no records — no traffic, zeros — instead of a branch in the block)
+  //   K step CH - 2 of its last chunk: the patch registers -> the other patch buffer; then the LDS barrier
+  constexpr int SLOTS = TILES * MT;
+  constexpr int PFK = NCH == 1 ? 0 : (CH > 2 ? 2 : CH - 1);           // (one chunk per block: as early as possible)
+  constexpr int PF0 = NCH == 1 ? STAGE : 0;                           // its first slot
+  constexpr int PS0 = (CH - 2 == 0 || CH - 2 == 1) ? STAGE : 0;       // the patch store's first slot (behind the weights' of that step)
+  static_assert(CH >= 3, "K steps 0, 1 and CH - 2 of a chunk carry its staging");
+  // (piece pc of a kind whose first slot is F sits in slot (F + pc) % SLOTS: the 128-channel builds have 8 slots for 10
+  // patch pieces)
   auto channel_block = [&](const int cbi, const int chunk0, const int wpar, const int pb)
                            __attribute__((always_inline)) {
     const bool more = cbi + 1 < cb;
     const unsigned char* pbase = smem + pb * PATCH_BYTES;
     const unsigned char* pnext = smem + (pb ^ 1) * PATCH_BYTES;
+    unsigned char* const pdstb = smem + (pb ^ 1) * PATCH_BYTES;
+    const __amdgpu_buffer_rsrc_t xrn = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(x + cur.n * c.H * c.W * c.Cin), 0, more ? c.H * c.W * c.Cin * 2 : 0, 0x00020000);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int buf = wpar ^ (ch & 1);
       const bf16x8* abase = reinterpret_cast<const bf16x8*>(wl + buf * WBUF_BYTES) + lane;
       const bf16x8* anext = reinterpret_cast<const bf16x8*>(wl + (buf ^ 1) * WBUF_BYTES) + lane;
+      u32x4* const wdst = reinterpret_cast<u32x4*>(wl + (buf ^ 1) * WBUF_BYTES) + tid;
+      const unsigned int wv0 = static_cast<unsigned int>(chunk0 + ch + 2) * (CHUNK_FRAGS * 16u) + tid * 16u;   // (past the last chunk: outside the buffer)
 #if TFC_CONV3_EXP & 64
-      {   // (timing build: the wait the store below begins with, by hand — the chunk requested a chunk ago; behind it in
-          // this wave's queue only the patch gather of chunk 0)
+      {   // (timing build: the wait the first store below begins with, by hand)
         const long long w0 = clock64();
-        if (ch == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPG) : "memory");
+        if (NCH > 1 && ch == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");      // (behind it: the patch gather)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        kwait[ch < 5 ? ch : 4] += clock64() - w0;
+        kwait[4] += clock64() - w0;
       }
-#endif
-#if !(TFC_CONV3_EXP & 2)
-      wstore(buf ^ 1);
-      wfetch(wr, chunk0 + ch + 2);          // (past the last chunk: outside the buffer)
-#endif
-#if !(TFC_CONV3_EXP & 4)
-      if (ch == 0 && more) pfetch(xr, poff, cbi + 1);
 #endif
 #pragma unroll
       for (int kk = 0; kk < CH; ++kk) {
         const int k = ch * CH + kk;
         const int cur_set = k & 1, nxt_set = cur_set ^ 1;
-        if (kk + 1 < CH) {
+        const bool last_kk = kk + 1 == CH, block_end = ch + 1 == NCH;
+        // the next K step's tap (the item's last step reads ahead for nothing)
+        const unsigned int tn = last_kk ? toff[!block_end && k + 1 < NT ? k + 1 : 0] : toff[k + 1 < NT ? k + 1 : 0];
+        const unsigned char* const bsrc = last_kk && block_end ? pnext : pbase;
 #pragma unroll
-          for (int t = 0; t < TILES; ++t) af[nxt_set][t] = abase[((kk + 1) * TILES + t) * 64];
+        for (int i = 0; i < SLOTS; ++i) {
+          const int t = i / MT, p = i % MT;
+          acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              af[cur_set][t], __builtin_bit_cast(bf16x8, bq[cur_set][p]), acc[p][t], 0, 0, 0);
 #pragma unroll
-          for (int p = 0; p < MT; ++p) bq[nxt_set][p] = *reinterpret_cast<const u32x4*>(pbase + lb[p] + toff[k + 1 < NT ? k + 1 : 0]);
-        } else {
-          const bool block_end = ch + 1 == NCH;
-          const unsigned int tn = toff[!block_end && k + 1 < NT ? k + 1 : 0];      // (the item's last step reads ahead for nothing)
+          for (int f = 0; f < MT + TILES; ++f) {          // fragment f of the next K step: B first, in slot f % SLOTS
+            if (f % SLOTS != i) continue;
+            if (f < MT) bq[nxt_set][f] = *reinterpret_cast<const u32x4*>(bsrc + lb[f] + tn);
+            else af[nxt_set][f - MT] = last_kk ? anext[(f - MT) * 64] : abase[((kk + 1) * TILES + (f - MT)) * 64];
+          }
+#if !(TFC_CONV3_EXP & 2)
+          if (kk == 0) {
 #pragma unroll
-          for (int t = 0; t < TILES; ++t) af[nxt_set][t] = anext[t * 64];
+            for (int pc = 0; pc < STAGE; ++pc)
+              if (pc % SLOTS == i) TFC_CONV3_ISSUE(2, wdst[pc * NTHR] = stage[pc]);
+          }
+          if (kk == 1) {
 #pragma unroll
-          for (int p = 0; p < MT; ++p)
-            bq[nxt_set][p] = *reinterpret_cast<const u32x4*>((block_end ? pnext : pbase) + lb[p] + tn);
-        }
-#pragma unroll
-        for (int t = 0; t < TILES; ++t)
-#pragma unroll
-          for (int p = 0; p < MT; ++p)
-            acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                af[cur_set][t], __builtin_bit_cast(bf16x8, bq[cur_set][p]), acc[p][t], 0, 0, 0);
-#if TFC_CONV_INTERLEAVE
-#pragma unroll
-        for (int i = 0; i < TILES * MT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
-          if (i < TILES + MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one A / B fragment read
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        // an LDS write of the staging
-          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                        // global loads of the prefetches
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                        // VALU
-          __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                        // SALU
-        }
+            for (int pc = 0; pc < STAGE; ++pc)
+              if (pc % SLOTS == i) TFC_CONV3_ISSUE(0, stage[pc] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv0 + pc * TPIECE, 0, 0));
+          }
 #endif
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk == CH - 2) {
 #if !(TFC_CONV3_EXP & 4)
+          if (ch == 0 && kk == PFK) {
+#pragma unroll
+            for (int pc = 0; pc < NPT; ++pc)
+              if ((PF0 + pc) % SLOTS == i)
+                TFC_CONV3_ISSUE(1, pst[pc] = __builtin_amdgcn_raw_buffer_load_b128(xrn, poff[pc], (cbi + 1) * 32, 0));
+          }
           // requested in the block's first chunk, stored in its last: the gather has the whole block to arrive
-          if (ch + 1 == NCH && more) pstore(pb ^ 1);
+          if (block_end && kk == CH - 2) {
+#pragma unroll
+            for (int pc = 0; pc < NPT; ++pc)
+              if ((PS0 + pc) % SLOTS == i)
+                TFC_CONV3_ISSUE(3, *reinterpret_cast<u32x4*>(pdstb + pdst[pc]) = pst[pc]);
+          }
 #endif
+#if TFC_CONV3_EXP & 64
+          if (i == SLOTS - 1) TFC_CONV3_ISSUE(7, (void)0);        // (calibration: the pair of clock reads by itself)
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kk == CH - 2) {
 #if !(TFC_CONV3_EXP & 1)
 #if TFC_CONV3_EXP & 64
           const long long b0 = clock64();
@@ -1611,24 +1654,18 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     const long long nblk = c.N * d.BXn * d.BYn * d.gcount;
     if (nblk >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
     const dim3 grid(static_cast<unsigned>(nblk));
-#define TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, G)                                                          \
+#define TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, G, F32)                                                    \
     do {                                                                                                   \
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G>),  \
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G, F32>),  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_all)));     \
-      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G>), grid, dim3(256), lds_all, st, x, packed.p, bias, y, c, d); \
-    } while (0)
-#define TFC_CONV3_LAUNCH_F(NT, CHV, NCHV, NPGV)                                                            \
-    do {                                                                                                   \
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<NT, CHV, NCHV, NPGV, 0, true>),  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_all)));     \
-      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, 0, true>), grid, dim3(256), lds_all, st, x, packed.p, bias, y, c, d); \
+      hipLaunchKernelGGL((conv3_bf16_kernel<NT, CHV, NCHV, NPGV, G, F32>), grid, dim3(256), lds_all, st, x, packed.p, bias, y, c, d); \
     } while (0)
 #define TFC_CONV3_LAUNCH(NT, CHV, NCHV, NPGV)                                                              \
     do {                                                                                                   \
-      if (c.out_f32) TFC_CONV3_LAUNCH_F(NT, CHV, NCHV, NPGV);                                              \
-      else if (c.gdn == 2) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 2);                                     \
-      else if (c.gdn) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 1);                                          \
-      else TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 0);                                                     \
+      if (c.out_f32) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 0, true);                                     \
+      else if (c.gdn == 2) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 2, false);                              \
+      else if (c.gdn) TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 1, false);                                   \
+      else TFC_CONV3_LAUNCH_G(NT, CHV, NCHV, NPGV, 0, false);                                              \
     } while (0)
 #define TFC_CONV3_TAPS(NT)                                                   \
     do {                                                                     \
@@ -1640,7 +1677,6 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     if (c.tiles == 6) TFC_CONV3_TAPS(6); else TFC_CONV3_TAPS(4);
 #undef TFC_CONV3_TAPS
 #undef TFC_CONV3_LAUNCH
-#undef TFC_CONV3_LAUNCH_F
 #undef TFC_CONV3_LAUNCH_G
   }
   TFC_HIP(hipGetLastError());

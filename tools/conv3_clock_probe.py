@@ -90,6 +90,7 @@ starts = np.sort(us[:, 0])
 print("entries in the first 400 us, 20-us bins:", np.histogram(starts, bins=np.arange(0, 420, 20))[0].tolist())
 
 # where the first wave waited inside the K loop (core-clock cycles, tfc_debug_conv3_waits)
+ksteps = 12 * (25 if which == "down" else 4)      # K steps of an item (the up layer: of its last launch, the 4-tap phase)
 wb = (C.c_ulonglong * (8 * wgs))()
 if hasattr(lib, "tfc_debug_conv3_waits") and lib.tfc_debug_conv3_waits(wb, wgs) == wgs:
     wv = np.frombuffer(wb, dtype=np.uint64).reshape(wgs, 8).astype(np.float64)
@@ -97,6 +98,12 @@ if hasattr(lib, "tfc_debug_conv3_waits") and lib.tfc_debug_conv3_waits(wb, wgs) 
     tot = np.median(wv[:, 6])
     print("K loop of the first wave: %.0f core-clock cycles (median) = %.2f GHz against the 100 MHz clock; of them waiting" % (
         tot, tot / (np.median(kloop) * 1e3)))
-    for i in range(5):
-        print("   weight chunk stored at chunk %d of a channel block: %5.1f %%" % (i, 100 * np.median(wv[:, i]) / tot))
+    # per instruction: weight chunks of STAGE pieces (8 at 192 channels x 5 taps), patches of NPG pieces
+    per_step = np.median(wv[:, 7]) / max(1, ksteps)
+    print("   a pair of clock reads by itself: %.0f cycles" % per_step)
+    for i, name in enumerate(("weight requests (buffer_load_dwordx4, 1 KB contiguous)", "patch requests (buffer_load_dwordx4, 64 lanes x 16 B gathered)",
+                              "weight ds_write_b128", "patch ds_write_b128")):
+        print("   issuing the %s: %5.1f %% of the K loop" % (name, 100 * np.median(wv[:, i]) / tot))
+    print("   waiting at a chunk's start for its weights: %5.1f %%" % (100 * np.median(wv[:, 4]) / tot))
     print("   barriers: %5.1f %%" % (100 * np.median(wv[:, 5]) / tot))
+    print("   raw medians (cycles):", [int(np.median(wv[:, i])) for i in range(8)])
