@@ -372,8 +372,14 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
 
   // Software pipeline: the next stage's global loads are issued into registers before the MFMAs
   // of the current one and written to LDS after them.
-  //   bf16: chunk = 8 channels of one pixel, consecutive lanes = consecutive pixels; thread owns
-  //         chunks tid + 256 k (k < KT): pixel tid & 63, channel group (tid >> 6) + 4 k.
+  //   bf16: chunk = 8 channels (16 bytes) of one pixel.  A QUAD of lanes holds two neighbouring channel groups of two
+  //         neighbouring pixels — lane r of quad qd = tid >> 2: pixel 2 (qd & 31) + (r >> 1), channel group
+  //         2 ((qd >> 5) + 2 k) + (r & 1) in round k < KT — so that a lane PAIR reads 32 contiguous bytes and a load
+  //         instruction touches 32 lines, and the pixel pair whose values share a 4-byte word of the transposed image
+  //         is two lanes apart (DPP quad_perm).  (Round 6.  Before: consecutive lanes = consecutive pixels of one
+  //         channel group, 64 lines per instruction; the CU's address unit takes ~4 cycles per line an instruction
+  //         touches — measured in the convolution kernel, profiles/r06_notes.md: 83.8 -> 77.0 us for the pass on
+  //         [262144, 192].  Two stages requested ahead instead of one: 78.2, as in round 5 — not the loads' latency.)
   //   f32:  chunk = 4 channels of one pixel, channel group fastest (coalesced, conflict-free).
   constexpr int NCH = BF ? KT : 2 * KT;
   u32x4 xq[NCH], tq[NCH];
@@ -382,8 +388,8 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int c = tid + 256 * k;
-      const int px = BF ? (c % PG_PIX) : (c / (C / 4));
-      const int off = BF ? 8 * (c / PG_PIX) : 4 * (c % (C / 4));
+      const int px = BF ? 2 * ((tid >> 2) & 31) + ((tid >> 1) & 1) : (c / (C / 4));
+      const int off = BF ? 8 * (2 * ((tid >> 7) + 2 * k) + (tid & 1)) : 4 * (c % (C / 4));
       xq[k] = u32x4{0, 0, 0, 0};
       tq[k] = u32x4{0, 0, 0, 0};
       if (p0 + px < p.pixels) {
@@ -400,7 +406,7 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
     for (int k = 0; k < NCH; ++k) {
       const int c = tid + 256 * k;
       if (BF) {
-        const int px = c % PG_PIX, cg = c / PG_PIX;
+        const int px = 2 * ((tid >> 2) & 31) + ((tid >> 1) & 1), cg = 2 * ((tid >> 7) + 2 * k) + (tid & 1);
         u32x4 uv = xq[k];
         if (plain) {
           uv &= 0x7FFF7FFFu;
@@ -419,8 +425,8 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
         auto pair_store = [&](const u32x4& v, unsigned short* base) {
           const unsigned int send0 = odd ? v[0] : v[2], send1 = odd ? v[1] : v[3];
           const unsigned int keep0 = odd ? v[2] : v[0], keep1 = odd ? v[3] : v[1];
-          unsigned int recv0 = __builtin_amdgcn_update_dpp(0u, send0, 0xB1, 0xF, 0xF, false);
-          unsigned int recv1 = __builtin_amdgcn_update_dpp(0u, send1, 0xB1, 0xF, 0xF, false);
+          unsigned int recv0 = __builtin_amdgcn_update_dpp(0u, send0, 0x4E, 0xF, 0xF, false);      // quad_perm [2, 3, 0, 1]
+          unsigned int recv1 = __builtin_amdgcn_update_dpp(0u, send1, 0x4E, 0xF, 0xF, false);
           asm volatile("" : "+v"(recv0), "+v"(recv1));
           const unsigned int e0 = odd ? recv0 : keep0, o0 = odd ? keep0 : recv0;
           const unsigned int e1 = odd ? recv1 : keep1, o1 = odd ? keep1 : recv1;

@@ -87,7 +87,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
     }
   };
 
-  // wide tensors: 16-byte chunks held in registers one stage ahead
+  // wide tensors: 16-byte chunks held in registers one stage ahead.  bf16: a QUAD of lanes holds two neighbouring channel
+  // groups of two neighbouring pixels (lane r of quad tid >> 2: pixel quad_px, channel group quad_cg(k) in round k), so
+  // that a lane pair reads 32 contiguous bytes — 32 lines per load instruction instead of the 64 that consecutive
+  // lanes = consecutive pixels touch (the CU's address unit takes ~4 cycles per line: gdn_backward.hip, profiles/r06_notes.md)
+  // — and the pixel pair that shares a word of the transposed image is two lanes apart.
+  const int quad_px = 2 * ((tid >> 2) & 31) + ((tid >> 1) & 1);
+  auto quad_cg = [&](int k) -> int { return 2 * ((tid >> 7) + 2 * k) + (tid & 1); };
   constexpr int NA = BF ? KTA : 2 * KTA, NB = BF ? KTB : 2 * KTB;
   u32x4 aq[NA], bq[NB];
   auto fetch = [&](long long st) {
@@ -96,8 +102,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
         const int c = tid + 256 * k;
-        const int px = BF ? (c % WG_PIX) : (c / (RA / 4));
-        const int off = BF ? 8 * (c / WG_PIX) : 4 * (c % (RA / 4));
+        const int px = BF ? quad_px : (c / (RA / 4));
+        const int off = BF ? 8 * quad_cg(k) : 4 * (c % (RA / 4));
         long long ra, rb;
         rows(m0 + px, &ra, &rb);
         aq[k] = ra >= 0 ? *reinterpret_cast<const u32x4*>(A + ra * g.CA + off) : u32x4{0, 0, 0, 0};
@@ -107,8 +113,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const int c = tid + 256 * k;
-        const int px = BF ? (c % WG_PIX) : (c / (RB / 4));
-        const int off = BF ? 8 * (c / WG_PIX) : 4 * (c % (RB / 4));
+        const int px = BF ? quad_px : (c / (RB / 4));
+        const int off = BF ? 8 * quad_cg(k) : 4 * (c % (RB / 4));
         long long ra, rb;
         rows(m0 + px, &ra, &rb);
         bq[k] = rb >= 0 ? *reinterpret_cast<const u32x4*>(B + rb * g.CB + off) : u32x4{0, 0, 0, 0};
@@ -120,8 +126,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
     const bool odd = px & 1;
     const unsigned int send0 = odd ? v[0] : v[2], send1 = odd ? v[1] : v[3];
     const unsigned int keep0 = odd ? v[2] : v[0], keep1 = odd ? v[3] : v[1];
-    unsigned int recv0 = __builtin_amdgcn_update_dpp(0u, send0, 0xB1, 0xF, 0xF, false);
-    unsigned int recv1 = __builtin_amdgcn_update_dpp(0u, send1, 0xB1, 0xF, 0xF, false);
+    unsigned int recv0 = __builtin_amdgcn_update_dpp(0u, send0, 0x4E, 0xF, 0xF, false);      // quad_perm [2, 3, 0, 1]
+    unsigned int recv1 = __builtin_amdgcn_update_dpp(0u, send1, 0x4E, 0xF, 0xF, false);
     asm volatile("" : "+v"(recv0), "+v"(recv1));
     const unsigned int e0 = odd ? recv0 : keep0, o0 = odd ? keep0 : recv0;
     const unsigned int e1 = odd ? recv1 : keep1, o1 = odd ? keep1 : recv1;
@@ -155,7 +161,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
         const int c = tid + 256 * k;
-        if (BF) pair_store(aq[k], aT, c % WG_PIX, c / WG_PIX);
+        if (BF) pair_store(aq[k], aT, quad_px, quad_cg(k));
         else *reinterpret_cast<u32x4*>(as + (c / (RA / 4)) * RA + 4 * (c % (RA / 4))) = aq[k];
       }
     }
@@ -165,7 +171,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const int c = tid + 256 * k;
-        if (BF) pair_store(bq[k], bT, c % WG_PIX, c / WG_PIX);
+        if (BF) pair_store(bq[k], bT, quad_px, quad_cg(k));
         else *reinterpret_cast<u32x4*>(bs + (c / (RB / 4)) * RB + 4 * (c % (RB / 4))) = bq[k];
       }
     }
