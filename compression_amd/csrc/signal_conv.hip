@@ -941,8 +941,21 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   constexpr int NPT = NPG;
   constexpr unsigned int WBUF_BYTES = STAGE * TPIECE;
   static_assert(NPG % 2 == 0, "two pieces per patch pixel");
+  // WDMA (round 6): the weight chunks travel global -> LDS without passing the wave's registers (buffer_load ... lds: a
+  // wave's piece is 1 KB contiguous on both sides; no ds_write_b128, 37 cycles of issue each, and 32 registers less).
+  // Short chunks (3 / 4 K steps): chunk c + 2 is requested in the LAST K step of chunk c — behind the barrier that ended the
+  // reads of chunk c's own buffer, which it goes to — and has to have landed at chunk c + 1's barrier: CH K steps.  The
+  // 5-K-step chunks: chunk c + 1 in the FIRST K step of chunk c (CH - 1 K steps; measured against the last K step of the chunk
+  // before on the stride-2 5x5 layer: 5.11 / 5.18 ms, through registers 5.22; the transposed layer's three launches 5.68
+  // against 5.75).  TFC_CONV3_WDMA = 0: through registers (requested a chunk earlier).
+#ifndef TFC_CONV3_WDMA
+#define TFC_CONV3_WDMA 1
+#endif
+  constexpr bool WDMA = TFC_CONV3_WDMA != 0;
+  constexpr bool WEARLY = CH == 5;            // (see above) request in K step 0 of the chunk before, else K step CH - 1 of two before
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6, h = lane >> 5, l = lane & 31;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wid);
   const int lg = d.lg, sd = 1 << lg, PWh = d.PWh;
   const int cb = c.Cin / 16;
   unsigned char* wl = smem + 2 * PATCH_BYTES;
@@ -1329,7 +1342,17 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   }
   pstore(0);
   wstore(0);
-  wfetch(wr, 1);
+  if constexpr (WDMA && WEARLY) {
+    // (chunk 1: requested by chunk 0's first K step)
+  } else if constexpr (WDMA) {   // chunk 1 -> the second buffer, on its way while chunk 0 is worked on
+#pragma unroll
+    for (int pc = 0; pc < STAGE; ++pc)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wr, (__attribute__((address_space(3))) void*)(wl + WBUF_BYTES + wave_u * 1024 + pc * TPIECE), 16,
+          CHUNK_FRAGS * 16u + tid * 16u + pc * TPIECE, 0, 0, 0);
+  } else {
+    wfetch(wr, 1);
+  }
   TFC_LDS_BARRIER();
   TFC_CONV3_CLOCK(1);
 
@@ -1390,6 +1413,7 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
       const bf16x8* abase = reinterpret_cast<const bf16x8*>(wl + buf * WBUF_BYTES) + lane;
       const bf16x8* anext = reinterpret_cast<const bf16x8*>(wl + (buf ^ 1) * WBUF_BYTES) + lane;
       u32x4* const wdst = reinterpret_cast<u32x4*>(wl + (buf ^ 1) * WBUF_BYTES) + tid;
+      unsigned char* const wdma = wl + (WEARLY ? buf ^ 1 : buf) * WBUF_BYTES + wave_u * 1024;      // this wave's KB of a piece (+ lane * 16: the hardware)
       const unsigned int wv0 = static_cast<unsigned int>(chunk0 + ch + 2) * (CHUNK_FRAGS * 16u) + tid * 16u;   // (past the last chunk: outside the buffer)
 #if TFC_CONV3_EXP & 64
       {   // (timing build: the wait the first store below begins with, by hand)
@@ -1419,15 +1443,26 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
             else af[nxt_set][f - MT] = last_kk ? anext[(f - MT) * 64] : abase[((kk + 1) * TILES + (f - MT)) * 64];
           }
 #if !(TFC_CONV3_EXP & 2)
-          if (kk == 0) {
+          if constexpr (WDMA) {
+            if (kk == (WEARLY ? 0 : CH - 1)) {
 #pragma unroll
-            for (int pc = 0; pc < STAGE; ++pc)
-              if (pc % SLOTS == i) TFC_CONV3_ISSUE(2, wdst[pc * NTHR] = stage[pc]);
-          }
-          if (kk == 1) {
+              for (int pc = 0; pc < STAGE; ++pc)
+                if (pc % SLOTS == i)
+                  TFC_CONV3_ISSUE(0, __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                         wr, (__attribute__((address_space(3))) void*)(wdma + pc * TPIECE), 16,
+                                         wv0 - (WEARLY ? CHUNK_FRAGS * 16u : 0u) + pc * TPIECE, 0, 0, 0));
+            }
+          } else {
+            if (kk == 0) {
 #pragma unroll
-            for (int pc = 0; pc < STAGE; ++pc)
-              if (pc % SLOTS == i) TFC_CONV3_ISSUE(0, stage[pc] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv0 + pc * TPIECE, 0, 0));
+              for (int pc = 0; pc < STAGE; ++pc)
+                if (pc % SLOTS == i) TFC_CONV3_ISSUE(2, wdst[pc * NTHR] = stage[pc]);
+            }
+            if (kk == 1) {
+#pragma unroll
+              for (int pc = 0; pc < STAGE; ++pc)
+                if (pc % SLOTS == i) TFC_CONV3_ISSUE(0, stage[pc] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv0 + pc * TPIECE, 0, 0));
+            }
           }
 #endif
 #if !(TFC_CONV3_EXP & 4)
@@ -1451,6 +1486,11 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
           __builtin_amdgcn_sched_barrier(0);
         }
         if (kk == CH - 2) {
+          if constexpr (WDMA) {       // this wave's pieces of the next chunk have landed (behind them in the queue: a patch gather
+                                      // requested in this chunk)
+            if (ch == 0 && PFK <= CH - 2 && (!WEARLY || PFK > 0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
 #if !(TFC_CONV3_EXP & 1)
 #if TFC_CONV3_EXP & 64
           const long long b0 = clock64();
