@@ -1444,6 +1444,8 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
           }
 #if !(TFC_CONV3_EXP & 2)
           if constexpr (WDMA) {
+            // (a request past the item's last chunk is outside the weights' buffer: no traffic, zeros written; the one the
+            // last K step makes is waited for behind the loop.  Under a condition instead, the branch cost 4 % of the layer)
             if (kk == (WEARLY ? 0 : CH - 1)) {
 #pragma unroll
               for (int pc = 0; pc < STAGE; ++pc)
@@ -1523,6 +1525,12 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
   if (threadIdx.x == 0 && blockIdx.x < kConv3ClockWgs)
     for (int i = 0; i < 8; ++i) g_conv3_waits[blockIdx.x * 8 + i] = kwait[i];
 #endif
+  if constexpr (WDMA && !WEARLY) {
+    // the last K step's request (zeros for a chunk past the item's last) has landed before the epilogue takes LDS over —
+    // with gamma's image resident its staging area IS the weight buffers, and another wave's piece may lie in this wave's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (GRES) TFC_LDS_BARRIER();
+  }
   TFC_CONV3_CLOCK(2);
   epilogue(cur, (pcb - 1) & 1);
 #if TFC_CONV3_EXP & 64
