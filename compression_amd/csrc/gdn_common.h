@@ -155,6 +155,29 @@ __device__ inline unsigned int float_to_bf16_bits(float f) {
 //   element e of lane (i = lane & 31, h = lane >> 5) at (t, s) is
 //   gamma[ch(s, h, e)][32 t + i],  ch(s, h, e) = 16 s + 4 h + (e & 3) + 8 (e >> 2).
 // ---------------------------------------------------------------------------
+// TFC_GDN_DMA (build switch, round 6 experiment): the forward kernel's x tile travels global -> LDS with buffer_load ... lds,
+// LINEAR (a tile of 32 pixels is 64 C contiguous bytes: 1 KB per instruction, 8 lines), into a wave-private buffer behind
+// the fragment image, and the B fragments are ds_read_b128 from it in the MFMA's order (row stride 2 C bytes: 8-way bank
+// conflicts at 192 channels, 12 reads per tile).  The workgroup is 7 waves at 192 channels (72.75 + 7 x 12 KB of LDS).
+#ifndef TFC_GDN_DMA
+#define TFC_GDN_DMA 0
+#endif
+// TFC_GDN_LINES (round 6): the forward kernel's y leaves as WHOLE 128-byte lines.  Straight from the accumulators' layout a
+// store instruction is 32 pixels x 32 bytes — four instructions fill a line, each a partial write on its way through L2 —
+// and with them in flight the kernel's reads ran at 60 % of what they reach alone (builds without the stores 32 us, without
+// the loads 28, with both 54.5 on [262144, 192]: profiles/r06_notes.md).  Instead four K steps' results (64 channels, one
+// line per pixel) go to a wave-private 4 KB of LDS as [pixel][8 granules], granule g at g ^ (pixel / 2 & 7) (all banks
+// once per 16 lanes), and leave 8 lanes to a line, 8 pixels to an instruction.
+#ifndef TFC_GDN_LINES
+#define TFC_GDN_LINES 1
+#endif
+// TFC_GDN_PAIRS (experiment): 1 loads, 2 stores (3 both) by lane pairs — lanes 2 i, 2 i + 1 touch the 32 contiguous bytes
+// pixel i has of a K step — with ds_bpermute_b32 between that order and the MFMA's.
+#ifndef TFC_GDN_PAIRS
+#define TFC_GDN_PAIRS 0
+#endif
+template <int KT>
+constexpr int gdn_dma_waves() { return (160 * 1024 - (16 * KT * KT * 2 * 64 + KT * 128)) / (KT * 2048) >= 8 ? 8 : (160 * 1024 - (16 * KT * KT * 2 * 64 + KT * 128)) / (KT * 2048); }
 template <int KT, int MODE, bool PLAIN, bool GEN = false>
 __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
   static_assert(!GEN || (MODE == MODE_FWD && !PLAIN), "general exponents: forward only");
@@ -166,7 +189,9 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
 
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5;
-  const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // (the wave's number as a scalar: tile numbers, the tile's base addresses and bounds then live in SGPRs)
+  const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) +
+                         __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const long long nwaves = static_cast<long long>(gridDim.x) * (blockDim.x >> 6);
   const unsigned short* x = static_cast<const unsigned short*>(p.x);
   unsigned short* y = static_cast<unsigned short*>(p.y);
@@ -177,12 +202,51 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
   // alternatives that did NOT pay (profiles/r01_e_gdn_notes.md): double-buffered A fragments, and
   // fully coalesced tile I/O staged through LDS.
   constexpr bool PREFETCH = MODE == MODE_FWD && (KT <= 5 || (PLAIN && KT == 6));
-  u32x4 xn[PREFETCH ? KS : 1];
+  constexpr bool DMA = TFC_GDN_DMA != 0 && PREFETCH;
+  constexpr bool LINES = TFC_GDN_LINES != 0 && MODE == MODE_FWD && KT <= 7;      // (256 channels: the image leaves no room)
+  constexpr int IMG_BYTES = static_cast<int>(sizeof(bf16x8)) * KT * KS * 64 + C * 4;
+  constexpr int TILE_BYTES = 64 * C;
+  unsigned char* const tbuf = smem + IMG_BYTES + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * TILE_BYTES;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.x), 0, DMA ? static_cast<int>(p.pixels * C * 2) : 0, 0x00020000);
+  auto dma_tile = [&](long long tile) __attribute__((always_inline)) {
+    const unsigned int v0 = static_cast<unsigned int>(tile * TILE_BYTES) + lane * 16u;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(tbuf + 1024 * j), 16,
+                                               v0 + 1024u * j, 0, 0, 0);
+  };
+  u32x4 xn[PREFETCH && !DMA ? KS : 1];
+  const int from_mem = 4 * (2 * (lane & 31) + h);              // bpermute address: the memory-order lane an MFMA-order lane reads
+  const int from_mfma = 4 * ((lane >> 1) + 32 * (lane & 1));   // ... and the MFMA-order lane a memory-order lane reads
+  auto perm4 = [&](int addr, const u32x4& v) -> u32x4 {
+    return u32x4{static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(addr, v.x)),
+                 static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(addr, v.y)),
+                 static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(addr, v.z)),
+                 static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(addr, v.w))};
+  };
+  auto mem_row = [&](long long tile) -> long long {
+    const long long pix = tile * 32 + (lane >> 1);
+    return (pix < p.pixels ? pix : p.pixels - 1) * C + 8 * (lane & 1);
+  };
   auto fetch = [&](long long tile) {
+#if TFC_GDN_PAIRS & 1
+    {
+      const long long mrow = mem_row(tile);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = *reinterpret_cast<const u32x4*>(x + mrow + 16 * s);
+      return;
+    }
+#endif
+#if defined(TFC_GDN_EXP) && (TFC_GDN_EXP & 2)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = u32x4{lane + 0x3f803f80u, static_cast<unsigned int>(tile), 0x3f803f80u, 0x40004000u};   // (timing: no loads)
+    return;
+#endif
     const long long pix = tile * 32 + (lane & 31);
     const long long row = (pix < p.pixels ? pix : p.pixels - 1) * C;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xn[PREFETCH ? s : 0] = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
+    for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
   };
   {
     // fragment image (built once per call by gdn_prep_bf16_kernel): linear 16-byte copy.  Its loads are
@@ -191,17 +255,19 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
     const u32x4* src = static_cast<const u32x4*>(p.image);
     u32x4* dstv = reinterpret_cast<u32x4*>(smem);
     constexpr int n16 = KT * KS * 64 + (C * 4) / 16;
-    constexpr int PER = (n16 + 511) / 512;   // the kernel is launched with 512 threads
+    constexpr int NTH = DMA ? 64 * gdn_dma_waves<KT>() : 512;   // threads the kernel is launched with
+    constexpr int PER = (n16 + NTH - 1) / NTH;
     u32x4 img[PER];
+    if (DMA && wave < p.tiles) dma_tile(wave);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = threadIdx.x + k * 512;
+      const int i = threadIdx.x + k * NTH;
       if (i < n16) img[k] = src[i];
     }
-    if (PREFETCH && wave < p.tiles) fetch(wave);
+    if (PREFETCH && !DMA && wave < p.tiles) fetch(wave);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = threadIdx.x + k * 512;
+      const int i = threadIdx.x + k * NTH;
       if (i < n16) dstv[i] = img[k];
     }
   }
@@ -213,18 +279,29 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
     const long long row = (live ? pix : p.pixels - 1) * C;
     // ---- loads: after the swap, K-step s holds channels 16s+4h+{0..3} and 16s+4h+8+{0..3} ----
     u32x4 xr[KS];
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed in the wave's buffer
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       // One 16-byte load per lane (channels 16s + 8h + 0..7), then v_permlane32_swap trades
       // the inner halves between lanes l and l+32 so that the lane ends up with channels
       // 16s + 4h + {0..3} and 16s + 4h + 8 + {0..3} — twice the bytes per cache line touched
       // by one load instruction compared with two 8-byte loads.
-      const u32x4 v = PREFETCH ? xn[PREFETCH ? s : 0] : *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
+#if TFC_GDN_PAIRS & 1
+      const u32x4 v = perm4(from_mem, PREFETCH ? xn[PREFETCH && !DMA ? s : 0] : *reinterpret_cast<const u32x4*>(x + mem_row(tile) + 16 * s));
+#else
+      const u32x4 v = DMA ? *reinterpret_cast<const u32x4*>(tbuf + (lane & 31) * (2 * C) + 32 * s + 16 * h)
+                          : PREFETCH ? xn[PREFETCH && !DMA ? s : 0] : *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
+#endif
       const auto s0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
       const auto s1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
       xr[s] = u32x4{s0[0], s1[0], s0[1], s1[1]};
     }
-    if (PREFETCH && tile + nwaves < p.tiles) fetch(tile + nwaves);
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer is read out: the next tile may land in it
+      if (tile + nwaves < p.tiles) dma_tile(tile + nwaves);
+    } else if (PREFETCH && tile + nwaves < p.tiles) {
+      fetch(tile + nwaves);
+    }
     f32x16 acc[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
@@ -268,7 +345,47 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
     auto frag_store = [&](unsigned short* base, int s, u32x4 out) {
       const auto s0 = __builtin_amdgcn_permlane32_swap(out.x, out.z, false, false);
       const auto s1 = __builtin_amdgcn_permlane32_swap(out.y, out.w, false, false);
+      if constexpr (LINES) {
+        // (this lane: channels 16 s + 8 h + {0 .. 7} of pixel lane & 31 = granule 2 (s & 3) + h of the pixel's line s >> 2)
+        unsigned char* const ost = smem + ((IMG_BYTES + 15) & ~15) + DMA * 0 + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * 4096;
+        auto slot = [&](int pix, int g) -> unsigned char* { return ost + pix * 128 + ((g ^ ((pix >> 1) & 7)) << 4); };
+        auto wave_sync = [&]() __attribute__((always_inline)) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        *reinterpret_cast<u32x4*>(slot(lane & 31, 2 * (s & 3) + h)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        if ((s & 3) == 3 || s == KS - 1) {
+          const int granules = 2 * ((s & 3) + 1);            // of this line (a last line of 32 or 96 channels: fewer)
+          wave_sync();
+          unsigned short* const tbase = base + tile * (32 * C);                       // (wave-uniform)
+          const int loff = (lane >> 3) * C + 8 * (lane & 7);
+          const long long left = p.pixels - tile * 32;
+          const int room = left < 32 ? static_cast<int>(left) : 32;                   // pixels of this tile inside the tensor
+          // (pixels 8 k + lane / 8: the swizzle of k + 2 is that of k — two LDS addresses, + 2 KB)
+          const unsigned char* const rd[2] = {slot(lane >> 3, lane & 7), slot(8 + (lane >> 3), lane & 7)};
+          const bool on = (lane & 7) < granules;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(rd[k & 1] + 2048 * (k >> 1));
+            if (on && 8 * k + (lane >> 3) < room) *reinterpret_cast<u32x4*>(tbase + loff + 8 * k * C + 64 * (s >> 2)) = v;
+            __builtin_amdgcn_sched_barrier(0);        // (one granule at a time: registers)
+          }
+          wave_sync();
+        }
+        return;
+      }
+#if TFC_GDN_PAIRS & 2
+      const u32x4 m = perm4(from_mfma, u32x4{s0[0], s1[0], s0[1], s1[1]});
+#if defined(TFC_GDN_EXP) && (TFC_GDN_EXP & 1)
+      if (m.x == 0x12345u)
+#endif
+      if (tile * 32 + (lane >> 1) < p.pixels) *reinterpret_cast<u32x4*>(base + mem_row(tile) + 16 * s) = m;
+#elif defined(TFC_GDN_EXP) && (TFC_GDN_EXP & 1)
+      if (live && s0[0] == 0x12345u) *reinterpret_cast<u32x4*>(base + row + 16 * s + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};   // (timing: no stores)
+#else
       if (live) *reinterpret_cast<u32x4*>(base + row + 16 * s + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+#endif
     };
     auto elem = [&](const u32x4& f, int half, int r) -> float {
       const unsigned int word = f[2 * half + (r >> 1)];
@@ -519,10 +636,21 @@ int launch_gdn_variant(GdnParams p, int dtype, hipStream_t st) {
       p.image = image.p;
     }
     KernelTimer timer(label, st);
+    const size_t lds_lines = TFC_GDN_LINES != 0 && MODE == MODE_FWD && KT <= 7 ? ((lds + 15) & ~size_t{15}) + static_cast<size_t>(waves_per_block) * 4096 : lds;
+    constexpr bool DMA = TFC_GDN_DMA != 0 && MODE == MODE_FWD && (KT <= 5 || (PLAIN && KT == 6));
+    if (DMA && static_cast<long long>(p.pixels) * KT * 64 < (1ll << 31)) {
+      constexpr int W = gdn_dma_waves<KT>();
+      const size_t lds_dma = lds + static_cast<size_t>(W) * KT * 2048;
+      const unsigned blocks_dma = static_cast<unsigned>(std::max<long long>(1, std::min<long long>(ceil_div(p.tiles, W), cus)));
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_dma)));
+      hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>), dim3(blocks_dma), dim3(64 * W), lds_dma, st, p);
+    } else {
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>), dim3(blocks), dim3(64 * waves_per_block), lds,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_lines)));
+    hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>), dim3(blocks), dim3(64 * waves_per_block), lds_lines,
                        st, p);
+    }
    } else {
     return fail("tfc_gdn: bfloat16 kernel not built for this configuration");
    }
