@@ -60,6 +60,7 @@ struct GdnParams {
   long long tiles;      // ceil(pixels / 32)
   const void* image;    // fragment-ordered Gamma^T (+ beta) built by gdn_prep_*_kernel
   const void* prepared; // != null: the caller's image of these parameters (tfc_gdn_params): no prep launch
+  int nt_store;         // forward, whole-line stores: non-temporal (the tensors are larger than the caches)
   // backward passes (see the mode table above the kernels)
   const void* g;        // dL/dy                      (MODE_BWD_T)
   const void* r;        // g * n^s from pass 1        (MODE_BWD_DX)
@@ -246,7 +247,11 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
     const long long pix = tile * 32 + (lane & 31);
     const long long row = (pix < p.pixels ? pix : p.pixels - 1) * C;
 #pragma unroll
+#if defined(TFC_GDN_NT) && (TFC_GDN_NT & 2)
+    for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h));
+#else
     for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
+#endif
   };
   {
     // fragment image (built once per call by gdn_prep_bf16_kernel): linear 16-byte copy.  Its loads are
@@ -368,7 +373,20 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(rd[k & 1] + 2048 * (k >> 1));
-            if (on && 8 * k + (lane >> 3) < room) *reinterpret_cast<u32x4*>(tbase + loff + 8 * k * C + 64 * (s >> 2)) = v;
+#if defined(TFC_GDN_EXP) && (TFC_GDN_EXP & 1)
+            if (on && 8 * k + (lane >> 3) < room && v.x == 0x12345u) *reinterpret_cast<u32x4*>(tbase + loff + 8 * k * C + 64 * (s >> 2)) = v;      // (timing: no stores)
+#else
+            // whole lines, non-temporal where the tensors cannot stay in the caches anyway (p.nt_store, launch_gdn_variant):
+            // 46.8 -> 41.8 us on [262144, 192].  (With the 32-byte partial stores of rounds 1-5 non-temporal was 2-3x slower;
+            // non-temporal LOADS — still 32 bytes of a line per instruction — 57 us)
+            if (on && 8 * k + (lane >> 3) < room) {
+              u32x4* const dst = reinterpret_cast<u32x4*>(tbase + loff + 8 * k * C + 64 * (s >> 2));
+              // (as an instruction by hand: with __builtin_nontemporal_store in one branch and a plain store in the other the
+              // optimiser merges the two into ONE plain store)
+              if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+              else *dst = v;
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);        // (one granule at a time: registers)
           }
           wave_sync();
@@ -636,6 +654,11 @@ int launch_gdn_variant(GdnParams p, int dtype, hipStream_t st) {
       p.image = image.p;
     }
     KernelTimer timer(label, st);
+    // x + y beyond half the 256 MB Infinity Cache: y's lines go out non-temporal (TFC_GDN_NT = 0 / 1: never / always)
+    {
+      static const int nt_env = [] { const char* e = std::getenv("TFC_GDN_NT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+      p.nt_store = nt_env >= 0 ? nt_env : (static_cast<long long>(p.pixels) * KT * 32 * 4 > (128ll << 20) ? 1 : 0);
+    }
     const size_t lds_lines = TFC_GDN_LINES != 0 && MODE == MODE_FWD && KT <= 7 ? ((lds + 15) & ~size_t{15}) + static_cast<size_t>(waves_per_block) * 4096 : lds;
     constexpr bool DMA = TFC_GDN_DMA != 0 && MODE == MODE_FWD && (KT <= 5 || (PLAIN && KT == 6));
     if (DMA && static_cast<long long>(p.pixels) * KT * 64 < (1ll << 31)) {
