@@ -90,6 +90,7 @@ struct ConvGeom {
   int gdn;
   const void* gdn_image;
   int xcd;                  // 1: the third-generation kernel's workgroups take their blocks in XCD order (xcd_order)
+  int nt_out;               // third generation: the output's whole-line stores non-temporal (an output beyond the caches)
 };
 
 // Third-generation kernel: a workgroup computes an 8 x 32 block of low-resolution output pixels of ONE image
@@ -1284,7 +1285,10 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
 #if TFC_CONV3_EXP & 32
             if (v[k].x != 0x12345u) continue;     // (no stores)
 #endif
-            __builtin_amdgcn_raw_buffer_store_b128(v[k], yr, 8 * k < xroom ? yrow[p] : 0x80000000u, 128 * rd + k * xstep, 0);
+            // (non-temporal — cache policy 2 — where the output cannot stay in the caches: the lines do not displace the
+            // patches and weights other workgroups are about to read)
+            if (c.nt_out) __builtin_amdgcn_raw_buffer_store_b128(v[k], yr, 8 * k < xroom ? yrow[p] : 0x80000000u, 128 * rd + k * xstep, 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(v[k], yr, 8 * k < xroom ? yrow[p] : 0x80000000u, 128 * rd + k * xstep, 0);
           }
         }
         wave_sync();
@@ -1699,6 +1703,11 @@ int run_conv3(const __bf16* x, const float* w, const float* bias, __bf16* y, Con
     // speed alone on the chip — round 6, with the cheaper epilogue: 2 % / 6 % ahead on the stride-2 / transposed layer —
     // but keeps the kernels of other steps in flight out of its CUs: C4 51.6 instead of 47.6 ms per step,
     // profiles/r03_notes.md.)
+    {
+      static const int nt_env = [] { const char* e = std::getenv("TFC_CONV_NT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+      const long long out_bytes = c.N * c.OH * c.OW * c.Cout * (c.out_f32 ? 4 : 2);
+      c.nt_out = nt_env >= 0 ? nt_env : (out_bytes > (128ll << 20) ? 1 : 0);
+    }
     const long long nblk = c.N * d.BXn * d.BYn * d.gcount;
     if (nblk >= (1ll << 31)) return fail("tfc_conv2d: problem too large for one launch");
     const dim3 grid(static_cast<unsigned>(nblk));
@@ -2412,6 +2421,8 @@ __global__ void __launch_bounds__(512, 1) conv_image_direct_kernel(const __bf16*
         for (int j = 0; j < 4; ++j) {
           const int px = 8 * j + (lane >> 3), piece = lane & 7;
           const u32x4 o = *reinterpret_cast<const u32x4*>(stg + px * ROW + piece * 16);
+          // (non-temporal stores measured level here: 1.56 ms either way at 128 x 768x512 — the layer writes at 3.1 TB/s where a
+          // fill of its output runs at 6.9: it is bound by instruction issue, profiles/r04_notes.md)
           *reinterpret_cast<u32x4*>(yrow + px * C + 64 * cnk + 8 * piece) = o;
         }
       }
@@ -2441,6 +2452,8 @@ __global__ void __launch_bounds__(512, 1) conv_image_direct_kernel(const __bf16*
         for (int j = 0; j < 4; ++j) {
           const int px = 8 * j + (lane >> 3), piece = lane & 7;
           const u32x4 o = *reinterpret_cast<const u32x4*>(stg + px * ROW + piece * 16);
+          // (non-temporal stores measured level here: 1.56 ms either way at 128 x 768x512 — the layer writes at 3.1 TB/s where a
+          // fill of its output runs at 6.9: it is bound by instruction issue, profiles/r04_notes.md)
           *reinterpret_cast<u32x4*>(yrow + px * C + 64 * cnk + 8 * piece) = o;
         }
       }
