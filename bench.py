@@ -973,6 +973,32 @@ def conv_layer_table(device, batch=128):
         tf = flops / 1e12 / (ms / 1e3)
         rows.append({"layer": name, "ms": round(ms, 3), "tflops": round(tf, 1), "frac_of_2500": round(tf / 2500.0, 4)})
         del x
+    # the two big layers as a model step launches them: GDN / IGDN as the layer's activation, inside the kernel
+    # (tfc_conv2d_gdn; FLOP count: the convolution's + the 2 C^2 per pixel of the norm's contraction)
+    from compression_amd.layers.functional import GDNPrepared, conv2d_gdn
+    prepared = GDNPrepared(torch.rand(C_) + 1.0, torch.rand(C_, C_) * 0.01 + 0.1 * torch.eye(C_), dt)
+    for name, shp, up in (("analysis 5x5 192->192 /2 @384x256 + GDN", (H // 2, W // 2, C_), False),
+                          ("synthesis 5x5 192->192 x2 @192x128 + IGDN", (H // 4, W // 4, C_), True)):
+        x = torch.randn((batch,) + shp, device=device).to(dt)
+        w = k(5, C_, C_)
+        b = torch.zeros(C_, device=device)
+        fused = True
+        for _ in range(2):
+            _, fused = conv2d_gdn(x, w, b, 2, up, prepared, up)
+        if not fused:
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            conv2d_gdn(x, w, b, 2, up, prepared, up)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        out_pix = batch * shp[0] * shp[1] * (4 if up else 0.25)
+        flops = 2.0 * out_pix * 25 * C_ * C_ / (4 if up else 1) + 2.0 * out_pix * C_ * C_
+        tf = flops / 1e12 / (ms / 1e3)
+        rows.append({"layer": name, "ms": round(ms, 3), "tflops": round(tf, 1), "frac_of_2500": round(tf / 2500.0, 4)})
+        del x
     return {"workload": f"SignalConv2D layer shapes of bmshj2018 at {batch} x 768x512, bf16", "layers": rows}
 
 
