@@ -49,7 +49,7 @@ def test_gdn_f32(C, inverse, rectify, alpha, eps):
         assert np.max(err / np.maximum(1.0, np.abs(want))) <= 1e-5
 
 
-@pytest.mark.parametrize("C", [64, 192, 256])
+@pytest.mark.parametrize("C", [32, 64, 96, 160, 192, 224, 256])     # (an odd number of 32-channel tiles: a last output line of 64 bytes)
 @pytest.mark.parametrize("inverse", [False, True])
 def test_gdn_bf16(C, inverse):
     from compression_amd.layers import gdn_forward
@@ -60,6 +60,25 @@ def test_gdn_bf16(C, inverse):
     # reference on the bf16-rounded inputs the kernel sees
     want = ref_gdn(x.float().numpy(), beta.numpy(), gamma.bfloat16().float().numpy(), inverse, False, 1, 1)
     assert np.max(np.abs(y - want) / (np.abs(want) + 1e-3)) <= 2 ** -7   # one bf16 ulp of slack on the output
+
+
+def test_gdn_bf16_whole_line_stores_both_ways():
+    """The forward kernel stores y as whole 128-byte lines, non-temporal where x + y exceed 128 MB (gdn_common.h): a tensor
+    on each side of that line, ragged in pixels (not a multiple of the 32-pixel tile), gives the values of the
+    pixel-by-pixel float64 evaluation on a sample of its rows — first, last and the rows around a tile boundary."""
+    from compression_amd.layers import gdn_forward
+    C = 192
+    beta, gamma = params(C, 2)
+    gen = torch.Generator().manual_seed(11)
+    for pixels in (1000 + 7, 200_000 + 13):          # 0.8 MB and 154 MB of x + y
+        x = torch.randn(pixels, C, generator=gen).bfloat16()
+        y = gdn_forward(x.cuda(), beta, gamma, False).float().cpu()
+        rows = torch.tensor([0, 1, 31, 32, 33, pixels // 2, pixels - 34, pixels - 33, pixels - 2, pixels - 1])
+        want = ref_gdn(x[rows].float().numpy(), beta.numpy(), gamma.bfloat16().float().numpy(), False, False, 1, 1)
+        got = y[rows].numpy()
+        assert np.max(np.abs(got - want) / (np.abs(want) + 1e-3)) <= 2 ** -7, pixels
+        # and every row was written: nothing of the output is left at the allocator's fill
+        assert torch.isfinite(y).all() and (y.abs().sum(dim=1) > 0).all()
 
 
 def test_gdn_closed_form():
