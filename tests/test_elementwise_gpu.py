@@ -18,6 +18,9 @@ def test_image_to_unit(dtype):
     want = torch.from_numpy(x.cpu().numpy().astype(np.float32) / np.float32(255.0)).to(dtype).cuda()
     assert got.dtype == dtype and torch.equal(got, want)
     assert (got.float() - (x.to(dtype) / 255.0).float()).abs().max() <= 2.0 ** -23
+    # a contiguous tensor whose first element is not 16-byte aligned (the kernel's element-by-element path)
+    xo = x.view(-1)[3:]
+    assert torch.equal(functional.image_to_unit(xo, dtype), want.view(-1)[3:])
     # non-contiguous input: the torch expression
     xt = x.expand(2, 73, 137, 3)[:, ::2]
     assert torch.equal(functional.image_to_unit(xt, dtype), xt.to(dtype) / 255.0)     # (the fallback IS that expression)
@@ -33,6 +36,7 @@ def test_unit_to_image(dtype):
     got = functional.unit_to_image(x)
     want = torch.clamp(torch.round((x * 255.0).float()), 0, 255).to(torch.uint8)     # the product in x's dtype
     assert got.dtype == torch.uint8 and torch.equal(got, want)
+    assert torch.equal(functional.unit_to_image(x[5:]), want[5:])          # (base not 16-byte aligned)
     xs = x.reshape(-1, 3)[:, :2]
     assert torch.equal(functional.unit_to_image(xs), torch.clamp(torch.round((xs * 255.0).float()), 0, 255).to(torch.uint8))
 
@@ -46,5 +50,7 @@ def test_index_prepare_equals_the_bound_ops(dtype):
     got = functional.index_prepare(idx, 64)
     want = math_ops.upper_bound(math_ops.lower_bound(idx, 0), 63).to(torch.int32)
     assert got.dtype == torch.int32 and torch.equal(got, want) and int(got.min()) >= 0 and int(got.max()) <= 63
+    got1 = functional.index_prepare(idx.view(-1)[1:], 64)                     # (base not 16-byte aligned)
+    assert got1 is None or torch.equal(got1, want.view(-1)[1:])
     assert functional.index_prepare(idx.to(torch.int32), 64) is None          # integer indexes: the torch ops
     assert functional.index_prepare(idx[..., :3], 64) is None                 # not contiguous
