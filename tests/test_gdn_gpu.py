@@ -62,6 +62,27 @@ def test_gdn_bf16(C, inverse):
     assert np.max(np.abs(y - want) / (np.abs(want) + 1e-3)) <= 2 ** -7   # one bf16 ulp of slack on the output
 
 
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("inverse,rectify,alpha,eps", [
+    (False, True, 1, 1), (True, False, 2, 0.5), (False, False, 2, 1), (True, True, 1, 0.5), (False, True, 1.5, 0.7)])
+def test_gdn_bf16_every_forward_variant(C, inverse, rectify, alpha, eps):
+    """The bfloat16 forward kernel's other builds (rectify / alpha = 2 / epsilon = 1/2: the general epilogue without the
+    next-tile prefetch at 192 channels; learned exponents: the GEN build) write through the same whole-line store path."""
+    from compression_amd.layers import gdn_forward
+    torch.manual_seed(9)
+    x = torch.randn(5, 41, C).bfloat16()
+    beta, gamma = params(C, 3)
+    y = gdn_forward(x.cuda(), beta, gamma, inverse=inverse, rectify=rectify, alpha=alpha, epsilon=eps).float().cpu().numpy()
+    xf = x.float().numpy().astype(np.float64)
+    if rectify:
+        xf = np.maximum(xf, 0)
+    u = np.abs(xf) ** alpha
+    # (the kernel feeds |x|^alpha to the matrix cores as bfloat16, gamma likewise)
+    n = u @ gamma.bfloat16().float().numpy().astype(np.float64) + beta.numpy().astype(np.float64)
+    want = xf * n ** eps if inverse else xf / n ** eps
+    assert np.max(np.abs(y - want) / (np.abs(want) + 1e-2)) <= 2 ** -6
+
+
 def test_gdn_bf16_whole_line_stores_both_ways():
     """The forward kernel stores y as whole 128-byte lines, non-temporal where x + y exceed 128 MB (gdn_common.h): a tensor
     on each side of that line, ragged in pixels (not a multiple of the 32-pixel tile), gives the values of the
