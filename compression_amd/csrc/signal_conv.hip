@@ -867,10 +867,16 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
 //   * lays the patch out as [row][x parity][h][x / sd] granules of 16 bytes (h = which 8 of the 16 channels):
 //     the 32 pixels of a tile (one output row segment, input stride sd) are consecutive granules of one
 //     parity / h plane, i.e. all 64 banks once per 16-lane group of the ds_read_b128;
-//   * keeps the rest of the second generation: weights as packed A fragments through a double-buffered LDS
-//     chunk (here CH K steps = CH taps of one channel block, CH | taps), A / B fragments double-buffered in
-//     registers, 2 pixel tiles x TILES column tiles per wave, 16-byte output stores.
+//   * keeps of the second generation: weights as packed A fragments in a double-buffered LDS chunk (here CH K steps =
+//     CH taps of one channel block, CH | taps), A / B fragments double-buffered in registers, 2 pixel tiles x TILES
+//     column tiles per wave.
 // NPG = 16-byte patch pieces per thread (granules / 256, rounded up).
+// Round 6 (measured from the inside with the timing build below; DESIGN.md §3, profiles/r06_notes.md):
+//   * the patch loader reads a pixel's 32 bytes of the channel block with a lane PAIR (32 lines per request instead of 64);
+//   * the weight chunks go global -> LDS by buffer_load ... lds (WDMA), not through registers;
+//   * every staging instruction sits behind an MFMA of its own (slots, below);
+//   * the output leaves as whole 128-byte lines through a wave-private LDS area, non-temporal for big outputs;
+//   * GDN / IGDN as the activation: builds of their own (GDNK), no scratch.
 //   * one ITEM per workgroup: a block and one of the launch's column groups (round 6; before: a workgroup took a
 //     block's groups, or every W-th block, one after the other with the next item's first requests under the last K
 //     steps — per item the same time, tools/conv3_clock_probe.py: what the prologue saved the longer K loop and the
@@ -1303,10 +1309,12 @@ __global__ void __launch_bounds__(256, 1) conv3_bf16_kernel(const __bf16* x, con
     }
   };
 
-  // Schedule of a chunk c (CH K steps, weights in LDS buffer c & 1):
-  //   start        chunk c + 1 (requested during chunk c - 1) registers -> LDS buffer (c + 1) & 1, whose last readers
-  //                finished before the barrier of chunk c - 1; request chunk c + 2; first chunk of a channel block:
-  //                request the next channel block's patch (the next ITEM's first, behind an item's last)
+  // Schedule of a chunk c (CH K steps, weights in LDS buffer c & 1; the slots of every kind of staging: at channel_block):
+  //   the next chunks' weights   WDMA: chunk c + 1 requested into buffer (c + 1) & 1 in chunk c's first K step (5-K-step
+  //                chunks) or chunk c + 2 into buffer c & 1 in its last (shorter chunks) — either way into a buffer whose
+  //                last readers finished before a barrier, and waited for (vmcnt) in front of the barrier that publishes it.
+  //                Through registers (TFC_CONV3_WDMA = 0): requested a chunk earlier, registers -> LDS in the first K step
+  //   first chunk of a channel block: the next channel block's patch requested
   //   K step kk    reads the fragments of K step kk + 1 under its MFMAs
   //   end of kk = CH - 2   (last chunk of a channel block: the patch registers -> the other patch buffer;) wait for
   //                this wave's LDS traffic, barrier
