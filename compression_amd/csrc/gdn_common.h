@@ -17,8 +17,10 @@
 //     outputs land in that lane's accumulator registers
 //     (C/D map: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).
 //     The epilogue (add beta, reciprocal, multiply by x) therefore needs no
-//     transpose, no shuffle and no second read of x; y leaves with the same
-//     access pattern x came in with.
+//     transpose, no shuffle and no second read of x.  The forward kernel's y
+//     leaves as whole 128-byte lines through a wave-private LDS area
+//     (TFC_GDN_LINES, round 6); the backward kernels' outputs with the access
+//     pattern x came in with.
 //   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate), gamma rounded to bf16
 //     like a Keras mixed_bfloat16 policy would.  f32: v_mfma_f32_32x32x2_f32,
 //     bit-exact fp32 FMA chains (the <=1e-5 parity path).
@@ -156,13 +158,6 @@ __device__ inline unsigned int float_to_bf16_bits(float f) {
 //   element e of lane (i = lane & 31, h = lane >> 5) at (t, s) is
 //   gamma[ch(s, h, e)][32 t + i],  ch(s, h, e) = 16 s + 4 h + (e & 3) + 8 (e >> 2).
 // ---------------------------------------------------------------------------
-// TFC_GDN_DMA (build switch, round 6 experiment): the forward kernel's x tile travels global -> LDS with buffer_load ... lds,
-// LINEAR (a tile of 32 pixels is 64 C contiguous bytes: 1 KB per instruction, 8 lines), into a wave-private buffer behind
-// the fragment image, and the B fragments are ds_read_b128 from it in the MFMA's order (row stride 2 C bytes: 8-way bank
-// conflicts at 192 channels, 12 reads per tile).  The workgroup is 7 waves at 192 channels (72.75 + 7 x 12 KB of LDS).
-#ifndef TFC_GDN_DMA
-#define TFC_GDN_DMA 0
-#endif
 // TFC_GDN_LINES (round 6): the forward kernel's y leaves as WHOLE 128-byte lines.  Straight from the accumulators' layout a
 // store instruction is 32 pixels x 32 bytes — four instructions fill a line, each a partial write on its way through L2 —
 // and with them in flight the kernel's reads ran at 60 % of what they reach alone (builds without the stores 32 us, without
@@ -172,13 +167,9 @@ __device__ inline unsigned int float_to_bf16_bits(float f) {
 #ifndef TFC_GDN_LINES
 #define TFC_GDN_LINES 1
 #endif
-// TFC_GDN_PAIRS (experiment): 1 loads, 2 stores (3 both) by lane pairs — lanes 2 i, 2 i + 1 touch the 32 contiguous bytes
-// pixel i has of a K step — with ds_bpermute_b32 between that order and the MFMA's.
-#ifndef TFC_GDN_PAIRS
-#define TFC_GDN_PAIRS 0
-#endif
-template <int KT>
-constexpr int gdn_dma_waves() { return (160 * 1024 - (16 * KT * KT * 2 * 64 + KT * 128)) / (KT * 2048) >= 8 ? 8 : (160 * 1024 - (16 * KT * KT * 2 * 64 + KT * 128)) / (KT * 2048); }
+// (Measured in round 6 and not kept, profiles/r06_notes.md: global accesses by lane pairs with ds_bpermute_b32 between memory
+// order and the MFMA's, either direction; the x tile by linear buffer_load ... lds into a wave-private buffer; non-temporal
+// loads.)  TFC_GDN_EXP (timing builds, wrong results): 1 no stores, 2 no loads.
 template <int KT, int MODE, bool PLAIN, bool GEN = false>
 __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
   static_assert(!GEN || (MODE == MODE_FWD && !PLAIN), "general exponents: forward only");
@@ -203,55 +194,19 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
   // alternatives that did NOT pay (profiles/r01_e_gdn_notes.md): double-buffered A fragments, and
   // fully coalesced tile I/O staged through LDS.
   constexpr bool PREFETCH = MODE == MODE_FWD && (KT <= 5 || (PLAIN && KT == 6));
-  constexpr bool DMA = TFC_GDN_DMA != 0 && PREFETCH;
   constexpr bool LINES = TFC_GDN_LINES != 0 && MODE == MODE_FWD && KT <= 7;      // (256 channels: the image leaves no room)
   constexpr int IMG_BYTES = static_cast<int>(sizeof(bf16x8)) * KT * KS * 64 + C * 4;
-  constexpr int TILE_BYTES = 64 * C;
-  unsigned char* const tbuf = smem + IMG_BYTES + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * TILE_BYTES;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.x), 0, DMA ? static_cast<int>(p.pixels * C * 2) : 0, 0x00020000);
-  auto dma_tile = [&](long long tile) __attribute__((always_inline)) {
-    const unsigned int v0 = static_cast<unsigned int>(tile * TILE_BYTES) + lane * 16u;
-#pragma unroll
-    for (int j = 0; j < KS; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(tbuf + 1024 * j), 16,
-                                               v0 + 1024u * j, 0, 0, 0);
-  };
-  u32x4 xn[PREFETCH && !DMA ? KS : 1];
-  const int from_mem = 4 * (2 * (lane & 31) + h);              // bpermute address: the memory-order lane an MFMA-order lane reads
-  const int from_mfma = 4 * ((lane >> 1) + 32 * (lane & 1));   // ... and the MFMA-order lane a memory-order lane reads
-  auto perm4 = [&](int addr, const u32x4& v) -> u32x4 {
-    return u32x4{static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(addr, v.x)),
-                 static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(addr, v.y)),
-                 static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(addr, v.z)),
-                 static_cast<unsigned int>(__builtin_amdgcn_ds_bpermute(addr, v.w))};
-  };
-  auto mem_row = [&](long long tile) -> long long {
-    const long long pix = tile * 32 + (lane >> 1);
-    return (pix < p.pixels ? pix : p.pixels - 1) * C + 8 * (lane & 1);
-  };
+  u32x4 xn[PREFETCH ? KS : 1];
   auto fetch = [&](long long tile) {
-#if TFC_GDN_PAIRS & 1
-    {
-      const long long mrow = mem_row(tile);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = *reinterpret_cast<const u32x4*>(x + mrow + 16 * s);
-      return;
-    }
-#endif
 #if defined(TFC_GDN_EXP) && (TFC_GDN_EXP & 2)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = u32x4{lane + 0x3f803f80u, static_cast<unsigned int>(tile), 0x3f803f80u, 0x40004000u};   // (timing: no loads)
+    for (int s = 0; s < KS; ++s) xn[PREFETCH ? s : 0] = u32x4{lane + 0x3f803f80u, static_cast<unsigned int>(tile), 0x3f803f80u, 0x40004000u};   // (timing: no loads)
     return;
 #endif
     const long long pix = tile * 32 + (lane & 31);
     const long long row = (pix < p.pixels ? pix : p.pixels - 1) * C;
 #pragma unroll
-#if defined(TFC_GDN_NT) && (TFC_GDN_NT & 2)
-    for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h));
-#else
-    for (int s = 0; s < KS; ++s) xn[PREFETCH && !DMA ? s : 0] = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
-#endif
+    for (int s = 0; s < KS; ++s) xn[PREFETCH ? s : 0] = *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
   };
   {
     // fragment image (built once per call by gdn_prep_bf16_kernel): linear 16-byte copy.  Its loads are
@@ -260,19 +215,17 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
     const u32x4* src = static_cast<const u32x4*>(p.image);
     u32x4* dstv = reinterpret_cast<u32x4*>(smem);
     constexpr int n16 = KT * KS * 64 + (C * 4) / 16;
-    constexpr int NTH = DMA ? 64 * gdn_dma_waves<KT>() : 512;   // threads the kernel is launched with
-    constexpr int PER = (n16 + NTH - 1) / NTH;
+    constexpr int PER = (n16 + 511) / 512;   // the kernel is launched with 512 threads
     u32x4 img[PER];
-    if (DMA && wave < p.tiles) dma_tile(wave);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = threadIdx.x + k * NTH;
+      const int i = threadIdx.x + k * 512;
       if (i < n16) img[k] = src[i];
     }
-    if (PREFETCH && !DMA && wave < p.tiles) fetch(wave);
+    if (PREFETCH && wave < p.tiles) fetch(wave);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = threadIdx.x + k * NTH;
+      const int i = threadIdx.x + k * 512;
       if (i < n16) dstv[i] = img[k];
     }
   }
@@ -284,29 +237,18 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
     const long long row = (live ? pix : p.pixels - 1) * C;
     // ---- loads: after the swap, K-step s holds channels 16s+4h+{0..3} and 16s+4h+8+{0..3} ----
     u32x4 xr[KS];
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed in the wave's buffer
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       // One 16-byte load per lane (channels 16s + 8h + 0..7), then v_permlane32_swap trades
       // the inner halves between lanes l and l+32 so that the lane ends up with channels
       // 16s + 4h + {0..3} and 16s + 4h + 8 + {0..3} — twice the bytes per cache line touched
       // by one load instruction compared with two 8-byte loads.
-#if TFC_GDN_PAIRS & 1
-      const u32x4 v = perm4(from_mem, PREFETCH ? xn[PREFETCH && !DMA ? s : 0] : *reinterpret_cast<const u32x4*>(x + mem_row(tile) + 16 * s));
-#else
-      const u32x4 v = DMA ? *reinterpret_cast<const u32x4*>(tbuf + (lane & 31) * (2 * C) + 32 * s + 16 * h)
-                          : PREFETCH ? xn[PREFETCH && !DMA ? s : 0] : *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
-#endif
+      const u32x4 v = PREFETCH ? xn[PREFETCH ? s : 0] : *reinterpret_cast<const u32x4*>(x + row + 16 * s + 8 * h);
       const auto s0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
       const auto s1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
       xr[s] = u32x4{s0[0], s1[0], s0[1], s1[1]};
     }
-    if constexpr (DMA) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer is read out: the next tile may land in it
-      if (tile + nwaves < p.tiles) dma_tile(tile + nwaves);
-    } else if (PREFETCH && tile + nwaves < p.tiles) {
-      fetch(tile + nwaves);
-    }
+    if (PREFETCH && tile + nwaves < p.tiles) fetch(tile + nwaves);
     f32x16 acc[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
@@ -352,7 +294,7 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
       const auto s1 = __builtin_amdgcn_permlane32_swap(out.y, out.w, false, false);
       if constexpr (LINES) {
         // (this lane: channels 16 s + 8 h + {0 .. 7} of pixel lane & 31 = granule 2 (s & 3) + h of the pixel's line s >> 2)
-        unsigned char* const ost = smem + ((IMG_BYTES + 15) & ~15) + DMA * 0 + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * 4096;
+        unsigned char* const ost = smem + ((IMG_BYTES + 15) & ~15) + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * 4096;
         auto slot = [&](int pix, int g) -> unsigned char* { return ost + pix * 128 + ((g ^ ((pix >> 1) & 7)) << 4); };
         auto wave_sync = [&]() __attribute__((always_inline)) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -393,13 +335,7 @@ __global__ void __launch_bounds__(512) gdn_fwd_bf16_kernel(GdnParams p) {
         }
         return;
       }
-#if TFC_GDN_PAIRS & 2
-      const u32x4 m = perm4(from_mfma, u32x4{s0[0], s1[0], s0[1], s1[1]});
 #if defined(TFC_GDN_EXP) && (TFC_GDN_EXP & 1)
-      if (m.x == 0x12345u)
-#endif
-      if (tile * 32 + (lane >> 1) < p.pixels) *reinterpret_cast<u32x4*>(base + mem_row(tile) + 16 * s) = m;
-#elif defined(TFC_GDN_EXP) && (TFC_GDN_EXP & 1)
       if (live && s0[0] == 0x12345u) *reinterpret_cast<u32x4*>(base + row + 16 * s + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};   // (timing: no stores)
 #else
       if (live) *reinterpret_cast<u32x4*>(base + row + 16 * s + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
@@ -660,20 +596,10 @@ int launch_gdn_variant(GdnParams p, int dtype, hipStream_t st) {
       p.nt_store = nt_env >= 0 ? nt_env : (static_cast<long long>(p.pixels) * KT * 32 * 4 > (128ll << 20) ? 1 : 0);
     }
     const size_t lds_lines = TFC_GDN_LINES != 0 && MODE == MODE_FWD && KT <= 7 ? ((lds + 15) & ~size_t{15}) + static_cast<size_t>(waves_per_block) * 4096 : lds;
-    constexpr bool DMA = TFC_GDN_DMA != 0 && MODE == MODE_FWD && (KT <= 5 || (PLAIN && KT == 6));
-    if (DMA && static_cast<long long>(p.pixels) * KT * 64 < (1ll << 31)) {
-      constexpr int W = gdn_dma_waves<KT>();
-      const size_t lds_dma = lds + static_cast<size_t>(W) * KT * 2048;
-      const unsigned blocks_dma = static_cast<unsigned>(std::max<long long>(1, std::min<long long>(ceil_div(p.tiles, W), cus)));
-      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_dma)));
-      hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>), dim3(blocks_dma), dim3(64 * W), lds_dma, st, p);
-    } else {
     TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_lines)));
     hipLaunchKernelGGL((gdn_fwd_bf16_kernel<KT, MODE, PLAIN, GEN>), dim3(blocks), dim3(64 * waves_per_block), lds_lines,
                        st, p);
-    }
    } else {
     return fail("tfc_gdn: bfloat16 kernel not built for this configuration");
    }
