@@ -344,6 +344,18 @@ constexpr int PG_STRIDE = 72;     // bf16 elements per transposed LDS row (144 B
 #endif
 template <typename T, int KT>
 constexpr int pg_wgs() { return (sizeof(T) == 2 && KT <= 6) ? TFC_GDN_PG_WGS : 1; }
+// TFC_GDN_PG_TR (round 6, bf16): the stage stays ROW-MAJOR in LDS ([pixel][channel], rows padded so that the reads below are
+// conflict-free) — a thread's 16-byte pieces go global -> registers -> LDS as they are, linear on both sides — and the MFMA
+// operands, whose K runs over pixels, are read with ds_read_b64_tr_b16: every lane gives the address of four consecutive
+// channels of one pixel, and within a group of 16 lanes (4 pixels x 16 channels) lane c receives the 4 pixels of channel c
+// (checked on the device: tools/ubench/tr_read_probe.hip).  Two reads = the 8 K values of a 32x32x16 operand.  dbeta comes
+// out of the matrix cores too: a row of ones against the T operand.  (Before: the transpose by hand, per 16-byte piece two
+// DPP moves, four byte permutes, eight selects and four ds_write_b32, and a gather of 32 lines per load instruction.)
+#ifndef TFC_GDN_PG_TR
+#define TFC_GDN_PG_TR 1
+#endif
+template <int C>
+constexpr int pg_row_elems() { return C + 2 * (((16 - (C / 2) % 32) + 32) % 32); }      // row stride in dwords = 16 mod 32
 template <typename T, int KT>
 __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(GdnParams p, float* partial) {
   constexpr int C = KT * 32;
@@ -353,6 +365,10 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
   // bf16: uT[C][PG_STRIDE], tT[C][PG_STRIDE] (u16); f32: us[PG_PIX][C], ts[PG_PIX][C] (float)
   unsigned short* uT = reinterpret_cast<unsigned short*>(smem);
   unsigned short* tT = uT + C * PG_STRIDE;
+  constexpr bool TR = BF && TFC_GDN_PG_TR != 0 && KT <= 6;      // (224 / 256 channels: no registers for the ones-row products)
+  constexpr int RS = pg_row_elems<C>();                 // TR: us[PG_PIX][RS], ts[PG_PIX][RS] (u16)
+  unsigned short* const usr = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* const tsr = usr + PG_PIX * RS;
   float* us = reinterpret_cast<float*>(smem);
   float* ts = us + PG_PIX * C;
 
@@ -369,6 +385,11 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bsum = 0.f;
+  f32x16 accb[NH];          // (TR) the ones-row products: every row of accb[b] is the column sums of T's tile wi + 2 b
+#pragma unroll
+  for (int b = 0; b < NH; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[b][r] = 0.f;
 
   // Software pipeline: the next stage's global loads are issued into registers before the MFMAs
   // of the current one and written to LDS after them.
@@ -388,8 +409,8 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int c = tid + 256 * k;
-      const int px = BF ? 2 * ((tid >> 2) & 31) + ((tid >> 1) & 1) : (c / (C / 4));
-      const int off = BF ? 8 * (2 * ((tid >> 7) + 2 * k) + (tid & 1)) : 4 * (c % (C / 4));
+      const int px = TR ? c / (C / 8) : BF ? 2 * ((tid >> 2) & 31) + ((tid >> 1) & 1) : (c / (C / 4));
+      const int off = TR ? 8 * (c % (C / 8)) : BF ? 8 * (2 * ((tid >> 7) + 2 * k) + (tid & 1)) : 4 * (c % (C / 4));
       xq[k] = u32x4{0, 0, 0, 0};
       tq[k] = u32x4{0, 0, 0, 0};
       if (p0 + px < p.pixels) {
@@ -405,7 +426,22 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int c = tid + 256 * k;
-      if (BF) {
+      if (TR) {
+        const int px = c / (C / 8), cg = c % (C / 8);
+        u32x4 uv = xq[k];
+        if (plain) {
+          uv &= 0x7FFF7FFFu;
+        } else {
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) {
+            const float lo = fmaxf(bf16_bits_to_float(uv[w2] & 0xFFFFu), relu_floor);
+            const float hi = fmaxf(__uint_as_float(uv[w2] & 0xFFFF0000u), relu_floor);
+            uv[w2] = pack_bf16(gdn_u(lo, a2), gdn_u(hi, a2));
+          }
+        }
+        *reinterpret_cast<u32x4*>(usr + px * RS + 8 * cg) = uv;
+        *reinterpret_cast<u32x4*>(tsr + px * RS + 8 * cg) = tq[k];
+      } else if (BF) {
         const int px = 2 * ((tid >> 2) & 31) + ((tid >> 1) & 1), cg = 2 * ((tid >> 7) + 2 * k) + (tid & 1);
         u32x4 uv = xq[k];
         if (plain) {
@@ -456,8 +492,8 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
     stage_to_lds();
     __syncthreads();
     if (st + gridDim.x < stages) fetch(st + gridDim.x);
-    // dbeta: thread c sums column c of the staged T tile
-    if (tid < C) {
+    // dbeta: thread c sums column c of the staged T tile (TR: the matrix cores do, below)
+    if (!TR && tid < C) {
       if (BF) {
 #pragma unroll
         for (int k = 0; k < PG_PIX / 8; ++k) {
@@ -470,7 +506,56 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
         for (int k = 0; k < PG_PIX; ++k) bsum += ts[k * C + tid];
       }
     }
-    if (BF) {
+    if (TR) {
+      // this lane's chunk of tile 0, K step 0, first half: pixel 8 (g >> 1) + (j >> 2), channels 16 (g & 1) + 4 (j & 3) ...
+      const int g = lane >> 4, j = lane & 15;
+      const unsigned int lane_off = static_cast<unsigned int>(((8 * (g >> 1) + (j >> 2)) * RS + 16 * (g & 1) + 4 * (j & 3)) * 2);
+      const unsigned int ubase = static_cast<unsigned int>(reinterpret_cast<size_t>(usr)) + lane_off;
+      const unsigned int tbase = static_cast<unsigned int>(reinterpret_cast<size_t>(tsr)) + lane_off;
+      // (the reads of K step ks + 1 are issued in front of the MFMAs of K step ks; the compiler does not count these reads:
+      // one wait per K step, tied to the registers they fill)
+      u32x2 ra[2][NH][2], rb[2][NH][2];
+      // (plain unrolled code: a generic lambda does not capture variables that only inline-asm operands name)
+#define TFC_PG_REQUEST(S, KS)                                                                                        \
+      _Pragma("unroll") for (int a = 0; a < NH; ++a)                                                                 \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                           \
+          const int jt = wj + 2 * a, it = wi + 2 * a;                                                                \
+          const unsigned int rowoff = static_cast<unsigned int>(((16 * (KS) + 4 * hf) * RS) * 2);                    \
+          ra[S][a][hf] = u32x2{0u, 0u};                                                                              \
+          rb[S][a][hf] = u32x2{0u, 0u};                                                                              \
+          if (jt < KT) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ra[S][a][hf]) : "v"(ubase + rowoff + 64u * jt)); \
+          if (it < KT) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(rb[S][a][hf]) : "v"(tbase + rowoff + 64u * it)); \
+        }
+      TFC_PG_REQUEST(0, 0)
+#pragma unroll
+      for (int ks = 0; ks < PG_PIX / 16; ++ks) {
+        const int S = ks & 1;
+#pragma unroll
+        for (int a = 0; a < NH; ++a)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[S][a][0]), "+v"(ra[S][a][1]), "+v"(rb[S][a][0]), "+v"(rb[S][a][1]) : : "memory");
+        if (ks + 1 < PG_PIX / 16) { TFC_PG_REQUEST(S ^ 1, ks + 1) }
+        bf16x8 af[NH], bfr[NH];
+#pragma unroll
+        for (int a = 0; a < NH; ++a) {
+          af[a] = __builtin_bit_cast(bf16x8, u32x4{ra[S][a][0].x, ra[S][a][0].y, ra[S][a][1].x, ra[S][a][1].y});
+          bfr[a] = __builtin_bit_cast(bf16x8, u32x4{rb[S][a][0].x, rb[S][a][0].y, rb[S][a][1].x, rb[S][a][1].y});
+        }
+#pragma unroll
+        for (int a = 0; a < NH; ++a)
+#pragma unroll
+          for (int b = 0; b < NH; ++b)
+            if (wj + 2 * a < KT && wi + 2 * b < KT)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        // dbeta[i] = sum over the pixels of T[., i]: a row of ones as the A operand (the waves of the first j parity)
+        if (wj == 0) {
+          const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+#pragma unroll
+          for (int b = 0; b < NH; ++b)
+            if (wi + 2 * b < KT) accb[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[b], accb[b], 0, 0, 0);
+        }
+      }
+#undef TFC_PG_REQUEST
+    } else if (BF) {
 #pragma unroll
       for (int ks = 0; ks < PG_PIX / 16; ++ks) {
         bf16x8 af[NH], bfr[NH];
@@ -520,7 +605,15 @@ __global__ void __launch_bounds__(256, (pg_wgs<T, KT>())) gdn_param_grad_kernel(
         }
       }
     }
-  if (tid < C) out[C * C + tid] = bsum;
+  if (TR) {
+    if (wj == 0 && h == 0) {
+#pragma unroll
+      for (int b = 0; b < NH; ++b)
+        if (wi + 2 * b < KT) out[C * C + 32 * (wi + 2 * b) + i32] = accb[b][0];
+    }
+  } else if (tid < C) {
+    out[C * C + tid] = bsum;
+  }
 }
 
 template <typename T, int KT>
@@ -531,7 +624,9 @@ int launch_param_grad(GdnParams p, float* dgamma, float* dbeta, hipStream_t st) 
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const long long stages = ceil_div(p.pixels, static_cast<long long>(PG_PIX));
   const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(stages, pg_wgs<T, KT>() * cus)));
-  const size_t lds = sizeof(T) == 2 ? sizeof(unsigned short) * 2 * C * PG_STRIDE : sizeof(float) * 2 * PG_PIX * C;
+  const size_t lds = sizeof(T) == 2 ? (TFC_GDN_PG_TR != 0 && KT <= 6 ? sizeof(unsigned short) * 2 * PG_PIX * pg_row_elems<C>()
+                                                           : sizeof(unsigned short) * 2 * C * PG_STRIDE)
+                                    : sizeof(float) * 2 * PG_PIX * C;
   DevBuf partial;
   TFC_HIP(partial.alloc(sizeof(float) * static_cast<size_t>(blocks) * (C * C + C), st));
   KernelTimer timer("gdn_backward_params", st);   // gradient kernel + the reduction of its partials
