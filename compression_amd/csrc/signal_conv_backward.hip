@@ -42,10 +42,29 @@ struct WgradGeom {
   int kh, kw, stride;
   int chunks;            // workgroups per tap
   float* partial;        // [kh*kw][chunks][CA][CB]
+  unsigned int wb_mul, wb_sh, hb_mul, hb_sh;      // n / WB, n / HB as multiplications (wg_fast_div)
+  int tr;                // bf16, both tensors wide, < 2^31 pixels: row-major stages + ds_read_b64_tr_b16 (below)
 };
 
+// n / d for 0 <= n < 2^31 as a multiplication (signal_conv.hip fast_div): mul = ceil(2^(31 + s) / d), s = ceil(log2 d)
+inline void wg_fast_div_setup(unsigned int d, unsigned int* mul, unsigned int* sh) {
+  if (d <= 1) { *mul = 0; *sh = 0; return; }
+  unsigned int s = 0;
+  while ((1ull << s) < d) ++s;
+  *mul = static_cast<unsigned int>(((1ull << (31 + s)) + d - 1) / d);
+  *sh = s - 1;
+}
+__device__ inline unsigned int wg_fast_div(unsigned int n, unsigned int mul, unsigned int sh) {
+  return mul ? __umulhi(n, mul) >> sh : n;
+}
+// Row stride (elements) of a row-major bf16 stage in LDS whose rows ds_read_b64_tr_b16 reads without bank conflicts:
+// stride in dwords = 16 mod 32 (gdn_backward.hip pg_row_elems).
+template <int C>
+constexpr int wg_row_elems() { return C + 2 * (((16 - (C / 2) % 32) + 32) % 32); }
+typedef __attribute__((ext_vector_type(2))) unsigned int wg_u32x2;
+
 // KTA / KTB = 32-channel tiles of A / B (1 with CA <= 4 = narrow tensor)
-template <typename T, int KTA, int KTB>
+template <typename T, int KTA, int KTB, bool TRB = false>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int RA = KTA * 32, RB = KTB * 32;          // LDS rows
@@ -56,6 +75,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
   unsigned short* bT = aT + RA * WG_STRIDE;
   float* as = reinterpret_cast<float*>(smem);
   float* bs = as + WG_PIX * RA;
+  // TR (round 6; g.tr): the stages stay ROW-MAJOR in LDS — a thread's 16-byte pieces go global -> registers -> LDS as they
+  // are, a load instruction 1 KB contiguous wherever the tap leaves A's rows contiguous — and the MFMA operands, whose K runs
+  // over pixels, are read with ds_read_b64_tr_b16 (gdn_backward.hip TFC_GDN_PG_TR; tools/ubench/tr_read_probe.hip).  The
+  // pixel -> (image, row, column) arithmetic is 32-bit with the divisions as multiplications (it was three 64-bit
+  // divisions per stage and thread).
+  constexpr int RSA = wg_row_elems<RA>(), RSB = wg_row_elems<RB>();
+  unsigned short* const asr = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* const bsr = asr + WG_PIX * RSA;
+  constexpr bool tr = TRB;          // (a build of its own: with both stagings in one kernel the registers ran out)
+  static_assert(!TRB || BF, "transposing reads: bfloat16");
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wa = w >> 1, wb = w & 1, i32 = lane & 31, h = lane >> 5;
@@ -98,6 +127,32 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
   u32x4 aq[NA], bq[NB];
   auto fetch = [&](long long st) {
     const long long m0 = st * WG_PIX;
+    if constexpr (BF && tr) {
+      const unsigned int m32 = static_cast<unsigned int>(m0), M32 = static_cast<unsigned int>(M);
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const int c = tid + 256 * k;
+        const unsigned int m = m32 + static_cast<unsigned int>(c / (RA / 8));
+        const int cg = c % (RA / 8);
+        long long ra = -1;
+        if (m < M32) {
+          const unsigned int r1 = wg_fast_div(m, g.wb_mul, g.wb_sh);              // n * HB + qy
+          const int qx = static_cast<int>(m - r1 * static_cast<unsigned int>(g.WB));
+          const unsigned int n1 = wg_fast_div(r1, g.hb_mul, g.hb_sh);
+          const int qy = static_cast<int>(r1 - n1 * static_cast<unsigned int>(g.HB));
+          const int iy = qy * g.stride + ty - g.kh / 2, ix = qx * g.stride + tx - g.kw / 2;
+          if (iy >= 0 && iy < g.HA && ix >= 0 && ix < g.WA) ra = (static_cast<long long>(n1) * g.HA + iy) * g.WA + ix;
+        }
+        aq[k] = ra >= 0 ? *reinterpret_cast<const u32x4*>(A + ra * g.CA + 8 * cg) : u32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int c = tid + 256 * k;
+        const unsigned int m = m32 + static_cast<unsigned int>(c / (RB / 8));
+        bq[k] = m < M32 ? *reinterpret_cast<const u32x4*>(B + static_cast<long long>(m) * g.CB + 8 * (c % (RB / 8))) : u32x4{0, 0, 0, 0};
+      }
+      return;
+    }
     if (!narrowA) {
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
@@ -155,6 +210,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
     }
   };
   auto stage_to_lds = [&](long long st) {
+    if constexpr (BF && tr) {
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const int c = tid + 256 * k;
+        *reinterpret_cast<u32x4*>(asr + (c / (RA / 8)) * RSA + 8 * (c % (RA / 8))) = aq[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int c = tid + 256 * k;
+        *reinterpret_cast<u32x4*>(bsr + (c / (RB / 8)) * RSB + 8 * (c % (RB / 8))) = bq[k];
+      }
+      return;
+    }
     if (narrowA) {
       stage_narrow(A, g.CA, true, st);
     } else {
@@ -184,7 +252,57 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
     stage_to_lds(st);
     __syncthreads();
     if (st + g.chunks < stages) fetch(st + g.chunks);
-    if (BF) {
+    if constexpr (BF && tr) {
+      // this lane's chunk of tile 0, K step 0, first half: pixel 8 (grp >> 1) + (j >> 2), channels 16 (grp & 1) + 4 (j & 3) ...
+      const int grp = lane >> 4, j = lane & 15;
+      const unsigned int abase = static_cast<unsigned int>(reinterpret_cast<size_t>(asr)) +
+                                 static_cast<unsigned int>(((8 * (grp >> 1) + (j >> 2)) * RSA + 16 * (grp & 1) + 4 * (j & 3)) * 2);
+      const unsigned int bbase = static_cast<unsigned int>(reinterpret_cast<size_t>(bsr)) +
+                                 static_cast<unsigned int>(((8 * (grp >> 1) + (j >> 2)) * RSB + 16 * (grp & 1) + 4 * (j & 3)) * 2);
+      wg_u32x2 ra2[2][NHA][2], rb2[2][NHB][2];
+      // (the reads of K step ks + 1 are issued in front of the MFMAs of K step ks; the compiler does not count these reads:
+      // a wait per K step, tied to the registers they fill.  Plain unrolled code: a generic lambda does not capture
+      // variables that only inline-asm operands name)
+#define TFC_WG_REQUEST(S, KS)                                                                                             \
+      _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                                  \
+        _Pragma("unroll") for (int a = 0; a < NHA; ++a) {                                                                 \
+          ra2[S][a][hf] = wg_u32x2{0u, 0u};                                                                               \
+          if (wa + 2 * a < KTA)                                                                                           \
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ra2[S][a][hf])                                               \
+                         : "v"(abase + static_cast<unsigned int>(((16 * (KS) + 4 * hf) * RSA) * 2) + 64u * (wa + 2 * a))); \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int b = 0; b < NHB; ++b) {                                                                 \
+          rb2[S][b][hf] = wg_u32x2{0u, 0u};                                                                               \
+          if (wb + 2 * b < KTB)                                                                                           \
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(rb2[S][b][hf])                                               \
+                         : "v"(bbase + static_cast<unsigned int>(((16 * (KS) + 4 * hf) * RSB) * 2) + 64u * (wb + 2 * b))); \
+        }                                                                                                                 \
+      }
+      TFC_WG_REQUEST(0, 0)
+#pragma unroll
+      for (int ks = 0; ks < WG_PIX / 16; ++ks) {
+        const int S = ks & 1;
+#pragma unroll
+        for (int a = 0; a < NHA; ++a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra2[S][a][0]), "+v"(ra2[S][a][1]) : : "memory");
+#pragma unroll
+        for (int b = 0; b < NHB; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb2[S][b][0]), "+v"(rb2[S][b][1]) : : "memory");
+        if (ks + 1 < WG_PIX / 16) { TFC_WG_REQUEST(S ^ 1, ks + 1) }
+        bf16x8 af[NHA], bfr[NHB];
+#pragma unroll
+        for (int a = 0; a < NHA; ++a)
+          af[a] = __builtin_bit_cast(bf16x8, u32x4{ra2[S][a][0].x, ra2[S][a][0].y, ra2[S][a][1].x, ra2[S][a][1].y});
+#pragma unroll
+        for (int b = 0; b < NHB; ++b)
+          bfr[b] = __builtin_bit_cast(bf16x8, u32x4{rb2[S][b][0].x, rb2[S][b][0].y, rb2[S][b][1].x, rb2[S][b][1].y});
+#pragma unroll
+        for (int a = 0; a < NHA; ++a)
+#pragma unroll
+          for (int b = 0; b < NHB; ++b)
+            if (wa + 2 * a < KTA && wb + 2 * b < KTB)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+#undef TFC_WG_REQUEST
+    } else if (BF) {
 #pragma unroll
       for (int ks = 0; ks < WG_PIX / 16; ++ks) {
         bf16x8 af[NHA], bfr[NHB];
@@ -260,18 +378,39 @@ int launch_wgrad(WgradGeom g, int transpose, float* dw, hipStream_t st) {
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int taps = g.kh * g.kw;
   const long long stages = ceil_div(g.N * g.HB * g.WB, static_cast<long long>(WG_PIX));
-  g.chunks = static_cast<int>(std::max<long long>(1, std::min<long long>(stages, ceil_div(2 * cus, taps))));
+  // taps x chunks workgroups: at most two per CU, and not a few more than that (525 workgroups on 256 CUs, one resident
+  // per CU, were three rounds of which the last ran 13)
+  g.chunks = static_cast<int>(std::max<long long>(1, std::min<long long>(stages, (2 * cus) / taps)));
   DevBuf partial;
   TFC_HIP(partial.alloc(sizeof(float) * static_cast<size_t>(taps) * g.chunks * g.CA * g.CB, st));
   g.partial = partial.as<float>();
-  const size_t lds = sizeof(T) == 2 ? sizeof(unsigned short) * (KTA + KTB) * 32 * WG_STRIDE
-                                    : sizeof(float) * WG_PIX * (KTA + KTB) * 32;
+  size_t lds = sizeof(T) == 2 ? sizeof(unsigned short) * (KTA + KTB) * 32 * WG_STRIDE
+                              : sizeof(float) * WG_PIX * (KTA + KTB) * 32;
+  {
+    // TFC_WGRAD_TR = 0: the transpose by hand (the round-5 staging)
+    static const bool tr_on = [] { const char* e = std::getenv("TFC_WGRAD_TR"); return !(e && e[0] == '0'); }();
+    g.tr = tr_on && sizeof(T) == 2 && g.CA >= 32 && g.CB >= 32 && g.N * g.HB * g.WB < (1ll << 31) ? 1 : 0;
+    wg_fast_div_setup(static_cast<unsigned int>(g.WB), &g.wb_mul, &g.wb_sh);
+    wg_fast_div_setup(static_cast<unsigned int>(g.HB), &g.hb_mul, &g.hb_sh);
+    if (g.tr)
+      lds = std::max(lds, sizeof(unsigned short) * WG_PIX * (wg_row_elems<KTA * 32>() + wg_row_elems<KTB * 32>()));
+  }
   {
     KernelTimer timer("conv2d_wgrad", st);
-    TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, KTA, KTB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, KTA, KTB>), dim3(static_cast<unsigned>(taps * g.chunks)), dim3(256),
-                       lds, st, g);
+    if constexpr (sizeof(T) == 2) {
+      if (g.tr) {
+        TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, KTA, KTB, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL((conv_wgrad_kernel<T, KTA, KTB, true>), dim3(static_cast<unsigned>(taps * g.chunks)), dim3(256),
+                           lds, st, g);
+      }
+    }
+    if (!g.tr) {
+      TFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, KTA, KTB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL((conv_wgrad_kernel<T, KTA, KTB>), dim3(static_cast<unsigned>(taps * g.chunks)), dim3(256),
+                         lds, st, g);
+    }
   }
   const long long n = static_cast<long long>(taps) * g.CA * g.CB;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
