@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
   const T* B = static_cast<const T*>(g.B);
   const long long M = g.N * g.HB * g.WB;
   const bool narrowA = g.CA < 32, narrowB = g.CB < 32;
+  const bool small = M < (1ll << 31);
 
   f32x16 acc[NHA][NHB];
 #pragma unroll
@@ -108,9 +109,20 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom g) {
     *rowB = m < M ? m : -1;
     *rowA = -1;
     if (m < M) {
-      const int qx = static_cast<int>(m % g.WB);
-      const int qy = static_cast<int>((m / g.WB) % g.HB);
-      const long long n = m / (static_cast<long long>(g.WB) * g.HB);
+      int qx, qy;
+      long long n;
+      if (small) {          // (< 2^31 pixels: the divisions as multiplications — a 64-bit division is ~150 instructions)
+        const unsigned int m32 = static_cast<unsigned int>(m);
+        const unsigned int r1 = wg_fast_div(m32, g.wb_mul, g.wb_sh);
+        qx = static_cast<int>(m32 - r1 * static_cast<unsigned int>(g.WB));
+        const unsigned int n1 = wg_fast_div(r1, g.hb_mul, g.hb_sh);
+        qy = static_cast<int>(r1 - n1 * static_cast<unsigned int>(g.HB));
+        n = n1;
+      } else {
+        qx = static_cast<int>(m % g.WB);
+        qy = static_cast<int>((m / g.WB) % g.HB);
+        n = m / (static_cast<long long>(g.WB) * g.HB);
+      }
       const int iy = qy * g.stride + ty - g.kh / 2, ix = qx * g.stride + tx - g.kw / 2;
       if (iy >= 0 && iy < g.HA && ix >= 0 && ix < g.WA) *rowA = (n * g.HA + iy) * g.WA + ix;
     }
