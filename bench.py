@@ -1002,6 +1002,64 @@ def conv_layer_table(device, batch=128):
     return {"workload": f"SignalConv2D layer shapes of bmshj2018 at {batch} x 768x512, bf16", "layers": rows}
 
 
+def training_figures(device):
+    """SURVEY 8(f) row 2, the training-time path: one bls2017 training step (forward, backward through every HIP kernel,
+    Adam) at 16 x 256x256 bf16 — wall time per step and the library's kernel split (tfc_profile_enable) — and the
+    weight-gradient kernel alone on the 5x5 / 2 192 -> 192 layer at 16 x 384x256."""
+    from compression_amd import models
+    from compression_amd.layers.functional import conv2d_wgrad
+    torch.manual_seed(0)
+    model = models.BLS2017Model(lmbda=0.01, num_filters=192, compute_dtype=torch.bfloat16).to(device)
+    x = torch.from_numpy(synthetic.lowpass_images(8, 256, 256, seed=3)).to(device).repeat(2, 1, 1, 1)
+    model(x)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad()
+        loss, _, _ = model(x, training=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n
+    _lib.lib().tfc_profile_enable(1)
+    step()
+    torch.cuda.synchronize()
+    split = {}
+    for name in ("conv2d", "conv2d_wgrad", "gdn_forward", "gdn_backward_fused", "gdn_backward_params",
+                 "factorized_forward", "factorized_backward"):
+        ms, cnt = profile_query(name)
+        if cnt:
+            split[name] = round(ms, 3)
+    _lib.lib().tfc_profile_enable(0)
+    del model, opt
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    a = torch.randn(16, 256, 384, 192, generator=gen).to(torch.bfloat16).to(device)
+    b = torch.randn(16, 128, 192, 192, generator=gen).to(torch.bfloat16).to(device)
+    conv2d_wgrad(a, b, (5, 5), 2, False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        conv2d_wgrad(a, b, (5, 5), 2, False)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    flops = 2.0 * 16 * 128 * 192 * 25 * 192 * 192
+    return {"workload": "bls2017 training step (forward + backward + Adam), 16 x 256x256, bf16, synthetic images",
+            "ms_per_step": round(1e3 * wall, 3), "mpixels_s": round(16 * 256 * 256 / 1e6 / wall, 1),
+            "kernels_ms": split, "note": "wall time of a host-driven step; kernels_ms = the library's launches of one step",
+            "wgrad_5x5_s2_192_192_at_16x384x256": {"ms": round(ms, 3), "tflops": round(flops / 1e12 / (ms / 1e3), 1),
+                                                   "frac_of_2500": round(flops / 1e12 / (ms / 1e3) / 2500.0, 4)}}
+
+
 def model_group(args, workload):
     return args.model_group if args.model_group > 0 else (8 if workload == "bmshj2018" else 1)
 
@@ -1619,6 +1677,9 @@ def main():
                                                  out.get("cpu_baseline", {}).get("value"), fold=True)}
             torch.cuda.empty_cache()
             out["conv"] = conv_layer_table(device)
+            torch.cuda.empty_cache()
+            out["training"] = training_figures(device)
+            torch.cuda.empty_cache()
             out["models"] = {}
             for name, key in (("bls2017", "c1"), ("bmshj2018", "c4")):
                 torch.cuda.empty_cache()

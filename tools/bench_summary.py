@@ -28,3 +28,7 @@ for r in d.get("conv", {}).get("layers", []):
     print(r)
 if "escapes" in d:
     print("escapes", d["escapes"]["0.01"]["value"], d["escapes"]["escape_free"]["value"])
+if "training" in d:
+    t = d["training"]
+    print("training", t["ms_per_step"], t["kernels_ms"], t["wgrad_5x5_s2_192_192_at_16x384x256"])
+
