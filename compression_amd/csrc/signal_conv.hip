@@ -91,6 +91,10 @@ struct ConvGeom {
   const void* gdn_image;
   int xcd;                  // 1: the third-generation kernel's workgroups take their blocks in XCD order (xcd_order)
   int nt_out;               // third generation: the output's whole-line stores non-temporal (an output beyond the caches)
+  // first / second generation: pixel -> (image, row, column) with the divisions as multiplications where the launch has
+  // fewer than 2^31 low-resolution pixels (pix32; fast_div by OWq, OHq)
+  unsigned int owq_mul, owq_sh, ohq_mul, ohq_sh;
+  int pix32;
 };
 
 // Third-generation kernel: a workgroup computes an 8 x 32 block of low-resolution output pixels of ONE image
@@ -349,9 +353,20 @@ __global__ void __launch_bounds__(64 * kConvWaves) conv_kernel(const T* x, const
   const long long m = (pblock * kConvWaves + wid) * 32 + (lane & 31);
   const bool live = m < M;
   const long long mm = live ? m : M - 1;
-  const int qx = mm % c.OWq;
-  const int qy = (mm / c.OWq) % c.OHq;
-  const long long n = mm / (static_cast<long long>(c.OWq) * c.OHq);
+  int qx, qy;
+  long long n;
+  if (c.pix32) {          // (a 64-bit division is ~150 instructions in front of the first request)
+    const unsigned int m32 = static_cast<unsigned int>(mm);
+    const unsigned int r1 = fast_div(m32, c.owq_mul, c.owq_sh);
+    qx = static_cast<int>(m32 - r1 * static_cast<unsigned int>(c.OWq));
+    const unsigned int n1 = fast_div(r1, c.ohq_mul, c.ohq_sh);
+    qy = static_cast<int>(r1 - n1 * static_cast<unsigned int>(c.OHq));
+    n = n1;
+  } else {
+    qx = mm % c.OWq;
+    qy = (mm / c.OWq) % c.OHq;
+    n = mm / (static_cast<long long>(c.OWq) * c.OHq);
+  }
 
   f32x16 acc[TILES];
 #pragma unroll
@@ -556,9 +571,18 @@ __global__ void __launch_bounds__(256, TFC_CONV_WGS) conv_bf16_kernel(const __bf
     const long long m = ((pblock * 4 + wid) * MT + p) * 32 + (lane & 31);
     live[p] = m < M;
     mm[p] = live[p] ? m : M - 1;
-    qx[p] = static_cast<int>(mm[p] % c.OWq);
-    qy[p] = static_cast<int>((mm[p] / c.OWq) % c.OHq);
-    nn[p] = mm[p] / (static_cast<long long>(c.OWq) * c.OHq);
+    if (c.pix32) {          // (a 64-bit division is ~150 instructions in front of the first request)
+      const unsigned int m32 = static_cast<unsigned int>(mm[p]);
+      const unsigned int r1 = fast_div(m32, c.owq_mul, c.owq_sh);
+      qx[p] = static_cast<int>(m32 - r1 * static_cast<unsigned int>(c.OWq));
+      const unsigned int n1 = fast_div(r1, c.ohq_mul, c.ohq_sh);
+      qy[p] = static_cast<int>(r1 - n1 * static_cast<unsigned int>(c.OHq));
+      nn[p] = n1;
+    } else {
+      qx[p] = static_cast<int>(mm[p] % c.OWq);
+      qy[p] = static_cast<int>((mm[p] / c.OWq) % c.OHq);
+      nn[p] = mm[p] / (static_cast<long long>(c.OWq) * c.OHq);
+    }
     iy0[p] = qy[p] * c.sd - c.py0;
     ix0[p] = qx[p] * c.sd - c.px0;
     base_off[p] = ((nn[p] * c.H + iy0[p]) * c.W + ix0[p]) * c.Cin + 8 * h;
@@ -3223,6 +3247,9 @@ int conv_entry(const void* x, const void* w, const float* bias, void* y, int dty
     c.OHq = c.H; c.OWq = c.W;
   }
   g.Uy = c.Uy; g.Ux = c.Ux;
+  fast_div_setup(static_cast<unsigned int>(c.OWq), &c.owq_mul, &c.owq_sh);
+  fast_div_setup(static_cast<unsigned int>(c.OHq), &c.ohq_mul, &c.ohq_sh);
+  c.pix32 = static_cast<long long>(n) * c.OHq * c.OWq + 512 < (1ll << 31) ? 1 : 0;      // (+ the last workgroup's overhang)
   c.cols = c.su * c.su * c.Cout;
   c.OH = c.OHq * c.su; c.OW = c.OWq * c.su;
   if (cin <= 4) {
