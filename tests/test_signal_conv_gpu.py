@@ -295,6 +295,35 @@ def test_conv_gradients_bf16_and_module():
     assert grads and all(g is not None and torch.isfinite(g).all() and g.abs().sum() > 0 for g in grads)
 
 
+@pytest.mark.parametrize("ca,cb,k,s,transpose", [
+    (32, 64, 5, 2, False), (192, 192, 5, 2, False), (128, 256, 3, 1, False), (256, 64, 5, 2, True),
+    (160, 96, 4, 2, False), (192, 192, 5, 2, True), (224, 32, 3, 1, True)])
+def test_wgrad_bf16_channel_pairs(ca, cb, k, s, transpose):
+    """tfc_conv2d_wgrad in bfloat16 — the build with row-major stages and transposing LDS reads takes every pair of wide
+    tensors — against the definition G[t][a][b] = sum_{n, q} A[n, q s + t - k/2, a] B[n, q, b] in float64 on the same
+    (bfloat16-rounded) inputs; a pixel count that is not a multiple of the 64-pixel stage."""
+    from compression_amd.layers.functional import conv2d_wgrad
+    torch.manual_seed(12)
+    n, hb, wb = 2, 7, 9
+    ha, wa = hb * s, wb * s
+    a = torch.randn(n, ha, wa, ca).bfloat16()
+    b = torch.randn(n, hb, wb, cb).bfloat16()
+    got = conv2d_wgrad(a.cuda(), b.cuda(), (k, k), s, transpose).cpu().double()
+    ad, bd = a.double(), b.double()
+    pad = k // 2
+    ap = torch.zeros(n, ha + 2 * k, wa + 2 * k, ca, dtype=torch.float64)
+    ap[:, k:k + ha, k:k + wa] = ad
+    want = torch.zeros(k, k, ca, cb, dtype=torch.float64)
+    for ty in range(k):
+        for tx in range(k):
+            win = ap[:, k + ty - pad:k + ty - pad + hb * s:s, k + tx - pad:k + tx - pad + wb * s:s]
+            want[ty, tx] = torch.einsum("nyxa,nyxb->ab", win, bd)
+    if transpose:
+        want = want.transpose(2, 3)
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 1e-3 * want.abs().max()      # float32 accumulation of exact bfloat16 products
+
+
 def scipy_same_zeros(x, kernel, stride, up):
     """The reference test's oracle (signal_conv_test.py:171-218: zero-insertion upsampling, scipy.signal
     correlate / convolve in `valid` mode, strided read-out) behind the `same_zeros` padding of
